@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Benchmark of the NVSF render hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1], "C2"): per step and per GPU one KITTI-360-shaped frame =
+4096 LiDAR rays + 4096 camera rays, 768 uniform samples per ray, static hash grid L=16 F=2 T=2^19
+(base 16 -> 2048), sigma MLP 32->64->16, LiDAR heads 2 x (87->64->64->1), colour head 31->64->64->3,
+freshly initialised parameters (tcnn init: every sample passes the w > 1e-4 colour mask, i.e. no work is
+skipped), synthetic rays resident in HBM.  A step renders both ray batches (forward render, fp16 field /
+fp32 compositing).  Frames are independent: with N GPUs each rank renders its own frame, no data-path
+collective (weak scaling); value = total rays / max-over-ranks time.
+
+One JSON line on stdout (rank 0): metric / value / ... plus
+  roofline      the dominant kernel (fused density kernel: hash-grid gather + sigma MLP), timed live with HIP
+                events on the launch stream; achieved = 588 algorithmic B/sample / duration
+  kernels       the same figures for every kernel of the step
+  cpu_baseline  the CPU oracle (oracle/, scalar C port, 1 thread) on a bounded sample of the same workload
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "selfsupervised-nvsf_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--num-rays", type=int, default=4096)
+    ap.add_argument("--num-rays-lidar", type=int, default=4096)
+    ap.add_argument("--num-steps", type=int, default=768)
+    ap.add_argument("--cpu-rays", type=int, default=96, help="rays per modality in the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--no-kernel-breakdown", action="store_true")
+    return ap.parse_args()
+
+
+def event_time_ms(fn, iters):
+    """Average duration of fn() over `iters` back-to-back launches, HIP events on the current stream."""
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    torch.cuda.synchronize()
+    start.record()
+    for _ in range(iters):
+        fn()
+    stop.record()
+    stop.synchronize()
+    return start.elapsed_time(stop) / iters
+
+
+def kernel_breakdown(model, batches, T, iters):
+    """Times each kernel of the step in isolation (same inputs, same stream) and prices it against its roofline."""
+    from nvsf import field_ops as ops
+    rows = []
+    for name, (o, d, lidar) in batches.items():
+        N = o.shape[0]
+        M = N * T
+        enc = model.hash_encoder_lidar if lidar else model.hash_encoder_camera
+        if lidar:
+            nears = torch.full((N,), float(model.min_near_lidar), device=o.device)
+            fars = torch.full((N,), float(model.lidar_max_depth), device=o.device)
+        else:
+            from nvsf.nerf.raymarching import raymarching
+            nears, fars = raymarching.near_far_from_aabb(o, d, model.aabb_infer, model.min_near)
+        dens = lambda: ops.density_uniform(o, d, nears, fars, T, model._aabb_host, float(model.bound), enc.table_f16(), enc.spec,
+                                           model.sigma_net.weights_f16())
+        z, sig, geo = dens()
+        comp = lambda: ops.CompositeWeightsFn.apply(sig, z, nears, fars, model._k_scale())
+        w, ws, dp = comp()
+        if lidar:
+            heads = lambda: ops.heads_uniform(w, geo, d, ws, True, model.raydrop_net.weights_f16(), model.intensity_net.weights_f16())
+            head_flops = 2 * 22528
+        else:
+            heads = lambda: ops.heads_uniform(w, geo, d, ws, False, model.color_net.weights_f16(), None, [1.0, 1.0, 1.0])
+            head_flops = 14336
+        active = float((w > ops.W_THRESH).float().mean())
+        t_d, t_c, t_h = event_time_ms(dens, iters), event_time_ms(comp, iters), event_time_ms(heads, iters)
+        rows.append(dict(kernel=f"density_uniform[{name}]", ms=t_d, bound="hbm", unit="GB/s", achieved=588.0 * M / t_d / 1e6,
+                         peak=HBM_PEAK_GBS, per_unit="588 B/sample", units=M))
+        rows.append(dict(kernel=f"composite_weights[{name}]", ms=t_c, bound="hbm", unit="GB/s", achieved=12.0 * M / t_c / 1e6,
+                         peak=HBM_PEAK_GBS, per_unit="12 B/sample (sigma, z read; weights written)", units=M))
+        rows.append(dict(kernel=f"heads_uniform[{name}]", ms=t_h, bound="mfma", unit="TFLOP/s",
+                         achieved=head_flops * M * active / t_h / 1e9, peak=MFMA_PEAK_TFLOPS,
+                         per_unit=f"{head_flops} FLOP/sample x active fraction {active:.3f}", units=M))
+    for r in rows:
+        r["frac"] = r["achieved"] / r["peak"]
+    return rows
+
+
+def cpu_baseline(model, T, n_rays, seed=1234):
+    """Times the scalar CPU oracle on `n_rays` LiDAR + `n_rays` camera rays of the same workload (1 thread)."""
+    import oracle_lib as O
+    from nvsf import synthetic as S
+    rng = np.random.default_rng(seed)
+    f16 = lambda net: net.params.detach().cpu().numpy().astype(np.float16)
+    lin = torch.linspace(0.0, 1.0, T).numpy()
+    aabb = np.array([-S.BOUND] * 3 + [S.BOUND] * 3, np.float32)
+    t0 = time.perf_counter()
+    for lidar in (True, False):
+        o, d = (S.lidar_rays if lidar else S.camera_rays)(n_rays, rng)
+        enc = model.hash_encoder_lidar if lidar else model.hash_encoder_camera
+        table = enc.params.detach().cpu().numpy().astype(np.float16)
+        if lidar:
+            nears, fars = np.full(n_rays, model.min_near_lidar, np.float32), np.full(n_rays, model.lidar_max_depth, np.float32)
+        else:
+            nears, fars = O.near_far_from_aabb(o, d, aabb, model.min_near)
+        O.render_static(o, d, nears, fars, lin, None, float(S.BOUND), table, enc.spec, f16(model.sigma_net), lidar,
+                        f16(model.raydrop_net) if lidar else f16(model.color_net), f16(model.intensity_net) if lidar else None,
+                        np.ones(3, np.float32), k_scale=model._k_scale())
+    dt = time.perf_counter() - t0
+    return {"value": 2 * n_rays / dt, "unit": "rays/s", "cores": 1, "kind": "port",
+            "sample": f"{n_rays} LiDAR + {n_rays} camera rays x {T} samples, same field, scalar C oracle (oracle/*.c) + numpy glue, "
+                      f"{dt:.1f} s wall"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the NVSF hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)  # RCCL
+
+    import build as nvsf_build
+    if rank == 0:
+        nvsf_build.build(verbose=False)
+    if dist is not None:
+        dist.barrier()
+    from nvsf import synthetic as S
+    from nvsf.nerf.models.network_static import NeRFNetworkStatic
+
+    torch.manual_seed(0)
+    model = NeRFNetworkStatic(bound=S.BOUND, min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH,
+                              num_frames=S.NUM_FRAMES).to(dev).eval()
+    rng = np.random.default_rng(1000 + rank)  # every rank renders its own frame
+    lo, ld = S.lidar_rays(args.num_rays_lidar, rng)
+    co, cd = S.camera_rays(args.num_rays, rng)
+    tl = (torch.from_numpy(lo).to(dev)[None], torch.from_numpy(ld).to(dev)[None])
+    tc = (torch.from_numpy(co).to(dev)[None], torch.from_numpy(cd).to(dev)[None])
+    tm = torch.tensor([[0.5]], device=dev)
+    T = args.num_steps
+
+    def step():
+        with torch.no_grad():
+            a = model.render(tl[0], tl[1], tm, cal_lidar_color=True, num_steps=T)
+            b = model.render(tc[0], tc[1], tm, cal_lidar_color=False, num_steps=T)
+        return a, b
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    finite = bool(torch.isfinite(out[0]["image_lidar"]).all() and torch.isfinite(out[1]["image"]).all())
+
+    if rank == 0:
+        rays_per_step = (args.num_rays + args.num_rays_lidar) * world
+        ms_per_step = elapsed / args.steps * 1e3
+        line = {
+            "metric": "rendered rays/sec (LiDAR+cam)", "value": rays_per_step * args.steps / elapsed, "unit": "rays/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "C2: KITTI-360 seq-1908-shaped frame per GPU, uniform sampling, static hash field",
+                       "num_rays": args.num_rays, "num_rays_lidar": args.num_rays_lidar, "num_steps": T,
+                       "hash_grid": "L16 F2 T2^19 base16 max2048", "sigma_mlp": "32-64-16", "heads": "lidar 2x(87-64-64-1), rgb 31-64-64-3",
+                       "pass": "forward render (no_grad), fused kernels", "parallelism": f"frame-sharded x{world}, no collective"},
+            "outputs_finite": finite,
+        }
+        if not args.no_kernel_breakdown:
+            rows = kernel_breakdown(model, {"lidar": (tl[0][0], tl[1][0], True), "camera": (tc[0][0], tc[1][0], False)}, T,
+                                    max(5, args.steps))
+            line["kernels"] = rows
+            dom = max((r for r in rows if r["kernel"].startswith("density")), key=lambda r: r["ms"])
+            top = max(rows, key=lambda r: r["ms"])
+            pick = top if top["ms"] > 1.25 * dom["ms"] else dom
+            line["roofline"] = {"kernel": pick["kernel"], "bound": pick["bound"], "achieved": pick["achieved"], "peak": pick["peak"],
+                                "unit": pick["unit"], "frac": pick["frac"], "traffic": None, "avg_launch_ms": pick["ms"],
+                                "algorithmic": pick["per_unit"], "units_per_launch": pick["units"]}
+            line["kernel_ms_sum"] = sum(r["ms"] for r in rows)
+        if args.cpu_rays > 0 and world == 1:
+            line["cpu_baseline"] = cpu_baseline(model, T, args.cpu_rays)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,202 @@
+/*
+ * nvsf_hip.h -- C ABI of libnvsf_hip.so, the MI355X (gfx950) implementation of the NVSF volumetric
+ * rendering hot path.  This is the drop-in boundary: plain pointers to DEVICE memory, sizes, scalars and
+ * the HIP stream to launch on.  No torch / ATen types.  Every entry point
+ *   - is asynchronous on `stream` (pass torch.cuda.current_stream().cuda_stream; NULL = default stream),
+ *   - never allocates, frees or retains device memory (the caller owns every buffer, exactly as the
+ *     reference's Python wrappers allocate all outputs: nvsf/nerf/raymarching/raymarching.py:40-43,
+ *     235-270, 314-320, 338-355, 424-455),
+ *   - returns 0 on success, a negative NVSF_ERR_* code for rejected arguments (nothing is launched),
+ *     or a positive hipError_t if the launch itself failed.  (The reference returns void and never
+ *     polls launch errors: raymarching.cu:159-177.)
+ *
+ * "ref:" lines name the reference interface each function replaces, relative to /root/reference.
+ * All float buffers are fp32 unless stated; index buffers are int32; layouts are the reference's
+ * (row-major, AoS [N,3] rays).
+ */
+#ifndef NVSF_HIP_H
+#define NVSF_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* nvsf_stream_t; /* == hipStream_t */
+
+#define NVSF_OK 0
+#define NVSF_ERR_INVALID_ARG (-1)
+#define NVSF_ERR_UNSUPPORTED (-2)
+
+/* library / build identification: returns a static string "nvsf_hip <version> gfx950" */
+const char* nvsf_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Section 1: the `_raymarching` extension (ref: nvsf/nerf/raymarching/src/raymarching.h:6-96,
+ * registered by src/bindings.cpp:5-21).  Argument order follows the reference launchers.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* ref: near_far_from_aabb, raymarching.h:6-12, kernel raymarching.cu:104-157.
+ * rays_o, rays_d [N,3]; aabb [6] = (xmin,ymin,zmin,xmax,ymax,zmax); nears, fars [N].
+ * Miss => near = far = FLT_MAX; near is clamped up to min_near. */
+int nvsf_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N,
+                            float min_near, float* nears, float* fars, nvsf_stream_t stream);
+
+/* ref: sph_from_ray, raymarching.h:13-17, kernel raymarching.cu:182-217.  coords [N,2] in [-1,1]. */
+int nvsf_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords,
+                      nvsf_stream_t stream);
+
+/* ref: morton3D / morton3D_invert, raymarching.h:18-21, kernels raymarching.cu:237-272.
+ * coords int32 [N,3] (10 bits per axis), indices int32 [N]. */
+int nvsf_morton3D(const int32_t* coords, uint32_t N, int32_t* indices, nvsf_stream_t stream);
+int nvsf_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, nvsf_stream_t stream);
+
+/* ref: packbits, raymarching.h:22-25, kernel raymarching.cu:286-306.
+ * grid fp32 [8*N] (16-byte aligned); bitfield uint8 [N]; bit i of byte n = grid[8n+i] > density_thresh. */
+int nvsf_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, nvsf_stream_t stream);
+
+/* ref: march_rays_train, raymarching.h:27-44, kernel raymarching.cu:331-534.
+ * grid: uint8 occupancy bitfield [C*H^3/8] in Morton order per cascade.  Outputs xyzs, dirs [M,3],
+ * deltas [M,2] must be zero-initialised by the caller (raymarching.py:235-237); rays int32 [N,3] =
+ * (ray id, sample offset, sample count); counter int32 [2] is read-modify-written:
+ * counter[0] += total samples, counter[1] += N.  Rays whose range would exceed M are recorded in
+ * `rays` but write no samples (raymarching.cu:457).
+ * Deviation (documented in DESIGN.md): sample ranges are assigned in ray-index order by a prefix
+ * sum, not in atomicAdd arrival order, and ray n is recorded at rays[n] (the reference's slot is
+ * atomicAdd(counter+1,1), which equals n only up to a permutation). */
+int nvsf_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
+                          float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                          const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
+                          int32_t* rays, int32_t* counter, const float* noises, nvsf_stream_t stream);
+
+/* ref: composite_rays_train_forward, raymarching.h:45-54, kernel raymarching.cu:577-655.
+ * sigmas [M], rgbs [M,3], deltas [M,2], rays [N,3] -> weights_sum, depth [N], image [N,3]
+ * (indexed by rays[n,0]).  Early exit once transmittance < T_thresh (sample included). */
+int nvsf_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas,
+                                      const int32_t* rays, uint32_t M, uint32_t N, float T_thresh,
+                                      float* weights_sum, float* depth, float* image, nvsf_stream_t stream);
+
+/* ref: composite_rays_train_backward, raymarching.h:55-67, kernel raymarching.cu:690-772.
+ * grad_sigmas [M], grad_rgbs [M,3] must be zero-initialised by the caller (raymarching.py:338-339);
+ * no gradient flows from depth (raymarching.py:330). */
+int nvsf_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image,
+                                       const float* sigmas, const float* rgbs, const float* deltas,
+                                       const int32_t* rays, const float* weights_sum, const float* image,
+                                       uint32_t M, uint32_t N, float T_thresh, float* grad_sigmas,
+                                       float* grad_rgbs, nvsf_stream_t stream);
+
+/* ref: march_rays, raymarching.h:69-86, kernel raymarching.cu:808-928.
+ * Outputs [n_alive*n_step (+pad), 3/3/2] zero-initialised by the caller; unfilled slots stay 0. */
+int nvsf_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
+                    const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                    uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars,
+                    float* xyzs, float* dirs, float* deltas, const float* noises, nvsf_stream_t stream);
+
+/* ref: composite_rays, raymarching.h:87-96, kernel raymarching.cu:966-1053.  In-place update of
+ * weights_sum, depth [N], image [N,3], rays_t [N]; rays_alive[n] = -1 when the ray terminated. */
+int nvsf_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t,
+                        const float* sigmas, const float* rgbs, const float* deltas, float* weights_sum,
+                        float* depth, float* image, nvsf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Section 2: uniform sampler + alpha compositor -- the arithmetic of NeRFRenderer.run that the
+ * reference issues as ~10 elementwise / cumprod torch kernels (ref: nvsf/nerf/models/renderer_dynamic.py).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* ref: renderer_dynamic.py:155-169.  z = near + (far-near)*lin[i] [+ (noise-0.5)*(far-near)/T];
+ * xyz = clip(o + d*z, aabb).  lin [T] = torch.linspace(0,1,T); noise [N,T] in [0,1) or NULL;
+ * aabb [6] device; z_vals [N,T]; xyzs [N,T,3] or NULL. */
+int nvsf_uniform_samples(const float* rays_o, const float* rays_d, const float* nears, const float* fars,
+                         const float* lin, const float* noise, const float* aabb, uint32_t N, uint32_t T,
+                         float* z_vals, float* xyzs, nvsf_stream_t stream);
+
+/* ref: renderer_dynamic.py:181-194 (deltas, alphas, cumprod weights) and :216-221 (weights_sum, depth).
+ * k_scale = density_scale (x2 for an active sensor, :187-189).  sigmas, z_vals, weights [N,T]. */
+int nvsf_composite_uniform_weights_fwd(const float* sigmas, const float* z_vals, const float* nears,
+                                       const float* fars, uint32_t N, uint32_t T, float k_scale, float* weights,
+                                       float* weights_sum, float* depth, nvsf_stream_t stream);
+
+/* autograd of the above (the reference relies on torch autograd through :181-221).
+ * grad_weights [N,T] / grad_weights_sum [N] / grad_depth [N] may each be NULL. */
+int nvsf_composite_uniform_weights_bwd(const float* sigmas, const float* z_vals, const float* nears,
+                                       const float* fars, const float* grad_weights, const float* grad_weights_sum,
+                                       const float* grad_depth, uint32_t N, uint32_t T, float k_scale,
+                                       float* grad_sigmas, nvsf_stream_t stream);
+
+/* ref: renderer_dynamic.py:224 and :236-237.  image[n,c] = sum_i w[n,i]*rgb[n,i,c] (+ (1-ws[n])*bg[c]).
+ * rgbs [N,T,C], C in 1..4; bg_color [C] device or NULL. */
+int nvsf_composite_uniform_image_fwd(const float* weights, const float* rgbs, const float* weights_sum, uint32_t N,
+                                     uint32_t T, uint32_t C, const float* bg_color, float* image,
+                                     nvsf_stream_t stream);
+int nvsf_composite_uniform_image_bwd(const float* weights, const float* rgbs, const float* grad_image, uint32_t N,
+                                     uint32_t T, uint32_t C, const float* bg_color, float* grad_weights,
+                                     float* grad_rgbs, float* grad_weights_sum, nvsf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Section 3: per-sample field operators the reference obtains from tiny-cuda-nn (third party, unpinned:
+ * setup.py:97-99).  Semantics: DESIGN.md section 4.  fp16 buffers are passed as void*.
+ * Level metadata arrays (h_*) are HOST pointers, copied into the launch.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* ref: tcnn.Encoding("HashGrid") at hash_field.py:47-57 (D=2), hash_field.py:109-119 (D=3),
+ * flow_field.py:70-80 (D=3, F=8).  x fp32 [M, x_stride], cols[D] = columns of x to encode (host),
+ * table fp16 [h_offsets[L]*F], out fp16 [M, out_stride >= L*F].  D in {2,3}, F in {2,4,8}, L <= 32. */
+int nvsf_hashgrid_fwd(const float* x, uint32_t M, uint32_t x_stride, const uint32_t* cols, uint32_t D,
+                      const void* table_f16, uint32_t L, uint32_t F, const float* h_scales, const uint32_t* h_res,
+                      const uint32_t* h_offsets, void* out_f16, uint32_t out_stride, nvsf_stream_t stream);
+
+/* gradient wrt the table: grad_table_f32[row*F+f] += w_corner * grad_out[m, l*F+f] (fp32 atomics; the
+ * caller zero-initialises).  grad_out [M, go_stride] is fp16 (grad_is_f16 != 0) or fp32. */
+int nvsf_hashgrid_bwd(const float* x, uint32_t M, uint32_t x_stride, const uint32_t* cols, uint32_t D, uint32_t L,
+                      uint32_t F, const float* h_scales, const uint32_t* h_res, const uint32_t* h_offsets,
+                      const void* grad_out, int grad_is_f16, uint32_t go_stride, float* grad_table_f32,
+                      nvsf_stream_t stream);
+
+/* ref: tcnn.Encoding("Frequency") network_dynamic.py:108-114.  x fp32 [M,n_dims] ->
+ * out fp16 [M, out_stride >= 2*n_dims*n_freq], out[i*2K+2k] = sin(2^k pi x_i), [..+1] = cos. */
+int nvsf_freq_encode(const float* x, uint32_t M, uint32_t n_dims, uint32_t n_freq, void* out_f16,
+                     uint32_t out_stride, nvsf_stream_t stream);
+
+/* ref: tcnn.Encoding("SphericalHarmonics", degree 4) network_dynamic.py:165-170.
+ * dirs01 fp32 [M,3] in [0,1] -> out fp16 [M, out_stride >= 16]. */
+int nvsf_sh4_encode(const float* dirs01, uint32_t M, void* out_f16, uint32_t out_stride, nvsf_stream_t stream);
+
+/* ref: tcnn.Network("FullyFusedMLP") network_dynamic.py:125-135,138-161,180-189.
+ * x [M, x_stride] fp32 (x_is_f16 == 0) or fp16; weights fp16 = W0 [hidden][in_cols] ++ (n_hidden-1) x
+ * [hidden][hidden] ++ W_out [out_cols][hidden]; columns n_in..in_cols-1 of the input read as 1.0.
+ * Supported: hidden = 64, out_cols = 16, n_hidden in 1..3, in_cols in {16,...,128}. out fp16 [M, out_stride]. */
+int nvsf_mlp_fwd(const void* x, int x_is_f16, uint32_t M, uint32_t n_in, uint32_t x_stride, const void* weights_f16,
+                 uint32_t in_cols, uint32_t hidden, uint32_t n_hidden, uint32_t out_cols, void* out_f16,
+                 uint32_t out_stride, nvsf_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Section 4: fused kernels of the uniform-sampling render (BASELINE config 2 hot path).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* ref: renderer_dynamic.py:155-174 + network_dynamic.py:213-287 for a static hash field:
+ * sample generation -> normalise (x+bound)/(2 bound) -> 3-D hash grid (L*F = 32) -> sigma net 32->64->16
+ * -> sigma = exp(h0) (activation.py:9-11).  h_aabb[6] host.  Outputs z_vals, sigmas [N,T] fp32 and
+ * geo fp16 [N,T,16] = (h1..h15, 1.0). */
+int nvsf_field_density_uniform_fwd(const float* rays_o, const float* rays_d, const float* nears, const float* fars,
+                                   const float* lin, const float* noise, const float* h_aabb, float bound,
+                                   uint32_t N, uint32_t T, const void* table_f16, uint32_t L, uint32_t F,
+                                   const float* h_scales, const uint32_t* h_res, const uint32_t* h_offsets,
+                                   const void* sigma_weights_f16, float* z_vals, float* sigmas, void* geo_f16,
+                                   nvsf_stream_t stream);
+
+/* ref: renderer_dynamic.py:202-237 + network_dynamic.py:290-332.  Direction encoding (per ray), heads,
+ * sigmoid, weight mask (w > w_thresh) and image accumulation in one kernel.
+ * lidar == 0: head_a = colour net [SH16|geo15|1] 32->64->64->3;  image [N,3] (+ (1-ws)*h_bg_color[3])
+ * lidar != 0: head_a = raydrop net, head_b = intensity net, [Freq72|geo15|1x9] 96->64->64->1; image [N,2].
+ * h_bg_color: host pointer or NULL. */
+int nvsf_field_heads_uniform_fwd(const float* weights, const void* geo_f16, const float* rays_d,
+                                 const float* weights_sum, int lidar, const void* head_a_weights_f16,
+                                 const void* head_b_weights_f16, uint32_t N, uint32_t T, float w_thresh,
+                                 const float* h_bg_color, float* image, nvsf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NVSF_HIP_H */

@@ -1,0 +1,61 @@
+// Internal helpers shared by the HIP translation units of libnvsf_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NVSF_API extern "C" __attribute__((visibility("default")))
+
+// Status codes returned by every C-ABI entry point (include/nvsf_hip.h).
+enum : int {
+    NVSF_OK = 0,
+    NVSF_ERR_INVALID_ARG = -1,   // null pointer / inconsistent sizes / unsupported configuration
+    NVSF_ERR_UNSUPPORTED = -2,   // template instantiation not built for this shape
+};
+
+constexpr int kWave = 64;  // CDNA4 wavefront width
+
+static inline int nvsf_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? NVSF_OK : (int)e;  // positive values are hipError_t codes
+}
+
+static inline unsigned cdiv(unsigned long long a, unsigned b) { return (unsigned)((a + b - 1) / b); }
+
+// ---- wave-level primitives (64 lanes) -------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// inclusive scans over the 64 lanes of a wave (Hillis-Steele on cross-lane shuffles)
+__device__ __forceinline__ float wave_scan_add(float v) {
+    const int l = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float u = __shfl_up(v, o, 64);
+        if (l >= o) v += u;
+    }
+    return v;
+}
+__device__ __forceinline__ float wave_scan_mul(float v) {
+    const int l = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float u = __shfl_up(v, o, 64);
+        if (l >= o) v *= u;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t v) {
+    const int l = lane_id();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t u = __shfl_up(v, o, 64);
+        if (l >= o) v += u;
+    }
+    return v;
+}

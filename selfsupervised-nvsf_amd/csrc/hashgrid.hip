@@ -1,0 +1,175 @@
+// Stand-alone multiresolution hash-grid encoding (forward + table gradient) for gfx950.
+// Replaces the tcnn.Encoding("HashGrid") modules the reference builds at hash_field.py:47-57 (2-D, per
+// time slice), hash_field.py:109-119 (3-D static) and flow_field.py:70-80 (3-D, L16 F8).
+//
+// Work mapping (forward): a 256-thread workgroup encodes 64 consecutive samples.  Lanes of a wave are
+// 64 consecutive samples (consecutive samples along a ray touch neighbouring cells, so the 64 gathers of
+// one wave instruction fall into few cache lines); the four waves split the levels (wave w takes levels
+// w, w+4, ...).  Features are staged as fp16 in LDS in output order and leave the workgroup as 16-byte
+// stores of whole rows, instead of 4..16-byte stores at a stride of L*F*2 bytes.
+#include "hashgrid_device.h"
+
+namespace {
+constexpr int kBlock = 256;
+constexpr int kSamplesPerBlock = 64;
+
+template <int D, int F>
+__global__ __launch_bounds__(kBlock) void k_hashgrid_fwd(const float* __restrict__ x, uint32_t M, uint32_t x_stride, uint32_t c0,
+                                                         uint32_t c1, uint32_t c2, const _Float16* __restrict__ table, uint32_t L,
+                                                         GridMeta meta, _Float16* __restrict__ out, uint32_t out_stride) {
+    // staging tile [64 samples][L*F/2 + 1] dwords (half2 granularity; the odd row stride keeps the
+    // per-lane b32 writes and the row-major b32 read-back free of bank conflicts)
+    extern __shared__ uint32_t stage[];
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const uint32_t m = blockIdx.x * kSamplesPerBlock + lane;
+    const uint32_t row_dw = L * F / 2, row_pitch = row_dw + 1;
+    float xs[D];
+    {
+        const uint32_t mm = m < M ? m : M - 1;  // clamp: out-of-range lanes compute a valid sample and are dropped at the store
+        const float* px = x + (size_t)mm * x_stride;
+        xs[0] = px[c0];
+        xs[1] = px[c1];
+        if constexpr (D == 3) xs[2] = px[c2];
+    }
+    for (uint32_t l = wave; l < L; l += 4) {
+        float acc[F];
+        encode_level<D, F>(xs, table, meta.scale[l], meta.res[l], meta.offset[l], meta.offset[l + 1] - meta.offset[l], acc);
+#pragma unroll
+        for (int f = 0; f < F; f += 2) {
+            h2_t p;
+            p[0] = (_Float16)acc[f];
+            p[1] = (_Float16)acc[f + 1];
+            stage[lane * row_pitch + (l * F + f) / 2] = __builtin_bit_cast(uint32_t, p);
+        }
+    }
+    __syncthreads();
+    const uint32_t n_rows = min((uint32_t)kSamplesPerBlock, M - blockIdx.x * kSamplesPerBlock);
+    uint32_t* out_dw = reinterpret_cast<uint32_t*>(out);
+    for (uint32_t c = threadIdx.x; c < n_rows * row_dw; c += kBlock) {
+        const uint32_t row = c / row_dw, col = c - row * row_dw;
+        out_dw[(size_t)(blockIdx.x * kSamplesPerBlock + row) * (out_stride / 2) + col] = stage[row * row_pitch + col];
+    }
+}
+
+// Table gradient: one thread per (sample, level); fp32 atomics into grad_table.
+template <int D, int F, bool GRAD_F16>
+__global__ __launch_bounds__(kBlock) void k_hashgrid_bwd(const float* __restrict__ x, uint32_t M, uint32_t x_stride, uint32_t c0,
+                                                         uint32_t c1, uint32_t c2, uint32_t L, GridMeta meta,
+                                                         const void* __restrict__ grad_out, uint32_t go_stride,
+                                                         float* __restrict__ grad_table) {
+    const uint32_t m = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t l = blockIdx.y;
+    if (m >= M) return;
+    float xs[D];
+    const float* px = x + (size_t)m * x_stride;
+    xs[0] = px[c0];
+    xs[1] = px[c1];
+    if constexpr (D == 3) xs[2] = px[c2];
+    float g[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        if constexpr (GRAD_F16) g[f] = (float)reinterpret_cast<const _Float16*>(grad_out)[(size_t)m * go_stride + l * F + f];
+        else g[f] = reinterpret_cast<const float*>(grad_out)[(size_t)m * go_stride + l * F + f];
+    }
+    bool any = false;
+#pragma unroll
+    for (int f = 0; f < F; ++f) any |= (g[f] != 0.0f);
+    if (!any) return;
+    const float scale = meta.scale[l];
+    const uint32_t res = meta.res[l], row0 = meta.offset[l], hsize = meta.offset[l + 1] - row0;
+    float frac[D];
+    uint32_t cell[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const float pos = fmaf(scale, xs[d], 0.5f);
+        const float fl = floorf(pos);
+        frac[d] = pos - fl;
+        cell[d] = (uint32_t)(int32_t)fl;
+    }
+#pragma unroll
+    for (int c = 0; c < (1 << D); ++c) {
+        uint32_t cc[D];
+        float w = 1.0f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (c & (1 << d)) { w = w * frac[d]; cc[d] = cell[d] + 1u; }
+            else { w = w * (1.0f - frac[d]); cc[d] = cell[d]; }
+        }
+        float* dst = grad_table + ((size_t)row0 + grid_row<D>(cc, res, hsize)) * F;
+#pragma unroll
+        for (int f = 0; f < F; ++f) atomicAdd(dst + f, w * g[f]);
+    }
+}
+
+int fill_meta(GridMeta& meta, uint32_t L, const float* scales, const uint32_t* res, const uint32_t* offsets) {
+    if (L == 0 || L > (uint32_t)kMaxLevels || !scales || !res || !offsets) return NVSF_ERR_INVALID_ARG;
+    for (uint32_t l = 0; l < L; ++l) {
+        meta.scale[l] = scales[l];
+        meta.res[l] = res[l];
+        meta.offset[l] = offsets[l];
+        if (offsets[l + 1] <= offsets[l] || res[l] == 0) return NVSF_ERR_INVALID_ARG;
+    }
+    meta.offset[L] = offsets[L];
+    return NVSF_OK;
+}
+}  // namespace
+
+#define REQUIRE(cond) do { if (!(cond)) return NVSF_ERR_INVALID_ARG; } while (0)
+
+#define DISPATCH_DF(D, F, CALL)                                         \
+    do {                                                                \
+        if (D == 2 && F == 2) { CALL(2, 2); }                           \
+        else if (D == 2 && F == 4) { CALL(2, 4); }                      \
+        else if (D == 2 && F == 8) { CALL(2, 8); }                      \
+        else if (D == 3 && F == 2) { CALL(3, 2); }                      \
+        else if (D == 3 && F == 4) { CALL(3, 4); }                      \
+        else if (D == 3 && F == 8) { CALL(3, 8); }                      \
+        else return NVSF_ERR_UNSUPPORTED;                               \
+    } while (0)
+
+NVSF_API int nvsf_hashgrid_fwd(const float* x, uint32_t M, uint32_t x_stride, const uint32_t* cols, uint32_t D, const void* table_f16,
+                               uint32_t L, uint32_t F, const float* h_scales, const uint32_t* h_res, const uint32_t* h_offsets,
+                               void* out_f16, uint32_t out_stride, hipStream_t stream) {
+    if (M == 0) return NVSF_OK;
+    REQUIRE(x && cols && table_f16 && out_f16 && (D == 2 || D == 3));
+    REQUIRE(out_stride >= L * F && out_stride % 2 == 0);
+    REQUIRE((reinterpret_cast<uintptr_t>(out_f16) & 3u) == 0 && (reinterpret_cast<uintptr_t>(table_f16) & 15u) == 0);
+    for (uint32_t d = 0; d < D; ++d) REQUIRE(cols[d] < x_stride);
+    GridMeta meta;
+    const int st = fill_meta(meta, L, h_scales, h_res, h_offsets);
+    if (st != NVSF_OK) return st;
+    const uint32_t c0 = cols[0], c1 = cols[1], c2 = D == 3 ? cols[2] : 0;
+    const size_t lds = (size_t)kSamplesPerBlock * (L * F / 2 + 1) * sizeof(uint32_t);
+#define CALL(DD, FF)                                                                                                        \
+    hipLaunchKernelGGL((k_hashgrid_fwd<DD, FF>), dim3(cdiv(M, kSamplesPerBlock)), dim3(kBlock), lds, stream, x, M, x_stride, c0, \
+                       c1, c2, reinterpret_cast<const _Float16*>(table_f16), L, meta, reinterpret_cast<_Float16*>(out_f16),  \
+                       out_stride)
+    DISPATCH_DF(D, F, CALL);
+#undef CALL
+    return nvsf_launch_status();
+}
+
+NVSF_API int nvsf_hashgrid_bwd(const float* x, uint32_t M, uint32_t x_stride, const uint32_t* cols, uint32_t D, uint32_t L, uint32_t F,
+                               const float* h_scales, const uint32_t* h_res, const uint32_t* h_offsets, const void* grad_out,
+                               int grad_is_f16, uint32_t go_stride, float* grad_table_f32, hipStream_t stream) {
+    if (M == 0) return NVSF_OK;
+    REQUIRE(x && cols && grad_out && grad_table_f32 && (D == 2 || D == 3) && go_stride >= L * F);
+    for (uint32_t d = 0; d < D; ++d) REQUIRE(cols[d] < x_stride);
+    GridMeta meta;
+    const int st = fill_meta(meta, L, h_scales, h_res, h_offsets);
+    if (st != NVSF_OK) return st;
+    const uint32_t c0 = cols[0], c1 = cols[1], c2 = D == 3 ? cols[2] : 0;
+    const dim3 grid(cdiv(M, kBlock), L);
+#define CALL(DD, FF)                                                                                                             \
+    do {                                                                                                                         \
+        if (grad_is_f16)                                                                                                         \
+            hipLaunchKernelGGL((k_hashgrid_bwd<DD, FF, true>), grid, dim3(kBlock), 0, stream, x, M, x_stride, c0, c1, c2, L, meta, \
+                               grad_out, go_stride, grad_table_f32);                                                             \
+        else                                                                                                                     \
+            hipLaunchKernelGGL((k_hashgrid_bwd<DD, FF, false>), grid, dim3(kBlock), 0, stream, x, M, x_stride, c0, c1, c2, L, meta, \
+                               grad_out, go_stride, grad_table_f32);                                                             \
+    } while (0)
+    DISPATCH_DF(D, F, CALL);
+#undef CALL
+    return nvsf_launch_status();
+}

@@ -1,0 +1,134 @@
+// Stand-alone fused MLP forward (all layers in one kernel, activations in registers) for gfx950.
+// Replaces tcnn.Network("FullyFusedMLP") as instantiated at network_dynamic.py:125-135 (sigma_net
+// 120->64->16), :138-161 (intensity / raydrop 87->64->64->1) and :180-189 (color 31->64->64->3).
+//
+// One wave = one 16-sample tile at a time (grid-stride over tiles); every weight fragment is fetched once
+// per wave and stays in VGPRs.  Input rows may be fp32 or fp16; they are rounded to fp16, columns
+// n_in..in_cols-1 read as 1.0 (tcnn pads the network input with ones), the rest of the last k-step is 0.
+#include "mlp_device.h"
+
+namespace {
+constexpr int kBlock = 256;
+
+template <bool X_F16>
+__device__ __forceinline__ half8_t load_x_frag(const void* __restrict__ x, size_t row, uint32_t x_stride, int k0, int n_in,
+                                               int in_cols, bool vec_ok) {
+    half8_t v;
+    if (k0 + 8 <= n_in && vec_ok) {
+        if constexpr (X_F16) {
+            v = *reinterpret_cast<const half8_t*>(reinterpret_cast<const _Float16*>(x) + row * x_stride + k0);
+        } else {
+            const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(x) + row * x_stride + k0);
+            const float4 a = p[0], b = p[1];
+            v[0] = (_Float16)a.x; v[1] = (_Float16)a.y; v[2] = (_Float16)a.z; v[3] = (_Float16)a.w;
+            v[4] = (_Float16)b.x; v[5] = (_Float16)b.y; v[6] = (_Float16)b.z; v[7] = (_Float16)b.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + j;
+            float e = k < in_cols ? 1.0f : 0.0f;
+            if (k < n_in) {
+                if constexpr (X_F16) e = (float)reinterpret_cast<const _Float16*>(x)[row * x_stride + k];
+                else e = reinterpret_cast<const float*>(x)[row * x_stride + k];
+            }
+            v[j] = (_Float16)e;
+        }
+    }
+    return v;
+}
+
+template <int IN_STEPS, int N_HIDDEN, bool X_F16>
+__global__ __launch_bounds__(kBlock) void k_mlp_fwd(const void* __restrict__ x, uint32_t M, uint32_t n_in, uint32_t x_stride,
+                                                    const _Float16* __restrict__ weights, uint32_t in_cols,
+                                                    _Float16* __restrict__ out, uint32_t out_stride, int vec_ok) {
+    const int lane = lane_id();
+    const int g = lane >> 4, sl = lane & 15;
+    // ---- weights -> registers
+    half8_t w0[kHidTiles][IN_STEPS];
+#pragma unroll
+    for (int t = 0; t < kHidTiles; ++t)
+#pragma unroll
+        for (int s = 0; s < IN_STEPS; ++s) w0[t][s] = load_w_natural(weights, (int)in_cols, t, s, lane);
+    const _Float16* wp = weights + (size_t)kHidden * in_cols;
+    HiddenLayerW hid[N_HIDDEN > 1 ? N_HIDDEN - 1 : 1];
+#pragma unroll
+    for (int i = 0; i < N_HIDDEN - 1; ++i) {
+        hid[i].load(wp, lane);
+        wp += kHidden * kHidden;
+    }
+    OutLayerW wout;
+    wout.load(wp, lane);
+
+    const uint32_t n_tiles = (M + 15) / 16;
+    const uint32_t wave_global = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    const uint32_t wave_count = gridDim.x * (kBlock / kWave);
+    for (uint32_t tile = wave_global; tile < n_tiles; tile += wave_count) {
+        const uint32_t m = tile * 16 + sl;
+        const size_t row = m < M ? m : M - 1;
+        half8_t xf[IN_STEPS];
+#pragma unroll
+        for (int s = 0; s < IN_STEPS; ++s) xf[s] = load_x_frag<X_F16>(x, row, x_stride, 32 * s + 8 * g, (int)n_in, (int)in_cols, vec_ok != 0);
+        float4_t acc[kHidTiles];
+#pragma unroll
+        for (int t = 0; t < kHidTiles; ++t) {
+            float4_t c = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < IN_STEPS; ++s) c = mfma16(w0[t][s], xf[s], c);
+            acc[t] = c;
+        }
+        half8_t h[kHidSteps];
+        pack_hidden(acc, h);
+#pragma unroll
+        for (int i = 0; i < N_HIDDEN - 1; ++i) {
+            hid[i].apply(h, acc);
+            pack_hidden(acc, h);
+        }
+        const float4_t o = wout.apply(h);
+        if (m < M) {
+            half4_t ov;
+            ov[0] = (_Float16)o[0]; ov[1] = (_Float16)o[1]; ov[2] = (_Float16)o[2]; ov[3] = (_Float16)o[3];
+            *reinterpret_cast<half4_t*>(out + (size_t)m * out_stride + 4 * g) = ov;
+        }
+    }
+}
+}  // namespace
+
+#define REQUIRE(cond) do { if (!(cond)) return NVSF_ERR_INVALID_ARG; } while (0)
+
+// weights: fp16 [64][in_cols] ++ (n_hidden-1) x [64][64] ++ [16][64]; out fp16 [M, out_stride>=16]
+NVSF_API int nvsf_mlp_fwd(const void* x, int x_is_f16, uint32_t M, uint32_t n_in, uint32_t x_stride, const void* weights_f16,
+                          uint32_t in_cols, uint32_t hidden, uint32_t n_hidden, uint32_t out_cols, void* out_f16,
+                          uint32_t out_stride, hipStream_t stream) {
+    if (M == 0) return NVSF_OK;
+    REQUIRE(x && weights_f16 && out_f16);
+    REQUIRE(n_in >= 1 && n_in <= in_cols && in_cols % 16 == 0 && x_stride >= n_in);
+    REQUIRE(out_stride >= 16 && out_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(out_f16) & 7u) == 0);
+    REQUIRE((reinterpret_cast<uintptr_t>(weights_f16) & 15u) == 0);
+    if (hidden != (uint32_t)kHidden || out_cols != 16 || n_hidden < 1 || n_hidden > 3 || in_cols > 128) return NVSF_ERR_UNSUPPORTED;
+    const int in_steps = (int)((in_cols + 31) / 32);
+    const size_t esz = x_is_f16 ? 2 : 4;
+    const int vec_ok = ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) && ((x_stride * esz) % 16 == 0);
+    const uint32_t n_tiles = (M + 15) / 16;
+    const uint32_t blocks = n_tiles / 4 + 1 < 2048u ? n_tiles / 4 + 1 : 2048u;
+    const _Float16* w = reinterpret_cast<const _Float16*>(weights_f16);
+    _Float16* o = reinterpret_cast<_Float16*>(out_f16);
+#define LAUNCH(S, H, XF)                                                                                                   \
+    hipLaunchKernelGGL((k_mlp_fwd<S, H, XF>), dim3(blocks), dim3(kBlock), 0, stream, x, M, n_in, x_stride, w, in_cols, o, \
+                       out_stride, vec_ok)
+#define BY_X(S, H) do { if (x_is_f16) LAUNCH(S, H, true); else LAUNCH(S, H, false); } while (0)
+#define BY_H(S)                                       \
+    do {                                              \
+        if (n_hidden == 1) BY_X(S, 1);                \
+        else if (n_hidden == 2) BY_X(S, 2);           \
+        else BY_X(S, 3);                              \
+    } while (0)
+    switch (in_steps) {
+        case 1: BY_H(1); break;
+        case 2: BY_H(2); break;
+        case 3: BY_H(3); break;
+        case 4: BY_H(4); break;
+        default: return NVSF_ERR_UNSUPPORTED;
+    }
+    return nvsf_launch_status();
+}

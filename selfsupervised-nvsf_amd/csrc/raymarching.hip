@@ -1,0 +1,543 @@
+// Ray-marching operators for gfx950 (MI355X): AABB intersection, background-sphere coords, Morton
+// codes, occupancy bit packing, occupancy-grid sample generation (training + inference) and the
+// packed-sample compositors.  Behavioural contract: /root/reference/nvsf/nerf/raymarching/src/raymarching.cu
+// (kernel line ranges cited per entry point in include/nvsf_hip.h).  Design differences, all MI355X-driven:
+//   * wave64 everywhere; 256-thread workgroups;
+//   * march_rays_train is three launches (count -> single-workgroup exclusive scan -> write) so the
+//     packed sample order is deterministic (ray-index order) instead of atomicAdd arrival order;
+//   * the packed compositors give one 64-lane wave to each ray: coalesced sigma/rgb/delta reads and a
+//     cross-lane product scan for the transmittance instead of a per-thread serial loop, so that a
+//     4096-ray batch fills 4096 waves rather than 64;
+//   * packbits builds each output byte from two 16-byte loads per lane (full 128-B lines per wave).
+// Arithmetic is fp32 with every operation individually rounded (-ffp-contract=off) so discrete
+// decisions (floor, frexp, occupancy bit) agree with the CPU oracle bit for bit.
+#include "common.h"
+#include <float.h>
+#include <math.h>
+
+namespace {
+
+constexpr float kSqrt3 = 1.7320508075688772f;
+constexpr float kRPi = 0.3183098861837907f;
+constexpr int kBlock = 256;
+
+__device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
+
+__device__ __forceinline__ uint32_t spread3(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t morton_encode(uint32_t x, uint32_t y, uint32_t z) {
+    return spread3(x) | (spread3(y) << 1) | (spread3(z) << 2);
+}
+__device__ __forceinline__ uint32_t compact3(uint32_t x) {
+    x &= 0x49249249u;
+    x = (x | (x >> 2)) & 0xc30c30c3u;
+    x = (x | (x >> 4)) & 0x0f00f00fu;
+    x = (x | (x >> 8)) & 0xff0000ffu;
+    x = (x | (x >> 16)) & 0x0000ffffu;
+    return x;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_near_far(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                     const float* __restrict__ aabb, uint32_t N, float min_near,
+                                                     float* __restrict__ nears, float* __restrict__ fars) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    const float ox = rays_o[3 * n], oy = rays_o[3 * n + 1], oz = rays_o[3 * n + 2];
+    const float ix = 1.0f / rays_d[3 * n], iy = 1.0f / rays_d[3 * n + 1], iz = 1.0f / rays_d[3 * n + 2];
+    float lo = (aabb[0] - ox) * ix, hi = (aabb[3] - ox) * ix;
+    if (lo > hi) { float s = lo; lo = hi; hi = s; }
+    float ylo = (aabb[1] - oy) * iy, yhi = (aabb[4] - oy) * iy;
+    if (ylo > yhi) { float s = ylo; ylo = yhi; yhi = s; }
+    bool miss = (lo > yhi) || (ylo > hi);
+    if (!miss) {
+        if (ylo > lo) lo = ylo;
+        if (yhi < hi) hi = yhi;
+        float zlo = (aabb[2] - oz) * iz, zhi = (aabb[5] - oz) * iz;
+        if (zlo > zhi) { float s = zlo; zlo = zhi; zhi = s; }
+        miss = (lo > zhi) || (zlo > hi);
+        if (!miss) {
+            if (zlo > lo) lo = zlo;
+            if (zhi < hi) hi = zhi;
+            if (lo < min_near) lo = min_near;
+        }
+    }
+    nears[n] = miss ? FLT_MAX : lo;
+    fars[n] = miss ? FLT_MAX : hi;
+}
+
+__global__ __launch_bounds__(kBlock) void k_sph_from_ray(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                         float radius, uint32_t N, float* __restrict__ coords) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    const float ox = rays_o[3 * n], oy = rays_o[3 * n + 1], oz = rays_o[3 * n + 2];
+    const float dx = rays_d[3 * n], dy = rays_d[3 * n + 1], dz = rays_d[3 * n + 2];
+    const float A = dx * dx + dy * dy + dz * dz;
+    const float B = ox * dx + oy * dy + oz * dz;
+    const float C = ox * ox + oy * oy + oz * oz - radius * radius;
+    const float t = (-B + sqrtf(B * B - A * C)) / A;
+    const float x = ox + t * dx, y = oy + t * dy, z = oz + t * dz;
+    const float theta = atan2f(sqrtf(x * x + z * z), y);
+    const float phi = atan2f(z, x);
+    coords[2 * n] = 2.0f * theta * kRPi - 1.0f;
+    coords[2 * n + 1] = phi * kRPi;
+}
+
+__global__ __launch_bounds__(kBlock) void k_morton3D(const int* __restrict__ coords, uint32_t N, int* __restrict__ indices) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    indices[n] = (int)morton_encode((uint32_t)coords[3 * n], (uint32_t)coords[3 * n + 1], (uint32_t)coords[3 * n + 2]);
+}
+
+__global__ __launch_bounds__(kBlock) void k_morton3D_invert(const int* __restrict__ indices, uint32_t N, int* __restrict__ coords) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    const int ind = indices[n];
+    coords[3 * n] = (int)compact3((uint32_t)(ind >> 0));
+    coords[3 * n + 1] = (int)compact3((uint32_t)(ind >> 1));
+    coords[3 * n + 2] = (int)compact3((uint32_t)(ind >> 2));
+}
+
+// One thread = one output byte = 8 consecutive floats, fetched as two float4 (the wave reads 2 KiB of
+// whole cache lines and writes 64 contiguous bytes).
+__global__ __launch_bounds__(kBlock) void k_packbits(const float* __restrict__ grid, uint32_t N, float thresh,
+                                                     uint8_t* __restrict__ bitfield) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    const float4 a = reinterpret_cast<const float4*>(grid)[2 * (size_t)n];
+    const float4 b = reinterpret_cast<const float4*>(grid)[2 * (size_t)n + 1];
+    uint32_t bits = (a.x > thresh ? 1u : 0u) | (a.y > thresh ? 2u : 0u) | (a.z > thresh ? 4u : 0u) |
+                    (a.w > thresh ? 8u : 0u) | (b.x > thresh ? 16u : 0u) | (b.y > thresh ? 32u : 0u) |
+                    (b.z > thresh ? 64u : 0u) | (b.w > thresh ? 128u : 0u);
+    bitfield[n] = (uint8_t)bits;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Occupancy-grid marcher.  `Marcher` carries the per-ray constants; probe() classifies the cell at
+// parameter t and, for an empty cell, advances t past it.
+struct Marcher {
+    float ox, oy, oz, dx, dy, dz, ix, iy, iz;
+    float bound, dt_gamma, dt_min, dt_max, rH, H3, Hf, Hm1, Cf;
+    const uint8_t* grid;
+
+    __device__ __forceinline__ void init(const float* o, const float* d, const uint8_t* g, float bound_, float dt_gamma_,
+                                         uint32_t max_steps, uint32_t C, uint32_t H) {
+        ox = o[0]; oy = o[1]; oz = o[2];
+        dx = d[0]; dy = d[1]; dz = d[2];
+        ix = 1.0f / dx; iy = 1.0f / dy; iz = 1.0f / dz;
+        bound = bound_; dt_gamma = dt_gamma_; grid = g;
+        Hf = (float)H; Hm1 = (float)(H - 1); Cf = (float)C;
+        rH = 1.0f / Hf;
+        H3 = (float)(H * H * H);
+        dt_min = 2.0f * kSqrt3 / (float)max_steps;
+        dt_max = 2.0f * kSqrt3 * (float)(1 << (C - 1)) / Hf;
+    }
+    __device__ __forceinline__ float step_len(float t) const { return clampf(t * dt_gamma, dt_min, dt_max); }
+
+    __device__ __forceinline__ int level_of(float x, float y, float z, float dt) const {
+        int e0, e1;
+        (void)frexpf(fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))), &e0);
+        (void)frexpf(dt * Hf * 0.5f, &e1);
+        const int l0 = (int)fminf(Cf - 1.0f, fmaxf(0.0f, (float)e0));
+        const int l1 = (int)fminf(Cf - 1.0f, fmaxf(0.0f, (float)e1));
+        return l0 > l1 ? l0 : l1;
+    }
+    // returns true when the cell containing o + t d is occupied; x,y,z,dt describe the sample.
+    // Otherwise t is advanced past the empty cell.
+    __device__ __forceinline__ bool probe(float& t, float& x, float& y, float& z, float& dt) const {
+        x = clampf(ox + t * dx, -bound, bound);
+        y = clampf(oy + t * dy, -bound, bound);
+        z = clampf(oz + t * dz, -bound, bound);
+        dt = step_len(t);
+        const int level = level_of(x, y, z, dt);
+        const float mb = fminf(ldexpf(1.0f, level), bound);
+        const float rmb = 1.0f / mb;
+        const int nx = (int)clampf(0.5f * (x * rmb + 1.0f) * Hf, 0.0f, Hm1);
+        const int ny = (int)clampf(0.5f * (y * rmb + 1.0f) * Hf, 0.0f, Hm1);
+        const int nz = (int)clampf(0.5f * (z * rmb + 1.0f) * Hf, 0.0f, Hm1);
+        const uint32_t cell = (uint32_t)((float)level * H3 + (float)morton_encode((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+        if (grid[cell >> 3] & (1u << (cell & 7u))) return true;
+        const float tx = ((((float)nx + 0.5f + 0.5f * copysignf(1.0f, dx)) * rH * 2.0f - 1.0f) * mb - x) * ix;
+        const float ty = ((((float)ny + 0.5f + 0.5f * copysignf(1.0f, dy)) * rH * 2.0f - 1.0f) * mb - y) * iy;
+        const float tz = ((((float)nz + 0.5f + 0.5f * copysignf(1.0f, dz)) * rH * 2.0f - 1.0f) * mb - z) * iz;
+        const float t_exit = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+        do {
+            const float t_next = t + step_len(t);
+            if (t_next == t) { t = INFINITY; break; }  // step below 1 ulp of t: leave instead of spinning forever
+            t = t_next;
+        } while (t < t_exit);
+        return false;
+    }
+};
+
+// pass 1: per-ray sample count -> rays[n].z
+__global__ __launch_bounds__(kBlock) void k_march_count(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                        const uint8_t* __restrict__ grid, float bound, float dt_gamma,
+                                                        uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                                                        const float* __restrict__ nears, const float* __restrict__ fars,
+                                                        const float* __restrict__ noises, int* __restrict__ rays) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    Marcher m;
+    m.init(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, grid, bound, dt_gamma, max_steps, C, H);
+    const float far = fars[n];
+    float t = nears[n];
+    t += m.step_len(t) * noises[n];
+    uint32_t count = 0;
+    float x, y, z, dt;
+    while (t < far && count < max_steps) {
+        if (m.probe(t, x, y, z, dt)) { ++count; t += dt; }
+    }
+    rays[3 * (size_t)n + 2] = (int)count;
+}
+
+// pass 2: one workgroup; exclusive scan of the counts in ray order, reserving [counter[0], +total).
+__global__ __launch_bounds__(1024) void k_march_scan(uint32_t N, int* __restrict__ rays, int* __restrict__ counter) {
+    __shared__ uint32_t wave_tot[16];
+    __shared__ uint32_t carry_s;
+    const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
+    if (threadIdx.x == 0) carry_s = (uint32_t)counter[0];
+    __syncthreads();
+    for (uint32_t base = 0; base < N; base += 1024) {
+        const uint32_t n = base + threadIdx.x;
+        const uint32_t c = n < N ? (uint32_t)rays[3 * (size_t)n + 2] : 0u;
+        const uint32_t incl = wave_scan_add_u32(c);
+        if (lane == 63) wave_tot[wid] = incl;
+        __syncthreads();
+        uint32_t before = carry_s;
+        for (int w = 0; w < wid; ++w) before += wave_tot[w];
+        if (n < N) {
+            rays[3 * (size_t)n + 0] = (int)n;
+            rays[3 * (size_t)n + 1] = (int)(before + incl - c);
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = before + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        counter[0] = (int)carry_s;
+        counter[1] += (int)N;
+    }
+}
+
+// pass 3: re-march and write the packed samples
+__global__ __launch_bounds__(kBlock) void k_march_write(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                        const uint8_t* __restrict__ grid, float bound, float dt_gamma,
+                                                        uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                                                        const float* __restrict__ nears, const float* __restrict__ fars,
+                                                        const float* __restrict__ noises, const int* __restrict__ rays,
+                                                        float* __restrict__ xyzs, float* __restrict__ dirs,
+                                                        float* __restrict__ deltas) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t offset = (uint32_t)rays[3 * (size_t)n + 1], count = (uint32_t)rays[3 * (size_t)n + 2];
+    if (count == 0 || offset + count > M) return;
+    Marcher m;
+    m.init(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, grid, bound, dt_gamma, max_steps, C, H);
+    const float far = fars[n];
+    float t = nears[n];
+    t += m.step_len(t) * noises[n];
+    float last_t = t;
+    float* px = xyzs + 3 * (size_t)offset;
+    float* pd = dirs + 3 * (size_t)offset;
+    float* pl = deltas + 2 * (size_t)offset;
+    uint32_t step = 0;
+    float x, y, z, dt;
+    while (t < far && step < count) {
+        if (m.probe(t, x, y, z, dt)) {
+            px[0] = x; px[1] = y; px[2] = z;
+            pd[0] = m.dx; pd[1] = m.dy; pd[2] = m.dz;
+            t += dt;
+            pl[0] = dt;
+            pl[1] = t - last_t;
+            last_t = t;
+            px += 3; pd += 3; pl += 2;
+            ++step;
+        }
+    }
+}
+
+// inference marcher: fixed n_step slots per alive ray
+__global__ __launch_bounds__(kBlock) void k_march_rays(uint32_t n_alive, uint32_t n_step, const int* __restrict__ rays_alive,
+                                                       const float* __restrict__ rays_t, const float* __restrict__ rays_o,
+                                                       const float* __restrict__ rays_d, float bound, float dt_gamma,
+                                                       uint32_t max_steps, uint32_t C, uint32_t H,
+                                                       const uint8_t* __restrict__ grid, const float* __restrict__ fars,
+                                                       float* __restrict__ xyzs, float* __restrict__ dirs,
+                                                       float* __restrict__ deltas, const float* __restrict__ noises) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= n_alive) return;
+    const int index = rays_alive[n];
+    Marcher m;
+    m.init(rays_o + 3 * (size_t)index, rays_d + 3 * (size_t)index, grid, bound, dt_gamma, max_steps, C, H);
+    float* px = xyzs + 3 * (size_t)n * n_step;
+    float* pd = dirs + 3 * (size_t)n * n_step;
+    float* pl = deltas + 2 * (size_t)n * n_step;
+    const float far = fars[index];
+    float t = rays_t[index];
+    t += m.step_len(t) * noises[n];
+    float last_t = t;
+    uint32_t step = 0;
+    float x, y, z, dt;
+    while (t < far && step < n_step) {
+        if (m.probe(t, x, y, z, dt)) {
+            px[0] = x; px[1] = y; px[2] = z;
+            pd[0] = m.dx; pd[1] = m.dy; pd[2] = m.dz;
+            t += dt;
+            pl[0] = dt;
+            pl[1] = t - last_t;
+            last_t = t;
+            px += 3; pd += 3; pl += 2;
+            ++step;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Packed-sample compositor, one wave per ray.  Lanes take 64 consecutive samples per round; the
+// transmittance is a cross-lane exclusive product scan carried between rounds.
+constexpr int kRaysPerBlock = kBlock / kWave;
+
+__global__ __launch_bounds__(kBlock) void k_composite_train_fwd(const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                                const float* __restrict__ deltas, const int* __restrict__ rays,
+                                                                uint32_t M, uint32_t N, float T_thresh,
+                                                                float* __restrict__ weights_sum, float* __restrict__ depth,
+                                                                float* __restrict__ image) {
+    const uint32_t n = blockIdx.x * kRaysPerBlock + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const int lane = lane_id();
+    const uint32_t index = (uint32_t)rays[3 * (size_t)n], offset = (uint32_t)rays[3 * (size_t)n + 1],
+                   count = (uint32_t)rays[3 * (size_t)n + 2];
+    float r = 0, g = 0, b = 0, ws = 0, d = 0;
+    if (count != 0 && offset + count <= M) {
+        float T_carry = 1.0f, t_carry = 0.0f;
+        for (uint32_t base = 0; base < count; base += 64) {
+            const uint32_t i = base + lane;
+            const bool valid = i < count;
+            float sg = 0, d0 = 0, d1 = 0, cr = 0, cg = 0, cb = 0;
+            if (valid) {
+                const size_t p = (size_t)offset + i;
+                sg = sigmas[p];
+                const float2 dl = reinterpret_cast<const float2*>(deltas)[p];
+                d0 = dl.x; d1 = dl.y;
+                cr = rgbs[3 * p]; cg = rgbs[3 * p + 1]; cb = rgbs[3 * p + 2];
+            }
+            const float alpha = valid ? 1.0f - expf(-sg * d0) : 0.0f;
+            const float om = 1.0f - alpha;
+            const float incl = wave_scan_mul(om);
+            float excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 1.0f;
+            const float T_before = T_carry * excl, T_after = T_carry * incl;
+            const unsigned long long stop = __ballot(valid && (T_after < T_thresh));
+            const int first_stop = stop ? (int)__builtin_ctzll(stop) : 64;
+            const float w = (valid && lane <= first_stop) ? alpha * T_before : 0.0f;
+            const float t_here = t_carry + wave_scan_add(d1);
+            r += w * cr; g += w * cg; b += w * cb;
+            d += w * t_here;
+            ws += w;
+            if (stop) break;
+            T_carry = __shfl(T_after, 63, 64);
+            t_carry = __shfl(t_here, 63, 64);
+        }
+        r = wave_sum(r); g = wave_sum(g); b = wave_sum(b); ws = wave_sum(ws); d = wave_sum(d);
+    }
+    if (lane == 0) {
+        weights_sum[index] = ws;
+        depth[index] = d;
+        image[3 * (size_t)index] = r; image[3 * (size_t)index + 1] = g; image[3 * (size_t)index + 2] = b;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_composite_train_bwd(const float* __restrict__ grad_ws, const float* __restrict__ grad_image,
+                                                                const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                                const float* __restrict__ deltas, const int* __restrict__ rays,
+                                                                const float* __restrict__ weights_sum, const float* __restrict__ image,
+                                                                uint32_t M, uint32_t N, float T_thresh,
+                                                                float* __restrict__ grad_sigmas, float* __restrict__ grad_rgbs) {
+    const uint32_t n = blockIdx.x * kRaysPerBlock + (threadIdx.x >> 6);
+    if (n >= N) return;
+    const int lane = lane_id();
+    const uint32_t index = (uint32_t)rays[3 * (size_t)n], offset = (uint32_t)rays[3 * (size_t)n + 1],
+                   count = (uint32_t)rays[3 * (size_t)n + 2];
+    if (count == 0 || offset + count > M) return;
+    const float gws = grad_ws[index];
+    const float gr = grad_image[3 * (size_t)index], gg = grad_image[3 * (size_t)index + 1], gb = grad_image[3 * (size_t)index + 2];
+    const float rF = image[3 * (size_t)index], gF = image[3 * (size_t)index + 1], bF = image[3 * (size_t)index + 2];
+    const float wsF = weights_sum[index];
+    float T_carry = 1.0f, r_carry = 0, g_carry = 0, b_carry = 0;
+    for (uint32_t base = 0; base < count; base += 64) {
+        const uint32_t i = base + lane;
+        const bool valid = i < count;
+        const size_t p = (size_t)offset + (valid ? i : 0);
+        float sg = 0, d0 = 0, cr = 0, cg = 0, cb = 0;
+        if (valid) {
+            sg = sigmas[p];
+            d0 = deltas[2 * p];
+            cr = rgbs[3 * p]; cg = rgbs[3 * p + 1]; cb = rgbs[3 * p + 2];
+        }
+        const float alpha = valid ? 1.0f - expf(-sg * d0) : 0.0f;
+        const float incl = wave_scan_mul(1.0f - alpha);
+        float excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0f;
+        const float T_before = T_carry * excl, T_after = T_carry * incl;
+        const unsigned long long stop = __ballot(valid && (T_after < T_thresh));
+        const int first_stop = stop ? (int)__builtin_ctzll(stop) : 64;
+        const bool live = valid && lane <= first_stop;
+        const float w = live ? alpha * T_before : 0.0f;
+        const float r = r_carry + wave_scan_add(w * cr);
+        const float g = g_carry + wave_scan_add(w * cg);
+        const float b = b_carry + wave_scan_add(w * cb);
+        if (live) {
+            grad_rgbs[3 * p] = gr * w; grad_rgbs[3 * p + 1] = gg * w; grad_rgbs[3 * p + 2] = gb * w;
+            grad_sigmas[p] = d0 * (gr * (T_after * cr - (rF - r)) + gg * (T_after * cg - (gF - g)) +
+                                   gb * (T_after * cb - (bF - b)) + gws * (1.0f - wsF));
+        }
+        if (stop) break;
+        T_carry = __shfl(T_after, 63, 64);
+        r_carry = __shfl(r, 63, 64); g_carry = __shfl(g, 63, 64); b_carry = __shfl(b, 63, 64);
+    }
+}
+
+// inference compositor: n_step is small (1..8 in practice) and n_alive large -> one lane per ray.
+__global__ __launch_bounds__(kBlock) void k_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh,
+                                                           int* __restrict__ rays_alive, float* __restrict__ rays_t,
+                                                           const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                           const float* __restrict__ deltas, float* __restrict__ weights_sum,
+                                                           float* __restrict__ depth, float* __restrict__ image) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= n_alive) return;
+    const int index = rays_alive[n];
+    const float* s = sigmas + (size_t)n * n_step;
+    const float* c = rgbs + 3 * (size_t)n * n_step;
+    const float* dl = deltas + 2 * (size_t)n * n_step;
+    float t = rays_t[index], ws = weights_sum[index], d = depth[index];
+    float r = image[3 * (size_t)index], g = image[3 * (size_t)index + 1], b = image[3 * (size_t)index + 2];
+    uint32_t step = 0;
+    while (step < n_step) {
+        if (dl[0] == 0.0f) break;
+        const float alpha = 1.0f - expf(-s[0] * dl[0]);
+        const float T = 1.0f - ws;
+        const float w = alpha * T;
+        ws += w;
+        t += dl[1];
+        d += w * t;
+        r += w * c[0]; g += w * c[1]; b += w * c[2];
+        if (T < T_thresh) break;
+        ++s; c += 3; dl += 2; ++step;
+    }
+    if (step < n_step) rays_alive[n] = -1;
+    else rays_t[index] = t;
+    weights_sum[index] = ws;
+    depth[index] = d;
+    image[3 * (size_t)index] = r; image[3 * (size_t)index + 1] = g; image[3 * (size_t)index + 2] = b;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C-ABI (declared and documented in include/nvsf_hip.h)
+// ================================================================================================
+#define REQUIRE(cond) do { if (!(cond)) return NVSF_ERR_INVALID_ARG; } while (0)
+
+NVSF_API int nvsf_near_far_from_aabb(const float* rays_o, const float* rays_d, const float* aabb, uint32_t N,
+                                     float min_near, float* nears, float* fars, hipStream_t stream) {
+    if (N == 0) return NVSF_OK;
+    REQUIRE(rays_o && rays_d && aabb && nears && fars);
+    hipLaunchKernelGGL(k_near_far, dim3(cdiv(N, kBlock)), dim3(kBlock), 0, stream, rays_o, rays_d, aabb, N, min_near, nears, fars);
+    return nvsf_launch_status();
+}
+
+NVSF_API int nvsf_sph_from_ray(const float* rays_o, const float* rays_d, float radius, uint32_t N, float* coords,
+                               hipStream_t stream) {
+    if (N == 0) return NVSF_OK;
+    REQUIRE(rays_o && rays_d && coords);
+    hipLaunchKernelGGL(k_sph_from_ray, dim3(cdiv(N, kBlock)), dim3(kBlock), 0, stream, rays_o, rays_d, radius, N, coords);
+    return nvsf_launch_status();
+}
+
+NVSF_API int nvsf_morton3D(const int32_t* coords, uint32_t N, int32_t* indices, hipStream_t stream) {
+    if (N == 0) return NVSF_OK;
+    REQUIRE(coords && indices);
+    hipLaunchKernelGGL(k_morton3D, dim3(cdiv(N, kBlock)), dim3(kBlock), 0, stream, coords, N, indices);
+    return nvsf_launch_status();
+}
+
+NVSF_API int nvsf_morton3D_invert(const int32_t* indices, uint32_t N, int32_t* coords, hipStream_t stream) {
+    if (N == 0) return NVSF_OK;
+    REQUIRE(coords && indices);
+    hipLaunchKernelGGL(k_morton3D_invert, dim3(cdiv(N, kBlock)), dim3(kBlock), 0, stream, indices, N, coords);
+    return nvsf_launch_status();
+}
+
+NVSF_API int nvsf_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* bitfield, hipStream_t stream) {
+    if (N == 0) return NVSF_OK;
+    REQUIRE(grid && bitfield);
+    REQUIRE((reinterpret_cast<uintptr_t>(grid) & 15u) == 0);
+    hipLaunchKernelGGL(k_packbits, dim3(cdiv(N, kBlock)), dim3(kBlock), 0, stream, grid, N, density_thresh, bitfield);
+    return nvsf_launch_status();
+}
+
+NVSF_API int nvsf_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
+                                   uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
+                                   const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays,
+                                   int32_t* counter, const float* noises, hipStream_t stream) {
+    if (N == 0) return NVSF_OK;
+    REQUIRE(rays_o && rays_d && grid && nears && fars && xyzs && dirs && deltas && rays && counter && noises);
+    REQUIRE(C >= 1 && C <= 8 && H >= 2 && H <= 1024 && max_steps >= 1);
+    hipLaunchKernelGGL(k_march_count, dim3(cdiv(N, kBlock)), dim3(kBlock), 0, stream, rays_o, rays_d, grid, bound, dt_gamma,
+                       max_steps, N, C, H, nears, fars, noises, rays);
+    hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(1024), 0, stream, N, rays, counter);
+    hipLaunchKernelGGL(k_march_write, dim3(cdiv(N, kBlock)), dim3(kBlock), 0, stream, rays_o, rays_d, grid, bound, dt_gamma,
+                       max_steps, N, C, H, M, nears, fars, noises, rays, xyzs, dirs, deltas);
+    return nvsf_launch_status();
+}
+
+NVSF_API int nvsf_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,
+                                               uint32_t M, uint32_t N, float T_thresh, float* weights_sum, float* depth,
+                                               float* image, hipStream_t stream) {
+    if (N == 0) return NVSF_OK;
+    REQUIRE(rays && weights_sum && depth && image);
+    REQUIRE(M == 0 || (sigmas && rgbs && deltas));
+    hipLaunchKernelGGL(k_composite_train_fwd, dim3(cdiv(N, kRaysPerBlock)), dim3(kBlock), 0, stream, sigmas, rgbs, deltas, rays,
+                       M, N, T_thresh, weights_sum, depth, image);
+    return nvsf_launch_status();
+}
+
+NVSF_API int nvsf_composite_rays_train_backward(const float* grad_weights_sum, const float* grad_image, const float* sigmas,
+                                                const float* rgbs, const float* deltas, const int32_t* rays,
+                                                const float* weights_sum, const float* image, uint32_t M, uint32_t N,
+                                                float T_thresh, float* grad_sigmas, float* grad_rgbs, hipStream_t stream) {
+    if (N == 0 || M == 0) return NVSF_OK;
+    REQUIRE(grad_weights_sum && grad_image && sigmas && rgbs && deltas && rays && weights_sum && image && grad_sigmas && grad_rgbs);
+    hipLaunchKernelGGL(k_composite_train_bwd, dim3(cdiv(N, kRaysPerBlock)), dim3(kBlock), 0, stream, grad_weights_sum, grad_image,
+                       sigmas, rgbs, deltas, rays, weights_sum, image, M, N, T_thresh, grad_sigmas, grad_rgbs);
+    return nvsf_launch_status();
+}
+
+NVSF_API int nvsf_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* rays_alive, const float* rays_t,
+                             const float* rays_o, const float* rays_d, float bound, float dt_gamma, uint32_t max_steps,
+                             uint32_t C, uint32_t H, const uint8_t* grid, const float* nears, const float* fars, float* xyzs,
+                             float* dirs, float* deltas, const float* noises, hipStream_t stream) {
+    if (n_alive == 0 || n_step == 0) return NVSF_OK;
+    REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && nears && fars && xyzs && dirs && deltas && noises);
+    REQUIRE(C >= 1 && C <= 8 && H >= 2 && H <= 1024 && max_steps >= 1);
+    hipLaunchKernelGGL(k_march_rays, dim3(cdiv(n_alive, kBlock)), dim3(kBlock), 0, stream, n_alive, n_step, rays_alive, rays_t,
+                       rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas, noises);
+    return nvsf_launch_status();
+}
+
+NVSF_API int nvsf_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thresh, int32_t* rays_alive, float* rays_t,
+                                 const float* sigmas, const float* rgbs, const float* deltas, float* weights_sum, float* depth,
+                                 float* image, hipStream_t stream) {
+    if (n_alive == 0) return NVSF_OK;
+    REQUIRE(rays_alive && rays_t && weights_sum && depth && image);
+    REQUIRE(n_step == 0 || (sigmas && rgbs && deltas));
+    hipLaunchKernelGGL(k_composite_rays, dim3(cdiv(n_alive, kBlock)), dim3(kBlock), 0, stream, n_alive, n_step, T_thresh,
+                       rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image);
+    return nvsf_launch_status();
+}

@@ -1,0 +1,104 @@
+"""ctypes binding of libnvsf_hip.so (the C ABI declared in include/nvsf_hip.h).
+
+This is the only place where Python touches the native library.  There is deliberately NO fallback:
+if the shared object is missing or a call is made without a HIP device the caller gets an exception,
+never a silently slower PyTorch/CPU path.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libnvsf_hip.so")
+
+_P, _U, _F, _I = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_float, ctypes.c_int
+
+# name -> argument ctypes (the trailing stream argument is appended automatically)
+SIGNATURES = {
+    # section 1: raymarching extension
+    "nvsf_near_far_from_aabb": [_P, _P, _P, _U, _F, _P, _P],
+    "nvsf_sph_from_ray": [_P, _P, _F, _U, _P],
+    "nvsf_morton3D": [_P, _U, _P],
+    "nvsf_morton3D_invert": [_P, _U, _P],
+    "nvsf_packbits": [_P, _U, _F, _P],
+    "nvsf_march_rays_train": [_P, _P, _P, _F, _F, _U, _U, _U, _U, _U, _P, _P, _P, _P, _P, _P, _P, _P],
+    "nvsf_composite_rays_train_forward": [_P, _P, _P, _P, _U, _U, _F, _P, _P, _P],
+    "nvsf_composite_rays_train_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _F, _P, _P],
+    "nvsf_march_rays": [_U, _U, _P, _P, _P, _P, _F, _F, _U, _U, _U, _P, _P, _P, _P, _P, _P, _P],
+    "nvsf_composite_rays": [_U, _U, _F, _P, _P, _P, _P, _P, _P, _P, _P],
+    # section 2: uniform sampler / compositor
+    "nvsf_uniform_samples": [_P, _P, _P, _P, _P, _P, _P, _U, _U, _P, _P],
+    "nvsf_composite_uniform_weights_fwd": [_P, _P, _P, _P, _U, _U, _F, _P, _P, _P],
+    "nvsf_composite_uniform_weights_bwd": [_P, _P, _P, _P, _P, _P, _P, _U, _U, _F, _P],
+    "nvsf_composite_uniform_image_fwd": [_P, _P, _P, _U, _U, _U, _P, _P],
+    "nvsf_composite_uniform_image_bwd": [_P, _P, _P, _U, _U, _U, _P, _P, _P, _P],
+    # section 3: field operators
+    "nvsf_hashgrid_fwd": [_P, _U, _U, _P, _U, _P, _U, _U, _P, _P, _P, _P, _U],
+    "nvsf_hashgrid_bwd": [_P, _U, _U, _P, _U, _U, _U, _P, _P, _P, _P, _I, _U, _P],
+    "nvsf_freq_encode": [_P, _U, _U, _U, _P, _U],
+    "nvsf_sh4_encode": [_P, _U, _P, _U],
+    "nvsf_mlp_fwd": [_P, _I, _U, _U, _U, _P, _U, _U, _U, _U, _P, _U],
+    # section 4: fused uniform-render kernels
+    "nvsf_field_density_uniform_fwd": [_P, _P, _P, _P, _P, _P, _P, _F, _U, _U, _P, _U, _U, _P, _P, _P, _P, _P, _P, _P],
+    "nvsf_field_heads_uniform_fwd": [_P, _P, _P, _P, _I, _P, _P, _U, _U, _F, _P, _P],
+}
+
+_lib = None
+
+
+class NvsfHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads libnvsf_hip.so (once).  Raises NvsfHipError when the library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NvsfHipError(
+            f"{LIB_PATH} is missing: build it with `python selfsupervised-nvsf_amd/build.py` "
+            "(or __graft_entry__.build()).  There is no CPU / PyTorch fallback for the NVSF hot path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here == header / library mismatch
+        fn.argtypes = list(argtypes) + [_P]
+        fn.restype = ctypes.c_int
+    lib.nvsf_version.restype = ctypes.c_char_p
+    lib.nvsf_version.argtypes = []
+    _lib = lib
+    return lib
+
+
+def version():
+    return load().nvsf_version().decode()
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  The tensor must live on a HIP device."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise NvsfHipError("NVSF HIP kernels need tensors on a HIP device (got a CPU tensor); there is no CPU fallback")
+    if not t.is_contiguous():
+        raise NvsfHipError("NVSF HIP kernels need contiguous tensors")
+    return t.data_ptr()
+
+
+def host_f32(values):
+    return (ctypes.c_float * len(values))(*[float(v) for v in values])
+
+
+def host_u32(values):
+    return (ctypes.c_uint32 * len(values))(*[int(v) for v in values])
+
+
+def call(name, *args):
+    """Launches `name` on PyTorch's current HIP stream and raises on a non-zero status."""
+    lib = load()
+    stream = torch.cuda.current_stream().cuda_stream
+    status = getattr(lib, name)(*args, stream)
+    if status != 0:
+        kind = "rejected arguments" if status < 0 else "hipError_t"
+        raise NvsfHipError(f"{name} failed with status {status} ({kind})")

@@ -1,0 +1,290 @@
+"""Host-side (PyTorch) entry points of the per-sample field operators and the uniform compositor.
+
+Thin, allocation-only wrappers over the C ABI (include/nvsf_hip.h sections 2-4) plus the autograd glue
+the trainer needs.  No arithmetic of the hot path happens in Python: every function here ends in a HIP
+kernel launch on the current stream.  Backward passes of the MLPs are plain fp16 GEMMs and are issued
+through torch.matmul (rocBLAS/hipBLASLt); everything else is a kernel of libnvsf_hip.so.
+"""
+import math
+
+import numpy as np
+import torch
+from torch.autograd import Function
+
+from nvsf import _hip
+
+W_THRESH = 1e-4  # colour is only evaluated where the compositing weight exceeds this (renderer_dynamic.py:202)
+
+
+# ------------------------------------------------------------------------------------------------
+# multiresolution hash grid
+# ------------------------------------------------------------------------------------------------
+class GridSpec:
+    """Level table of a multiresolution hash grid (Instant-NGP / tcnn "HashGrid" conventions).
+
+    scale_l = exp2(l * log2(per_level_scale)) * base_resolution - 1 ; res_l = ceil(scale_l) + 1 ;
+    rows_l = min(round_up(res_l^D, 8), 2^log2_hashmap_size).  Evaluated once, on the host, in fp32.
+    """
+
+    def __init__(self, n_dims, n_levels, n_features, log2_hashmap_size, base_resolution, per_level_scale):
+        self.D, self.L, self.F = int(n_dims), int(n_levels), int(n_features)
+        self.log2_hashmap_size = int(log2_hashmap_size)
+        self.base_resolution = int(base_resolution)
+        self.per_level_scale = float(per_level_scale)
+        log2_pls = np.float32(np.log2(np.float32(per_level_scale)))
+        scales, res, offsets = [], [], [0]
+        for l in range(self.L):
+            s = np.float32(np.exp2(np.float32(l) * log2_pls)) * np.float32(base_resolution) - np.float32(1.0)
+            r = int(np.ceil(s)) + 1
+            rows = min(r ** self.D, 2 ** 31)
+            rows = (rows + 7) // 8 * 8
+            rows = min(rows, 1 << self.log2_hashmap_size)
+            scales.append(float(s))
+            res.append(r)
+            offsets.append(offsets[-1] + rows)
+        self.scales, self.res, self.offsets = scales, res, offsets
+        self.n_rows = offsets[-1]
+        self.n_params = self.n_rows * self.F
+        self.n_output_dims = self.L * self.F
+        self.h_scales, self.h_res, self.h_offsets = _hip.host_f32(scales), _hip.host_u32(res), _hip.host_u32(offsets)
+
+
+def hashgrid_forward(x, cols, table_f16, spec, out=None):
+    """x fp32 [M, x_stride]; cols = the D columns of x to encode; table fp16 [n_params] -> fp16 [M, L*F]."""
+    x = x.contiguous()
+    M, x_stride = x.shape[0], x.shape[1]
+    if out is None:
+        out = torch.empty(M, spec.n_output_dims, dtype=torch.float16, device=x.device)
+    _hip.call("nvsf_hashgrid_fwd", _hip.ptr(x), M, x_stride, _hip.host_u32(cols), spec.D, _hip.ptr(table_f16), spec.L, spec.F,
+              spec.h_scales, spec.h_res, spec.h_offsets, _hip.ptr(out), out.stride(0))
+    return out
+
+
+def hashgrid_backward(x, cols, spec, grad_out, grad_table=None):
+    """Scatter-adds d L / d table (fp32 [n_params]) from grad_out ([M, L*F], fp16 or fp32)."""
+    x = x.contiguous()
+    grad_out = grad_out.contiguous()
+    if grad_table is None:
+        grad_table = torch.zeros(spec.n_params, dtype=torch.float32, device=x.device)
+    _hip.call("nvsf_hashgrid_bwd", _hip.ptr(x), x.shape[0], x.shape[1], _hip.host_u32(cols), spec.D, spec.L, spec.F, spec.h_scales,
+              spec.h_res, spec.h_offsets, _hip.ptr(grad_out), 1 if grad_out.dtype == torch.float16 else 0, grad_out.stride(0),
+              _hip.ptr(grad_table))
+    return grad_table
+
+
+class HashGridFn(Function):
+    """fp16 features = encode(x; table).  Gradient flows to the (fp32 master) table only."""
+
+    @staticmethod
+    def forward(ctx, x, params, table_f16, spec, cols):
+        x = x.float().contiguous()
+        out = hashgrid_forward(x, cols, table_f16, spec)
+        ctx.save_for_backward(x)
+        ctx.spec, ctx.cols = spec, cols
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (x,) = ctx.saved_tensors
+        grad_params = hashgrid_backward(x, ctx.cols, ctx.spec, grad_out) if ctx.needs_input_grad[1] else None
+        return None, grad_params, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# direction encodings
+# ------------------------------------------------------------------------------------------------
+def freq_encode(x, n_freq=12):
+    x = x.float().contiguous()
+    M, n_dims = x.shape
+    out = torch.empty(M, 2 * n_dims * n_freq, dtype=torch.float16, device=x.device)
+    _hip.call("nvsf_freq_encode", _hip.ptr(x), M, n_dims, n_freq, _hip.ptr(out), out.stride(0))
+    return out
+
+
+def sh4_encode(d01):
+    d01 = d01.float().contiguous()
+    M = d01.shape[0]
+    out = torch.empty(M, 16, dtype=torch.float16, device=d01.device)
+    _hip.call("nvsf_sh4_encode", _hip.ptr(d01), M, _hip.ptr(out), out.stride(0))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# fused MLP
+# ------------------------------------------------------------------------------------------------
+class MlpSpec:
+    """Shapes + fp16 parameter layout of a bias-free ReLU MLP (tcnn "FullyFusedMLP" conventions):
+    W0 [hidden][in_cols] ++ (n_hidden-1) x [hidden][hidden] ++ W_out [out_cols][hidden], row-major;
+    in_cols = round_up(n_in, 16) (padding inputs read as 1), out_cols = round_up(n_out, 16)."""
+
+    def __init__(self, n_in, n_out, hidden=64, n_hidden=1):
+        self.n_in, self.n_out, self.hidden, self.n_hidden = int(n_in), int(n_out), int(hidden), int(n_hidden)
+        self.in_cols = (self.n_in + 15) // 16 * 16
+        self.out_cols = (self.n_out + 15) // 16 * 16
+        self.shapes = [(self.hidden, self.in_cols)] + [(self.hidden, self.hidden)] * (self.n_hidden - 1) + [(self.out_cols, self.hidden)]
+        self.n_params = sum(a * b for a, b in self.shapes)
+
+    def split(self, flat):
+        mats, o = [], 0
+        for a, b in self.shapes:
+            mats.append(flat[o:o + a * b].view(a, b))
+            o += a * b
+        return mats
+
+
+def mlp_forward(x, weights_f16, spec):
+    """x [M, n_in] (fp32 or fp16) -> fp16 [M, out_cols]."""
+    if x.dtype not in (torch.float16, torch.float32):
+        x = x.float()
+    x = x.contiguous()
+    M = x.shape[0]
+    out = torch.empty(M, spec.out_cols, dtype=torch.float16, device=x.device)
+    _hip.call("nvsf_mlp_fwd", _hip.ptr(x), 1 if x.dtype == torch.float16 else 0, M, spec.n_in, x.stride(0), _hip.ptr(weights_f16),
+              spec.in_cols, spec.hidden, spec.n_hidden, spec.out_cols, _hip.ptr(out), out.stride(0))
+    return out
+
+
+class MlpFn(Function):
+    """out = MLP(x; params).  Forward: one fused MFMA kernel.  Backward: the chain of plain fp16 GEMMs
+    (dW_l = dY_l^T A_{l-1}, dA_{l-1} = dY_l W_l) through torch.matmul, with the hidden activations
+    recomputed from the saved input."""
+
+    @staticmethod
+    def forward(ctx, x, params, weights_f16, spec):
+        out = mlp_forward(x, weights_f16, spec)
+        ctx.save_for_backward(x, weights_f16)
+        ctx.spec = spec
+        return out[:, :spec.n_out]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weights_f16 = ctx.saved_tensors
+        spec = ctx.spec
+        mats = spec.split(weights_f16)
+        M = x.shape[0]
+        a0 = torch.ones(M, spec.in_cols, dtype=torch.float16, device=x.device)
+        a0[:, :spec.n_in] = x.to(torch.float16)
+        acts = [a0]
+        for W in mats[:-1]:
+            acts.append(torch.relu(acts[-1] @ W.t()))
+        g = torch.zeros(M, spec.out_cols, dtype=torch.float16, device=x.device)
+        g[:, :spec.n_out] = grad_out.to(torch.float16)
+        grads = []
+        for li in range(len(mats) - 1, -1, -1):
+            grads.append((g.t() @ acts[li]).float())
+            if li > 0 or ctx.needs_input_grad[0]:
+                g = g @ mats[li]
+                if li > 0:
+                    g = g * (acts[li] > 0)
+        grad_params = torch.cat([t.reshape(-1) for t in reversed(grads)]) if ctx.needs_input_grad[1] else None
+        grad_x = g[:, :spec.n_in].to(x.dtype) if ctx.needs_input_grad[0] else None
+        return grad_x, grad_params, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# uniform sampler / compositor (renderer_dynamic.py:155-237)
+# ------------------------------------------------------------------------------------------------
+_LIN_CACHE = {}
+
+
+def linspace01(T, device):
+    """torch.linspace(0, 1, T) on `device`, cached (renderer_dynamic.py:155)."""
+    key = (int(T), str(device))
+    if key not in _LIN_CACHE:
+        _LIN_CACHE[key] = torch.linspace(0.0, 1.0, int(T), device=device)
+    return _LIN_CACHE[key]
+
+
+def uniform_samples(rays_o, rays_d, nears, fars, T, aabb, noise=None, want_xyz=True):
+    """z_vals [N,T] (+ clipped xyzs [N,T,3])."""
+    N = rays_o.shape[0]
+    dev = rays_o.device
+    z_vals = torch.empty(N, T, dtype=torch.float32, device=dev)
+    xyzs = torch.empty(N, T, 3, dtype=torch.float32, device=dev) if want_xyz else None
+    _hip.call("nvsf_uniform_samples", _hip.ptr(rays_o), _hip.ptr(rays_d), _hip.ptr(nears), _hip.ptr(fars), _hip.ptr(linspace01(T, dev)),
+              _hip.ptr(noise), _hip.ptr(aabb), N, T, _hip.ptr(z_vals), _hip.ptr(xyzs))
+    return z_vals, xyzs
+
+
+class CompositeWeightsFn(Function):
+    """(sigmas [N,T], z_vals, nears, fars) -> weights [N,T], weights_sum [N], depth [N]."""
+
+    @staticmethod
+    def forward(ctx, sigmas, z_vals, nears, fars, k_scale):
+        sigmas = sigmas.float().contiguous()
+        N, T = sigmas.shape
+        weights = torch.empty_like(sigmas)
+        weights_sum = torch.empty(N, dtype=torch.float32, device=sigmas.device)
+        depth = torch.empty(N, dtype=torch.float32, device=sigmas.device)
+        _hip.call("nvsf_composite_uniform_weights_fwd", _hip.ptr(sigmas), _hip.ptr(z_vals), _hip.ptr(nears), _hip.ptr(fars), N, T,
+                  float(k_scale), _hip.ptr(weights), _hip.ptr(weights_sum), _hip.ptr(depth))
+        ctx.save_for_backward(sigmas, z_vals, nears, fars)
+        ctx.k_scale = float(k_scale)
+        return weights, weights_sum, depth
+
+    @staticmethod
+    def backward(ctx, g_weights, g_ws, g_depth):
+        sigmas, z_vals, nears, fars = ctx.saved_tensors
+        N, T = sigmas.shape
+        grad = torch.empty_like(sigmas)
+        gw = g_weights.float().contiguous() if g_weights is not None else None
+        gs = g_ws.float().contiguous() if g_ws is not None else None
+        gd = g_depth.float().contiguous() if g_depth is not None else None
+        _hip.call("nvsf_composite_uniform_weights_bwd", _hip.ptr(sigmas), _hip.ptr(z_vals), _hip.ptr(nears), _hip.ptr(fars),
+                  _hip.ptr(gw), _hip.ptr(gs), _hip.ptr(gd), N, T, ctx.k_scale, _hip.ptr(grad))
+        return grad, None, None, None, None
+
+
+class CompositeImageFn(Function):
+    """image[n] = sum_i w[n,i] rgb[n,i,:] (+ (1 - ws[n]) * bg)."""
+
+    @staticmethod
+    def forward(ctx, weights, rgbs, weights_sum, bg):
+        weights, rgbs = weights.contiguous(), rgbs.float().contiguous()
+        N, T, C = rgbs.shape
+        image = torch.empty(N, C, dtype=torch.float32, device=rgbs.device)
+        _hip.call("nvsf_composite_uniform_image_fwd", _hip.ptr(weights), _hip.ptr(rgbs), _hip.ptr(weights_sum), N, T, C, _hip.ptr(bg),
+                  _hip.ptr(image))
+        ctx.save_for_backward(weights, rgbs, bg if bg is not None else torch.empty(0, device=rgbs.device))
+        ctx.has_bg = bg is not None
+        return image
+
+    @staticmethod
+    def backward(ctx, g_image):
+        weights, rgbs, bg = ctx.saved_tensors
+        N, T, C = rgbs.shape
+        g_image = g_image.float().contiguous()
+        g_w = torch.empty_like(weights)
+        g_rgb = torch.empty_like(rgbs)
+        g_ws = torch.empty(N, dtype=torch.float32, device=rgbs.device) if ctx.has_bg else None
+        _hip.call("nvsf_composite_uniform_image_bwd", _hip.ptr(weights), _hip.ptr(rgbs), _hip.ptr(g_image), N, T, C,
+                  _hip.ptr(bg) if ctx.has_bg else None, _hip.ptr(g_w), _hip.ptr(g_rgb), _hip.ptr(g_ws))
+        return g_w, g_rgb, g_ws, None
+
+
+# ------------------------------------------------------------------------------------------------
+# fused uniform-render kernels (static hash field)
+# ------------------------------------------------------------------------------------------------
+def density_uniform(rays_o, rays_d, nears, fars, T, aabb_host, bound, table_f16, spec, sigma_weights_f16, noise=None):
+    """ray batch -> z_vals [N,T] fp32, sigmas [N,T] fp32, geo [N,T,16] fp16 (h1..h15, 1.0)."""
+    N = rays_o.shape[0]
+    dev = rays_o.device
+    z_vals = torch.empty(N, T, dtype=torch.float32, device=dev)
+    sigmas = torch.empty(N, T, dtype=torch.float32, device=dev)
+    geo = torch.empty(N, T, 16, dtype=torch.float16, device=dev)
+    _hip.call("nvsf_field_density_uniform_fwd", _hip.ptr(rays_o), _hip.ptr(rays_d), _hip.ptr(nears), _hip.ptr(fars),
+              _hip.ptr(linspace01(T, dev)), _hip.ptr(noise), _hip.host_f32(aabb_host), float(bound), N, T, _hip.ptr(table_f16),
+              spec.L, spec.F, spec.h_scales, spec.h_res, spec.h_offsets, _hip.ptr(sigma_weights_f16), _hip.ptr(z_vals),
+              _hip.ptr(sigmas), _hip.ptr(geo))
+    return z_vals, sigmas, geo
+
+
+def heads_uniform(weights, geo, rays_d, weights_sum, lidar, head_a_f16, head_b_f16, bg_host=None, w_thresh=W_THRESH):
+    """(weights, geo, dirs) -> image [N, 2 (LiDAR: raydrop, intensity) | 3 (camera rgb)]."""
+    N, T = weights.shape
+    C = 2 if lidar else 3
+    image = torch.empty(N, C, dtype=torch.float32, device=weights.device)
+    _hip.call("nvsf_field_heads_uniform_fwd", _hip.ptr(weights), _hip.ptr(geo), _hip.ptr(rays_d), _hip.ptr(weights_sum),
+              1 if lidar else 0, _hip.ptr(head_a_f16), _hip.ptr(head_b_f16), N, T, float(w_thresh),
+              _hip.host_f32(bg_host) if bg_host is not None else None, _hip.ptr(image))
+    return image

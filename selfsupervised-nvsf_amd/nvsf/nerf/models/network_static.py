@@ -1,0 +1,100 @@
+"""Static hash-grid field (BASELINE config 2: "hash-grid L=16 F=2, 2x64 MLP").
+
+The static sub-graph of the reference's NeRFNetwork (network_dynamic.py:12-192): one 3-D multiresolution
+hash grid per modality (hash_field.py:107-119) feeding the shared density MLP (`sigma_net`,
+network_dynamic.py:125-135), and the same direction encoders + heads (`view_encoder_lidar` Frequency ->
+`intensity_net` / `raydrop_net`, `view_encoder_camera` SH4 -> `color_net`, :108-114,138-189), with the same
+`density` / `color` / `get_params` signatures and result conventions (LiDAR channel order = [raydrop,
+intensity], :317).  The space-time parts (K-planes, time-sliced 2-D grids, flow field) live in
+network_dynamic.py.
+
+Two execution paths, numerically equivalent (tests/test_render_static_gpu.py):
+  * operator path (`density` / `color`): stand-alone HIP operators with autograd -- used for training;
+  * `fused_uniform_render`: three fused kernels per ray batch -- used whenever no gradient is recorded.
+"""
+import numpy as np
+import torch
+
+import tinycudann as tcnn
+from nvsf import field_ops as ops
+from nvsf.nerf.activation import trunc_exp
+from nvsf.nerf.models.renderer_dynamic import NeRFRenderer
+
+
+class NeRFNetworkStatic(NeRFRenderer):
+    def __init__(self, base_resolution=16, max_resolution=2048, n_levels_hash=16, n_features_per_level_hash=2,
+                 log2_hashmap_size=19, num_layers_sigma=2, hidden_dim_sigma=64, geo_feat_dim=15, num_layers_lidar=3,
+                 hidden_dim_lidar=64, num_layers_color=3, hidden_dim_color=64, out_color_dim=3, out_lidar_color_dim=2,
+                 num_frames=64, bound=1, **kwargs):
+        super().__init__(bound, **kwargs)
+        self.out_color_dim, self.out_lidar_color_dim = out_color_dim, out_lidar_color_dim
+        self.num_frames = num_frames
+        per_level_scale = float(np.exp2(np.log2(max_resolution / base_resolution) / (n_levels_hash - 1)))
+        grid_cfg = {"otype": "HashGrid", "n_levels": n_levels_hash, "n_features_per_level": n_features_per_level_hash,
+                    "log2_hashmap_size": log2_hashmap_size, "base_resolution": base_resolution,
+                    "per_level_scale": per_level_scale}
+        self.hash_encoder_lidar = tcnn.Encoding(n_input_dims=3, encoding_config=grid_cfg, seed=11)
+        self.hash_encoder_camera = tcnn.Encoding(n_input_dims=3, encoding_config=grid_cfg, seed=12)
+
+        def mlp(n_in, n_out, hidden, layers, seed):
+            return tcnn.Network(n_input_dims=n_in, n_output_dims=n_out, seed=seed,
+                                network_config={"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None",
+                                                "n_neurons": hidden, "n_hidden_layers": layers - 1})
+
+        self.sigma_net = mlp(self.hash_encoder_lidar.n_output_dims, 1 + geo_feat_dim, hidden_dim_sigma, num_layers_sigma, 21)
+        self.view_encoder_lidar = tcnn.Encoding(n_input_dims=3, encoding_config={"otype": "Frequency", "degree": 12})
+        self.intensity_net = mlp(self.view_encoder_lidar.n_output_dims + geo_feat_dim, 1, hidden_dim_lidar, num_layers_lidar, 22)
+        self.raydrop_net = mlp(self.view_encoder_lidar.n_output_dims + geo_feat_dim, 1, hidden_dim_lidar, num_layers_lidar, 23)
+        self.view_encoder_camera = tcnn.Encoding(n_input_dims=3, encoding_config={"otype": "SphericalHarmonics", "degree": 4})
+        self.color_net = mlp(self.view_encoder_camera.n_output_dims + geo_feat_dim, out_color_dim, hidden_dim_color,
+                             num_layers_color, 24)
+
+    # ---- operator path (signatures of network_dynamic.py:213, :290) ---------------------------------
+    def density(self, x, t=None, cal_lidar_color=False, **kwargs):
+        x = (x + self.bound) / (2 * self.bound)
+        enc = self.hash_encoder_lidar if cal_lidar_color else self.hash_encoder_camera
+        h = self.sigma_net(enc(x))
+        return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
+
+    def color(self, x, d, cal_lidar_color=False, mask=None, geo_feat=None, **kwargs):
+        if mask is not None:
+            rgbs = torch.zeros(mask.shape[0], self.out_dim, dtype=x.dtype, device=x.device)
+            if not mask.any():
+                return rgbs
+            d, geo_feat = d[mask], geo_feat[mask]
+        d = (d + 1) / 2
+        if cal_lidar_color:
+            logits = torch.cat([self.view_encoder_lidar(d), geo_feat], dim=-1)
+            h = torch.cat([self.raydrop_net(logits), self.intensity_net(logits)], dim=-1)
+        else:
+            h = self.color_net(torch.cat([self.view_encoder_camera(d), geo_feat], dim=-1))
+        h = torch.sigmoid(h)
+        if mask is None:
+            return h
+        rgbs[mask] = h.to(rgbs.dtype)
+        return rgbs
+
+    # ---- fused path ------------------------------------------------------------------------------------
+    def fused_uniform_render(self, rays_o, rays_d, nears, fars, T, aabb, noise, cal_lidar_color, bg_host, **kwargs):
+        enc = self.hash_encoder_lidar if cal_lidar_color else self.hash_encoder_camera
+        aabb_host = self._aabb_host  # host copy of the (constant) box: no device->host read on the hot path
+        z_vals, sigmas, geo = ops.density_uniform(rays_o, rays_d, nears, fars, T, aabb_host, float(self.bound), enc.table_f16(),
+                                                  enc.spec, self.sigma_net.weights_f16(), noise)
+        weights, weights_sum, depth = ops.CompositeWeightsFn.apply(sigmas, z_vals, nears, fars, self._k_scale())
+        if cal_lidar_color:
+            image = ops.heads_uniform(weights, geo, rays_d, weights_sum, True, self.raydrop_net.weights_f16(),
+                                      self.intensity_net.weights_f16(), None)
+        else:
+            image = ops.heads_uniform(weights, geo, rays_d, weights_sum, False, self.color_net.weights_f16(), None, bg_host)
+        return z_vals, weights, weights_sum, depth, image
+
+    def get_params(self, lr):
+        """Optimiser groups with the reference's per-group learning rates (network_dynamic.py:335-357)."""
+        return [
+            {"params": self.hash_encoder_lidar.parameters(), "lr": lr},
+            {"params": self.hash_encoder_camera.parameters(), "lr": lr},
+            {"params": self.sigma_net.parameters(), "lr": lr},
+            {"params": self.intensity_net.parameters(), "lr": 0.1 * lr},
+            {"params": self.raydrop_net.parameters(), "lr": 0.1 * lr},
+            {"params": self.color_net.parameters(), "lr": lr},
+        ]

@@ -1,0 +1,227 @@
+"""GPU parity: the nine `nvsf.nerf.raymarching.raymarching` operators (HIP, through the C ABI) against the CPU
+oracle (oracle/raymarching_oracle.c) on the same seeded inputs.
+
+Bars: bit-exact for integer / index / byte outputs and for the marcher (sample counts, offsets, positions,
+step sizes: every decision is fp32 with identical rounding); 1e-5 abs for the compositors (wave-parallel
+product scan + fast exp vs sequential expf; north_star tolerance is 1e-4).
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.fixture(scope="module")
+def rm(dev):
+    from nvsf.nerf.raymarching import raymarching
+    return raymarching
+
+
+@pytest.fixture(scope="module")
+def scene():
+    from nvsf import synthetic as S
+    rng = np.random.default_rng(0)
+    grid = S.boxes_density_grid(rng, cascades=2, H=128, n_boxes=64)
+    bits = O.packbits(grid, 0.5)
+    return dict(grid=grid, bits=bits)
+
+
+def _rays(n, seed, kind="cam"):
+    from nvsf import synthetic as S
+    rng = np.random.default_rng(seed)
+    return (S.camera_rays if kind == "cam" else S.lidar_rays)(n, rng)
+
+
+@pytest.mark.parametrize("n", [1, 63, 4096])
+def test_near_far_from_aabb(rm, dev, n):
+    o, d = _rays(n, 1)
+    o = o * 8.0  # push some origins outside the box so that misses occur
+    d[: n // 8, 0] = 0.0  # axis-parallel rays: 1/0 = inf must behave as in the reference
+    aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
+    nr, fr = O.near_far_from_aabb(o, d, aabb, 0.05)
+    ng, fg = rm.near_far_from_aabb(_t(o, dev), _t(d, dev), _t(aabb, dev), 0.05)
+    assert np.array_equal(nr, ng.cpu().numpy(), equal_nan=True)
+    assert np.array_equal(fr, fg.cpu().numpy(), equal_nan=True)
+
+
+def test_near_far_default_min_near_and_cpu_inputs(rm, dev):
+    o, d = _rays(100, 2)
+    aabb = torch.tensor([-2, -2, -2, 2, 2, 2], dtype=torch.float32, device=dev)
+    n1, f1 = rm.near_far_from_aabb(torch.from_numpy(o), torch.from_numpy(d), aabb)  # CPU rays are moved to the device
+    nr, fr = O.near_far_from_aabb(o, d, aabb.cpu().numpy(), 0.2)
+    assert n1.is_cuda and np.array_equal(nr, n1.cpu().numpy()) and np.array_equal(fr, f1.cpu().numpy())
+
+
+def test_sph_from_ray(rm, dev):
+    o, d = _rays(2048, 3)
+    ref = O.sph_from_ray(o, d, 3.0)
+    got = rm.sph_from_ray(_t(o, dev), _t(d, dev), 3.0).cpu().numpy()
+    np.testing.assert_allclose(got, ref, atol=2e-6, rtol=0)  # atan2f / sqrtf: device libm vs glibc
+
+
+def test_morton_roundtrip_and_parity(rm, dev):
+    rng = np.random.default_rng(4)
+    c = rng.integers(0, 1024, size=(100000, 3)).astype(np.int32)
+    ref = O.morton3D(c)
+    got = rm.morton3D(_t(c, dev))
+    assert np.array_equal(ref, got.cpu().numpy())
+    back = rm.morton3D_invert(got)
+    assert np.array_equal(back.cpu().numpy(), c)
+    assert np.array_equal(O.morton3D_invert(ref), c)
+
+
+def test_morton_full_128_cube_is_a_permutation(rm, dev):
+    idx = torch.arange(128, device=dev, dtype=torch.int32)
+    c = torch.stack(torch.meshgrid(idx, idx, idx, indexing="ij"), -1).reshape(-1, 3)
+    m = rm.morton3D(c).long()
+    assert torch.equal(torch.sort(m).values, torch.arange(128 ** 3, device=dev))
+
+
+def test_packbits(rm, dev, scene):
+    grid = scene["grid"]
+    got = rm.packbits(_t(grid, dev), 0.5).cpu().numpy()
+    assert np.array_equal(got, scene["bits"])
+    assert np.array_equal(got, np.packbits(grid.reshape(-1) > 0.5, bitorder="little"))
+    rng = np.random.default_rng(5)
+    g2 = rng.standard_normal((2, 128 ** 3)).astype(np.float32)
+    assert np.array_equal(rm.packbits(_t(g2, dev), 0.01).cpu().numpy(), O.packbits(g2, 0.01))
+
+
+@pytest.mark.parametrize("n,max_steps,dt_gamma,perturb_seed", [(4096, 1024, 0.0, None), (1000, 256, 1.0 / 128, 7), (1, 64, 0.0, None)])
+def test_march_rays_train(rm, dev, scene, n, max_steps, dt_gamma, perturb_seed):
+    o, d = _rays(n, 6, "lidar" if n == 1000 else "cam")
+    aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
+    nears, fars = O.near_far_from_aabb(o, d, aabb, 0.02)
+    noises = np.zeros(n, np.float32) if perturb_seed is None else np.random.default_rng(perturb_seed).random(n).astype(np.float32)
+    M = n * max_steps
+    xr, dr, lr, rr, cr = O.march_rays_train(o, d, scene["bits"], 2.0, dt_gamma, max_steps, 2, 128, M, nears, fars, noises)
+    # drive the C ABI directly so that the same noises are used
+    from nvsf import _hip
+    T = lambda a: _t(a, dev)
+    to, td, tb, tn, tf, tz = T(o), T(d), T(scene["bits"]), T(nears), T(fars), T(noises)
+    xyzs = torch.zeros(M, 3, device=dev); dirs = torch.zeros(M, 3, device=dev); deltas = torch.zeros(M, 2, device=dev)
+    rays = torch.empty(n, 3, dtype=torch.int32, device=dev); counter = torch.zeros(2, dtype=torch.int32, device=dev)
+    _hip.call("nvsf_march_rays_train", _hip.ptr(to), _hip.ptr(td), _hip.ptr(tb), 2.0, float(dt_gamma), max_steps, n, 2, 128, M,
+              _hip.ptr(tn), _hip.ptr(tf), _hip.ptr(xyzs), _hip.ptr(dirs), _hip.ptr(deltas), _hip.ptr(rays), _hip.ptr(counter), _hip.ptr(tz))
+    assert np.array_equal(counter.cpu().numpy(), cr)
+    assert np.array_equal(rays.cpu().numpy(), rr)
+    m = int(cr[0])
+    assert m > 0 or n == 1
+    assert np.array_equal(xyzs.cpu().numpy()[:m], xr[:m])
+    assert np.array_equal(dirs.cpu().numpy()[:m], dr[:m])
+    assert np.array_equal(deltas.cpu().numpy()[:m], lr[:m])
+    assert not xyzs[m:].any()
+
+
+def test_march_rays_train_wrapper_semantics(rm, dev, scene):
+    """Python-level rules of raymarching.py:225-284: aligned slicing, mean_count overflow drops rays."""
+    n = 512
+    o, d = _rays(n, 8)
+    aabb = torch.tensor([-2, -2, -2, 2, 2, 2], dtype=torch.float32, device=dev)
+    to, td, tb = _t(o, dev), _t(d, dev), _t(scene["bits"], dev)
+    nears, fars = rm.near_far_from_aabb(to, td, aabb, 0.02)
+    counter = torch.zeros(2, dtype=torch.int32, device=dev)
+    xyzs, dirs, deltas, rays = rm.march_rays_train(to, td, 2.0, tb, 2, 128, nears, fars, counter, -1, False, 128, True, 0, 256)
+    total = int(counter[0])
+    assert int(counter[1]) == n and xyzs.shape[0] % 128 == 0 and xyzs.shape[0] >= total and xyzs.shape[0] - total <= 128
+    assert int(rays[:, 2].sum()) == total
+    assert torch.equal(rays[:, 1].long(), torch.cumsum(rays[:, 2].long(), 0) - rays[:, 2].long())  # ray-order prefix sums
+    # under-estimated mean_count: rays past the budget are recorded but emit nothing, composite zeroes them
+    small = max(total // 2, 1)
+    counter.zero_()
+    x2, d2, l2, r2 = rm.march_rays_train(to, td, 2.0, tb, 2, 128, nears, fars, counter, small, False, 128, False, 0, 256)
+    M2 = x2.shape[0]
+    assert M2 == small + (128 - small % 128)
+    over = (r2[:, 1] + r2[:, 2]) > M2
+    assert over.any()
+    sig = torch.rand(M2, device=dev); rgb = torch.rand(M2, 3, device=dev)
+    ws, dp, img = rm.composite_rays_train(sig, rgb, l2, r2)
+    assert not ws[over].any() and not img[over].any() and not dp[over].any()
+
+
+def _packed_inputs(scene, n=2048, max_steps=512, seed=9):
+    o, d = _rays(n, seed)
+    aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
+    nears, fars = O.near_far_from_aabb(o, d, aabb, 0.02)
+    M = n * max_steps
+    xr, dr, lr, rr, cr = O.march_rays_train(o, d, scene["bits"], 2.0, 0.0, max_steps, 2, 128, M, nears, fars, np.zeros(n, np.float32))
+    m = int(cr[0])
+    rng = np.random.default_rng(seed + 1)
+    sig = (rng.random(m).astype(np.float32) * 60.0)
+    sig[rng.random(m) < 0.3] = 0.0
+    rgb = rng.random((m, 3)).astype(np.float32)
+    return sig, rgb, lr[:m].copy(), rr
+
+
+@pytest.mark.parametrize("T_thresh", [1e-4, 0.0, 0.5])
+def test_composite_rays_train_forward(rm, dev, scene, T_thresh):
+    sig, rgb, dl, rays = _packed_inputs(scene)
+    wr, dr, ir = O.composite_rays_train_forward(sig, rgb, dl, rays, T_thresh)
+    wg, dg, ig = rm.composite_rays_train(_t(sig, dev), _t(rgb, dev), _t(dl, dev), _t(rays, dev), T_thresh)
+    np.testing.assert_allclose(wg.cpu().numpy(), wr, atol=1e-5, rtol=0)
+    np.testing.assert_allclose(dg.cpu().numpy(), dr, atol=1e-5, rtol=0)
+    np.testing.assert_allclose(ig.cpu().numpy(), ir, atol=1e-5, rtol=0)
+
+
+def test_composite_rays_train_backward(rm, dev, scene):
+    sig, rgb, dl, rays = _packed_inputs(scene, n=1024, seed=11)
+    T_thresh = 1e-4
+    ws, dp, img = O.composite_rays_train_forward(sig, rgb, dl, rays, T_thresh)
+    rng = np.random.default_rng(12)
+    g_ws, g_img = rng.standard_normal(ws.shape).astype(np.float32), rng.standard_normal(img.shape).astype(np.float32)
+    gs_r, gc_r = O.composite_rays_train_backward(g_ws, g_img, sig, rgb, dl, rays, ws, img, T_thresh)
+    ts, tc = _t(sig, dev).requires_grad_(), _t(rgb, dev).requires_grad_()
+    wg, dg, ig = rm.composite_rays_train(ts, tc, _t(dl, dev), _t(rays, dev), T_thresh)
+    (wg * _t(g_ws, dev)).sum().add((ig * _t(g_img, dev)).sum()).add(dg.sum() * 3.0).backward()  # depth grad must be ignored
+    np.testing.assert_allclose(ts.grad.cpu().numpy(), gs_r, atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(tc.grad.cpu().numpy(), gc_r, atol=1e-5, rtol=1e-4)
+
+
+def test_inference_march_and_composite_loop(rm, dev, scene):
+    """The n_alive loop of the reference's docstrings (raymarching.py:389-409, 480-493), against the oracle."""
+    n, n_step, max_steps = 1500, 4, 256
+    o, d = _rays(n, 13)
+    aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
+    nears, fars = O.near_far_from_aabb(o, d, aabb, 0.02)
+    rng = np.random.default_rng(14)
+    T = lambda a: _t(a, dev)
+    to, td, tb, tn, tf = T(o), T(d), T(scene["bits"]), T(nears), T(fars)
+    alive_r = np.arange(n, dtype=np.int32); t_r = nears.copy()
+    ws_r, dp_r, img_r = np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros((n, 3), np.float32)
+    alive_g, t_g = T(alive_r), T(t_r)
+    ws_g, dp_g, img_g = torch.zeros(n, device=dev), torch.zeros(n, device=dev), torch.zeros(n, 3, device=dev)
+    for it in range(6):
+        n_alive = len(alive_r)
+        if n_alive == 0:
+            break
+        xr, dr, lr = O.march_rays(n_alive, n_step, alive_r, t_r, o, d, 2.0, 0.0, max_steps, 2, 128, scene["bits"], nears, fars,
+                                  np.zeros(n_alive, np.float32))
+        xg, dg, lg = rm.march_rays(n_alive, n_step, alive_g, t_g, to, td, 2.0, tb, 2, 128, tn, tf, -1, False, 0, max_steps)
+        assert np.array_equal(xg.cpu().numpy(), xr) and np.array_equal(lg.cpu().numpy(), lr) and np.array_equal(dg.cpu().numpy(), dr)
+        sig = rng.random(n_alive * n_step).astype(np.float32) * 80.0
+        rgb = rng.random((n_alive * n_step, 3)).astype(np.float32)
+        alive_r, t_r, ws_r, dp_r, img_r = O.composite_rays(n_alive, n_step, 1e-2, alive_r, t_r, sig, rgb, lr, ws_r, dp_r, img_r)
+        rm.composite_rays(n_alive, n_step, alive_g, t_g, T(sig), T(rgb), lg, ws_g, dp_g, img_g, 1e-2)
+        assert np.array_equal(alive_g.cpu().numpy(), alive_r)
+        np.testing.assert_allclose(ws_g.cpu().numpy(), ws_r, atol=1e-5, rtol=0)
+        np.testing.assert_allclose(img_g.cpu().numpy(), img_r, atol=1e-5, rtol=0)
+        np.testing.assert_allclose(dp_g.cpu().numpy(), dp_r, atol=1e-5, rtol=0)
+        np.testing.assert_allclose(t_g.cpu().numpy(), t_r, atol=0, rtol=0)
+        keep = alive_r >= 0
+        alive_r = alive_r[keep]
+        alive_g = alive_g[alive_g >= 0].contiguous()
+
+
+def test_empty_inputs(rm, dev):
+    z3 = torch.zeros(0, 3, device=dev)
+    aabb = torch.tensor([-1, -1, -1, 1, 1, 1], dtype=torch.float32, device=dev)
+    n, f = rm.near_far_from_aabb(z3, z3, aabb, 0.1)
+    assert n.shape == (0,) and f.shape == (0,)
+    assert rm.morton3D(torch.zeros(0, 3, dtype=torch.int32, device=dev)).shape == (0,)
