@@ -166,9 +166,10 @@ int nvsf_sh4_encode(const float* dirs01, uint32_t M, void* out_f16, uint32_t out
 /* ref: tcnn.Network("FullyFusedMLP") network_dynamic.py:125-135,138-161,180-189.
  * x [M, x_stride] fp32 (x_is_f16 == 0) or fp16; weights fp16 = W0 [hidden][in_cols] ++ (n_hidden-1) x
  * [hidden][hidden] ++ W_out [out_cols][hidden]; columns n_in..in_cols-1 of the input read as 1.0.
- * Supported: hidden = 64, out_cols = 16, n_hidden in 1..3, in_cols in {16,...,128}. out fp16 [M, out_stride]. */
+ * Supported: hidden = 64, out_cols = 16, n_hidden in 1..3, in_cols in {16,...,128}.
+ * out fp32 [M, out_stride >= 16] (16-byte aligned rows): the output layer is NOT rounded to fp16. */
 int nvsf_mlp_fwd(const void* x, int x_is_f16, uint32_t M, uint32_t n_in, uint32_t x_stride, const void* weights_f16,
-                 uint32_t in_cols, uint32_t hidden, uint32_t n_hidden, uint32_t out_cols, void* out_f16,
+                 uint32_t in_cols, uint32_t hidden, uint32_t n_hidden, uint32_t out_cols, float* out_f32,
                  uint32_t out_stride, nvsf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------

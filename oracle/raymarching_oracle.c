@@ -222,13 +222,12 @@ ORACLE_API void oracle_march_rays_train(const float *rays_o, const float *rays_d
         /* reservation (:445-454); sequential execution == ray-index order */
         const uint32_t point_index = (uint32_t)counter[0];
         counter[0] += (int32_t)num_steps;
-        const uint32_t ray_index = (uint32_t)counter[1];
+        /* the reference's slot is atomicAdd(counter+1, 1): with a zeroed counter and sequential execution that
+         * is n; with a carried-over counter it indexes past the [N,3] buffer.  Canonical slot here: n. */
         counter[1] += 1;
-        if (ray_index < N) {
-            rays[3 * (size_t)ray_index + 0] = (int32_t)n;
-            rays[3 * (size_t)ray_index + 1] = (int32_t)point_index;
-            rays[3 * (size_t)ray_index + 2] = (int32_t)num_steps;
-        }
+        rays[3 * (size_t)n + 0] = (int32_t)n;
+        rays[3 * (size_t)n + 1] = (int32_t)point_index;
+        rays[3 * (size_t)n + 2] = (int32_t)num_steps;
         if (num_steps == 0) continue;               /* :456 */
         if (point_index + num_steps > M) continue;  /* :457 */
 

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kBlock) void k_density_uniform(RayBatch rb, const _
             ov[0] = (_Float16)o[0]; ov[1] = (_Float16)o[1]; ov[2] = (_Float16)o[2]; ov[3] = (_Float16)o[3];
             if (g == 3) {
                 z_vals[s] = z;
-                sigmas[s] = expf((float)ov[3]);  // trunc_exp forward (activation.py:9-11) on the fp16 network output
+                sigmas[s] = expf(o[3]);  // trunc_exp forward (activation.py:9-11) on the fp32 density logit
                 ov[3] = (_Float16)1.0f;          // geo row = (h1 .. h15, 1.0): 15 features + the ones-padding the heads expect
             }
             *reinterpret_cast<half4_t*>(geo + s * 16 + 4 * g) = ov;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kBlock) void k_density_uniform(RayBatch rb, const _
 //   LIDAR = false : colour net  [SH16(d) | geo15 | 1] (32)  -> 64 -> 64 -> 3 (padded 16)
 //   LIDAR = true  : raydrop net and intensity net  [Freq72(d) | geo15 | 1 x 9] (96) -> 64 -> 64 -> 1;
 //                   image channels = (raydrop, intensity)  (network_dynamic.py:317)
-// rgb = fp16(sigmoid(fp16 logits)); samples with weight <= w_thresh contribute 0 (renderer_dynamic.py:202,
+// rgb = sigmoid(fp32 logits); samples with weight <= w_thresh contribute 0 (renderer_dynamic.py:202,
 // network_dynamic.py:297-307, 325-330); image = sum_i w_i rgb_i (+ (1 - ws) * bg for the camera, :236-237).
 template <int IN_STEPS>
 struct HeadW {
@@ -140,10 +140,8 @@ struct HeadW {
     }
 };
 
-__device__ __forceinline__ float sigmoid_f16(float logit_f32) {
-    const float x = (float)(_Float16)logit_f32;
-    const float s = 1.0f / (1.0f + expf(-x));
-    return (float)(_Float16)s;
+__device__ __forceinline__ float sigmoid_f16(float logit_f32) {  // fp32 logit -> fp32 sigmoid (no fp16 rounding of outputs)
+    return 1.0f / (1.0f + expf(-logit_f32));
 }
 
 template <bool LIDAR>

@@ -41,7 +41,7 @@ __device__ __forceinline__ half8_t load_x_frag(const void* __restrict__ x, size_
 template <int IN_STEPS, int N_HIDDEN, bool X_F16>
 __global__ __launch_bounds__(kBlock) void k_mlp_fwd(const void* __restrict__ x, uint32_t M, uint32_t n_in, uint32_t x_stride,
                                                     const _Float16* __restrict__ weights, uint32_t in_cols,
-                                                    _Float16* __restrict__ out, uint32_t out_stride, int vec_ok) {
+                                                    float* __restrict__ out, uint32_t out_stride, int vec_ok) {
     const int lane = lane_id();
     const int g = lane >> 4, sl = lane & 15;
     // ---- weights -> registers
@@ -85,25 +85,21 @@ __global__ __launch_bounds__(kBlock) void k_mlp_fwd(const void* __restrict__ x, 
             pack_hidden(acc, h);
         }
         const float4_t o = wout.apply(h);
-        if (m < M) {
-            half4_t ov;
-            ov[0] = (_Float16)o[0]; ov[1] = (_Float16)o[1]; ov[2] = (_Float16)o[2]; ov[3] = (_Float16)o[3];
-            *reinterpret_cast<half4_t*>(out + (size_t)m * out_stride + 4 * g) = ov;
-        }
+        if (m < M) *reinterpret_cast<float4_t*>(out + (size_t)m * out_stride + 4 * g) = o;  // fp32 logits (not rounded to fp16)
     }
 }
 }  // namespace
 
 #define REQUIRE(cond) do { if (!(cond)) return NVSF_ERR_INVALID_ARG; } while (0)
 
-// weights: fp16 [64][in_cols] ++ (n_hidden-1) x [64][64] ++ [16][64]; out fp16 [M, out_stride>=16]
+// weights: fp16 [64][in_cols] ++ (n_hidden-1) x [64][64] ++ [16][64]; out fp32 [M, out_stride>=16]
 NVSF_API int nvsf_mlp_fwd(const void* x, int x_is_f16, uint32_t M, uint32_t n_in, uint32_t x_stride, const void* weights_f16,
-                          uint32_t in_cols, uint32_t hidden, uint32_t n_hidden, uint32_t out_cols, void* out_f16,
+                          uint32_t in_cols, uint32_t hidden, uint32_t n_hidden, uint32_t out_cols, float* out_f32,
                           uint32_t out_stride, hipStream_t stream) {
     if (M == 0) return NVSF_OK;
-    REQUIRE(x && weights_f16 && out_f16);
+    REQUIRE(x && weights_f16 && out_f32);
     REQUIRE(n_in >= 1 && n_in <= in_cols && in_cols % 16 == 0 && x_stride >= n_in);
-    REQUIRE(out_stride >= 16 && out_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(out_f16) & 7u) == 0);
+    REQUIRE(out_stride >= 16 && out_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(out_f32) & 15u) == 0);
     REQUIRE((reinterpret_cast<uintptr_t>(weights_f16) & 15u) == 0);
     if (hidden != (uint32_t)kHidden || out_cols != 16 || n_hidden < 1 || n_hidden > 3 || in_cols > 128) return NVSF_ERR_UNSUPPORTED;
     const int in_steps = (int)((in_cols + 31) / 32);
@@ -112,7 +108,7 @@ NVSF_API int nvsf_mlp_fwd(const void* x, int x_is_f16, uint32_t M, uint32_t n_in
     const uint32_t n_tiles = (M + 15) / 16;
     const uint32_t blocks = n_tiles / 4 + 1 < 2048u ? n_tiles / 4 + 1 : 2048u;
     const _Float16* w = reinterpret_cast<const _Float16*>(weights_f16);
-    _Float16* o = reinterpret_cast<_Float16*>(out_f16);
+    float* o = out_f32;
 #define LAUNCH(S, H, XF)                                                                                                   \
     hipLaunchKernelGGL((k_mlp_fwd<S, H, XF>), dim3(blocks), dim3(kBlock), 0, stream, x, M, n_in, x_stride, w, in_cols, o, \
                        out_stride, vec_ok)

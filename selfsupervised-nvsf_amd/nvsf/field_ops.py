@@ -133,12 +133,12 @@ class MlpSpec:
 
 
 def mlp_forward(x, weights_f16, spec):
-    """x [M, n_in] (fp32 or fp16) -> fp16 [M, out_cols]."""
+    """x [M, n_in] (fp32 or fp16) -> fp32 [M, out_cols] (fp16 operands, fp32 accumulate, output not rounded)."""
     if x.dtype not in (torch.float16, torch.float32):
         x = x.float()
     x = x.contiguous()
     M = x.shape[0]
-    out = torch.empty(M, spec.out_cols, dtype=torch.float16, device=x.device)
+    out = torch.empty(M, spec.out_cols, dtype=torch.float32, device=x.device)
     _hip.call("nvsf_mlp_fwd", _hip.ptr(x), 1 if x.dtype == torch.float16 else 0, M, spec.n_in, x.stride(0), _hip.ptr(weights_f16),
               spec.in_cols, spec.hidden, spec.n_hidden, spec.out_cols, _hip.ptr(out), out.stride(0))
     return out

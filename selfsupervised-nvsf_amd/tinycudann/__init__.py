@@ -3,8 +3,8 @@
 The reference builds its encoders and MLPs as `tcnn.Encoding(n_input_dims, encoding_config)` and
 `tcnn.Network(n_input_dims, n_output_dims, network_config)` (hash_field.py:47-57,109-119;
 flow_field.py:70-80; network_dynamic.py:108-114,125-135,138-161,165-170,180-189).  This package offers
-the same constructors, `.n_input_dims`, `.n_output_dims`, a flat fp32 `.params` nn.Parameter and an
-fp16-returning `forward(x)`, implemented on the HIP kernels of libnvsf_hip.so -- so the reference's model
+the same constructors, `.n_input_dims`, `.n_output_dims`, a flat fp32 `.params` nn.Parameter and
+`forward(x)` (encodings return fp16 features, networks return their fp32 logits -- see DESIGN.md 4.3), implemented on the HIP kernels of libnvsf_hip.so -- so the reference's model
 files construct and run against it unchanged.  Numerics follow DESIGN.md section 4 (the published
 tiny-cuda-nn algorithm; that library is an unpinned third-party dependency of the reference).
 

@@ -176,7 +176,7 @@ def mlp_fwd(x, weights_f16, n_in, in_cols, n_hidden, hidden=64, out_cols=16, wan
     if not is_f16:
         xx = _f32(xx)
     M = xx.shape[0]
-    out = np.empty((M, out_cols), np.float16)
+    out = np.empty((M, out_cols), np.float32)  # fp32 logits (the output layer is not rounded to fp16)
     hid = np.empty((M, n_hidden, hidden), np.float16) if want_hidden else None
     w = np.ascontiguousarray(weights_f16, dtype=np.float16)
     _lib("field").oracle_mlp_fwd(_p(xx), ctypes.c_int(1 if is_f16 else 0), U(M), U(n_in), U(xx.shape[1]), _p(w), U(in_cols), U(hidden),
@@ -212,10 +212,9 @@ def composite_uniform_image(weights, rgbs, weights_sum, bg):
 
 
 # ---- composition: the static-field uniform render (what NeRFNetworkStatic.render computes) --------
-def sigmoid_f16(h16):
-    """torch.sigmoid on an fp16 tensor: evaluate in fp32, round to fp16."""
-    x = h16.astype(np.float32)
-    return (1.0 / (1.0 + np.exp(-x))).astype(np.float16)
+def sigmoid_f32(h):
+    x = h.astype(np.float32)
+    return (np.float32(1.0) / (np.float32(1.0) + np.exp(-x))).astype(np.float32)
 
 
 def render_static(rays_o, rays_d, nears, fars, lin, noise, bound, table_f16, spec, w_sigma, lidar, w_head_a, w_head_b, bg,
@@ -227,8 +226,8 @@ def render_static(rays_o, rays_d, nears, fars, lin, noise, bound, table_f16, spe
     x01 = ((xyz.reshape(-1, 3) + np.float32(bound)) * np.float32(1.0 / (2.0 * bound))).astype(np.float32)
     feat = hashgrid_fwd(x01, (0, 1, 2), table_f16, spec)
     h = mlp_fwd(feat, w_sigma, 32, 32, 1)
-    sigmas = np.exp(h[:, 0].astype(np.float32)).reshape(N, T)
-    geo = h[:, 1:16]
+    sigmas = np.exp(h[:, 0]).astype(np.float32).reshape(N, T)
+    geo = h[:, 1:16].astype(np.float16)  # geometry features enter the heads as fp16 operands
     w, ws, dp = composite_uniform_weights(sigmas, z, nears, fars, k_scale)
     mask = (w > np.float32(w_thresh)).reshape(-1)
     d01 = ((_f32(rays_d) + 1.0) / 2.0).astype(np.float32)
@@ -244,7 +243,7 @@ def render_static(rays_o, rays_d, nears, fars, lin, noise, bound, table_f16, spe
             hh = np.concatenate([ra, it], axis=1)
         else:
             hh = mlp_fwd(logits, w_head_a, 31, 32, 2)[:, :3]
-        rgbs[mask] = sigmoid_f16(hh).astype(np.float32)
+        rgbs[mask] = sigmoid_f32(hh)
     img = composite_uniform_image(w, rgbs.reshape(N, T, C), ws, None if lidar else bg)
     return dict(z_vals=z, sigmas=sigmas, geo=geo.reshape(N, T, 15), weights=w, weights_sum=ws, depth=dp, image=img,
                 rgbs=rgbs.reshape(N, T, C))

@@ -1,0 +1,111 @@
+"""CPU tests of the drop-in boundary (no GPU, no compute calls): the C-ABI library builds for gfx950, loads, and
+exports exactly the symbols include/nvsf_hip.h declares; the Python binding table matches the header; the
+reference-shaped Python surface imports; the product path never imports the oracle and fails loudly without a
+device."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "nvsf_hip.h")
+PKG = os.path.join(ROOT, "selfsupervised-nvsf_amd")
+
+
+def _declared():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    decls = {}
+    for m in re.finditer(r"\b(?:int|const char\*)\s+(nvsf_[A-Za-z0-9_]+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+        args = [a.strip() for a in m.group(2).replace("\n", " ").split(",")]
+        decls[m.group(1)] = [] if args == ["void"] else args
+    return decls
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    decls = _declared()
+    assert len(decls) >= 23
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(PKG, "lib", "libnvsf_hip.so")], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (nvsf_[A-Za-z0-9_]+)", out))
+    assert set(decls) == exported, (set(decls) ^ exported)
+
+
+def test_python_binding_table_matches_header(hip_lib):
+    from nvsf import _hip
+    decls = _declared()
+    assert set(_hip.SIGNATURES) == set(decls) - {"nvsf_version"}
+    for name, argtypes in _hip.SIGNATURES.items():
+        c_args = decls[name]
+        assert c_args[-1].startswith("nvsf_stream_t"), name
+        assert len(argtypes) == len(c_args) - 1, name
+        for ct, decl in zip(argtypes, c_args):
+            if "*" in decl:
+                assert ct is ctypes.c_void_p, (name, decl)
+            elif decl.startswith("uint32_t"):
+                assert ct is ctypes.c_uint32, (name, decl)
+            elif decl.startswith("float"):
+                assert ct is ctypes.c_float, (name, decl)
+            elif decl.startswith("int"):
+                assert ct is ctypes.c_int, (name, decl)
+            else:
+                raise AssertionError((name, decl))
+    assert _hip.version().endswith("gfx950")
+
+
+def test_code_object_targets_gfx950_only(hip_lib):
+    lib = os.path.join(PKG, "lib", "libnvsf_hip.so")
+    data = open(lib, "rb").read()
+    assert b"amdgcn-amd-amdhsa--gfx950" in data
+    for other in (b"gfx90a", b"gfx942", b"sm_80", b"nvptx"):
+        assert other not in data
+
+
+def test_reference_shaped_surface_imports():
+    from nvsf.nerf.raymarching import raymarching
+    for name in ("near_far_from_aabb", "sph_from_ray", "morton3D", "morton3D_invert", "packbits", "march_rays_train",
+                 "composite_rays_train", "march_rays", "composite_rays"):  # raymarching.py:48,82,108,133,164,289,360,460,510
+        assert callable(getattr(raymarching, name))
+    import tinycudann as tcnn
+    enc = tcnn.Encoding(n_input_dims=3, encoding_config={"otype": "HashGrid", "n_levels": 16, "n_features_per_level": 2,
+                                                         "log2_hashmap_size": 19, "base_resolution": 16, "per_level_scale": 1.3819})
+    assert enc.n_output_dims == 32 and enc.params.dtype == torch.float32 and enc.params.dim() == 1
+    assert abs(enc.params.numel() - 12.2e6) < 0.3e6  # 12.2 M parameters at ngp defaults
+    net = tcnn.Network(n_input_dims=87, n_output_dims=1, network_config={"otype": "FullyFusedMLP", "activation": "ReLU",
+                                                                          "output_activation": "None", "n_neurons": 64, "n_hidden_layers": 2})
+    assert net.params.numel() == 64 * 96 + 64 * 64 + 16 * 64
+    assert tcnn.Encoding(3, {"otype": "Frequency", "degree": 12}).n_output_dims == 72
+    assert tcnn.Encoding(3, {"otype": "SphericalHarmonics", "degree": 4}).n_output_dims == 16
+    from nvsf.nerf.models.network_static import NeRFNetworkStatic
+    m = NeRFNetworkStatic(bound=2)
+    assert m.cascade == 2 and m.grid_size == 128 and len(m.get_params(1e-2)) == 6
+    sd = m.state_dict()
+    assert "hash_encoder_lidar.params" in sd and "sigma_net.params" in sd and "aabb_train" in sd
+
+
+def test_no_cpu_fallback_and_no_oracle_in_product():
+    from nvsf.nerf.raymarching import raymarching
+    from nvsf import _hip
+    if not torch.cuda.is_available():
+        with pytest.raises((RuntimeError, AssertionError)):  # moving to the device fails loudly; nothing is computed on CPU
+            raymarching.near_far_from_aabb(torch.zeros(4, 3), torch.ones(4, 3), torch.tensor([-1., -1, -1, 1, 1, 1]), 0.1)
+        with pytest.raises(_hip.NvsfHipError):
+            _hip.ptr(torch.zeros(3))
+    for dirpath, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle_lib" not in text and "liboracle" not in text and "import oracle" not in text, os.path.join(dirpath, f)
+
+
+def test_grid_spec_matches_published_level_rules():
+    from nvsf.field_ops import GridSpec
+    import numpy as np
+    s = GridSpec(3, 8, 4, 19, 512, float(np.exp2(np.log2(32768 / 512) / 7)))  # reference default static grid (hash_field.py:107-119)
+    assert s.res[0] == 512 and s.res[-1] == 32768 and all(r == 2 ** 19 for r in np.diff(s.offsets)) and s.n_params == 8 * 2 ** 19 * 4
+    t = GridSpec(2, 8, 4, 15, 512, float(np.exp2(np.log2(32768 / 512) / 7)))   # time-slice grid (hash_field.py:47-57)
+    assert t.n_params == 8 * 2 ** 15 * 4 and t.n_output_dims == 32
+    f = GridSpec(3, 16, 8, 18, 32, float(np.exp2(np.log2(8192 / 32) / 15)))    # flow grid (flow_field.py:68-84)
+    assert f.n_output_dims == 128 and f.res[0] == 32 and f.res[-1] == 8192 and abs(f.n_params - 30.5e6) < 1.5e6

@@ -27,7 +27,7 @@ def _model(dev, table_std=None, seed=0):
         with torch.no_grad():
             for enc in (m.hash_encoder_lidar, m.hash_encoder_camera):
                 enc.params.copy_(torch.randn(enc.params.shape, generator=g) * table_std)
-            m.sigma_net.params.mul_(4.0)
+            m.sigma_net.params.mul_(2.0)
     return m.to(dev).eval()
 
 
@@ -48,7 +48,7 @@ def _oracle(m, o, d, lidar, T, noise=None, bg=(1.0, 1.0, 1.0)):
 
 
 @pytest.mark.parametrize("lidar", [True, False])
-@pytest.mark.parametrize("table_std", [None, 0.5])
+@pytest.mark.parametrize("table_std", [None, 0.1])
 def test_fused_render_matches_oracle(dev, lidar, table_std):
     from nvsf import synthetic as S
     m = _model(dev, table_std)
@@ -71,7 +71,7 @@ def test_fused_density_per_sample(dev):
     """sigma / geo of the fused density kernel, sample by sample (fp16 logits: identical except for rare
     1-ulp flips from the MFMA summation order)."""
     from nvsf import field_ops as ops, synthetic as S
-    m = _model(dev, 0.5)
+    m = _model(dev, 0.1)
     rng = np.random.default_rng(5)
     N, T = 64, 80
     o, d = S.lidar_rays(N, rng)
@@ -86,15 +86,16 @@ def test_fused_density_per_sample(dev):
     assert np.all(geo[..., 15] == 1.0)
     g_ref = ref["geo"].astype(np.float32)
     np.testing.assert_allclose(geo[..., :15].astype(np.float32), g_ref, atol=2e-3 * np.abs(g_ref).max(), rtol=0)
-    assert (geo[..., :15] == ref["geo"]).mean() > 0.95
-    np.testing.assert_allclose(sig.cpu().numpy(), ref["sigmas"], rtol=4e-3, atol=0)
-    assert (sig.cpu().numpy() == ref["sigmas"]).mean() > 0.9
+    assert (geo[..., :15] == ref["geo"]).mean() > 0.99  # fp16 features: identical except rare 1-ulp rounding flips
+    s, sr = sig.cpu().numpy(), ref["sigmas"]
+    np.testing.assert_allclose(s, sr, rtol=2e-3, atol=0)
+    assert (np.abs(s / sr - 1) < 1e-5).mean() > 0.99  # fp32 logit + expf: ulp-level agreement for almost every sample
 
 
 @pytest.mark.parametrize("lidar", [True, False])
 def test_operator_path_equals_fused_path(dev, lidar):
     from nvsf import synthetic as S
-    m = _model(dev, 0.5)
+    m = _model(dev, 0.1)
     rng = np.random.default_rng(7)
     N, T = 150, 64
     o, d = (S.lidar_rays if lidar else S.camera_rays)(N, rng)
@@ -115,7 +116,7 @@ def test_operator_path_equals_fused_path(dev, lidar):
 
 def test_perturb_and_staged_and_bg(dev):
     from nvsf import synthetic as S
-    m = _model(dev, 0.5)
+    m = _model(dev, 0.1)
     rng = np.random.default_rng(9)
     N, T = 300, 32
     o, d = S.camera_rays(N, rng)
