@@ -17,6 +17,7 @@
 #include "hashgrid_device.h"
 #include "mlp_device.h"
 #include "encodings_device.h"
+#include <stdlib.h>
 
 namespace {
 constexpr int kBlock = 256;
@@ -104,34 +105,262 @@ __global__ __launch_bounds__(kBlock) void k_density_uniform(RayBatch rb, const _
 }
 
 // ------------------------------------------------------------------------------------------------
+// Density kernel, second formulation (same arithmetic, same results bit for bit in the encoding):
+//   * lane group g takes levels {g, 4+g, 8+g, ...} (interleaved) instead of a contiguous block, so that in
+//     unrolled step q all four lane groups work on levels 4q..4q+3: "all dense" / "all hashed" becomes a
+//     wave-uniform branch (levels are dense up to `first_hashed` and hashed from there on) and only one
+//     index formula is evaluated per step.  The feature order seen by the MLP changes, which is undone by
+//     permuting the columns of W0 when its fragment is fetched;
+//   * per-lane level constants are read once from an LDS copy of the level table and stay in registers;
+//   * gathers are buffer loads with 32-bit byte offsets (no 64-bit address arithmetic per corner);
+//   * the corner hashes share their y/z partial terms; the dense index wraps by a conditional subtract
+//     (index < 2*rows there) instead of an integer division.
+template <int F>
+struct LaneLevels {
+    static constexpr int Q = 8 / F;
+    float scale[Q];
+    uint32_t res[Q], res2[Q], boff[Q], rows[Q];
+};
+
+template <int F>
+__device__ __forceinline__ uint32_t gather_raw(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off);
+template <>
+__device__ __forceinline__ uint32_t gather_raw<2>(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b32(rsrc, byte_off, 0, 0);
+}
+
+// Per-wave constants of the v2 kernel: level table slice, permuted W0 fragment, rotated output fragment.
+template <int F>
+struct DensityCtx {
+    static constexpr int Q = 8 / F;
+    LaneLevels<F> lv;
+    half8_t w0[kHidTiles];
+    OutLayerW wout;
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t first_hashed;
+    int g;
+};
+
+// One 16-sample tile: encode (x in [0,1]^3 per lane) -> sigma MLP -> store sigma / geo / z.
+template <int F, int QG>
+__device__ __forceinline__ void density_tile(const DensityCtx<F>& cx, const float (&x)[3], float z, unsigned long long s, bool in_range,
+                                             float* __restrict__ z_vals, float* __restrict__ sigmas, _Float16* __restrict__ geo) {
+    constexpr int Q = 8 / F;
+    const LaneLevels<F>& lv = cx.lv;
+    const uint32_t first_hashed = cx.first_hashed;
+    const int g = cx.g;
+    // phase 1: cell / fraction per level, issue all 8*Q gathers
+    half8_t xf;
+#pragma unroll
+    for (int q0 = 0; q0 < Q; q0 += QG) {
+    float frac[Q][3];
+    uint32_t raw[Q][8];
+#pragma unroll
+    for (int q = q0; q < q0 + QG; ++q) {
+        uint32_t c[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float pos = fmaf(lv.scale[q], x[d], 0.5f);
+            const float fl = floorf(pos);
+            frac[q][d] = pos - fl;
+            c[d] = (uint32_t)(int32_t)fl;
+        }
+        uint32_t idx[8];
+        const bool all_dense = (uint32_t)(4 * q + 3) < first_hashed, all_hashed = (uint32_t)(4 * q) >= first_hashed;
+        if (all_dense || !all_hashed) {  // dense rows: c0 + c1*res + c2*res^2, wrapped once
+            const uint32_t b00 = c[0] + c[1] * lv.res[q] + c[2] * lv.res2[q];
+            const uint32_t b10 = b00 + lv.res[q], b01 = b00 + lv.res2[q], b11 = b10 + lv.res2[q];
+            const uint32_t base[4] = {b00, b10, b01, b11};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                uint32_t v = base[k >> 1] + (uint32_t)(k & 1);
+                v = v >= lv.rows[q] ? v - lv.rows[q] : v;
+                idx[k] = v;
+            }
+        }
+        if (all_hashed || !all_dense) {
+            const uint32_t hy0 = c[1] * 2654435761u, hy1 = hy0 + 2654435761u;
+            const uint32_t hz0 = c[2] * 805459861u, hz1 = hz0 + 805459861u;
+            const uint32_t yz[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+            const uint32_t mask = lv.rows[q] - 1u;
+            const bool lane_hashed = (uint32_t)(4 * q + g) >= first_hashed;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t v = ((c[0] + (uint32_t)(k & 1)) ^ yz[k >> 1]) & mask;
+                idx[k] = (all_hashed || lane_hashed) ? v : idx[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) raw[q][k] = gather_raw<F>(cx.rsrc, lv.boff[q] + idx[k] * (uint32_t)(F * sizeof(_Float16)));
+    }
+    // phase 2: trilinear blend (corner order and fma chain of the specification)
+#pragma unroll
+    for (int q = q0; q < q0 + QG; ++q) {
+        const float fx = frac[q][0], fy = frac[q][1], fz = frac[q][2];
+        const float wx[2] = {1.0f - fx, fx}, wy[2] = {1.0f - fy, fy}, wz[2] = {1.0f - fz, fz};
+        float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float w = (wx[k & 1] * wy[(k >> 1) & 1]) * wz[k >> 2];
+            const h2_t v = __builtin_bit_cast(h2_t, raw[q][k]);
+            a0 = fmaf(w, (float)v[0], a0);
+            a1 = fmaf(w, (float)v[1], a1);
+        }
+        xf[q * F] = (_Float16)a0;
+        xf[q * F + 1] = (_Float16)a1;
+    }
+    }
+    float4_t acc1[kHidTiles];
+#pragma unroll
+    for (int t = 0; t < kHidTiles; ++t) {
+        const float4_t zero = {0, 0, 0, 0};
+        acc1[t] = mfma16(cx.w0[t], xf, zero);
+    }
+    half8_t h[kHidSteps];
+    pack_hidden(acc1, h);
+    const float4_t o = cx.wout.apply(h);
+    if (in_range) {
+        half4_t ov;
+        ov[0] = (_Float16)o[0]; ov[1] = (_Float16)o[1]; ov[2] = (_Float16)o[2]; ov[3] = (_Float16)o[3];
+        if (g == 3) {
+            z_vals[s] = z;
+            sigmas[s] = expf(o[3]);
+            ov[3] = (_Float16)1.0f;
+        }
+        *reinterpret_cast<half4_t*>(geo + s * 16 + 4 * g) = ov;
+    }
+}
+
+// SEG = true (T % 16 == 0): the unit of work is a ray SEGMENT owned by a whole workgroup.  The ray index is
+// block-uniform, so origin / direction / near / far are scalar loads held in SGPRs for the whole segment and the
+// per-lane 64-bit sample -> (ray, step) division disappears.  SEG = false: generic tile loop (any T).
+template <int F, bool SEG, int QG>
+__global__ __launch_bounds__(kBlock) void k_density_uniform_v2(RayBatch rb, const _Float16* __restrict__ table, uint32_t table_bytes,
+                                                               GridMeta meta, uint32_t first_hashed, uint32_t seg_tiles,
+                                                               const _Float16* __restrict__ w_sigma, float* __restrict__ z_vals,
+                                                               float* __restrict__ sigmas, _Float16* __restrict__ geo) {
+    static_assert(F == 2, "v2 is built for F = 2 (BASELINE config 2); other shapes use k_density_uniform");
+    constexpr int Q = 8 / F;
+    __shared__ float s_scale[kMaxLevels];
+    __shared__ uint32_t s_res[kMaxLevels], s_off[kMaxLevels + 1];
+    if (threadIdx.x < kMaxLevels) {
+        s_scale[threadIdx.x] = meta.scale[threadIdx.x];
+        s_res[threadIdx.x] = meta.res[threadIdx.x];
+    }
+    if (threadIdx.x <= kMaxLevels) s_off[threadIdx.x] = meta.offset[threadIdx.x];
+    __syncthreads();
+    const int lane = lane_id(), g = lane >> 4, sl = lane & 15;
+    DensityCtx<F> cx;
+    cx.g = g;
+    cx.first_hashed = first_hashed;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int l = 4 * q + g;
+        cx.lv.scale[q] = s_scale[l];
+        cx.lv.res[q] = s_res[l];
+        cx.lv.res2[q] = s_res[l] * s_res[l];
+        cx.lv.boff[q] = s_off[l] * (uint32_t)(F * sizeof(_Float16));
+        cx.lv.rows[q] = s_off[l + 1] - s_off[l];
+    }
+    // W0 fragment with permuted columns: fragment element j = q*F + f of lane group g  <-  feature (4q+g)*F + f
+#pragma unroll
+    for (int t = 0; t < kHidTiles; ++t) {
+        const _Float16* row = w_sigma + (size_t)(16 * t + sl) * 32;
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int f = 0; f < F; ++f) cx.w0[t][q * F + f] = row[(4 * q + g) * F + f];
+    }
+    cx.wout.load(w_sigma + kHidden * 32, lane, 1);
+    cx.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(table), 0, (int)table_bytes, 0x00020000);
+
+    const uint32_t wave_global = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const uint32_t wave_count = gridDim.x * kWavesPerBlock;
+    if constexpr (SEG) {
+        // unit = 16 consecutive tiles (256 samples) of one ray, walked by the 4 waves of the workgroup in lock step
+        // (wave w takes tiles 4j + w): the workgroup's gathers of one round are spatially adjacent, and a CU holds
+        // only as many rays as it holds workgroups, so the rays' cache lines survive in L1 from round to round.
+        const uint32_t tiles_per_ray = rb.T / 16;
+        const uint32_t segs_per_ray = (tiles_per_ray + seg_tiles - 1) / seg_tiles;
+        const uint32_t n_units = rb.N * segs_per_ray;
+        const uint32_t wave_in_block = threadIdx.x >> 6;
+        for (uint32_t unit = blockIdx.x; unit < n_units; unit += gridDim.x) {
+            const uint32_t n = unit / segs_per_ray;
+            const uint32_t seg = unit - n * segs_per_ray;
+            const float near = rb.nears[n], range = rb.fars[n] - near;
+            const float ox = rb.rays_o[3 * (size_t)n], oy = rb.rays_o[3 * (size_t)n + 1], oz = rb.rays_o[3 * (size_t)n + 2];
+            const float dx = rb.rays_d[3 * (size_t)n], dy = rb.rays_d[3 * (size_t)n + 1], dz = rb.rays_d[3 * (size_t)n + 2];
+            const float sample_dist = range / (float)rb.T;
+            const uint32_t t_end = min(tiles_per_ray, (seg + 1) * seg_tiles);
+            for (uint32_t tt = seg * seg_tiles + wave_in_block; tt < t_end; tt += kWavesPerBlock) {
+                const uint32_t i = tt * 16 + sl;
+                const unsigned long long s = (unsigned long long)n * rb.T + i;
+                float z = near + range * rb.lin[i];
+                if (rb.noise) z = z + (rb.noise[s] - 0.5f) * sample_dist;
+                float x[3];
+                x[0] = (fminf(fmaxf(ox + dx * z, rb.lo[0]), rb.hi[0]) + rb.bound) * rb.inv_extent;
+                x[1] = (fminf(fmaxf(oy + dy * z, rb.lo[1]), rb.hi[1]) + rb.bound) * rb.inv_extent;
+                x[2] = (fminf(fmaxf(oz + dz * z, rb.lo[2]), rb.hi[2]) + rb.bound) * rb.inv_extent;
+                density_tile<F, QG>(cx, x, z, s, true, z_vals, sigmas, geo);
+            }
+        }
+    } else {
+        const unsigned long long total = (unsigned long long)rb.N * rb.T;
+        const unsigned long long n_tiles = (total + 15) / 16;
+        for (unsigned long long tile = wave_global; tile < n_tiles; tile += wave_count) {
+            const unsigned long long s_raw = tile * 16 + sl;
+            const bool in_range = s_raw < total;
+            const unsigned long long s = in_range ? s_raw : total - 1;
+            const uint32_t n = (uint32_t)(s / rb.T), i = (uint32_t)(s - (unsigned long long)n * rb.T);
+            const float near = rb.nears[n], range = rb.fars[n] - near;
+            float z = near + range * rb.lin[i];
+            if (rb.noise) z = z + (rb.noise[s] - 0.5f) * (range / (float)rb.T);
+            float x[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float p = rb.rays_o[3 * (size_t)n + k] + rb.rays_d[3 * (size_t)n + k] * z;
+                p = fminf(fmaxf(p, rb.lo[k]), rb.hi[k]);
+                x[k] = (p + rb.bound) * rb.inv_extent;
+            }
+            density_tile<F, QG>(cx, x, z, s, in_range, z_vals, sigmas, geo);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Heads + image accumulation, one wave per ray.
 //   LIDAR = false : colour net  [SH16(d) | geo15 | 1] (32)  -> 64 -> 64 -> 3 (padded 16)
 //   LIDAR = true  : raydrop net and intensity net  [Freq72(d) | geo15 | 1 x 9] (96) -> 64 -> 64 -> 1;
 //                   image channels = (raydrop, intensity)  (network_dynamic.py:317)
 // rgb = sigmoid(fp32 logits); samples with weight <= w_thresh contribute 0 (renderer_dynamic.py:202,
 // network_dynamic.py:297-307, 325-330); image = sum_i w_i rgb_i (+ (1 - ws) * bg for the camera, :236-237).
+// One head.  Only the LAST 32-wide k-step of the first layer varies along a ray (it holds the geometry
+// features); the leading k-steps hold the direction encoding, which is constant per ray, so their partial
+// products are computed once per ray (`ray_const`) and re-used as the MFMA's C operand for every tile.  The
+// accumulation chain (k-steps in order 0,1,2, fp32) is unchanged, hence the result is bit-identical to the
+// unfactored evaluation while 8 of the 12 first-layer MFMAs of a LiDAR head disappear from the tile loop.
 template <int IN_STEPS>
 struct HeadW {
-    half8_t w0[kHidTiles][IN_STEPS];
+    half8_t w0_last[kHidTiles];      // first layer, last k-step
+    float4_t ray_const[kHidTiles];   // first layer, k-steps 0..IN_STEPS-2 applied to the ray-constant features
     HiddenLayerW w1;
     OutLayerW w2;
-    __device__ __forceinline__ void load(const _Float16* __restrict__ W, int lane) {
-#pragma unroll
-        for (int t = 0; t < kHidTiles; ++t)
-#pragma unroll
-            for (int s = 0; s < IN_STEPS; ++s) w0[t][s] = load_w_natural(W, 32 * IN_STEPS, t, s, lane);
-        w1.load(W + kHidden * 32 * IN_STEPS, lane);
-        w2.load(W + kHidden * 32 * IN_STEPS + kHidden * kHidden, lane);
-    }
-    __device__ __forceinline__ float4_t apply(const half8_t (&xf)[IN_STEPS]) const {
-        float4_t acc[kHidTiles];
+    __device__ __forceinline__ void load(const _Float16* __restrict__ W, int lane, const half8_t (&xf_const)[IN_STEPS]) {
 #pragma unroll
         for (int t = 0; t < kHidTiles; ++t) {
             float4_t c = {0, 0, 0, 0};
 #pragma unroll
-            for (int s = 0; s < IN_STEPS; ++s) c = mfma16(w0[t][s], xf[s], c);
-            acc[t] = c;
+            for (int s = 0; s < IN_STEPS - 1; ++s) c = mfma16(load_w_natural(W, 32 * IN_STEPS, t, s, lane), xf_const[s], c);
+            ray_const[t] = c;
+            w0_last[t] = load_w_natural(W, 32 * IN_STEPS, t, IN_STEPS - 1, lane);
         }
+        w1.load(W + kHidden * 32 * IN_STEPS, lane);
+        w2.load(W + kHidden * 32 * IN_STEPS + kHidden * kHidden, lane);
+    }
+    __device__ __forceinline__ float4_t apply(const half8_t& x_last) const {
+        float4_t acc[kHidTiles];
+#pragma unroll
+        for (int t = 0; t < kHidTiles; ++t) acc[t] = mfma16(w0_last[t], x_last, ray_const[t]);
         half8_t h[kHidSteps];
         pack_hidden(acc, h);
         w1.apply(h, acc);
@@ -140,10 +369,11 @@ struct HeadW {
     }
 };
 
-__device__ __forceinline__ float sigmoid_f16(float logit_f32) {  // fp32 logit -> fp32 sigmoid (no fp16 rounding of outputs)
-    return 1.0f / (1.0f + expf(-logit_f32));
-}
+// sigmoid with the hardware exp2 / reciprocal (each ~1 ulp): well inside the 1e-4 budget of the composited image
+__device__ __forceinline__ float sigmoid_f32(float logit) { return __builtin_amdgcn_rcpf(1.0f + __expf(-logit)); }
 
+// Two 16-sample tiles per iteration (independent MFMA chains for the scheduler to interleave); the weights and
+// geometry rows of the next iteration are fetched before the current one is evaluated.
 template <bool LIDAR>
 __global__ __launch_bounds__(kBlock) void k_heads_uniform(const float* __restrict__ weights, const _Float16* __restrict__ geo,
                                                           const float* __restrict__ rays_d, const float* __restrict__ weights_sum,
@@ -151,14 +381,11 @@ __global__ __launch_bounds__(kBlock) void k_heads_uniform(const float* __restric
                                                           uint32_t N, uint32_t T, float w_thresh, float bg0, float bg1, float bg2,
                                                           int use_bg, float* __restrict__ image) {
     constexpr int IN_STEPS = LIDAR ? 3 : 1;
-    constexpr int C = LIDAR ? 2 : 3;
+    constexpr int C = LIDAR ? 1 : 3;   // channels accumulated by this wave
+    constexpr int CI = LIDAR ? 2 : 3;  // channels of the image
     const uint32_t n = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (n >= N) return;
     const int lane = lane_id(), g = lane >> 4, sl = lane & 15;
-    HeadW<IN_STEPS> net_a;
-    net_a.load(w_a, lane);
-    HeadW<IN_STEPS> net_b;  // second head only exists for LiDAR
-    if constexpr (LIDAR) net_b.load(w_b, lane);
 
     // per-ray direction encoding -> the ray-constant part of the B fragments
     const float d0 = (rays_d[3 * (size_t)n] + 1.0f) / 2.0f, d1 = (rays_d[3 * (size_t)n + 1] + 1.0f) / 2.0f,
@@ -185,40 +412,52 @@ __global__ __launch_bounds__(kBlock) void k_heads_uniform(const float* __restric
                 xf[s][j + 1] = (_Float16)cs;
             }
     }
+    // LiDAR: the two heads run as separate waves (blockIdx.y selects raydrop / intensity -> image channel 0 / 1):
+    // half the weight registers per wave (twice the resident waves) and twice as many waves to fill the chip.
+    const int head = LIDAR ? (int)blockIdx.y : 0;
+    HeadW<IN_STEPS> net_a;
+    net_a.load(head == 0 ? w_a : w_b, lane, xf);
+    const half8_t x_base = xf[IN_STEPS - 1];  // ray-constant lanes of the varying k-step
+    // lane groups that carry geometry features in the varying k-step, and which half of the 16-wide geo row they take
+    const bool takes_geo = LIDAR ? (g == 1 || g == 2) : (g >= 2);
+    const int geo_half = LIDAR ? (g == 2 ? 8 : 0) : (g == 3 ? 8 : 0);
+
     float acc[C];
 #pragma unroll
     for (int c = 0; c < C; ++c) acc[c] = 0.0f;
-
     const float* w_row = weights + (size_t)n * T;
-    const _Float16* geo_row = geo + (size_t)n * T * 16;
-    for (uint32_t base = 0; base < T; base += 16) {
-        const uint32_t i = base + sl;
-        const bool valid = i < T;
-        const float w = valid ? w_row[i] : 0.0f;
-        const bool on = valid && (w > w_thresh);
-        if (__ballot(on) == 0ull) continue;  // whole tile below the weight threshold
-        const half8_t glo = *reinterpret_cast<const half8_t*>(geo_row + (size_t)(valid ? i : 0) * 16);
-        const half8_t ghi = *reinterpret_cast<const half8_t*>(geo_row + (size_t)(valid ? i : 0) * 16 + 8);
-        if constexpr (!LIDAR) {
-            if (g == 2) xf[0] = glo;
-            if (g == 3) xf[0] = ghi;
-        } else {
-            if (g == 1) xf[2] = glo;
-            if (g == 2) xf[2] = ghi;
+    const _Float16* geo_row = geo + (size_t)n * T * 16 + geo_half;
+
+    auto fetch = [&](uint32_t base, float (&w)[2], half8_t (&gv)[2]) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t i = base + 16 * u + sl;
+            w[u] = i < T ? w_row[i] : 0.0f;
+            gv[u] = x_base;
+            if (takes_geo && i < T) gv[u] = *reinterpret_cast<const half8_t*>(geo_row + (size_t)i * 16);
         }
-        const float4_t oa = net_a.apply(xf);
-        float4_t ob = {0, 0, 0, 0};
-        if constexpr (LIDAR) ob = net_b.apply(xf);
-        if (g == 0 && on) {
-            if constexpr (LIDAR) {
-                acc[0] += w * sigmoid_f16(oa[0]);  // raydrop
-                acc[1] += w * sigmoid_f16(ob[0]);  // intensity
-            } else {
-                acc[0] += w * sigmoid_f16(oa[0]);
-                acc[1] += w * sigmoid_f16(oa[1]);
-                acc[2] += w * sigmoid_f16(oa[2]);
+    };
+    float w_cur[2], w_nxt[2];
+    half8_t g_cur[2], g_nxt[2];
+    fetch(0, w_cur, g_cur);
+    for (uint32_t base = 0; base < T; base += 32) {
+        if (base + 32 < T) fetch(base + 32, w_nxt, g_nxt);
+        const bool on0 = w_cur[0] > w_thresh, on1 = w_cur[1] > w_thresh;  // (out-of-range lanes carry w = 0)
+        const unsigned long long any0 = __ballot(on0), any1 = __ballot(on1);
+        if (any0 | any1) {
+            float4_t oa0 = {0, 0, 0, 0}, oa1 = {0, 0, 0, 0};
+            if (any0) oa0 = net_a.apply(g_cur[0]);
+            if (any1) oa1 = net_a.apply(g_cur[1]);
+            if (g == 0) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    if (on0) acc[c] += w_cur[0] * sigmoid_f32(oa0[c]);
+                    if (on1) acc[c] += w_cur[1] * sigmoid_f32(oa1[c]);
+                }
             }
         }
+        w_cur[0] = w_nxt[0]; w_cur[1] = w_nxt[1];
+        g_cur[0] = g_nxt[0]; g_cur[1] = g_nxt[1];
     }
 #pragma unroll
     for (int c = 0; c < C; ++c) acc[c] = wave_sum(acc[c]);  // only lanes 0..15 hold non-zero partial sums
@@ -226,7 +465,7 @@ __global__ __launch_bounds__(kBlock) void k_heads_uniform(const float* __restric
         const float bg[3] = {bg0, bg1, bg2};
         const float rest = use_bg ? 1.0f - weights_sum[n] : 0.0f;
 #pragma unroll
-        for (int c = 0; c < C; ++c) image[(size_t)n * C + c] = use_bg ? acc[c] + rest * bg[c] : acc[c];
+        for (int c = 0; c < C; ++c) image[(size_t)n * CI + head + c] = use_bg ? acc[c] + rest * bg[c] : acc[c];
     }
 }
 
@@ -271,7 +510,34 @@ NVSF_API int nvsf_field_density_uniform_fwd(const float* rays_o, const float* ra
     const _Float16* tb = reinterpret_cast<const _Float16*>(table_f16);
     const _Float16* ws = reinterpret_cast<const _Float16*>(sigma_weights_f16);
     _Float16* gp = reinterpret_cast<_Float16*>(geo_f16);
-    if (F == 2) hipLaunchKernelGGL(k_density_uniform<2>, dim3(blocks), dim3(kBlock), 0, stream, rb, tb, meta, ws, z_vals, sigmas, gp);
+    // v2 needs "dense levels first, hashed levels after" (true for any per_level_scale >= 1) and a table < 2 GiB
+    uint32_t first_hashed = L;
+    bool monotone = true;
+    for (uint32_t l = 0; l < L; ++l) {
+        const unsigned long long cells = (unsigned long long)h_res[l] * h_res[l] * h_res[l];
+        const bool hashed = cells > (unsigned long long)(h_offsets[l + 1] - h_offsets[l]);
+        if (hashed && first_hashed == L) first_hashed = l;
+        if (!hashed && first_hashed != L) monotone = false;
+        if (hashed && ((h_offsets[l + 1] - h_offsets[l]) & (h_offsets[l + 1] - h_offsets[l] - 1u)) != 0u) monotone = false;
+    }
+    const unsigned long long table_bytes = (unsigned long long)h_offsets[L] * F * sizeof(_Float16);
+    const char* variant = getenv("NVSF_DENSITY_KERNEL");  // "1" forces the first formulation (A/B timing)
+    const bool use_v2 = F == 2 && monotone && table_bytes < (1ull << 31) && !(variant && variant[0] == '1');
+    if (use_v2) {
+        const bool seg = (T % 16u == 0u) && !(variant && variant[0] == '2');  // "2" = v2 with the generic tile loop
+        if (seg) {
+            const char* st_env = getenv("NVSF_DENSITY_SEG_TILES");
+            const uint32_t seg_tiles = st_env ? (uint32_t)atoi(st_env) : 4u;  // 4 tiles = one round of the 4 waves (measured best)
+            const unsigned long long units = (unsigned long long)N * ((T / 16 + seg_tiles - 1) / seg_tiles);
+            const uint32_t segb = (uint32_t)(units < 3072ull ? units : 3072ull);  // 256 CUs x 3 workgroups (VGPR-limited residency) x 4
+            hipLaunchKernelGGL((k_density_uniform_v2<2, true, 4>), dim3(segb), dim3(kBlock), 0, stream, rb, tb, (uint32_t)table_bytes, meta,
+                               first_hashed, seg_tiles, ws, z_vals, sigmas, gp);
+        } else {
+            hipLaunchKernelGGL((k_density_uniform_v2<2, false, 4>), dim3(blocks), dim3(kBlock), 0, stream, rb, tb, (uint32_t)table_bytes, meta,
+                               first_hashed, 0u, ws, z_vals, sigmas, gp);
+        }
+    }
+    else if (F == 2) hipLaunchKernelGGL(k_density_uniform<2>, dim3(blocks), dim3(kBlock), 0, stream, rb, tb, meta, ws, z_vals, sigmas, gp);
     else hipLaunchKernelGGL(k_density_uniform<4>, dim3(blocks), dim3(kBlock), 0, stream, rb, tb, meta, ws, z_vals, sigmas, gp);
     return nvsf_launch_status();
 }
@@ -292,7 +558,7 @@ NVSF_API int nvsf_field_heads_uniform_fwd(const float* weights, const void* geo_
                 b2 = (h_bg_color && !lidar) ? h_bg_color[2] : 0.0f;
     const dim3 grid(cdiv(N, kWavesPerBlock)), block(kBlock);
     if (lidar)
-        hipLaunchKernelGGL(k_heads_uniform<true>, grid, block, 0, stream, weights, gp, rays_d, weights_sum, wa, wb, N, T, w_thresh, b0,
+        hipLaunchKernelGGL(k_heads_uniform<true>, dim3(grid.x, 2), block, 0, stream, weights, gp, rays_d, weights_sum, wa, wb, N, T, w_thresh, b0,
                            b1, b2, h_bg_color ? 1 : 0, image);
     else
         hipLaunchKernelGGL(k_heads_uniform<false>, grid, block, 0, stream, weights, gp, rays_d, weights_sum, wa, wb, N, T, w_thresh,

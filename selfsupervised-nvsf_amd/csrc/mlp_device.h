@@ -46,15 +46,32 @@ __device__ __forceinline__ half8_t load_w_chained(const _Float16* __restrict__ W
     return v;
 }
 
-// ReLU + round to fp16 of two accumulator tiles (2s, 2s+1) -> B fragment of k-step s of the next layer
+// ReLU + round to fp16 of two accumulator tiles (2s, 2s+1) -> B fragment of k-step s of the next layer.
+// Order: round to fp16 first (v_cvt_pk_f16_f32, two values per instruction), then clamp the packed halves with
+// an INTEGER max against 0 (v_pk_max_i16): an fp16 with the sign bit set is a negative int16.  Rounding is
+// sign-preserving and monotonic, so this equals fp16(max(x, 0)) for every finite x, and it avoids both the
+// per-value fp32 v_max and the canonicalising v_max hipcc puts in front of fmaxf on MFMA results.
+typedef short short2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t relu_pack2(float a, float b) {
+    half2_t h;
+    h[0] = (_Float16)a;
+    h[1] = (_Float16)b;
+    const short2_t zero = {0, 0};
+    const short2_t r = __builtin_elementwise_max(__builtin_bit_cast(short2_t, h), zero);
+    return __builtin_bit_cast(uint32_t, r);
+}
+
+typedef uint32_t uint4_t __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ half8_t relu_pack(float4_t a, float4_t b) {
-    half8_t v;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        v[r] = (_Float16)fmaxf(a[r], 0.0f);
-        v[4 + r] = (_Float16)fmaxf(b[r], 0.0f);
-    }
-    return v;
+    uint4_t v;
+    v[0] = relu_pack2(a[0], a[1]);
+    v[1] = relu_pack2(a[2], a[3]);
+    v[2] = relu_pack2(b[0], b[1]);
+    v[3] = relu_pack2(b[2], b[3]);
+    return __builtin_bit_cast(half8_t, v);
 }
 
 // Hidden layer (64 -> 64) on register-resident activations.
