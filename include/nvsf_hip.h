@@ -172,6 +172,21 @@ int nvsf_mlp_fwd(const void* x, int x_is_f16, uint32_t M, uint32_t n_in, uint32_
                  uint32_t in_cols, uint32_t hidden, uint32_t n_hidden, uint32_t out_cols, float* out_f32,
                  uint32_t out_stride, nvsf_stream_t stream);
 
+/* ref: Planes4D.forward / forward_static / forward_dynamic, nvsf/nerf/models/planes_field.py:86-140,196-238
+ * (24 F.grid_sample(bilinear, align_corners=True, padding='border') calls + products + concat per call).
+ * xt fp32 [M,4] in [0,1] (16-byte aligned); planes_cl: all 6*n_scales planes CHANNEL-LAST [H][W][C] fp32 in
+ * (scale, pair) order, pair = (0,1) (0,2) (0,3) (1,2) (1,3) (2,3), plane (a,b) has W = res[a], H = res[b];
+ * h_res host [n_scales][4]; want bit 0: static (xy*xz*yz), bit 1: dynamic (xt*yt*zt);
+ * outputs fp32 [M, n_scales*C].  C must be 8. */
+int nvsf_planes_fwd(const float* xt, uint32_t M, const float* planes_cl, uint32_t n_scales, uint32_t C,
+                    const uint32_t* h_res, int want, float* out_static, float* out_dynamic, nvsf_stream_t stream);
+
+/* autograd of the above: grad_planes_cl (same layout as planes_cl, fp32 atomics, caller zero-initialises; may be
+ * NULL) and grad_xt [M,4] (may be NULL). */
+int nvsf_planes_bwd(const float* xt, uint32_t M, const float* planes_cl, uint32_t n_scales, uint32_t C,
+                    const uint32_t* h_res, int want, const float* grad_static, const float* grad_dynamic,
+                    float* grad_planes_cl, float* grad_xt, nvsf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Section 4: fused kernels of the uniform-sampling render (BASELINE config 2 hot path).
  * ---------------------------------------------------------------------------------------------- */

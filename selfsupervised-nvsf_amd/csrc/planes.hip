@@ -1,0 +1,221 @@
+// K-planes space-time encoder (Planes4D) for gfx950: forward, and backward wrt planes and coordinates.
+// Reference: /root/reference/nvsf/nerf/models/planes_field.py:55-140 (24 F.grid_sample launches + products +
+// concatenation per call; bilinear, align_corners=True, padding_mode='border').
+//
+// Layout: the reference keeps each plane channel-first [C][H][W]; the HIP path reads a CHANNEL-LAST copy
+// [H][W][C=8] (refreshed by the host when the parameters change), so one texel is 32 contiguous bytes = two
+// 16-byte loads instead of eight 4-byte loads at a stride of H*W*4 bytes.  All 24 planes of an encoder are
+// one buffer, in (scale, pair) order with pair = (0,1) (0,2) (0,3) (1,2) (1,3) (2,3); static feature =
+// (xy * xz) * yz, dynamic = (xt * yt) * zt, per scale, concatenated over scales.
+// The whole table (2.2 M parameters = 8.7 MB) lives in L2 / Infinity Cache; one thread = one (sample, scale).
+#include "common.h"
+#include <math.h>
+
+namespace {
+constexpr int kBlock = 256;
+constexpr int kC = 8;          // features per plane (n_features_per_level_plane)
+constexpr int kMaxScales = 8;
+
+struct PlaneMeta {
+    uint32_t res[kMaxScales][4];   // per scale: resolution of x, y, z, t
+    uint32_t off[kMaxScales][6];   // float offset of plane (scale, pair) in the channel-last buffer
+    uint32_t n_scales;
+};
+
+__device__ __constant__ const int kPa[6] = {0, 0, 0, 1, 1, 2};
+__device__ __constant__ const int kPb[6] = {1, 2, 3, 2, 3, 3};
+
+struct Tap {
+    uint32_t i00, i01, i10, i11;   // texel indices (row-major, clamped into the image)
+    float nw, ne, sw, se;          // bilinear weights, torch naming
+    float gx, gy;                  // d ix / d p_a, d iy / d p_b (0 where the border clamp is active)
+    float ix_f, iy_f, x0, y0;
+};
+
+__device__ __forceinline__ Tap make_tap(float pa, float pb, uint32_t W, uint32_t H) {
+    Tap t;
+    float ix = ((pa * 2.0f - 1.0f + 1.0f) / 2.0f) * (float)(W - 1);
+    float iy = ((pb * 2.0f - 1.0f + 1.0f) / 2.0f) * (float)(H - 1);
+    // torch's border clamp passes no gradient AT the border either (clip_coordinates_set_grad: in <= 0, in >= max)
+    t.gx = (ix <= 0.0f || ix >= (float)(W - 1)) ? 0.0f : (float)(W - 1);
+    t.gy = (iy <= 0.0f || iy >= (float)(H - 1)) ? 0.0f : (float)(H - 1);
+    ix = fminf((float)(W - 1), fmaxf(ix, 0.0f));
+    iy = fminf((float)(H - 1), fmaxf(iy, 0.0f));
+    const float x0 = floorf(ix), y0 = floorf(iy), x1 = x0 + 1.0f, y1 = y0 + 1.0f;
+    t.nw = (x1 - ix) * (y1 - iy);
+    t.ne = (ix - x0) * (y1 - iy);
+    t.sw = (x1 - ix) * (iy - y0);
+    t.se = (ix - x0) * (iy - y0);
+    const uint32_t X0 = (uint32_t)x0, Y0 = (uint32_t)y0;
+    const uint32_t X1 = X0 + 1 < W ? X0 + 1 : W - 1, Y1 = Y0 + 1 < H ? Y0 + 1 : H - 1;  // out-of-image taps carry weight 0
+    t.i00 = Y0 * W + X0; t.i01 = Y0 * W + X1; t.i10 = Y1 * W + X0; t.i11 = Y1 * W + X1;
+    t.ix_f = ix; t.iy_f = iy; t.x0 = x0; t.y0 = y0;
+    return t;
+}
+
+__device__ __forceinline__ void load_texel(const float* __restrict__ plane, uint32_t idx, float (&v)[kC]) {
+    const float4 a = reinterpret_cast<const float4*>(plane + (size_t)idx * kC)[0];
+    const float4 b = reinterpret_cast<const float4*>(plane + (size_t)idx * kC)[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+__device__ __forceinline__ void interp(const float* __restrict__ plane, const Tap& t, float (&out)[kC]) {
+    float a[kC], b[kC], c[kC], d[kC];
+    load_texel(plane, t.i00, a);
+    load_texel(plane, t.i01, b);
+    load_texel(plane, t.i10, c);
+    load_texel(plane, t.i11, d);
+#pragma unroll
+    for (int k = 0; k < kC; ++k) out[k] = ((a[k] * t.nw + b[k] * t.ne) + c[k] * t.sw) + d[k] * t.se;
+}
+
+// want: bit 0 static, bit 1 dynamic
+__global__ __launch_bounds__(kBlock) void k_planes_fwd(const float* __restrict__ xt, uint32_t M, const float* __restrict__ planes,
+                                                       PlaneMeta meta, int want, float* __restrict__ out_static,
+                                                       float* __restrict__ out_dynamic) {
+    const uint32_t m = blockIdx.x * kBlock + threadIdx.x, s = blockIdx.y;
+    if (m >= M) return;
+    const float4 p4 = reinterpret_cast<const float4*>(xt)[m];
+    const float p[4] = {p4.x, p4.y, p4.z, p4.w};
+    float fs[kC], fd[kC];
+    bool first_s = true, first_d = true;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int a = kPa[q], b = kPb[q];
+        const bool is_time = b == 3;
+        if ((is_time && !(want & 2)) || (!is_time && !(want & 1))) continue;
+        const Tap t = make_tap(p[a], p[b], meta.res[s][a], meta.res[s][b]);
+        float v[kC];
+        interp(planes + meta.off[s][q], t, v);
+        if (is_time) {
+#pragma unroll
+            for (int k = 0; k < kC; ++k) fd[k] = first_d ? v[k] : fd[k] * v[k];
+            first_d = false;
+        } else {
+#pragma unroll
+            for (int k = 0; k < kC; ++k) fs[k] = first_s ? v[k] : fs[k] * v[k];
+            first_s = false;
+        }
+    }
+    const uint32_t stride = meta.n_scales * kC;
+    if (want & 1) {
+        float4* o = reinterpret_cast<float4*>(out_static + (size_t)m * stride + s * kC);
+        o[0] = make_float4(fs[0], fs[1], fs[2], fs[3]);
+        o[1] = make_float4(fs[4], fs[5], fs[6], fs[7]);
+    }
+    if (want & 2) {
+        float4* o = reinterpret_cast<float4*>(out_dynamic + (size_t)m * stride + s * kC);
+        o[0] = make_float4(fd[0], fd[1], fd[2], fd[3]);
+        o[1] = make_float4(fd[4], fd[5], fd[6], fd[7]);
+    }
+}
+
+// Backward: one thread = one sample (loops over scales so that grad_xt needs no atomics); plane gradients are
+// fp32 atomics into the channel-last gradient buffer.
+__global__ __launch_bounds__(kBlock) void k_planes_bwd(const float* __restrict__ xt, uint32_t M, const float* __restrict__ planes,
+                                                       PlaneMeta meta, int want, const float* __restrict__ g_static,
+                                                       const float* __restrict__ g_dynamic, float* __restrict__ g_planes,
+                                                       float* __restrict__ g_xt) {
+    const uint32_t m = blockIdx.x * kBlock + threadIdx.x;
+    if (m >= M) return;
+    const float4 p4 = reinterpret_cast<const float4*>(xt)[m];
+    const float p[4] = {p4.x, p4.y, p4.z, p4.w};
+    float gp[4] = {0, 0, 0, 0};
+    const uint32_t stride = meta.n_scales * kC;
+    for (uint32_t s = 0; s < meta.n_scales; ++s) {
+#pragma unroll
+        for (int grp = 0; grp < 2; ++grp) {  // 0: static planes (pairs 0,1,3), 1: time planes (pairs 2,4,5)
+            if (!(want & (1 << grp))) continue;
+            const float* gout = (grp == 0 ? g_static : g_dynamic) + (size_t)m * stride + s * kC;
+            const int pairs[3] = {grp == 0 ? 0 : 2, grp == 0 ? 1 : 4, grp == 0 ? 3 : 5};
+            Tap t[3];
+            float v[3][kC];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int a = kPa[pairs[j]], b = kPb[pairs[j]];
+                t[j] = make_tap(p[a], p[b], meta.res[s][a], meta.res[s][b]);
+                interp(planes + meta.off[s][pairs[j]], t[j], v[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int q = pairs[j], a = kPa[q], b = kPb[q];
+                const float* plane = planes + meta.off[s][q];
+                float* gpl = g_planes ? g_planes + meta.off[s][q] : nullptr;
+                float tex00[kC], tex01[kC], tex10[kC], tex11[kC];
+                load_texel(plane, t[j].i00, tex00);
+                load_texel(plane, t[j].i01, tex01);
+                load_texel(plane, t[j].i10, tex10);
+                load_texel(plane, t[j].i11, tex11);
+                const float wx1 = t[j].ix_f - t[j].x0, wx0 = 1.0f - wx1, wy1 = t[j].iy_f - t[j].y0, wy0 = 1.0f - wy1;
+                float dix = 0.0f, diy = 0.0f;
+#pragma unroll
+                for (int k = 0; k < kC; ++k) {
+                    const float other = v[(j + 1) % 3][k] * v[(j + 2) % 3][k];
+                    const float gv = gout[k] * other;  // d L / d (interpolated value of this plane, channel k)
+                    if (gpl) {
+                        atomicAdd(gpl + (size_t)t[j].i00 * kC + k, gv * t[j].nw);
+                        atomicAdd(gpl + (size_t)t[j].i01 * kC + k, gv * t[j].ne);
+                        atomicAdd(gpl + (size_t)t[j].i10 * kC + k, gv * t[j].sw);
+                        atomicAdd(gpl + (size_t)t[j].i11 * kC + k, gv * t[j].se);
+                    }
+                    dix += gv * ((tex01[k] - tex00[k]) * wy0 + (tex11[k] - tex10[k]) * wy1);
+                    diy += gv * ((tex10[k] - tex00[k]) * wx0 + (tex11[k] - tex01[k]) * wx1);
+                }
+                gp[a] += dix * t[j].gx;
+                gp[b] += diy * t[j].gy;
+            }
+        }
+    }
+    if (g_xt) reinterpret_cast<float4*>(g_xt)[m] = make_float4(gp[0], gp[1], gp[2], gp[3]);
+}
+
+int fill_plane_meta(PlaneMeta& meta, uint32_t n_scales, const uint32_t* h_res) {
+    if (n_scales == 0 || n_scales > (uint32_t)kMaxScales || !h_res) return NVSF_ERR_INVALID_ARG;
+    static const int pa[6] = {0, 0, 0, 1, 1, 2}, pb[6] = {1, 2, 3, 2, 3, 3};
+    meta.n_scales = n_scales;
+    unsigned long long off = 0;
+    for (uint32_t s = 0; s < n_scales; ++s) {
+        for (int d = 0; d < 4; ++d) {
+            meta.res[s][d] = h_res[4 * s + d];
+            if (h_res[4 * s + d] < 2) return NVSF_ERR_INVALID_ARG;
+        }
+        for (int q = 0; q < 6; ++q) {
+            meta.off[s][q] = (uint32_t)off;
+            off += (unsigned long long)h_res[4 * s + pa[q]] * h_res[4 * s + pb[q]] * kC;
+            if (off >= (1ull << 31)) return NVSF_ERR_INVALID_ARG;
+        }
+    }
+    return NVSF_OK;
+}
+}  // namespace
+
+#define REQUIRE(cond) do { if (!(cond)) return NVSF_ERR_INVALID_ARG; } while (0)
+
+NVSF_API int nvsf_planes_fwd(const float* xt, uint32_t M, const float* planes_cl, uint32_t n_scales, uint32_t C, const uint32_t* h_res,
+                             int want, float* out_static, float* out_dynamic, hipStream_t stream) {
+    if (M == 0) return NVSF_OK;
+    REQUIRE(xt && planes_cl && (want & 3) && (!(want & 1) || out_static) && (!(want & 2) || out_dynamic));
+    REQUIRE((reinterpret_cast<uintptr_t>(xt) & 15u) == 0 && (reinterpret_cast<uintptr_t>(planes_cl) & 15u) == 0);
+    if (C != (uint32_t)kC) return NVSF_ERR_UNSUPPORTED;
+    PlaneMeta meta;
+    const int st = fill_plane_meta(meta, n_scales, h_res);
+    if (st != NVSF_OK) return st;
+    hipLaunchKernelGGL(k_planes_fwd, dim3(cdiv(M, kBlock), n_scales), dim3(kBlock), 0, stream, xt, M, planes_cl, meta, want, out_static,
+                       out_dynamic);
+    return nvsf_launch_status();
+}
+
+NVSF_API int nvsf_planes_bwd(const float* xt, uint32_t M, const float* planes_cl, uint32_t n_scales, uint32_t C, const uint32_t* h_res,
+                             int want, const float* grad_static, const float* grad_dynamic, float* grad_planes_cl, float* grad_xt,
+                             hipStream_t stream) {
+    if (M == 0) return NVSF_OK;
+    REQUIRE(xt && planes_cl && (want & 3) && (!(want & 1) || grad_static) && (!(want & 2) || grad_dynamic));
+    REQUIRE(grad_planes_cl || grad_xt);
+    if (C != (uint32_t)kC) return NVSF_ERR_UNSUPPORTED;
+    PlaneMeta meta;
+    const int st = fill_plane_meta(meta, n_scales, h_res);
+    if (st != NVSF_OK) return st;
+    hipLaunchKernelGGL(k_planes_bwd, dim3(cdiv(M, kBlock)), dim3(kBlock), 0, stream, xt, M, planes_cl, meta, want, grad_static, grad_dynamic,
+                       grad_planes_cl, grad_xt);
+    return nvsf_launch_status();
+}

@@ -182,6 +182,56 @@ class MlpFn(Function):
 
 
 # ------------------------------------------------------------------------------------------------
+# K-planes (planes_field.py)
+# ------------------------------------------------------------------------------------------------
+PLANE_PAIRS = ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))  # itertools.combinations(range(4), 2)
+
+
+class PlanesFn(Function):
+    """(xt [M,4], planes channel-last buffer) -> static [M, S*8] and / or dynamic [M, S*8] features.
+
+    `plane_params` is the flat tuple of the 6*S reference-layout parameters [1, C, H, W]; they only receive
+    the gradient (the forward reads `planes_cl`, their channel-last copy)."""
+
+    @staticmethod
+    def forward(ctx, xt, planes_cl, res_host, want, *plane_params):
+        xt = xt.float().contiguous()
+        M, S = xt.shape[0], len(res_host) // 4
+        dev = xt.device
+        out_s = torch.empty(M, S * 8, dtype=torch.float32, device=dev) if want & 1 else None
+        out_d = torch.empty(M, S * 8, dtype=torch.float32, device=dev) if want & 2 else None
+        _hip.call("nvsf_planes_fwd", _hip.ptr(xt), M, _hip.ptr(planes_cl), S, 8, _hip.host_u32(res_host), int(want), _hip.ptr(out_s),
+                  _hip.ptr(out_d))
+        ctx.save_for_backward(xt, planes_cl)
+        ctx.res_host, ctx.want, ctx.shapes = res_host, want, [p.shape for p in plane_params]
+        outs = tuple(o for o in (out_s, out_d) if o is not None)
+        return outs if len(outs) > 1 else outs[0]
+
+    @staticmethod
+    def backward(ctx, *grads):
+        xt, planes_cl = ctx.saved_tensors
+        want, S = ctx.want, len(ctx.res_host) // 4
+        gi = iter(grads)
+        g_s = next(gi).float().contiguous() if want & 1 else None
+        g_d = next(gi).float().contiguous() if want & 2 else None
+        need_p = any(ctx.needs_input_grad[4:])
+        need_x = ctx.needs_input_grad[0]
+        g_planes = torch.zeros_like(planes_cl) if need_p else None
+        g_xt = torch.empty_like(xt) if need_x else None
+        if need_p or need_x:
+            _hip.call("nvsf_planes_bwd", _hip.ptr(xt), xt.shape[0], _hip.ptr(planes_cl), S, 8, _hip.host_u32(ctx.res_host), int(want),
+                      _hip.ptr(g_s), _hip.ptr(g_d), _hip.ptr(g_planes), _hip.ptr(g_xt))
+        g_params = [None] * len(ctx.shapes)
+        if need_p:
+            off = 0
+            for i, shp in enumerate(ctx.shapes):  # channel-last [H, W, C] slices back to the reference layout [1, C, H, W]
+                _, C, H, W = shp
+                g_params[i] = g_planes[off:off + H * W * C].view(H, W, C).permute(2, 0, 1).unsqueeze(0).contiguous()
+                off += H * W * C
+        return (g_xt, None, None, None, *g_params)
+
+
+# ------------------------------------------------------------------------------------------------
 # uniform sampler / compositor (renderer_dynamic.py:155-237)
 # ------------------------------------------------------------------------------------------------
 _LIN_CACHE = {}

@@ -1,0 +1,113 @@
+"""Space-time hash encoders (`HashGridT`, `HashGrid4D`) for MI355X.
+
+Module tree, constructor arguments, `n_output_dims` and results follow
+/root/reference/nvsf/nerf/models/hash_field.py:29-173 (state_dict keys `hash_static.params`,
+`hash_dynamic.<plane>.hash_t.<slice>.params`): one 3-D multiresolution grid for the static scene plus, for each
+coordinate pair (xy, xz, yz), `time_resolution` 2-D grids that are blended linearly between the two time slices
+around t and then reduced over groups of 4 features with cubic Lagrange weights at nodes 0, 1/3, 2/3, 1.
+Every grid evaluation is the HIP hash-grid kernel (csrc/hashgrid.hip) reading the coordinate columns of x in
+place (no x[:, [0, 2]] copies).
+
+Arithmetic order and dtypes are kept exactly as in the reference (its results depend on them): with `t` a
+dimensioned tensor the blend and the Lagrange reduction run in fp32; with a 0-dim `t` (the flow-warped
+neighbour frames, network_dynamic.py:244,260) they run in fp16 -- PyTorch type promotion does the same here
+because the same expressions are applied to the same operand types.  The reference indexes its ModuleList with
+device tensors and branches on `idx1 == idx2` (one device->host sync per plane per call); here the slice indices
+come from one host copy of t per call.
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+import tinycudann as tcnn
+
+
+def _host_time(t):
+    return float(t) if not torch.is_tensor(t) else float(t.detach().reshape(-1)[0])
+
+
+def lagrange_weights(t, num_basis):
+    """w_j(t) = prod_{m != j} (t - T_m) / (T_j - T_m), T_m = m / (num_basis - 1); factors multiplied in order of m."""
+    nodes = [i / (num_basis - 1) for i in range(num_basis)]
+    weights = []
+    for j in range(num_basis):
+        w = None
+        for m in range(num_basis):
+            if m == j:
+                continue
+            f = (t - nodes[m]) / (nodes[j] - nodes[m])
+            w = f if w is None else w * f
+        weights.append(w)
+    return weights
+
+
+def lagrange_reduce(feat, t, n_levels, n_features, num_basis):
+    """[N, L*F] -> [N, L*F/num_basis]: the F features of every level are split into `num_basis` chunks which are
+    combined with the Lagrange weights (hash_field.py:65-74, flow_field.py:105-114)."""
+    chunks = torch.chunk(feat.view(-1, n_levels, n_features), num_basis, dim=-1)
+    w = lagrange_weights(t, num_basis)
+    out = w[0] * chunks[0]
+    for i in range(1, num_basis):
+        out = out + w[i] * chunks[i]
+    return out.view(-1, n_levels * n_features // num_basis)
+
+
+class HashGridT(nn.Module):
+    def __init__(self, time_resolution=25, base_resolution=512, max_resolution=32768, n_levels=8, n_features_per_level=4,
+                 log2_hashmap_size=14, num_basis=4, cols=(0, 1)):
+        super().__init__()
+        self.time_resolution = time_resolution
+        per_level_scale = np.exp2(np.log2(max_resolution / base_resolution) / (n_levels - 1))
+        cfg = {"otype": "HashGrid", "n_levels": n_levels, "n_features_per_level": n_features_per_level,
+               "log2_hashmap_size": log2_hashmap_size, "base_resolution": base_resolution, "per_level_scale": per_level_scale}
+        self.hash_t = nn.ModuleList([tcnn.Encoding(n_input_dims=2, encoding_config=cfg) for _ in range(time_resolution)])
+        self.n_levels, self.n_features_per_level, self.num_basis = n_levels, n_features_per_level, num_basis
+        self.n_output_dims = n_levels * n_features_per_level // num_basis
+        self.cols = tuple(cols)
+
+    def _slice(self, k, x):
+        return self.hash_t[k].encode_columns(x, self.cols)
+
+    def forward(self, x, t, t_host=None):
+        """x: [N, >=2] (the two columns `self.cols` are encoded), t in [0, 1]."""
+        t_host = _host_time(t) if t_host is None else t_host
+        idx_host = np.float32(t_host) * np.float32(self.time_resolution - 1)
+        k1, k2 = int(math.floor(idx_host)), int(math.ceil(idx_host))
+        if k1 == k2:
+            feat = self._slice(k1, x)
+        else:
+            idx = t * (self.time_resolution - 1)
+            feat = (k2 - idx) * self._slice(k1, x) + (idx - k1) * self._slice(k2, x)
+        return lagrange_reduce(feat, t, self.n_levels, self.n_features_per_level, self.num_basis)
+
+
+class HashGrid4D(nn.Module):
+    def __init__(self, base_resolution=512, max_resolution=32768, time_resolution=8, n_levels=8, n_features_per_level=4,
+                 log2_hashmap_size=19, hash_size_dynamic=[15, 13, 13], decompose=True, reduction="concat"):
+        super().__init__()
+        if reduction != "concat":
+            raise NotImplementedError("HashGrid4D: only the 'concat' reduction of the reference configuration is implemented")
+        per_level_scale = np.exp2(np.log2(max_resolution / base_resolution) / (n_levels - 1))
+        self.hash_static = tcnn.Encoding(n_input_dims=3, encoding_config={
+            "otype": "HashGrid", "n_levels": n_levels, "n_features_per_level": n_features_per_level,
+            "log2_hashmap_size": log2_hashmap_size, "base_resolution": base_resolution, "per_level_scale": per_level_scale})
+        pairs = ((0, 1), (0, 2), (1, 2))  # xyt, xzt, yzt
+        self.hash_dynamic = nn.ModuleList([
+            HashGridT(time_resolution=time_resolution, base_resolution=base_resolution, max_resolution=max_resolution, n_levels=n_levels,
+                      n_features_per_level=n_features_per_level, log2_hashmap_size=hash_size_dynamic[i], cols=pairs[i])
+            for i in range(3)])
+        self.decompose, self.reduction = decompose, reduction
+        self.n_output_dims = self.hash_static.n_output_dims + self.hash_dynamic[0].n_output_dims * 3
+
+    def forward_static(self, x):
+        return self.hash_static(x)
+
+    def forward_dynamic(self, x, t):
+        t_host = _host_time(t)
+        return torch.cat([plane(x, t, t_host) for plane in self.hash_dynamic], dim=-1)
+
+    def forward(self, x, t):
+        static, dynamic = self.forward_static(x), self.forward_dynamic(x, t)
+        return [static, dynamic] if self.decompose else torch.cat([static, dynamic], dim=-1)

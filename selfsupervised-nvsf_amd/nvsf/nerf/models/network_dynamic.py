@@ -1,0 +1,141 @@
+"""The full space-time field (`NeRFNetwork`) for MI355X.
+
+Constructor arguments, sub-module names (hence state_dict keys), `density` / `color` / `flow` / `get_params`
+signatures and results follow /root/reference/nvsf/nerf/models/network_dynamic.py:12-357:
+
+  density(x, t):  x -> [0,1]^3;  per modality: static 3-D hash grid + time-sliced 2-D hash grids (HashGrid4D),
+                  K-planes (Planes4D); the flow field warps x to the previous / next frame where the dynamic
+                  encoders are evaluated again (hash grids without gradient, planes with gradient, :242-271);
+                  dynamic features = 0.5 current + 0.25 (previous + next); the 120 features feed the density MLP
+                  (120 -> 64 -> 16); sigma = trunc_exp(h0), geo_feat = h[1:].
+  color(x, d, mask, geo_feat): direction encoding + heads on the masked samples, sigmoid, scatter (:290-332);
+                  LiDAR channel order = [raydrop, intensity] (:317).
+
+Every encoder / MLP evaluation is a HIP kernel (hash grid, K-planes, fused MLP, Frequency / SH); the glue between
+them is the same tensor algebra as the reference.  Differences, all host-side: `t` is read back once per call
+(the reference syncs >= 10 times per `density`); the modules the reference constructs but never uses
+(`planes_encoder`, `hash_encoder`, `unet`: network_dynamic.py:47-65,192, excluded from the optimiser at :337-338)
+are not instantiated, so DistributedDataParallel needs no find_unused_parameters.
+"""
+import numpy as np
+import torch
+
+import tinycudann as tcnn
+from nvsf.nerf.activation import trunc_exp
+from nvsf.nerf.models.flow_field import FlowField
+from nvsf.nerf.models.hash_field import HashGrid4D, _host_time
+from nvsf.nerf.models.planes_field import Planes4D
+from nvsf.nerf.models.renderer_dynamic import NeRFRenderer
+
+
+class NeRFNetwork(NeRFRenderer):
+    def __init__(self, min_resolution=32, base_resolution=512, max_resolution=32768, time_resolution=25, n_levels_plane=4,
+                 n_features_per_level_plane=8, n_levels_hash=8, n_features_per_level_hash=4, log2_hashmap_size=19,
+                 num_layers_flow=3, hidden_dim_flow=64, num_layers_sigma=2, hidden_dim_sigma=64, geo_feat_dim=15,
+                 num_layers_lidar=3, hidden_dim_lidar=64, num_layers_color=3, hidden_dim_color=64, out_color_dim=3,
+                 out_lidar_color_dim=2, num_frames=51, bound=1, **kwargs):
+        super().__init__(bound, **kwargs)
+        self.out_color_dim, self.out_lidar_color_dim = out_color_dim, out_lidar_color_dim
+        self.num_frames = num_frames
+        self.n_features_per_level_hash = n_features_per_level_hash
+
+        def planes():
+            return Planes4D(grid_dimensions=2, input_dim=4, output_dim=n_features_per_level_plane,
+                            resolution=[min_resolution] * 3 + [time_resolution], multiscale_res=[2 ** n for n in range(n_levels_plane)],
+                            concat_ms_feat=True, decompose=True)
+
+        def hashes():
+            return HashGrid4D(base_resolution=base_resolution, max_resolution=max_resolution, time_resolution=time_resolution,
+                              n_levels=n_levels_hash, n_features_per_level=n_features_per_level_hash, log2_hashmap_size=log2_hashmap_size)
+
+        def mlp(n_in, n_out, hidden, layers):
+            return tcnn.Network(n_input_dims=n_in, n_output_dims=n_out,
+                                network_config={"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None",
+                                                "n_neurons": hidden, "n_hidden_layers": layers - 1})
+
+        self.planes_encoder_lidar, self.hash_encoder_lidar = planes(), hashes()
+        self.planes_encoder_camera, self.hash_encoder_camera = planes(), hashes()
+        self.view_encoder_lidar = tcnn.Encoding(n_input_dims=3, encoding_config={"otype": "Frequency", "degree": 12})
+        self.flow_net = FlowField(input_dim=4, num_layers=num_layers_flow, hidden_dim=hidden_dim_flow, use_grid=True)
+        self.sigma_net = mlp(self.planes_encoder_lidar.n_output_dims + self.hash_encoder_lidar.n_output_dims, 1 + geo_feat_dim,
+                             hidden_dim_sigma, num_layers_sigma)
+        self.intensity_net = mlp(self.view_encoder_lidar.n_output_dims + geo_feat_dim, 1, hidden_dim_lidar, num_layers_lidar)
+        self.raydrop_net = mlp(self.view_encoder_lidar.n_output_dims + geo_feat_dim, 1, hidden_dim_lidar, num_layers_lidar)
+        self.view_encoder_camera = tcnn.Encoding(n_input_dims=3, encoding_config={"otype": "SphericalHarmonics", "degree": 4})
+        self.color_net = mlp(self.view_encoder_camera.n_output_dims + geo_feat_dim, self.out_color_dim, hidden_dim_color, num_layers_color)
+
+    def forward(self, x, d):
+        pass
+
+    def _unit_cube(self, x):
+        return (x + self.bound) / (2 * self.bound)
+
+    def flow(self, x, t):
+        x = self._unit_cube(x)
+        if t.shape[0] == 1:
+            t = t.repeat(x.shape[0], 1)
+        f = self.flow_net(torch.cat([x, t], dim=-1))
+        return {"flow_forward": f[:, :3], "flow_backward": f[:, 3:]}
+
+    def density(self, x, t=None, cal_lidar_color=False, **kwargs):
+        x = self._unit_cube(x)
+        t_host = _host_time(t)  # the one device->host read of this call
+        frame_idx = int(np.float32(t_host) * np.float32(self.num_frames - 1))
+        hash_enc = self.hash_encoder_lidar if cal_lidar_color else self.hash_encoder_camera
+        planes_enc = self.planes_encoder_lidar if cal_lidar_color else self.planes_encoder_camera
+
+        hash_s, hash_d = hash_enc(x, t)
+        t_col = t.repeat(x.shape[0], 1) if t.shape[0] == 1 else t
+        xt = torch.cat([x, t_col], dim=-1)
+        plane_s, plane_d = planes_enc(xt)
+        flow = self.flow_net(xt)
+
+        def neighbour(offset, frame):
+            """dynamic features at the flow-warped position in an adjacent frame (:242-271)"""
+            xn = x + offset
+            tn = torch.tensor(frame / self.num_frames)
+            with torch.no_grad():
+                hn = hash_enc.forward_dynamic(xn, tn)
+            pn = planes_enc.forward_dynamic(torch.cat([xn, tn.repeat(xn.shape[0], 1).to(xn.device)], dim=-1))
+            return hn, pn
+
+        hash_1 = hash_2 = hash_d
+        plane_1 = plane_2 = plane_d
+        if frame_idx < self.num_frames - 1:
+            hash_1, plane_1 = neighbour(flow[:, :3], frame_idx + 1)
+        if frame_idx > 0:
+            hash_2, plane_2 = neighbour(flow[:, 3:], frame_idx - 1)
+        plane_d = 0.5 * plane_d + 0.25 * (plane_1 + plane_2)
+        hash_d = 0.5 * hash_d + 0.25 * (hash_1 + hash_2)
+
+        h = self.sigma_net(torch.cat([plane_s, plane_d, hash_s, hash_d], dim=-1))
+        return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
+
+    def color(self, x, d, cal_lidar_color=False, mask=None, geo_feat=None, **kwargs):
+        if mask is not None:
+            rgbs = torch.zeros(mask.shape[0], self.out_dim, dtype=x.dtype, device=x.device)
+            if not mask.any():
+                return rgbs
+            d, geo_feat = d[mask], geo_feat[mask]
+        d = (d + 1) / 2  # the direction encoders expect [0, 1]
+        if cal_lidar_color:
+            logits = torch.cat([self.view_encoder_lidar(d), geo_feat], dim=-1)
+            h = torch.cat([self.raydrop_net(logits), self.intensity_net(logits)], dim=-1)
+        else:
+            h = self.color_net(torch.cat([self.view_encoder_camera(d), geo_feat], dim=-1))
+        h = torch.sigmoid(h)
+        if mask is None:
+            return h
+        rgbs[mask] = h.to(rgbs.dtype)
+        return rgbs
+
+    def get_params(self, lr):
+        """Optimiser groups and learning-rate ratios of network_dynamic.py:335-357."""
+        groups = [(self.planes_encoder_lidar, 1.0), (self.hash_encoder_lidar, 1.0), (self.planes_encoder_camera, 1.0),
+                  (self.hash_encoder_camera, 1.0), (self.view_encoder_lidar, 1.0), (self.view_encoder_camera, 1.0),
+                  (self.flow_net, 0.1), (self.sigma_net, 1.0), (self.intensity_net, 0.1), (self.raydrop_net, 0.1), (self.color_net, 1.0)]
+        params = [{"params": m.parameters(), "lr": r * lr} for m, r in groups]
+        if self.bg_radius > 0:
+            params.append({"params": self.encoder_bg.parameters(), "lr": lr})
+            params.append({"params": self.bg_net.parameters(), "lr": lr})
+        return params

@@ -79,6 +79,12 @@ class Encoding(nn.Module):
             return _ops.freq_encode(x, self.n_frequencies)
         return _ops.sh4_encode(x)
 
+    def encode_columns(self, x, cols):
+        """HashGrid only: encode the columns `cols` of a wider coordinate matrix in place (no gather copy) --
+        e.g. the (x, z) pair of an [N, 3] position tensor for a 2-D time-slice grid."""
+        assert self.otype in ("HashGrid", "Grid") and len(cols) == self.n_input_dims
+        return _ops.HashGridFn.apply(x, self.params, self.table_f16(), self.spec, tuple(cols))
+
     def extra_repr(self):
         return f"n_input_dims={self.n_input_dims}, n_output_dims={self.n_output_dims}, {self.encoding_config}"
 

@@ -33,6 +33,8 @@ import oracle_lib as O  # noqa: E402
 import tcnn_cpu_spec  # noqa: E402  (imports this repo's nvsf.field_ops BEFORE the name `nvsf` is stubbed below)
 from nvsf import synthetic as S  # noqa: E402
 
+sys.modules["make_golden_synth"] = S  # lets golden_dynamic.py reach this repo's ray generators after `nvsf` is stubbed
+
 _OWN = {k: v for k, v in sys.modules.items() if k == "nvsf" or k.startswith("nvsf.")}  # this repo's package modules
 
 

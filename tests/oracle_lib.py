@@ -211,6 +211,20 @@ def composite_uniform_image(weights, rgbs, weights_sum, bg):
     return img
 
 
+def planes_fwd(xt, planes, res, want=3, C=8):
+    """planes: list of 6*S arrays in the reference layout [1, C, H, W] (or [C, H, W]); res: [S][4].
+    Returns (static, dynamic) fp32 [M, S*C] (None where not wanted)."""
+    x = _f32(xt)
+    M, S = x.shape[0], len(res)
+    arrs = [np.ascontiguousarray(np.asarray(p, np.float32).reshape(C, *np.asarray(p).shape[-2:])) for p in planes]
+    ptrs = (ctypes.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    r = np.ascontiguousarray(np.asarray(res, np.uint32).reshape(-1))
+    out_s = np.empty((M, S * C), np.float32) if want & 1 else None
+    out_d = np.empty((M, S * C), np.float32) if want & 2 else None
+    _lib("field").oracle_planes_fwd(_p(x), U(M), ptrs, U(S), U(C), _p(r), ctypes.c_int(want), _p(out_s), _p(out_d))
+    return out_s, out_d
+
+
 # ---- composition: the static-field uniform render (what NeRFNetworkStatic.render computes) --------
 def sigmoid_f32(h):
     x = h.astype(np.float32)

@@ -1,0 +1,138 @@
+"""GPU parity of the space-time rows (a13 HashGridT / HashGrid4D, a14 Planes4D, a15 FlowField, a18 NeRFNetwork) against
+fixtures produced by running the REFERENCE's own model files on CPU (tests/golden/make_golden.py + golden_dynamic.py;
+`tinycudann` inside the reference = the CPU specification of those operators).  Parameters are rebuilt from
+name-derived seeds (golden_dynamic.init_by_name), not stored.
+
+Tolerances: K-planes fp32 1e-5 (same formulas, different summation granularity inside grid_sample); hash features
+that end in fp16 arithmetic 2e-3 relative (1 fp16 ulp); network outputs 1e-4 abs on composited images / depth.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+
+import golden_dynamic as GD  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(HERE, "golden")
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def test_planes4d_forward_backward(dev):
+    from nvsf.nerf.models.planes_field import Planes4D
+    g = np.load(os.path.join(GOLD, "planes4d.npz"))
+    enc = Planes4D(resolution=[8, 8, 8, 5], multiscale_res=[1, 2, 4, 8])
+    GD.init_by_name(enc)
+    enc = enc.to(dev)
+    assert enc.n_output_dims == 64 and [tuple(p.shape) for p in enc.planes[1]][2] == (1, 8, 5, 16)
+    xt = _t(g["xt"], dev).requires_grad_()
+    s, d = enc(xt)
+    np.testing.assert_allclose(s.detach().cpu().numpy(), g["static"], atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(d.detach().cpu().numpy(), g["dynamic"], atol=1e-5, rtol=1e-5)
+    assert torch.equal(enc.forward_static(xt.detach()), s.detach()) and torch.equal(enc.forward_dynamic(xt.detach()), d.detach())
+    ((s * _t(g["grad_static"], dev)).sum() + (d * _t(g["grad_dynamic"], dev)).sum()).backward()
+    np.testing.assert_allclose(xt.grad.cpu().numpy(), g["grad_xt"], atol=2e-3, rtol=2e-3)
+    for (si, pi), key in (((0, 0), "grad_plane_0_0"), ((3, 5), "grad_plane_3_5"), ((2, 3), "grad_plane_2_3")):
+        np.testing.assert_allclose(enc.planes[si][pi].grad.cpu().numpy(), g[key], atol=2e-4, rtol=2e-4)
+    # the channel-last cache follows in-place parameter updates
+    with torch.no_grad():
+        enc.planes[0][0].mul_(2.0)
+    s2 = enc.forward_static(xt.detach()).detach()
+    np.testing.assert_allclose(s2[:, :8].cpu().numpy(), 2 * g["static"][:, :8], atol=2e-5, rtol=1e-5)
+
+
+def test_hashgrid4d_and_flow(dev):
+    from nvsf.nerf.models.hash_field import HashGrid4D
+    from nvsf.nerf.models.flow_field import FlowField
+    g = np.load(os.path.join(GOLD, "hash4d_flow.npz"))
+    enc = HashGrid4D(base_resolution=16, max_resolution=256, time_resolution=4, n_levels=8, n_features_per_level=4, log2_hashmap_size=12)
+    GD.init_by_name(enc)
+    enc = enc.to(dev)
+    assert enc.n_output_dims == 56 and "hash_dynamic.1.hash_t.3.params" in enc.state_dict()
+    x = _t(g["x"], dev)
+    torch.set_grad_enabled(False)
+    for i in range(5):
+        tv = float(g[f"t{i}"])
+        s, d = enc(x, torch.tensor([[tv]], dtype=torch.float32, device=dev))
+        assert np.array_equal(s.cpu().numpy().view(np.uint16), g[f"static{i}"].view(np.uint16))  # 3-D grid: bit-exact fp16
+        assert d.dtype == torch.float32
+        np.testing.assert_allclose(d.cpu().numpy(), g[f"dyn_t11_{i}"], atol=1e-6, rtol=1e-5)
+        d0 = enc.forward_dynamic(x, torch.tensor(tv))
+        assert d0.dtype == torch.float16  # 0-dim t keeps the blend in fp16, as in the reference
+        ref0 = g[f"dyn_t0_{i}"].astype(np.float32)
+        np.testing.assert_allclose(d0.float().cpu().numpy(), ref0, atol=2e-3 * np.abs(ref0).max(), rtol=0)
+    flow = FlowField(n_levels=16, n_features_per_level=8, base_resolution=32, max_resolution=8192, log2_hashmap_size=14)
+    GD.init_by_name(flow)
+    flow = flow.to(dev)
+    out = flow(_t(g["flow_xt"], dev))
+    torch.set_grad_enabled(True)
+    np.testing.assert_allclose(out.cpu().numpy(), g["flow"], atol=1e-5, rtol=1e-4)
+
+
+@pytest.fixture(scope="module")
+def net(dev):
+    from nvsf.nerf.models.network_dynamic import NeRFNetwork
+    from nvsf import synthetic as S
+    m = NeRFNetwork(min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH, **GD.SMALL).eval()
+    GD.init_by_name(m)
+    return m.to(dev)
+
+
+def test_network_density_and_flow(dev, net):
+    g = np.load(os.path.join(GOLD, "network_dynamic.npz"))
+    pts = _t(g["pts"], dev)
+    with torch.no_grad():
+        for tag, tv in (("mid", 0.5), ("first", 0.0), ("last", 1.0)):
+            t = torch.tensor([[tv]], dtype=torch.float32, device=dev)
+            for lidar in (1, 0):
+                out = net.density(pts, t, bool(lidar))
+                sr, gr = g[f"density_{tag}_{lidar}_sigma"], g[f"density_{tag}_{lidar}_geo"]
+                np.testing.assert_allclose(out["sigma"].cpu().numpy(), sr, rtol=3e-3, atol=1e-6, err_msg=f"{tag} {lidar}")
+                np.testing.assert_allclose(out["geo_feat"].cpu().numpy(), gr, atol=3e-3 * np.abs(gr).max(), rtol=0)
+        fl = net.flow(pts, torch.tensor([[0.5]], device=dev))
+    np.testing.assert_allclose(fl["flow_forward"].cpu().numpy(), g["flow_forward"], atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(fl["flow_backward"].cpu().numpy(), g["flow_backward"], atol=1e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("lidar", [True, False])
+def test_network_render_matches_reference(dev, net, lidar):
+    g = np.load(os.path.join(GOLD, "network_dynamic.npz"))
+    k = "lidar" if lidar else "cam"
+    sfx = "_lidar" if lidar else ""
+    o, d = _t(g[f"{k}_rays_o"], dev)[None], _t(g[f"{k}_rays_d"], dev)[None]
+    with torch.no_grad():
+        out = net.render(o, d, torch.tensor([[0.375]], device=dev), cal_lidar_color=lidar, num_steps=g[f"{k}_z_vals"].shape[1])
+    assert np.array_equal(out["z_vals"].cpu().numpy(), g[f"{k}_z_vals"])
+    np.testing.assert_allclose(out["weights"].cpu().numpy(), g[f"{k}_weights"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(out["weights_sum" + sfx].cpu().numpy(), g[f"{k}_weights_sum"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(out["depth" + sfx][0].cpu().numpy(), g[f"{k}_depth"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(out["image" + sfx][0].cpu().numpy(), g[f"{k}_image"], atol=1e-4, rtol=0)
+
+
+def test_network_trains_end_to_end(dev, net):
+    """One optimisation step through every encoder (gradients reach the hash tables, the planes, the flow MLP)."""
+    import copy
+    from nvsf import synthetic as S
+    m = copy.deepcopy(net).train()
+    opt = torch.optim.Adam(m.get_params(1e-2), betas=(0.9, 0.99), eps=1e-15)
+    rng = np.random.default_rng(3)
+    o, d = S.lidar_rays(64, rng)
+    out = m.render(_t(o, dev)[None], _t(d, dev)[None], torch.tensor([[0.5]], device=dev), cal_lidar_color=True, num_steps=32, perturb=True)
+    loss = (out["depth_lidar"] - 0.3).abs().mean() + (out["image_lidar"] - 0.5).pow(2).mean()
+    loss.backward()
+    for name in ("hash_encoder_lidar.hash_static.params", "planes_encoder_lidar.planes.0.0", "planes_encoder_lidar.planes.0.2",
+                 "flow_net.mlp.0.weight", "sigma_net.params", "raydrop_net.params"):
+        p = dict(m.named_parameters())[name]
+        assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0, name
+    assert dict(m.named_parameters())["hash_encoder_camera.hash_static.params"].grad is None  # untouched modality
+    before = m.sigma_net.params.detach().clone()
+    opt.step()
+    assert not torch.equal(before, m.sigma_net.params.detach())

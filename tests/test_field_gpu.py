@@ -95,7 +95,10 @@ def test_hashgrid_autograd_module(dev):
     # linearity of the encoding in the table: encode(2*table) == 2*encode(table) exactly in fp16 (powers of two)
     with torch.no_grad():
         enc.params.mul_(2.0)
-    assert torch.equal(enc(x), y * 2)
+    y2 = enc(x).detach()
+    normal = y.detach().abs() > 2.0 ** -13  # below that the fp16 result is subnormal and rounds on an absolute grid
+    assert torch.equal(y2[normal], (y.detach() * 2)[normal])
+    assert torch.allclose(y2.float(), y.detach().float() * 2, atol=2.0 ** -23)
 
 
 def test_frequency_and_sh(ops, dev):

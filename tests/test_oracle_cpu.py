@@ -70,6 +70,26 @@ def test_trunc_exp_golden():
     assert np.array_equal(y.detach().numpy(), g["y"]) and np.array_equal(x.grad.numpy(), g["grad"])
 
 
+def test_planes_restatement_matches_reference():
+    """oracle_planes_fwd vs the outputs of the reference's own Planes4D (pure torch, F.grid_sample)."""
+    import sys
+    sys.path.insert(0, GOLD)
+    import golden_dynamic as GD
+    import param_init
+    g = np.load(os.path.join(GOLD, "planes4d.npz"))
+    res = [[8 * m, 8 * m, 8 * m, 5] for m in (1, 2, 4, 8)]
+    pairs = ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))
+    planes = []
+    for s, r in enumerate(res):
+        for p, (a, b) in enumerate(pairs):
+            planes.append(param_init.plane_params((1, 8, r[b], r[a]), GD._seed(f"planes.{s}.{p}"), time_plane=p in (2, 4, 5)))
+    st, dy = O.planes_fwd(g["xt"], planes, res, 3)
+    np.testing.assert_allclose(st, g["static"], atol=1e-6, rtol=1e-5)
+    np.testing.assert_allclose(dy, g["dynamic"], atol=1e-6, rtol=1e-5)
+    st_only, none = O.planes_fwd(g["xt"], planes, res, 1)
+    assert none is None and np.array_equal(st_only, st)
+
+
 # ---- raymarching restatement: closed-form pins ------------------------------------------------------
 def test_near_far_against_fp64_slab_test():
     rng = np.random.default_rng(0)
