@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--num-steps", type=int, default=768)
     ap.add_argument("--cpu-rays", type=int, default=96, help="rays per modality in the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=3, help="extra leg: timed training steps reported under `train` (0 = skip)")
     return ap.parse_args()
 
 
@@ -99,6 +100,24 @@ def kernel_breakdown(model, batches, T, iters):
     return rows
 
 
+def pmc_traffic(kernel_label):
+    """HBM-side bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes
+    (profiles/*_pmc_traffic.json, produced by tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of
+    this same command; counters cannot be collected from inside the timed process).  gfx950 correction: FETCH_SIZE
+    counts 64 B per 128-B request, i.e. half the bytes (verified on k_weights_fwd: 12.4 MB reported for 25.2 MB of
+    coalesced reads), so bytes = 2 * FETCH_SIZE + WRITE_SIZE."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return {"traffic": None}
+    k = json.load(open(files[-1]))["kernels"].get("density_uniform_v2")
+    which = "camera" if "camera" in kernel_label else "lidar"
+    if not kernel_label.startswith("density") or not k or f"fetch_kb_{which}" not in k:
+        return {"traffic": None}
+    return {"traffic": (2.0 * k[f"fetch_kb_{which}"] + k[f"write_kb_{which}"]) * 1024.0,
+            "traffic_source": os.path.relpath(files[-1], ROOT) + " (2*FETCH_SIZE + WRITE_SIZE, bytes per launch)"}
+
+
 def cpu_baseline(model, T, n_rays, seed=1234):
     """Times the scalar CPU oracle on `n_rays` LiDAR + `n_rays` camera rays of the same workload (1 thread)."""
     import oracle_lib as O
@@ -123,6 +142,39 @@ def cpu_baseline(model, T, n_rays, seed=1234):
     return {"value": 2 * n_rays / dt, "unit": "rays/s", "cores": 1, "kind": "port",
             "sample": f"{n_rays} LiDAR + {n_rays} camera rays x {T} samples, same field, scalar C oracle (oracle/*.c) + numpy glue, "
                       f"{dt:.1f} s wall"}
+
+
+def train_leg(model, tl, tc, tm, T, steps, dev, dist):
+    """Secondary figure (not `value`): full multimodal training steps (BASELINE config 4 shape) -- both renders with
+    gradient, losses, backward through the HIP operators, one bucketed RCCL gradient all-reduce when N > 1, Adam."""
+    from nvsf.nerf.train_step import RenderTrainStep
+    n_l, n_c = tl[0].shape[1], tc[0].shape[1]
+    g = torch.Generator(device="cpu").manual_seed(3)
+    batch = {"rays_o_lidar": tl[0], "rays_d_lidar": tl[1], "rays_o": tc[0], "rays_d": tc[1], "time": tm,
+             "gt_depth": torch.rand(1, n_l, generator=g).to(dev) * 0.5, "gt_raydrop": (torch.rand(1, n_l, generator=g) > 0.3).float().to(dev),
+             "gt_intensity": torch.rand(1, n_l, generator=g).to(dev), "gt_rgb": torch.rand(1, n_c, 3, generator=g).to(dev)}
+    step = RenderTrainStep(model, num_steps=T)
+    n_coll = 0
+    for _ in range(2):
+        step.step(batch)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        _, _, n_coll = step.step(batch)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    world = dist.get_world_size() if dist is not None else 1
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    model.eval()
+    return {"metric": "trained rays/sec (LiDAR+cam, fwd+bwd+Adam)", "value": (n_l + n_c) * world * steps / dt, "ms_per_step": dt / steps * 1e3,
+            "steps": steps, "allreduce_collectives_per_step": n_coll, "path": "operator path (autograd): HIP fwd kernels, HIP hash-grid/compositor bwd, rocBLAS MLP bwd"}
 
 
 def main():
@@ -207,9 +259,15 @@ def main():
             line["roofline"] = {"kernel": pick["kernel"], "bound": pick["bound"], "achieved": pick["achieved"], "peak": pick["peak"],
                                 "unit": pick["unit"], "frac": pick["frac"], "traffic": None, "avg_launch_ms": pick["ms"],
                                 "algorithmic": pick["per_unit"], "units_per_launch": pick["units"]}
+            line["roofline"].update(pmc_traffic(pick["kernel"]))
             line["kernel_ms_sum"] = sum(r["ms"] for r in rows)
         if args.cpu_rays > 0 and world == 1:
             line["cpu_baseline"] = cpu_baseline(model, T, args.cpu_rays)
+    if args.train_steps > 0:
+        tr = train_leg(model, tl, tc, tm, T, args.train_steps, dev, dist)
+        if rank == 0:
+            line["train"] = tr
+    if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -1,0 +1,102 @@
+"""Frame-sharded data parallelism over the GPUs of one node (one process per GPU, torch.distributed).
+
+Rays are independent and a training step of the reference is one frame's ray batch (batch_size = 1 frame,
+/root/reference/nvsf/nerf/dataset/base_dataset.py:415-421), so the path shards without any data-path collective:
+
+  * training : rank r of W takes frame perm[epoch][step * W + r] (the DistributedSampler semantics the reference
+               gestures at with `loader.sampler.set_epoch`, trainer.py:1301-1302); the ONLY communication is one
+               bucketed all-reduce (sum, / W) of the gradients per step -- RCCL over xGMI with backend "nccl";
+  * rendering: a frame's rays are split into W contiguous chunks and the [N/W, .] outputs are all-gathered
+               (what trainer.py:1511-1524 intended).
+
+The reference's own multi-GPU path is vestigial (DDP wrap without init_process_group, SURVEY finding 5); this
+module is new design.  Everything here is host logic on torch tensors and runs unchanged on the gloo backend
+(tests/test_frame_shard_cpu.py, world size 2).
+"""
+import torch
+import torch.distributed as dist
+
+
+def world():
+    return (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+
+
+def frame_order(num_frames, epoch, seed=0):
+    """Epoch permutation shared by all ranks (same generator seed everywhere)."""
+    g = torch.Generator().manual_seed(int(seed) * 1000003 + int(epoch))
+    return torch.randperm(int(num_frames), generator=g).tolist()
+
+
+def frames_for_rank(num_frames, epoch, rank, world_size, seed=0, drop_last=False):
+    """Frames of this rank for one epoch, in step order.  Without drop_last the order is padded by wrapping around so
+    every rank runs the same number of steps (and enters the same number of all-reduces)."""
+    order = frame_order(num_frames, epoch, seed)
+    if drop_last:
+        order = order[: len(order) // world_size * world_size]
+    elif len(order) % world_size:
+        order = order + order[: world_size - len(order) % world_size]
+    return order[rank::world_size]
+
+
+def ray_chunk(n_rays, rank, world_size):
+    """[begin, end) of this rank's contiguous chunk of a frame's rays (sizes differ by at most one)."""
+    base, extra = divmod(int(n_rays), int(world_size))
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def gather_ray_outputs(local, n_rays):
+    """All-gathers per-rank [n_local, ...] outputs (ragged by at most one row) back into [n_rays, ...]."""
+    rank, ws = world()
+    if ws == 1:
+        return local
+    sizes = [ray_chunk(n_rays, r, ws)[1] - ray_chunk(n_rays, r, ws)[0] for r in range(ws)]
+    width = max(sizes)
+    pad = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    pad[: local.shape[0]] = local
+    bufs = [torch.empty_like(pad) for _ in range(ws)]
+    dist.all_gather(bufs, pad)
+    return torch.cat([b[:s] for b, s in zip(bufs, sizes)], dim=0)
+
+
+def allreduce_gradients(params, bucket_bytes=64 << 20):
+    """Averages the gradients of `params` over all ranks with as few, as large all-reduces as `bucket_bytes` allows.
+
+    xGMI is point-to-point (7 links x ~153 GB/s per GPU): ring all-reduce time is set by the per-link rate, so a few
+    large buckets (64 MiB default; the whole model is ~190-375 MB of gradients) beat many small ones.  A parameter
+    whose gradient is None on this rank (e.g. the camera tables in a LiDAR-only step) contributes zeros, so every
+    rank issues identical collectives."""
+    rank, ws = world()
+    params = [p for p in params if p.requires_grad]
+    if ws == 1 or not params:
+        return 0
+    n_collectives = 0
+    bucket, size = [], 0
+
+    def flush():
+        nonlocal bucket, size, n_collectives
+        if not bucket:
+            return
+        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in bucket])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(ws)
+        off = 0
+        for p in bucket:
+            n = p.numel()
+            g = flat[off:off + n].view_as(p).to(p.dtype)
+            if p.grad is None:
+                p.grad = g.clone()
+            else:
+                p.grad.copy_(g)
+            off += n
+        n_collectives += 1
+        bucket, size = [], 0
+
+    for p in params:
+        nbytes = p.numel() * 4
+        if bucket and size + nbytes > bucket_bytes:
+            flush()
+        bucket.append(p)
+        size += nbytes
+    flush()
+    return n_collectives

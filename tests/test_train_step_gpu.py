@@ -1,0 +1,58 @@
+"""GPU: the thin multimodal training step (losses -> backward through the HIP operators -> Adam) learns a synthetic
+target, and the quality metrics agree with their reference formulas."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _batch(S, teacher, dev, n=512, T=48, seed=0):
+    rng = np.random.default_rng(seed)
+    lo, ld = S.lidar_rays(n, rng)
+    co, cd = S.camera_rays(n, rng)
+    t = lambda a: torch.from_numpy(a).to(dev)[None]
+    b = {"rays_o_lidar": t(lo), "rays_d_lidar": t(ld), "rays_o": t(co), "rays_d": t(cd), "time": torch.tensor([[0.5]], device=dev)}
+    with torch.no_grad():
+        rl = teacher.render(b["rays_o_lidar"], b["rays_d_lidar"], b["time"], cal_lidar_color=True, num_steps=T)
+        rc = teacher.render(b["rays_o"], b["rays_d"], b["time"], num_steps=T)
+    b["gt_depth"] = rl["depth_lidar"]
+    b["gt_raydrop"] = (rl["image_lidar"][..., 0] > 0.45).float()
+    b["gt_intensity"] = rl["image_lidar"][..., 1] * b["gt_raydrop"]
+    b["gt_rgb"] = rc["image"]
+    return b
+
+
+def test_training_reduces_loss_and_metrics(dev):
+    from nvsf import synthetic as S
+    from nvsf.nerf.models.network_static import NeRFNetworkStatic
+    from nvsf.nerf.train_step import RenderTrainStep, psnr, depth_rmse
+    kw = dict(bound=S.BOUND, min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH, log2_hashmap_size=14)
+    torch.manual_seed(1)
+    teacher = NeRFNetworkStatic(**kw)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(7)
+        for enc in (teacher.hash_encoder_lidar, teacher.hash_encoder_camera):
+            enc.params.copy_(torch.randn(enc.params.shape, generator=g) * 0.2)
+    teacher = teacher.to(dev).eval()
+    student = NeRFNetworkStatic(**kw).to(dev)
+    step = RenderTrainStep(student, lr=1e-2, iters=400, num_steps=48, use_urf_loss=True)
+    batch = _batch(S, teacher, dev)
+    losses = []
+    for _ in range(120):
+        loss, parts, n_coll = step.step(batch)
+        losses.append(float(loss))
+        assert n_coll == 0  # single process: no collective
+    first, last = float(np.mean(losses[:5])), float(np.mean(losses[-5:]))
+    assert np.isfinite(losses).all() and last < 0.8 * first, (first, last)
+    assert set(parts) == {"depth", "raydrop", "intensity", "los", "rgb"}
+    student.eval()
+    with torch.no_grad():
+        rc = student.render(batch["rays_o"], batch["rays_d"], batch["time"], num_steps=48)
+        rl = student.render(batch["rays_o_lidar"], batch["rays_d_lidar"], batch["time"], cal_lidar_color=True, num_steps=48)
+    p = psnr(rc["image"], batch["gt_rgb"])
+    assert p > 12.0
+    ref = -10 * np.log10(np.mean((rc["image"].cpu().numpy().astype(np.float64) - batch["gt_rgb"].cpu().numpy()) ** 2) + 1e-8)
+    assert abs(p - ref) < 1e-9
+    r = depth_rmse(rl["depth_lidar"], batch["gt_depth"], S.SCALE)
+    assert 0.0 <= r < 80.0

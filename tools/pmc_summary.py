@@ -1,0 +1,37 @@
+"""Summarises rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, CSV output) into
+profiles/<tag>_pmc_traffic.json: mean KB per launch for each kernel, split by launch order where a kernel is
+launched with alternating workloads (LiDAR, camera)."""
+import csv, json, sys, collections
+
+def load(path, counter):
+    rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    per = collections.defaultdict(list)
+    for r in rows:
+        per[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return per
+
+def short(name):
+    for key in ("density_uniform_v2", "density_uniform", "heads_uniformILb1", "heads_uniformILb0", "k_weights_fwd", "k_near_far"):
+        if key in name:
+            return {"heads_uniformILb1": "heads_uniform<lidar>", "heads_uniformILb0": "heads_uniform<camera>"}.get(key, key)
+    return None
+
+fetch, write, out_path = sys.argv[1], sys.argv[2], sys.argv[3]
+f, w = load(fetch, "FETCH_SIZE"), load(write, "WRITE_SIZE")
+out = {"units": "KB per launch (rocprofv3 FETCH_SIZE / WRITE_SIZE; gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x, 4-byte gathers uncalibrated)", "kernels": {}}
+for name in f:
+    s = short(name)
+    if not s:
+        continue
+    fv, wv = f[name], w.get(name, [])
+    entry = {"launches": len(fv), "fetch_kb_mean": sum(fv) / len(fv), "write_kb_mean": (sum(wv) / len(wv)) if wv else None}
+    if s.startswith(("density", "k_weights")) and len(fv) % 2 == 0:  # launched alternately for the LiDAR and the camera batch
+        entry["fetch_kb_lidar"] = sum(fv[0::2]) / (len(fv) // 2)
+        entry["fetch_kb_camera"] = sum(fv[1::2]) / (len(fv) // 2)
+        if wv:
+            entry["write_kb_lidar"] = sum(wv[0::2]) / (len(wv) // 2)
+            entry["write_kb_camera"] = sum(wv[1::2]) / (len(wv) // 2)
+    out["kernels"][s] = entry
+json.dump(out, open(out_path, "w"), indent=1)
+print(json.dumps(out, indent=1))
