@@ -225,6 +225,63 @@ def planes_fwd(xt, planes, res, want=3, C=8):
     return out_s, out_d
 
 
+# ---- composition: occupancy-grid render of the static field (BASELINE config 3) ---------------------
+def _static_field_packed(xyz, dirs, bound, table_f16, spec, w_sigma, lidar, w_head_a, w_head_b):
+    """sigma [M], rgb [M,3] for packed samples (all samples go through the heads; LiDAR = raydrop, intensity, 0)."""
+    M = xyz.shape[0]
+    if M == 0:
+        return np.zeros(0, np.float32), np.zeros((0, 3), np.float32)
+    x01 = ((_f32(xyz) + np.float32(bound)) * np.float32(1.0 / (2.0 * bound))).astype(np.float32)
+    h = mlp_fwd(hashgrid_fwd(x01, (0, 1, 2), table_f16, spec), w_sigma, 32, 32, 1)
+    sigma = np.exp(h[:, 0]).astype(np.float32)
+    geo = h[:, 1:16].astype(np.float16)
+    d01 = ((_f32(dirs) + 1.0) / 2.0).astype(np.float32)
+    rgb = np.zeros((M, 3), np.float32)
+    if lidar:
+        logits = np.concatenate([freq_encode(d01), geo], 1)
+        rgb[:, 0] = sigmoid_f32(mlp_fwd(logits, w_head_a, 87, 96, 2)[:, 0])
+        rgb[:, 1] = sigmoid_f32(mlp_fwd(logits, w_head_b, 87, 96, 2)[:, 0])
+    else:
+        rgb[:] = sigmoid_f32(mlp_fwd(np.concatenate([sh4_encode(d01), geo], 1), w_head_a, 31, 32, 2)[:, :3])
+    return sigma, rgb
+
+
+def render_occupancy_train(rays_o, rays_d, nears, fars, bits, bound, C, H, max_steps, dt_gamma, noises, field, lidar, T_thresh=1e-4, bg=1.0):
+    """march_rays_train -> field -> composite_rays_train (the training-mode sequence of raymarching.py:192-212, 296-306)."""
+    N = rays_o.shape[0]
+    xyz, dirs, deltas, rays, counter = march_rays_train(rays_o, rays_d, bits, bound, dt_gamma, max_steps, C, H, N * max_steps, nears, fars, noises)
+    m = int(counter[0])
+    sigma, rgb = _static_field_packed(xyz[:m], dirs[:m], bound, field[0], field[1], field[2], lidar, field[3], field[4])
+    ws, dp, img = composite_rays_train_forward(sigma, rgb, deltas[:m], rays, T_thresh)
+    if not lidar:
+        img = img + (1.0 - ws)[:, None] * np.float32(bg)
+    return dict(weights_sum=ws, depth=dp, image=img[:, :2] if lidar else img, n_samples=m, rays=rays)
+
+
+def render_occupancy_infer(rays_o, rays_d, nears, fars, bits, bound, C, H, max_steps, dt_gamma, field, lidar, T_thresh=1e-4, bg=1.0):
+    """Evaluation-mode loop: march_rays -> field -> composite_rays on the surviving rays (raymarching.py:389-409, 480-493)."""
+    N = rays_o.shape[0]
+    ws, dp, img = np.zeros(N, np.float32), np.zeros(N, np.float32), np.zeros((N, 3), np.float32)
+    alive, rays_t = np.arange(N, dtype=np.int32), _f32(nears).copy()
+    step = 0
+    while step < max_steps:
+        n_alive = len(alive)
+        if n_alive <= 0:
+            break
+        n_step = max(min(N // n_alive, 8), 1)
+        M = n_alive * n_step
+        M += 128 - M % 128
+        xyz, dirs, deltas = march_rays(n_alive, n_step, alive, rays_t, rays_o, rays_d, bound, dt_gamma, max_steps, C, H, bits, nears, fars,
+                                       np.zeros(n_alive, np.float32), M=M)
+        sigma, rgb = _static_field_packed(xyz, dirs, bound, field[0], field[1], field[2], lidar, field[3], field[4])
+        alive, rays_t, ws, dp, img = composite_rays(n_alive, n_step, T_thresh, alive, rays_t, sigma, rgb, deltas, ws, dp, img)
+        alive = alive[alive >= 0]
+        step += n_step
+    if not lidar:
+        img = img + (1.0 - ws)[:, None] * np.float32(bg)
+    return dict(weights_sum=ws, depth=dp, image=img[:, :2] if lidar else img)
+
+
 # ---- composition: the static-field uniform render (what NeRFNetworkStatic.render computes) --------
 def sigmoid_f32(h):
     x = h.astype(np.float32)
