@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--num-rays", type=int, default=4096)
     ap.add_argument("--num-rays-lidar", type=int, default=4096)
     ap.add_argument("--num-steps", type=int, default=768)
-    ap.add_argument("--cpu-rays", type=int, default=96, help="rays per modality in the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--cpu-rays", type=int, default=320, help="rays per modality in the cpu_baseline sample (~10 s of CPU work; 0 = skip)")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
     ap.add_argument("--train-steps", type=int, default=3, help="extra leg: timed training steps reported under `train` (0 = skip)")
     return ap.parse_args()

@@ -144,6 +144,23 @@ def mlp_forward(x, weights_f16, spec):
     return out
 
 
+def _weight_grad(g, a, rows_per_slice=4096):
+    """dW = g^T a for g [M, out], a [M, in] with M in the millions and out, in <= 128: a GEMM whose reduction
+    dimension is the sample count.  Issued as a batched GEMM over row slices (split-K) with an fp32 sum of the
+    partial products -- a single [out x M] @ [M x in] call leaves most of the chip idle."""
+    M = g.shape[0]
+    n_slices = M // rows_per_slice
+    if n_slices < 8:
+        return (g.t() @ a).float()
+    body = n_slices * rows_per_slice
+    gs = g[:body].view(n_slices, rows_per_slice, g.shape[1])
+    as_ = a[:body].view(n_slices, rows_per_slice, a.shape[1])
+    out = torch.bmm(gs.transpose(1, 2), as_).float().sum(0)
+    if body < M:
+        out = out + (g[body:].t() @ a[body:]).float()
+    return out
+
+
 class MlpFn(Function):
     """out = MLP(x; params).  Forward: one fused MFMA kernel.  Backward: the chain of plain fp16 GEMMs
     (dW_l = dY_l^T A_{l-1}, dA_{l-1} = dY_l W_l) through torch.matmul, with the hidden activations
@@ -171,7 +188,7 @@ class MlpFn(Function):
         g[:, :spec.n_out] = grad_out.to(torch.float16)
         grads = []
         for li in range(len(mats) - 1, -1, -1):
-            grads.append((g.t() @ acts[li]).float())
+            grads.append(_weight_grad(g, acts[li]))
             if li > 0 or ctx.needs_input_grad[0]:
                 g = g @ mats[li]
                 if li > 0:
