@@ -212,6 +212,22 @@ int nvsf_field_heads_uniform_fwd(const float* weights, const void* geo_f16, cons
                                  const void* head_b_weights_f16, uint32_t N, uint32_t T, float w_thresh,
                                  const float* h_bg_color, float* image, nvsf_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Section 5 ("next" rows of SURVEY 8f): loss-side kernel adjacent to the path.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* ref: chamfer_3D.forward, nvsf/nerf/chamfer3D/chamfer_cuda.cpp + chamfer3D.cu:9-165 (NmDistanceKernel x2).
+ * xyz1 [B,n,3], xyz2 [B,m,3] -> dist1 [B,n] (squared distance to the nearest point of xyz2), idx1 int32 [B,n],
+ * dist2 [B,m], idx2 [B,m].  workspace_u64: B*max(n,m) 64-bit words of scratch owned by the caller. */
+int nvsf_chamfer_forward(const float* xyz1, const float* xyz2, uint32_t B, uint32_t n, uint32_t m, float* dist1,
+                         float* dist2, int32_t* idx1, int32_t* idx2, void* workspace_u64, nvsf_stream_t stream);
+
+/* ref: chamfer_3D.backward, chamfer3D.cu:167-234.  grad_xyz1 [B,n,3], grad_xyz2 [B,m,3] zero-initialised by the
+ * caller (dist_chamfer_3D.py:79-80). */
+int nvsf_chamfer_backward(const float* xyz1, const float* xyz2, uint32_t B, uint32_t n, uint32_t m,
+                          const float* grad_dist1, const float* grad_dist2, const int32_t* idx1, const int32_t* idx2,
+                          float* grad_xyz1, float* grad_xyz2, nvsf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -291,3 +291,32 @@ def test_mlp_frequency_sh_against_fp64():
     Y = O.sh4_encode(((u + 1) / 2).astype(np.float32)).astype(np.float64)
     gram = Y.T @ Y / len(u) * 4 * np.pi
     np.testing.assert_allclose(gram, np.eye(16), atol=0.03)
+
+
+def test_chamfer_restatement_against_numpy():
+    import ctypes
+    O.build()
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(GOLD), "..", "oracle", "liboracle_chamfer.so"))
+    rng = np.random.default_rng(9)
+    B, n, m = 2, 300, 170
+    a, b = rng.standard_normal((B, n, 3)).astype(np.float32), rng.standard_normal((B, m, 3)).astype(np.float32)
+    d1, d2 = np.empty((B, n), np.float32), np.empty((B, m), np.float32)
+    i1, i2 = np.empty((B, n), np.int32), np.empty((B, m), np.int32)
+    P = lambda x: x.ctypes.data_as(ctypes.c_void_p)
+    U = ctypes.c_uint32
+    lib.oracle_chamfer_forward(P(a), P(b), U(B), U(n), U(m), P(d1), P(d2), P(i1), P(i2))
+    D = ((a[:, :, None, :].astype(np.float64) - b[:, None, :, :]) ** 2).sum(-1)
+    assert np.array_equal(i1, D.argmin(2)) and np.array_equal(i2, D.argmin(1))
+    np.testing.assert_allclose(d1, D.min(2), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(d2, D.min(1), rtol=1e-5, atol=1e-6)
+    # gradient of sum(g1*d1) + sum(g2*d2) by finite differences on one coordinate
+    g1, g2 = rng.standard_normal((B, n)).astype(np.float32), rng.standard_normal((B, m)).astype(np.float32)
+    ga, gb = np.zeros_like(a), np.zeros_like(b)
+    lib.oracle_chamfer_backward(P(a), P(b), U(B), U(n), U(m), P(g1), P(g2), P(i1), P(i2), P(ga), P(gb))
+    def loss(a_, b_):
+        D_ = ((a_[:, :, None, :].astype(np.float64) - b_[:, None, :, :]) ** 2).sum(-1)
+        return (g1 * D_.min(2)).sum() + (g2 * D_.min(1)).sum()
+    eps = 1e-4
+    ap = a.copy(); ap[1, 17, 2] += eps
+    am = a.copy(); am[1, 17, 2] -= eps
+    np.testing.assert_allclose((loss(ap, b) - loss(am, b)) / (2 * eps), ga[1, 17, 2], rtol=2e-2, atol=2e-3)
