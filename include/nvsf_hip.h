@@ -228,6 +228,16 @@ int nvsf_chamfer_backward(const float* xyz1, const float* xyz2, uint32_t B, uint
                           const float* grad_dist1, const float* grad_dist2, const int32_t* idx1, const int32_t* idx2,
                           float* grad_xyz1, float* grad_xyz2, nvsf_stream_t stream);
 
+/* ref: get_lidar_rays, nvsf/nerf/dataset/dataset_utils.py:369-536 (direction model :506-528).
+ * pose44 device fp32 [4,4] row-major (sensor-to-world); inds device int64 [N] row-major pixel indices of the H x W
+ * range image, or NULL for all pixels 0..N-1; fov_up, fov, fov_hoz in degrees -> rays_o, rays_d [N,3]. */
+int nvsf_lidar_rays(const float* pose44, const int64_t* inds, uint32_t N, uint32_t H, uint32_t W, float fov_up,
+                    float fov, float fov_hoz, float* rays_o, float* rays_d, nvsf_stream_t stream);
+
+/* ref: get_rays, dataset_utils.py:539-687 (pixel centre +0.5, pinhole, normalised, rotated by the pose). */
+int nvsf_camera_rays(const float* pose44, const int64_t* inds, uint32_t N, uint32_t W, float fx, float fy, float cx,
+                     float cy, float* rays_o, float* rays_d, nvsf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -41,6 +41,9 @@ SIGNATURES = {
     "nvsf_mlp_fwd": [_P, _I, _U, _U, _U, _P, _U, _U, _U, _U, _P, _U],
     "nvsf_planes_fwd": [_P, _U, _P, _U, _U, _P, _I, _P, _P],
     "nvsf_planes_bwd": [_P, _U, _P, _U, _U, _P, _I, _P, _P, _P, _P],
+    # section 5: ray generation
+    "nvsf_lidar_rays": [_P, _P, _U, _U, _U, _F, _F, _F, _P, _P],
+    "nvsf_camera_rays": [_P, _P, _U, _U, _F, _F, _F, _F, _P, _P],
     # section 5: chamfer distance
     "nvsf_chamfer_forward": [_P, _P, _U, _U, _U, _P, _P, _P, _P, _P],
     "nvsf_chamfer_backward": [_P, _P, _U, _U, _U, _P, _P, _P, _P, _P, _P],

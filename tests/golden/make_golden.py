@@ -176,6 +176,11 @@ def main():
         gens.update(golden_dynamic.GENERATORS)
     except ImportError:
         pass
+    try:
+        import golden_rays  # device ray generation (row f1)
+        gens.update(golden_rays.GENERATORS)
+    except ImportError:
+        pass
     for name, fn in gens.items():
         if args.only in (None, name):
             fn(mods, HERE)
