@@ -123,6 +123,9 @@ def gen_network(mods, out_dir):
             out[f"{k}_image"], out[f"{k}_depth"] = res["image" + sfx][0].numpy(), res["depth" + sfx][0].numpy()
             out[f"{k}_weights"], out[f"{k}_z_vals"], out[f"{k}_weights_sum"] = res["weights"].numpy(), res["z_vals"].numpy(), res["weights_sum" + sfx].numpy()
     out["pts"] = pts
+    import json
+    with open(os.path.join(out_dir, "network_state_dict_keys.json"), "w") as f:  # checkpoint schema of the reference model (row f4)
+        json.dump({k: list(v.shape) for k, v in net.state_dict().items()}, f, indent=0, sort_keys=True)
     np.savez_compressed(os.path.join(out_dir, "network_dynamic.npz"), **out)
     print("network_dynamic.npz", len(out), "arrays")
 
