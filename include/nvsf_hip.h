@@ -187,6 +187,36 @@ int nvsf_planes_bwd(const float* xt, uint32_t M, const float* planes_cl, uint32_
                     const uint32_t* h_res, int want, const float* grad_static, const float* grad_dynamic,
                     float* grad_planes_cl, float* grad_xt, nvsf_stream_t stream);
 
+/* ref: HashGrid4D.forward_dynamic, nvsf/nerf/models/hash_field.py:148-159 with HashGridT.forward / interpT
+ * (:65-88) for the three coordinate pairs (x,y), (x,z), (y,z): two 2-D hash grids (time slices floor / ceil of
+ * t*(R-1)), linear blend, cubic Lagrange reduction of the 4 features of each of the 8 levels -> [M,24].
+ * x fp32 [M,x_stride] (columns 0..2), optional offset [M,off_stride] whose columns off_col..off_col+2 are added
+ * first (the flow warp of network_dynamic.py:243,259).  h_tables_f16: host array of 6 device pointers (lo slice of
+ * pair 0,1,2, hi slice of pair 0,1,2); h_scales/h_res [3][8], h_offsets [3][9]; h_time = {k2-idx, idx-k1, w0..w3}
+ * (fp32); same_slice != 0 when idx is integral.  mode 0: fp32 arithmetic, out fp32 (tensor t); mode 1: every
+ * product / sum rounded to fp16, out fp16 (0-dim t) -- the two type-promotion regimes of the reference. */
+int nvsf_hashgrid4d_dynamic_fwd(const float* x, uint32_t x_stride, const float* offset, uint32_t off_stride,
+                                uint32_t off_col, uint32_t M, const void* const* h_tables_f16, const float* h_scales,
+                                const uint32_t* h_res, const uint32_t* h_offsets, const float* h_time, int same_slice,
+                                int mode, void* out, nvsf_stream_t stream);
+
+/* ref: FlowField.forward front end, nvsf/nerf/models/flow_field.py:123-128 (grid_enc -> .float() -> interpT):
+ * 3-D hash grid with F = 8 followed by the Lagrange reduction over the 4 feature pairs of each level.
+ * h_weights4 = w0..w3 (fp32, host) -> out fp32 [M, 2L]. */
+int nvsf_hashgrid3d_lagrange_fwd(const float* x, uint32_t x_stride, uint32_t M, const void* table_f16, uint32_t L,
+                                 uint32_t F, const float* h_scales, const uint32_t* h_res, const uint32_t* h_offsets,
+                                 const float* h_weights4, float* out, nvsf_stream_t stream);
+
+/* ref: NeRFNetwork.density tail, nvsf/nerf/models/network_dynamic.py:273-287: blend of current / flow-warped
+ * neighbour features (0.5, 0.25, 0.25), concatenation to 120 features, sigma_net (120 -> 64 -> 16).
+ * plane_* fp32 [M,32]; hash_s fp16 [M,32]; hash_d fp32 [M,24]; hash_1/hash_2 [M,24] fp16 (flag != 0) or fp32.
+ * Either out_h fp32 [M,16] (the 16 network outputs) or, when out_h is NULL, sigmas fp32 [M] = exp(h0) and
+ * geo fp16 [M,16] = (h1..h15, 1.0).  All pointers 16-byte aligned. */
+int nvsf_density_dynamic_fwd(const float* plane_s, const float* plane_d, const float* plane_1, const float* plane_2,
+                             const void* hash_s_f16, const float* hash_d, const void* hash_1, int hash_1_is_f16,
+                             const void* hash_2, int hash_2_is_f16, uint32_t M, const void* sigma_weights_f16,
+                             float* out_h, float* sigmas, void* geo_f16, nvsf_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Section 4: fused kernels of the uniform-sampling render (BASELINE config 2 hot path).
  * ---------------------------------------------------------------------------------------------- */

@@ -1,0 +1,186 @@
+// Fused space-time hash encoder (the dynamic half of HashGrid4D) and the flow-field grid reduction for gfx950.
+// Reference: /root/reference/nvsf/nerf/models/hash_field.py:29-88 (HashGridT), :148-159 (forward_dynamic) and
+// flow_field.py:105-128 -- there: per coordinate pair two tcnn HashGrid launches (the time slices around t), a linear
+// blend, a view/chunk and seven elementwise kernels for the cubic Lagrange reduction, three times per call, three
+// calls per density evaluation (t, t+1, t-1): ~40 launches and ~30 [M,32] temporaries per call.
+// Here: ONE launch per (positions, time): every (sample, pair, level) item gathers its 2 x 4 corners, blends the two
+// slices and reduces its 4 features with the Lagrange weights; results are staged in LDS and leave as whole rows.
+//
+// The reference's arithmetic depends on the operand types PyTorch sees (hash_field.py docstring in this repo):
+//   mode 0 ("tensor t"): blend and reduction in fp32, output fp32;
+//   mode 1 ("0-dim t", the flow-warped neighbour frames): every product and every sum is rounded to fp16.
+// Both are reproduced operation by operation (tests/test_dynamic_gpu.py against fixtures from the reference code).
+#include "hashgrid_device.h"
+
+namespace {
+constexpr int kBlock = 256;
+constexpr int kSamplesPerBlock = 64;
+constexpr int kPlaneLevels = 8;   // HashGridT: n_levels = 8, F = 4, num_basis = 4 (hash_field.py:35-38)
+constexpr int kF = 4;
+
+struct PlaneSet {
+    const _Float16* table_lo[3];  // slice floor(idx) of the pairs (x,y), (x,z), (y,z)
+    const _Float16* table_hi[3];  // slice ceil(idx)
+    GridMeta meta[3];
+    float blend_lo, blend_hi;     // (k2 - idx), (idx - k1)
+    float lag[4];                 // Lagrange weights at t
+    int same_slice;               // idx integral: no blend, the slice features are used as they are (fp16)
+};
+
+__device__ __forceinline__ float r16(float v) { return (float)(_Float16)v; }  // round-trip through fp16
+
+template <int MODE>
+__device__ __forceinline__ float blend_reduce(const float (&f_lo)[kF], const float (&f_hi)[kF], const PlaneSet& ps) {
+    float feat[kF];
+#pragma unroll
+    for (int i = 0; i < kF; ++i) {
+        if (ps.same_slice) feat[i] = f_lo[i];
+        else if (MODE == 0) feat[i] = ps.blend_lo * f_lo[i] + ps.blend_hi * f_hi[i];
+        else feat[i] = r16(r16(ps.blend_lo * f_lo[i]) + r16(ps.blend_hi * f_hi[i]));
+    }
+    float acc;
+    if (MODE == 0) {
+        acc = ps.lag[0] * feat[0];
+#pragma unroll
+        for (int i = 1; i < kF; ++i) acc = acc + ps.lag[i] * feat[i];
+    } else {
+        acc = r16(ps.lag[0] * feat[0]);
+#pragma unroll
+        for (int i = 1; i < kF; ++i) acc = r16(acc + r16(ps.lag[i] * feat[i]));
+    }
+    return acc;
+}
+
+// x' = x[:, 0:3] (+ offset[:, off_col : off_col+3]); out [M, 24]: fp32 (MODE 0) or fp16 (MODE 1)
+template <int MODE>
+__global__ __launch_bounds__(kBlock) void k_hash_dynamic(const float* __restrict__ x, uint32_t x_stride, const float* __restrict__ offset,
+                                                         uint32_t off_stride, uint32_t off_col, uint32_t M, PlaneSet ps,
+                                                         void* __restrict__ out) {
+    __shared__ float stage[kSamplesPerBlock][3 * kPlaneLevels + 1];
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const uint32_t m = blockIdx.x * kSamplesPerBlock + lane;
+    const uint32_t mm = m < M ? m : M - 1;
+    float p[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        p[d] = x[(size_t)mm * x_stride + d];
+        if (offset) p[d] = p[d] + offset[(size_t)mm * off_stride + off_col + d];
+    }
+    for (int item = wave; item < 3 * kPlaneLevels; item += 4) {
+        const int pl = item / kPlaneLevels, l = item - pl * kPlaneLevels;
+        const float xy[2] = {p[pl == 2 ? 1 : 0], p[pl == 0 ? 1 : 2]};
+        const GridMeta& g = ps.meta[pl];
+        const uint32_t rows = g.offset[l + 1] - g.offset[l];
+        float f_lo[kF], f_hi[kF];
+        encode_level<2, kF>(xy, ps.table_lo[pl], g.scale[l], g.res[l], g.offset[l], rows, f_lo);
+#pragma unroll
+        for (int i = 0; i < kF; ++i) f_lo[i] = r16(f_lo[i]);  // the slice encoders return fp16
+        if (!ps.same_slice) {
+            encode_level<2, kF>(xy, ps.table_hi[pl], g.scale[l], g.res[l], g.offset[l], rows, f_hi);
+#pragma unroll
+            for (int i = 0; i < kF; ++i) f_hi[i] = r16(f_hi[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < kF; ++i) f_hi[i] = 0.0f;
+        }
+        stage[lane][item] = blend_reduce<MODE>(f_lo, f_hi, ps);
+    }
+    __syncthreads();
+    const uint32_t n_rows = min((uint32_t)kSamplesPerBlock, M - blockIdx.x * kSamplesPerBlock);
+    constexpr int kOut = 3 * kPlaneLevels;
+    for (uint32_t c = threadIdx.x; c < n_rows * kOut; c += kBlock) {
+        const uint32_t row = c / kOut, col = c - row * kOut;
+        const size_t o = (size_t)(blockIdx.x * kSamplesPerBlock + row) * kOut + col;
+        if (MODE == 0) reinterpret_cast<float*>(out)[o] = stage[row][col];
+        else reinterpret_cast<_Float16*>(out)[o] = (_Float16)stage[row][col];
+    }
+}
+
+// Flow-field front end (flow_field.py:123-128): 3-D grid (L levels, F = 8) -> .float() -> Lagrange reduction over the
+// two groups of 4 features of every level -> fp32 [M, 2 L].
+__global__ __launch_bounds__(kBlock) void k_hash3d_lagrange(const float* __restrict__ x, uint32_t x_stride, uint32_t M,
+                                                            const _Float16* __restrict__ table, uint32_t L, GridMeta meta, float w0, float w1,
+                                                            float w2, float w3, float* __restrict__ out) {
+    extern __shared__ float stage_dyn[];  // [64][2L + 1]
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const uint32_t m = blockIdx.x * kSamplesPerBlock + lane;
+    const uint32_t mm = m < M ? m : M - 1;
+    const uint32_t pitch = 2 * L + 1;
+    const float p[3] = {x[(size_t)mm * x_stride], x[(size_t)mm * x_stride + 1], x[(size_t)mm * x_stride + 2]};
+    const float w[4] = {w0, w1, w2, w3};
+    for (uint32_t l = wave; l < L; l += 4) {
+        float f[8];
+        encode_level<3, 8>(p, table, meta.scale[l], meta.res[l], meta.offset[l], meta.offset[l + 1] - meta.offset[l], f);
+        // x.view(-1, L, 8) chunked into 4 along the feature axis: chunk i = features (2i, 2i+1)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            float acc = w[0] * r16(f[e]);
+#pragma unroll
+            for (int i = 1; i < 4; ++i) acc = acc + w[i] * r16(f[2 * i + e]);
+            stage_dyn[lane * pitch + 2 * l + e] = acc;
+        }
+    }
+    __syncthreads();
+    const uint32_t n_rows = min((uint32_t)kSamplesPerBlock, M - blockIdx.x * kSamplesPerBlock);
+    for (uint32_t c = threadIdx.x; c < n_rows * 2 * L; c += kBlock) {
+        const uint32_t row = c / (2 * L), col = c - row * 2 * L;
+        out[(size_t)(blockIdx.x * kSamplesPerBlock + row) * 2 * L + col] = stage_dyn[row * pitch + col];
+    }
+}
+
+int fill_meta(GridMeta& meta, uint32_t L, const float* scales, const uint32_t* res, const uint32_t* offsets) {
+    if (L == 0 || L > (uint32_t)kMaxLevels || !scales || !res || !offsets) return NVSF_ERR_INVALID_ARG;
+    for (uint32_t l = 0; l < L; ++l) {
+        meta.scale[l] = scales[l];
+        meta.res[l] = res[l];
+        meta.offset[l] = offsets[l];
+        if (offsets[l + 1] <= offsets[l] || res[l] == 0) return NVSF_ERR_INVALID_ARG;
+    }
+    meta.offset[L] = offsets[L];
+    return NVSF_OK;
+}
+}  // namespace
+
+#define REQUIRE(cond) do { if (!(cond)) return NVSF_ERR_INVALID_ARG; } while (0)
+
+// tables: 6 device pointers (lo slice of pair 0,1,2 then hi slice of pair 0,1,2); h_scales / h_res: [3][8];
+// h_offsets: [3][9]; h_time: {blend_lo, blend_hi, w0, w1, w2, w3}
+NVSF_API int nvsf_hashgrid4d_dynamic_fwd(const float* x, uint32_t x_stride, const float* offset, uint32_t off_stride, uint32_t off_col,
+                                         uint32_t M, const void* const* h_tables_f16, const float* h_scales, const uint32_t* h_res,
+                                         const uint32_t* h_offsets, const float* h_time, int same_slice, int mode, void* out,
+                                         hipStream_t stream) {
+    if (M == 0) return NVSF_OK;
+    REQUIRE(x && h_tables_f16 && h_time && out && x_stride >= 3 && (mode == 0 || mode == 1));
+    REQUIRE(!offset || off_stride >= off_col + 3);
+    PlaneSet ps;
+    for (int p = 0; p < 3; ++p) {
+        ps.table_lo[p] = reinterpret_cast<const _Float16*>(h_tables_f16[p]);
+        ps.table_hi[p] = reinterpret_cast<const _Float16*>(h_tables_f16[3 + p]);
+        REQUIRE(ps.table_lo[p] && (same_slice || ps.table_hi[p]));
+        REQUIRE((reinterpret_cast<uintptr_t>(ps.table_lo[p]) & 7u) == 0 && (reinterpret_cast<uintptr_t>(ps.table_hi[p]) & 7u) == 0);
+        const int st = fill_meta(ps.meta[p], kPlaneLevels, h_scales + p * kPlaneLevels, h_res + p * kPlaneLevels, h_offsets + p * (kPlaneLevels + 1));
+        if (st != NVSF_OK) return st;
+    }
+    ps.blend_lo = h_time[0]; ps.blend_hi = h_time[1];
+    for (int i = 0; i < 4; ++i) ps.lag[i] = h_time[2 + i];
+    ps.same_slice = same_slice;
+    const dim3 grid(cdiv(M, kSamplesPerBlock)), block(kBlock);
+    if (mode == 0) hipLaunchKernelGGL(k_hash_dynamic<0>, grid, block, 0, stream, x, x_stride, offset, off_stride, off_col, M, ps, out);
+    else hipLaunchKernelGGL(k_hash_dynamic<1>, grid, block, 0, stream, x, x_stride, offset, off_stride, off_col, M, ps, out);
+    return nvsf_launch_status();
+}
+
+NVSF_API int nvsf_hashgrid3d_lagrange_fwd(const float* x, uint32_t x_stride, uint32_t M, const void* table_f16, uint32_t L, uint32_t F,
+                                          const float* h_scales, const uint32_t* h_res, const uint32_t* h_offsets, const float* h_weights4,
+                                          float* out, hipStream_t stream) {
+    if (M == 0) return NVSF_OK;
+    REQUIRE(x && table_f16 && h_weights4 && out && x_stride >= 3);
+    if (F != 8) return NVSF_ERR_UNSUPPORTED;
+    GridMeta meta;
+    const int st = fill_meta(meta, L, h_scales, h_res, h_offsets);
+    if (st != NVSF_OK) return st;
+    const size_t lds = (size_t)kSamplesPerBlock * (2 * L + 1) * sizeof(float);
+    hipLaunchKernelGGL(k_hash3d_lagrange, dim3(cdiv(M, kSamplesPerBlock)), dim3(kBlock), lds, stream, x, x_stride, M,
+                       reinterpret_cast<const _Float16*>(table_f16), L, meta, h_weights4[0], h_weights4[1], h_weights4[2], h_weights4[3], out);
+    return nvsf_launch_status();
+}

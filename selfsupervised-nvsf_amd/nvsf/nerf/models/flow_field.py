@@ -33,8 +33,23 @@ class FlowField(nn.Module):
         self.mlp = nn.Sequential(*layers)
         torch.nn.init.normal_(self.mlp[-1].weight.data, 0, 0.001)
 
-    def forward(self, xt):
-        """xt: [N, 4] = (x, y, z, t) in [0, 1]; all rows share one t (the reference reads xt[0, 3], :125)."""
+    def forward(self, xt, t_host=None):
+        """xt: [N, 4] = (x, y, z, t) in [0, 1]; all rows share one t (the reference reads xt[0, 3], :125).
+        Without autograd the grid lookup and the Lagrange reduction are one fused kernel (csrc/hashgrid4d.hip);
+        `t_host` (the value of t, if the caller already has it on the host) avoids a device->host read."""
         t = xt[0, 3]
-        feat = self.grid_enc.encode_columns(xt, (0, 1, 2)).float()
-        return self.mlp(lagrange_reduce(feat, t, self.n_levels, self.n_features_per_level, self.num_basis))
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            feat = self.grid_enc.encode_columns(xt, (0, 1, 2)).float()
+            return self.mlp(lagrange_reduce(feat, t, self.n_levels, self.n_features_per_level, self.num_basis))
+        from nvsf import _hip
+        from nvsf.nerf.models.hash_field import lagrange_weights_host
+        if self.n_features_per_level != 8 or self.num_basis != 4:
+            raise NotImplementedError("fused flow grid kernel: 8 features per level, 4 Lagrange nodes")
+        t_host = float(t) if t_host is None else t_host
+        spec = self.grid_enc.spec
+        xt = xt.float().contiguous()
+        M = xt.shape[0]
+        red = torch.empty(M, 2 * spec.L, dtype=torch.float32, device=xt.device)
+        _hip.call("nvsf_hashgrid3d_lagrange_fwd", _hip.ptr(xt), xt.shape[1], M, _hip.ptr(self.grid_enc.table_f16()), spec.L, spec.F,
+                  spec.h_scales, spec.h_res, spec.h_offsets, _hip.host_f32(lagrange_weights_host(t_host, 4, xt.is_cuda)), _hip.ptr(red))
+        return self.mlp(red)

@@ -28,6 +28,25 @@ def _host_time(t):
     return float(t) if not torch.is_tensor(t) else float(t.detach().reshape(-1)[0])
 
 
+def lagrange_weights_host(t_host, num_basis, reciprocal_division):
+    """The values `lagrange_weights` produces, evaluated on the host in fp32.  PyTorch divides a device tensor by a
+    Python scalar as a multiplication by the fp32 reciprocal and a CPU tensor by a true division; both are offered."""
+    t32 = np.float32(t_host)
+    nodes = [i / (num_basis - 1) for i in range(num_basis)]
+    out = []
+    for j in range(num_basis):
+        w = None
+        for m in range(num_basis):
+            if m == j:
+                continue
+            num = np.float32(t32 - np.float32(nodes[m]))
+            den = np.float32(nodes[j] - nodes[m])
+            f = np.float32(num * (np.float32(1.0) / den)) if reciprocal_division else np.float32(num / den)
+            w = f if w is None else np.float32(w * f)
+        out.append(float(w))
+    return out
+
+
 def lagrange_weights(t, num_basis):
     """w_j(t) = prod_{m != j} (t - T_m) / (T_j - T_m), T_m = m / (num_basis - 1); factors multiplied in order of m."""
     nodes = [i / (num_basis - 1) for i in range(num_basis)]
@@ -104,10 +123,43 @@ class HashGrid4D(nn.Module):
     def forward_static(self, x):
         return self.hash_static(x)
 
-    def forward_dynamic(self, x, t):
-        t_host = _host_time(t)
-        return torch.cat([plane(x, t, t_host) for plane in self.hash_dynamic], dim=-1)
+    def forward_dynamic(self, x, t, t_host=None, offset=None, offset_col=0):
+        """Dynamic features [N, 24] at positions x (+ offset[:, offset_col:offset_col+3]).  Without autograd the three
+        planes run as ONE fused kernel (csrc/hashgrid4d.hip); with autograd recording, the per-slice operator path."""
+        t_host = _host_time(t) if t_host is None else t_host
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if offset is not None:
+                x = x + offset[:, offset_col:offset_col + 3]
+            return torch.cat([plane(x, t, t_host) for plane in self.hash_dynamic], dim=-1)
+        return self._forward_dynamic_fused(x, t, t_host, offset, offset_col)
 
-    def forward(self, x, t):
-        static, dynamic = self.forward_static(x), self.forward_dynamic(x, t)
+    def _forward_dynamic_fused(self, x, t, t_host, offset, offset_col):
+        from nvsf import _hip
+        import ctypes
+        first = self.hash_dynamic[0]
+        R, L = first.time_resolution, first.n_levels
+        if L != 8 or first.n_features_per_level != 4 or first.num_basis != 4:
+            raise NotImplementedError("fused HashGridT kernel: 8 levels x 4 features, 4 Lagrange nodes")
+        idx = np.float32(t_host) * np.float32(R - 1)
+        k1, k2 = int(math.floor(idx)), int(math.ceil(idx))
+        fp16_regime = torch.is_tensor(t) and t.dim() == 0  # PyTorch promotion: a 0-dim t keeps the arithmetic in fp16
+        on_device = torch.is_tensor(t) and t.is_cuda
+        lag = lagrange_weights_host(t_host, 4, reciprocal_division=on_device)
+        h_time = _hip.host_f32([float(np.float32(k2) - idx), float(idx - np.float32(k1))] + lag)
+        tables = [pl.hash_t[k1].table_f16() for pl in self.hash_dynamic] + [pl.hash_t[k2].table_f16() for pl in self.hash_dynamic]
+        h_tables = (ctypes.c_void_p * 6)(*[tb.data_ptr() for tb in tables])
+        specs = [pl.hash_t[0].spec for pl in self.hash_dynamic]
+        h_scales = _hip.host_f32([v for s in specs for v in s.scales])
+        h_res = _hip.host_u32([v for s in specs for v in s.res])
+        h_off = _hip.host_u32([v for s in specs for v in s.offsets])
+        x = x.float().contiguous()
+        M = x.shape[0]
+        out = torch.empty(M, 24, dtype=torch.float16 if fp16_regime else torch.float32, device=x.device)
+        off = offset.float().contiguous() if offset is not None else None
+        _hip.call("nvsf_hashgrid4d_dynamic_fwd", _hip.ptr(x), x.shape[1], _hip.ptr(off), off.shape[1] if off is not None else 0,
+                  int(offset_col), M, h_tables, h_scales, h_res, h_off, h_time, 1 if k1 == k2 else 0, 1 if fp16_regime else 0, _hip.ptr(out))
+        return out
+
+    def forward(self, x, t, t_host=None):
+        static, dynamic = self.forward_static(x), self.forward_dynamic(x, t, t_host)
         return [static, dynamic] if self.decompose else torch.cat([static, dynamic], dim=-1)

@@ -21,6 +21,7 @@ import numpy as np
 import torch
 
 import tinycudann as tcnn
+from nvsf import field_ops as ops
 from nvsf.nerf.activation import trunc_exp
 from nvsf.nerf.models.flow_field import FlowField
 from nvsf.nerf.models.hash_field import HashGrid4D, _host_time
@@ -77,25 +78,25 @@ class NeRFNetwork(NeRFRenderer):
         f = self.flow_net(torch.cat([x, t], dim=-1))
         return {"flow_forward": f[:, :3], "flow_backward": f[:, 3:]}
 
-    def density(self, x, t=None, cal_lidar_color=False, **kwargs):
-        x = self._unit_cube(x)
+    def _dynamic_features(self, x, t, cal_lidar_color):
+        """x in [0,1]^3 -> (plane_s, plane_d, plane_1, plane_2, hash_s, hash_d, hash_1, hash_2), network_dynamic.py:220-271."""
         t_host = _host_time(t)  # the one device->host read of this call
         frame_idx = int(np.float32(t_host) * np.float32(self.num_frames - 1))
         hash_enc = self.hash_encoder_lidar if cal_lidar_color else self.hash_encoder_camera
         planes_enc = self.planes_encoder_lidar if cal_lidar_color else self.planes_encoder_camera
 
-        hash_s, hash_d = hash_enc(x, t)
+        hash_s, hash_d = hash_enc(x, t, t_host)
         t_col = t.repeat(x.shape[0], 1) if t.shape[0] == 1 else t
         xt = torch.cat([x, t_col], dim=-1)
         plane_s, plane_d = planes_enc(xt)
-        flow = self.flow_net(xt)
+        flow = self.flow_net(xt, t_host)
 
         def neighbour(offset, frame):
             """dynamic features at the flow-warped position in an adjacent frame (:242-271)"""
             xn = x + offset
             tn = torch.tensor(frame / self.num_frames)
             with torch.no_grad():
-                hn = hash_enc.forward_dynamic(xn, tn)
+                hn = hash_enc.forward_dynamic(xn, tn, float(np.float32(frame / self.num_frames)))
             pn = planes_enc.forward_dynamic(torch.cat([xn, tn.repeat(xn.shape[0], 1).to(xn.device)], dim=-1))
             return hn, pn
 
@@ -105,11 +106,52 @@ class NeRFNetwork(NeRFRenderer):
             hash_1, plane_1 = neighbour(flow[:, :3], frame_idx + 1)
         if frame_idx > 0:
             hash_2, plane_2 = neighbour(flow[:, 3:], frame_idx - 1)
-        plane_d = 0.5 * plane_d + 0.25 * (plane_1 + plane_2)
-        hash_d = 0.5 * hash_d + 0.25 * (hash_1 + hash_2)
+        return plane_s, plane_d, plane_1, plane_2, hash_s, hash_d, hash_1, hash_2
 
-        h = self.sigma_net(torch.cat([plane_s, plane_d, hash_s, hash_d], dim=-1))
+    def density(self, x, t=None, cal_lidar_color=False, **kwargs):
+        plane_s, plane_d, plane_1, plane_2, hash_s, hash_d, hash_1, hash_2 = self._dynamic_features(self._unit_cube(x), t, cal_lidar_color)
+        if not torch.is_grad_enabled():
+            # fused tail (csrc/density_dynamic.hip): neighbour blend + concatenation + density MLP in one kernel
+            h = self._density_tail_fused(plane_s, plane_d, plane_1, plane_2, hash_s, hash_d, hash_1, hash_2)
+        else:
+            plane_d = 0.5 * plane_d + 0.25 * (plane_1 + plane_2)
+            hash_d = 0.5 * hash_d + 0.25 * (hash_1 + hash_2)
+            h = self.sigma_net(torch.cat([plane_s, plane_d, hash_s, hash_d], dim=-1))
         return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
+
+    def fused_uniform_render(self, rays_o, rays_d, nears, fars, T, aabb, noise, cal_lidar_color, bg_host, time=None, **kwargs):
+        """No-autograd render of a uniform ray batch: sampler kernel -> encoders -> fused density tail (sigma + fp16
+        geometry rows) -> weights kernel -> fused heads kernel; masks, per-sample colours and the [M,120] feature matrix are
+        never materialised (renderer_dynamic.NeRFRenderer.run dispatches here)."""
+        N = rays_o.shape[0]
+        z_vals, xyzs = ops.uniform_samples(rays_o, rays_d, nears, fars, T, aabb, noise)
+        feats = self._dynamic_features(self._unit_cube(xyzs.view(-1, 3)), time, cal_lidar_color)
+        sigmas, geo = self._density_tail_fused(*feats, sigma_geo=True)
+        weights, weights_sum, depth = ops.CompositeWeightsFn.apply(sigmas.view(N, T), z_vals, nears, fars, self._k_scale())
+        if cal_lidar_color:
+            image = ops.heads_uniform(weights, geo, rays_d, weights_sum, True, self.raydrop_net.weights_f16(), self.intensity_net.weights_f16(), None)
+        else:
+            image = ops.heads_uniform(weights, geo, rays_d, weights_sum, False, self.color_net.weights_f16(), None, bg_host)
+        return z_vals, weights, weights_sum, depth, image
+
+    def _density_tail_fused(self, plane_s, plane_d, plane_1, plane_2, hash_s, hash_d, hash_1, hash_2, sigma_geo=False):
+        from nvsf import _hip
+        if self.sigma_net.spec.in_cols != 128 or self.sigma_net.spec.n_hidden != 1:
+            raise NotImplementedError("fused density tail: 120 features, one hidden layer")
+        M, dev = plane_s.shape[0], plane_s.device
+        c = lambda a: a.contiguous()
+        hash_d = hash_d.float()
+        args = [_hip.ptr(c(plane_s)), _hip.ptr(c(plane_d)), _hip.ptr(c(plane_1)), _hip.ptr(c(plane_2)), _hip.ptr(c(hash_s)), _hip.ptr(c(hash_d)),
+                _hip.ptr(c(hash_1)), 1 if hash_1.dtype == torch.float16 else 0, _hip.ptr(c(hash_2)), 1 if hash_2.dtype == torch.float16 else 0,
+                M, _hip.ptr(self.sigma_net.weights_f16())]
+        if sigma_geo:
+            sigmas = torch.empty(M, dtype=torch.float32, device=dev)
+            geo = torch.empty(M, 16, dtype=torch.float16, device=dev)
+            _hip.call("nvsf_density_dynamic_fwd", *args, None, _hip.ptr(sigmas), _hip.ptr(geo))
+            return sigmas, geo
+        h = torch.empty(M, 16, dtype=torch.float32, device=dev)
+        _hip.call("nvsf_density_dynamic_fwd", *args, _hip.ptr(h), None, None)
+        return h
 
     def color(self, x, d, cal_lidar_color=False, mask=None, geo_feat=None, **kwargs):
         if mask is not None:
