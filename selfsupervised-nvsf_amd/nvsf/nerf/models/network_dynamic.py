@@ -97,7 +97,10 @@ class NeRFNetwork(NeRFRenderer):
             tn = torch.tensor(frame / self.num_frames)
             with torch.no_grad():
                 hn = hash_enc.forward_dynamic(xn, tn, float(np.float32(frame / self.num_frames)))
-            pn = planes_enc.forward_dynamic(torch.cat([xn, tn.repeat(xn.shape[0], 1).to(xn.device)], dim=-1))
+            # the reference builds this column on the host and copies it (t1.repeat(N, 1).to(device), :250): a pageable
+            # multi-megabyte H2D copy that also drains the stream; the same fp32 value is written on the device instead
+            t_coln = torch.full((xn.shape[0], 1), float(tn), dtype=torch.float32, device=xn.device)
+            pn = planes_enc.forward_dynamic(torch.cat([xn, t_coln], dim=-1))
             return hn, pn
 
         hash_1 = hash_2 = hash_d
