@@ -437,17 +437,18 @@ __global__ __launch_bounds__(kBlock) void k_heads_uniform(const float* __restric
             if (takes_geo && i < T) gv[u] = *reinterpret_cast<const half8_t*>(geo_row + (size_t)i * 16);
         }
     };
+    // software pipeline: the loads of the next iteration are in flight while the current one is evaluated
+    // (a second stage was measured: no gain for the camera head, one wave per SIMD fewer for the LiDAR heads)
     float w_cur[2], w_nxt[2];
     half8_t g_cur[2], g_nxt[2];
     fetch(0, w_cur, g_cur);
     for (uint32_t base = 0; base < T; base += 32) {
-        if (base + 32 < T) fetch(base + 32, w_nxt, g_nxt);
-        const bool on0 = w_cur[0] > w_thresh, on1 = w_cur[1] > w_thresh;  // (out-of-range lanes carry w = 0)
-        const unsigned long long any0 = __ballot(on0), any1 = __ballot(on1);
-        if (any0 | any1) {
-            float4_t oa0 = {0, 0, 0, 0}, oa1 = {0, 0, 0, 0};
-            if (any0) oa0 = net_a.apply(g_cur[0]);
-            if (any1) oa1 = net_a.apply(g_cur[1]);
+        fetch(base + 32, w_nxt, g_nxt);  // out-of-range tiles read nothing and carry w = 0
+        const bool on0 = w_cur[0] > w_thresh, on1 = w_cur[1] > w_thresh;
+        if (__ballot(on0 || on1)) {
+            // both tiles in one basic block: two independent MFMA chains for the scheduler to interleave
+            const float4_t oa0 = net_a.apply(g_cur[0]);
+            const float4_t oa1 = net_a.apply(g_cur[1]);
             if (g == 0) {
 #pragma unroll
                 for (int c = 0; c < C; ++c) {

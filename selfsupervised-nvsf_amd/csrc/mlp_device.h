@@ -51,27 +51,15 @@ __device__ __forceinline__ half8_t load_w_chained(const _Float16* __restrict__ W
 // an INTEGER max against 0 (v_pk_max_i16): an fp16 with the sign bit set is a negative int16.  Rounding is
 // sign-preserving and monotonic, so this equals fp16(max(x, 0)) for every finite x, and it avoids both the
 // per-value fp32 v_max and the canonicalising v_max hipcc puts in front of fmaxf on MFMA results.
-typedef short short2_t __attribute__((ext_vector_type(2)));
-typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ uint32_t relu_pack2(float a, float b) {
-    half2_t h;
-    h[0] = (_Float16)a;
-    h[1] = (_Float16)b;
-    const short2_t zero = {0, 0};
-    const short2_t r = __builtin_elementwise_max(__builtin_bit_cast(short2_t, h), zero);
-    return __builtin_bit_cast(uint32_t, r);
-}
-
-typedef uint32_t uint4_t __attribute__((ext_vector_type(4)));
+typedef short short8_t __attribute__((ext_vector_type(8)));
+typedef float float8_t __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ half8_t relu_pack(float4_t a, float4_t b) {
-    uint4_t v;
-    v[0] = relu_pack2(a[0], a[1]);
-    v[1] = relu_pack2(a[2], a[3]);
-    v[2] = relu_pack2(b[0], b[1]);
-    v[3] = relu_pack2(b[2], b[3]);
-    return __builtin_bit_cast(half8_t, v);
+    // a VECTOR fp32 -> fp16 conversion selects gfx950's v_cvt_pk_f16_f32 (two values per instruction, round-to-nearest-even)
+    const float8_t v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    const half8_t h = __builtin_convertvector(v, half8_t);
+    const short8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    return __builtin_bit_cast(half8_t, __builtin_elementwise_max(__builtin_bit_cast(short8_t, h), zero));
 }
 
 // Hidden layer (64 -> 64) on register-resident activations.
