@@ -184,12 +184,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the NVSF hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # NVSF_BENCH_SAME_DEVICE=1 is a control-flow check for 1-GPU boxes: every rank uses cuda:0 and the (timing /
+    # gradient) collectives run over gloo.  The numbers of such a run are meaningless; the default is one GPU per rank.
+    same_device = os.environ.get("NVSF_BENCH_SAME_DEVICE", "0") == "1"
+    dev_index = 0 if same_device else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)  # RCCL
+        if same_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # RCCL
 
     import build as nvsf_build
     if rank == 0:
@@ -249,6 +256,8 @@ def main():
                        "pass": "forward render (no_grad), fused kernels", "parallelism": f"frame-sharded x{world}, no collective"},
             "outputs_finite": finite,
         }
+        if same_device:
+            line["invalid"] = "NVSF_BENCH_SAME_DEVICE=1: all ranks shared cuda:0 (control-flow check only)"
         if not args.no_kernel_breakdown:
             rows = kernel_breakdown(model, {"lidar": (tl[0][0], tl[1][0], True), "camera": (tc[0][0], tc[1][0], False)}, T,
                                     max(5, args.steps))
