@@ -75,8 +75,10 @@ def kernel_breakdown(model, batches, T, iters):
         else:
             from nvsf.nerf.raymarching import raymarching
             nears, fars = raymarching.near_far_from_aabb(o, d, model.aabb_infer, model.min_near)
-        dens = lambda: ops.density_uniform(o, d, nears, fars, T, model._aabb_host, float(model.bound), enc.table_f16(), enc.spec,
-                                           model.sigma_net.weights_f16())
+        ray_length = float(model.lidar_max_depth - model.min_near_lidar) if lidar else 2.0 * float(model.bound)
+        sliced = ops.prefer_sliced(enc.spec, N, T, ray_length, float(model.bound))  # the choice model.render makes
+        dargs = (o, d, nears, fars, T, model._aabb_host, float(model.bound), enc.table_f16(), enc.spec, model.sigma_net.weights_f16())
+        dens = lambda: ops.density_uniform(*dargs, sliced=sliced)
         z, sig, geo = dens()
         comp = lambda: ops.CompositeWeightsFn.apply(sig, z, nears, fars, model._k_scale())
         w, ws, dp = comp()
@@ -88,8 +90,19 @@ def kernel_breakdown(model, batches, T, iters):
             head_flops = 14336
         active = float((w > ops.W_THRESH).float().mean())
         t_d, t_c, t_h = event_time_ms(dens, iters), event_time_ms(comp, iters), event_time_ms(heads, iters)
-        rows.append(dict(kernel=f"density_uniform[{name}]", ms=t_d, bound="hbm", unit="GB/s", achieved=588.0 * M / t_d / 1e6,
-                         peak=HBM_PEAK_GBS, per_unit="588 B/sample", units=M))
+        if sliced:
+            # two launches (levels partitioned over the XCDs + streaming MLP pass), timed separately on shared buffers;
+            # the 64 B/sample scratch round trip is extra traffic of this formulation and is counted in its bytes
+            bufs = ops.density_uniform(*dargs, sliced=True, _buffers=(z, sig, geo, torch.empty(enc.spec.L, M, dtype=torch.int32, device=o.device)))
+            t_a = event_time_ms(lambda: ops.density_uniform(*dargs, sliced=True, _passes=1, _buffers=bufs), iters)
+            t_b = event_time_ms(lambda: ops.density_uniform(*dargs, sliced=True, _passes=2, _buffers=bufs), iters)
+            rows.append(dict(kernel=f"density_encode_sliced[{name}]", ms=t_a, bound="hbm", unit="GB/s", achieved=580.0 * M / t_a / 1e6,
+                             peak=HBM_PEAK_GBS, per_unit="580 B/sample (512 gathered + 64 features + 4 z written)", units=M))
+            rows.append(dict(kernel=f"density_from_features[{name}]", ms=t_b, bound="hbm", unit="GB/s", achieved=100.0 * M / t_b / 1e6,
+                             peak=HBM_PEAK_GBS, per_unit="100 B/sample (64 features read; 32 geo + 4 sigma written)", units=M))
+        else:
+            rows.append(dict(kernel=f"density_uniform[{name}]", ms=t_d, bound="hbm", unit="GB/s", achieved=588.0 * M / t_d / 1e6,
+                             peak=HBM_PEAK_GBS, per_unit="588 B/sample", units=M))
         rows.append(dict(kernel=f"composite_weights[{name}]", ms=t_c, bound="hbm", unit="GB/s", achieved=12.0 * M / t_c / 1e6,
                          peak=HBM_PEAK_GBS, per_unit="12 B/sample (sigma, z read; weights written)", units=M))
         rows.append(dict(kernel=f"heads_uniform[{name}]", ms=t_h, bound="mfma", unit="TFLOP/s",
@@ -110,12 +123,17 @@ def pmc_traffic(kernel_label):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     if not files:
         return {"traffic": None}
-    k = json.load(open(files[-1]))["kernels"].get("density_uniform_v2")
+    ks = json.load(open(files[-1]))["kernels"]
     which = "camera" if "camera" in kernel_label else "lidar"
-    if not kernel_label.startswith("density") or not k or f"fetch_kb_{which}" not in k:
-        return {"traffic": None}
-    return {"traffic": (2.0 * k[f"fetch_kb_{which}"] + k[f"write_kb_{which}"]) * 1024.0,
-            "traffic_source": os.path.relpath(files[-1], ROOT) + " (2*FETCH_SIZE + WRITE_SIZE, bytes per launch)"}
+    src = os.path.relpath(files[-1], ROOT) + " (2*FETCH_SIZE + WRITE_SIZE, bytes per launch)"
+    if kernel_label.startswith("density_encode_sliced") and "encode_sliced" in ks:  # launched for one batch kind only
+        k = ks["encode_sliced"]
+        return {"traffic": (2.0 * k["fetch_kb_mean"] + k["write_kb_mean"]) * 1024.0, "traffic_source": src}
+    k = ks.get("density_uniform_v2")
+    if kernel_label.startswith("density_uniform") and k:
+        f, w = k.get(f"fetch_kb_{which}", k["fetch_kb_mean"]), k.get(f"write_kb_{which}", k["write_kb_mean"])
+        return {"traffic": (2.0 * f + w) * 1024.0, "traffic_source": src}
+    return {"traffic": None}
 
 
 def cpu_baseline(model, T, n_rays, seed=1234):

@@ -232,6 +232,22 @@ int nvsf_field_density_uniform_fwd(const float* rays_o, const float* rays_d, con
                                    const void* sigma_weights_f16, float* z_vals, float* sigmas, void* geo_f16,
                                    nvsf_stream_t stream);
 
+/* Same operator, same results bit for bit, as two launches with the LEVELS partitioned over the 8 XCDs (each
+ * XCD's L2 then holds 2 of the 16 levels): pays when consecutive samples of a ray are several finest-level cells
+ * apart, i.e. when the fine levels have no reuse along the ray (camera rays through the whole box).
+ * feat_scratch: device buffer of 4 * L * N * T bytes (encoded features, written and read once).
+ * passes: 3 = both launches; 1 = encode only (fills feat_scratch and z_vals), 2 = MLP only (reads feat_scratch) --
+ * the split exists so that each launch can be timed on its own.
+ * Requires L == 16, F == 2, N*T < 2^32; NVSF_ERR_UNSUPPORTED otherwise. */
+int nvsf_field_density_uniform_sliced_fwd(const float* rays_o, const float* rays_d, const float* nears,
+                                          const float* fars, const float* lin, const float* noise,
+                                          const float* h_aabb, float bound, uint32_t N, uint32_t T,
+                                          const void* table_f16, uint32_t L, uint32_t F, const float* h_scales,
+                                          const uint32_t* h_res, const uint32_t* h_offsets,
+                                          const void* sigma_weights_f16, float* z_vals, float* sigmas,
+                                          void* geo_f16, void* feat_scratch, uint32_t passes,
+                                          nvsf_stream_t stream);
+
 /* ref: renderer_dynamic.py:202-237 + network_dynamic.py:290-332.  Direction encoding (per ray), heads,
  * sigmoid, weight mask (w > w_thresh) and image accumulation in one kernel.
  * lidar == 0: head_a = colour net [SH16|geo15|1] 32->64->64->3;  image [N,3] (+ (1-ws)*h_bg_color[3])

@@ -328,6 +328,217 @@ __global__ __launch_bounds__(kBlock) void k_density_uniform_v2(RayBatch rb, cons
 }
 
 // ------------------------------------------------------------------------------------------------
+// Density, level-sliced formulation (two launches; same arithmetic, bit-identical results).
+//
+// Why: with a 23 MB table every XCD's 4 MiB L2 sees all 16 levels; when consecutive samples of a ray are several
+// finest-level cells apart (camera rays through the whole box) the fine levels have no reuse along the ray and most
+// of their gathers miss L2 (measured: 3.8 GB of L2 fills per launch for 1.85 GB of algorithmic bytes).  Here the
+// LEVELS are partitioned over the XCDs instead: workgroups are dealt round-robin over the 8 XCDs, so all blocks with
+// equal (blockIdx.x & 7) share one L2; such a block group encodes only two levels (slice 2g: {g, g+12}, slice 2g+1:
+// {g+4, g+8}; at most ~4 MB of table per L2) for ALL samples and writes the two encoded half2 per sample to
+// its scratch plane [slice][M] of uint2 (64 B/sample over the 8 planes, written and read once, full lines).  A second
+// streaming kernel turns 32 features -> sigma MLP -> sigma / geo; its lane group g reads planes 2g and 2g+1, i.e.
+// levels {g, g+4, g+8, g+12} -- the assignment of the fused kernel, so the MFMA sums in the same order (bit-identical).  If the dispatcher placed blocks differently the result is the same,
+// only slower.
+template <int F>
+struct SliceLevel {
+    float scale;
+    uint32_t res, res2, boff, rows;
+    bool hashed;
+};
+
+template <int F>
+__device__ __forceinline__ void slice_issue(const SliceLevel<F>& lv, __amdgpu_buffer_rsrc_t rsrc, const float (&x)[3], float (&frac)[3],
+                                            uint32_t (&raw)[8]) {
+    uint32_t c[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float pos = fmaf(lv.scale, x[d], 0.5f);
+        const float fl = floorf(pos);
+        frac[d] = pos - fl;
+        c[d] = (uint32_t)(int32_t)fl;
+    }
+    uint32_t idx[8];
+    if (!lv.hashed) {  // block-uniform
+        const uint32_t b00 = c[0] + c[1] * lv.res + c[2] * lv.res2;
+        const uint32_t b10 = b00 + lv.res, b01 = b00 + lv.res2, b11 = b10 + lv.res2;
+        const uint32_t base[4] = {b00, b10, b01, b11};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            uint32_t v = base[k >> 1] + (uint32_t)(k & 1);
+            idx[k] = v >= lv.rows ? v - lv.rows : v;
+        }
+    } else {
+        const uint32_t hy0 = c[1] * 2654435761u, hy1 = hy0 + 2654435761u;
+        const uint32_t hz0 = c[2] * 805459861u, hz1 = hz0 + 805459861u;
+        const uint32_t yz[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+        const uint32_t mask = lv.rows - 1u;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) idx[k] = ((c[0] + (uint32_t)(k & 1)) ^ yz[k >> 1]) & mask;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) raw[k] = gather_raw<F>(rsrc, lv.boff + idx[k] * (uint32_t)(F * sizeof(_Float16)));
+}
+
+__device__ __forceinline__ uint32_t slice_blend(const float (&frac)[3], const uint32_t (&raw)[8]) {
+    const float fx = frac[0], fy = frac[1], fz = frac[2];
+    const float wx[2] = {1.0f - fx, fx}, wy[2] = {1.0f - fy, fy}, wz[2] = {1.0f - fz, fz};
+    float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float w = (wx[k & 1] * wy[(k >> 1) & 1]) * wz[k >> 2];
+        const h2_t v = __builtin_bit_cast(h2_t, raw[k]);
+        a0 = fmaf(w, (float)v[0], a0);
+        a1 = fmaf(w, (float)v[1], a1);
+    }
+    h2_t o;
+    o[0] = (_Float16)a0;
+    o[1] = (_Float16)a1;
+    return __builtin_bit_cast(uint32_t, o);
+}
+
+// pass A: grid = 8 * blocks_per_slice; a wave encodes 64 consecutive samples (one per lane) for the slice's two levels.
+template <int F, bool UNIFORM_RAY>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_encode_sliced(RayBatch rb, const _Float16* __restrict__ table, uint32_t table_bytes, GridMeta meta,
+                                                          uint32_t L, uint32_t first_hashed, uint32_t M,
+                                                          float* __restrict__ z_vals, uint2* __restrict__ feat) {
+    static_assert(F == 2, "F = 2 only");
+    const uint32_t slice = blockIdx.x & 7u, sb = blockIdx.x >> 3, n_sb = gridDim.x >> 3;
+    const uint32_t grp = slice >> 1;
+    const uint32_t lvl[2] = {(slice & 1u) ? grp + 4u : grp, (slice & 1u) ? grp + 8u : grp + 12u};
+    SliceLevel<F> lv[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const uint32_t l = lvl[a];
+        lv[a].scale = meta.scale[l];
+        lv[a].res = meta.res[l];
+        lv[a].res2 = meta.res[l] * meta.res[l];
+        lv[a].boff = meta.offset[l] * (uint32_t)(F * sizeof(_Float16));
+        lv[a].rows = meta.offset[l + 1] - meta.offset[l];
+        lv[a].hashed = l >= first_hashed;
+    }
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(table), 0, (int)table_bytes, 0x00020000);
+    const int lane = lane_id();
+    const uint32_t n_units = (M + 63u) / 64u;
+    const uint32_t wave = sb * kWavesPerBlock + (threadIdx.x >> 6), wave_count = n_sb * kWavesPerBlock;
+    // The ray record and lin[] of the NEXT unit are fetched while the current unit's gathers are in flight.
+    struct Unit {
+        uint32_t s, n;
+        bool in_range;
+        float near, far, lin, noise, o[3], d[3];
+    };
+    auto fetch = [&](uint32_t unit) {
+        Unit u;
+        const uint32_t s_raw = unit * 64u + (uint32_t)lane;
+        u.in_range = s_raw < M;
+        u.s = u.in_range ? s_raw : M - 1u;
+        if constexpr (UNIFORM_RAY) u.n = __builtin_amdgcn_readfirstlane((unit * 64u) / rb.T);  // T % 64 == 0: scalar ray loads
+        else u.n = u.s / rb.T;
+        const uint32_t i = u.s - u.n * rb.T;
+        u.near = rb.nears[u.n];
+        u.far = rb.fars[u.n];
+        u.lin = rb.lin[i];
+        u.noise = rb.noise ? rb.noise[u.s] : 0.5f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            u.o[k] = rb.rays_o[3 * (size_t)u.n + k];
+            u.d[k] = rb.rays_d[3 * (size_t)u.n + k];
+        }
+        return u;
+    };
+    if (wave >= n_units) return;
+    Unit cur = fetch(wave);
+    for (uint32_t unit = wave; unit < n_units; unit += wave_count) {
+        const uint32_t next = unit + wave_count < n_units ? unit + wave_count : unit;
+        const Unit nxt = fetch(next);
+        const float range = cur.far - cur.near;
+        float z = cur.near + range * cur.lin;
+        if (rb.noise) z = z + (cur.noise - 0.5f) * (range / (float)rb.T);
+        float x[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float p = cur.o[k] + cur.d[k] * z;
+            p = fminf(fmaxf(p, rb.lo[k]), rb.hi[k]);
+            x[k] = (p + rb.bound) * rb.inv_extent;
+        }
+        float frac[2][3];
+        uint32_t raw[2][8];
+        slice_issue<F>(lv[0], rsrc, x, frac[0], raw[0]);
+        slice_issue<F>(lv[1], rsrc, x, frac[1], raw[1]);
+        const uint32_t f0 = slice_blend(frac[0], raw[0]);
+        const uint32_t f1 = slice_blend(frac[1], raw[1]);
+        if (cur.in_range) {
+            feat[(size_t)slice * M + cur.s] = make_uint2(f0, f1);
+            if (slice == 0u) z_vals[cur.s] = z;
+        }
+        cur = nxt;
+    }
+}
+
+// pass B: 32 encoded features per sample (scratch planes) -> sigma MLP -> sigma, geo.
+template <int F>
+__global__ __launch_bounds__(kBlock) void k_density_from_features(const uint2* __restrict__ feat, uint32_t M, uint32_t L,
+                                                                  const _Float16* __restrict__ w_sigma, float* __restrict__ sigmas,
+                                                                  _Float16* __restrict__ geo) {
+    static_assert(F == 2, "F = 2 only");
+    const int lane = lane_id(), g = lane >> 4, sl = lane & 15;
+    const uint32_t lv4[4] = {(uint32_t)g, (uint32_t)g + 4u, (uint32_t)g + 8u, (uint32_t)g + 12u};  // as in k_density_uniform_v2
+    half8_t w0[kHidTiles];
+#pragma unroll
+    for (int t = 0; t < kHidTiles; ++t) {
+        const _Float16* row = w_sigma + (size_t)(16 * t + sl) * 32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int f = 0; f < F; ++f) w0[t][i * F + f] = row[lv4[i] * F + f];
+    }
+    OutLayerW wout;
+    wout.load(w_sigma + kHidden * 32, lane, 1);
+    const uint2* plane0 = feat + (size_t)(2 * g) * M;
+    const uint2* plane1 = feat + (size_t)(2 * g + 1) * M;
+    const uint32_t n_tiles = (M + 15u) / 16u;
+    const uint32_t wave = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6), wave_count = gridDim.x * kWavesPerBlock;
+    constexpr int U = 4;  // tiles per iteration (independent load / MFMA chains)
+    for (uint32_t tile0 = wave * U; tile0 < n_tiles; tile0 += wave_count * U) {
+        uint2 w[U][2];
+        uint32_t s[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t s_raw = (tile0 + u) * 16u + (uint32_t)sl;
+            ok[u] = s_raw < M;
+            s[u] = ok[u] ? s_raw : M - 1u;
+            w[u][0] = plane0[s[u]];
+            w[u][1] = plane1[s[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
+            const u4_t packed = {w[u][0].x, w[u][1].x, w[u][1].y, w[u][0].y};
+            const half8_t xf = __builtin_bit_cast(half8_t, packed);
+            float4_t acc1[kHidTiles];
+#pragma unroll
+            for (int t = 0; t < kHidTiles; ++t) {
+                const float4_t zero = {0, 0, 0, 0};
+                acc1[t] = mfma16(w0[t], xf, zero);
+            }
+            half8_t h[kHidSteps];
+            pack_hidden(acc1, h);
+            const float4_t o = wout.apply(h);
+            if (ok[u]) {
+                half4_t ov;
+                ov[0] = (_Float16)o[0]; ov[1] = (_Float16)o[1]; ov[2] = (_Float16)o[2]; ov[3] = (_Float16)o[3];
+                if (g == 3) {
+                    sigmas[s[u]] = expf(o[3]);
+                    ov[3] = (_Float16)1.0f;
+                }
+                *reinterpret_cast<half4_t*>(geo + (size_t)s[u] * 16 + 4 * g) = ov;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Heads + image accumulation, one wave per ray.
 //   LIDAR = false : colour net  [SH16(d) | geo15 | 1] (32)  -> 64 -> 64 -> 3 (padded 16)
 //   LIDAR = true  : raydrop net and intensity net  [Freq72(d) | geo15 | 1 x 9] (96) -> 64 -> 64 -> 1;
@@ -485,11 +696,11 @@ int fill_meta(GridMeta& meta, uint32_t L, const float* scales, const uint32_t* r
 
 #define REQUIRE(cond) do { if (!(cond)) return NVSF_ERR_INVALID_ARG; } while (0)
 
-NVSF_API int nvsf_field_density_uniform_fwd(const float* rays_o, const float* rays_d, const float* nears, const float* fars,
-                                            const float* lin, const float* noise, const float* h_aabb, float bound, uint32_t N,
-                                            uint32_t T, const void* table_f16, uint32_t L, uint32_t F, const float* h_scales,
-                                            const uint32_t* h_res, const uint32_t* h_offsets, const void* sigma_weights_f16,
-                                            float* z_vals, float* sigmas, void* geo_f16, hipStream_t stream) {
+static int density_uniform_impl(const float* rays_o, const float* rays_d, const float* nears, const float* fars,
+                                const float* lin, const float* noise, const float* h_aabb, float bound, uint32_t N,
+                                uint32_t T, const void* table_f16, uint32_t L, uint32_t F, const float* h_scales,
+                                const uint32_t* h_res, const uint32_t* h_offsets, const void* sigma_weights_f16,
+                                float* z_vals, float* sigmas, void* geo_f16, void* feat_scratch, uint32_t sliced_passes, hipStream_t stream) {
     if (N == 0 || T == 0) return NVSF_OK;
     REQUIRE(rays_o && rays_d && nears && fars && lin && h_aabb && table_f16 && sigma_weights_f16 && z_vals && sigmas && geo_f16);
     REQUIRE(bound > 0.0f);
@@ -522,6 +733,28 @@ NVSF_API int nvsf_field_density_uniform_fwd(const float* rays_o, const float* ra
         if (hashed && ((h_offsets[l + 1] - h_offsets[l]) & (h_offsets[l + 1] - h_offsets[l] - 1u)) != 0u) monotone = false;
     }
     const unsigned long long table_bytes = (unsigned long long)h_offsets[L] * F * sizeof(_Float16);
+    if (sliced_passes) {
+        const unsigned long long total = (unsigned long long)N * T;
+        if (!(F == 2 && L == 16 && monotone && table_bytes < (1ull << 31) && total < (1ull << 32))) return NVSF_ERR_UNSUPPORTED;
+        REQUIRE(feat_scratch && (reinterpret_cast<uintptr_t>(feat_scratch) & 15u) == 0);
+        const uint32_t M = (uint32_t)total;
+        uint2* fp = reinterpret_cast<uint2*>(feat_scratch);
+        const uint32_t units = (M + 63u) / 64u;
+        uint32_t per_slice = (units + kWavesPerBlock - 1) / kWavesPerBlock;
+        if (per_slice > 512u) per_slice = 512u;  // 32 CUs per XCD x 8 resident workgroups x 2 (measured: 256 -> 512 gains 1.5 %)
+        if (!(sliced_passes & 1u)) {
+        } else if (T % 64u == 0u)
+            hipLaunchKernelGGL((k_encode_sliced<2, true>), dim3(8u * per_slice), dim3(kBlock), 0, stream, rb, tb, (uint32_t)table_bytes, meta, L,
+                               first_hashed, M, z_vals, fp);
+        else
+            hipLaunchKernelGGL((k_encode_sliced<2, false>), dim3(8u * per_slice), dim3(kBlock), 0, stream, rb, tb, (uint32_t)table_bytes, meta, L,
+                               first_hashed, M, z_vals, fp);
+        const uint32_t tiles = (M + 15u) / 16u;
+        uint32_t bb = (tiles + 4u * kWavesPerBlock - 1u) / (4u * kWavesPerBlock);
+        if (bb > 4096u) bb = 4096u;
+        if (sliced_passes & 2u) hipLaunchKernelGGL(k_density_from_features<2>, dim3(bb), dim3(kBlock), 0, stream, fp, M, L, ws, sigmas, gp);
+        return nvsf_launch_status();
+    }
     const char* variant = getenv("NVSF_DENSITY_KERNEL");  // "1" forces the first formulation (A/B timing)
     const bool use_v2 = F == 2 && monotone && table_bytes < (1ull << 31) && !(variant && variant[0] == '1');
     if (use_v2) {
@@ -541,6 +774,26 @@ NVSF_API int nvsf_field_density_uniform_fwd(const float* rays_o, const float* ra
     else if (F == 2) hipLaunchKernelGGL(k_density_uniform<2>, dim3(blocks), dim3(kBlock), 0, stream, rb, tb, meta, ws, z_vals, sigmas, gp);
     else hipLaunchKernelGGL(k_density_uniform<4>, dim3(blocks), dim3(kBlock), 0, stream, rb, tb, meta, ws, z_vals, sigmas, gp);
     return nvsf_launch_status();
+}
+
+NVSF_API int nvsf_field_density_uniform_fwd(const float* rays_o, const float* rays_d, const float* nears, const float* fars,
+                                            const float* lin, const float* noise, const float* h_aabb, float bound, uint32_t N,
+                                            uint32_t T, const void* table_f16, uint32_t L, uint32_t F, const float* h_scales,
+                                            const uint32_t* h_res, const uint32_t* h_offsets, const void* sigma_weights_f16,
+                                            float* z_vals, float* sigmas, void* geo_f16, hipStream_t stream) {
+    return density_uniform_impl(rays_o, rays_d, nears, fars, lin, noise, h_aabb, bound, N, T, table_f16, L, F, h_scales, h_res, h_offsets,
+                                sigma_weights_f16, z_vals, sigmas, geo_f16, nullptr, 0u, stream);
+}
+
+NVSF_API int nvsf_field_density_uniform_sliced_fwd(const float* rays_o, const float* rays_d, const float* nears, const float* fars,
+                                                   const float* lin, const float* noise, const float* h_aabb, float bound, uint32_t N,
+                                                   uint32_t T, const void* table_f16, uint32_t L, uint32_t F, const float* h_scales,
+                                                   const uint32_t* h_res, const uint32_t* h_offsets, const void* sigma_weights_f16,
+                                                   float* z_vals, float* sigmas, void* geo_f16, void* feat_scratch, uint32_t passes,
+                                                   hipStream_t stream) {
+    if (passes == 0u || passes > 3u) return NVSF_ERR_INVALID_ARG;
+    return density_uniform_impl(rays_o, rays_d, nears, fars, lin, noise, h_aabb, bound, N, T, table_f16, L, F, h_scales, h_res, h_offsets,
+                                sigma_weights_f16, z_vals, sigmas, geo_f16, feat_scratch, passes, stream);
 }
 
 NVSF_API int nvsf_field_heads_uniform_fwd(const float* weights, const void* geo_f16, const float* rays_d, const float* weights_sum,

@@ -78,8 +78,11 @@ class NeRFNetworkStatic(NeRFRenderer):
     def fused_uniform_render(self, rays_o, rays_d, nears, fars, T, aabb, noise, cal_lidar_color, bg_host, **kwargs):
         enc = self.hash_encoder_lidar if cal_lidar_color else self.hash_encoder_camera
         aabb_host = self._aabb_host  # host copy of the (constant) box: no device->host read on the hot path
+        # host-side estimate of far - near: exact for LiDAR (constant range), the box side for camera rays (AABB exit)
+        ray_length = float(self.lidar_max_depth - self.min_near_lidar) if cal_lidar_color else 2.0 * float(self.bound)
+        sliced = ops.prefer_sliced(enc.spec, rays_o.shape[0], T, ray_length, float(self.bound))
         z_vals, sigmas, geo = ops.density_uniform(rays_o, rays_d, nears, fars, T, aabb_host, float(self.bound), enc.table_f16(),
-                                                  enc.spec, self.sigma_net.weights_f16(), noise)
+                                                  enc.spec, self.sigma_net.weights_f16(), noise, sliced=sliced)
         weights, weights_sum, depth = ops.CompositeWeightsFn.apply(sigmas, z_vals, nears, fars, self._k_scale())
         if cal_lidar_color:
             image = ops.heads_uniform(weights, geo, rays_d, weights_sum, True, self.raydrop_net.weights_f16(),

@@ -1,0 +1,93 @@
+"""The level-sliced formulation of the fused density operator (nvsf_field_density_uniform_sliced_fwd: levels
+partitioned over the XCDs + a streaming MLP pass) must reproduce the single-launch kernel bit for bit -- same
+per-lane arithmetic, same MFMA operand order -- and therefore inherits its parity with the oracle
+(test_render_static_gpu.py).  Also covers the host-side choice between the two and the argument checks."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from test_render_static_gpu import _model, _oracle, _t
+
+
+def _batch(m, dev, lidar, N, rng):
+    from nvsf import synthetic as S
+    from nvsf.nerf.raymarching import raymarching
+    o, d = (S.lidar_rays if lidar else S.camera_rays)(N, rng)
+    o, d = _t(o, dev), _t(d, dev)
+    if lidar:
+        nears = torch.full((N,), float(m.min_near_lidar), device=dev)
+        fars = torch.full((N,), float(m.lidar_max_depth), device=dev)
+    else:
+        nears, fars = raymarching.near_far_from_aabb(o, d, m.aabb_infer, m.min_near)
+    return o, d, nears, fars
+
+
+@pytest.mark.parametrize("lidar", [True, False])
+@pytest.mark.parametrize("N,T,noise", [(64, 128, False), (37, 100, True), (1, 16, False), (300, 768, True), (5, 7, False)])
+def test_sliced_equals_fused_bitwise(dev, lidar, N, T, noise):
+    """T % 64 == 0 (wave-uniform rays) and ragged T, with and without perturbation, tiny and multi-block sizes."""
+    from nvsf import field_ops as ops
+    m = _model(dev, 0.1)
+    rng = np.random.default_rng(11)
+    o, d, nears, fars = _batch(m, dev, lidar, N, rng)
+    nz = torch.rand(N, T, device=dev) if noise else None
+    enc = m.hash_encoder_lidar if lidar else m.hash_encoder_camera
+    args = (o, d, nears, fars, T, m._aabb_host, float(m.bound), enc.table_f16(), enc.spec, m.sigma_net.weights_f16(), nz)
+    a = ops.density_uniform(*args, sliced=False)
+    b = ops.density_uniform(*args, sliced=True)
+    for x, y, name in zip(a, b, ("z_vals", "sigmas", "geo")):
+        assert torch.equal(x, y), name
+
+
+def test_sliced_render_matches_oracle(dev, monkeypatch):
+    """Whole camera render through the sliced path (forced) against the CPU oracle composition, 1e-4."""
+    from nvsf import synthetic as S
+    monkeypatch.setenv("NVSF_DENSITY_SLICED", "1")
+    m = _model(dev, 0.1)
+    rng = np.random.default_rng(13)
+    N, T = 160, 128
+    o, d = S.camera_rays(N, rng)
+    ref = _oracle(m, o, d, False, T)
+    with torch.no_grad():
+        out = m.render(_t(o, dev)[None], _t(d, dev)[None], torch.tensor([[0.5]], device=dev), cal_lidar_color=False, num_steps=T)
+    assert np.array_equal(out["z_vals"].cpu().numpy(), ref["z_vals"])
+    np.testing.assert_allclose(out["weights"].cpu().numpy(), ref["weights"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(out["depth"][0].cpu().numpy(), ref["depth"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(out["image"][0].cpu().numpy(), ref["image"], atol=1e-4, rtol=0)
+
+
+def test_sliced_passes_split(dev):
+    """passes = 1 then passes = 2 on shared buffers == passes = 3."""
+    from nvsf import field_ops as ops
+    m = _model(dev, 0.1)
+    rng = np.random.default_rng(17)
+    N, T = 48, 192
+    o, d, nears, fars = _batch(m, dev, False, N, rng)
+    enc = m.hash_encoder_camera
+    args = (o, d, nears, fars, T, m._aabb_host, float(m.bound), enc.table_f16(), enc.spec, m.sigma_net.weights_f16())
+    ref = ops.density_uniform(*args, sliced=True)
+    bufs = (torch.zeros(N, T, device=dev), torch.zeros(N, T, device=dev), torch.zeros(N, T, 16, dtype=torch.float16, device=dev),
+            torch.zeros(16, N * T, dtype=torch.int32, device=dev))
+    ops.density_uniform(*args, sliced=True, _passes=1, _buffers=bufs)
+    assert torch.equal(bufs[0], ref[0]) and float(bufs[1].abs().sum()) == 0.0  # encode pass: z written, sigma untouched
+    ops.density_uniform(*args, sliced=True, _passes=2, _buffers=bufs)
+    assert torch.equal(bufs[1], ref[1]) and torch.equal(bufs[2], ref[2])
+
+
+def test_prefer_sliced_choice_and_rejections(dev):
+    from nvsf import field_ops as ops, _hip, synthetic as S
+    m = _model(dev)
+    spec = m.hash_encoder_camera.spec
+    lidar_len = float(m.lidar_max_depth - m.min_near_lidar)
+    assert ops.prefer_sliced(spec, 4096, 768, 2.0 * S.BOUND, S.BOUND) is True       # camera batch of config 2
+    assert ops.prefer_sliced(spec, 4096, 768, lidar_len, S.BOUND) is False           # LiDAR batch: < 1 finest cell per step
+    assert ops.prefer_sliced(spec, 64, 64, 2.0 * S.BOUND, S.BOUND) is False          # too small to pay for two launches
+    small = ops.GridSpec(3, 8, 4, 19, 16, 1.5)
+    assert ops.prefer_sliced(small, 4096, 768, 2.0 * S.BOUND, S.BOUND) is False      # shape the sliced kernels are not built for
+    # the C entry point rejects such a shape instead of silently running something else
+    o, d, nears, fars = _batch(m, dev, False, 8, np.random.default_rng(1))
+    table = torch.zeros(small.n_params, dtype=torch.float16, device=dev)
+    with pytest.raises(_hip.NvsfHipError):
+        ops.density_uniform(o, d, nears, fars, 16, m._aabb_host, float(m.bound), table, small, m.sigma_net.weights_f16(), sliced=True)

@@ -20,15 +20,17 @@ for name, fn in (("lidar", S.lidar_rays), ("camera", S.camera_rays)):
         nears, fars = raymarching.near_far_from_aabb(o, d, m.aabb_infer, m.min_near)
     batches[name] = (o, d, nears, fars)
 variants = sys.argv[1:] or ["1", "2"]
+SLICED = [False]
 def run(name):
     o, d, nears, fars = batches[name]
     enc = m.hash_encoder_lidar if name == "lidar" else m.hash_encoder_camera
-    return ops.density_uniform(o, d, nears, fars, T, m._aabb_host, float(m.bound), enc.table_f16(), enc.spec, m.sigma_net.weights_f16())
+    return ops.density_uniform(o, d, nears, fars, T, m._aabb_host, float(m.bound), enc.table_f16(), enc.spec, m.sigma_net.weights_f16(), sliced=SLICED[0])
 res = {}
 outs = {}
 for rnd in range(5):
     for v in variants:
-        os.environ["NVSF_DENSITY_KERNEL"] = v.split(":")[0]
+        SLICED[0] = v == "S"
+        os.environ["NVSF_DENSITY_KERNEL"] = "0" if v == "S" else v.split(":")[0]
         if ":" in v: os.environ["NVSF_DENSITY_SEG_TILES"] = v.split(":")[1]
         for name in batches:
             out = run(name); torch.cuda.synchronize()
@@ -43,4 +45,4 @@ for k, v in sorted(res.items()):
 if len(variants) > 1:
     for name in batches:
         a, b = outs[(variants[0], name)], outs[(variants[1], name)]
-        print(name, "z equal", torch.equal(a[0], b[0]), "sigma max rel", float(((a[1] - b[1]).abs() / b[1]).max()), "geo equal frac", float((a[2] == b[2]).float().mean()))
+        print(name, "z equal", torch.equal(a[0], b[0]), "sigma max rel", float(((a[1] - b[1]).abs() / b[1]).max()), "sigma equal", torch.equal(a[1], b[1]), "geo equal frac", float((a[2] == b[2]).float().mean()))

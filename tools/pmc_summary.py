@@ -1,7 +1,13 @@
 """Summarises rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs, CSV output) into
 profiles/<tag>_pmc_traffic.json: mean KB per launch for each kernel, split by launch order where a kernel is
-launched with alternating workloads (LiDAR, camera)."""
+launched with alternating workloads (LiDAR, camera).
+
+    python tools/pmc_summary.py <fetch.csv> <write.csv> <out.json> [--alternating kernel_key ...]
+
+Kernels named after --alternating (default: k_weights_fwd) are launched once per batch kind in LiDAR, camera order;
+the others are launched for one batch kind only in bench.py's step (fused density: LiDAR; sliced density: camera)."""
 import csv, json, sys, collections
+
 
 def load(path, counter):
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
@@ -11,13 +17,26 @@ def load(path, counter):
         per[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     return per
 
+
+KEYS = {"k_density_uniform_v2": "density_uniform_v2", "k_density_uniformILi": "density_uniform", "k_encode_sliced": "encode_sliced",
+        "k_density_from_features": "density_from_features", "heads_uniformILb1": "heads_uniform<lidar>",
+        "heads_uniformILb0": "heads_uniform<camera>", "k_weights_fwd": "k_weights_fwd", "k_near_far": "k_near_far"}
+
+
 def short(name):
-    for key in ("density_uniform_v2", "density_uniform", "heads_uniformILb1", "heads_uniformILb0", "k_weights_fwd", "k_near_far"):
+    for key, label in KEYS.items():
         if key in name:
-            return {"heads_uniformILb1": "heads_uniform<lidar>", "heads_uniformILb0": "heads_uniform<camera>"}.get(key, key)
+            return label
     return None
 
-fetch, write, out_path = sys.argv[1], sys.argv[2], sys.argv[3]
+
+args = sys.argv[1:]
+alternating = ["k_weights_fwd"]
+if "--alternating" in args:
+    i = args.index("--alternating")
+    alternating = args[i + 1:]
+    args = args[:i]
+fetch, write, out_path = args
 f, w = load(fetch, "FETCH_SIZE"), load(write, "WRITE_SIZE")
 out = {"units": "KB per launch (rocprofv3 FETCH_SIZE / WRITE_SIZE; gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x, 4-byte gathers uncalibrated)", "kernels": {}}
 for name in f:
@@ -26,7 +45,7 @@ for name in f:
         continue
     fv, wv = f[name], w.get(name, [])
     entry = {"launches": len(fv), "fetch_kb_mean": sum(fv) / len(fv), "write_kb_mean": (sum(wv) / len(wv)) if wv else None}
-    if s.startswith(("density", "k_weights")) and len(fv) % 2 == 0:  # launched alternately for the LiDAR and the camera batch
+    if s in alternating and len(fv) % 2 == 0:
         entry["fetch_kb_lidar"] = sum(fv[0::2]) / (len(fv) // 2)
         entry["fetch_kb_camera"] = sum(fv[1::2]) / (len(fv) // 2)
         if wv:
