@@ -232,6 +232,26 @@ int nvsf_field_density_uniform_fwd(const float* rays_o, const float* rays_d, con
                                    const void* sigma_weights_f16, float* z_vals, float* sigmas, void* geo_f16,
                                    nvsf_stream_t stream);
 
+/* ref: the evaluation-mode protocol of the raymarching extension, raymarching.py:389-409 (march_rays) + 480-493
+ * (composite_rays) around the field, for a static hash field (L*F = 32, F = 2): ONE launch instead of the host
+ * loop over surviving rays.  Per ray: march through the occupancy bit field `grid` (layout of nvsf_march_rays),
+ * field on every sample (sigma = exp(h0) * density_scale; colour = sigmoid(heads), LiDAR: raydrop, intensity),
+ * alpha compositing in sample order, stop at the first sample whose incoming transmittance < T_thresh, at `far`,
+ * or after max_steps samples.  Outputs weights_sum, depth [N]; image [N,3] (+ (1 - weights_sum) * h_bg_color,
+ * h_bg_color = 3 host floats or NULL) or [N,2] for LiDAR.  No perturbation (the host loop applies its noise
+ * offset to the first call only, which ties the result to the loop's batching).
+ * Deviations from the host loop: the loop restarts each march call from the compositor's
+ * accumulated t (1-ulp differences in later sample positions) and caps a ray at max_steps .. max_steps+7 samples
+ * depending on how many rays survive; this kernel marches each ray continuously and caps at max_steps. */
+int nvsf_render_occupancy_fwd(const float* rays_o, const float* rays_d, const float* nears, const float* fars,
+                              const uint8_t* grid, float bound, float dt_gamma, uint32_t max_steps, uint32_t C,
+                              uint32_t H, uint32_t N, const void* table_f16, uint32_t L, uint32_t F,
+                              const float* h_scales, const uint32_t* h_res, const uint32_t* h_offsets,
+                              const void* sigma_weights_f16, int lidar, const void* head_a_weights_f16,
+                              const void* head_b_weights_f16, float density_scale, float T_thresh,
+                              const float* h_bg_color, float* weights_sum, float* depth, float* image,
+                              nvsf_stream_t stream);
+
 /* Same operator, same results bit for bit, as two launches with the LEVELS partitioned over the 8 XCDs (each
  * XCD's L2 then holds 2 of the 16 levels): pays when consecutive samples of a ray are several finest-level cells
  * apart, i.e. when the fine levels have no reuse along the ray (camera rays through the whole box).

@@ -17,6 +17,7 @@
 #include "hashgrid_device.h"
 #include "mlp_device.h"
 #include "encodings_device.h"
+#include "march_device.h"
 #include <stdlib.h>
 
 namespace {
@@ -141,10 +142,10 @@ struct DensityCtx {
     int g;
 };
 
-// One 16-sample tile: encode (x in [0,1]^3 per lane) -> sigma MLP -> store sigma / geo / z.
+// One 16-sample tile: encode (x in [0,1]^3 per lane) -> sigma MLP.  Returns the rotated output rows 4g..4g+3 of
+// sample (lane & 15): rows 0..14 = h1..h15, row 15 = density logit h0.
 template <int F, int QG>
-__device__ __forceinline__ void density_tile(const DensityCtx<F>& cx, const float (&x)[3], float z, unsigned long long s, bool in_range,
-                                             float* __restrict__ z_vals, float* __restrict__ sigmas, _Float16* __restrict__ geo) {
+__device__ __forceinline__ float4_t density_eval(const DensityCtx<F>& cx, const float (&x)[3]) {
     constexpr int Q = 8 / F;
     const LaneLevels<F>& lv = cx.lv;
     const uint32_t first_hashed = cx.first_hashed;
@@ -218,7 +219,15 @@ __device__ __forceinline__ void density_tile(const DensityCtx<F>& cx, const floa
     }
     half8_t h[kHidSteps];
     pack_hidden(acc1, h);
-    const float4_t o = cx.wout.apply(h);
+    return cx.wout.apply(h);
+}
+
+// density_eval + store of sigma / geo / z.
+template <int F, int QG>
+__device__ __forceinline__ void density_tile(const DensityCtx<F>& cx, const float (&x)[3], float z, unsigned long long s, bool in_range,
+                                             float* __restrict__ z_vals, float* __restrict__ sigmas, _Float16* __restrict__ geo) {
+    const int g = cx.g;
+    const float4_t o = density_eval<F, QG>(cx, x);
     if (in_range) {
         half4_t ov;
         ov[0] = (_Float16)o[0]; ov[1] = (_Float16)o[1]; ov[2] = (_Float16)o[2]; ov[3] = (_Float16)o[3];
@@ -681,6 +690,196 @@ __global__ __launch_bounds__(kBlock) void k_heads_uniform(const float* __restric
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fused occupancy-grid render, evaluation mode (BASELINE config 3).  The reference's protocol is a host loop over
+// the surviving rays (march_rays -> field -> composite_rays, a device->host sync per iteration, raymarching.py:
+// 389-409 / 480-493); here ONE launch renders the batch: a wave owns a ray, marches it through the occupancy
+// bit field 16 samples at a time (all lanes execute the serial march redundantly and lane l keeps sample l & 15,
+// so no cross-lane traffic is needed to form the MFMA tile), evaluates hash grid -> sigma MLP -> heads on the tile
+// with the fragments of the uniform kernels, composites the 16 samples in order and stops at the first sample whose
+// incoming transmittance is below T_thresh, at the far plane, or after max_steps samples.
+struct OccRays {
+    const float* rays_o;
+    const float* rays_d;
+    const float* nears;
+    const float* fars;
+    const uint8_t* grid;
+    float bound, dt_gamma;
+    uint32_t max_steps, C, H, N;
+};
+
+__device__ __forceinline__ float readlane_f32(float v, int src_lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src_lane));
+}
+
+__device__ __forceinline__ uint32_t pack_h2(float a, float b) {
+    h2_t v;
+    v[0] = (_Float16)a;
+    v[1] = (_Float16)b;
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+template <bool LIDAR>
+__global__ __launch_bounds__(kBlock) void k_render_occupancy(OccRays rr, const _Float16* __restrict__ table, uint32_t table_bytes, GridMeta meta,
+                                                             uint32_t first_hashed, const _Float16* __restrict__ w_sigma,
+                                                             const _Float16* __restrict__ w_a, const _Float16* __restrict__ w_b,
+                                                             float density_scale, float T_thresh, float bg0, float bg1, float bg2,
+                                                             float* __restrict__ weights_sum, float* __restrict__ depth,
+                                                             float* __restrict__ image) {
+    constexpr int F = 2, Q = 8 / F;
+    constexpr int IN_STEPS = LIDAR ? 3 : 1;
+    __shared__ float s_scale[kMaxLevels];
+    __shared__ uint32_t s_res[kMaxLevels], s_off[kMaxLevels + 1];
+    if (threadIdx.x < kMaxLevels) {
+        s_scale[threadIdx.x] = meta.scale[threadIdx.x];
+        s_res[threadIdx.x] = meta.res[threadIdx.x];
+    }
+    if (threadIdx.x <= kMaxLevels) s_off[threadIdx.x] = meta.offset[threadIdx.x];
+    __syncthreads();
+    const uint32_t n = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    if (n >= rr.N) return;
+    const int lane = lane_id(), g = lane >> 4, sl = lane & 15;
+
+    DensityCtx<F> cx;
+    cx.g = g;
+    cx.first_hashed = first_hashed;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int l = 4 * q + g;
+        cx.lv.scale[q] = s_scale[l];
+        cx.lv.res[q] = s_res[l];
+        cx.lv.res2[q] = s_res[l] * s_res[l];
+        cx.lv.boff[q] = s_off[l] * (uint32_t)(F * sizeof(_Float16));
+        cx.lv.rows[q] = s_off[l + 1] - s_off[l];
+    }
+#pragma unroll
+    for (int t = 0; t < kHidTiles; ++t) {
+        const _Float16* row = w_sigma + (size_t)(16 * t + sl) * 32;
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+#pragma unroll
+            for (int f = 0; f < F; ++f) cx.w0[t][q * F + f] = row[(4 * q + g) * F + f];
+    }
+    cx.wout.load(w_sigma + kHidden * 32, lane, 1);
+    cx.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(table), 0, (int)table_bytes, 0x00020000);
+
+    // direction encoding of the ray -> ray-constant operands of the heads (as in k_heads_uniform)
+    const float rd0 = rr.rays_d[3 * (size_t)n], rd1 = rr.rays_d[3 * (size_t)n + 1], rd2 = rr.rays_d[3 * (size_t)n + 2];
+    const float d0 = (rd0 + 1.0f) / 2.0f, d1 = (rd1 + 1.0f) / 2.0f, d2 = (rd2 + 1.0f) / 2.0f;
+    half8_t xf[IN_STEPS];
+    if constexpr (!LIDAR) {
+        float sh[16];
+        sh4_basis(d0, d1, d2, sh);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xf[0][j] = (_Float16)(g == 0 ? sh[j] : sh[8 + j]);
+    } else {
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const int k = 32 * s + 8 * g + j;
+                float sn = 1.0f, cs = 1.0f;
+                if (k < 72) {
+                    const int i = k / 24, f = (k - 24 * i) >> 1;
+                    freq_pair(i == 0 ? d0 : (i == 1 ? d1 : d2), f, sn, cs);
+                }
+                xf[s][j] = (_Float16)sn;
+                xf[s][j + 1] = (_Float16)cs;
+            }
+    }
+    HeadW<IN_STEPS> net_a;
+    net_a.load(w_a, lane, xf);
+    const half8_t x_base = xf[IN_STEPS - 1];
+    const bool takes_geo = LIDAR ? (g == 1 || g == 2) : (g >= 2);
+    const int src_a = sl + 16 * (LIDAR ? 2 * (g - 1) : 2 * (g - 2)), src_b = src_a + 16;  // lanes holding geo rows 8h..8h+3, +4..+7
+
+    const float o3[3] = {rr.rays_o[3 * (size_t)n], rr.rays_o[3 * (size_t)n + 1], rr.rays_o[3 * (size_t)n + 2]};
+    const float dd[3] = {rd0, rd1, rd2};
+    Marcher m;
+    m.init(o3, dd, rr.grid, rr.bound, rr.dt_gamma, rr.max_steps, rr.C, rr.H);
+    const float far = rr.fars[n];
+    float t = rr.nears[n];
+    float last_t = t, t_comp = t;
+    float ws = 0.0f, dep = 0.0f, col[3] = {0.0f, 0.0f, 0.0f};
+    uint32_t total = 0;
+    const float extent = 2.0f * rr.bound;
+    bool alive = true;
+    while (alive) {
+        // ---- march: up to 16 samples; every lane walks the ray, lane (g, sl) keeps sample sl
+        uint32_t count = 0;
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f, sdt = 0.0f, sd1 = 0.0f;
+        while (t < far && count < 16u && total + count < rr.max_steps) {
+            float x, y, z, dt;
+            if (m.probe(t, x, y, z, dt)) {
+                t += dt;
+                const float d1s = t - last_t;
+                last_t = t;
+                if (count == (uint32_t)sl) { sx = x; sy = y; sz = z; sdt = dt; sd1 = d1s; }
+                ++count;
+            }
+        }
+        const uint32_t cnt = __builtin_amdgcn_readfirstlane(count);
+        if (cnt == 0u) break;
+        // ---- field on the tile (lanes sl >= cnt evaluate the box centre; their results are never read)
+        const float x01[3] = {(sx + rr.bound) / extent, (sy + rr.bound) / extent, (sz + rr.bound) / extent};
+        const float4_t o = density_eval<F, 4>(cx, x01);
+        const float sigma = expf(o[3]) * density_scale;  // meaningful in lanes g == 3
+        const uint32_t p0 = pack_h2(o[0], o[1]), p1 = pack_h2(o[2], g == 3 ? 1.0f : o[3]);
+        typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
+        u4_t gv;
+        gv[0] = (uint32_t)__shfl((int)p0, src_a & 63);
+        gv[1] = (uint32_t)__shfl((int)p1, src_a & 63);
+        gv[2] = (uint32_t)__shfl((int)p0, src_b & 63);
+        gv[3] = (uint32_t)__shfl((int)p1, src_b & 63);
+        const half8_t x_last = takes_geo ? __builtin_bit_cast(half8_t, gv) : x_base;
+        float c[3] = {0.0f, 0.0f, 0.0f};  // colour of sample sl, meaningful in lanes g == 0
+        {
+            const float4_t oa = net_a.apply(x_last);
+            if constexpr (LIDAR) {
+                c[0] = sigmoid_f32(oa[0]);
+                HeadW<IN_STEPS> net_b;  // second head: weights fetched per tile (registers are the scarce resource here)
+                net_b.load(w_b, lane, xf);
+                const float4_t ob = net_b.apply(x_last);
+                c[1] = sigmoid_f32(ob[0]);
+            } else {
+                c[0] = sigmoid_f32(oa[0]); c[1] = sigmoid_f32(oa[1]); c[2] = sigmoid_f32(oa[2]);
+            }
+        }
+        // ---- composite the tile in order (composite_rays, raymarching.cu:966-1053)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if ((uint32_t)i < cnt && alive) {
+                const float s_i = readlane_f32(sigma, 48 + i);
+                const float dt_i = readlane_f32(sdt, i), d1_i = readlane_f32(sd1, i);
+                const float alpha = 1.0f - expf(-s_i * dt_i);
+                const float T = 1.0f - ws;
+                const float w = alpha * T;
+                ws += w;
+                t_comp += d1_i;
+                dep += w * t_comp;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) col[k] += w * readlane_f32(c[k], i);
+                if (T < T_thresh) alive = false;
+            }
+        }
+        total += cnt;
+        if (cnt < 16u) alive = false;
+    }
+    if (lane == 0) {
+        weights_sum[n] = ws;
+        depth[n] = dep;
+        if constexpr (LIDAR) {
+            image[2 * (size_t)n] = col[0];
+            image[2 * (size_t)n + 1] = col[1];
+        } else {
+            const float rest = 1.0f - ws;
+            image[3 * (size_t)n] = col[0] + rest * bg0;
+            image[3 * (size_t)n + 1] = col[1] + rest * bg1;
+            image[3 * (size_t)n + 2] = col[2] + rest * bg2;
+        }
+    }
+}
+
 int fill_meta(GridMeta& meta, uint32_t L, const float* scales, const uint32_t* res, const uint32_t* offsets) {
     if (L == 0 || L > (uint32_t)kMaxLevels || !scales || !res || !offsets) return NVSF_ERR_INVALID_ARG;
     for (uint32_t l = 0; l < L; ++l) {
@@ -817,5 +1016,51 @@ NVSF_API int nvsf_field_heads_uniform_fwd(const float* weights, const void* geo_
     else
         hipLaunchKernelGGL(k_heads_uniform<false>, grid, block, 0, stream, weights, gp, rays_d, weights_sum, wa, wb, N, T, w_thresh,
                            b0, b1, b2, h_bg_color ? 1 : 0, image);
+    return nvsf_launch_status();
+}
+
+NVSF_API int nvsf_render_occupancy_fwd(const float* rays_o, const float* rays_d, const float* nears, const float* fars,
+                                       const uint8_t* grid, float bound, float dt_gamma, uint32_t max_steps, uint32_t C, uint32_t H,
+                                       uint32_t N, const void* table_f16, uint32_t L, uint32_t F, const float* h_scales,
+                                       const uint32_t* h_res, const uint32_t* h_offsets, const void* sigma_weights_f16, int lidar,
+                                       const void* head_a_weights_f16, const void* head_b_weights_f16, float density_scale,
+                                       float T_thresh, const float* h_bg_color, float* weights_sum, float* depth, float* image,
+                                       hipStream_t stream) {
+    if (N == 0) return NVSF_OK;
+    REQUIRE(rays_o && rays_d && nears && fars && grid && table_f16 && sigma_weights_f16 && head_a_weights_f16 && weights_sum && depth && image);
+    REQUIRE(!lidar || head_b_weights_f16);
+    REQUIRE(bound > 0.0f && C >= 1 && C <= 8 && H >= 2 && H <= 1024 && max_steps >= 1);
+    REQUIRE((reinterpret_cast<uintptr_t>(table_f16) & 15u) == 0 && (reinterpret_cast<uintptr_t>(sigma_weights_f16) & 15u) == 0 &&
+            (reinterpret_cast<uintptr_t>(head_a_weights_f16) & 15u) == 0 && (reinterpret_cast<uintptr_t>(head_b_weights_f16) & 15u) == 0);
+    if (F != 2 || L * F != 32) return NVSF_ERR_UNSUPPORTED;
+    GridMeta meta;
+    const int st = fill_meta(meta, L, h_scales, h_res, h_offsets);
+    if (st != NVSF_OK) return st;
+    uint32_t first_hashed = L;
+    for (uint32_t l = 0; l < L; ++l) {
+        const unsigned long long cells = (unsigned long long)h_res[l] * h_res[l] * h_res[l];
+        const uint32_t rows = h_offsets[l + 1] - h_offsets[l];
+        const bool hashed = cells > (unsigned long long)rows;
+        if (hashed && first_hashed == L) first_hashed = l;
+        if (!hashed && first_hashed != L) return NVSF_ERR_UNSUPPORTED;         // dense levels must come first
+        if (hashed && (rows & (rows - 1u)) != 0u) return NVSF_ERR_UNSUPPORTED;  // hashed levels: power-of-two rows
+    }
+    const unsigned long long table_bytes = (unsigned long long)h_offsets[L] * F * sizeof(_Float16);
+    if (table_bytes >= (1ull << 31)) return NVSF_ERR_UNSUPPORTED;
+    OccRays rr;
+    rr.rays_o = rays_o; rr.rays_d = rays_d; rr.nears = nears; rr.fars = fars; rr.grid = grid;
+    rr.bound = bound; rr.dt_gamma = dt_gamma; rr.max_steps = max_steps; rr.C = C; rr.H = H; rr.N = N;
+    const _Float16* tb = reinterpret_cast<const _Float16*>(table_f16);
+    const _Float16* ws = reinterpret_cast<const _Float16*>(sigma_weights_f16);
+    const _Float16* wa = reinterpret_cast<const _Float16*>(head_a_weights_f16);
+    const _Float16* wb = reinterpret_cast<const _Float16*>(head_b_weights_f16);
+    const float b0 = h_bg_color ? h_bg_color[0] : 0.0f, b1 = h_bg_color ? h_bg_color[1] : 0.0f, b2 = h_bg_color ? h_bg_color[2] : 0.0f;
+    const dim3 grid_dim(cdiv(N, kWavesPerBlock)), block(kBlock);
+    if (lidar)
+        hipLaunchKernelGGL(k_render_occupancy<true>, grid_dim, block, 0, stream, rr, tb, (uint32_t)table_bytes, meta, first_hashed, ws, wa, wb,
+                           density_scale, T_thresh, b0, b1, b2, weights_sum, depth, image);
+    else
+        hipLaunchKernelGGL(k_render_occupancy<false>, grid_dim, block, 0, stream, rr, tb, (uint32_t)table_bytes, meta, first_hashed, ws, wa, wb,
+                           density_scale, T_thresh, b0, b1, b2, weights_sum, depth, image);
     return nvsf_launch_status();
 }

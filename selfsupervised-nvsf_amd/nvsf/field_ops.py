@@ -388,3 +388,24 @@ def heads_uniform(weights, geo, rays_d, weights_sum, lidar, head_a_f16, head_b_f
               1 if lidar else 0, _hip.ptr(head_a_f16), _hip.ptr(head_b_f16), N, T, float(w_thresh),
               _hip.host_f32(bg_host) if bg_host is not None else None, _hip.ptr(image))
     return image
+
+
+def occupancy_fused_eligible(spec):
+    """Static hash fields nvsf_render_occupancy_fwd is built for."""
+    return spec.D == 3 and spec.F == 2 and spec.L * spec.F == 32
+
+
+def render_occupancy(rays_o, rays_d, nears, fars, bitfield, bound, dt_gamma, max_steps, C, H, table_f16, spec, sigma_weights_f16, lidar,
+                     head_a_f16, head_b_f16, density_scale, T_thresh, bg_host=None):
+    """One-launch evaluation-mode occupancy render -> weights_sum [N], depth [N], image [N, 2 | 3]."""
+    N = rays_o.shape[0]
+    dev = rays_o.device
+    ws = torch.empty(N, dtype=torch.float32, device=dev)
+    depth = torch.empty(N, dtype=torch.float32, device=dev)
+    image = torch.empty(N, 2 if lidar else 3, dtype=torch.float32, device=dev)
+    _hip.call("nvsf_render_occupancy_fwd", _hip.ptr(rays_o), _hip.ptr(rays_d), _hip.ptr(nears), _hip.ptr(fars), _hip.ptr(bitfield),
+              float(bound), float(dt_gamma), int(max_steps), int(C), int(H), N, _hip.ptr(table_f16), spec.L, spec.F, spec.h_scales,
+              spec.h_res, spec.h_offsets, _hip.ptr(sigma_weights_f16), 1 if lidar else 0, _hip.ptr(head_a_f16), _hip.ptr(head_b_f16),
+              float(density_scale), float(T_thresh), _hip.host_f32(bg_host) if bg_host is not None else None, _hip.ptr(ws),
+              _hip.ptr(depth), _hip.ptr(image))
+    return ws, depth, image

@@ -91,6 +91,17 @@ class NeRFNetworkStatic(NeRFRenderer):
             image = ops.heads_uniform(weights, geo, rays_d, weights_sum, False, self.color_net.weights_f16(), None, bg_host)
         return z_vals, weights, weights_sum, depth, image
 
+    def fused_occupancy_render(self, rays_o, rays_d, nears, fars, cal_lidar_color, dt_gamma, max_steps, T_thresh, bg_host):
+        """Evaluation-mode occupancy render in one launch (NeRFRenderer.run_cuda hands over here when it can)."""
+        enc = self.hash_encoder_lidar if cal_lidar_color else self.hash_encoder_camera
+        if cal_lidar_color:
+            head_a, head_b = self.raydrop_net.weights_f16(), self.intensity_net.weights_f16()
+        else:
+            head_a, head_b = self.color_net.weights_f16(), None
+        return ops.render_occupancy(rays_o, rays_d, nears, fars, self.density_bitfield, float(self.bound), dt_gamma, max_steps,
+                                    self.cascade, self.grid_size, enc.table_f16(), enc.spec, self.sigma_net.weights_f16(),
+                                    cal_lidar_color, head_a, head_b, float(self.density_scale), T_thresh, bg_host)
+
     def get_params(self, lr):
         """Optimiser groups with the reference's per-group learning rates (network_dynamic.py:335-357)."""
         return [

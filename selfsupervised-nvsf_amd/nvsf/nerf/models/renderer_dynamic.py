@@ -142,6 +142,22 @@ class NeRFRenderer(nn.Module):
                                                                     counter, self.mean_count, perturb, 128, force_all_rays, dt_gamma, max_steps)
             sigmas, rgbs = self._packed_field(xyzs, dirs, time, cal_lidar_color)
             weights_sum, depth, image = raymarching.composite_rays_train(sigmas, rgbs, deltas, rays, T_thresh)
+        elif (not perturb and not torch.is_grad_enabled() and hasattr(self, "fused_occupancy_render")
+              and (bg_color is None or not torch.is_tensor(bg_color) or bg_color.numel() <= 3) and kwargs.get("fused", True)):
+            # one launch for the whole survivor loop (static hash fields): nvsf_render_occupancy_fwd
+            if cal_lidar_color:
+                bg_host = None
+            elif bg_color is None:
+                bg_host = [1.0, 1.0, 1.0]
+            elif torch.is_tensor(bg_color):
+                bg_host = [float(v) for v in bg_color.reshape(-1).expand(3).tolist()] if bg_color.numel() == 1 \
+                    else [float(v) for v in bg_color.reshape(-1).tolist()]
+            else:
+                bg_host = [float(bg_color)] * 3
+            weights_sum, depth, image = self.fused_occupancy_render(rays_o, rays_d, nears, fars, cal_lidar_color, dt_gamma, max_steps,
+                                                                    T_thresh, bg_host)
+            suffix = "_lidar" if cal_lidar_color else ""
+            return {"depth" + suffix: depth.view(*prefix), "image" + suffix: image.view(*prefix, out_dim), "weights_sum" + suffix: weights_sum}
         else:
             weights_sum = torch.zeros(N, dtype=torch.float32, device=dev)
             depth = torch.zeros(N, dtype=torch.float32, device=dev)

@@ -70,8 +70,11 @@ def test_training_mode_matches_oracle_and_backpropagates(dev, setup, lidar):
     m.zero_grad(set_to_none=True)
 
 
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("lidar", [True, False])
-def test_evaluation_loop_matches_oracle(dev, setup, lidar):
+def test_evaluation_loop_matches_oracle(dev, setup, lidar, fused):
+    """fused=False: the host loop over surviving rays (march_rays -> field -> composite_rays);
+    fused=True: the one-launch kernel nvsf_render_occupancy_fwd.  Both against the oracle's loop."""
     m, bits, S = setup
     m.eval()
     rng = np.random.default_rng(6)
@@ -82,7 +85,7 @@ def test_evaluation_loop_matches_oracle(dev, setup, lidar):
                                    T_thresh=1e-2)
     with torch.no_grad():
         out = m.render(_t(o, dev)[None], _t(d, dev)[None], torch.tensor([[0.5]], device=dev), cal_lidar_color=lidar, max_steps=max_steps,
-                       T_thresh=1e-2)
+                       T_thresh=1e-2, fused=fused)
     sfx = "_lidar" if lidar else ""
     close = lambda a, b: np.abs(a - b) <= 1e-4
     ws_ok = close(out["weights_sum" + sfx].cpu().numpy(), ref["weights_sum"])
@@ -90,6 +93,49 @@ def test_evaluation_loop_matches_oracle(dev, setup, lidar):
     assert ws_ok.mean() > 0.99
     assert (close(out["depth" + sfx][0].cpu().numpy(), ref["depth"]) | ~ws_ok).all()
     assert (close(out["image" + sfx][0].cpu().numpy(), ref["image"]).all(-1) | ~ws_ok).all()
+
+
+@pytest.mark.parametrize("lidar", [True, False])
+def test_fused_occupancy_equals_host_loop(dev, setup, lidar):
+    """Larger batch, default T_thresh, coloured background: one-launch kernel vs the host loop of the same library.
+    The two differ only in where a march restarts (the loop restarts from the compositor's accumulated t), i.e. by
+    float noise; a ray may flip one borderline sample, hence the 99.5 % criterion."""
+    m, bits, S = setup
+    m.eval()
+    rng = np.random.default_rng(8)
+    N, max_steps = 2000, 512
+    o, d = (S.lidar_rays if lidar else S.camera_rays)(N, rng)
+    args = (_t(o, dev)[None], _t(d, dev)[None], torch.tensor([[0.5]], device=dev))
+    bg = None if lidar else torch.tensor([0.1, 0.5, 0.9], device=dev)
+    with torch.no_grad():
+        a = m.render(*args, cal_lidar_color=lidar, max_steps=max_steps, bg_color=bg, fused=True)
+        b = m.render(*args, cal_lidar_color=lidar, max_steps=max_steps, bg_color=bg, fused=False)
+    sfx = "_lidar" if lidar else ""
+    assert float(b["weights_sum" + sfx].max()) > 0.05  # the batch does hit occupied space
+    for k in ("weights_sum" + sfx, "depth" + sfx, "image" + sfx):
+        x, y = a[k].reshape(N, -1), b[k].reshape(N, -1)
+        ok = ((x - y).abs() <= 1e-4).all(-1).float().mean()
+        assert float(ok) > 0.995, (k, float(ok))
+
+
+def test_fused_occupancy_step_cap_and_empty(dev, setup):
+    """max_steps caps the samples of a ray; rays that never meet an occupied cell return the background."""
+    m, bits, S = setup
+    m.eval()
+    rng = np.random.default_rng(9)
+    o, d = S.camera_rays(64, rng)
+    args = (_t(o, dev)[None], _t(d, dev)[None], torch.tensor([[0.5]], device=dev))
+    with torch.no_grad():
+        few = m.render(*args, max_steps=4, fused=True)
+        many = m.render(*args, max_steps=1024, fused=True)
+    assert float(few["weights_sum"].max()) < float(many["weights_sum"].max())
+    saved = m.density_bitfield.clone()
+    m.density_bitfield.zero_()
+    with torch.no_grad():
+        empty = m.render(*args, max_steps=256, fused=True)
+    m.density_bitfield.copy_(saved)
+    assert float(empty["weights_sum"].abs().max()) == 0.0 and float(empty["depth"].abs().max()) == 0.0
+    assert torch.equal(empty["image"], torch.ones_like(empty["image"]))
 
 
 def test_density_grid_maintenance(dev, setup):

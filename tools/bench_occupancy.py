@@ -1,0 +1,45 @@
+"""Timing of the occupancy-grid render (BASELINE config 3): config-2 field and ray batches, procedural occupancy grid
+(union of random boxes, S.boxes_density_grid), max 1024 samples per ray.
+
+    eval : march_rays -> field -> composite_rays survivor loop (early termination)      [NeRFRenderer.run_cuda, eval]
+    train: march_rays_train -> field -> composite_rays_train, one packed batch, no grad [NeRFRenderer.run_cuda, train]
+"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "selfsupervised-nvsf_amd"))
+import numpy as np, torch
+from nvsf import synthetic as S
+from nvsf.nerf.models.network_static import NeRFNetworkStatic
+
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+m = NeRFNetworkStatic(bound=S.BOUND, min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH, num_frames=S.NUM_FRAMES)
+m = m.to(dev).enable_occupancy_grid().to(dev)
+rng = np.random.default_rng(0)
+grid = S.boxes_density_grid(rng, cascades=m.cascade, H=m.grid_size, n_boxes=int(os.environ.get("BOXES", 64)))
+m.set_density_grid(torch.from_numpy(grid).to(dev), thresh=0.5)
+print("occupied fraction per cascade:", [float((g > 0.5).mean()) for g in grid])
+N = int(os.environ.get("N", 4096))
+lo, ld = S.lidar_rays(N, rng); co, cd = S.camera_rays(N, rng)
+tl = [torch.from_numpy(a).to(dev)[None] for a in (lo, ld)]; tc = [torch.from_numpy(a).to(dev)[None] for a in (co, cd)]
+tm = torch.tensor([[0.5]], device=dev)
+
+
+def step():
+    with torch.no_grad():
+        a = m.render(tl[0], tl[1], tm, cal_lidar_color=True, max_steps=1024)
+        b = m.render(tc[0], tc[1], tm, cal_lidar_color=False, max_steps=1024)
+    return a, b
+
+
+for mode in ("eval", "train"):
+    m.train(mode == "train")
+    for _ in range(3): step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    K = 10
+    for _ in range(K): out = step()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
+    extra = ""
+    if mode == "train":
+        extra = f", samples/step {int(m.step_counter[(m.local_step - 1) % 16][0])} (camera batch)"
+    print(f"occupancy {mode}: {dt*1e3:.2f} ms/step, {2*N/dt:.0f} rays/s{extra}")
