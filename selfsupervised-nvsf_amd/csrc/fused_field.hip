@@ -18,6 +18,8 @@
 #include "mlp_device.h"
 #include "encodings_device.h"
 #include "march_device.h"
+// k_render_occupancy_lds asks for 4 waves per SIMD; its LiDAR instantiation settles at 3 (LDS-bound anyway)
+#pragma clang diagnostic ignored "-Wpass-failed"
 #include <stdlib.h>
 
 namespace {
@@ -142,10 +144,10 @@ struct DensityCtx {
     int g;
 };
 
-// One 16-sample tile: encode (x in [0,1]^3 per lane) -> sigma MLP.  Returns the rotated output rows 4g..4g+3 of
-// sample (lane & 15): rows 0..14 = h1..h15, row 15 = density logit h0.
+// One 16-sample tile: hash-grid encode of x in [0,1]^3 (per lane) -> this lane's B fragment of the sigma MLP
+// (levels {g, g+4, g+8, g+12} of sample lane & 15).
 template <int F, int QG>
-__device__ __forceinline__ float4_t density_eval(const DensityCtx<F>& cx, const float (&x)[3]) {
+__device__ __forceinline__ half8_t density_encode(const DensityCtx<F>& cx, const float (&x)[3]) {
     constexpr int Q = 8 / F;
     const LaneLevels<F>& lv = cx.lv;
     const uint32_t first_hashed = cx.first_hashed;
@@ -211,6 +213,14 @@ __device__ __forceinline__ float4_t density_eval(const DensityCtx<F>& cx, const 
         xf[q * F + 1] = (_Float16)a1;
     }
     }
+    return xf;
+}
+
+// encode -> sigma MLP.  Returns the rotated output rows 4g..4g+3 of sample (lane & 15): rows 0..14 = h1..h15,
+// row 15 = density logit h0.
+template <int F, int QG>
+__device__ __forceinline__ float4_t density_eval(const DensityCtx<F>& cx, const float (&x)[3]) {
+    const half8_t xf = density_encode<F, QG>(cx, x);
     float4_t acc1[kHidTiles];
 #pragma unroll
     for (int t = 0; t < kHidTiles; ++t) {
@@ -880,6 +890,231 @@ __global__ __launch_bounds__(kBlock) void k_render_occupancy(OccRays rr, const _
     }
 }
 
+// Second formulation of the same kernel: every MLP weight fragment lives in LDS in MFMA-operand order ([fragment][lane]
+// x 16 B, conflict-free ds_read_b128) instead of registers.  The kernel is latency-bound (a serial march per ray), so
+// what counts is how many rays are resident: 226 / 256 VGPRs (2 / 1 waves per SIMD) become ~128 (4 per SIMD, all 4096
+// rays of a batch in flight at once).  Arithmetic and operand order are those of k_render_occupancy.
+template <bool LIDAR>
+struct OccFrags {
+    static constexpr int IN_STEPS = LIDAR ? 3 : 1;
+    static constexpr int kSigma = 0;                           // 4 x W0 (permuted columns), 2 x W_out (rows rotated by one)
+    static constexpr int kHead = 6;                            // per head: 4*IN_STEPS first layer, 8 hidden, 2 output
+    static constexpr int kPerHead = 4 * IN_STEPS + 8 + 2;
+    static constexpr int kCount = kHead + (LIDAR ? 2 : 1) * kPerHead;
+};
+
+template <bool LIDAR>
+__device__ __forceinline__ half8_t occ_fragment(int f, int lane, const _Float16* __restrict__ w_sigma, const _Float16* __restrict__ w_a,
+                                                const _Float16* __restrict__ w_b) {
+    using FR = OccFrags<LIDAR>;
+    constexpr int IN_STEPS = FR::IN_STEPS;
+    const int g = lane >> 4, sl = lane & 15;
+    if (f < 4) {
+        const _Float16* row = w_sigma + (size_t)(16 * f + sl) * 32;
+        half8_t v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            v[2 * q] = row[(4 * q + g) * 2];
+            v[2 * q + 1] = row[(4 * q + g) * 2 + 1];
+        }
+        return v;
+    }
+    if (f < 6) return load_w_chained(w_sigma + kHidden * 32, 0, f - 4, lane, 1);
+    int r = f - FR::kHead;
+    const _Float16* W = w_a;
+    if (r >= FR::kPerHead) { r -= FR::kPerHead; W = w_b; }
+    if (r < 4 * IN_STEPS) return load_w_natural(W, 32 * IN_STEPS, r / IN_STEPS, r % IN_STEPS, lane);
+    r -= 4 * IN_STEPS;
+    if (r < 8) return load_w_chained(W + kHidden * 32 * IN_STEPS, r >> 1, r & 1, lane);
+    return load_w_chained(W + kHidden * 32 * IN_STEPS + kHidden * kHidden, 0, r - 8, lane);
+}
+
+template <bool LIDAR>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_render_occupancy_lds(OccRays rr, const _Float16* __restrict__ table, uint32_t table_bytes,
+                                                                 GridMeta meta, uint32_t first_hashed, const _Float16* __restrict__ w_sigma,
+                                                                 const _Float16* __restrict__ w_a, const _Float16* __restrict__ w_b,
+                                                                 float density_scale, float T_thresh, float bg0, float bg1, float bg2,
+                                                                 float* __restrict__ weights_sum, float* __restrict__ depth,
+                                                                 float* __restrict__ image) {
+    using FR = OccFrags<LIDAR>;
+    constexpr int F = 2, Q = 8 / F;
+    constexpr int IN_STEPS = FR::IN_STEPS;
+    __shared__ float s_scale[kMaxLevels];
+    __shared__ uint32_t s_res[kMaxLevels], s_off[kMaxLevels + 1];
+    __shared__ half8_t s_frag[FR::kCount * kWave];
+    if (threadIdx.x < kMaxLevels) {
+        s_scale[threadIdx.x] = meta.scale[threadIdx.x];
+        s_res[threadIdx.x] = meta.res[threadIdx.x];
+    }
+    if (threadIdx.x <= kMaxLevels) s_off[threadIdx.x] = meta.offset[threadIdx.x];
+    const int lane = lane_id(), g = lane >> 4, sl = lane & 15;
+    for (int f = (int)(threadIdx.x >> 6); f < FR::kCount; f += kWavesPerBlock) s_frag[f * kWave + lane] = occ_fragment<LIDAR>(f, lane, w_sigma, w_a, w_b);
+    __syncthreads();
+    const uint32_t n = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    if (n >= rr.N) return;
+    const half8_t* frag = s_frag + lane;
+
+    DensityCtx<F> cx;  // level constants + table descriptor; the weight members stay unused (LDS fragments instead)
+    cx.g = g;
+    cx.first_hashed = first_hashed;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        const int l = 4 * q + g;
+        cx.lv.scale[q] = s_scale[l];
+        cx.lv.res[q] = s_res[l];
+        cx.lv.res2[q] = s_res[l] * s_res[l];
+        cx.lv.boff[q] = s_off[l] * (uint32_t)(F * sizeof(_Float16));
+        cx.lv.rows[q] = s_off[l + 1] - s_off[l];
+    }
+    cx.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(table), 0, (int)table_bytes, 0x00020000);
+
+    const float rd0 = rr.rays_d[3 * (size_t)n], rd1 = rr.rays_d[3 * (size_t)n + 1], rd2 = rr.rays_d[3 * (size_t)n + 2];
+    const float d0 = (rd0 + 1.0f) / 2.0f, d1 = (rd1 + 1.0f) / 2.0f, d2 = (rd2 + 1.0f) / 2.0f;
+    half8_t xf[IN_STEPS];
+    if constexpr (!LIDAR) {
+        float sh[16];
+        sh4_basis(d0, d1, d2, sh);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xf[0][j] = (_Float16)(g == 0 ? sh[j] : sh[8 + j]);
+    } else {
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const int k = 32 * s + 8 * g + j;
+                float sn = 1.0f, cs = 1.0f;
+                if (k < 72) {
+                    const int i = k / 24, f = (k - 24 * i) >> 1;
+                    freq_pair(i == 0 ? d0 : (i == 1 ? d1 : d2), f, sn, cs);
+                }
+                xf[s][j] = (_Float16)sn;
+                xf[s][j + 1] = (_Float16)cs;
+            }
+    }
+    const bool takes_geo = LIDAR ? (g == 1 || g == 2) : (g >= 2);
+    const int src_a = (sl + 16 * (LIDAR ? 2 * (g - 1) : 2 * (g - 2))) & 63, src_b = (src_a + 16) & 63;
+
+    // one head on a tile: first layer over the k-steps in order (bit-identical to the ray-constant factoring), two more layers
+    auto head = [&](int base, const half8_t& x_last) {
+        float4_t acc[kHidTiles];
+#pragma unroll
+        for (int t = 0; t < kHidTiles; ++t) {
+            float4_t c = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < IN_STEPS; ++s) c = mfma16(frag[(base + t * IN_STEPS + s) * kWave], s == IN_STEPS - 1 ? x_last : xf[s], c);
+            acc[t] = c;
+        }
+        half8_t h[kHidSteps];
+        pack_hidden(acc, h);
+#pragma unroll
+        for (int t = 0; t < kHidTiles; ++t) {
+            float4_t c = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < kHidSteps; ++s) c = mfma16(frag[(base + 4 * IN_STEPS + 2 * t + s) * kWave], h[s], c);
+            acc[t] = c;
+        }
+        pack_hidden(acc, h);
+        float4_t c = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < kHidSteps; ++s) c = mfma16(frag[(base + 4 * IN_STEPS + 8 + s) * kWave], h[s], c);
+        return c;
+    };
+
+    const float o3[3] = {rr.rays_o[3 * (size_t)n], rr.rays_o[3 * (size_t)n + 1], rr.rays_o[3 * (size_t)n + 2]};
+    const float dd[3] = {rd0, rd1, rd2};
+    Marcher m;
+    m.init(o3, dd, rr.grid, rr.bound, rr.dt_gamma, rr.max_steps, rr.C, rr.H);
+    const float far = rr.fars[n];
+    float t = rr.nears[n];
+    float last_t = t, t_comp = t;
+    float ws = 0.0f, dep = 0.0f, col[3] = {0.0f, 0.0f, 0.0f};
+    uint32_t total = 0;
+    const float extent = 2.0f * rr.bound;
+    bool alive = true;
+    while (alive) {
+        uint32_t count = 0;
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f, sdt = 0.0f, sd1 = 0.0f;
+        while (t < far && count < 16u && total + count < rr.max_steps) {
+            float x, y, z, dt;
+            if (m.probe(t, x, y, z, dt)) {
+                t += dt;
+                const float d1s = t - last_t;
+                last_t = t;
+                if (count == (uint32_t)sl) { sx = x; sy = y; sz = z; sdt = dt; sd1 = d1s; }
+                ++count;
+            }
+        }
+        const uint32_t cnt = __builtin_amdgcn_readfirstlane(count);
+        if (cnt == 0u) break;
+        const float x01[3] = {(sx + rr.bound) / extent, (sy + rr.bound) / extent, (sz + rr.bound) / extent};
+        const half8_t feat = density_encode<F, 4>(cx, x01);
+        float4_t o;
+        {
+            float4_t acc1[kHidTiles];
+#pragma unroll
+            for (int tt = 0; tt < kHidTiles; ++tt) {
+                const float4_t zero = {0, 0, 0, 0};
+                acc1[tt] = mfma16(frag[(FR::kSigma + tt) * kWave], feat, zero);
+            }
+            half8_t h[kHidSteps];
+            pack_hidden(acc1, h);
+            float4_t c = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < kHidSteps; ++s) c = mfma16(frag[(FR::kSigma + 4 + s) * kWave], h[s], c);
+            o = c;
+        }
+        const float sigma = expf(o[3]) * density_scale;  // meaningful in lanes g == 3
+        const uint32_t p0 = pack_h2(o[0], o[1]), p1 = pack_h2(o[2], g == 3 ? 1.0f : o[3]);
+        typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
+        u4_t gv;
+        gv[0] = (uint32_t)__shfl((int)p0, src_a);
+        gv[1] = (uint32_t)__shfl((int)p1, src_a);
+        gv[2] = (uint32_t)__shfl((int)p0, src_b);
+        gv[3] = (uint32_t)__shfl((int)p1, src_b);
+        const half8_t x_last = takes_geo ? __builtin_bit_cast(half8_t, gv) : xf[IN_STEPS - 1];
+        float c[3] = {0.0f, 0.0f, 0.0f};  // colour of sample sl, meaningful in lanes g == 0
+        const float4_t oa = head(FR::kHead, x_last);
+        if constexpr (LIDAR) {
+            const float4_t ob = head(FR::kHead + FR::kPerHead, x_last);
+            c[0] = sigmoid_f32(oa[0]);
+            c[1] = sigmoid_f32(ob[0]);
+        } else {
+            c[0] = sigmoid_f32(oa[0]); c[1] = sigmoid_f32(oa[1]); c[2] = sigmoid_f32(oa[2]);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if ((uint32_t)i < cnt && alive) {
+                const float s_i = readlane_f32(sigma, 48 + i);
+                const float dt_i = readlane_f32(sdt, i), d1_i = readlane_f32(sd1, i);
+                const float alpha = 1.0f - expf(-s_i * dt_i);
+                const float T = 1.0f - ws;
+                const float w = alpha * T;
+                ws += w;
+                t_comp += d1_i;
+                dep += w * t_comp;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) col[k] += w * readlane_f32(c[k], i);
+                if (T < T_thresh) alive = false;
+            }
+        }
+        total += cnt;
+        if (cnt < 16u) alive = false;
+    }
+    if (lane == 0) {
+        weights_sum[n] = ws;
+        depth[n] = dep;
+        if constexpr (LIDAR) {
+            image[2 * (size_t)n] = col[0];
+            image[2 * (size_t)n + 1] = col[1];
+        } else {
+            const float rest = 1.0f - ws;
+            image[3 * (size_t)n] = col[0] + rest * bg0;
+            image[3 * (size_t)n + 1] = col[1] + rest * bg1;
+            image[3 * (size_t)n + 2] = col[2] + rest * bg2;
+        }
+    }
+}
+
 int fill_meta(GridMeta& meta, uint32_t L, const float* scales, const uint32_t* res, const uint32_t* offsets) {
     if (L == 0 || L > (uint32_t)kMaxLevels || !scales || !res || !offsets) return NVSF_ERR_INVALID_ARG;
     for (uint32_t l = 0; l < L; ++l) {
@@ -1056,6 +1291,16 @@ NVSF_API int nvsf_render_occupancy_fwd(const float* rays_o, const float* rays_d,
     const _Float16* wb = reinterpret_cast<const _Float16*>(head_b_weights_f16);
     const float b0 = h_bg_color ? h_bg_color[0] : 0.0f, b1 = h_bg_color ? h_bg_color[1] : 0.0f, b2 = h_bg_color ? h_bg_color[2] : 0.0f;
     const dim3 grid_dim(cdiv(N, kWavesPerBlock)), block(kBlock);
+    const char* variant = getenv("NVSF_OCC_KERNEL");  // "reg": weights in registers (first formulation, A/B timing)
+    if (!(variant && variant[0] == 'r')) {
+        if (lidar)
+            hipLaunchKernelGGL(k_render_occupancy_lds<true>, grid_dim, block, 0, stream, rr, tb, (uint32_t)table_bytes, meta, first_hashed, ws,
+                               wa, wb, density_scale, T_thresh, b0, b1, b2, weights_sum, depth, image);
+        else
+            hipLaunchKernelGGL(k_render_occupancy_lds<false>, grid_dim, block, 0, stream, rr, tb, (uint32_t)table_bytes, meta, first_hashed, ws,
+                               wa, wb, density_scale, T_thresh, b0, b1, b2, weights_sum, depth, image);
+        return nvsf_launch_status();
+    }
     if (lidar)
         hipLaunchKernelGGL(k_render_occupancy<true>, grid_dim, block, 0, stream, rr, tb, (uint32_t)table_bytes, meta, first_hashed, ws, wa, wb,
                            density_scale, T_thresh, b0, b1, b2, weights_sum, depth, image);
