@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--num-steps", type=int, default=768)
     ap.add_argument("--cpu-rays", type=int, default=320, help="rays per modality in the cpu_baseline sample (~10 s of CPU work; 0 = skip)")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the occupancy-grid (config 3) and dynamic-field (config 5) legs")
     ap.add_argument("--train-steps", type=int, default=3, help="extra leg: timed training steps reported under `train` (0 = skip)")
     return ap.parse_args()
 
@@ -195,6 +196,84 @@ def train_leg(model, tl, tc, tm, T, steps, dev, dist):
             "steps": steps, "allreduce_collectives_per_step": n_coll, "path": "operator path (autograd): HIP fwd kernels, HIP hash-grid/compositor bwd, rocBLAS MLP bwd"}
 
 
+def occupancy_leg(model_cls, dev, n_rays, steps):
+    """Secondary figure (BASELINE config 3): the config-2 field and ray batches through the occupancy-grid renderer,
+    procedural occupancy grid (union of 64 random boxes, ~10 % occupied), max 1024 samples per ray.
+    eval = the one-launch fused kernel; eval_host_loop = the reference's protocol (march_rays -> field -> composite_rays
+    per survivor round, one device->host sync each); train = march_rays_train -> field -> composite_rays_train forward."""
+    from nvsf import synthetic as S
+    torch.manual_seed(0)
+    m = model_cls(bound=S.BOUND, min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH, num_frames=S.NUM_FRAMES)
+    m = m.to(dev).enable_occupancy_grid().to(dev)
+    rng = np.random.default_rng(0)
+    grid = S.boxes_density_grid(rng, cascades=m.cascade, H=m.grid_size, n_boxes=64)
+    m.set_density_grid(torch.from_numpy(grid).to(dev), thresh=0.5)
+    lo, ld = S.lidar_rays(n_rays, rng)
+    co, cd = S.camera_rays(n_rays, rng)
+    tl = [torch.from_numpy(a).to(dev)[None] for a in (lo, ld)]
+    tc = [torch.from_numpy(a).to(dev)[None] for a in (co, cd)]
+    tm = torch.tensor([[0.5]], device=dev)
+
+    def timed(fused, k):
+        def step():
+            with torch.no_grad():
+                m.render(tl[0], tl[1], tm, cal_lidar_color=True, max_steps=1024, fused=fused)
+                m.render(tc[0], tc[1], tm, cal_lidar_color=False, max_steps=1024, fused=fused)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / k
+
+    out = {"metric": "rendered rays/sec (LiDAR+cam), occupancy grid + early termination", "max_steps": 1024,
+           "occupied_fraction": [float((g > 0.5).mean()) for g in grid]}
+    m.eval()
+    dt = timed(True, steps)
+    out["eval"] = {"value": 2 * n_rays / dt, "ms_per_step": dt * 1e3, "path": "nvsf_render_occupancy_fwd (one launch per batch)"}
+    dt = timed(False, max(2, steps // 4))
+    out["eval_host_loop"] = {"value": 2 * n_rays / dt, "ms_per_step": dt * 1e3, "path": "march_rays -> field -> composite_rays survivor loop"}
+    m.train()
+    dt = timed(True, steps)
+    out["train_forward"] = {"value": 2 * n_rays / dt, "ms_per_step": dt * 1e3, "path": "march_rays_train -> field -> composite_rays_train",
+                            "samples_camera_batch": int(m.step_counter[(m.local_step - 1) % 16][0])}
+    return out
+
+
+def dynamic_leg(dev, n_rays, T, steps):
+    """Secondary figure (BASELINE config 5): the reference-default space-time field (K-planes + static / dynamic hash grids
+    + flow field, 93.6 M parameters, time_resolution 8), forward render of n_rays LiDAR + n_rays camera rays."""
+    from nvsf import synthetic as S
+    from nvsf.nerf.models.network_dynamic import NeRFNetwork
+    torch.manual_seed(0)
+    m = NeRFNetwork(time_resolution=8, num_frames=S.NUM_FRAMES, bound=S.BOUND, min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR,
+                    lidar_max_depth=S.LIDAR_MAX_DEPTH).to(dev).eval()
+    rng = np.random.default_rng(0)
+    lo, ld = S.lidar_rays(n_rays, rng)
+    co, cd = S.camera_rays(n_rays, rng)
+    tl = [torch.from_numpy(a).to(dev)[None] for a in (lo, ld)]
+    tc = [torch.from_numpy(a).to(dev)[None] for a in (co, cd)]
+    tm = torch.tensor([[0.5]], device=dev)
+
+    def step():
+        with torch.no_grad():
+            m.render(tl[0], tl[1], tm, cal_lidar_color=True, num_steps=T)
+            m.render(tc[0], tc[1], tm, cal_lidar_color=False, num_steps=T)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"metric": "rendered rays/sec (LiDAR+cam), dynamic 4-D field", "value": 2 * n_rays / dt, "ms_per_step": dt * 1e3,
+            "num_rays": n_rays, "num_rays_lidar": n_rays, "num_steps": T, "parameters_M": sum(p.numel() for p in m.parameters()) / 1e6,
+            "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -290,6 +369,9 @@ def main():
             line["kernel_ms_sum"] = sum(r["ms"] for r in rows)
         if args.cpu_rays > 0 and world == 1:
             line["cpu_baseline"] = cpu_baseline(model, T, args.cpu_rays)
+        if not args.no_extra_legs and world == 1:  # secondary figures for BASELINE configs 3 and 5 (never `value`)
+            line["occupancy"] = occupancy_leg(NeRFNetworkStatic, dev, args.num_rays, 10)
+            line["dynamic"] = dynamic_leg(dev, args.num_rays, T, 3)
     if args.train_steps > 0:
         tr = train_leg(model, tl, tc, tm, T, args.train_steps, dev, dist)
         if rank == 0:
