@@ -101,6 +101,103 @@ __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd(const float* __restrict
     }
 }
 
+// Table gradient, run-merging formulation.  Float atomics execute at the memory side and their cost follows the
+// number of distinct 64-B segments a wave-instruction touches (MI355X_MICROARCH.md, Global float atomics), while
+// consecutive rows of x are neighbouring samples of a ray: at every level but the finest few they stay in the same
+// cell for several rows.  A thread therefore owns (a chunk of `run` consecutive rows, one level), walks the rows in
+// order, keeps the 2^D x F corner sums of the current cell in registers and issues its atomics only when the cell
+// changes.  Lanes of a chunk are adjacent (lane = chunk * L + level), so the gradient row is read as one contiguous
+// segment and the position is a broadcast.  Same sums as k_hashgrid_bwd up to the order of the fp32 additions.
+template <int D, int F, bool GRAD_F16>
+__global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_runs(const float* __restrict__ x, uint32_t M, uint32_t x_stride, uint32_t c0,
+                                                              uint32_t c1, uint32_t c2, uint32_t L, GridMeta meta,
+                                                              const void* __restrict__ grad_out, uint32_t go_stride,
+                                                              float* __restrict__ grad_table, uint32_t run) {
+    const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t chunk = tid / L, l = tid - chunk * L;
+    const unsigned long long first = (unsigned long long)chunk * run;
+    if (first >= M) return;
+    const uint32_t m0 = (uint32_t)first, m1 = (uint32_t)(first + run < M ? first + run : M);
+    const float scale = meta.scale[l];
+    const uint32_t res = meta.res[l], row0 = meta.offset[l], hsize = meta.offset[l + 1] - row0;
+    constexpr int NC = 1 << D;
+    float acc[NC][F];
+    uint32_t cur[D];
+    bool have = false;
+#pragma unroll
+    for (int d = 0; d < D; ++d) cur[d] = 0u;
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int f = 0; f < F; ++f) acc[c][f] = 0.0f;
+
+    auto flush = [&]() {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            uint32_t cc[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) cc[d] = cur[d] + ((c >> d) & 1u);
+            float* dst = grad_table + ((size_t)row0 + grid_row<D>(cc, res, hsize)) * F;
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                atomicAdd(dst + f, acc[c][f]);
+                acc[c][f] = 0.0f;
+            }
+        }
+    };
+    auto load_row = [&](uint32_t m, float (&xs)[D], float (&g)[F]) {
+        const float* px = x + (size_t)m * x_stride;
+        xs[0] = px[c0];
+        xs[1] = px[c1];
+        if constexpr (D == 3) xs[2] = px[c2];
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            if constexpr (GRAD_F16) g[f] = (float)reinterpret_cast<const _Float16*>(grad_out)[(size_t)m * go_stride + l * F + f];
+            else g[f] = reinterpret_cast<const float*>(grad_out)[(size_t)m * go_stride + l * F + f];
+        }
+    };
+    float xs_n[D], g_n[F];
+    load_row(m0, xs_n, g_n);
+    for (uint32_t m = m0; m < m1; ++m) {
+        float xs[D], g[F];
+#pragma unroll
+        for (int d = 0; d < D; ++d) xs[d] = xs_n[d];
+#pragma unroll
+        for (int f = 0; f < F; ++f) g[f] = g_n[f];
+        if (m + 1 < m1) load_row(m + 1, xs_n, g_n);  // next row in flight while this one is processed
+        bool any = false;
+#pragma unroll
+        for (int f = 0; f < F; ++f) any |= (g[f] != 0.0f);
+        if (!any) continue;
+        float frac[D];
+        uint32_t cell[D];
+        bool same = have;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float pos = fmaf(scale, xs[d], 0.5f);
+            const float fl = floorf(pos);
+            frac[d] = pos - fl;
+            cell[d] = (uint32_t)(int32_t)fl;
+            same = same && (cell[d] == cur[d]);
+        }
+        if (!same) {
+            if (have) flush();
+#pragma unroll
+            for (int d = 0; d < D; ++d) cur[d] = cell[d];
+            have = true;
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            float w = 1.0f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) w = w * ((c & (1 << d)) ? frac[d] : (1.0f - frac[d]));
+#pragma unroll
+            for (int f = 0; f < F; ++f) acc[c][f] += w * g[f];
+        }
+    }
+    if (have) flush();
+}
+
 int fill_meta(GridMeta& meta, uint32_t L, const float* scales, const uint32_t* res, const uint32_t* offsets) {
     if (L == 0 || L > (uint32_t)kMaxLevels || !scales || !res || !offsets) return NVSF_ERR_INVALID_ARG;
     for (uint32_t l = 0; l < L; ++l) {
@@ -159,8 +256,27 @@ NVSF_API int nvsf_hashgrid_bwd(const float* x, uint32_t M, uint32_t x_stride, co
     const int st = fill_meta(meta, L, h_scales, h_res, h_offsets);
     if (st != NVSF_OK) return st;
     const uint32_t c0 = cols[0], c1 = cols[1], c2 = D == 3 ? cols[2] : 0;
+    const char* variant = getenv("NVSF_HASHGRID_BWD");  // "atomic": one thread per (row, level), no run merging (A/B timing)
+    if (!(variant && variant[0] == 'a')) {
+        const char* run_env = getenv("NVSF_HASHGRID_BWD_RUN");
+        const uint32_t run = run_env ? (uint32_t)atoi(run_env) : (M >= (1u << 20) ? 128u : 32u);
+        const unsigned long long threads = (unsigned long long)cdiv(M, run) * L;
+        const dim3 rgrid((uint32_t)((threads + kBlock - 1) / kBlock));
+#define CALLR(DD, FF)                                                                                                                \
+    do {                                                                                                                             \
+        if (grad_is_f16)                                                                                                             \
+            hipLaunchKernelGGL((k_hashgrid_bwd_runs<DD, FF, true>), rgrid, dim3(kBlock), 0, stream, x, M, x_stride, c0, c1, c2, L, meta, \
+                               grad_out, go_stride, grad_table_f32, run);                                                            \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((k_hashgrid_bwd_runs<DD, FF, false>), rgrid, dim3(kBlock), 0, stream, x, M, x_stride, c0, c1, c2, L, meta, \
+                               grad_out, go_stride, grad_table_f32, run);                                                            \
+    } while (0)
+        DISPATCH_DF(D, F, CALLR);
+#undef CALLR
+        return nvsf_launch_status();
+    }
     const dim3 grid(cdiv(M, kBlock), L);
-#define CALL(DD, FF)                                                                                                             \
+#define CALL(DD, FF)                                                                                                          \
     do {                                                                                                                         \
         if (grad_is_f16)                                                                                                         \
             hipLaunchKernelGGL((k_hashgrid_bwd<DD, FF, true>), grid, dim3(kBlock), 0, stream, x, M, x_stride, c0, c1, c2, L, meta, \

@@ -57,11 +57,18 @@ class NeRFNetworkStatic(NeRFRenderer):
         return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
 
     def color(self, x, d, cal_lidar_color=False, mask=None, geo_feat=None, **kwargs):
+        dense_mask = None
         if mask is not None:
-            rgbs = torch.zeros(mask.shape[0], self.out_dim, dtype=x.dtype, device=x.device)
-            if not mask.any():
-                return rgbs
-            d, geo_feat = d[mask], geo_feat[mask]
+            n_active = int(mask.sum())  # one host sync (the reference's `mask.any()` costs the same)
+            if n_active == 0:
+                return torch.zeros(mask.shape[0], self.out_dim, dtype=x.dtype, device=x.device)
+            if 4 * n_active >= mask.numel():
+                # most samples are active: evaluate all of them and zero the rest -- same values and gradients as the
+                # gather / scatter form (masked rows are constants), without three index kernels each way
+                dense_mask, mask = mask, None
+            else:
+                rgbs = torch.zeros(mask.shape[0], self.out_dim, dtype=x.dtype, device=x.device)
+                d, geo_feat = d[mask], geo_feat[mask]
         d = (d + 1) / 2
         if cal_lidar_color:
             logits = torch.cat([self.view_encoder_lidar(d), geo_feat], dim=-1)
@@ -69,6 +76,8 @@ class NeRFNetworkStatic(NeRFRenderer):
         else:
             h = self.color_net(torch.cat([self.view_encoder_camera(d), geo_feat], dim=-1))
         h = torch.sigmoid(h)
+        if dense_mask is not None:
+            return (h * dense_mask.unsqueeze(-1)).to(x.dtype)
         if mask is None:
             return h
         rgbs[mask] = h.to(rgbs.dtype)
