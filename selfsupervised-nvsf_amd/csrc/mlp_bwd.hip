@@ -1,0 +1,335 @@
+// Fused MLP backward for gfx950: data gradients AND weight gradients of the bias-free ReLU MLPs of the NVSF hot path
+// (width 64, 1 or 2 hidden layers, up to 128 padded inputs, 16 padded outputs) in one kernel.  It replaces, for the
+// training path, what tcnn's FullyFusedMLP backward does behind tcnn.Network (network_dynamic.py:125-161, 180-189).
+//
+// A workgroup (4 waves) takes 64 samples per iteration, one 16-sample tile per wave.
+//   data path (per wave, sample on the lane, units in registers -- the layout of mlp_device.h):
+//     recompute the forward activations from x, then  dH_l^T = W_{l+1}^T dP_{l+1}^T  with the TRANSPOSED weights as
+//     MFMA A operand, ReLU mask from the recomputed activations (same lane, same register slot: no data movement),
+//     down to dX (stored) -- activations and gradients never leave registers between layers;
+//   weight gradients: dW_l[o][k] = sum over samples dP_l[s][o] A_{l-1}[s][k] has the SAMPLE as the MFMA K dimension,
+//     so both operands need "unit on the lane, 8 consecutive samples in registers".  The four waves transpose their
+//     tiles through LDS ([unit][64 samples], 2-byte scatter writes, 16-byte fragment reads), then wave w accumulates
+//     the output-tile row w of dW_l over the 64 samples (K = 2 x 32) in registers; after the last iteration the
+//     accumulators are added to the fp32 gradient buffer with one atomic per element and workgroup.
+// Every weight fragment (forward and transposed) lives in LDS in MFMA-operand order ([fragment][lane] x 16 B).
+// Gradients travel in fp16 scaled by `grad_scale` (tcnn's loss_scale); dX and dW are unscaled in fp32 on the way out.
+#include "mlp_device.h"
+
+namespace {
+constexpr int kBlock = 256;
+constexpr int kWavesPerBlock = kBlock / kWave;
+constexpr int kPitch = 72;  // halfs per LDS row of the transposed staging: 64 samples + 8 (16-B aligned, spreads the banks)
+
+__device__ __forceinline__ int kappa(int s, int g, int j) { return 16 * (2 * s + (j >> 2)) + 4 * g + (j & 3); }
+
+// fp32 accumulator tiles (2s, 2s+1) -> B fragment of k-step s, no activation (cf. relu_pack)
+__device__ __forceinline__ half8_t plain_pack(float4_t a, float4_t b) {
+    const float8_t v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_convertvector(v, half8_t);
+}
+
+template <bool X_F16>
+__device__ __forceinline__ half8_t load_x_frag_b(const void* __restrict__ x, size_t row, uint32_t x_stride, int k0, int n_in, int in_cols,
+                                                 bool vec_ok) {
+    half8_t v;
+    if (k0 + 8 <= n_in && vec_ok) {
+        if constexpr (X_F16) {
+            v = *reinterpret_cast<const half8_t*>(reinterpret_cast<const _Float16*>(x) + row * x_stride + k0);
+        } else {
+            const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(x) + row * x_stride + k0);
+            const float4 a = p[0], b = p[1];
+            v[0] = (_Float16)a.x; v[1] = (_Float16)a.y; v[2] = (_Float16)a.z; v[3] = (_Float16)a.w;
+            v[4] = (_Float16)b.x; v[5] = (_Float16)b.y; v[6] = (_Float16)b.z; v[7] = (_Float16)b.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = k0 + j;
+            float e = k < in_cols ? 1.0f : 0.0f;
+            if (k < n_in) {
+                if constexpr (X_F16) e = (float)reinterpret_cast<const _Float16*>(x)[row * x_stride + k];
+                else e = reinterpret_cast<const float*>(x)[row * x_stride + k];
+            }
+            v[j] = (_Float16)e;
+        }
+    }
+    return v;
+}
+
+template <int IN_STEPS, int N_HIDDEN>
+struct BwdFrags {
+    static constexpr int IN_TILES = 2 * IN_STEPS;                   // 16-wide tiles of the (padded) input
+    static constexpr int kF0 = 0;                                   // forward first layer [t][s]
+    static constexpr int kF1 = kF0 + 4 * IN_STEPS;                  // forward hidden layer [t][s] (N_HIDDEN == 2)
+    static constexpr int kFO = kF1 + (N_HIDDEN == 2 ? 8 : 0);       // forward output layer [s]
+    static constexpr int kBO = kFO + 2;                             // W_out^T [t] (K = 16 outputs, zero-padded to 32)
+    static constexpr int kB1 = kBO + 4;                             // W_1^T [t][s]
+    static constexpr int kB0 = kB1 + (N_HIDDEN == 2 ? 8 : 0);       // W_0^T [input tile][s]
+    static constexpr int kCount = kB0 + 2 * IN_TILES;
+};
+
+template <int IN_STEPS, int N_HIDDEN>
+__device__ __forceinline__ half8_t bwd_fragment(int f, int lane, const _Float16* __restrict__ W, int in_cols) {
+    using FR = BwdFrags<IN_STEPS, N_HIDDEN>;
+    const int g = lane >> 4, c = lane & 15;
+    const _Float16* W0 = W;
+    const _Float16* W1 = W + (size_t)kHidden * in_cols;
+    const _Float16* WO = W1 + (N_HIDDEN == 2 ? kHidden * kHidden : 0);
+    half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (f < FR::kF1) return load_w_natural(W0, in_cols, f / IN_STEPS, f % IN_STEPS, lane);
+    if (f < FR::kFO) { const int r = f - FR::kF1; return load_w_chained(W1, r >> 1, r & 1, lane); }
+    if (f < FR::kBO) return load_w_chained(WO, 0, f - FR::kFO, lane);
+    if (f < FR::kB1) {  // A[m = hidden unit 16t + c][k = output 8g + j]
+        const int t = f - FR::kBO;
+        if (g < 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = WO[(size_t)(8 * g + j) * kHidden + 16 * t + c];
+        }
+        return v;
+    }
+    if (f < FR::kB0) {  // A[m = hidden unit 16t + c][k <-> hidden unit kappa(s, g, j)] = W1[kappa][16t + c]
+        const int r = f - FR::kB1, t = r >> 1, s = r & 1;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = W1[(size_t)kappa(s, g, j) * kHidden + 16 * t + c];
+        return v;
+    }
+    {  // A[m = input 16ti + c][k <-> hidden unit kappa(s, g, j)] = W0[kappa][16ti + c]
+        const int r = f - FR::kB0, ti = r >> 1, s = r & 1;
+        if (16 * ti + c < in_cols) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = W0[(size_t)kappa(s, g, j) * in_cols + 16 * ti + c];
+        }
+        return v;
+    }
+}
+
+// ReLU mask: accumulator tile t, register r of this lane  <->  element (t & 1) * 4 + r of B fragment h[t >> 1]
+__device__ __forceinline__ void relu_mask(float4_t (&gacc)[kHidTiles], const half8_t (&h)[kHidSteps]) {
+#pragma unroll
+    for (int t = 0; t < kHidTiles; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (!(h[t >> 1][(t & 1) * 4 + r] > (_Float16)0.0f)) gacc[t][r] = 0.0f;
+}
+
+template <int IN_STEPS, int N_HIDDEN, bool X_F16>
+__global__ __launch_bounds__(kBlock) void k_mlp_bwd(const void* __restrict__ x, uint32_t M, uint32_t n_in, uint32_t x_stride,
+                                                    const _Float16* __restrict__ weights, uint32_t in_cols,
+                                                    const float* __restrict__ grad_out, uint32_t n_out, uint32_t go_stride, float grad_scale,
+                                                    float* __restrict__ grad_x, uint32_t gx_stride, float* __restrict__ grad_w, int vec_ok) {
+    using FR = BwdFrags<IN_STEPS, N_HIDDEN>;
+    constexpr int IN_TILES = FR::IN_TILES;
+    __shared__ half8_t s_frag[FR::kCount * kWave];
+    __shared__ _Float16 s_g[kHidden * kPitch];           // dP^T  [unit][sample]
+    __shared__ _Float16 s_a[(IN_STEPS > 2 ? 32 * IN_STEPS : 64) * kPitch];  // A^T [unit][sample]: hidden (64) or padded input units
+    const int lane = lane_id(), g = lane >> 4, c = lane & 15, w = (int)(threadIdx.x >> 6);
+    for (int f = w; f < FR::kCount; f += kWavesPerBlock) s_frag[f * kWave + lane] = bwd_fragment<IN_STEPS, N_HIDDEN>(f, lane, weights, (int)in_cols);
+    __syncthreads();
+    const half8_t* frag = s_frag + lane;
+    const float inv_scale = 1.0f / grad_scale;
+
+    // weight-gradient accumulators of this wave: output-tile row w of dW0 and dW1, k-tile w of dW_out
+    float4_t dw0[IN_TILES], dw1[kHidTiles], dwo;
+#pragma unroll
+    for (int i = 0; i < IN_TILES; ++i) dw0[i] = float4_t{0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < kHidTiles; ++i) dw1[i] = float4_t{0, 0, 0, 0};
+    dwo = float4_t{0, 0, 0, 0};
+
+    const uint32_t n_tiles = (M + 15) / 16;
+    const uint32_t tiles_per_iter = gridDim.x * kWavesPerBlock;
+    const uint32_t n_iters = (n_tiles + tiles_per_iter - 1) / tiles_per_iter;
+    const int col = 16 * w + c;  // this lane's sample column in the staging arrays
+
+    // transposed fragment (unit row0 + c, samples 32*ks + 8g .. +7) of a staging array
+    auto t_frag = [&](const _Float16* arr, int row0, int ks) {
+        return *reinterpret_cast<const half8_t*>(arr + (size_t)(row0 + c) * kPitch + 32 * ks + 8 * g);
+    };
+
+    for (uint32_t it = 0; it < n_iters; ++it) {
+        const uint32_t tile = (it * gridDim.x + blockIdx.x) * kWavesPerBlock + (uint32_t)w;
+        const uint32_t m = tile * 16 + (uint32_t)c;
+        const bool valid = tile < n_tiles && m < M;
+        const size_t row = valid ? m : (M - 1);
+        // ---- forward recompute
+        half8_t xf[IN_STEPS];
+#pragma unroll
+        for (int s = 0; s < IN_STEPS; ++s) xf[s] = load_x_frag_b<X_F16>(x, row, x_stride, 32 * s + 8 * g, (int)n_in, (int)in_cols, vec_ok != 0);
+        float4_t acc[kHidTiles];
+#pragma unroll
+        for (int t = 0; t < kHidTiles; ++t) {
+            float4_t a = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < IN_STEPS; ++s) a = mfma16(frag[(FR::kF0 + t * IN_STEPS + s) * kWave], xf[s], a);
+            acc[t] = a;
+        }
+        half8_t h0[kHidSteps], h1[kHidSteps];
+        pack_hidden(acc, h0);
+        if constexpr (N_HIDDEN == 2) {
+#pragma unroll
+            for (int t = 0; t < kHidTiles; ++t) {
+                float4_t a = {0, 0, 0, 0};
+#pragma unroll
+                for (int s = 0; s < kHidSteps; ++s) a = mfma16(frag[(FR::kF1 + 2 * t + s) * kWave], h0[s], a);
+                acc[t] = a;
+            }
+            pack_hidden(acc, h1);
+        }
+        const half8_t(&h_last)[kHidSteps] = N_HIDDEN == 2 ? h1 : h0;
+        // ---- output gradient -> B fragment (natural order of the 16 outputs, zero beyond n_out, scaled)
+        half8_t go = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (valid && g < 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t o = 8 * g + j;
+                if (o < n_out) go[j] = (_Float16)(grad_out[(size_t)m * go_stride + o] * grad_scale);
+            }
+        }
+        // ---- data path backward
+        float4_t gacc[kHidTiles];
+#pragma unroll
+        for (int t = 0; t < kHidTiles; ++t) gacc[t] = mfma16(frag[(FR::kBO + t) * kWave], go, float4_t{0, 0, 0, 0});
+        relu_mask(gacc, h_last);
+        half8_t gp_last[kHidSteps], gp0[kHidSteps];
+#pragma unroll
+        for (int s = 0; s < kHidSteps; ++s) gp_last[s] = plain_pack(gacc[2 * s], gacc[2 * s + 1]);
+        if constexpr (N_HIDDEN == 2) {
+#pragma unroll
+            for (int t = 0; t < kHidTiles; ++t) {
+                float4_t a = {0, 0, 0, 0};
+#pragma unroll
+                for (int s = 0; s < kHidSteps; ++s) a = mfma16(frag[(FR::kB1 + 2 * t + s) * kWave], gp_last[s], a);
+                gacc[t] = a;
+            }
+            relu_mask(gacc, h0);
+#pragma unroll
+            for (int s = 0; s < kHidSteps; ++s) gp0[s] = plain_pack(gacc[2 * s], gacc[2 * s + 1]);
+        } else {
+#pragma unroll
+            for (int s = 0; s < kHidSteps; ++s) gp0[s] = gp_last[s];
+        }
+        if (grad_x) {
+#pragma unroll
+            for (int ti = 0; ti < IN_TILES; ++ti) {
+                if (16u * ti < n_in) {
+                    float4_t a = {0, 0, 0, 0};
+#pragma unroll
+                    for (int s = 0; s < kHidSteps; ++s) a = mfma16(frag[(FR::kB0 + 2 * ti + s) * kWave], gp0[s], a);
+                    if (valid) {
+                        const uint32_t k0 = 16 * ti + 4 * g;
+                        float* dst = grad_x + (size_t)m * gx_stride + k0;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (k0 + r < n_in) dst[r] = a[r] * inv_scale;
+                    }
+                }
+            }
+        }
+        // ---- weight gradients, layer by layer through the transposed staging
+        // (1) output layer: dW_out[o][k] = sum_s dOut[s][o] * h_last[s][k]
+        if (g < 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s_g[(size_t)(8 * g + j) * kPitch + col] = go[j];
+        }
+#pragma unroll
+        for (int s = 0; s < kHidSteps; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s_a[(size_t)kappa(s, g, j) * kPitch + col] = h_last[s][j];
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) dwo = mfma16(t_frag(s_g, 0, ks), t_frag(s_a, 16 * w, ks), dwo);
+        __syncthreads();
+        // (2) hidden layer: dW1[o][k] = sum_s dP1[s][o] * h0[s][k]
+        if constexpr (N_HIDDEN == 2) {
+#pragma unroll
+            for (int s = 0; s < kHidSteps; ++s)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    s_g[(size_t)kappa(s, g, j) * kPitch + col] = gp_last[s][j];
+                    s_a[(size_t)kappa(s, g, j) * kPitch + col] = h0[s][j];
+                }
+            __syncthreads();
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const half8_t a = t_frag(s_g, 16 * w, ks);
+#pragma unroll
+                for (int tk = 0; tk < kHidTiles; ++tk) dw1[tk] = mfma16(a, t_frag(s_a, 16 * tk, ks), dw1[tk]);
+            }
+            __syncthreads();
+        }
+        // (3) first layer: dW0[o][k] = sum_s dP0[s][o] * x[s][k]
+#pragma unroll
+        for (int s = 0; s < kHidSteps; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s_g[(size_t)kappa(s, g, j) * kPitch + col] = gp0[s][j];
+#pragma unroll
+        for (int s = 0; s < IN_STEPS; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s_a[(size_t)(32 * s + 8 * g + j) * kPitch + col] = xf[s][j];
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const half8_t a = t_frag(s_g, 16 * w, ks);
+#pragma unroll
+            for (int tk = 0; tk < IN_TILES; ++tk) dw0[tk] = mfma16(a, t_frag(s_a, 16 * tk, ks), dw0[tk]);
+        }
+        __syncthreads();
+    }
+    // ---- flush: accumulator element (row 4g + r, column c) of tile (to, tk)
+    float* gw0 = grad_w;
+    float* gw1 = grad_w + (size_t)kHidden * in_cols;
+    float* gwo = gw1 + (N_HIDDEN == 2 ? kHidden * kHidden : 0);
+#pragma unroll
+    for (int tk = 0; tk < IN_TILES; ++tk) {
+        const uint32_t k = 16 * tk + c;
+        if (k < in_cols) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(gw0 + (size_t)(16 * w + 4 * g + r) * in_cols + k, dw0[tk][r] * inv_scale);
+        }
+    }
+    if constexpr (N_HIDDEN == 2) {
+#pragma unroll
+        for (int tk = 0; tk < kHidTiles; ++tk)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(gw1 + (size_t)(16 * w + 4 * g + r) * kHidden + 16 * tk + c, dw1[tk][r] * inv_scale);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(gwo + (size_t)(4 * g + r) * kHidden + 16 * w + c, dwo[r] * inv_scale);
+}
+}  // namespace
+
+#define REQUIRE(cond) do { if (!(cond)) return NVSF_ERR_INVALID_ARG; } while (0)
+
+NVSF_API int nvsf_mlp_bwd(const void* x, int x_is_f16, uint32_t M, uint32_t n_in, uint32_t x_stride, const void* weights_f16,
+                          uint32_t in_cols, uint32_t hidden, uint32_t n_hidden, uint32_t out_cols, const float* grad_out, uint32_t n_out,
+                          uint32_t go_stride, float grad_scale, float* grad_x, uint32_t gx_stride, float* grad_weights_f32,
+                          hipStream_t stream) {
+    if (M == 0) return NVSF_OK;
+    REQUIRE(x && weights_f16 && grad_out && grad_weights_f32);
+    REQUIRE(n_in >= 1 && n_in <= in_cols && in_cols % 16 == 0 && x_stride >= n_in);
+    REQUIRE(n_out >= 1 && n_out <= 16 && go_stride >= n_out && grad_scale > 0.0f);
+    REQUIRE(!grad_x || gx_stride >= n_in);
+    REQUIRE((reinterpret_cast<uintptr_t>(weights_f16) & 15u) == 0);
+    if (hidden != (uint32_t)kHidden || out_cols != 16 || n_hidden < 1 || n_hidden > 2 || in_cols > 128) return NVSF_ERR_UNSUPPORTED;
+    const int in_steps = (int)((in_cols + 31) / 32);
+    const size_t esz = x_is_f16 ? 2 : 4;
+    const int vec_ok = ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) && ((x_stride * esz) % 16 == 0);
+    const uint32_t n_tiles = (M + 15) / 16;
+    uint32_t blocks = (n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (blocks > 512u) blocks = 512u;  // 256 CUs x 2 resident workgroups; fewer workgroups = fewer flush atomics
+    const _Float16* w = reinterpret_cast<const _Float16*>(weights_f16);
+#define LAUNCH(S, H, XF)                                                                                                          \
+    hipLaunchKernelGGL((k_mlp_bwd<S, H, XF>), dim3(blocks), dim3(kBlock), 0, stream, x, M, n_in, x_stride, w, in_cols, grad_out, \
+                       n_out, go_stride, grad_scale, grad_x, gx_stride, grad_weights_f32, vec_ok)
+#define BY_X(S, H) do { if (x_is_f16) LAUNCH(S, H, true); else LAUNCH(S, H, false); } while (0)
+#define BY_H(S) do { if (n_hidden == 1) BY_X(S, 1); else BY_X(S, 2); } while (0)
+    switch (in_steps) {
+        case 1: BY_H(1); break;
+        case 2: BY_H(2); break;
+        case 3: BY_H(3); break;
+        case 4: BY_H(4); break;
+        default: return NVSF_ERR_UNSUPPORTED;
+    }
+    return nvsf_launch_status();
+}

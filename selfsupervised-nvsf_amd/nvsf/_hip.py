@@ -39,6 +39,7 @@ SIGNATURES = {
     "nvsf_freq_encode": [_P, _U, _U, _U, _P, _U],
     "nvsf_sh4_encode": [_P, _U, _P, _U],
     "nvsf_mlp_fwd": [_P, _I, _U, _U, _U, _P, _U, _U, _U, _U, _P, _U],
+    "nvsf_mlp_bwd": [_P, _I, _U, _U, _U, _P, _U, _U, _U, _U, _P, _U, _U, _F, _P, _U, _P],
     "nvsf_planes_fwd": [_P, _U, _P, _U, _U, _P, _I, _P, _P],
     "nvsf_planes_bwd": [_P, _U, _P, _U, _U, _P, _I, _P, _P, _P, _P],
     "nvsf_hashgrid4d_dynamic_fwd": [_P, _U, _P, _U, _U, _U, _P, _P, _P, _P, _P, _I, _I, _P],

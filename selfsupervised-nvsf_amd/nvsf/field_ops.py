@@ -161,10 +161,27 @@ def _weight_grad(g, a, rows_per_slice=4096):
     return out
 
 
+MLP_GRAD_SCALE = 128.0  # fp16 gradients inside nvsf_mlp_bwd are multiplied by this (tcnn's default loss_scale)
+
+
+def mlp_backward(x, weights_f16, spec, grad_out, need_grad_x=True, grad_scale=MLP_GRAD_SCALE):
+    """One fused kernel: (x, weights, dL/dout [M, n_out] fp32) -> dL/dx fp32 [M, n_in] (or None), dL/dW fp32 [n_params]."""
+    if x.dtype not in (torch.float16, torch.float32):
+        x = x.float()
+    x = x.contiguous()
+    grad_out = grad_out.float().contiguous()
+    M = x.shape[0]
+    grad_w = torch.zeros(spec.n_params, dtype=torch.float32, device=x.device)
+    grad_x = torch.empty(M, spec.n_in, dtype=torch.float32, device=x.device) if need_grad_x else None
+    _hip.call("nvsf_mlp_bwd", _hip.ptr(x), 1 if x.dtype == torch.float16 else 0, M, spec.n_in, x.stride(0), _hip.ptr(weights_f16),
+              spec.in_cols, spec.hidden, spec.n_hidden, spec.out_cols, _hip.ptr(grad_out), grad_out.shape[1], grad_out.stride(0),
+              float(grad_scale), _hip.ptr(grad_x), spec.n_in, _hip.ptr(grad_w))
+    return grad_x, grad_w
+
+
 class MlpFn(Function):
-    """out = MLP(x; params).  Forward: one fused MFMA kernel.  Backward: the chain of plain fp16 GEMMs
-    (dW_l = dY_l^T A_{l-1}, dA_{l-1} = dY_l W_l) through torch.matmul, with the hidden activations
-    recomputed from the saved input."""
+    """out = MLP(x; params).  Forward: one fused MFMA kernel.  Backward: one fused MFMA kernel (nvsf_mlp_bwd:
+    activations recomputed from the saved input, data and weight gradients in the same launch)."""
 
     @staticmethod
     def forward(ctx, x, params, weights_f16, spec):
@@ -175,6 +192,20 @@ class MlpFn(Function):
 
     @staticmethod
     def backward(ctx, grad_out):
+        x, weights_f16 = ctx.saved_tensors
+        spec = ctx.spec
+        if spec.n_hidden <= 2 and spec.hidden == 64 and spec.out_cols == 16:
+            grad_x, grad_w = mlp_backward(x, weights_f16, spec, grad_out, need_grad_x=ctx.needs_input_grad[0])
+            if grad_x is not None and grad_x.dtype != x.dtype:
+                grad_x = grad_x.to(x.dtype)
+            return grad_x, (grad_w if ctx.needs_input_grad[1] else None), None, None
+        return MlpFn._backward_gemm(ctx, grad_out)
+
+    @staticmethod
+    def _backward_gemm(ctx, grad_out):
+        """Shapes nvsf_mlp_bwd is not built for (3 hidden layers): the chain of plain fp16 GEMMs through torch.matmul
+        (dW_l = dY_l^T A_{l-1}, dA_{l-1} = dY_l W_l), hidden activations recomputed from the saved input.  Also the
+        independent formulation the kernel is tested against (tests/test_field_gpu.py)."""
         x, weights_f16 = ctx.saved_tensors
         spec = ctx.spec
         mats = spec.split(weights_f16)

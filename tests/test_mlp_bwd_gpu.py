@@ -1,0 +1,113 @@
+"""nvsf_mlp_bwd (fused data + weight gradients of the width-64 MLPs) against two independent formulations:
+  * exact small-integer arithmetic (every product and sum representable: a transposed / permuted MFMA fragment
+    or a wrong LDS transpose cannot pass), evaluated in numpy float64;
+  * fp32 torch autograd of the same network on random data (tolerances of the fp16 operand rounding), and the
+    fp16 GEMM chain kept in field_ops.MlpFn._backward_gemm.
+Shapes: every (in_cols, n_hidden) the models instantiate (32/1, 32/2, 96/2, 128/1) plus ragged inputs and sizes."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _numpy_backward(x, mats, g_out, n_in):
+    """float64 reference: padded-ones input, ReLU hidden layers, no bias."""
+    M = x.shape[0]
+    in_cols = mats[0].shape[1]
+    a = np.ones((M, in_cols), np.float64)
+    a[:, :n_in] = x
+    acts = [a]
+    for W in mats[:-1]:
+        acts.append(np.maximum(acts[-1] @ W.T.astype(np.float64), 0.0))
+    g = np.zeros((M, mats[-1].shape[0]), np.float64)
+    g[:, :g_out.shape[1]] = g_out
+    grads = []
+    peak = max(np.abs(a_).max() for a_ in acts)  # largest fp16 operand the kernel has to carry
+    for li in range(len(mats) - 1, -1, -1):
+        peak = max(peak, np.abs(g).max())
+        grads.append(g.T @ acts[li])
+        g = g @ mats[li].astype(np.float64)
+        if li > 0:
+            g = g * (acts[li] > 0)
+    return g[:, :n_in], np.concatenate([w.reshape(-1) for w in reversed(grads)]), peak
+
+
+@pytest.mark.parametrize("n_in,n_out,n_hidden,M", [(32, 16, 1, 64), (31, 3, 2, 100), (87, 1, 2, 257), (120, 16, 1, 130), (16, 2, 2, 16)])
+def test_mlp_bwd_exact_integers(dev, n_in, n_out, n_hidden, M):
+    from nvsf import field_ops as ops
+    spec = ops.MlpSpec(n_in, n_out, 64, n_hidden)
+    rng = np.random.default_rng(n_in + M)
+    # sparse small integers keep every intermediate exactly representable in fp16 operands / fp32 accumulators
+    mats = []
+    for a, b in spec.shapes:
+        W = rng.integers(-2, 3, size=(a, b)).astype(np.float32)
+        W[rng.random((a, b)) < 0.8] = 0
+        mats.append(W)
+    x = rng.integers(-2, 3, size=(M, n_in)).astype(np.float32)
+    g_out = rng.integers(-2, 3, size=(M, n_out)).astype(np.float32)
+    w16 = np.concatenate([m.reshape(-1) for m in mats]).astype(np.float16)
+    gx_ref, gw_ref, peak = _numpy_backward(x.astype(np.float64), mats, g_out.astype(np.float64), n_in)
+    assert peak <= 2048 and np.abs(gw_ref).max() < 2 ** 24 and np.abs(gx_ref).max() < 2 ** 24  # fp16 operands / fp32 sums stay exact
+    gx, gw = ops.mlp_backward(_t(x, dev), _t(w16, dev), spec, _t(g_out, dev), grad_scale=1.0)
+    assert np.array_equal(gx.cpu().numpy(), gx_ref.astype(np.float32))
+    assert np.array_equal(gw.cpu().numpy(), gw_ref.astype(np.float32))
+    # fp16 input rows, no input gradient requested
+    gx2, gw2 = ops.mlp_backward(_t(x.astype(np.float16), dev), _t(w16, dev), spec, _t(g_out, dev), need_grad_x=False, grad_scale=1.0)
+    assert gx2 is None and np.array_equal(gw2.cpu().numpy(), gw_ref.astype(np.float32))
+
+
+@pytest.mark.parametrize("n_in,n_out,n_hidden,M", [(32, 16, 1, 5000), (31, 3, 2, 4097), (87, 1, 2, 3000), (120, 16, 1, 2048)])
+def test_mlp_bwd_random_vs_fp32_autograd(dev, n_in, n_out, n_hidden, M):
+    from nvsf import field_ops as ops
+    spec = ops.MlpSpec(n_in, n_out, 64, n_hidden)
+    g = torch.Generator().manual_seed(n_in)
+    w16 = torch.cat([((torch.rand(a * b, generator=g) * 2 - 1) * (6.0 / (a + b)) ** 0.5) for a, b in spec.shapes]).half().to(dev)
+    x = torch.randn(M, n_in, generator=g).to(dev)
+    g_out = (torch.randn(M, n_out, generator=g) * 0.01).to(dev)  # small gradients: exercises the fp16 scaling
+    gx, gw = ops.mlp_backward(x, w16, spec, g_out)
+    # fp32 autograd on the fp16-rounded operands
+    mats = [m.float().clone().requires_grad_() for m in spec.split(w16)]
+    xr = x.half().float().requires_grad_()
+    a = torch.cat([xr, torch.ones(M, spec.in_cols - n_in, device=dev)], 1)
+    for W in mats[:-1]:
+        a = torch.relu(a @ W.t())
+    y = (a @ mats[-1].t())[:, :n_out]
+    (y * g_out).sum().backward()
+    gw_ref = torch.cat([m.grad.reshape(-1) for m in mats])
+    gx_ref = xr.grad
+    # fp16 rounding of activations / gradients: relative error ~1e-3 per element, ReLU gates of near-zero units may flip
+    sw, sx = float(gw_ref.abs().max()), float(gx_ref.abs().max())
+    ctx = types.SimpleNamespace(saved_tensors=(x, w16), spec=spec, needs_input_grad=(True, True, False, False))
+    gx_g, gw_g, _, _ = ops.MlpFn._backward_gemm(ctx, g_out)
+    # measured: kernel vs GEMM chain 2-4e-4 of the largest entry; either of them vs fp32 up to 3e-2 (fp16 activations)
+    assert float((gw - gw_ref).abs().max()) < 5e-2 * sw
+    assert float(((gw - gw_ref).abs() <= 1e-2 * sw).float().mean()) > 0.99
+    assert float(((gx - gx_ref).abs() <= 2e-2 * sx).float().mean()) > 0.995
+    assert float((gx - gx_ref).abs().mean()) < 2e-3 * sx
+    # and the fp16 GEMM chain (same operand precision): much closer
+    assert float((gw - gw_g).abs().max()) < 2e-3 * sw
+    assert float((gx - gx_g.float()).abs().mean()) < 1e-3 * sx
+
+
+def test_mlp_bwd_accumulates_and_rejects(dev):
+    from nvsf import field_ops as ops, _hip
+    spec = ops.MlpSpec(32, 16, 64, 1)
+    x = torch.randn(100, 32, device=dev)
+    w16 = (torch.randn(spec.n_params, device=dev) * 0.1).half()
+    g_out = torch.randn(100, 16, device=dev)
+    _, gw = ops.mlp_backward(x, w16, spec, g_out)
+    # the entry point ADDS into grad_weights
+    buf = gw.clone()
+    _hip.call("nvsf_mlp_bwd", _hip.ptr(x), 0, 100, 32, 32, _hip.ptr(w16), 32, 64, 1, 16, _hip.ptr(g_out), 16, 16, 128.0, None, 0,
+              _hip.ptr(buf))
+    torch.testing.assert_close(buf, 2 * gw, rtol=1e-5, atol=1e-6)
+    with pytest.raises(_hip.NvsfHipError):  # three hidden layers: not built (the GEMM chain serves them)
+        _hip.call("nvsf_mlp_bwd", _hip.ptr(x), 0, 100, 32, 32, _hip.ptr(w16), 32, 64, 3, 16, _hip.ptr(g_out), 16, 16, 128.0, None, 0,
+                  _hip.ptr(buf))
