@@ -2,8 +2,8 @@
 
 Thin, allocation-only wrappers over the C ABI (include/nvsf_hip.h sections 2-4) plus the autograd glue
 the trainer needs.  No arithmetic of the hot path happens in Python: every function here ends in a HIP
-kernel launch on the current stream.  Backward passes of the MLPs are plain fp16 GEMMs and are issued
-through torch.matmul (rocBLAS/hipBLASLt); everything else is a kernel of libnvsf_hip.so.
+kernel launch on the current stream, forward and backward (the only torch.matmul left is the GEMM-chain
+backward kept for MLP shapes nvsf_mlp_bwd is not built for, which no model of this package instantiates).
 """
 import math
 
