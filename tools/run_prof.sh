@@ -1,15 +1,24 @@
+# Round profile set: bash tools/run_prof.sh <tag>   (run on the GPU box through gpurun; outputs under gpurun_out/<tag>/)
 set -x
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-mkdir -p $R/gpurun_out/c
-# 1. two-rank control-flow check on one device
-NVSF_BENCH_SAME_DEVICE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 2 --steps 5 --warmup 2 --train-steps 2 > $R/gpurun_out/c/bench2.log 2>&1
-echo "rc2=$?" >> $R/gpurun_out/c/bench2.log
+T=${1:-d}
+O=$R/gpurun_out/$T
+mkdir -p $O
+# 1. two-rank control-flow check on one device (numbers meaningless, tagged invalid)
+NVSF_BENCH_SAME_DEVICE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 2 --steps 5 --warmup 2 --train-steps 2 --no-extra-legs > $O/bench2.log 2>&1
+echo "rc2=$?" >> $O/bench2.log
 # 2. default bench line
-timeout 900 python bench.py > $R/gpurun_out/c/bench1.log 2>&1
+timeout 900 python bench.py > $O/bench1.log 2>&1
 cd /tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/c/kt -- python3 $R/bench.py --steps 20 --warmup 5 --cpu-rays 0 --no-kernel-breakdown --no-extra-legs --train-steps 0 > $R/gpurun_out/c/kt.log 2>&1
-timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/c/pf -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-rays 0 --no-kernel-breakdown --no-extra-legs --train-steps 0 > $R/gpurun_out/c/pf.log 2>&1
-timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/c/pw -- python3 $R/bench.py --steps 3 --warmup 1 --cpu-rays 0 --no-kernel-breakdown --no-extra-legs --train-steps 0 > $R/gpurun_out/c/pw.log 2>&1
-find $R/gpurun_out/c -name '*.csv' | head -30
-tail -3 $R/gpurun_out/c/bench2.log
+B="python3 $R/bench.py --cpu-rays 0 --no-kernel-breakdown --no-extra-legs --train-steps 0"
+# 3. kernel trace of the timed render loop; 4./5. PMC passes (separate runs, counters only)
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- $B --steps 20 --warmup 5 > $O/kt.log 2>&1
+timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pf -- $B --steps 3 --warmup 1 > $O/pf.log 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pw -- $B --steps 3 --warmup 1 > $O/pw.log 2>&1
+# 6. kernel traces of the secondary legs
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_train -- python3 $R/tools/bench_train.py > $O/kt_train.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_occ -- python3 $R/tools/bench_occupancy.py > $O/kt_occ.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_dyn -- python3 $R/tools/bench_dynamic.py > $O/kt_dyn.log 2>&1
+find $O -name '*_kernel_stats.csv' -o -name '*_counter_collection.csv'
+tail -c 300 $O/bench2.log
