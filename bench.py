@@ -12,9 +12,11 @@ fp32 compositing).  Frames are independent: with N GPUs each rank renders its ow
 collective (weak scaling); value = total rays / max-over-ranks time.
 
 One JSON line on stdout (rank 0): metric / value / ... plus
-  roofline      the dominant kernel (fused density kernel: hash-grid gather + sigma MLP), timed live with HIP
-                events on the launch stream; achieved = 588 algorithmic B/sample / duration
-  kernels       the same figures for every kernel of the step
+  roofline      the dominant launch of the step (the hash-grid encode pass of the camera batch), timed live with HIP
+                events on the launch stream; achieved = algorithmic B/sample (512 gathered + what the
+                launch writes) x samples / duration; traffic = 2*FETCH_SIZE + WRITE_SIZE of the committed PMC passes
+  kernels       the same figures for every launch of the step
+  occupancy / dynamic / train   secondary legs (BASELINE configs 3, 5, 4), never `value`
   cpu_baseline  the CPU oracle (oracle/, scalar C port, 1 thread) on a bounded sample of the same workload
 """
 import argparse
@@ -79,16 +81,40 @@ def kernel_breakdown(model, batches, T, iters):
         ray_length = float(model.lidar_max_depth - model.min_near_lidar) if lidar else 2.0 * float(model.bound)
         sliced = ops.prefer_sliced(enc.spec, N, T, ray_length, float(model.bound))  # the choice model.render makes
         dargs = (o, d, nears, fars, T, model._aabb_host, float(model.bound), enc.table_f16(), enc.spec, model.sigma_net.weights_f16())
+        if lidar:
+            head_a, head_b, head_flops, bg = model.raydrop_net.weights_f16(), model.intensity_net.weights_f16(), 2 * 22528, None
+        else:
+            head_a, head_b, head_flops, bg = model.color_net.weights_f16(), None, 14336, [1.0, 1.0, 1.0]
+        sigma_flops = 2 * (32 * 64 + 64 * 16)
+        if os.environ.get("NVSF_RENDER_UNIFORM", "fused") != "split":
+            # the launches model.render issues: one wave-per-ray kernel for the whole render; on the level-sliced path the
+            # encode pass (levels partitioned over the XCDs) runs first and the render kernel reads its feature planes
+            rargs = dargs + (lidar, head_a, head_b, model._k_scale(), bg)
+            full = lambda: ops.render_uniform(*rargs, sliced=sliced)
+            z, w, ws, dp, img = full()
+            active = float((w > ops.W_THRESH).float().mean())
+            flops = sigma_flops + head_flops * active
+            if sliced:
+                bufs = ops.render_uniform(*rargs, sliced=True, _stage="encode")
+                t_a = event_time_ms(lambda: ops.render_uniform(*rargs, sliced=True, _stage="encode", _buffers=bufs), iters)
+                t_b = event_time_ms(lambda: ops.render_uniform(*rargs, sliced=True, _stage="tail", _buffers=bufs), iters)
+                rows.append(dict(kernel=f"density_encode_sliced[{name}]", ms=t_a, bound="hbm", unit="GB/s", achieved=580.0 * M / t_a / 1e6,
+                                 peak=HBM_PEAK_GBS, per_unit="580 B/sample (512 gathered + 64 features + 4 z written)", units=M))
+                rows.append(dict(kernel=f"render_uniform_tail[{name}]", ms=t_b, bound="mfma", unit="TFLOP/s", achieved=flops * M / t_b / 1e9,
+                                 peak=MFMA_PEAK_TFLOPS, units=M,
+                                 per_unit=f"{sigma_flops} + {head_flops} x active fraction {active:.3f} FLOP/sample (sigma MLP, compositing, heads); "
+                                          "76 B/sample of HBM traffic (64 features + 4 z read, 4 weights written)"))
+            else:
+                t = event_time_ms(full, iters)
+                rows.append(dict(kernel=f"render_uniform[{name}]", ms=t, bound="hbm", unit="GB/s", achieved=520.0 * M / t / 1e6, peak=HBM_PEAK_GBS,
+                                 units=M, per_unit="520 B/sample (512 gathered + 4 z + 4 weights written); gather, sigma MLP, compositing and heads "
+                                                   f"in one launch ({flops:.0f} FLOP/sample = {flops * M / t / 1e9:.0f} TFLOP/s)"))
+            continue
         dens = lambda: ops.density_uniform(*dargs, sliced=sliced)
         z, sig, geo = dens()
         comp = lambda: ops.CompositeWeightsFn.apply(sig, z, nears, fars, model._k_scale())
         w, ws, dp = comp()
-        if lidar:
-            heads = lambda: ops.heads_uniform(w, geo, d, ws, True, model.raydrop_net.weights_f16(), model.intensity_net.weights_f16())
-            head_flops = 2 * 22528
-        else:
-            heads = lambda: ops.heads_uniform(w, geo, d, ws, False, model.color_net.weights_f16(), None, [1.0, 1.0, 1.0])
-            head_flops = 14336
+        heads = lambda: ops.heads_uniform(w, geo, d, ws, lidar, head_a, head_b, bg)
         active = float((w > ops.W_THRESH).float().mean())
         t_d, t_c, t_h = event_time_ms(dens, iters), event_time_ms(comp, iters), event_time_ms(heads, iters)
         if sliced:
@@ -351,7 +377,7 @@ def main():
             "config": {"workload": "C2: KITTI-360 seq-1908-shaped frame per GPU, uniform sampling, static hash field",
                        "num_rays": args.num_rays, "num_rays_lidar": args.num_rays_lidar, "num_steps": T,
                        "hash_grid": "L16 F2 T2^19 base16 max2048", "sigma_mlp": "32-64-16", "heads": "lidar 2x(87-64-64-1), rgb 31-64-64-3",
-                       "pass": "forward render (no_grad), fused kernels", "parallelism": f"frame-sharded x{world}, no collective"},
+                       "pass": "forward render (no_grad): one wave-per-ray launch per batch (+ the XCD-sliced encode pass for the camera batch)", "parallelism": f"frame-sharded x{world}, no collective"},
             "outputs_finite": finite,
         }
         if same_device:
@@ -360,9 +386,7 @@ def main():
             rows = kernel_breakdown(model, {"lidar": (tl[0][0], tl[1][0], True), "camera": (tc[0][0], tc[1][0], False)}, T,
                                     max(5, args.steps))
             line["kernels"] = rows
-            dom = max((r for r in rows if r["kernel"].startswith("density")), key=lambda r: r["ms"])
-            top = max(rows, key=lambda r: r["ms"])
-            pick = top if top["ms"] > 1.25 * dom["ms"] else dom
+            pick = max(rows, key=lambda r: r["ms"])  # the dominant launch of the step
             line["roofline"] = {"kernel": pick["kernel"], "bound": pick["bound"], "achieved": pick["achieved"], "peak": pick["peak"],
                                 "unit": pick["unit"], "frac": pick["frac"], "traffic": None, "avg_launch_ms": pick["ms"],
                                 "algorithmic": pick["per_unit"], "units_per_launch": pick["units"]}

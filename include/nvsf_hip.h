@@ -244,6 +244,23 @@ int nvsf_field_density_uniform_fwd(const float* rays_o, const float* rays_d, con
                                    const void* sigma_weights_f16, float* z_vals, float* sigmas, void* geo_f16,
                                    nvsf_stream_t stream);
 
+/* ref: NeRFRenderer.run for a static hash field, renderer_dynamic.py:155-244 (sample generation, density, alpha
+ * compositing, masked colour, image), evaluation only: the whole render of a ray in one wave, ONE launch per batch.
+ * Same arithmetic as nvsf_field_density_uniform_fwd -> nvsf_composite_uniform_weights_fwd ->
+ * nvsf_field_heads_uniform_fwd, but sigma and the geometry features stay in registers (the three-kernel form writes
+ * and re-reads 48 B per sample) and the transmittance product is scanned per 16 samples.  Requires L == 16, F == 2.
+ * feat_scratch: NULL (the kernel gathers from the table itself) or the feature planes filled by
+ * nvsf_field_density_uniform_sliced_fwd(passes = 1), which must also have written z_vals.
+ * Outputs: z_vals, weights [N,T]; weights_sum, depth [N]; image [N,3] (+ (1 - weights_sum) * h_bg_color when
+ * h_bg_color != NULL) or [N,2] (raydrop, intensity) for lidar != 0.  Colour is evaluated where weight > w_thresh. */
+int nvsf_render_uniform_fwd(const float* rays_o, const float* rays_d, const float* nears, const float* fars,
+                            const float* lin, const float* noise, const float* h_aabb, float bound, uint32_t N,
+                            uint32_t T, const void* table_f16, uint32_t L, uint32_t F, const float* h_scales,
+                            const uint32_t* h_res, const uint32_t* h_offsets, const void* sigma_weights_f16, int lidar,
+                            const void* head_a_weights_f16, const void* head_b_weights_f16, float k_scale,
+                            float w_thresh, const float* h_bg_color, const void* feat_scratch, float* z_vals,
+                            float* weights, float* weights_sum, float* depth, float* image, nvsf_stream_t stream);
+
 /* ref: the evaluation-mode protocol of the raymarching extension, raymarching.py:389-409 (march_rays) + 480-493
  * (composite_rays) around the field, for a static hash field (L*F = 32, F = 2): ONE launch instead of the host
  * loop over surviving rays.  Per ray: march through the occupancy bit field `grid` (layout of nvsf_march_rays),

@@ -1115,6 +1115,220 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Whole uniform render of a ray in one wave (evaluation, no_grad): samples -> hash grid -> sigma MLP -> alpha
+// compositing -> masked heads -> image, 16 samples (one MFMA tile) at a time in sample order.  sigma and the geometry
+// features never reach HBM (the three-kernel form writes and re-reads 48 B per sample); only z_vals and weights, which
+// NeRFRenderer.run returns, are stored.  FROM_FEATURES = true is the tail of the level-sliced path: the encoded
+// features come from the scratch planes of k_encode_sliced instead of gathers.  Weight fragments in LDS as in
+// k_render_occupancy_lds; arithmetic of the encode / MLPs / sigmoid identical to the separate kernels, the
+// transmittance product is scanned per 16 samples instead of per 64 (differences at the 1e-7 level).
+__device__ __forceinline__ float row16_scan_mul(float v, int c) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+        const float u = __shfl_up(v, o, 16);
+        if (c >= o) v *= u;
+    }
+    return v;
+}
+
+template <bool LIDAR, bool FROM_FEATURES>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FROM_FEATURES ? 4 : 3, 4))) void k_render_uniform(
+    RayBatch rb, const _Float16* __restrict__ table, uint32_t table_bytes, GridMeta meta, uint32_t first_hashed,
+    const uint2* __restrict__ feat, const _Float16* __restrict__ w_sigma, const _Float16* __restrict__ w_a, const _Float16* __restrict__ w_b,
+    float k_scale, float w_thresh, float bg0, float bg1, float bg2, int use_bg, float* __restrict__ z_vals, float* __restrict__ weights,
+    float* __restrict__ weights_sum, float* __restrict__ depth, float* __restrict__ image) {
+    using FR = OccFrags<LIDAR>;
+    constexpr int F = 2, Q = 8 / F;
+    constexpr int IN_STEPS = FR::IN_STEPS;
+    constexpr int C = LIDAR ? 2 : 3;
+    __shared__ float s_scale[kMaxLevels];
+    __shared__ uint32_t s_res[kMaxLevels], s_off[kMaxLevels + 1];
+    __shared__ half8_t s_frag[FR::kCount * kWave];
+    if (threadIdx.x < kMaxLevels) {
+        s_scale[threadIdx.x] = meta.scale[threadIdx.x];
+        s_res[threadIdx.x] = meta.res[threadIdx.x];
+    }
+    if (threadIdx.x <= kMaxLevels) s_off[threadIdx.x] = meta.offset[threadIdx.x];
+    const int lane = lane_id(), g = lane >> 4, c = lane & 15;
+    for (int f = (int)(threadIdx.x >> 6); f < FR::kCount; f += kWavesPerBlock) s_frag[f * kWave + lane] = occ_fragment<LIDAR>(f, lane, w_sigma, w_a, w_b);
+    __syncthreads();
+    const uint32_t n = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    if (n >= rb.N) return;
+    const half8_t* frag = s_frag + lane;
+    const uint32_t T = rb.T;
+    const size_t M = (size_t)rb.N * T;
+
+    DensityCtx<F> cx;
+    if constexpr (!FROM_FEATURES) {
+        cx.g = g;
+        cx.first_hashed = first_hashed;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int l = 4 * q + g;
+            cx.lv.scale[q] = s_scale[l];
+            cx.lv.res[q] = s_res[l];
+            cx.lv.res2[q] = s_res[l] * s_res[l];
+            cx.lv.boff[q] = s_off[l] * (uint32_t)(F * sizeof(_Float16));
+            cx.lv.rows[q] = s_off[l + 1] - s_off[l];
+        }
+        cx.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(table), 0, (int)table_bytes, 0x00020000);
+    }
+    const float rd0 = rb.rays_d[3 * (size_t)n], rd1 = rb.rays_d[3 * (size_t)n + 1], rd2 = rb.rays_d[3 * (size_t)n + 2];
+    const float d0 = (rd0 + 1.0f) / 2.0f, d1 = (rd1 + 1.0f) / 2.0f, d2 = (rd2 + 1.0f) / 2.0f;
+    half8_t xf[IN_STEPS];
+    if constexpr (!LIDAR) {
+        float sh[16];
+        sh4_basis(d0, d1, d2, sh);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xf[0][j] = (_Float16)(g == 0 ? sh[j] : sh[8 + j]);
+    } else {
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const int k = 32 * s + 8 * g + j;
+                float sn = 1.0f, cs = 1.0f;
+                if (k < 72) {
+                    const int i = k / 24, f = (k - 24 * i) >> 1;
+                    freq_pair(i == 0 ? d0 : (i == 1 ? d1 : d2), f, sn, cs);
+                }
+                xf[s][j] = (_Float16)sn;
+                xf[s][j + 1] = (_Float16)cs;
+            }
+    }
+    const bool takes_geo = LIDAR ? (g == 1 || g == 2) : (g >= 2);
+    const int src_a = (c + 16 * (LIDAR ? 2 * (g - 1) : 2 * (g - 2))) & 63, src_b = (src_a + 16) & 63;
+    auto head = [&](int base, const half8_t& x_last) {
+        float4_t acc[kHidTiles];
+#pragma unroll
+        for (int t = 0; t < kHidTiles; ++t) {
+            float4_t a = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < IN_STEPS; ++s) a = mfma16(frag[(base + t * IN_STEPS + s) * kWave], s == IN_STEPS - 1 ? x_last : xf[s], a);
+            acc[t] = a;
+        }
+        half8_t h[kHidSteps];
+        pack_hidden(acc, h);
+#pragma unroll
+        for (int t = 0; t < kHidTiles; ++t) {
+            float4_t a = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < kHidSteps; ++s) a = mfma16(frag[(base + 4 * IN_STEPS + 2 * t + s) * kWave], h[s], a);
+            acc[t] = a;
+        }
+        pack_hidden(acc, h);
+        float4_t a = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < kHidSteps; ++s) a = mfma16(frag[(base + 4 * IN_STEPS + 8 + s) * kWave], h[s], a);
+        return a;
+    };
+
+    const float near = rb.nears[n], range = rb.fars[n] - near;
+    const float sample_dist = range / (float)T;
+    const float ox = rb.rays_o[3 * (size_t)n], oy = rb.rays_o[3 * (size_t)n + 1], oz = rb.rays_o[3 * (size_t)n + 2];
+    const size_t row0 = (size_t)n * T;
+    float carry = 1.0f, ws = 0.0f, dp = 0.0f, img[C];
+#pragma unroll
+    for (int k = 0; k < C; ++k) img[k] = 0.0f;
+    for (uint32_t i0 = 0; i0 < T; i0 += 16) {
+        const uint32_t i = i0 + (uint32_t)c;
+        const bool valid = i < T;
+        const uint32_t ic = valid ? i : T - 1u;
+        const size_t s = row0 + ic;
+        // ---- sample position / features
+        float z, z_next;
+        half8_t feat8;
+        if constexpr (FROM_FEATURES) {
+            z = z_vals[s];
+            z_next = ic + 1u < T ? z_vals[s + 1] : z;
+            const uint2 p0 = feat[(size_t)(2 * g) * M + s], p1 = feat[(size_t)(2 * g + 1) * M + s];
+            typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
+            const u4_t packed = {p0.x, p1.x, p1.y, p0.y};
+            feat8 = __builtin_bit_cast(half8_t, packed);
+        } else {
+            z = near + range * rb.lin[ic];
+            z_next = near + range * rb.lin[ic + 1u < T ? ic + 1u : ic];
+            if (rb.noise) {
+                z = z + (rb.noise[s] - 0.5f) * sample_dist;
+                z_next = z_next + (rb.noise[ic + 1u < T ? s + 1 : s] - 0.5f) * sample_dist;
+            }
+            float x[3];
+            x[0] = (fminf(fmaxf(ox + rd0 * z, rb.lo[0]), rb.hi[0]) + rb.bound) * rb.inv_extent;
+            x[1] = (fminf(fmaxf(oy + rd1 * z, rb.lo[1]), rb.hi[1]) + rb.bound) * rb.inv_extent;
+            x[2] = (fminf(fmaxf(oz + rd2 * z, rb.lo[2]), rb.hi[2]) + rb.bound) * rb.inv_extent;
+            feat8 = density_encode<F, 4>(cx, x);
+        }
+        // ---- sigma MLP
+        float4_t o;
+        {
+            float4_t acc1[kHidTiles];
+#pragma unroll
+            for (int tt = 0; tt < kHidTiles; ++tt) acc1[tt] = mfma16(frag[(FR::kSigma + tt) * kWave], feat8, float4_t{0, 0, 0, 0});
+            half8_t h[kHidSteps];
+            pack_hidden(acc1, h);
+            float4_t a = {0, 0, 0, 0};
+#pragma unroll
+            for (int sx = 0; sx < kHidSteps; ++sx) a = mfma16(frag[(FR::kSigma + 4 + sx) * kWave], h[sx], a);
+            o = a;
+        }
+        // ---- alpha compositing of the tile (renderer_dynamic.py:176-194); lanes g == 3 hold sigma of sample c
+        const float delta = (i + 1u < T) ? z_next - z : sample_dist;
+        float alpha = 0.0f;
+        if (g == 3 && valid) alpha = 1.0f - expf(-delta * k_scale * expf(o[3]));
+        const float om = (g == 3 && valid) ? (1.0f - alpha + 1e-15f) : 1.0f;
+        const float incl = row16_scan_mul(om, c);
+        float excl = __shfl_up(incl, 1, 16);
+        if (c == 0) excl = 1.0f;
+        const float w = alpha * (carry * excl);  // zero outside lane group 3
+        carry = carry * __shfl(incl, 63, 64);
+        if (g == 3 && valid) {
+            weights[s] = w;
+            if constexpr (!FROM_FEATURES) z_vals[s] = z;
+        }
+        ws += w;
+        dp += w * z;
+        // ---- heads on the samples that carry weight
+        const float w0 = __shfl(w, 48 + c, 64);  // weight of sample c, for the lanes that hold its colour (g == 0)
+        const bool on = w0 > w_thresh;
+        if (__ballot(on)) {
+            const uint32_t p0 = pack_h2(o[0], o[1]), p1 = pack_h2(o[2], g == 3 ? 1.0f : o[3]);
+            typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
+            u4_t gv;
+            gv[0] = (uint32_t)__shfl((int)p0, src_a);
+            gv[1] = (uint32_t)__shfl((int)p1, src_a);
+            gv[2] = (uint32_t)__shfl((int)p0, src_b);
+            gv[3] = (uint32_t)__shfl((int)p1, src_b);
+            const half8_t x_last = takes_geo ? __builtin_bit_cast(half8_t, gv) : xf[IN_STEPS - 1];
+            const float4_t oa = head(FR::kHead, x_last);
+            if constexpr (LIDAR) {
+                const float4_t ob = head(FR::kHead + FR::kPerHead, x_last);
+                if (g == 0 && on) {
+                    img[0] += w0 * sigmoid_f32(oa[0]);
+                    img[1] += w0 * sigmoid_f32(ob[0]);
+                }
+            } else {
+                if (g == 0 && on) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) img[k] += w0 * sigmoid_f32(oa[k]);
+                }
+            }
+        }
+    }
+    ws = wave_sum(ws);
+    dp = wave_sum(dp);
+#pragma unroll
+    for (int k = 0; k < C; ++k) img[k] = wave_sum(img[k]);
+    if (lane == 0) {
+        weights_sum[n] = ws;
+        depth[n] = dp;
+        const float bg[3] = {bg0, bg1, bg2};
+        const float rest = use_bg ? 1.0f - ws : 0.0f;
+#pragma unroll
+        for (int k = 0; k < C; ++k) image[(size_t)n * C + k] = use_bg ? img[k] + rest * bg[k] : img[k];
+    }
+}
+
 int fill_meta(GridMeta& meta, uint32_t L, const float* scales, const uint32_t* res, const uint32_t* offsets) {
     if (L == 0 || L > (uint32_t)kMaxLevels || !scales || !res || !offsets) return NVSF_ERR_INVALID_ARG;
     for (uint32_t l = 0; l < L; ++l) {
@@ -1307,5 +1521,58 @@ NVSF_API int nvsf_render_occupancy_fwd(const float* rays_o, const float* rays_d,
     else
         hipLaunchKernelGGL(k_render_occupancy<false>, grid_dim, block, 0, stream, rr, tb, (uint32_t)table_bytes, meta, first_hashed, ws, wa, wb,
                            density_scale, T_thresh, b0, b1, b2, weights_sum, depth, image);
+    return nvsf_launch_status();
+}
+
+NVSF_API int nvsf_render_uniform_fwd(const float* rays_o, const float* rays_d, const float* nears, const float* fars, const float* lin,
+                                     const float* noise, const float* h_aabb, float bound, uint32_t N, uint32_t T, const void* table_f16,
+                                     uint32_t L, uint32_t F, const float* h_scales, const uint32_t* h_res, const uint32_t* h_offsets,
+                                     const void* sigma_weights_f16, int lidar, const void* head_a_weights_f16,
+                                     const void* head_b_weights_f16, float k_scale, float w_thresh, const float* h_bg_color,
+                                     const void* feat_scratch, float* z_vals, float* weights, float* weights_sum, float* depth, float* image,
+                                     hipStream_t stream) {
+    if (N == 0 || T == 0) return NVSF_OK;
+    REQUIRE(rays_o && rays_d && nears && fars && h_aabb && table_f16 && sigma_weights_f16 && head_a_weights_f16);
+    REQUIRE(z_vals && weights && weights_sum && depth && image && (feat_scratch || lin));
+    REQUIRE(!lidar || head_b_weights_f16);
+    REQUIRE(bound > 0.0f);
+    REQUIRE((reinterpret_cast<uintptr_t>(table_f16) & 15u) == 0 && (reinterpret_cast<uintptr_t>(sigma_weights_f16) & 15u) == 0 &&
+            (reinterpret_cast<uintptr_t>(head_a_weights_f16) & 15u) == 0 && (reinterpret_cast<uintptr_t>(head_b_weights_f16) & 15u) == 0 &&
+            (reinterpret_cast<uintptr_t>(feat_scratch) & 15u) == 0);
+    if (F != 2 || L != 16) return NVSF_ERR_UNSUPPORTED;
+    GridMeta meta;
+    const int st = fill_meta(meta, L, h_scales, h_res, h_offsets);
+    if (st != NVSF_OK) return st;
+    uint32_t first_hashed = L;
+    for (uint32_t l = 0; l < L; ++l) {
+        const unsigned long long cells = (unsigned long long)h_res[l] * h_res[l] * h_res[l];
+        const uint32_t rows = h_offsets[l + 1] - h_offsets[l];
+        const bool hashed = cells > (unsigned long long)rows;
+        if (hashed && first_hashed == L) first_hashed = l;
+        if (!hashed && first_hashed != L) return NVSF_ERR_UNSUPPORTED;
+        if (hashed && (rows & (rows - 1u)) != 0u) return NVSF_ERR_UNSUPPORTED;
+    }
+    const unsigned long long table_bytes = (unsigned long long)h_offsets[L] * F * sizeof(_Float16);
+    if (table_bytes >= (1ull << 31)) return NVSF_ERR_UNSUPPORTED;
+    RayBatch rb;
+    rb.rays_o = rays_o; rb.rays_d = rays_d; rb.nears = nears; rb.fars = fars; rb.lin = lin; rb.noise = noise;
+    for (int k = 0; k < 3; ++k) { rb.lo[k] = h_aabb[k]; rb.hi[k] = h_aabb[3 + k]; }
+    rb.bound = bound;
+    rb.inv_extent = 1.0f / (2.0f * bound);
+    rb.N = N; rb.T = T;
+    const _Float16* tb = reinterpret_cast<const _Float16*>(table_f16);
+    const _Float16* ws = reinterpret_cast<const _Float16*>(sigma_weights_f16);
+    const _Float16* wa = reinterpret_cast<const _Float16*>(head_a_weights_f16);
+    const _Float16* wb = reinterpret_cast<const _Float16*>(head_b_weights_f16);
+    const uint2* fp = reinterpret_cast<const uint2*>(feat_scratch);
+    const float b0 = h_bg_color ? h_bg_color[0] : 0.0f, b1 = h_bg_color ? h_bg_color[1] : 0.0f, b2 = h_bg_color ? h_bg_color[2] : 0.0f;
+    const int use_bg = (h_bg_color && !lidar) ? 1 : 0;
+    const dim3 grid_dim(cdiv(N, kWavesPerBlock)), block(kBlock);
+#define LAUNCH_RU(LD, FF)                                                                                                             \
+    hipLaunchKernelGGL((k_render_uniform<LD, FF>), grid_dim, block, 0, stream, rb, tb, (uint32_t)table_bytes, meta, first_hashed, fp, ws, wa, \
+                       wb, k_scale, w_thresh, b0, b1, b2, use_bg, z_vals, weights, weights_sum, depth, image)
+    if (lidar) { if (fp) LAUNCH_RU(true, true); else LAUNCH_RU(true, false); }
+    else { if (fp) LAUNCH_RU(false, true); else LAUNCH_RU(false, false); }
+#undef LAUNCH_RU
     return nvsf_launch_status();
 }

@@ -421,6 +421,45 @@ def heads_uniform(weights, geo, rays_d, weights_sum, lidar, head_a_f16, head_b_f
     return image
 
 
+def render_uniform(rays_o, rays_d, nears, fars, T, aabb_host, bound, table_f16, spec, sigma_weights_f16, lidar, head_a_f16, head_b_f16,
+                   k_scale, bg_host=None, noise=None, sliced=False, w_thresh=W_THRESH, _stage=None, _buffers=None):
+    """Whole uniform render of a ray batch (evaluation): -> z_vals, weights [N,T], weights_sum, depth [N], image [N, 2 | 3].
+    One launch (a wave per ray); with sliced=True the encode pass of the level-sliced path runs first and the render
+    kernel reads its feature planes instead of gathering.  `_stage` ("encode" | "tail") with `_buffers` = the tuple
+    returned by an earlier call lets bench.py time the two launches of the sliced form separately."""
+    N = rays_o.shape[0]
+    dev = rays_o.device
+    lin = linspace01(T, dev)
+    if _buffers is not None:
+        z_vals, weights, ws, depth, image, feat = _buffers
+    else:
+        z_vals = torch.empty(N, T, dtype=torch.float32, device=dev)
+        weights = torch.empty(N, T, dtype=torch.float32, device=dev)
+        ws = torch.empty(N, dtype=torch.float32, device=dev)
+        depth = torch.empty(N, dtype=torch.float32, device=dev)
+        image = torch.empty(N, 2 if lidar else 3, dtype=torch.float32, device=dev)
+        feat = torch.empty(spec.L, N * T, dtype=torch.int32, device=dev) if sliced else None
+    if sliced and _stage != "tail":
+        _hip.call("nvsf_field_density_uniform_sliced_fwd", _hip.ptr(rays_o), _hip.ptr(rays_d), _hip.ptr(nears), _hip.ptr(fars), _hip.ptr(lin),
+                  _hip.ptr(noise), _hip.host_f32(aabb_host), float(bound), N, T, _hip.ptr(table_f16), spec.L, spec.F, spec.h_scales,
+                  spec.h_res, spec.h_offsets, _hip.ptr(sigma_weights_f16), _hip.ptr(z_vals), _hip.ptr(weights), _hip.ptr(weights),
+                  _hip.ptr(feat), 1)  # passes = 1: encode only (the sigma / geo arguments are not touched)
+    if _stage == "encode":
+        return z_vals, weights, ws, depth, image, feat
+    _hip.call("nvsf_render_uniform_fwd", _hip.ptr(rays_o), _hip.ptr(rays_d), _hip.ptr(nears), _hip.ptr(fars), _hip.ptr(lin), _hip.ptr(noise),
+              _hip.host_f32(aabb_host), float(bound), N, T, _hip.ptr(table_f16), spec.L, spec.F, spec.h_scales, spec.h_res, spec.h_offsets,
+              _hip.ptr(sigma_weights_f16), 1 if lidar else 0, _hip.ptr(head_a_f16), _hip.ptr(head_b_f16), float(k_scale), float(w_thresh),
+              _hip.host_f32(bg_host) if bg_host is not None else None, _hip.ptr(feat), _hip.ptr(z_vals), _hip.ptr(weights), _hip.ptr(ws),
+              _hip.ptr(depth), _hip.ptr(image))
+    if _stage is not None:
+        return z_vals, weights, ws, depth, image, feat
+    return z_vals, weights, ws, depth, image
+
+
+def render_uniform_eligible(spec):
+    return spec.D == 3 and spec.F == 2 and spec.L == 16
+
+
 def occupancy_fused_eligible(spec):
     """Static hash fields nvsf_render_occupancy_fwd is built for."""
     return spec.D == 3 and spec.F == 2 and spec.L * spec.F == 32

@@ -12,6 +12,8 @@ Two execution paths, numerically equivalent (tests/test_render_static_gpu.py):
   * operator path (`density` / `color`): stand-alone HIP operators with autograd -- used for training;
   * `fused_uniform_render`: three fused kernels per ray batch -- used whenever no gradient is recorded.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -90,6 +92,15 @@ class NeRFNetworkStatic(NeRFRenderer):
         # host-side estimate of far - near: exact for LiDAR (constant range), the box side for camera rays (AABB exit)
         ray_length = float(self.lidar_max_depth - self.min_near_lidar) if cal_lidar_color else 2.0 * float(self.bound)
         sliced = ops.prefer_sliced(enc.spec, rays_o.shape[0], T, ray_length, float(self.bound))
+        if ops.render_uniform_eligible(enc.spec) and os.environ.get("NVSF_RENDER_UNIFORM", "fused") != "split":
+            # one launch per batch (plus the encode pass of the level-sliced path): sigma / geo never reach HBM
+            if cal_lidar_color:
+                head_a, head_b = self.raydrop_net.weights_f16(), self.intensity_net.weights_f16()
+            else:
+                head_a, head_b = self.color_net.weights_f16(), None
+            return ops.render_uniform(rays_o, rays_d, nears, fars, T, aabb_host, float(self.bound), enc.table_f16(), enc.spec,
+                                      self.sigma_net.weights_f16(), cal_lidar_color, head_a, head_b, self._k_scale(),
+                                      None if cal_lidar_color else bg_host, noise, sliced=sliced)
         z_vals, sigmas, geo = ops.density_uniform(rays_o, rays_d, nears, fars, T, aabb_host, float(self.bound), enc.table_f16(),
                                                   enc.spec, self.sigma_net.weights_f16(), noise, sliced=sliced)
         weights, weights_sum, depth = ops.CompositeWeightsFn.apply(sigmas, z_vals, nears, fars, self._k_scale())

@@ -18,7 +18,9 @@ def load(path, counter):
     return per
 
 
-KEYS = {"k_density_uniform_v2": "density_uniform_v2", "k_density_uniformILi": "density_uniform", "k_encode_sliced": "encode_sliced",
+KEYS = {"k_render_uniformILb1ELb0": "render_uniform<lidar>", "k_render_uniformILb0ELb0": "render_uniform<camera>",
+        "k_render_uniformILb1ELb1": "render_uniform_tail<lidar>", "k_render_uniformILb0ELb1": "render_uniform_tail<camera>",
+        "k_density_uniform_v2": "density_uniform_v2", "k_density_uniformILi": "density_uniform", "k_encode_sliced": "encode_sliced",
         "k_density_from_features": "density_from_features", "heads_uniformILb1": "heads_uniform<lidar>",
         "heads_uniformILb0": "heads_uniform<camera>", "k_weights_fwd": "k_weights_fwd", "k_near_far": "k_near_far"}
 
