@@ -1031,17 +1031,57 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     uint32_t total = 0;
     const float extent = 2.0f * rr.bound;
     bool alive = true;
+    // Marching, 64 chain members at a time.  The parameters a ray visits form one chain t_{k+1} = t_k + step_len(t_k)
+    // (march_device.h), so lane j can classify member j of the current batch on its own: ONE dependent occupancy load
+    // per 64 members instead of one per probe.  The walk below then reproduces the serial protocol of march_rays from
+    // the per-lane results: an occupied member becomes a sample and the walk moves to the next member; an empty one
+    // jumps to the first member at or beyond the cell's exit parameter (ballot + find-first), possibly in a later batch.
+    float bt = 0.0f, bx = 0.0f, by = 0.0f, bz = 0.0f, bdt = 0.0f, bexit = 0.0f;
+    bool bocc = false;
+    int j = 64;                   // next member of the batch to examine (64 = batch exhausted)
+    float pending = -INFINITY;    // exit parameter of an empty cell whose skip runs past the end of a batch
+    bool ray_done = false;
     while (alive) {
         uint32_t count = 0;
         float sx = 0.0f, sy = 0.0f, sz = 0.0f, sdt = 0.0f, sd1 = 0.0f;
-        while (t < far && count < 16u && total + count < rr.max_steps) {
-            float x, y, z, dt;
-            if (m.probe(t, x, y, z, dt)) {
-                t += dt;
-                const float d1s = t - last_t;
-                last_t = t;
-                if (count == (uint32_t)sl) { sx = x; sy = y; sz = z; sdt = dt; sd1 = d1s; }
+        while (count < 16u && total + count < rr.max_steps && !ray_done) {
+            if (j >= 64) {  // build the next batch: member 0 = t
+                float tc = t;
+                bt = t;
+                for (int k = 1; k < 64; ++k) {
+                    tc = m.next(tc);
+                    if (lane == k) bt = tc;
+                }
+                bocc = m.classify(bt, bx, by, bz, bdt, bexit);
+                t = m.next(tc);  // member 0 of the batch after this one
+                j = 0;
+                if (pending > -INFINITY) {
+                    const unsigned long long reach = __ballot(bt >= pending);
+                    if (reach) { j = __builtin_ctzll(reach); pending = -INFINITY; }
+                    else j = 64;
+                }
+                continue;
+            }
+            const int ju = __builtin_amdgcn_readfirstlane(j);
+            const float tj = readlane_f32(bt, ju);
+            if (!(tj < far)) { ray_done = true; break; }
+            const float xj = readlane_f32(bx, ju), yj = readlane_f32(by, ju), zj = readlane_f32(bz, ju);
+            const float dtj = readlane_f32(bdt, ju), tt = readlane_f32(bexit, ju);
+            if (__builtin_amdgcn_readlane((int)bocc, ju)) {
+                const float t_after = tj + dtj;
+                const float d1s = t_after - last_t;
+                last_t = t_after;
+                if (count == (uint32_t)sl) { sx = xj; sy = yj; sz = zj; sdt = dtj; sd1 = d1s; }
                 ++count;
+                j = ju + 1;
+            } else {
+                // march_rays would step to the first member at or beyond tt and stop there if it is not below `far`
+                if (!(tt < far)) { ray_done = true; break; }
+                // first member after j at or beyond tt; the chain is non-decreasing, members <= j are masked out
+                const unsigned long long later = ~0ull << ju << 1;
+                const unsigned long long reach = __ballot(bt >= tt) & later;
+                if (reach) j = __builtin_ctzll(reach);
+                else { j = 64; pending = tt; }
             }
         }
         const uint32_t cnt = __builtin_amdgcn_readfirstlane(count);

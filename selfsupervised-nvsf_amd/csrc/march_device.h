@@ -53,6 +53,34 @@ struct Marcher {
         const int l1 = (int)fminf(Cf - 1.0f, fmaxf(0.0f, (float)e1));
         return l0 > l1 ? l0 : l1;
     }
+    // The parameters visited along a ray form ONE chain t_{k+1} = t_k + step_len(t_k), whether a step is taken because a
+    // sample was emitted or while skipping an empty cell (probe() below: both add step_len(t)); next() is its recurrence.
+    __device__ __forceinline__ float next(float t) const {
+        const float tn = t + step_len(t);
+        return tn == t ? INFINITY : tn;
+    }
+    // Branch-free classification of chain member t (for lanes that examine many members at once): the sample
+    // description, whether its cell is occupied, and the parameter at which the ray leaves that cell (the skip target of
+    // probe()).  Same arithmetic as probe().
+    __device__ __forceinline__ bool classify(float t, float& x, float& y, float& z, float& dt, float& t_exit) const {
+        x = clampf(ox + t * dx, -bound, bound);
+        y = clampf(oy + t * dy, -bound, bound);
+        z = clampf(oz + t * dz, -bound, bound);
+        dt = step_len(t);
+        const int level = level_of(x, y, z, dt);
+        const float mb = fminf(ldexpf(1.0f, level), bound);
+        const float rmb = 1.0f / mb;
+        const int nx = (int)clampf(0.5f * (x * rmb + 1.0f) * Hf, 0.0f, Hm1);
+        const int ny = (int)clampf(0.5f * (y * rmb + 1.0f) * Hf, 0.0f, Hm1);
+        const int nz = (int)clampf(0.5f * (z * rmb + 1.0f) * Hf, 0.0f, Hm1);
+        const uint32_t cell = (uint32_t)((float)level * H3 + (float)morton_encode((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
+        const bool occ = (grid[cell >> 3] & (1u << (cell & 7u))) != 0;
+        const float tx = ((((float)nx + 0.5f + 0.5f * copysignf(1.0f, dx)) * rH * 2.0f - 1.0f) * mb - x) * ix;
+        const float ty = ((((float)ny + 0.5f + 0.5f * copysignf(1.0f, dy)) * rH * 2.0f - 1.0f) * mb - y) * iy;
+        const float tz = ((((float)nz + 0.5f + 0.5f * copysignf(1.0f, dz)) * rH * 2.0f - 1.0f) * mb - z) * iz;
+        t_exit = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+        return occ;
+    }
     // returns true when the cell containing o + t d is occupied; x,y,z,dt describe the sample.
     // Otherwise t is advanced past the empty cell.
     __device__ __forceinline__ bool probe(float& t, float& x, float& y, float& z, float& dt) const {
