@@ -109,4 +109,63 @@ struct Marcher {
     }
 };
 
+// Wave-cooperative marcher: all 64 lanes of a wave work on ONE ray.  Lane j classifies member j of the current batch of
+// 64 consecutive chain members (one dependent occupancy load per 64 members instead of one per probe); next_sample()
+// then replays the serial protocol of Marcher::probe from the per-lane results -- an occupied member is a sample and
+// the walk moves to the next member, an empty one jumps to the first member at or beyond the cell's exit parameter
+// (ballot + find-first), possibly in a later batch.  All results are wave-uniform.
+struct ChainWalker {
+    float bt, bx, by, bz, bdt, bexit;  // per lane: member parameter, sample position, step, exit parameter of its cell
+    bool bocc;
+    int j;          // next member of the batch to examine (64 = batch exhausted)
+    float pending;  // exit parameter of an empty cell whose skip runs past the end of a batch (-inf: none)
+    float t;        // member 0 of the NEXT batch
+    __device__ __forceinline__ void init(float t0) {
+        t = t0; j = 64; pending = -INFINITY;
+        bt = bx = by = bz = bdt = bexit = 0.0f;
+        bocc = false;
+    }
+    // Next sample of the ray with parameter < far: returns false when the ray is finished.
+    __device__ __forceinline__ bool next_sample(const Marcher& m, float far, int lane, float& x, float& y, float& z, float& dt,
+                                                float& t_sample) {
+        while (true) {
+            if (j >= 64) {
+                float tc = t;
+                bt = t;
+                for (int k = 1; k < 64; ++k) {
+                    tc = m.next(tc);
+                    if (lane == k) bt = tc;
+                }
+                bocc = m.classify(bt, bx, by, bz, bdt, bexit);
+                t = m.next(tc);
+                j = 0;
+                if (pending > -INFINITY) {
+                    const unsigned long long reach = __ballot(bt >= pending);
+                    if (reach) { j = __builtin_ctzll(reach); pending = -INFINITY; }
+                    else j = 64;
+                }
+                continue;
+            }
+            const int ju = __builtin_amdgcn_readfirstlane(j);
+            const float tj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bt), ju));
+            if (!(tj < far)) return false;
+            if (__builtin_amdgcn_readlane((int)bocc, ju)) {
+                x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bx), ju));
+                y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, by), ju));
+                z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bz), ju));
+                dt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bdt), ju));
+                t_sample = tj;
+                j = ju + 1;
+                return true;
+            }
+            const float tt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bexit), ju));
+            if (!(tt < far)) return false;  // the serial marcher would step to a member >= tt >= far and stop there
+            const unsigned long long later = ~0ull << ju << 1;
+            const unsigned long long reach = __ballot(bt >= tt) & later;
+            if (reach) j = __builtin_ctzll(reach);
+            else { j = 64; pending = tt; }
+        }
+    }
+};
+
 }  // namespace

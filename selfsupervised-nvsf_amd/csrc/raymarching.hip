@@ -125,6 +125,73 @@ __global__ __launch_bounds__(kBlock) void k_march_count(const float* __restrict_
     rays[3 * (size_t)n + 2] = (int)count;
 }
 
+// The same two passes with a WAVE per ray (ChainWalker, march_device.h): 64 chain members are classified per
+// dependent occupancy load and no lane waits for the longest ray of its wave.  Identical samples (same chain, same
+// classification arithmetic, same skip protocol) -- tests/test_raymarching_gpu.py pins both forms to the oracle.
+__global__ __launch_bounds__(kBlock) void k_march_count_wave(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                             const uint8_t* __restrict__ grid, float bound, float dt_gamma,
+                                                             uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
+                                                             const float* __restrict__ nears, const float* __restrict__ fars,
+                                                             const float* __restrict__ noises, int* __restrict__ rays) {
+    const uint32_t n = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6));
+    if (n >= N) return;
+    const int lane = lane_id();
+    Marcher m;
+    m.init(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, grid, bound, dt_gamma, max_steps, C, H);
+    const float far = fars[n];
+    float t = nears[n];
+    t += m.step_len(t) * noises[n];
+    ChainWalker w;
+    w.init(t);
+    uint32_t count = 0;
+    float x, y, z, dt, ts;
+    while (count < max_steps && w.next_sample(m, far, lane, x, y, z, dt, ts)) ++count;
+    if (lane == 0) rays[3 * (size_t)n + 2] = (int)count;
+}
+
+__global__ __launch_bounds__(kBlock) void k_march_write_wave(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                             const uint8_t* __restrict__ grid, float bound, float dt_gamma,
+                                                             uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                                                             const float* __restrict__ nears, const float* __restrict__ fars,
+                                                             const float* __restrict__ noises, const int* __restrict__ rays,
+                                                             float* __restrict__ xyzs, float* __restrict__ dirs,
+                                                             float* __restrict__ deltas) {
+    const uint32_t n = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6));
+    if (n >= N) return;
+    const int lane = lane_id();
+    const uint32_t offset = (uint32_t)rays[3 * (size_t)n + 1], count = (uint32_t)rays[3 * (size_t)n + 2];
+    if (count == 0 || offset + count > M) return;
+    Marcher m;
+    m.init(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, grid, bound, dt_gamma, max_steps, C, H);
+    const float far = fars[n];
+    float t = nears[n];
+    t += m.step_len(t) * noises[n];
+    float last_t = t;
+    ChainWalker w;
+    w.init(t);
+    // lane (step & 63) keeps sample `step`; every 64 samples (and at the end) the wave stores them together
+    float kx = 0.0f, ky = 0.0f, kz = 0.0f, kdt = 0.0f, kd1 = 0.0f;
+    auto flush = [&](uint32_t first, uint32_t n_valid) {
+        if ((uint32_t)lane < n_valid) {
+            const size_t s = (size_t)offset + first + (uint32_t)lane;
+            xyzs[3 * s] = kx; xyzs[3 * s + 1] = ky; xyzs[3 * s + 2] = kz;
+            dirs[3 * s] = m.dx; dirs[3 * s + 1] = m.dy; dirs[3 * s + 2] = m.dz;
+            deltas[2 * s] = kdt; deltas[2 * s + 1] = kd1;
+        }
+    };
+    uint32_t step = 0;
+    float x, y, z, dt, ts;
+    while (step < count && w.next_sample(m, far, lane, x, y, z, dt, ts)) {
+        const float t_after = ts + dt;
+        const float d1 = t_after - last_t;
+        last_t = t_after;
+        if ((uint32_t)lane == (step & 63u)) { kx = x; ky = y; kz = z; kdt = dt; kd1 = d1; }
+        ++step;
+        if ((step & 63u) == 0u) flush(step - 64u, 64u);
+    }
+    if (step & 63u) flush(step & ~63u, step & 63u);
+}
+
 // pass 2: one workgroup; exclusive scan of the counts in ray order, reserving [counter[0], +total).
 __global__ __launch_bounds__(1024) void k_march_scan(uint32_t N, int* __restrict__ rays, int* __restrict__ counter) {
     __shared__ uint32_t wave_tot[16];
@@ -418,11 +485,21 @@ NVSF_API int nvsf_march_rays_train(const float* rays_o, const float* rays_d, con
     if (N == 0) return NVSF_OK;
     REQUIRE(rays_o && rays_d && grid && nears && fars && xyzs && dirs && deltas && rays && counter && noises);
     REQUIRE(C >= 1 && C <= 8 && H >= 2 && H <= 1024 && max_steps >= 1);
-    hipLaunchKernelGGL(k_march_count, dim3(cdiv(N, kBlock)), dim3(kBlock), 0, stream, rays_o, rays_d, grid, bound, dt_gamma,
-                       max_steps, N, C, H, nears, fars, noises, rays);
+    const char* variant = getenv("NVSF_MARCH");  // "thread": one thread per ray (first formulation, A/B timing and tests)
+    if (variant && variant[0] == 't') {
+        hipLaunchKernelGGL(k_march_count, dim3(cdiv(N, kBlock)), dim3(kBlock), 0, stream, rays_o, rays_d, grid, bound, dt_gamma,
+                           max_steps, N, C, H, nears, fars, noises, rays);
+        hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(1024), 0, stream, N, rays, counter);
+        hipLaunchKernelGGL(k_march_write, dim3(cdiv(N, kBlock)), dim3(kBlock), 0, stream, rays_o, rays_d, grid, bound, dt_gamma,
+                           max_steps, N, C, H, M, nears, fars, noises, rays, xyzs, dirs, deltas);
+        return nvsf_launch_status();
+    }
+    const dim3 wgrid(cdiv(N, kBlock / kWave));
+    hipLaunchKernelGGL(k_march_count_wave, wgrid, dim3(kBlock), 0, stream, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H,
+                       nears, fars, noises, rays);
     hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(1024), 0, stream, N, rays, counter);
-    hipLaunchKernelGGL(k_march_write, dim3(cdiv(N, kBlock)), dim3(kBlock), 0, stream, rays_o, rays_d, grid, bound, dt_gamma,
-                       max_steps, N, C, H, M, nears, fars, noises, rays, xyzs, dirs, deltas);
+    hipLaunchKernelGGL(k_march_write_wave, wgrid, dim3(kBlock), 0, stream, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M,
+                       nears, fars, noises, rays, xyzs, dirs, deltas);
     return nvsf_launch_status();
 }
 

@@ -94,8 +94,10 @@ def test_packbits(rm, dev, scene):
     assert np.array_equal(rm.packbits(_t(g2, dev), 0.01).cpu().numpy(), O.packbits(g2, 0.01))
 
 
+@pytest.mark.parametrize("march", ["wave", "thread"])  # wave-per-ray ChainWalker kernels (default) / one thread per ray
 @pytest.mark.parametrize("n,max_steps,dt_gamma,perturb_seed", [(4096, 1024, 0.0, None), (1000, 256, 1.0 / 128, 7), (1, 64, 0.0, None)])
-def test_march_rays_train(rm, dev, scene, n, max_steps, dt_gamma, perturb_seed):
+def test_march_rays_train(rm, dev, scene, n, max_steps, dt_gamma, perturb_seed, march, monkeypatch):
+    monkeypatch.setenv("NVSF_MARCH", march)
     o, d = _rays(n, 6, "lidar" if n == 1000 else "cam")
     aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
     nears, fars = O.near_far_from_aabb(o, d, aabb, 0.02)
