@@ -17,6 +17,7 @@ One JSON line on stdout (rank 0): metric / value / ... plus
                 launch writes) x samples / duration; traffic = 2*FETCH_SIZE + WRITE_SIZE of the committed PMC passes
   kernels       the same figures for every launch of the step
   occupancy / dynamic / train   secondary legs (BASELINE configs 3, 5, 4), never `value`
+  raymarching   the raymarching-extension kernels (rows a1-a9) against the HBM roofline at non-latency-bound sizes
   cpu_baseline  the CPU oracle (oracle/, scalar C port, 1 thread) on a bounded sample of the same workload
 """
 import argparse
@@ -269,6 +270,19 @@ def occupancy_leg(model_cls, dev, n_rays, steps):
     return out
 
 
+def raymarching_leg(dev):
+    """Secondary figure: every kernel of the raymarching extension against the HBM roofline at a
+    size where the launch is not latency-bound (tools/bench_raymarching.py; at 4096 rays each of them moves < 1 MB).
+    march_rays_train is timed on a fully occupied grid (every chain member is a sample: the write-bound case) and on a
+    10 % per-cell random grid (a skip every few members: the worst case for the marcher)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bench_raymarching import raymarching_rooflines
+    rows = raymarching_rooflines(dev, occupied=1.0)
+    rows += [r for r in raymarching_rooflines(dev, occupied=0.1) if r["kernel"].startswith("march_rays_train")]
+    torch.cuda.empty_cache()
+    return {"note": "algorithmic bytes (SURVEY 8d) / HIP-event time, HBM peak 8000 GB/s", "kernels": rows}
+
+
 def dynamic_leg(dev, n_rays, T, steps):
     """Secondary figure (BASELINE config 5): the reference-default space-time field (K-planes + static / dynamic hash grids
     + flow field, 93.6 M parameters, time_resolution 8), forward render of n_rays LiDAR + n_rays camera rays."""
@@ -397,6 +411,7 @@ def main():
         if not args.no_extra_legs and world == 1:  # secondary figures for BASELINE configs 3 and 5 (never `value`)
             line["occupancy"] = occupancy_leg(NeRFNetworkStatic, dev, args.num_rays, 10)
             line["dynamic"] = dynamic_leg(dev, args.num_rays, T, 3)
+            line["raymarching"] = raymarching_leg(dev)
     if args.train_steps > 0:
         tr = train_leg(model, tl, tc, tm, T, args.train_steps, dev, dist)
         if rank == 0:

@@ -59,3 +59,20 @@ __device__ __forceinline__ uint32_t wave_scan_add_u32(uint32_t v) {
     }
     return v;
 }
+
+// inclusive max-scan over the 64 lanes on DPP (row shifts inside the 16-lane rows, then row_bcast:15 / row_bcast:31)
+__device__ __forceinline__ uint32_t wave_scan_max_u32(uint32_t v) {
+#define NVSF_DPP_MAX(ctrl, row_mask)                                                                                        \
+    {                                                                                                                      \
+        const uint32_t u = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, row_mask, 0xF, false);                   \
+        v = u > v ? u : v;                                                                                                 \
+    }
+    NVSF_DPP_MAX(0x111, 0xF)  // row_shr:1
+    NVSF_DPP_MAX(0x112, 0xF)  // row_shr:2
+    NVSF_DPP_MAX(0x114, 0xF)  // row_shr:4
+    NVSF_DPP_MAX(0x118, 0xF)  // row_shr:8
+    NVSF_DPP_MAX(0x142, 0xA)  // row_bcast:15 -> rows 1 and 3
+    NVSF_DPP_MAX(0x143, 0xC)  // row_bcast:31 -> rows 2 and 3
+#undef NVSF_DPP_MAX
+    return v;
+}

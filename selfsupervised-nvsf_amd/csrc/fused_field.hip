@@ -942,11 +942,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     __shared__ float s_scale[kMaxLevels];
     __shared__ uint32_t s_res[kMaxLevels], s_off[kMaxLevels + 1];
     __shared__ half8_t s_frag[FR::kCount * kWave];
+    constexpr uint32_t kLutH = 128;  // Morton bit-spread table for grids up to 128^3 (the reference's size); larger: computed
+    __shared__ uint32_t s_lut[kLutH];
     if (threadIdx.x < kMaxLevels) {
         s_scale[threadIdx.x] = meta.scale[threadIdx.x];
         s_res[threadIdx.x] = meta.res[threadIdx.x];
     }
     if (threadIdx.x <= kMaxLevels) s_off[threadIdx.x] = meta.offset[threadIdx.x];
+    if (threadIdx.x < kLutH) s_lut[threadIdx.x] = spread3(threadIdx.x);
     const int lane = lane_id(), g = lane >> 4, sl = lane & 15;
     for (int f = (int)(threadIdx.x >> 6); f < FR::kCount; f += kWavesPerBlock) s_frag[f * kWave + lane] = occ_fragment<LIDAR>(f, lane, w_sigma, w_a, w_b);
     __syncthreads();
@@ -1024,6 +1027,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     const float dd[3] = {rd0, rd1, rd2};
     Marcher m;
     m.init(o3, dd, rr.grid, rr.bound, rr.dt_gamma, rr.max_steps, rr.C, rr.H);
+    if (rr.H <= kLutH) m.lut = s_lut;
     const float far = rr.fars[n];
     float t = rr.nears[n];
     float last_t = t, t_comp = t;
@@ -1038,27 +1042,26 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     // jumps to the first member at or beyond the cell's exit parameter (ballot + find-first), possibly in a later batch.
     float bt = 0.0f, bx = 0.0f, by = 0.0f, bz = 0.0f, bdt = 0.0f, bexit = 0.0f;
     bool bocc = false;
-    int j = 64;                   // next member of the batch to examine (64 = batch exhausted)
+    int j = 64, nb = 64;          // next member of the batch to examine, members in the batch (j >= nb: exhausted)
+    unsigned long long bmask = ~0ull;
     float pending = -INFINITY;    // exit parameter of an empty cell whose skip runs past the end of a batch
     bool ray_done = false;
     while (alive) {
         uint32_t count = 0;
         float sx = 0.0f, sy = 0.0f, sz = 0.0f, sdt = 0.0f, sd1 = 0.0f;
         while (count < 16u && total + count < rr.max_steps && !ray_done) {
-            if (j >= 64) {  // build the next batch: member 0 = t
-                float tc = t;
-                bt = t;
-                for (int k = 1; k < 64; ++k) {
-                    tc = m.next(tc);
-                    if (lane == k) bt = tc;
-                }
-                bocc = m.classify(bt, bx, by, bz, bdt, bexit);
-                t = m.next(tc);  // member 0 of the batch after this one
+            if (j >= nb) {  // build the next batch: member 0 = t (closed form for a constant step, march_device.h)
+                const float t0 = t;
+                m.fill_batch(t0, lane, bt, nb, t);  // t <- member 0 of the batch after this one
+                Marcher::Cell cell;
+                bocc = m.classify_cell(bt, bx, by, bz, bdt, cell);
+                bmask = nb >= 64 ? ~0ull : (1ull << nb) - 1ull;
+                if (__ballot(!bocc) & bmask) bexit = m.cell_exit(bt, bx, by, bz, cell);  // exits matter for empty cells only
                 j = 0;
                 if (pending > -INFINITY) {
-                    const unsigned long long reach = __ballot(bt >= pending);
+                    const unsigned long long reach = __ballot(bt >= pending) & bmask;
                     if (reach) { j = __builtin_ctzll(reach); pending = -INFINITY; }
-                    else j = 64;
+                    else j = nb;
                 }
                 continue;
             }
@@ -1078,10 +1081,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                 // march_rays would step to the first member at or beyond tt and stop there if it is not below `far`
                 if (!(tt < far)) { ray_done = true; break; }
                 // first member after j at or beyond tt; the chain is non-decreasing, members <= j are masked out
-                const unsigned long long later = ~0ull << ju << 1;
+                const unsigned long long later = (~0ull << ju << 1) & bmask;
                 const unsigned long long reach = __ballot(bt >= tt) & later;
                 if (reach) j = __builtin_ctzll(reach);
-                else { j = 64; pending = tt; }
+                else { j = nb; pending = tt; }
             }
         }
         const uint32_t cnt = __builtin_amdgcn_readfirstlane(count);

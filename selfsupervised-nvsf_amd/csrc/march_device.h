@@ -12,6 +12,8 @@ namespace {
 constexpr float kSqrt3 = 1.7320508075688772f;
 
 __device__ __forceinline__ float clampf(float x, float lo, float hi) { return fminf(hi, fmaxf(lo, x)); }
+// the same value for lo <= hi as one v_med3_f32 (a NaN x gives lo either way: med3 returns min3 when an input is NaN)
+__device__ __forceinline__ float clamp_med3(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
 
 __device__ __forceinline__ uint32_t spread3(uint32_t v) {
     v = (v * 0x00010001u) & 0xFF0000FFu;
@@ -28,8 +30,11 @@ __device__ __forceinline__ uint32_t morton_encode(uint32_t x, uint32_t y, uint32
 // advances t past it.
 struct Marcher {
     float ox, oy, oz, dx, dy, dz, ix, iy, iz;
-    float bound, dt_gamma, dt_min, dt_max, rH, H3, Hf, Hm1, Cf;
+    float bound, rbound, dt_gamma, dt_min, dt_max, rH, H3, Hf, Hm1, Cf;
+    float dt_const;            // the step when dt_gamma == 0 (then every member has the same step and dt-level)
+    int l1_const;
     const uint8_t* grid;
+    const uint32_t* lut;       // optional LDS table lut[v] = spread3(v), v < H (fill_spread_lut); nullptr: computed
 
     __device__ __forceinline__ void init(const float* o, const float* d, const uint8_t* g, float bound_, float dt_gamma_,
                                          uint32_t max_steps, uint32_t C, uint32_t H) {
@@ -42,43 +47,111 @@ struct Marcher {
         H3 = (float)(H * H * H);
         dt_min = 2.0f * kSqrt3 / (float)max_steps;
         dt_max = 2.0f * kSqrt3 * (float)(1 << (C - 1)) / Hf;
+        rbound = 1.0f / bound;
+        dt_const = step_len(0.0f);
+        l1_const = dt_level(dt_const);
+        lut = nullptr;
+    }
+    __device__ __forceinline__ int dt_level(float dt) const {
+        int e1;
+        (void)frexpf(dt * Hf * 0.5f, &e1);
+        return (int)fminf(Cf - 1.0f, fmaxf(0.0f, (float)e1));
     }
     __device__ __forceinline__ float step_len(float t) const { return clampf(t * dt_gamma, dt_min, dt_max); }
 
     __device__ __forceinline__ int level_of(float x, float y, float z, float dt) const {
-        int e0, e1;
+        int e0;
         (void)frexpf(fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))), &e0);
-        (void)frexpf(dt * Hf * 0.5f, &e1);
         const int l0 = (int)fminf(Cf - 1.0f, fmaxf(0.0f, (float)e0));
-        const int l1 = (int)fminf(Cf - 1.0f, fmaxf(0.0f, (float)e1));
+        const int l1 = dt_gamma == 0.0f ? l1_const : dt_level(dt);  // wave-uniform choice
         return l0 > l1 ? l0 : l1;
     }
+    __device__ __forceinline__ uint32_t spread(uint32_t v) const { return lut ? lut[v] : spread3(v); }
     // The parameters visited along a ray form ONE chain t_{k+1} = t_k + step_len(t_k), whether a step is taken because a
     // sample was emitted or while skipping an empty cell (probe() below: both add step_len(t)); next() is its recurrence.
     __device__ __forceinline__ float next(float t) const {
         const float tn = t + step_len(t);
         return tn == t ? INFINITY : tn;
     }
+    // One batch of consecutive chain members starting at t: lane k receives member k in `bt`; nb (wave-uniform, 1..64)
+    // is the number of members in the batch (lanes >= nb hold a harmless copy of member 0) and t_next is member 0 of the
+    // following batch.
+    // dt_gamma == 0 (the reference's default): the step is the constant c = step_len(.) and the chain is the running
+    // fp32 sum t_k = fl(t_{k-1} + c).  Inside one binade of t that sum advances by a fixed number of ulps: with
+    // t = m u (u = ulp, 2^23 <= m < 2^24) and c = (q + r) u, 0 <= r < 1, round-to-nearest-even gives m + q (r < 1/2),
+    // m + q + 1 (r > 1/2), and for r = 1/2 the even one of the two -- after which m stays even and the step is
+    // q + (q & 1).  So member k is m_0 + s_first + (k - 1) s in integer arithmetic, valid as long as the exact sum of
+    // the previous step stayed inside the binade (m_{k-1} + q < 2^24); the batch ends there and the next batch starts
+    // from a real fp32 addition, which handles the crossing.  Bit-identical to the serial recurrence (checked
+    // exhaustively against it on the host: tests/test_oracle_cpu.py::test_constant_step_chain_closed_form).
+    __device__ __forceinline__ void fill_batch(float t, int lane, float& bt, int& nb, float& t_next) const {
+        if (dt_gamma == 0.0f) {
+            const float c = step_len(0.0f);
+            const uint32_t tb = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_bit_cast(uint32_t, t));
+            const uint32_t cb = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_bit_cast(uint32_t, c));
+            const int e = (int)(tb >> 23), ec = (int)(cb >> 23);  // a negative / NaN / inf t gives e >= 255: generic path
+            const int d = e - ec;
+            if (d >= 0 && d <= 24 && e >= 24 && e < 254 && ec > 0) {
+                const uint32_t m0 = (tb & 0x7FFFFFu) | 0x800000u, mc = (cb & 0x7FFFFFu) | 0x800000u;
+                const uint32_t q = mc >> d, rem = mc & ((1u << d) - 1u), half = d > 0 ? 1u << (d - 1) : 0u;
+                uint32_t s, s_first;
+                if (d > 0 && rem == half) { s = q + (q & 1u); s_first = q + ((m0 + q) & 1u); }
+                else { s = q + ((d > 0 && rem > half) ? 1u : 0u); s_first = s; }
+                if (s != 0u) {
+                    const uint32_t k = (uint32_t)lane;
+                    const uint32_t mk = k == 0u ? m0 : m0 + s_first + (k - 1u) * s;
+                    const uint32_t mprev = k <= 1u ? m0 : m0 + s_first + (k - 2u) * s;
+                    const bool valid = k == 0u || mprev + q < (1u << 24);
+                    nb = __builtin_popcountll(__ballot(valid));  // the valid lanes are a prefix (m_k increases with k)
+                    const float scale = __builtin_bit_cast(float, (uint32_t)(e - 23) << 23);
+                    bt = valid ? (float)mk * scale : t;
+                    const float t_last = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bt), nb - 1));
+                    t_next = next(t_last);
+                    return;
+                }
+            }
+        }
+        float tc = t;
+        bt = t;
+        for (int k = 1; k < 64; ++k) {
+            tc = next(tc);
+            if (lane == k) bt = tc;
+        }
+        nb = 64;
+        t_next = next(tc);
+    }
     // Branch-free classification of chain member t (for lanes that examine many members at once): the sample
-    // description, whether its cell is occupied, and the parameter at which the ray leaves that cell (the skip target of
-    // probe()).  Same arithmetic as probe().
-    __device__ __forceinline__ bool classify(float t, float& x, float& y, float& z, float& dt, float& t_exit) const {
-        x = clampf(ox + t * dx, -bound, bound);
-        y = clampf(oy + t * dy, -bound, bound);
-        z = clampf(oz + t * dz, -bound, bound);
-        dt = step_len(t);
+    // description, whether its cell is occupied (classify_cell), and the parameter at which the ray leaves that cell
+    // (cell_exit: the skip target of probe(); only needed for empty cells).  Same arithmetic as probe(): 1 / mip_bound is
+    // 2^-level (exact) or the ray-constant 1 / bound, the same IEEE quotients probe() computes per sample.
+    struct Cell { int nx, ny, nz; float mb; };
+    __device__ __forceinline__ bool classify_cell(float t, float& x, float& y, float& z, float& dt, Cell& c) const {
+        x = clamp_med3(ox + t * dx, -bound, bound);
+        y = clamp_med3(oy + t * dy, -bound, bound);
+        z = clamp_med3(oz + t * dz, -bound, bound);
+        dt = dt_gamma == 0.0f ? dt_const : step_len(t);
         const int level = level_of(x, y, z, dt);
-        const float mb = fminf(ldexpf(1.0f, level), bound);
-        const float rmb = 1.0f / mb;
-        const int nx = (int)clampf(0.5f * (x * rmb + 1.0f) * Hf, 0.0f, Hm1);
-        const int ny = (int)clampf(0.5f * (y * rmb + 1.0f) * Hf, 0.0f, Hm1);
-        const int nz = (int)clampf(0.5f * (z * rmb + 1.0f) * Hf, 0.0f, Hm1);
-        const uint32_t cell = (uint32_t)((float)level * H3 + (float)morton_encode((uint32_t)nx, (uint32_t)ny, (uint32_t)nz));
-        const bool occ = (grid[cell >> 3] & (1u << (cell & 7u))) != 0;
-        const float tx = ((((float)nx + 0.5f + 0.5f * copysignf(1.0f, dx)) * rH * 2.0f - 1.0f) * mb - x) * ix;
-        const float ty = ((((float)ny + 0.5f + 0.5f * copysignf(1.0f, dy)) * rH * 2.0f - 1.0f) * mb - y) * iy;
-        const float tz = ((((float)nz + 0.5f + 0.5f * copysignf(1.0f, dz)) * rH * 2.0f - 1.0f) * mb - z) * iz;
-        t_exit = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+        const float p = ldexpf(1.0f, level);
+        const bool capped = bound < p;  // mb = fminf(2^level, bound)
+        c.mb = capped ? bound : p;
+        const float rmb = capped ? rbound : ldexpf(1.0f, -level);
+        c.nx = (int)clamp_med3(0.5f * (x * rmb + 1.0f) * Hf, 0.0f, Hm1);
+        c.ny = (int)clamp_med3(0.5f * (y * rmb + 1.0f) * Hf, 0.0f, Hm1);
+        c.nz = (int)clamp_med3(0.5f * (z * rmb + 1.0f) * Hf, 0.0f, Hm1);
+        const uint32_t mort = spread((uint32_t)c.nx) | (spread((uint32_t)c.ny) << 1) | (spread((uint32_t)c.nz) << 2);
+        const uint32_t cell = (uint32_t)((float)level * H3 + (float)mort);
+        return (grid[cell >> 3] & (1u << (cell & 7u))) != 0;
+    }
+    __device__ __forceinline__ float cell_exit(float t, float x, float y, float z, const Cell& c) const {
+        const float tx = ((((float)c.nx + 0.5f + 0.5f * copysignf(1.0f, dx)) * rH * 2.0f - 1.0f) * c.mb - x) * ix;
+        const float ty = ((((float)c.ny + 0.5f + 0.5f * copysignf(1.0f, dy)) * rH * 2.0f - 1.0f) * c.mb - y) * iy;
+        const float tz = ((((float)c.nz + 0.5f + 0.5f * copysignf(1.0f, dz)) * rH * 2.0f - 1.0f) * c.mb - z) * iz;
+        return t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
+    }
+    __device__ __forceinline__ bool classify(float t, float& x, float& y, float& z, float& dt, float& t_exit) const {
+        Cell c;
+        const bool occ = classify_cell(t, x, y, z, dt, c);
+        t_exit = cell_exit(t, x, y, z, c);
         return occ;
     }
     // returns true when the cell containing o + t d is occupied; x,y,z,dt describe the sample.
@@ -109,6 +182,12 @@ struct Marcher {
     }
 };
 
+// Fills the workgroup's LDS table of spread3(v), v < H (H <= kSpreadLutMax); the caller synchronises afterwards.
+constexpr uint32_t kSpreadLutMax = 1024;
+__device__ __forceinline__ void fill_spread_lut(uint32_t* lut, uint32_t H) {
+    for (uint32_t v = threadIdx.x; v < H; v += blockDim.x) lut[v] = spread3(v);
+}
+
 // Wave-cooperative marcher: all 64 lanes of a wave work on ONE ray.  Lane j classifies member j of the current batch of
 // 64 consecutive chain members (one dependent occupancy load per 64 members instead of one per probe); next_sample()
 // then replays the serial protocol of Marcher::probe from the per-lane results -- an occupied member is a sample and
@@ -117,35 +196,34 @@ struct Marcher {
 struct ChainWalker {
     float bt, bx, by, bz, bdt, bexit;  // per lane: member parameter, sample position, step, exit parameter of its cell
     bool bocc;
-    int j;          // next member of the batch to examine (64 = batch exhausted)
+    int j, nb;      // next member of the batch to examine, members in the batch (j >= nb: batch exhausted)
     float pending;  // exit parameter of an empty cell whose skip runs past the end of a batch (-inf: none)
     float t;        // member 0 of the NEXT batch
+    bool done;      // next_samples(): the ray is finished
     __device__ __forceinline__ void init(float t0) {
-        t = t0; j = 64; pending = -INFINITY;
+        t = t0; j = 64; nb = 64; pending = -INFINITY; done = false;
         bt = bx = by = bz = bdt = bexit = 0.0f;
         bocc = false;
+    }
+    __device__ __forceinline__ unsigned long long batch_mask() const { return nb >= 64 ? ~0ull : (1ull << nb) - 1ull; }
+    __device__ __forceinline__ void refill(const Marcher& m, int lane) {
+        const float t0 = t;
+        m.fill_batch(t0, lane, bt, nb, t);
+        Marcher::Cell c;
+        bocc = m.classify_cell(bt, bx, by, bz, bdt, c);
+        if (__ballot(!bocc) & batch_mask()) bexit = m.cell_exit(bt, bx, by, bz, c);  // exits matter for empty cells only
+        j = 0;
+        if (pending > -INFINITY) {
+            const unsigned long long reach = __ballot(bt >= pending) & batch_mask();
+            if (reach) { j = __builtin_ctzll(reach); pending = -INFINITY; }
+            else j = nb;
+        }
     }
     // Next sample of the ray with parameter < far: returns false when the ray is finished.
     __device__ __forceinline__ bool next_sample(const Marcher& m, float far, int lane, float& x, float& y, float& z, float& dt,
                                                 float& t_sample) {
         while (true) {
-            if (j >= 64) {
-                float tc = t;
-                bt = t;
-                for (int k = 1; k < 64; ++k) {
-                    tc = m.next(tc);
-                    if (lane == k) bt = tc;
-                }
-                bocc = m.classify(bt, bx, by, bz, bdt, bexit);
-                t = m.next(tc);
-                j = 0;
-                if (pending > -INFINITY) {
-                    const unsigned long long reach = __ballot(bt >= pending);
-                    if (reach) { j = __builtin_ctzll(reach); pending = -INFINITY; }
-                    else j = 64;
-                }
-                continue;
-            }
+            if (j >= nb) { refill(m, lane); continue; }
             const int ju = __builtin_amdgcn_readfirstlane(j);
             const float tj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bt), ju));
             if (!(tj < far)) return false;
@@ -160,11 +238,115 @@ struct ChainWalker {
             }
             const float tt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bexit), ju));
             if (!(tt < far)) return false;  // the serial marcher would step to a member >= tt >= far and stop there
-            const unsigned long long later = ~0ull << ju << 1;
+            const unsigned long long later = (~0ull << ju << 1) & batch_mask();
             const unsigned long long reach = __ballot(bt >= tt) & later;
             if (reach) j = __builtin_ctzll(reach);
-            else { j = 64; pending = tt; }
+            else { j = nb; pending = tt; }
         }
+    }
+    // All samples of the next batch that has any, as a lane mask (lane k set: member k of the batch is a sample; its
+    // description sits in bt / bx / by / bz / bdt of that lane; samples are in chain order = lane order).  At most max_n
+    // (>= 1) samples.  Returns 0 when the ray is finished.
+    //
+    // Which members of a batch are visited is decided for all 64 lanes at once.  An empty member j skips to
+    // nxt_j = the first later member at or beyond its cell's exit (binary search over the non-decreasing bt), a member
+    // at / beyond `far` or an empty one whose exit is beyond `far` ends the ray (nxt = 255), an occupied one moves to
+    // j + 1.  With P_k = max nxt_j over the empty members j < k, member k is visited iff P_k <= k -- provided no skipped
+    // member would have skipped further than the member that skipped it (nxt_j <= P_j for every covered j; then covered
+    // members contribute nothing to P and an induction over k gives visited == uncovered).  Cells are convex, so the
+    // proviso only fails through rounding at a cell face; that batch is then walked serially (walk_serial, the protocol of
+    // Marcher::probe verbatim).  `serial` forces the serial walk (tests, A/B).
+    __device__ __forceinline__ unsigned long long next_samples(const Marcher& m, float far, int lane, uint32_t max_n, bool serial = false) {
+        while (true) {
+            if (done) return 0ull;
+            if (j >= nb) {
+                refill(m, lane);
+                if (j >= nb) continue;
+            }
+            unsigned long long S = 0ull;
+            if (serial || !walk_parallel(far, lane, S)) S = walk_serial(far);
+            if (S) {
+                if ((uint32_t)__builtin_popcountll(S) > max_n) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(S >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)S, 0u));
+                    S = __ballot(((S >> lane) & 1ull) && rank < max_n);
+                    done = true;
+                }
+                return S;
+            }
+        }
+    }
+    __device__ __forceinline__ unsigned long long walk_serial(float far) {
+        const unsigned long long bm = batch_mask();
+        const unsigned long long below = __ballot(bt < far) & bm;
+        const unsigned long long occ = __ballot(bocc) & below;
+        unsigned long long S = 0ull;
+        while (j < nb) {
+            const int ju = __builtin_amdgcn_readfirstlane(j);
+            if (!((below >> ju) & 1ull)) { done = true; break; }
+            if ((occ >> ju) & 1ull) {
+                const unsigned long long inv = ~(occ >> ju);
+                const int r = inv ? __builtin_ctzll(inv) : 64;
+                S |= (r >= 64 ? ~0ull : (1ull << r) - 1ull) << ju;
+                j = ju + r;
+                continue;
+            }
+            const float tt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bexit), ju));
+            if (!(tt < far)) { done = true; break; }  // the serial marcher would step to a member >= tt >= far and stop there
+            const unsigned long long later = (~0ull << ju << 1) & bm;
+            const unsigned long long reach = __ballot(bt >= tt) & later;
+            if (reach) j = __builtin_ctzll(reach);
+            else { j = nb; pending = tt; }
+        }
+        j = nb;
+        return S;
+    }
+    // returns false (state untouched) when the batch needs the serial walk
+    __device__ __forceinline__ bool walk_parallel(float far, int lane, unsigned long long& S) {
+        const int j0 = __builtin_amdgcn_readfirstlane(j);
+        const unsigned long long bm = batch_mask();
+        const unsigned long long active = bm & (~0ull << j0);
+        const bool in = (active >> lane) & 1ull;
+        const bool below = bt < far;
+        if (!__ballot(in && !(bocc && below))) {  // every remaining member is an occupied one below far: all are samples
+            S = active;
+            j = nb;
+            return true;
+        }
+        const bool empty = in && below && !bocc;
+        const bool stopper = in && (!below || (!bocc && !(bexit < far)));
+        uint32_t nxt = stopper ? 255u : 0u;
+        if (__ballot(empty && !stopper)) {
+            // cnt = number of batch members below this lane's exit parameter (bt is non-decreasing along the batch)
+            const float last = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bt), nb - 1));
+            int lo = 0;
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) {
+                const int probe = lo + step - 1;
+                const float v = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(probe << 2, __builtin_bit_cast(int, bt)));
+                if (probe < nb && v < bexit) lo += step;
+            }
+            const int cnt = last < bexit ? nb : lo;
+            const int jump = cnt > lane + 1 ? cnt : lane + 1;
+            if (empty && !stopper) nxt = (uint32_t)jump;
+        }
+        const uint32_t incl = wave_scan_max_u32(nxt);
+        uint32_t P = (uint32_t)__shfl_up((int)incl, 1);
+        if (lane == 0) P = 0u;
+        const bool covered = P > (uint32_t)lane;
+        if (__ballot((empty || stopper) && covered && nxt > P)) return false;
+        const bool vis = in && !covered;
+        const unsigned long long stop = __ballot(vis && stopper);
+        S = __ballot(vis && bocc && below);
+        if (stop) {
+            S &= (1ull << __builtin_ctzll(stop)) - 1ull;
+            done = true;
+        } else {
+            const unsigned long long visited = __ballot(vis);  // non-zero: member j0 is never covered
+            const int v = 63 - __builtin_clzll(visited);
+            if (!__builtin_amdgcn_readlane((int)bocc, v)) pending = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bexit), v));
+        }
+        j = nb;
+        return true;
     }
 };
 

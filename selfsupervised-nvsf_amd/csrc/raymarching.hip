@@ -132,20 +132,27 @@ __global__ __launch_bounds__(kBlock) void k_march_count_wave(const float* __rest
                                                              const uint8_t* __restrict__ grid, float bound, float dt_gamma,
                                                              uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H,
                                                              const float* __restrict__ nears, const float* __restrict__ fars,
-                                                             const float* __restrict__ noises, int* __restrict__ rays) {
+                                                             const float* __restrict__ noises, int* __restrict__ rays, int serial) {
+    __shared__ uint32_t s_lut[kSpreadLutMax];
+    fill_spread_lut(s_lut, H);  // H <= 1024 (checked by the launcher)
+    __syncthreads();
     const uint32_t n = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6));
     if (n >= N) return;
     const int lane = lane_id();
     Marcher m;
     m.init(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, grid, bound, dt_gamma, max_steps, C, H);
+    m.lut = s_lut;
     const float far = fars[n];
     float t = nears[n];
     t += m.step_len(t) * noises[n];
     ChainWalker w;
     w.init(t);
     uint32_t count = 0;
-    float x, y, z, dt, ts;
-    while (count < max_steps && w.next_sample(m, far, lane, x, y, z, dt, ts)) ++count;
+    while (count < max_steps) {
+        const unsigned long long S = w.next_samples(m, far, lane, max_steps - count, serial != 0);
+        if (!S) break;
+        count += (uint32_t)__builtin_popcountll(S);
+    }
     if (lane == 0) rays[3 * (size_t)n + 2] = (int)count;
 }
 
@@ -155,7 +162,10 @@ __global__ __launch_bounds__(kBlock) void k_march_write_wave(const float* __rest
                                                              const float* __restrict__ nears, const float* __restrict__ fars,
                                                              const float* __restrict__ noises, const int* __restrict__ rays,
                                                              float* __restrict__ xyzs, float* __restrict__ dirs,
-                                                             float* __restrict__ deltas) {
+                                                             float* __restrict__ deltas, int serial) {
+    __shared__ uint32_t s_lut[kSpreadLutMax];
+    fill_spread_lut(s_lut, H);
+    __syncthreads();
     const uint32_t n = __builtin_amdgcn_readfirstlane(blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6));
     if (n >= N) return;
     const int lane = lane_id();
@@ -163,53 +173,63 @@ __global__ __launch_bounds__(kBlock) void k_march_write_wave(const float* __rest
     if (count == 0 || offset + count > M) return;
     Marcher m;
     m.init(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, grid, bound, dt_gamma, max_steps, C, H);
+    m.lut = s_lut;
     const float far = fars[n];
     float t = nears[n];
     t += m.step_len(t) * noises[n];
     float last_t = t;
     ChainWalker w;
     w.init(t);
-    // lane (step & 63) keeps sample `step`; every 64 samples (and at the end) the wave stores them together
-    float kx = 0.0f, ky = 0.0f, kz = 0.0f, kdt = 0.0f, kd1 = 0.0f;
-    auto flush = [&](uint32_t first, uint32_t n_valid) {
-        if ((uint32_t)lane < n_valid) {
-            const size_t s = (size_t)offset + first + (uint32_t)lane;
-            xyzs[3 * s] = kx; xyzs[3 * s + 1] = ky; xyzs[3 * s + 2] = kz;
-            dirs[3 * s] = m.dx; dirs[3 * s + 1] = m.dy; dirs[3 * s + 2] = m.dz;
-            deltas[2 * s] = kdt; deltas[2 * s + 1] = kd1;
-        }
-    };
+    // the samples of a batch sit in the lanes of the mask S, in chain order: every such lane stores its own sample
     uint32_t step = 0;
-    float x, y, z, dt, ts;
-    while (step < count && w.next_sample(m, far, lane, x, y, z, dt, ts)) {
-        const float t_after = ts + dt;
-        const float d1 = t_after - last_t;
-        last_t = t_after;
-        if ((uint32_t)lane == (step & 63u)) { kx = x; ky = y; kz = z; kdt = dt; kd1 = d1; }
-        ++step;
-        if ((step & 63u) == 0u) flush(step - 64u, 64u);
+    while (step < count) {
+        const unsigned long long S = w.next_samples(m, far, lane, count - step, serial != 0);
+        if (!S) break;
+        const float t_after = w.bt + w.bdt;
+        const unsigned long long lower = S & ((1ull << lane) - 1ull);  // samples of this batch before this lane
+        const int prev_lane = lower ? 63 - __builtin_clzll(lower) : lane;
+        const float prev_after = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(prev_lane << 2, __builtin_bit_cast(int, t_after)));
+        if ((S >> lane) & 1ull) {
+            const size_t s = (size_t)offset + step + (uint32_t)__builtin_popcountll(lower);
+            xyzs[3 * s] = w.bx; xyzs[3 * s + 1] = w.by; xyzs[3 * s + 2] = w.bz;
+            dirs[3 * s] = m.dx; dirs[3 * s + 1] = m.dy; dirs[3 * s + 2] = m.dz;
+            deltas[2 * s] = w.bdt; deltas[2 * s + 1] = t_after - (lower ? prev_after : last_t);
+        }
+        last_t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t_after), 63 - __builtin_clzll(S)));
+        step += (uint32_t)__builtin_popcountll(S);
     }
-    if (step & 63u) flush(step & ~63u, step & 63u);
 }
 
 // pass 2: one workgroup; exclusive scan of the counts in ray order, reserving [counter[0], +total).
+// A thread takes kScanPer consecutive rays per round (4096 rays per round: one round at the BASELINE batch size).
+constexpr uint32_t kScanPer = 4;
 __global__ __launch_bounds__(1024) void k_march_scan(uint32_t N, int* __restrict__ rays, int* __restrict__ counter) {
     __shared__ uint32_t wave_tot[16];
     __shared__ uint32_t carry_s;
     const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
     if (threadIdx.x == 0) carry_s = (uint32_t)counter[0];
     __syncthreads();
-    for (uint32_t base = 0; base < N; base += 1024) {
-        const uint32_t n = base + threadIdx.x;
-        const uint32_t c = n < N ? (uint32_t)rays[3 * (size_t)n + 2] : 0u;
-        const uint32_t incl = wave_scan_add_u32(c);
+    for (uint32_t base = 0; base < N; base += 1024 * kScanPer) {
+        const uint32_t n0 = base + threadIdx.x * kScanPer;
+        uint32_t c[kScanPer], sum = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < kScanPer; ++i) {
+            c[i] = n0 + i < N ? (uint32_t)rays[3 * (size_t)(n0 + i) + 2] : 0u;
+            sum += c[i];
+        }
+        const uint32_t incl = wave_scan_add_u32(sum);
         if (lane == 63) wave_tot[wid] = incl;
         __syncthreads();
         uint32_t before = carry_s;
         for (int w = 0; w < wid; ++w) before += wave_tot[w];
-        if (n < N) {
-            rays[3 * (size_t)n + 0] = (int)n;
-            rays[3 * (size_t)n + 1] = (int)(before + incl - c);
+        uint32_t run = before + incl - sum;
+#pragma unroll
+        for (uint32_t i = 0; i < kScanPer; ++i) {
+            if (n0 + i < N) {
+                rays[3 * (size_t)(n0 + i) + 0] = (int)(n0 + i);
+                rays[3 * (size_t)(n0 + i) + 1] = (int)run;
+            }
+            run += c[i];
         }
         __syncthreads();
         if (threadIdx.x == 1023) carry_s = before + incl;
@@ -494,12 +514,13 @@ NVSF_API int nvsf_march_rays_train(const float* rays_o, const float* rays_d, con
                            max_steps, N, C, H, M, nears, fars, noises, rays, xyzs, dirs, deltas);
         return nvsf_launch_status();
     }
+    const int serial = variant && variant[0] == 's';  // "serial": wave kernels with the batch walked member by member (tests, A/B)
     const dim3 wgrid(cdiv(N, kBlock / kWave));
     hipLaunchKernelGGL(k_march_count_wave, wgrid, dim3(kBlock), 0, stream, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H,
-                       nears, fars, noises, rays);
+                       nears, fars, noises, rays, serial);
     hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(1024), 0, stream, N, rays, counter);
     hipLaunchKernelGGL(k_march_write_wave, wgrid, dim3(kBlock), 0, stream, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M,
-                       nears, fars, noises, rays, xyzs, dirs, deltas);
+                       nears, fars, noises, rays, xyzs, dirs, deltas, serial);
     return nvsf_launch_status();
 }
 

@@ -320,3 +320,62 @@ def test_chamfer_restatement_against_numpy():
     ap = a.copy(); ap[1, 17, 2] += eps
     am = a.copy(); am[1, 17, 2] -= eps
     np.testing.assert_allclose((loss(ap, b) - loss(am, b)) / (2 * eps), ga[1, 17, 2], rtol=2e-2, atol=2e-3)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The wave-cooperative marcher builds 64 chain members t_k = fl(t_{k-1} + c) at once for a constant step
+# (csrc/march_device.h, Marcher::fill_batch).  The integer closed form below is the host restatement of that device
+# code, line by line; it must reproduce the serial fp32 recurrence of the reference's marcher
+# (raymarching.cu:414-416, 434-437: `t += dt`) bit for bit.
+def _chain_closed_form(t0, c, K=64):
+    tb, cb = int(np.float32(t0).view(np.uint32)), int(np.float32(c).view(np.uint32))
+    e, ec = tb >> 23, cb >> 23
+    d = e - ec
+    if not (0 <= d <= 24 and 24 <= e < 254 and ec > 0):
+        return None  # the device takes the serial path
+    m0, mc = (tb & 0x7FFFFF) | 0x800000, (cb & 0x7FFFFF) | 0x800000
+    q, rem, half = mc >> d, mc & ((1 << d) - 1), (1 << (d - 1)) if d > 0 else 0
+    if d > 0 and rem == half:
+        s, s_first = q + (q & 1), q + ((m0 + q) & 1)
+    else:
+        s = q + (1 if (d > 0 and rem > half) else 0)
+        s_first = s
+    if s == 0:
+        return None
+    scale = np.uint32((e - 23) << 23).view(np.float32)
+    k = np.arange(K, dtype=np.int64)
+    mk = np.where(k == 0, m0, m0 + s_first + (k - 1) * s)
+    mprev = np.where(k <= 1, m0, m0 + s_first + (k - 2) * s)
+    valid = (k == 0) | (mprev + q < (1 << 24))
+    nb = int(valid.sum())
+    assert valid[:nb].all()
+    return (mk[:nb].astype(np.float32) * scale).astype(np.float32)
+
+
+def test_constant_step_chain_closed_form():
+    rng = np.random.default_rng(0)
+    checked = 0
+    for it in range(40000):
+        ee = int(rng.integers(-12, 4))
+        t0 = np.float32(rng.uniform(1, 2) * 2.0 ** ee)
+        mode = it % 4
+        if mode == 0:    # the marcher's own steps: 2 sqrt(3) / max_steps
+            c = np.float32(np.float32(2.0) * np.float32(1.7320508075688772) / np.float32(rng.choice([128, 256, 512, 768, 1000, 1024, 2048, 4096])))
+        elif mode == 1:  # arbitrary steps, from far below one ulp of t to larger than t
+            c = np.float32(rng.uniform(1, 2) * 2.0 ** int(rng.integers(ee - 26, ee + 2)))
+        elif mode == 2:  # exact ties (remainder == half an ulp): round-to-even alternation
+            d = int(rng.integers(1, 24))
+            cb = int(np.float32(rng.uniform(1, 2) * 2.0 ** (ee - d)).view(np.uint32))
+            c = np.uint32(((cb >> d) << d) | (1 << (d - 1))).view(np.float32)
+        else:            # start just below a power of two: the batch must stop at the binade crossing
+            t0 = np.float32(np.float32(2.0 ** (ee + 1)) - np.float32(int(rng.integers(1, 3000)) * 2.0 ** (ee - 23)))
+            c = np.float32(rng.uniform(1, 2) * 2.0 ** int(rng.integers(ee - 12, ee + 1)))
+        got = _chain_closed_form(t0, c)
+        if got is None:
+            continue
+        t = np.float32(t0)
+        for v in got:
+            assert v == t, (t0, c)
+            t = np.float32(t + np.float32(c))
+        checked += len(got)
+    assert checked > 1_000_000

@@ -94,7 +94,7 @@ def test_packbits(rm, dev, scene):
     assert np.array_equal(rm.packbits(_t(g2, dev), 0.01).cpu().numpy(), O.packbits(g2, 0.01))
 
 
-@pytest.mark.parametrize("march", ["wave", "thread"])  # wave-per-ray ChainWalker kernels (default) / one thread per ray
+@pytest.mark.parametrize("march", ["wave", "serial", "thread"])  # wave-per-ray ChainWalker kernels (default: whole batches decided at once; serial: member by member) / one thread per ray
 @pytest.mark.parametrize("n,max_steps,dt_gamma,perturb_seed", [(4096, 1024, 0.0, None), (1000, 256, 1.0 / 128, 7), (1, 64, 0.0, None)])
 def test_march_rays_train(rm, dev, scene, n, max_steps, dt_gamma, perturb_seed, march, monkeypatch):
     monkeypatch.setenv("NVSF_MARCH", march)
@@ -120,6 +120,43 @@ def test_march_rays_train(rm, dev, scene, n, max_steps, dt_gamma, perturb_seed, 
     assert np.array_equal(dirs.cpu().numpy()[:m], dr[:m])
     assert np.array_equal(deltas.cpu().numpy()[:m], lr[:m])
     assert not xyzs[m:].any()
+
+
+@pytest.mark.parametrize("kind", ["random10", "random50", "dense", "empty", "scene"])
+@pytest.mark.parametrize("dt_gamma,max_steps", [(0.0, 1024), (0.0, 300), (1.0 / 256, 512)])
+def test_march_rays_train_wave_forms_equal_the_thread_form(rm, dev, scene, kind, dt_gamma, max_steps, monkeypatch):
+    """The one-thread-per-ray kernels are pinned to the oracle above; here the wave kernels (closed-form chain,
+    batch-parallel visit decision, and the serial walk) must reproduce them bit for bit on grids that stress the skip
+    logic: per-cell random occupancy (a jump every few members), fully occupied, empty, and the blocky test scene."""
+    from nvsf import _hip
+    n = 6000
+    rng = np.random.default_rng(11)
+    if kind == "scene":
+        bits = scene["bits"]
+    else:
+        p = {"random10": 0.1, "random50": 0.5, "dense": 1.0, "empty": 0.0}[kind]
+        bits = np.packbits(rng.random(2 * 128 ** 3) < p, bitorder="little")
+    o, d = _rays(n, 12, "cam")
+    o[: n // 2] *= 3.0  # half of the origins far from the centre / outside the inner cascade
+    aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
+    nears, fars = O.near_far_from_aabb(o, d, aabb, 0.02)
+    noises = rng.random(n).astype(np.float32)
+    T = lambda a: _t(a, dev)
+    to, td, tb, tn, tf, tz = T(o), T(d), T(bits), T(nears), T(fars), T(noises)
+    M = n * max_steps
+    out = {}
+    for march in ("thread", "wave", "serial"):
+        monkeypatch.setenv("NVSF_MARCH", march)
+        xyzs = torch.zeros(M, 3, device=dev); dirs = torch.zeros(M, 3, device=dev); deltas = torch.zeros(M, 2, device=dev)
+        rays = torch.empty(n, 3, dtype=torch.int32, device=dev); counter = torch.zeros(2, dtype=torch.int32, device=dev)
+        _hip.call("nvsf_march_rays_train", _hip.ptr(to), _hip.ptr(td), _hip.ptr(tb), 2.0, float(dt_gamma), max_steps, n, 2, 128, M,
+                  _hip.ptr(tn), _hip.ptr(tf), _hip.ptr(xyzs), _hip.ptr(dirs), _hip.ptr(deltas), _hip.ptr(rays), _hip.ptr(counter), _hip.ptr(tz))
+        out[march] = (counter.cpu(), rays.cpu(), xyzs.cpu(), dirs.cpu(), deltas.cpu())
+    total = int(out["thread"][0][0])
+    assert (total > 0) == (kind != "empty")
+    for march in ("wave", "serial"):
+        for a, b in zip(out["thread"], out[march]):
+            assert torch.equal(a, b), (march, kind)
 
 
 def test_march_rays_train_wrapper_semantics(rm, dev, scene):

@@ -34,6 +34,8 @@ def _time_ms(fn, iters=10):
 
 def _row(kernel, ms, nbytes, per_unit, units):
     gbs = nbytes / (ms * 1e-3) / 1e9
+    if os.environ.get("NVSF_BENCH_VERBOSE"):
+        print(f"  {kernel}: {ms:.4f} ms, {gbs:.0f} GB/s", file=sys.stderr, flush=True)
     return {"kernel": kernel, "ms": ms, "bound": "hbm", "unit": "GB/s", "achieved": gbs, "peak": HBM_PEAK_GBS,
             "frac": gbs / HBM_PEAK_GBS, "per_unit": per_unit, "units": units}
 
@@ -73,7 +75,7 @@ def raymarching_rooflines(dev, n_rays_march=32768, occupied=1.0, seed=0):
     N = 16 * H ** 3
     grid = torch.rand(N, device=dev, generator=g)
     bits = torch.empty(N // 8, dtype=torch.uint8, device=dev)
-    ms = _time_ms(lambda: _hip.call("nvsf_packbits", P(grid), N, 0.5, P(bits)))
+    ms = _time_ms(lambda: _hip.call("nvsf_packbits", P(grid), N // 8, 0.5, P(bits)))  # N of the ABI = output bytes
     rows.append(_row("packbits", ms, 33 * (N // 8), "33 B/output byte", N // 8))
     del grid, bits
 
@@ -132,10 +134,15 @@ def raymarching_rooflines(dev, n_rays_march=32768, occupied=1.0, seed=0):
     ws, depth, image = torch.zeros(N, device=dev), torch.zeros(N, device=dev), torch.zeros(N, 3, device=dev)
     alive2, t2 = alive.clone(), rays_t.clone()
 
+    def reset():  # T = 1 - weights_sum stays above T_thresh and no ray is marked dead (-1): every launch reads every slot
+        ws.zero_()
+        alive2.copy_(alive)
+        t2.copy_(rays_t)
+
     def comp():
-        ws.zero_()  # keeps T = 1 - weights_sum above T_thresh so every launch reads every slot
+        reset()
         _hip.call("nvsf_composite_rays", N, n_step, 1e-2, P(alive2), P(t2), P(sigmas), P(rgbs), P(deltas), P(ws), P(depth), P(image))
-    ms = _time_ms(comp, 5)
+    ms = _time_ms(comp, 5) - _time_ms(reset, 5)
     rows.append(_row("composite_rays[n_step 8]", ms, 24 * M + 48 * N, "24 B/sample + 48 B/ray", M))
     return rows
 
