@@ -1035,57 +1035,35 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     uint32_t total = 0;
     const float extent = 2.0f * rr.bound;
     bool alive = true;
-    // Marching, 64 chain members at a time.  The parameters a ray visits form one chain t_{k+1} = t_k + step_len(t_k)
-    // (march_device.h), so lane j can classify member j of the current batch on its own: ONE dependent occupancy load
-    // per 64 members instead of one per probe.  The walk below then reproduces the serial protocol of march_rays from
-    // the per-lane results: an occupied member becomes a sample and the walk moves to the next member; an empty one
-    // jumps to the first member at or beyond the cell's exit parameter (ballot + find-first), possibly in a later batch.
-    float bt = 0.0f, bx = 0.0f, by = 0.0f, bz = 0.0f, bdt = 0.0f, bexit = 0.0f;
-    bool bocc = false;
-    int j = 64, nb = 64;          // next member of the batch to examine, members in the batch (j >= nb: exhausted)
-    unsigned long long bmask = ~0ull;
-    float pending = -INFINITY;    // exit parameter of an empty cell whose skip runs past the end of a batch
+    // Marching, 64 chain members at a time (ChainWalker, march_device.h): the parameters a ray visits form one chain
+    // t_{k+1} = t_k + step_len(t_k), lane j classifies member j of the current batch on its own (ONE dependent occupancy
+    // load per 64 members), and which members are visited -- hence which are samples -- is decided for the whole batch at
+    // once (next_samples).  The samples of a batch are then handed to the tile one by one (bit scan over the mask).
+    ChainWalker w;
+    w.init(t);
+    unsigned long long S = 0ull;  // samples of the current batch not yet consumed (wave-uniform)
+    float bd1 = 0.0f;             // per lane: second delta (t_after - previous sample's t_after) of this lane's sample
     bool ray_done = false;
     while (alive) {
         uint32_t count = 0;
         float sx = 0.0f, sy = 0.0f, sz = 0.0f, sdt = 0.0f, sd1 = 0.0f;
         while (count < 16u && total + count < rr.max_steps && !ray_done) {
-            if (j >= nb) {  // build the next batch: member 0 = t (closed form for a constant step, march_device.h)
-                const float t0 = t;
-                m.fill_batch(t0, lane, bt, nb, t);  // t <- member 0 of the batch after this one
-                Marcher::Cell cell;
-                bocc = m.classify_cell(bt, bx, by, bz, bdt, cell);
-                bmask = nb >= 64 ? ~0ull : (1ull << nb) - 1ull;
-                if (__ballot(!bocc) & bmask) bexit = m.cell_exit(bt, bx, by, bz, cell);  // exits matter for empty cells only
-                j = 0;
-                if (pending > -INFINITY) {
-                    const unsigned long long reach = __ballot(bt >= pending) & bmask;
-                    if (reach) { j = __builtin_ctzll(reach); pending = -INFINITY; }
-                    else j = nb;
-                }
-                continue;
+            if (!S) {
+                S = w.next_samples(m, far, lane, rr.max_steps - total - count);
+                if (!S) { ray_done = true; break; }
+                const float t_after = w.bt + w.bdt;
+                const unsigned long long lower = S & ((1ull << lane) - 1ull);
+                const int prev_lane = lower ? 63 - __builtin_clzll(lower) : lane;
+                const float prev_after = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(prev_lane << 2, __builtin_bit_cast(int, t_after)));
+                bd1 = t_after - (lower ? prev_after : last_t);
+                last_t = readlane_f32(t_after, 63 - __builtin_clzll(S));
             }
-            const int ju = __builtin_amdgcn_readfirstlane(j);
-            const float tj = readlane_f32(bt, ju);
-            if (!(tj < far)) { ray_done = true; break; }
-            const float xj = readlane_f32(bx, ju), yj = readlane_f32(by, ju), zj = readlane_f32(bz, ju);
-            const float dtj = readlane_f32(bdt, ju), tt = readlane_f32(bexit, ju);
-            if (__builtin_amdgcn_readlane((int)bocc, ju)) {
-                const float t_after = tj + dtj;
-                const float d1s = t_after - last_t;
-                last_t = t_after;
-                if (count == (uint32_t)sl) { sx = xj; sy = yj; sz = zj; sdt = dtj; sd1 = d1s; }
-                ++count;
-                j = ju + 1;
-            } else {
-                // march_rays would step to the first member at or beyond tt and stop there if it is not below `far`
-                if (!(tt < far)) { ray_done = true; break; }
-                // first member after j at or beyond tt; the chain is non-decreasing, members <= j are masked out
-                const unsigned long long later = (~0ull << ju << 1) & bmask;
-                const unsigned long long reach = __ballot(bt >= tt) & later;
-                if (reach) j = __builtin_ctzll(reach);
-                else { j = nb; pending = tt; }
-            }
+            const int ju = __builtin_ctzll(S);
+            S &= S - 1ull;
+            const float xj = readlane_f32(w.bx, ju), yj = readlane_f32(w.by, ju), zj = readlane_f32(w.bz, ju);
+            const float dtj = readlane_f32(w.bdt, ju), d1j = readlane_f32(bd1, ju);
+            if (count == (uint32_t)sl) { sx = xj; sy = yj; sz = zj; sdt = dtj; sd1 = d1j; }
+            ++count;
         }
         const uint32_t cnt = __builtin_amdgcn_readfirstlane(count);
         if (cnt == 0u) break;

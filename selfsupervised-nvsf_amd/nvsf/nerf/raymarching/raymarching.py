@@ -131,21 +131,46 @@ class _march_rays_train(Function):
             if align > 0:
                 mean_count += align - mean_count % align
             M = mean_count
-        xyzs = torch.zeros(M, 3, dtype=dt, device=dev)
-        dirs = torch.zeros(M, 3, dtype=dt, device=dev)
-        deltas = torch.zeros(M, 2, dtype=dt, device=dev)
+        # The reference zero-fills the three M-row outputs (raymarching.py:235-237).  When the result is sliced to the
+        # sample count anyway (force_all_rays / no mean_count), M = N * max_steps rows (134 MB at 4096 x 1024) would be
+        # cleared only to be discarded: allocate them uninitialised and clear just the rows the caller keeps beyond the
+        # written ones.  Same returned tensors.
+        sliced = force_all_rays or mean_count <= 0
+        alloc = torch.empty if sliced else torch.zeros
+        xyzs = alloc(M, 3, dtype=dt, device=dev)
+        dirs = alloc(M, 3, dtype=dt, device=dev)
+        deltas = alloc(M, 2, dtype=dt, device=dev)
         rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
         if step_counter is None:
             step_counter = torch.zeros(2, dtype=torch.int32, device=dev)
         noises = torch.rand(N, dtype=dt, device=dev) if perturb else torch.zeros(N, dtype=dt, device=dev)
-        _hip.call("nvsf_march_rays_train", _hip.ptr(rays_o), _hip.ptr(rays_d), _hip.ptr(density_bitfield), float(bound),
-                  float(dt_gamma), int(max_steps), N, int(C), int(H), M, _hip.ptr(nears), _hip.ptr(fars), _hip.ptr(xyzs),
-                  _hip.ptr(dirs), _hip.ptr(deltas), _hip.ptr(rays), _hip.ptr(step_counter), _hip.ptr(noises))
-        if force_all_rays or mean_count <= 0:
-            m = int(step_counter[0].item())  # the one device->host read of the reference (raymarching.py:277)
+
+        def launch():
+            _hip.call("nvsf_march_rays_train", _hip.ptr(rays_o), _hip.ptr(rays_d), _hip.ptr(density_bitfield), float(bound),
+                      float(dt_gamma), int(max_steps), N, int(C), int(H), M, _hip.ptr(nears), _hip.ptr(fars), _hip.ptr(xyzs),
+                      _hip.ptr(dirs), _hip.ptr(deltas), _hip.ptr(rays), _hip.ptr(step_counter), _hip.ptr(noises))
+        launch()
+        if sliced:
+            # the one device->host read of the reference (raymarching.py:277); rays[0,1] = counter value before the call
+            m, first = torch.stack([step_counter[0], rays[0, 1]]).tolist() if N > 0 else (int(step_counter[0].item()), 0)
+            if first != 0 or m > M:
+                # a pre-loaded counter or rays dropped for lack of room: the written rows are not one prefix -- redo on
+                # cleared buffers (never the case for the renderer, which passes a zeroed counter and M = N * max_steps)
+                for t in (xyzs, dirs, deltas):
+                    t.zero_()
+                step_counter[0] -= m - first
+                step_counter[1] -= N
+                launch()
+                written = M
+            else:
+                written = m
             if align > 0:
                 m += align - m % align
             xyzs, dirs, deltas = xyzs[:m], dirs[:m], deltas[:m]
+            if written < xyzs.shape[0]:
+                xyzs[written:].zero_()
+                dirs[written:].zero_()
+                deltas[written:].zero_()
         return xyzs, dirs, deltas, rays
 
 
