@@ -175,14 +175,17 @@ int nvsf_mlp_fwd(const void* x, int x_is_f16, uint32_t M, uint32_t n_in, uint32_
 /* ref: the backward pass tcnn.Network provides to autograd for the same FullyFusedMLP (tcnn's Module.backward behind
  * network_dynamic.py:125-161,180-189): one kernel, activations recomputed from x.
  * grad_out fp32 [M, go_stride], columns 0..n_out-1 used (the padded outputs carry no gradient).
- * grad_x fp32 [M, gx_stride] or NULL: dL/dx for columns 0..n_in-1 (written, not accumulated).
+ * grad_x fp32 [M, gx_stride] or NULL: column j receives dL/dx of input column gx_col0 + j, j < n_in - gx_col0 (gx_col0 = 0:
+ * the whole input gradient).  Input tiles left of gx_col0 are not computed -- a head whose leading columns are a
+ * parameter-free direction encoding only needs the gradient of its trailing geometry features.  gx_accumulate != 0 adds
+ * to grad_x instead of overwriting it (two heads sharing one input).
  * grad_weights_f32: fp32 buffer in the layout of weights_f16; dL/dW is ADDED to it (zero it first).
  * Gradients travel in fp16 multiplied by grad_scale (tcnn's loss_scale, e.g. 128) and are unscaled on the way out.
  * Supported: hidden = 64, out_cols = 16, n_hidden in 1..2, in_cols <= 128. */
 int nvsf_mlp_bwd(const void* x, int x_is_f16, uint32_t M, uint32_t n_in, uint32_t x_stride, const void* weights_f16,
                  uint32_t in_cols, uint32_t hidden, uint32_t n_hidden, uint32_t out_cols, const float* grad_out,
                  uint32_t n_out, uint32_t go_stride, float grad_scale, float* grad_x, uint32_t gx_stride,
-                 float* grad_weights_f32, nvsf_stream_t stream);
+                 float* grad_weights_f32, uint32_t gx_col0, int gx_accumulate, nvsf_stream_t stream);
 
 /* ref: Planes4D.forward / forward_static / forward_dynamic, nvsf/nerf/models/planes_field.py:86-140,196-238
  * (24 F.grid_sample(bilinear, align_corners=True, padding='border') calls + products + concat per call).

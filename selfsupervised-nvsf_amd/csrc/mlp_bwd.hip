@@ -117,7 +117,8 @@ template <int IN_STEPS, int N_HIDDEN, bool X_F16>
 __global__ __launch_bounds__(kBlock) void k_mlp_bwd(const void* __restrict__ x, uint32_t M, uint32_t n_in, uint32_t x_stride,
                                                     const _Float16* __restrict__ weights, uint32_t in_cols,
                                                     const float* __restrict__ grad_out, uint32_t n_out, uint32_t go_stride, float grad_scale,
-                                                    float* __restrict__ grad_x, uint32_t gx_stride, float* __restrict__ grad_w, int vec_ok) {
+                                                    float* __restrict__ grad_x, uint32_t gx_stride, float* __restrict__ grad_w, int vec_ok,
+                                                    uint32_t gx_col0, int gx_accumulate) {
     using FR = BwdFrags<IN_STEPS, N_HIDDEN>;
     constexpr int IN_TILES = FR::IN_TILES;
     __shared__ half8_t s_frag[FR::kCount * kWave];
@@ -212,16 +213,21 @@ __global__ __launch_bounds__(kBlock) void k_mlp_bwd(const void* __restrict__ x, 
         if (grad_x) {
 #pragma unroll
             for (int ti = 0; ti < IN_TILES; ++ti) {
-                if (16u * ti < n_in) {
+                if (16u * ti < n_in && 16u * ti + 16u > gx_col0) {  // input tiles without a requested column are skipped
                     float4_t a = {0, 0, 0, 0};
 #pragma unroll
                     for (int s = 0; s < kHidSteps; ++s) a = mfma16(frag[(FR::kB0 + 2 * ti + s) * kWave], gp0[s], a);
                     if (valid) {
                         const uint32_t k0 = 16 * ti + 4 * g;
-                        float* dst = grad_x + (size_t)m * gx_stride + k0;
+                        float* row_x = grad_x + (size_t)m * gx_stride;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (k0 + r < n_in) dst[r] = a[r] * inv_scale;
+                        for (int r = 0; r < 4; ++r) {
+                            const uint32_t k = k0 + r;
+                            if (k < n_in && k >= gx_col0) {
+                                const float v = a[r] * inv_scale;
+                                row_x[k - gx_col0] = gx_accumulate ? row_x[k - gx_col0] + v : v;
+                            }
+                        }
                     }
                 }
             }
@@ -304,12 +310,12 @@ __global__ __launch_bounds__(kBlock) void k_mlp_bwd(const void* __restrict__ x, 
 NVSF_API int nvsf_mlp_bwd(const void* x, int x_is_f16, uint32_t M, uint32_t n_in, uint32_t x_stride, const void* weights_f16,
                           uint32_t in_cols, uint32_t hidden, uint32_t n_hidden, uint32_t out_cols, const float* grad_out, uint32_t n_out,
                           uint32_t go_stride, float grad_scale, float* grad_x, uint32_t gx_stride, float* grad_weights_f32,
-                          hipStream_t stream) {
+                          uint32_t gx_col0, int gx_accumulate, hipStream_t stream) {
     if (M == 0) return NVSF_OK;
     REQUIRE(x && weights_f16 && grad_out && grad_weights_f32);
     REQUIRE(n_in >= 1 && n_in <= in_cols && in_cols % 16 == 0 && x_stride >= n_in);
     REQUIRE(n_out >= 1 && n_out <= 16 && go_stride >= n_out && grad_scale > 0.0f);
-    REQUIRE(!grad_x || gx_stride >= n_in);
+    REQUIRE(!grad_x || (gx_col0 < n_in && gx_stride >= n_in - gx_col0));
     REQUIRE((reinterpret_cast<uintptr_t>(weights_f16) & 15u) == 0);
     if (hidden != (uint32_t)kHidden || out_cols != 16 || n_hidden < 1 || n_hidden > 2 || in_cols > 128) return NVSF_ERR_UNSUPPORTED;
     const int in_steps = (int)((in_cols + 31) / 32);
@@ -321,7 +327,7 @@ NVSF_API int nvsf_mlp_bwd(const void* x, int x_is_f16, uint32_t M, uint32_t n_in
     const _Float16* w = reinterpret_cast<const _Float16*>(weights_f16);
 #define LAUNCH(S, H, XF)                                                                                                          \
     hipLaunchKernelGGL((k_mlp_bwd<S, H, XF>), dim3(blocks), dim3(kBlock), 0, stream, x, M, n_in, x_stride, w, in_cols, grad_out, \
-                       n_out, go_stride, grad_scale, grad_x, gx_stride, grad_weights_f32, vec_ok)
+                       n_out, go_stride, grad_scale, grad_x, gx_stride, grad_weights_f32, vec_ok, gx_col0, gx_accumulate)
 #define BY_X(S, H) do { if (x_is_f16) LAUNCH(S, H, true); else LAUNCH(S, H, false); } while (0)
 #define BY_H(S) do { if (n_hidden == 1) BY_X(S, 1); else BY_X(S, 2); } while (0)
     switch (in_steps) {

@@ -39,7 +39,7 @@ SIGNATURES = {
     "nvsf_freq_encode": [_P, _U, _U, _U, _P, _U],
     "nvsf_sh4_encode": [_P, _U, _P, _U],
     "nvsf_mlp_fwd": [_P, _I, _U, _U, _U, _P, _U, _U, _U, _U, _P, _U],
-    "nvsf_mlp_bwd": [_P, _I, _U, _U, _U, _P, _U, _U, _U, _U, _P, _U, _U, _F, _P, _U, _P],
+    "nvsf_mlp_bwd": [_P, _I, _U, _U, _U, _P, _U, _U, _U, _U, _P, _U, _U, _F, _P, _U, _P, _U, _I],
     "nvsf_planes_fwd": [_P, _U, _P, _U, _U, _P, _I, _P, _P],
     "nvsf_planes_bwd": [_P, _U, _P, _U, _U, _P, _I, _P, _P, _P, _P],
     "nvsf_hashgrid4d_dynamic_fwd": [_P, _U, _P, _U, _U, _U, _P, _P, _P, _P, _P, _I, _I, _P],
@@ -99,6 +99,16 @@ def ptr(t):
         raise NvsfHipError("NVSF HIP kernels need tensors on a HIP device (got a CPU tensor); there is no CPU fallback")
     if not t.is_contiguous():
         raise NvsfHipError("NVSF HIP kernels need contiguous tensors")
+    return t.data_ptr()
+
+
+def ptr_rows(t):
+    """Device pointer of a 2-D tensor whose rows are dense (stride(1) == 1) but may be separated by padding / belong to a
+    wider buffer: the kernels that take an explicit row stride accept such views without a copy."""
+    if not t.is_cuda:
+        raise NvsfHipError("NVSF HIP kernels need tensors on a HIP device (got a CPU tensor); there is no CPU fallback")
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise NvsfHipError("expected a 2-D tensor with unit column stride")
     return t.data_ptr()
 
 

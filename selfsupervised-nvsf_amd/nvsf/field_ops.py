@@ -93,19 +93,22 @@ class HashGridFn(Function):
 # ------------------------------------------------------------------------------------------------
 # direction encodings
 # ------------------------------------------------------------------------------------------------
-def freq_encode(x, n_freq=12):
+def freq_encode(x, n_freq=12, out=None):
+    """`out`: optional fp16 buffer with >= 2 * n_dims * n_freq columns (the encoding goes to its leading columns)."""
     x = x.float().contiguous()
     M, n_dims = x.shape
-    out = torch.empty(M, 2 * n_dims * n_freq, dtype=torch.float16, device=x.device)
-    _hip.call("nvsf_freq_encode", _hip.ptr(x), M, n_dims, n_freq, _hip.ptr(out), out.stride(0))
+    if out is None:
+        out = torch.empty(M, 2 * n_dims * n_freq, dtype=torch.float16, device=x.device)
+    _hip.call("nvsf_freq_encode", _hip.ptr(x), M, n_dims, n_freq, _hip.ptr_rows(out), out.stride(0))
     return out
 
 
-def sh4_encode(d01):
+def sh4_encode(d01, out=None):
     d01 = d01.float().contiguous()
     M = d01.shape[0]
-    out = torch.empty(M, 16, dtype=torch.float16, device=d01.device)
-    _hip.call("nvsf_sh4_encode", _hip.ptr(d01), M, _hip.ptr(out), out.stride(0))
+    if out is None:
+        out = torch.empty(M, 16, dtype=torch.float16, device=d01.device)
+    _hip.call("nvsf_sh4_encode", _hip.ptr(d01), M, _hip.ptr_rows(out), out.stride(0))
     return out
 
 
@@ -132,14 +135,22 @@ class MlpSpec:
         return mats
 
 
-def mlp_forward(x, weights_f16, spec):
-    """x [M, n_in] (fp32 or fp16) -> fp32 [M, out_cols] (fp16 operands, fp32 accumulate, output not rounded)."""
+def _rows(x):
+    """x as the kernels want it: fp16 / fp32, unit column stride; a row-strided view (columns of a wider, aligned
+    buffer) is passed as it is -- with 16-byte aligned rows the kernels load 8 halves per instruction."""
     if x.dtype not in (torch.float16, torch.float32):
         x = x.float()
-    x = x.contiguous()
+    if x.dim() != 2 or (x.shape[1] > 1 and x.stride(1) != 1) or x.stride(0) < x.shape[1]:
+        x = x.contiguous()
+    return x
+
+
+def mlp_forward(x, weights_f16, spec):
+    """x [M, n_in] (fp32 or fp16) -> fp32 [M, out_cols] (fp16 operands, fp32 accumulate, output not rounded)."""
+    x = _rows(x)
     M = x.shape[0]
     out = torch.empty(M, spec.out_cols, dtype=torch.float32, device=x.device)
-    _hip.call("nvsf_mlp_fwd", _hip.ptr(x), 1 if x.dtype == torch.float16 else 0, M, spec.n_in, x.stride(0), _hip.ptr(weights_f16),
+    _hip.call("nvsf_mlp_fwd", _hip.ptr_rows(x), 1 if x.dtype == torch.float16 else 0, M, spec.n_in, x.stride(0), _hip.ptr(weights_f16),
               spec.in_cols, spec.hidden, spec.n_hidden, spec.out_cols, _hip.ptr(out), out.stride(0))
     return out
 
@@ -164,19 +175,88 @@ def _weight_grad(g, a, rows_per_slice=4096):
 MLP_GRAD_SCALE = 128.0  # fp16 gradients inside nvsf_mlp_bwd are multiplied by this (tcnn's default loss_scale)
 
 
-def mlp_backward(x, weights_f16, spec, grad_out, need_grad_x=True, grad_scale=MLP_GRAD_SCALE):
-    """One fused kernel: (x, weights, dL/dout [M, n_out] fp32) -> dL/dx fp32 [M, n_in] (or None), dL/dW fp32 [n_params]."""
-    if x.dtype not in (torch.float16, torch.float32):
-        x = x.float()
-    x = x.contiguous()
-    grad_out = grad_out.float().contiguous()
+def mlp_backward(x, weights_f16, spec, grad_out, need_grad_x=True, grad_scale=MLP_GRAD_SCALE, grad_x=None, gx_col0=0,
+                 accumulate=False):
+    """One fused kernel: (x, weights, dL/dout [M, n_out] fp32) -> dL/dx fp32 [M, n_in] (or None), dL/dW fp32 [n_params].
+    With `grad_x` given (fp32, unit column stride) the input gradient of columns gx_col0.. is written (or added, with
+    `accumulate`) there: grad_x[:, j] = dL/dx[:, gx_col0 + j]."""
+    x = _rows(x)
+    grad_out = grad_out.float()
+    if grad_out.dim() != 2 or (grad_out.shape[1] > 1 and grad_out.stride(1) != 1):
+        grad_out = grad_out.contiguous()
     M = x.shape[0]
     grad_w = torch.zeros(spec.n_params, dtype=torch.float32, device=x.device)
-    grad_x = torch.empty(M, spec.n_in, dtype=torch.float32, device=x.device) if need_grad_x else None
-    _hip.call("nvsf_mlp_bwd", _hip.ptr(x), 1 if x.dtype == torch.float16 else 0, M, spec.n_in, x.stride(0), _hip.ptr(weights_f16),
-              spec.in_cols, spec.hidden, spec.n_hidden, spec.out_cols, _hip.ptr(grad_out), grad_out.shape[1], grad_out.stride(0),
-              float(grad_scale), _hip.ptr(grad_x), spec.n_in, _hip.ptr(grad_w))
+    if grad_x is None and need_grad_x:
+        grad_x = torch.empty(M, spec.n_in - gx_col0, dtype=torch.float32, device=x.device)
+    _hip.call("nvsf_mlp_bwd", _hip.ptr_rows(x), 1 if x.dtype == torch.float16 else 0, M, spec.n_in, x.stride(0), _hip.ptr(weights_f16),
+              spec.in_cols, spec.hidden, spec.n_hidden, spec.out_cols, _hip.ptr_rows(grad_out), grad_out.shape[1], grad_out.stride(0),
+              float(grad_scale), None if grad_x is None else _hip.ptr_rows(grad_x), 0 if grad_x is None else grad_x.stride(0),
+              _hip.ptr(grad_w), int(gx_col0), 1 if accumulate else 0)
     return grad_x, grad_w
+
+
+def heads(model, d01, geo_feat, cal_lidar_color):
+    """Logits of the per-sample heads of `model` (a NeRFNetwork / NeRFNetworkStatic): [M, 2] = [raydrop, intensity] for
+    LiDAR samples, [M, 3] colour logits otherwise.  d01: directions mapped to [0, 1]; geo_feat: [M, geo_feat_dim]."""
+    if cal_lidar_color:
+        net_a, net_b, enc = model.raydrop_net, model.intensity_net, model.view_encoder_lidar
+    else:
+        net_a, net_b, enc = model.color_net, None, model.view_encoder_camera
+    spec = net_a.spec
+    M = d01.shape[0]
+    buf = torch.empty(M, spec.in_cols, dtype=torch.float16, device=d01.device)
+    with torch.no_grad():
+        if enc.otype == "Frequency":
+            freq_encode(d01, enc.n_frequencies, out=buf)
+        else:
+            sh4_encode(d01, out=buf)
+    if net_b is None:
+        return HeadsFn.apply(buf, enc.n_output_dims, geo_feat, net_a.params, net_a.weights_f16(), spec)
+    return HeadsFn.apply(buf, enc.n_output_dims, geo_feat, net_a.params, net_a.weights_f16(), spec, net_b.params, net_b.weights_f16())
+
+
+class HeadsFn(Function):
+    """h = [MLP_a(u) | MLP_b(u)] for the per-sample heads (network_dynamic.py:297-330: colour, or ray-drop + intensity),
+    u = [direction encoding | geometry features | tcnn's ones padding].
+
+    `buf` is a caller-allocated fp16 [M, in_cols] buffer whose first n_enc columns already hold the direction encoding
+    (no parameters, no gradient); the geometry features are cast into the following columns here.  Rows are 16-byte
+    aligned, so both MLP kernels read 8 halves per load (the reference's torch.cat gives 87- / 31-column rows: element
+    loads), the heads share one input, and the backward produces only the gradient the graph needs -- the n_geo geometry
+    columns, summed over the heads inside the kernel -- instead of two [M, n_in] fp32 matrices that are sliced and added
+    afterwards."""
+
+    @staticmethod
+    def forward(ctx, buf, n_enc, geo, params_a, w16_a, spec, params_b=None, w16_b=None):
+        n_geo = geo.shape[1]
+        assert n_enc + n_geo == spec.n_in and buf.shape[1] >= spec.n_in and buf.dtype == torch.float16
+        buf[:, n_enc:n_enc + n_geo] = geo
+        u = buf[:, :spec.n_in]
+        outs = [mlp_forward(u, w16_a, spec)[:, :spec.n_out]]
+        if w16_b is not None:
+            outs.append(mlp_forward(u, w16_b, spec)[:, :spec.n_out])
+        ctx.save_for_backward(buf, w16_a, w16_b)
+        ctx.spec, ctx.n_enc, ctx.n_geo, ctx.geo_dtype = spec, n_enc, n_geo, geo.dtype
+        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=-1)
+
+    @staticmethod
+    def backward(ctx, grad_h):
+        buf, w16_a, w16_b = ctx.saved_tensors
+        spec, n_enc, n_geo = ctx.spec, ctx.n_enc, ctx.n_geo
+        u = buf[:, :spec.n_in]
+        grad_h = grad_h.float().contiguous()
+        M = buf.shape[0]
+        need_geo = ctx.needs_input_grad[2]
+        grad_geo = torch.empty(M, (n_geo + 3) // 4 * 4, dtype=torch.float32, device=buf.device)[:, :n_geo] if need_geo else None
+        _, gw_a = mlp_backward(u, w16_a, spec, grad_h[:, :spec.n_out], need_grad_x=need_geo, grad_x=grad_geo, gx_col0=n_enc)
+        gw_b = None
+        if w16_b is not None:
+            _, gw_b = mlp_backward(u, w16_b, spec, grad_h[:, spec.n_out:2 * spec.n_out], need_grad_x=need_geo, grad_x=grad_geo,
+                                   gx_col0=n_enc, accumulate=True)
+        if grad_geo is not None and grad_geo.dtype != ctx.geo_dtype:
+            grad_geo = grad_geo.to(ctx.geo_dtype)
+        return (None, None, grad_geo, gw_a if ctx.needs_input_grad[3] else None, None, None,
+                gw_b if (w16_b is not None and ctx.needs_input_grad[6]) else None, None)
 
 
 class MlpFn(Function):

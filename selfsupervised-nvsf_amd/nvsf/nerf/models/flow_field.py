@@ -1,13 +1,14 @@
 """Scene-flow field (`FlowField`) for MI355X: 3-D hash grid (L16 F8, HIP kernel) -> cubic Lagrange reduction over
 time -> bias-free MLP 32 -> 64 -> 64 -> 6 (forward and backward flow).  Same constructor, parameter names
 (`grid_enc.params`, `mlp.<i>.weight`) and arithmetic as /root/reference/nvsf/nerf/models/flow_field.py:41-133.
-The three small dense layers are plain GEMMs and go through torch (rocBLAS/hipBLASLt); their last layer is
-initialised N(0, 1e-3) as in the reference (:103)."""
+The three small dense layers are `nn.Linear` modules as in the reference (same state_dict keys; last layer
+initialised N(0, 1e-3), :103); with autograd they run through torch, without it on the fused MFMA MLP kernel."""
 import numpy as np
 import torch
 import torch.nn as nn
 
 import tinycudann as tcnn
+from nvsf import field_ops as ops
 from nvsf.nerf.models.hash_field import lagrange_reduce
 
 
@@ -52,4 +53,30 @@ class FlowField(nn.Module):
         red = torch.empty(M, 2 * spec.L, dtype=torch.float32, device=xt.device)
         _hip.call("nvsf_hashgrid3d_lagrange_fwd", _hip.ptr(xt), xt.shape[1], M, _hip.ptr(self.grid_enc.table_f16()), spec.L, spec.F,
                   spec.h_scales, spec.h_res, spec.h_offsets, _hip.host_f32(lagrange_weights_host(t_host, 4, xt.is_cuda)), _hip.ptr(red))
+        if self._fused_mlp_ok():
+            # NVSF_FLOW_MLP=fused (opt-in): the three bias-free layers on the fused MFMA MLP kernel -- fp16 operands, fp32
+            # accumulation, i.e. what the reference's Linear layers compute under the Trainer's autocast, 6x faster than
+            # the fp32 GEMM + ReLU launches, but only fp16-accurate (4e-5 abs on flows of 1e-2) where the CPU reference
+            # this repo is pinned against is fp32; the default therefore stays on torch.  Columns 6..15 are padding.
+            return ops.mlp_forward(red, self._mlp_weights_f16(), self._mlp_spec)[:, :6]
         return self.mlp(red)
+
+    def _fused_mlp_ok(self):
+        import os
+        lin = [m for m in self.mlp if isinstance(m, nn.Linear)]
+        return (os.environ.get("NVSF_FLOW_MLP", "torch") == "fused" and len(lin) == 3 and lin[0].in_features % 16 == 0
+                and lin[0].in_features <= 128 and lin[0].out_features == 64 and lin[1].out_features == 64 and lin[2].out_features <= 16)
+
+    def _mlp_weights_f16(self):
+        """fp16 copy of the Linear weights in the fused kernel's layout (W0 [64, in] ++ W1 [64, 64] ++ W2 zero-padded to
+        [16, 64], row-major = nn.Linear's [out, in]); rebuilt when a weight changes."""
+        lin = [m for m in self.mlp if isinstance(m, nn.Linear)]
+        key = tuple((l.weight.data_ptr(), l.weight._version) for l in lin)
+        if getattr(self, "_mlp_key", None) != key:
+            w2 = torch.zeros(16, 64, dtype=torch.float32, device=lin[2].weight.device)
+            w2[:lin[2].out_features] = lin[2].weight.detach().float()
+            self._mlp_w16 = torch.cat([lin[0].weight.detach().float().reshape(-1), lin[1].weight.detach().float().reshape(-1),
+                                       w2.reshape(-1)]).to(torch.float16).contiguous()
+            self._mlp_spec = ops.MlpSpec(lin[0].in_features, lin[2].out_features, hidden=64, n_hidden=2)
+            self._mlp_key = key
+        return self._mlp_w16

@@ -71,13 +71,10 @@ class NeRFNetworkStatic(NeRFRenderer):
             else:
                 rgbs = torch.zeros(mask.shape[0], self.out_dim, dtype=x.dtype, device=x.device)
                 d, geo_feat = d[mask], geo_feat[mask]
-        d = (d + 1) / 2
-        if cal_lidar_color:
-            logits = torch.cat([self.view_encoder_lidar(d), geo_feat], dim=-1)
-            h = torch.cat([self.raydrop_net(logits), self.intensity_net(logits)], dim=-1)
-        else:
-            h = self.color_net(torch.cat([self.view_encoder_camera(d), geo_feat], dim=-1))
-        h = torch.sigmoid(h)
+        d = (d + 1) / 2  # the direction encoders expect [0, 1]
+        # [direction encoding | geo_feat] assembled once in an aligned fp16 buffer shared by the heads (ops.HeadsFn); same
+        # values as the reference's torch.cat + tcnn calls (network_dynamic.py:310-325), LiDAR order [raydrop, intensity]
+        h = torch.sigmoid(ops.heads(self, d, geo_feat, cal_lidar_color))
         if dense_mask is not None:
             return (h * dense_mask.unsqueeze(-1)).to(x.dtype)
         if mask is None:

@@ -75,6 +75,15 @@ def test_hashgrid4d_and_flow(dev):
     out = flow(_t(g["flow_xt"], dev))
     torch.set_grad_enabled(True)
     np.testing.assert_allclose(out.cpu().numpy(), g["flow"], atol=1e-5, rtol=1e-4)
+    # opt-in fp16 MFMA form of the flow MLP (what autocast computes in the reference's Trainer): fp16-level agreement
+    os.environ["NVSF_FLOW_MLP"] = "fused"
+    try:
+        with torch.no_grad():
+            out16 = flow(_t(g["flow_xt"], dev))
+    finally:
+        del os.environ["NVSF_FLOW_MLP"]
+    assert out16.shape == out.shape
+    np.testing.assert_allclose(out16.cpu().numpy(), g["flow"], atol=1e-4, rtol=1e-2)
 
 
 @pytest.fixture(scope="module")

@@ -12,6 +12,6 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
     acc[r["Kernel_Name"][:70]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in acc.items():
-    if "march" in k or "composite" in k or os.environ.get("ALLK"):
+    if "march" in k or "composite" in k or (os.environ.get("ALLK") and (os.environ["ALLK"] == "1" or os.environ["ALLK"] in k)):
         print(k, {c: (round(sum(v) / len(v)), len(v)) for c, v in d.items()})
 PY
