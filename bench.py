@@ -18,6 +18,7 @@ One JSON line on stdout (rank 0): metric / value / ... plus
   kernels       the same figures for every launch of the step
   occupancy / dynamic / train   secondary legs (BASELINE configs 3, 5, 4), never `value`
   raymarching   the raymarching-extension kernels (rows a1-a9) against the HBM roofline at non-latency-bound sizes
+  field_ops     the stand-alone field operators (rows a12-a17) against their rooflines on the config-2 sample batches
   cpu_baseline  the CPU oracle (oracle/, scalar C port, 1 thread) on a bounded sample of the same workload
 """
 import argparse
@@ -283,6 +284,17 @@ def raymarching_leg(dev):
     return {"note": "algorithmic bytes (SURVEY 8d) / HIP-event time, HBM peak 8000 GB/s", "kernels": rows}
 
 
+def field_ops_leg(dev, n_rays, T):
+    """Secondary figure: the stand-alone field operators (SURVEY 8a rows a12-a17 -- the tiny-cuda-nn surface, K-planes,
+    the space-time grids) against their rooflines on the config-2 sample batches (tools/bench_field_ops.py).  These are
+    the launches of the training path and of the dynamic model; the fused render kernels above replace them for the
+    static no-grad render."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bench_field_ops import field_op_rooflines
+    return {"note": "algorithmic bytes / flops per sample (SURVEY 8d) / HIP-event time; peaks 8000 GB/s, 2500 TFLOP/s",
+            "kernels": field_op_rooflines(dev, n_rays, T)}
+
+
 def dynamic_leg(dev, n_rays, T, steps):
     """Secondary figure (BASELINE config 5): the reference-default space-time field (K-planes + static / dynamic hash grids
     + flow field, 93.6 M parameters, time_resolution 8), forward render of n_rays LiDAR + n_rays camera rays."""
@@ -412,6 +424,7 @@ def main():
             line["occupancy"] = occupancy_leg(NeRFNetworkStatic, dev, args.num_rays, 10)
             line["dynamic"] = dynamic_leg(dev, args.num_rays, T, 3)
             line["raymarching"] = raymarching_leg(dev)
+            line["field_ops"] = field_ops_leg(dev, args.num_rays, T)
     if args.train_steps > 0:
         tr = train_leg(model, tl, tc, tm, T, args.train_steps, dev, dist)
         if rank == 0:
