@@ -198,6 +198,85 @@ __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_runs(const float* __res
     if (have) flush();
 }
 
+// Table gradient, corner-parallel run merging.  The atomic adds are what bounds this pass once the gradients are dense
+// (805 M fp32 adds per 3.1 M-sample batch at L16 F2), and MI355X executes float atomics at the memory side at a cost
+// per wave-instruction and 64-B segment (MI355X_MICROARCH.md, Global float atomics): a lane that walks the 2^D x F
+// floats of a cell one after the other -- k_hashgrid_bwd_runs -- makes 2^D x F instructions whose 64 lanes sit in 64
+// unrelated rows, the slowest shape there is.  Here the 2^D x F floats of one (chunk of rows, level) item are spread over
+// G = 2^D x F adjacent lanes (lane = corner x F + feature), 64 / G items (consecutive levels of one chunk) per wave:
+// every lane keeps ONE running sum, the cell changes for all lanes of an item at once, and a flush is ONE atomic
+// instruction whose lanes cover whole table entries (F contiguous floats; the two x-neighbours of a corner pair are
+// adjacent entries on dense levels and for even cells on hashed ones).  Same sums as the other two kernels up to the
+// order of the fp32 additions.
+template <int D, int F, bool GRAD_F16>
+__global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_corners(const float* __restrict__ x, uint32_t M, uint32_t x_stride, uint32_t c0,
+                                                                 uint32_t c1, uint32_t c2, uint32_t L, GridMeta meta,
+                                                                 const void* __restrict__ grad_out, uint32_t go_stride,
+                                                                 float* __restrict__ grad_table, uint32_t run) {
+    constexpr int G = (1 << D) * F;  // lanes per item
+    constexpr int IPW = kWave / G;   // items per wave
+    static_assert(G <= kWave && kWave % G == 0, "2^D x F must divide the wave");
+    const int lane = lane_id();
+    const int sub = lane / G, r = lane - sub * G, c = r / F, f = r - c * F;
+    const unsigned long long item = ((unsigned long long)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) * IPW + (unsigned)sub;
+    const uint32_t chunk = (uint32_t)(item / L), l = (uint32_t)(item - (unsigned long long)chunk * L);
+    const unsigned long long first = (unsigned long long)chunk * run;
+    if (first >= M) return;
+    const uint32_t m0 = (uint32_t)first, m1 = (uint32_t)(first + run < M ? first + run : M);
+    const float scale = meta.scale[l];
+    const uint32_t res = meta.res[l], row0 = meta.offset[l], hsize = meta.offset[l + 1] - row0;
+    float acc = 0.0f;
+    uint32_t cur[D];
+    bool have = false;
+#pragma unroll
+    for (int d = 0; d < D; ++d) cur[d] = 0u;
+    float* dst = grad_table;
+    auto load_row = [&](uint32_t m, float (&xs)[D], float& g) {
+        const float* px = x + (size_t)m * x_stride;
+        xs[0] = px[c0];
+        xs[1] = px[c1];
+        if constexpr (D == 3) xs[2] = px[c2];
+        if constexpr (GRAD_F16) g = (float)reinterpret_cast<const _Float16*>(grad_out)[(size_t)m * go_stride + l * F + f];
+        else g = reinterpret_cast<const float*>(grad_out)[(size_t)m * go_stride + l * F + f];
+    };
+    float xs_n[D], g_n;
+    load_row(m0, xs_n, g_n);
+    for (uint32_t m = m0; m < m1; ++m) {
+        float xs[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) xs[d] = xs_n[d];
+        const float g = g_n;
+        if (m + 1 < m1) load_row(m + 1, xs_n, g_n);  // next row in flight while this one is processed
+        if (g == 0.0f) continue;                     // this lane's feature has nothing to add (its sum keeps its cell)
+        float w = 1.0f;
+        uint32_t cell[D];
+        bool same = have;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const float pos = fmaf(scale, xs[d], 0.5f);
+            const float fl = floorf(pos);
+            const float frac = pos - fl;
+            cell[d] = (uint32_t)(int32_t)fl;
+            same = same && (cell[d] == cur[d]);
+            w = w * ((c & (1 << d)) ? frac : (1.0f - frac));
+        }
+        if (!same) {
+            if (acc != 0.0f) atomicAdd(dst, acc);
+            acc = 0.0f;
+            have = true;
+            uint32_t cc[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                cur[d] = cell[d];
+                cc[d] = cell[d] + ((c >> d) & 1u);
+            }
+            dst = grad_table + ((size_t)row0 + grid_row<D>(cc, res, hsize)) * F + f;
+        }
+        acc += w * g;
+    }
+    if (acc != 0.0f) atomicAdd(dst, acc);
+}
+
 int fill_meta(GridMeta& meta, uint32_t L, const float* scales, const uint32_t* res, const uint32_t* offsets) {
     if (L == 0 || L > (uint32_t)kMaxLevels || !scales || !res || !offsets) return NVSF_ERR_INVALID_ARG;
     for (uint32_t l = 0; l < L; ++l) {
@@ -256,7 +335,26 @@ NVSF_API int nvsf_hashgrid_bwd(const float* x, uint32_t M, uint32_t x_stride, co
     const int st = fill_meta(meta, L, h_scales, h_res, h_offsets);
     if (st != NVSF_OK) return st;
     const uint32_t c0 = cols[0], c1 = cols[1], c2 = D == 3 ? cols[2] : 0;
-    const char* variant = getenv("NVSF_HASHGRID_BWD");  // "atomic": one thread per (row, level), no run merging (A/B timing)
+    const char* variant = getenv("NVSF_HASHGRID_BWD");  // "atomic": one thread per (row, level); "runs": one thread per (chunk, level) (A/B timing, tests)
+    if (!(variant && (variant[0] == 'a' || variant[0] == 'r')) && L % (kWave / ((1u << D) * F)) == 0) {
+        const char* run_env = getenv("NVSF_HASHGRID_BWD_RUN");
+        const uint32_t run = run_env ? (uint32_t)atoi(run_env) : (M >= (1u << 20) ? 128u : 32u);
+        const uint32_t ipw = kWave / ((1u << D) * F);
+        const unsigned long long waves = ((unsigned long long)cdiv(M, run) * L + ipw - 1) / ipw;
+        const dim3 cgrid((uint32_t)((waves + kBlock / kWave - 1) / (kBlock / kWave)));
+#define CALLC(DD, FF)                                                                                                                \
+    do {                                                                                                                             \
+        if (grad_is_f16)                                                                                                             \
+            hipLaunchKernelGGL((k_hashgrid_bwd_corners<DD, FF, true>), cgrid, dim3(kBlock), 0, stream, x, M, x_stride, c0, c1, c2, L, meta, \
+                               grad_out, go_stride, grad_table_f32, run);                                                            \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((k_hashgrid_bwd_corners<DD, FF, false>), cgrid, dim3(kBlock), 0, stream, x, M, x_stride, c0, c1, c2, L, meta, \
+                               grad_out, go_stride, grad_table_f32, run);                                                            \
+    } while (0)
+        DISPATCH_DF(D, F, CALLC);
+#undef CALLC
+        return nvsf_launch_status();
+    }
     if (!(variant && variant[0] == 'a')) {
         const char* run_env = getenv("NVSF_HASHGRID_BWD_RUN");
         const uint32_t run = run_env ? (uint32_t)atoi(run_env) : (M >= (1u << 20) ? 128u : 32u);

@@ -6,7 +6,7 @@ Only what sits directly around the hot path, restated from the reference:
     0.01), MSE intensity on returned rays (weight 0.1), MSE RGB, optional URF line-of-sight loss on
     (weights, z_vals);
   * optimiser: Adam(betas 0.9/0.99, eps 1e-15) on `model.get_params(lr)` and the 0.1^(iter/iters) decay
-    (main_nvsf.py:350-362);
+    (main_nvsf.py:350-362), under the GradScaler of the reference's fp16 run (trainer.py:119, 1332-1334);
   * PSNR (nvsf/lib/error_matrices.py:48-57) and depth RMSE in metres (error_matrices.py:263-285).
 Across GPUs the step is frame-sharded: every rank renders its own frame, then ONE bucketed gradient all-reduce
 (nvsf/frame_shard.py).  The reference's Trainer (logging, EMA, checkpoints, UNet refinement, error maps, chamfer and
@@ -39,8 +39,13 @@ def urf_line_of_sight_loss(weights, z_vals, gt_depth, eps):
 
 class RenderTrainStep:
     def __init__(self, model, lr=1e-2, iters=30000, num_steps=768, alpha_d=1.0, alpha_r=0.01, alpha_i=0.1, alpha_rgb=1.0,
-                 smooth_factor=0.2, use_urf_loss=False, bucket_bytes=64 << 20):
+                 smooth_factor=0.2, use_urf_loss=False, bucket_bytes=64 << 20, fp16=True):
         self.model = model
+        # loss scaling of the reference's mixed-precision run (trainer.py:119, 1332-1334: GradScaler(enabled=fp16) -> scale(loss)
+        # .backward() -> step -> update; `-L` / `--fp16` in main_nvsf.py:17,43,159).  The encoders hand fp16 features to the
+        # MLPs, so the gradients that travel back between them are fp16 tensors: unscaled, those of a mean-over-rays loss sit
+        # below the fp16 subnormal range and the hash tables receive zeros.
+        self.scaler = torch.amp.GradScaler("cuda", enabled=bool(fp16) and torch.cuda.is_available())
         self.opt = torch.optim.Adam(model.get_params(lr), betas=(0.9, 0.99), eps=1e-15)
         self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, lambda it: 0.1 ** min(it / iters, 1))
         self.iters, self.num_steps = iters, num_steps
@@ -77,9 +82,12 @@ class RenderTrainStep:
         self.model.train()
         self.opt.zero_grad(set_to_none=True)
         loss, parts = self.losses(batch)
-        loss.backward()
+        self.scaler.scale(loss).backward()
+        # the all-reduce is linear: it runs on the scaled gradients (an inf / nan on one rank reaches every rank, so all of
+        # them skip the step together); scaler.step unscales, checks and steps
         n_coll = frame_shard.allreduce_gradients([p for g in self.opt.param_groups for p in g["params"]], self.bucket_bytes)
-        self.opt.step()
+        self.scaler.step(self.opt)
+        self.scaler.update()
         self.sched.step()
         self.global_step += 1
         return loss.detach(), {k: v.detach() for k, v in parts.items()}, n_coll

@@ -81,6 +81,34 @@ def test_hashgrid_backward(ops, dev):
     np.testing.assert_allclose(got16, ref16, atol=2e-4, rtol=1e-4)
 
 
+@pytest.mark.parametrize("D,L,F,log2_T,base,top", [(3, 16, 2, 14, 16, 512), (3, 8, 4, 12, 16, 256), (3, 16, 8, 12, 32, 2048), (2, 8, 4, 10, 16, 256)])
+@pytest.mark.parametrize("variant", ["corners", "runs", "atomic"])
+def test_hashgrid_backward_kernels_agree_with_the_oracle(ops, dev, D, L, F, log2_T, base, top, variant, monkeypatch):
+    """The three formulations of the table gradient (corner-parallel run merging = default, one thread per (chunk, level),
+    one thread per (row, level)) on ray-ordered rows -- long runs inside one cell at the coarse levels, a new cell per row
+    at the fine ones -- with zero-gradient rows and zero features mixed in, fp32 and fp16 gradients."""
+    if variant != "corners":
+        monkeypatch.setenv("NVSF_HASHGRID_BWD", variant)
+    monkeypatch.setenv("NVSF_HASHGRID_BWD_RUN", "32")
+    spec = _spec(ops, D, L, F, log2_T, base, top)
+    rng = np.random.default_rng(D * 100 + L + F)
+    n_rays, T = 37, 97  # M is not a multiple of the chunk length
+    o = rng.random((n_rays, 1, 3)) * 0.5 + 0.1
+    d = rng.standard_normal((n_rays, 1, 3))
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    t = np.linspace(0.0, 0.35, T).reshape(1, T, 1)
+    x = np.clip(o + d * t, 0.0, 1.0).reshape(-1, 3).astype(np.float32)
+    M = x.shape[0]
+    go = rng.standard_normal((M, L * F)).astype(np.float32)
+    go[rng.random(M) < 0.3] = 0.0                 # rows without gradient
+    go[rng.random((M, L * F)) < 0.2] = 0.0         # single features without gradient
+    cols = (0, 1, 2)[:D]
+    for g_in in (go, go.astype(np.float16)):
+        ref = O.hashgrid_bwd(x, cols, spec, g_in.astype(np.float32))
+        got = ops.hashgrid_backward(_t(x, dev), cols, spec, _t(g_in, dev)).cpu().numpy()
+        np.testing.assert_allclose(got, ref, atol=5e-4, rtol=1e-4)  # fp32 atomics: order-dependent rounding
+
+
 def test_hashgrid_autograd_module(dev):
     import tinycudann as tcnn
     enc = tcnn.Encoding(3, {"otype": "HashGrid", "n_levels": 4, "n_features_per_level": 2, "log2_hashmap_size": 12,
