@@ -221,8 +221,8 @@ def train_leg(model, tl, tc, tm, T, steps, dev, dist):
         dt = float(t.item())
     model.eval()
     return {"metric": "trained rays/sec (LiDAR+cam, fwd+bwd+Adam)", "value": (n_l + n_c) * world * steps / dt, "ms_per_step": dt / steps * 1e3,
-            "steps": steps, "allreduce_collectives_per_step": n_coll, "path": "operator path (autograd): HIP forward kernels; HIP backward for hash grid (run-merging atomics), MLPs (fused data + weight "
-                    "gradients, nvsf_mlp_bwd) and compositors"}
+            "steps": steps, "allreduce_collectives_per_step": n_coll, "path": "operator path (autograd) under GradScaler (dense fp16 feature gradients): HIP forward kernels; HIP backward for hash grid "
+                    "(corner-parallel run-merging atomics), MLPs (fused data + weight gradients, shared aligned head input) and compositors"}
 
 
 def occupancy_leg(model_cls, dev, n_rays, steps):
