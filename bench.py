@@ -296,8 +296,10 @@ def field_ops_leg(dev, n_rays, T):
 
 
 def dynamic_leg(dev, n_rays, T, steps):
-    """Secondary figure (BASELINE config 5): the reference-default space-time field (K-planes + static / dynamic hash grids
-    + flow field, 93.6 M parameters, time_resolution 8), forward render of n_rays LiDAR + n_rays camera rays."""
+    """Secondary figure (BASELINE config 5: "dynamic 4D field, fp16 MFMA path"): the reference-default space-time field
+    (K-planes + static / dynamic hash grids + flow field, 93.6 M parameters, time_resolution 8), forward render of n_rays
+    LiDAR + n_rays camera rays.  The flow MLP runs on the fused fp16 MFMA kernel (NVSF_FLOW_MLP=fused: what the reference's
+    Linear layers compute under autocast; the fp32 torch form, which the CPU fixtures pin, is reported beside it)."""
     from nvsf import synthetic as S
     from nvsf.nerf.models.network_dynamic import NeRFNetwork
     torch.manual_seed(0)
@@ -314,15 +316,27 @@ def dynamic_leg(dev, n_rays, T, steps):
         with torch.no_grad():
             m.render(tl[0], tl[1], tm, cal_lidar_color=True, num_steps=T)
             m.render(tc[0], tc[1], tm, cal_lidar_color=False, num_steps=T)
-    for _ in range(2):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    def timed(flow_mlp):
+        prev = os.environ.get("NVSF_FLOW_MLP")
+        os.environ["NVSF_FLOW_MLP"] = flow_mlp
+        try:
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / steps
+        finally:
+            if prev is None:
+                del os.environ["NVSF_FLOW_MLP"]
+            else:
+                os.environ["NVSF_FLOW_MLP"] = prev
+    dt = timed("fused")
+    dt32 = timed("torch")
     return {"metric": "rendered rays/sec (LiDAR+cam), dynamic 4-D field", "value": 2 * n_rays / dt, "ms_per_step": dt * 1e3,
+            "flow_mlp": "fp16 MFMA (fused kernel)", "fp32_flow_mlp": {"value": 2 * n_rays / dt32, "ms_per_step": dt32 * 1e3},
             "num_rays": n_rays, "num_rays_lidar": n_rays, "num_steps": T, "parameters_M": sum(p.numel() for p in m.parameters()) / 1e6,
             "peak_mem_GiB": torch.cuda.max_memory_allocated() / 2 ** 30}
 

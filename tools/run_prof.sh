@@ -16,9 +16,14 @@ B="python3 $R/bench.py --cpu-rays 0 --no-kernel-breakdown --no-extra-legs --trai
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- $B --steps 20 --warmup 5 > $O/kt.log 2>&1
 timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pf -- $B --steps 3 --warmup 1 > $O/pf.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pw -- $B --steps 3 --warmup 1 > $O/pw.log 2>&1
+# 5b. MFMA pipe occupancy of the render kernels (SQ counters only, their own pass)
+timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_F16 --output-format csv -d $O/pm -- python3 $R/bench.py --cpu-rays 0 --no-extra-legs --train-steps 0 --steps 5 --warmup 1 > $O/pm.log 2>&1
 # 6. kernel traces of the secondary legs
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_train -- python3 $R/tools/bench_train.py > $O/kt_train.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_occ -- python3 $R/tools/bench_occupancy.py > $O/kt_occ.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_dyn -- python3 $R/tools/bench_dynamic.py > $O/kt_dyn.log 2>&1
+# 7. roofline tools of the extension kernels and the stand-alone operators
+timeout 600 python3 $R/tools/bench_raymarching.py > $O/raymarching.json 2> $O/raymarching.log
+timeout 600 python3 $R/tools/bench_field_ops.py > $O/field_ops.json 2> $O/field_ops.log
 find $O -name '*_kernel_stats.csv' -o -name '*_counter_collection.csv'
 tail -c 300 $O/bench2.log
