@@ -155,13 +155,16 @@ def pmc_traffic(kernel_label):
     ks = json.load(open(files[-1]))["kernels"]
     which = "camera" if "camera" in kernel_label else "lidar"
     src = os.path.relpath(files[-1], ROOT) + " (2*FETCH_SIZE + WRITE_SIZE, bytes per launch)"
-    if kernel_label.startswith("density_encode_sliced") and "encode_sliced" in ks:  # launched for one batch kind only
-        k = ks["encode_sliced"]
-        return {"traffic": (2.0 * k["fetch_kb_mean"] + k["write_kb_mean"]) * 1024.0, "traffic_source": src}
-    k = ks.get("density_uniform_v2")
-    if kernel_label.startswith("density_uniform") and k:
-        f, w = k.get(f"fetch_kb_{which}", k["fetch_kb_mean"]), k.get(f"write_kb_{which}", k["write_kb_mean"])
-        return {"traffic": (2.0 * f + w) * 1024.0, "traffic_source": src}
+    base = kernel_label.split("[")[0]
+    names = {"density_encode_sliced": ["encode_sliced"], "render_uniform": [f"render_uniform<{which}>"],
+             "render_uniform_tail": [f"render_uniform_tail<{which}>"], "density_uniform": ["density_uniform_v2", "density_uniform"],
+             "density_from_features": ["density_from_features"], "heads_uniform": [f"heads_uniform<{which}>"],
+             "composite_weights": ["k_weights_fwd"]}.get(base, [])
+    for name in names:
+        k = ks.get(name)
+        if k:
+            f, w = k.get(f"fetch_kb_{which}", k["fetch_kb_mean"]), k.get(f"write_kb_{which}", k["write_kb_mean"])
+            return {"traffic": (2.0 * f + w) * 1024.0, "traffic_source": src}
     return {"traffic": None}
 
 
