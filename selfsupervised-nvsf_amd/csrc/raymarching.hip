@@ -314,6 +314,62 @@ __global__ __launch_bounds__(kBlock) void k_march_rays(uint32_t n_alive, uint32_
     }
 }
 
+// n_step == 8: the samples of a ray are collected in registers and leave as whole records (xyz / dirs 96 B, deltas 64 B
+// per ray, 16-byte stores).  With one 12-byte store per step the 128-B lines of a ray's records are completed over the
+// ~10 us of its march while 134 MB of such lines are in flight -- more than the L2s hold -- and reach HBM in pieces.
+__global__ __launch_bounds__(kBlock) void k_march_rays8(uint32_t n_alive, const int* __restrict__ rays_alive,
+                                                        const float* __restrict__ rays_t, const float* __restrict__ rays_o,
+                                                        const float* __restrict__ rays_d, float bound, float dt_gamma,
+                                                        uint32_t max_steps, uint32_t C, uint32_t H,
+                                                        const uint8_t* __restrict__ grid, const float* __restrict__ fars,
+                                                        float* __restrict__ xyzs, float* __restrict__ dirs,
+                                                        float* __restrict__ deltas, const float* __restrict__ noises) {
+    const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
+    if (n >= n_alive) return;
+    const int index = rays_alive[n];
+    Marcher m;
+    m.init(rays_o + 3 * (size_t)index, rays_d + 3 * (size_t)index, grid, bound, dt_gamma, max_steps, C, H);
+    const float far = fars[index];
+    float t = rays_t[index];
+    t += m.step_len(t) * noises[n];
+    float last_t = t;
+    float rec[8][5];  // x, y, z, dt, t_new - last_t; unfilled slots stay zero (they signal termination to composite_rays)
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) rec[k][i] = 0.0f;
+    uint32_t step = 0;
+    float x, y, z, dt;
+    while (t < far && step < 8u) {
+        if (m.probe(t, x, y, z, dt)) {
+            t += dt;
+            const float d1 = t - last_t;
+            last_t = t;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (step == (uint32_t)k) { rec[k][0] = x; rec[k][1] = y; rec[k][2] = z; rec[k][3] = dt; rec[k][4] = d1; }
+            ++step;
+        }
+    }
+    float4* px = reinterpret_cast<float4*>(xyzs + 24 * (size_t)n);
+    float4* pd = reinterpret_cast<float4*>(dirs + 24 * (size_t)n);
+    float4* pl = reinterpret_cast<float4*>(deltas + 16 * (size_t)n);
+    float fx[24], fd[24];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        fx[3 * k] = rec[k][0]; fx[3 * k + 1] = rec[k][1]; fx[3 * k + 2] = rec[k][2];
+        const bool filled = (uint32_t)k < step;
+        fd[3 * k] = filled ? m.dx : 0.0f; fd[3 * k + 1] = filled ? m.dy : 0.0f; fd[3 * k + 2] = filled ? m.dz : 0.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        px[q] = make_float4(fx[4 * q], fx[4 * q + 1], fx[4 * q + 2], fx[4 * q + 3]);
+        pd[q] = make_float4(fd[4 * q], fd[4 * q + 1], fd[4 * q + 2], fd[4 * q + 3]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pl[q] = make_float4(rec[2 * q][3], rec[2 * q][4], rec[2 * q + 1][3], rec[2 * q + 1][4]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Packed-sample compositor, one wave per ray.  Lanes take 64 consecutive samples per round; the
 // transmittance is a cross-lane exclusive product scan carried between rounds.
@@ -453,6 +509,53 @@ __global__ __launch_bounds__(kBlock) void k_composite_rays(uint32_t n_alive, uin
     image[3 * (size_t)index] = r; image[3 * (size_t)index + 1] = g; image[3 * (size_t)index + 2] = b;
 }
 
+// The same accumulation with EIGHT lanes per ray (n_step <= 8): lane j of a group loads slot j of its ray, so the loads of
+// a wave are contiguous (sigma 4 B, rgb 12 B, deltas 8 B per lane) instead of 64 lanes striding over 8-slot records; the
+// serial recurrence then runs on values broadcast inside the group (every lane of a group carries the same state, lane 0
+// stores it).  Same operations in the same order as k_composite_rays: identical results.
+__global__ __launch_bounds__(kBlock) void k_composite_rays_g8(uint32_t n_alive, uint32_t n_step, float T_thresh,
+                                                              int* __restrict__ rays_alive, float* __restrict__ rays_t,
+                                                              const float* __restrict__ sigmas, const float* __restrict__ rgbs,
+                                                              const float* __restrict__ deltas, float* __restrict__ weights_sum,
+                                                              float* __restrict__ depth, float* __restrict__ image) {
+    const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t n = tid >> 3, j = tid & 7u;
+    const bool ray_ok = n < n_alive;
+    const uint32_t nn = ray_ok ? n : n_alive - 1;
+    const bool has = ray_ok && j < n_step;
+    const size_t slot = (size_t)nn * n_step + (has ? j : 0u);
+    const float sg = has ? sigmas[slot] : 0.0f;
+    const float d0 = has ? deltas[2 * slot] : 0.0f, d1 = has ? deltas[2 * slot + 1] : 0.0f;
+    const float c0 = has ? rgbs[3 * slot] : 0.0f, c1 = has ? rgbs[3 * slot + 1] : 0.0f, c2 = has ? rgbs[3 * slot + 2] : 0.0f;
+    const int index = rays_alive[nn];
+    float t = rays_t[index], ws = weights_sum[index], d = depth[index];
+    float r = image[3 * (size_t)index], g = image[3 * (size_t)index + 1], b = image[3 * (size_t)index + 2];
+    uint32_t step = 0;
+    bool stopped = false;
+    for (uint32_t k = 0; k < 8u; ++k) {  // uniform trip count: the shuffles need every lane
+        const float sk = __shfl(sg, (int)k, 8), dk0 = __shfl(d0, (int)k, 8), dk1 = __shfl(d1, (int)k, 8);
+        const float ck0 = __shfl(c0, (int)k, 8), ck1 = __shfl(c1, (int)k, 8), ck2 = __shfl(c2, (int)k, 8);
+        if (stopped || k >= n_step) continue;
+        if (dk0 == 0.0f) { stopped = true; continue; }
+        const float alpha = 1.0f - expf(-sk * dk0);
+        const float T = 1.0f - ws;
+        const float w = alpha * T;
+        ws += w;
+        t += dk1;
+        d += w * t;
+        r += w * ck0; g += w * ck1; b += w * ck2;
+        if (T < T_thresh) { stopped = true; continue; }
+        ++step;
+    }
+    if (ray_ok && j == 0u) {
+        if (step < n_step) rays_alive[n] = -1;
+        else rays_t[index] = t;
+        weights_sum[index] = ws;
+        depth[index] = d;
+        image[3 * (size_t)index] = r; image[3 * (size_t)index + 1] = g; image[3 * (size_t)index + 2] = b;
+    }
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -553,6 +656,12 @@ NVSF_API int nvsf_march_rays(uint32_t n_alive, uint32_t n_step, const int32_t* r
     if (n_alive == 0 || n_step == 0) return NVSF_OK;
     REQUIRE(rays_alive && rays_t && rays_o && rays_d && grid && nears && fars && xyzs && dirs && deltas && noises);
     REQUIRE(C >= 1 && C <= 8 && H >= 2 && H <= 1024 && max_steps >= 1);
+    if (n_step == 8u && (reinterpret_cast<uintptr_t>(xyzs) & 15u) == 0 && (reinterpret_cast<uintptr_t>(dirs) & 15u) == 0 &&
+        (reinterpret_cast<uintptr_t>(deltas) & 15u) == 0) {
+        hipLaunchKernelGGL(k_march_rays8, dim3(cdiv(n_alive, kBlock)), dim3(kBlock), 0, stream, n_alive, rays_alive, rays_t, rays_o, rays_d,
+                           bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas, noises);
+        return nvsf_launch_status();
+    }
     hipLaunchKernelGGL(k_march_rays, dim3(cdiv(n_alive, kBlock)), dim3(kBlock), 0, stream, n_alive, n_step, rays_alive, rays_t,
                        rays_o, rays_d, bound, dt_gamma, max_steps, C, H, grid, fars, xyzs, dirs, deltas, noises);
     return nvsf_launch_status();
@@ -564,7 +673,11 @@ NVSF_API int nvsf_composite_rays(uint32_t n_alive, uint32_t n_step, float T_thre
     if (n_alive == 0) return NVSF_OK;
     REQUIRE(rays_alive && rays_t && weights_sum && depth && image);
     REQUIRE(n_step == 0 || (sigmas && rgbs && deltas));
-    hipLaunchKernelGGL(k_composite_rays, dim3(cdiv(n_alive, kBlock)), dim3(kBlock), 0, stream, n_alive, n_step, T_thresh,
-                       rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image);
+    if (n_step <= 8u && n_alive <= (1u << 28))
+        hipLaunchKernelGGL(k_composite_rays_g8, dim3(cdiv((unsigned long long)n_alive * 8u, kBlock)), dim3(kBlock), 0, stream, n_alive, n_step,
+                           T_thresh, rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image);
+    else
+        hipLaunchKernelGGL(k_composite_rays, dim3(cdiv(n_alive, kBlock)), dim3(kBlock), 0, stream, n_alive, n_step, T_thresh,
+                           rays_alive, rays_t, sigmas, rgbs, deltas, weights_sum, depth, image);
     return nvsf_launch_status();
 }

@@ -223,9 +223,10 @@ def test_composite_rays_train_backward(rm, dev, scene):
     np.testing.assert_allclose(tc.grad.cpu().numpy(), gc_r, atol=1e-5, rtol=1e-4)
 
 
-def test_inference_march_and_composite_loop(rm, dev, scene):
+@pytest.mark.parametrize("n_step", [4, 8, 3, 1])  # 8: the record-store march kernel; <= 8: eight lanes per ray in composite_rays
+def test_inference_march_and_composite_loop(rm, dev, scene, n_step):
     """The n_alive loop of the reference's docstrings (raymarching.py:389-409, 480-493), against the oracle."""
-    n, n_step, max_steps = 1500, 4, 256
+    n, max_steps = 1500, 256
     o, d = _rays(n, 13)
     aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
     nears, fars = O.near_far_from_aabb(o, d, aabb, 0.02)

@@ -142,7 +142,7 @@ def raymarching_rooflines(dev, n_rays_march=32768, occupied=1.0, seed=0):
     def comp():
         reset()
         _hip.call("nvsf_composite_rays", N, n_step, 1e-2, P(alive2), P(t2), P(sigmas), P(rgbs), P(deltas), P(ws), P(depth), P(image))
-    ms = _time_ms(comp, 5) - _time_ms(reset, 5)
+    ms = max(_time_ms(comp, 5) - _time_ms(reset, 5), 1e-4)
     rows.append(_row("composite_rays[n_step 8]", ms, 24 * M + 48 * N, "24 B/sample + 48 B/ray", M))
     return rows
 
