@@ -10,6 +10,7 @@
 // The whole table (2.2 M parameters = 8.7 MB) lives in L2 / Infinity Cache; one thread = one (sample, scale).
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 constexpr int kBlock = 256;
@@ -169,6 +170,76 @@ __global__ __launch_bounds__(kBlock) void k_planes_bwd(const float* __restrict__
     if (g_xt) reinterpret_cast<float4*>(g_xt)[m] = make_float4(gp[0], gp[1], gp[2], gp[3]);
 }
 
+// Plane gradients with run merging (the form nvsf_planes_bwd launches; k_planes_bwd above then only produces grad_xt).
+// One atomic per (sample, texel, channel) is 1.2 G adds per 1.6 M samples into tables of 8 K - 0.5 M floats, and the time
+// planes receive all of them in the two rows around the frame's t: float atomics execute at the memory side and many
+// adders on one row are the slowest case (MI355X_MICROARCH.md, Global float atomics) -- 171 ms per call.  Rows of xt are
+// consecutive samples of a ray, 0.07 - 0.3 texels apart even at the finest scale, so an item = (chunk of `run` rows,
+// scale, static | time group) keeps the sums of the current texel quad of each of its three planes in registers and adds
+// them only when that plane's quad changes.  32 lanes per item: lane = (texel of the quad, channel), i.e. a flush is one
+// atomic instruction covering four whole 32-byte texels.  The interpolated values the products need are rebuilt from the
+// lanes' own gathers (butterfly sum over the four texel lanes).
+__global__ __launch_bounds__(kBlock) void k_planes_bwd_runs(const float* __restrict__ xt, uint32_t M, const float* __restrict__ planes,
+                                                            PlaneMeta meta, int want, const float* __restrict__ g_static,
+                                                            const float* __restrict__ g_dynamic, float* __restrict__ g_planes,
+                                                            uint32_t run) {
+    const int lane = lane_id();
+    const int half = lane >> 5, tex = (lane >> 3) & 3, ch = lane & 7;
+    const uint32_t n_grp = (want & 1 ? 1u : 0u) + (want & 2 ? 1u : 0u);
+    const unsigned long long item = ((unsigned long long)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) * 2ull + (unsigned)half;
+    const uint32_t per_chunk = meta.n_scales * n_grp;
+    const uint32_t chunk = (uint32_t)(item / per_chunk), rest = (uint32_t)(item - (unsigned long long)chunk * per_chunk);
+    const uint32_t s = rest / n_grp;
+    const int grp = n_grp == 2 ? (int)(rest - s * n_grp) : ((want & 1) ? 0 : 1);
+    const unsigned long long first = (unsigned long long)chunk * run;
+    const bool active = first < M;  // inactive halves still execute the shuffles below
+    const uint32_t m0 = active ? (uint32_t)first : 0u, m1 = active ? (uint32_t)(first + run < M ? first + run : M) : 0u;
+    const uint32_t ss = active ? s : 0u;
+    const float* gbase = grp == 0 ? g_static : g_dynamic;
+    const uint32_t stride = meta.n_scales * kC;
+    const int pairs[3] = {grp == 0 ? 0 : 2, grp == 0 ? 1 : 4, grp == 0 ? 3 : 5};
+    float acc[3] = {0.0f, 0.0f, 0.0f};
+    uint32_t cur[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};  // i00 of the quad being summed (identifies the quad)
+    uint32_t dst[3] = {0u, 0u, 0u};
+    const uint32_t n_rows = m1 - m0;
+    for (uint32_t r = 0; r < run; ++r) {  // uniform trip count over the wave
+        const bool row_ok = r < n_rows;
+        const uint32_t m = row_ok ? m0 + r : (M - 1);
+        const float4 p4 = reinterpret_cast<const float4*>(xt)[m];
+        const float p[4] = {p4.x, p4.y, p4.z, p4.w};
+        const float g = row_ok ? gbase[(size_t)m * stride + ss * kC + ch] : 0.0f;
+        float v[3], w[3];
+        uint32_t idx[3], quad[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int a = kPa[pairs[j]], b = kPb[pairs[j]];
+            const Tap t = make_tap(p[a], p[b], meta.res[ss][a], meta.res[ss][b]);
+            idx[j] = tex == 0 ? t.i00 : tex == 1 ? t.i01 : tex == 2 ? t.i10 : t.i11;
+            w[j] = tex == 0 ? t.nw : tex == 1 ? t.ne : tex == 2 ? t.sw : t.se;
+            quad[j] = t.i00;
+            float part = planes[meta.off[ss][pairs[j]] + (size_t)idx[j] * kC + ch] * w[j];
+            part += __shfl_xor(part, 8);
+            part += __shfl_xor(part, 16);
+            v[j] = part;  // interpolated value of plane j, channel ch (in all four texel lanes)
+        }
+        if (!row_ok) continue;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float gv = g * (v[(j + 1) % 3] * v[(j + 2) % 3]);
+            if (quad[j] != cur[j]) {
+                if (acc[j] != 0.0f) atomicAdd(g_planes + dst[j], acc[j]);
+                acc[j] = 0.0f;
+                cur[j] = quad[j];
+                dst[j] = meta.off[ss][pairs[j]] + idx[j] * kC + ch;
+            }
+            acc[j] += gv * w[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        if (acc[j] != 0.0f) atomicAdd(g_planes + dst[j], acc[j]);
+}
+
 int fill_plane_meta(PlaneMeta& meta, uint32_t n_scales, const uint32_t* h_res) {
     if (n_scales == 0 || n_scales > (uint32_t)kMaxScales || !h_res) return NVSF_ERR_INVALID_ARG;
     static const int pa[6] = {0, 0, 0, 1, 1, 2}, pb[6] = {1, 2, 3, 2, 3, 3};
@@ -215,7 +286,24 @@ NVSF_API int nvsf_planes_bwd(const float* xt, uint32_t M, const float* planes_cl
     PlaneMeta meta;
     const int st = fill_plane_meta(meta, n_scales, h_res);
     if (st != NVSF_OK) return st;
-    hipLaunchKernelGGL(k_planes_bwd, dim3(cdiv(M, kBlock)), dim3(kBlock), 0, stream, xt, M, planes_cl, meta, want, grad_static, grad_dynamic,
-                       grad_planes_cl, grad_xt);
+    const char* variant = getenv("NVSF_PLANES_BWD");  // "atomic": one atomic per (sample, texel, channel) (first formulation; tests, A/B)
+    if (variant && variant[0] == 'a') {
+        hipLaunchKernelGGL(k_planes_bwd, dim3(cdiv(M, kBlock)), dim3(kBlock), 0, stream, xt, M, planes_cl, meta, want, grad_static,
+                           grad_dynamic, grad_planes_cl, grad_xt);
+        return nvsf_launch_status();
+    }
+    if (grad_xt)  // coordinate gradients: one thread per sample, no atomics
+        hipLaunchKernelGGL(k_planes_bwd, dim3(cdiv(M, kBlock)), dim3(kBlock), 0, stream, xt, M, planes_cl, meta, want, grad_static,
+                           grad_dynamic, static_cast<float*>(nullptr), grad_xt);
+    if (grad_planes_cl) {
+        const char* run_env = getenv("NVSF_PLANES_BWD_RUN");
+        const uint32_t run = run_env ? (uint32_t)atoi(run_env) : 128u;
+        REQUIRE(run >= 1);
+        const uint32_t n_grp = ((want & 1) ? 1u : 0u) + ((want & 2) ? 1u : 0u);
+        const unsigned long long items = (unsigned long long)cdiv(M, run) * n_scales * n_grp;
+        const unsigned long long waves = (items + 1) / 2;
+        hipLaunchKernelGGL(k_planes_bwd_runs, dim3((uint32_t)((waves + kBlock / kWave - 1) / (kBlock / kWave))), dim3(kBlock), 0, stream, xt, M,
+                           planes_cl, meta, want, grad_static, grad_dynamic, grad_planes_cl, run);
+    }
     return nvsf_launch_status();
 }

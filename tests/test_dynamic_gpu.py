@@ -49,6 +49,49 @@ def test_planes4d_forward_backward(dev):
     np.testing.assert_allclose(s2[:, :8].cpu().numpy(), 2 * g["static"][:, :8], atol=2e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize("dynamic_only", [False, True])
+def test_planes_backward_run_merging_equals_per_sample_atomics(dev, dynamic_only, monkeypatch):
+    """The run-merging plane-gradient kernel (default) against the one-atomic-per-(sample, texel, channel) kernel -- itself
+    pinned by the reference's autograd above -- on ray-ordered rows (long runs inside one texel quad at the coarse scales,
+    a constant time coordinate as in a training step), both `want` forms, M not a multiple of the chunk length."""
+    from nvsf.nerf.models.planes_field import Planes4D
+    rng = np.random.default_rng(3)
+    n_rays, T = 29, 211
+    o = rng.random((n_rays, 1, 3)) * 0.4 + 0.3
+    d = rng.standard_normal((n_rays, 1, 3))
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    x = np.clip(o + d * np.linspace(0, 0.3, T).reshape(1, T, 1), 0, 1).reshape(-1, 3)
+    xt_np = np.concatenate([x, np.full((x.shape[0], 1), 0.37)], -1).astype(np.float32)
+    grads = {}
+    for variant in ("runs", "atomic"):
+        if variant == "atomic":
+            monkeypatch.setenv("NVSF_PLANES_BWD", "atomic")
+        monkeypatch.setenv("NVSF_PLANES_BWD_RUN", "64")
+        torch.manual_seed(0)
+        enc = Planes4D(resolution=[32, 32, 32, 8], multiscale_res=[1, 2, 4, 8]).to(dev)
+        xt = _t(xt_np, dev).requires_grad_()
+        g = torch.Generator().manual_seed(1)
+        if dynamic_only:
+            out = enc.forward_dynamic(xt)
+            w = torch.randn(out.shape, generator=g).to(dev)
+            w[::7] = 0.0
+            (out * w).sum().backward()
+        else:
+            s_, d_ = enc(xt)
+            ws, wd = torch.randn(s_.shape, generator=g).to(dev), torch.randn(d_.shape, generator=g).to(dev)
+            ws[::5] = 0.0
+            ((s_ * ws).sum() + (d_ * wd).sum()).backward()
+        grads[variant] = [xt.grad.clone()] + [None if p.grad is None else p.grad.clone() for sc in enc.planes for p in sc]
+    assert torch.equal(grads["runs"][0], grads["atomic"][0])  # coordinate gradients come from the same kernel
+    n_checked = 0
+    for a, b in zip(grads["runs"][1:], grads["atomic"][1:]):
+        assert (a is None) == (b is None)
+        if a is not None:
+            torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-5 * float(b.abs().max()) + 1e-7)
+            n_checked += 1
+    assert n_checked == 24  # with want = dynamic the static planes receive zero gradients, not None
+
+
 def test_hashgrid4d_and_flow(dev):
     from nvsf.nerf.models.hash_field import HashGrid4D
     from nvsf.nerf.models.flow_field import FlowField
