@@ -41,7 +41,14 @@ class FlowField(nn.Module):
         t = xt[0, 3]
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             feat = self.grid_enc.encode_columns(xt, (0, 1, 2)).float()
-            return self.mlp(lagrange_reduce(feat, t, self.n_levels, self.n_features_per_level, self.num_basis))
+            red = lagrange_reduce(feat, t, self.n_levels, self.n_features_per_level, self.num_basis)
+            if self.mlp_mode() == "fused" and self._fused_mlp_ok():
+                # the mixed-precision training run: the Linear layers on the fused MFMA forward / backward kernels (what
+                # autocast makes of them in the reference's Trainer), instead of three fp32 GEMMs + two ReLU launches forward
+                # and six GEMMs backward whose weight gradients reduce over millions of rows
+                lin = [m for m in self.mlp if isinstance(m, nn.Linear)]
+                return FlowMlpFn.apply(red, lin[0].weight, lin[1].weight, lin[2].weight)
+            return self.mlp(red)
         from nvsf import _hip
         from nvsf.nerf.models.hash_field import lagrange_weights_host
         if self.n_features_per_level != 8 or self.num_basis != 4:
@@ -53,7 +60,7 @@ class FlowField(nn.Module):
         red = torch.empty(M, 2 * spec.L, dtype=torch.float32, device=xt.device)
         _hip.call("nvsf_hashgrid3d_lagrange_fwd", _hip.ptr(xt), xt.shape[1], M, _hip.ptr(self.grid_enc.table_f16()), spec.L, spec.F,
                   spec.h_scales, spec.h_res, spec.h_offsets, _hip.host_f32(lagrange_weights_host(t_host, 4, xt.is_cuda)), _hip.ptr(red))
-        if self._fused_mlp_ok():
+        if self.mlp_mode() == "fused" and self._fused_mlp_ok():
             # NVSF_FLOW_MLP=fused (opt-in): the three bias-free layers on the fused MFMA MLP kernel -- fp16 operands, fp32
             # accumulation, i.e. what the reference's Linear layers compute under the Trainer's autocast, 6x faster than
             # the fp32 GEMM + ReLU launches, but only fp16-accurate (4e-5 abs on flows of 1e-2) where the CPU reference
@@ -61,11 +68,16 @@ class FlowField(nn.Module):
             return ops.mlp_forward(red, self._mlp_weights_f16(), self._mlp_spec)[:, :6]
         return self.mlp(red)
 
-    def _fused_mlp_ok(self):
+    def mlp_mode(self):
+        """"torch" (fp32 Linear layers, the form the CPU fixtures pin) or "fused" (fp16 MFMA kernels = the reference under
+        autocast).  NVSF_FLOW_MLP overrides; RenderTrainStep(fp16=True) sets `flow_mlp_mode = "fused"` on the module."""
         import os
+        return os.environ.get("NVSF_FLOW_MLP", getattr(self, "flow_mlp_mode", "torch"))
+
+    def _fused_mlp_ok(self):
         lin = [m for m in self.mlp if isinstance(m, nn.Linear)]
-        return (os.environ.get("NVSF_FLOW_MLP", "torch") == "fused" and len(lin) == 3 and lin[0].in_features % 16 == 0
-                and lin[0].in_features <= 128 and lin[0].out_features == 64 and lin[1].out_features == 64 and lin[2].out_features <= 16)
+        return (len(lin) == 3 and lin[0].in_features % 16 == 0 and lin[0].in_features <= 128 and lin[0].out_features == 64
+                and lin[1].out_features == 64 and lin[2].out_features <= 16)
 
     def _mlp_weights_f16(self):
         """fp16 copy of the Linear weights in the fused kernel's layout (W0 [64, in] ++ W1 [64, 64] ++ W2 zero-padded to
@@ -80,3 +92,31 @@ class FlowField(nn.Module):
             self._mlp_spec = ops.MlpSpec(lin[0].in_features, lin[2].out_features, hidden=64, n_hidden=2)
             self._mlp_key = key
         return self._mlp_w16
+
+
+def _pack_flow_weights(w0, w1, w2):
+    """nn.Linear weights [out, in] -> the fused kernels' fp16 layout W0 [64, in] ++ W1 [64, 64] ++ W2 zero-padded to [16, 64]."""
+    w2p = torch.zeros(16, 64, dtype=torch.float32, device=w2.device)
+    w2p[:w2.shape[0]] = w2.detach().float()
+    return torch.cat([w0.detach().float().reshape(-1), w1.detach().float().reshape(-1), w2p.reshape(-1)]).to(torch.float16).contiguous()
+
+
+class FlowMlpFn(torch.autograd.Function):
+    """flow = W2 relu(W1 relu(W0 x)) on nvsf_mlp_fwd / nvsf_mlp_bwd; gradients are returned in the Linear layers' shapes."""
+
+    @staticmethod
+    def forward(ctx, x, w0, w1, w2):
+        spec = ops.MlpSpec(w0.shape[1], w2.shape[0], hidden=64, n_hidden=2)
+        w16 = _pack_flow_weights(w0, w1, w2)
+        out = ops.mlp_forward(x, w16, spec)
+        ctx.save_for_backward(x, w16)
+        ctx.spec, ctx.shapes = spec, (w0.shape, w1.shape, w2.shape)
+        return out[:, :spec.n_out]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, w16 = ctx.saved_tensors
+        spec, (s0, s1, s2) = ctx.spec, ctx.shapes
+        grad_x, gw = ops.mlp_backward(x, w16, spec, grad_out, need_grad_x=ctx.needs_input_grad[0])
+        g0, g1, g2 = spec.split(gw)
+        return grad_x, g0.view(s0), g1.view(s1), g2[:s2[0]].contiguous().view(s2)

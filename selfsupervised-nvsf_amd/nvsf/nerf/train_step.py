@@ -46,6 +46,8 @@ class RenderTrainStep:
         # MLPs, so the gradients that travel back between them are fp16 tensors: unscaled, those of a mean-over-rays loss sit
         # below the fp16 subnormal range and the hash tables receive zeros.
         self.scaler = torch.amp.GradScaler("cuda", enabled=bool(fp16) and torch.cuda.is_available())
+        if fp16 and hasattr(model, "flow_net"):
+            model.flow_net.flow_mlp_mode = "fused"  # the flow MLP as autocast runs it: fp16 MFMA kernels (flow_field.FlowMlpFn)
         self.opt = torch.optim.Adam(model.get_params(lr), betas=(0.9, 0.99), eps=1e-15)
         self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, lambda it: 0.1 ** min(it / iters, 1))
         self.iters, self.num_steps = iters, num_steps

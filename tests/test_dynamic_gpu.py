@@ -129,6 +129,36 @@ def test_hashgrid4d_and_flow(dev):
     np.testing.assert_allclose(out16.cpu().numpy(), g["flow"], atol=1e-4, rtol=1e-2)
 
 
+def test_flow_mlp_fused_training_path_against_fp32_autograd(dev):
+    """flow_field.FlowMlpFn (the Linear layers on the fused MFMA forward / backward kernels, used by the loss-scaled training
+    step) against torch's fp32 Linear stack: values and all gradients at fp16 accuracy."""
+    from nvsf.nerf.models.flow_field import FlowField, FlowMlpFn
+    import torch.nn as nn
+    torch.manual_seed(2)
+    flow = FlowField(n_levels=16, n_features_per_level=8, base_resolution=32, max_resolution=512, log2_hashmap_size=12).to(dev)
+    with torch.no_grad():
+        flow.mlp[-1].weight.normal_(0, 0.3)  # the reference's 1e-3 init makes every gradient tiny: use a visible scale
+    lin = [m for m in flow.mlp if isinstance(m, nn.Linear)]
+    x = (torch.randn(5000, 32, device=dev) * 0.5).requires_grad_()
+    g = torch.randn(5000, 6, device=dev)
+    out = FlowMlpFn.apply(x, lin[0].weight, lin[1].weight, lin[2].weight)
+    out.backward(g)
+    got = [out.detach().clone(), x.grad.clone()] + [l.weight.grad.clone() for l in lin]
+    x.grad = None
+    for l in lin:
+        l.weight.grad = None
+    ref_out = flow.mlp(x)
+    ref_out.backward(g)
+    ref = [ref_out.detach(), x.grad] + [l.weight.grad for l in lin]
+    # fp16 activations: ~1e-3 relative per element; the ReLU gate of a unit near zero may flip, which moves single entries
+    # of the input gradient by a whole weight -- hence the fraction / mean criteria (as in tests/test_mlp_bwd_gpu.py)
+    for a, b in zip(got, ref):
+        assert a.shape == b.shape
+        scale = float(b.abs().max())
+        err = (a - b).abs()
+        assert float((err <= 2e-2 * scale).float().mean()) > 0.995 and float(err.mean()) < 5e-3 * scale, (float(err.max()), scale)
+
+
 @pytest.fixture(scope="module")
 def net(dev):
     from nvsf.nerf.models.network_dynamic import NeRFNetwork
