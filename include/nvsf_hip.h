@@ -215,6 +215,15 @@ int nvsf_hashgrid4d_dynamic_fwd(const float* x, uint32_t x_stride, const float* 
                                 const uint32_t* h_res, const uint32_t* h_offsets, const float* h_time, int same_slice,
                                 int mode, void* out, nvsf_stream_t stream);
 
+/* Table gradients of nvsf_hashgrid4d_dynamic_fwd, regime 0 (ref: what autograd derives for HashGridT.forward,
+ * hash_field.py:76-88, summed over the three planes of HashGrid4D.forward_dynamic :148-159): one launch for the three
+ * coordinate pairs and both time slices.  grad_out fp32 [M, 24]; h_grad_tables_f32: 6 device pointers to fp32 buffers
+ * in the layout of the slice tables (lo slice of pair 0,1,2, then hi slice of pair 0,1,2 -- ignored when same_slice);
+ * dL/dtable is ADDED to them.  h_scales / h_res / h_offsets / h_time as in the forward. */
+int nvsf_hashgrid4d_dynamic_bwd(const float* x, uint32_t x_stride, uint32_t M, const float* h_scales, const uint32_t* h_res,
+                                const uint32_t* h_offsets, const float* h_time, int same_slice, const float* grad_out,
+                                void* const* h_grad_tables_f32, nvsf_stream_t stream);
+
 /* ref: FlowField.forward front end, nvsf/nerf/models/flow_field.py:123-128 (grid_enc -> .float() -> interpT):
  * 3-D hash grid with F = 8 followed by the Lagrange reduction over the 4 feature pairs of each level.
  * h_weights4 = w0..w3 (fp32, host) -> out fp32 [M, 2L]. */

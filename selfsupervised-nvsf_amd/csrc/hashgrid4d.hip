@@ -128,6 +128,73 @@ __global__ __launch_bounds__(kBlock) void k_hash3d_lagrange(const float* __restr
     }
 }
 
+// Table gradients of the fused space-time encoder, regime 0 (fp32 blend / reduction: the current frame, the only call that
+// records a gradient -- the neighbour frames are evaluated under no_grad, network_dynamic.py:242-271):
+//   out[pair][level] = sum_i lag_i (blend_lo f_lo[i] + blend_hi f_hi[i]),  f_*[i] = sum_corners w_c table_*[row_c][i]
+//   => d L / d table_lo[row_c][i] += g[pair][level] lag_i blend_lo w_c      (the fp16 rounding of f passes the gradient)
+// One launch for the three pairs and both slices instead of six hash-grid backward launches fed by ~30 elementwise kernels
+// that materialise per-slice gradient matrices.  Same scheme as k_hashgrid_bwd_corners (hashgrid.hip): an item = (chunk of
+// rows, pair, level, slice), 16 lanes per item (lane = corner x 4 + feature), the sums of the current cell in registers,
+// one atomic instruction per cell change covering whole 16-byte table entries.
+struct PlaneGrads {
+    float* g_lo[3];
+    float* g_hi[3];
+    GridMeta meta[3];
+    float blend_lo, blend_hi;
+    float lag[4];
+    int same_slice;
+};
+
+__global__ __launch_bounds__(kBlock) void k_hash_dynamic_bwd(const float* __restrict__ x, uint32_t x_stride, uint32_t M,
+                                                             const float* __restrict__ grad_out, PlaneGrads pg, uint32_t run) {
+    const int lane = lane_id();
+    const int sub = lane >> 4, r = lane & 15, c = r >> 2, f = r & 3;
+    const uint32_t n_sl = pg.same_slice ? 1u : 2u;
+    const uint32_t per_chunk = 3u * kPlaneLevels * n_sl;
+    const unsigned long long item = ((unsigned long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 4ull + (unsigned)sub;
+    const uint32_t chunk = (uint32_t)(item / per_chunk), rest = (uint32_t)(item - (unsigned long long)chunk * per_chunk);
+    const uint32_t pl = rest / (kPlaneLevels * n_sl), l = (rest / n_sl) % kPlaneLevels, sl = rest % n_sl;
+    const unsigned long long first = (unsigned long long)chunk * run;
+    if (first >= M) return;
+    const uint32_t m0 = (uint32_t)first, m1 = (uint32_t)(first + run < M ? first + run : M);
+    const GridMeta& g = pg.meta[pl];
+    const float scale = g.scale[l];
+    const uint32_t res = g.res[l], row0 = g.offset[l], hsize = g.offset[l + 1] - row0;
+    float* table = sl ? pg.g_hi[pl] : pg.g_lo[pl];
+    const float factor = pg.lag[f] * (pg.same_slice ? 1.0f : (sl ? pg.blend_hi : pg.blend_lo));
+    const uint32_t ca = pl == 2 ? 1u : 0u, cb = pl == 0 ? 1u : 2u;  // coordinate columns of the pair: (x,y), (x,z), (y,z)
+    float acc = 0.0f;
+    uint32_t cur0 = 0u, cur1 = 0u;
+    bool have = false;
+    float* dst = table;
+    float xa_n = x[(size_t)m0 * x_stride + ca], xb_n = x[(size_t)m0 * x_stride + cb];
+    float g_n = grad_out[(size_t)m0 * (3 * kPlaneLevels) + pl * kPlaneLevels + l];
+    for (uint32_t m = m0; m < m1; ++m) {
+        const float xa = xa_n, xb = xb_n, go = g_n;
+        if (m + 1 < m1) {
+            xa_n = x[(size_t)(m + 1) * x_stride + ca];
+            xb_n = x[(size_t)(m + 1) * x_stride + cb];
+            g_n = grad_out[(size_t)(m + 1) * (3 * kPlaneLevels) + pl * kPlaneLevels + l];
+        }
+        if (go == 0.0f) continue;
+        const float pa = fmaf(scale, xa, 0.5f), pb = fmaf(scale, xb, 0.5f);
+        const float fa = floorf(pa), fb = floorf(pb);
+        const float ra = pa - fa, rb = pb - fb;
+        const uint32_t ia = (uint32_t)(int32_t)fa, ib = (uint32_t)(int32_t)fb;
+        const float w = ((c & 1) ? ra : (1.0f - ra)) * ((c & 2) ? rb : (1.0f - rb));
+        if (!(have && ia == cur0 && ib == cur1)) {
+            if (acc != 0.0f) atomicAdd(dst, acc);
+            acc = 0.0f;
+            have = true;
+            cur0 = ia; cur1 = ib;
+            const uint32_t cc[2] = {ia + (uint32_t)(c & 1), ib + (uint32_t)((c >> 1) & 1)};
+            dst = table + ((size_t)row0 + grid_row<2>(cc, res, hsize)) * kF + f;
+        }
+        acc += w * (go * factor);
+    }
+    if (acc != 0.0f) atomicAdd(dst, acc);
+}
+
 int fill_meta(GridMeta& meta, uint32_t L, const float* scales, const uint32_t* res, const uint32_t* offsets) {
     if (L == 0 || L > (uint32_t)kMaxLevels || !scales || !res || !offsets) return NVSF_ERR_INVALID_ARG;
     for (uint32_t l = 0; l < L; ++l) {
@@ -182,5 +249,31 @@ NVSF_API int nvsf_hashgrid3d_lagrange_fwd(const float* x, uint32_t x_stride, uin
     const size_t lds = (size_t)kSamplesPerBlock * (2 * L + 1) * sizeof(float);
     hipLaunchKernelGGL(k_hash3d_lagrange, dim3(cdiv(M, kSamplesPerBlock)), dim3(kBlock), lds, stream, x, x_stride, M,
                        reinterpret_cast<const _Float16*>(table_f16), L, meta, h_weights4[0], h_weights4[1], h_weights4[2], h_weights4[3], out);
+    return nvsf_launch_status();
+}
+
+// grad tables: 6 device pointers to fp32 buffers in the layout of the slice tables (lo slice of pair 0,1,2 then hi slice of pair 0,1,2;
+// the hi pointers are ignored when same_slice); dL/dtable is ADDED to them.  grad_out fp32 [M, 24] (regime 0 only).
+NVSF_API int nvsf_hashgrid4d_dynamic_bwd(const float* x, uint32_t x_stride, uint32_t M, const float* h_scales, const uint32_t* h_res,
+                                         const uint32_t* h_offsets, const float* h_time, int same_slice, const float* grad_out,
+                                         void* const* h_grad_tables_f32, hipStream_t stream) {
+    if (M == 0) return NVSF_OK;
+    REQUIRE(x && h_time && grad_out && h_grad_tables_f32 && x_stride >= 3);
+    PlaneGrads pg;
+    for (int p = 0; p < 3; ++p) {
+        pg.g_lo[p] = reinterpret_cast<float*>(h_grad_tables_f32[p]);
+        pg.g_hi[p] = reinterpret_cast<float*>(h_grad_tables_f32[3 + p]);
+        REQUIRE(pg.g_lo[p] && (same_slice || pg.g_hi[p]));
+        const int st = fill_meta(pg.meta[p], kPlaneLevels, h_scales + p * kPlaneLevels, h_res + p * kPlaneLevels, h_offsets + p * (kPlaneLevels + 1));
+        if (st != NVSF_OK) return st;
+    }
+    pg.blend_lo = h_time[0]; pg.blend_hi = h_time[1];
+    for (int i = 0; i < 4; ++i) pg.lag[i] = h_time[2 + i];
+    pg.same_slice = same_slice;
+    const uint32_t run = M >= (1u << 20) ? 128u : 32u;
+    const unsigned long long items = (unsigned long long)cdiv(M, run) * 3ull * kPlaneLevels * (same_slice ? 1u : 2u);
+    const unsigned long long waves = (items + 3) / 4;
+    hipLaunchKernelGGL(k_hash_dynamic_bwd, dim3((uint32_t)((waves + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, stream, x, x_stride, M,
+                       grad_out, pg, run);
     return nvsf_launch_status();
 }

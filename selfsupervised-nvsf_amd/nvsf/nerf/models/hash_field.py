@@ -16,6 +16,7 @@ device tensors and branches on `idx1 == idx2` (one device->host sync per plane p
 come from one host copy of t per call.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -130,6 +131,16 @@ class HashGrid4D(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             if offset is not None:
                 x = x + offset[:, offset_col:offset_col + 3]
+            first = self.hash_dynamic[0]
+            fp32_regime = torch.is_tensor(t) and t.dim() > 0
+            if (fp32_regime and not x.requires_grad and first.n_levels == 8 and first.n_features_per_level == 4 and first.num_basis == 4
+                    and os.environ.get("NVSF_HASH4D_TRAIN", "fused") == "fused"):
+                # fused forward + fused table-gradient kernel (csrc/hashgrid4d.hip) instead of six per-slice encoder calls,
+                # their blends / Lagrange reductions and six backward launches
+                idx = np.float32(t_host) * np.float32(first.time_resolution - 1)
+                k1, k2 = int(math.floor(idx)), int(math.ceil(idx))
+                params = [pl.hash_t[k1].params for pl in self.hash_dynamic] + [pl.hash_t[k2].params for pl in self.hash_dynamic]
+                return HashDynFn.apply(self, x, t, t_host, k1, k2, *params)
             return torch.cat([plane(x, t, t_host) for plane in self.hash_dynamic], dim=-1)
         return self._forward_dynamic_fused(x, t, t_host, offset, offset_col)
 
@@ -163,3 +174,43 @@ class HashGrid4D(nn.Module):
     def forward(self, x, t, t_host=None):
         static, dynamic = self.forward_static(x), self.forward_dynamic(x, t, t_host)
         return [static, dynamic] if self.decompose else torch.cat([static, dynamic], dim=-1)
+
+
+class HashDynFn(torch.autograd.Function):
+    """HashGrid4D.forward_dynamic at the current frame (fp32 regime) with autograd: the fused forward kernel and the fused
+    table-gradient kernel.  `params` = the slice parameters (floor slice of the three pairs, then ceil slice) so that the
+    gradients reach exactly the tensors the per-slice path would have touched."""
+
+    @staticmethod
+    def forward(ctx, enc, x, t, t_host, k1, k2, *params):
+        x = x.float().contiguous()
+        out = enc._forward_dynamic_fused(x, t, t_host, None, 0)
+        ctx.save_for_backward(x)
+        ctx.enc, ctx.t, ctx.t_host, ctx.k1, ctx.k2 = enc, t, t_host, k1, k2
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from nvsf import _hip
+        import ctypes
+        (x,) = ctx.saved_tensors
+        enc, t_host, k1, k2 = ctx.enc, ctx.t_host, ctx.k1, ctx.k2
+        first = enc.hash_dynamic[0]
+        idx = np.float32(t_host) * np.float32(first.time_resolution - 1)
+        lag = lagrange_weights_host(t_host, 4, reciprocal_division=torch.is_tensor(ctx.t) and ctx.t.is_cuda)
+        h_time = _hip.host_f32([float(np.float32(k2) - idx), float(idx - np.float32(k1))] + lag)
+        specs = [pl.hash_t[0].spec for pl in enc.hash_dynamic]
+        h_scales = _hip.host_f32([v for s in specs for v in s.scales])
+        h_res = _hip.host_u32([v for s in specs for v in s.res])
+        h_off = _hip.host_u32([v for s in specs for v in s.offsets])
+        same = k1 == k2
+        grads = [torch.zeros(s.n_params, dtype=torch.float32, device=x.device) for s in specs]
+        if not same:
+            grads += [torch.zeros(s.n_params, dtype=torch.float32, device=x.device) for s in specs]
+        ptrs = [g.data_ptr() for g in grads] + ([0, 0, 0] if same else [])
+        g_out = grad_out.float().contiguous()
+        _hip.call("nvsf_hashgrid4d_dynamic_bwd", _hip.ptr(x), x.shape[1], x.shape[0], h_scales, h_res, h_off, h_time, 1 if same else 0,
+                  _hip.ptr(g_out), (ctypes.c_void_p * 6)(*ptrs))
+        if same:  # the same parameter tensors were passed twice: the whole gradient goes to the first occurrence
+            grads = grads + [None, None, None]
+        return (None, None, None, None, None, None, *grads)

@@ -129,6 +129,44 @@ def test_hashgrid4d_and_flow(dev):
     np.testing.assert_allclose(out16.cpu().numpy(), g["flow"], atol=1e-4, rtol=1e-2)
 
 
+@pytest.mark.parametrize("t_val", [0.37, 0.0, 1.0])  # between two slices / exactly on the first / on the last slice
+def test_hashgrid4d_fused_training_path_equals_the_per_slice_path(dev, t_val, monkeypatch):
+    """HashDynFn (fused forward + fused table-gradient kernel) against the per-slice operator path (six tcnn.Encoding calls,
+    blend, Lagrange reduction through autograd): same features, same gradients on the same slice parameters, none elsewhere."""
+    from nvsf.nerf.models.hash_field import HashGrid4D
+    rng = np.random.default_rng(5)
+    n_rays, T = 23, 150
+    o = rng.random((n_rays, 1, 3)) * 0.4 + 0.3
+    d = rng.standard_normal((n_rays, 1, 3))
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    x = _t(np.clip(o + d * np.linspace(0, 0.3, T).reshape(1, T, 1), 0, 1).reshape(-1, 3).astype(np.float32), dev)
+    t = torch.tensor([[t_val]], dtype=torch.float32, device=dev)
+    res = {}
+    for mode in ("fused", "ops"):
+        monkeypatch.setenv("NVSF_HASH4D_TRAIN", mode)
+        torch.manual_seed(0)
+        enc = HashGrid4D(base_resolution=16, max_resolution=512, time_resolution=4, n_levels=8, n_features_per_level=4, log2_hashmap_size=12,
+                         hash_size_dynamic=[11, 10, 10]).to(dev)
+        with torch.no_grad():
+            for p in enc.parameters():
+                p.uniform_(-0.5, 0.5)
+        out = enc.forward_dynamic(x, t)
+        g = torch.Generator().manual_seed(1)
+        w = torch.randn(out.shape, generator=g).to(dev)
+        w[::6] = 0.0
+        (out.float() * w).sum().backward()
+        res[mode] = (out.detach().float().clone(), {n: (None if p.grad is None else p.grad.clone()) for n, p in enc.named_parameters()})
+    torch.testing.assert_close(res["fused"][0], res["ops"][0], rtol=1e-5, atol=1e-6)
+    n_grad = 0
+    for name, gr in res["ops"][1].items():
+        gf = res["fused"][1][name]
+        assert (gr is None or not gr.any()) == (gf is None or not gf.any()), name
+        if gr is not None and gr.any():
+            torch.testing.assert_close(gf, gr, rtol=2e-3, atol=2e-4 * float(gr.abs().max()))
+            n_grad += 1
+    assert n_grad == (3 if t_val in (0.0, 1.0) else 6)
+
+
 def test_flow_mlp_fused_training_path_against_fp32_autograd(dev):
     """flow_field.FlowMlpFn (the Linear layers on the fused MFMA forward / backward kernels, used by the loss-scaled training
     step) against torch's fp32 Linear stack: values and all gradients at fp16 accuracy."""
