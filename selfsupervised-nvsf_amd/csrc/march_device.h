@@ -189,10 +189,10 @@ __device__ __forceinline__ void fill_spread_lut(uint32_t* lut, uint32_t H) {
 }
 
 // Wave-cooperative marcher: all 64 lanes of a wave work on ONE ray.  Lane j classifies member j of the current batch of
-// 64 consecutive chain members (one dependent occupancy load per 64 members instead of one per probe); next_sample()
-// then replays the serial protocol of Marcher::probe from the per-lane results -- an occupied member is a sample and
-// the walk moves to the next member, an empty one jumps to the first member at or beyond the cell's exit parameter
-// (ballot + find-first), possibly in a later batch.  All results are wave-uniform.
+// up to 64 consecutive chain members (one dependent occupancy load per batch instead of one per probe); next_samples()
+// then decides which members the serial protocol of Marcher::probe would visit -- an occupied member is a sample and
+// the walk moves to the next member, an empty one jumps to the first member at or beyond the cell's exit parameter,
+// possibly in a later batch -- for the whole batch at once and returns the samples as a lane mask (wave-uniform).
 struct ChainWalker {
     float bt, bx, by, bz, bdt, bexit;  // per lane: member parameter, sample position, step, exit parameter of its cell
     bool bocc;
@@ -217,31 +217,6 @@ struct ChainWalker {
             const unsigned long long reach = __ballot(bt >= pending) & batch_mask();
             if (reach) { j = __builtin_ctzll(reach); pending = -INFINITY; }
             else j = nb;
-        }
-    }
-    // Next sample of the ray with parameter < far: returns false when the ray is finished.
-    __device__ __forceinline__ bool next_sample(const Marcher& m, float far, int lane, float& x, float& y, float& z, float& dt,
-                                                float& t_sample) {
-        while (true) {
-            if (j >= nb) { refill(m, lane); continue; }
-            const int ju = __builtin_amdgcn_readfirstlane(j);
-            const float tj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bt), ju));
-            if (!(tj < far)) return false;
-            if (__builtin_amdgcn_readlane((int)bocc, ju)) {
-                x = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bx), ju));
-                y = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, by), ju));
-                z = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bz), ju));
-                dt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bdt), ju));
-                t_sample = tj;
-                j = ju + 1;
-                return true;
-            }
-            const float tt = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bexit), ju));
-            if (!(tt < far)) return false;  // the serial marcher would step to a member >= tt >= far and stop there
-            const unsigned long long later = (~0ull << ju << 1) & batch_mask();
-            const unsigned long long reach = __ballot(bt >= tt) & later;
-            if (reach) j = __builtin_ctzll(reach);
-            else { j = nb; pending = tt; }
         }
     }
     // All samples of the next batch that has any, as a lane mask (lane k set: member k of the batch is a sample; its

@@ -15,6 +15,7 @@
 // Every weight fragment (forward and transposed) lives in LDS in MFMA-operand order ([fragment][lane] x 16 B).
 // Gradients travel in fp16 scaled by `grad_scale` (tcnn's loss_scale); dX and dW are unscaled in fp32 on the way out.
 #include "mlp_device.h"
+#include <stdlib.h>
 
 namespace {
 constexpr int kBlock = 256;
@@ -323,7 +324,9 @@ NVSF_API int nvsf_mlp_bwd(const void* x, int x_is_f16, uint32_t M, uint32_t n_in
     const int vec_ok = ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) && ((x_stride * esz) % 16 == 0);
     const uint32_t n_tiles = (M + 15) / 16;
     uint32_t blocks = (n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (blocks > 512u) blocks = 512u;  // 256 CUs x 2 resident workgroups; fewer workgroups = fewer flush atomics
+    const char* cap_env = getenv("NVSF_MLP_BWD_BLOCKS");
+    const uint32_t cap = cap_env ? (uint32_t)atoi(cap_env) : 512u;  // 256 CUs x 2 resident workgroups; fewer workgroups = fewer flush atomics
+    if (blocks > cap) blocks = cap;
     const _Float16* w = reinterpret_cast<const _Float16*>(weights_f16);
 #define LAUNCH(S, H, XF)                                                                                                          \
     hipLaunchKernelGGL((k_mlp_bwd<S, H, XF>), dim3(blocks), dim3(kBlock), 0, stream, x, M, n_in, x_stride, w, in_cols, grad_out, \
