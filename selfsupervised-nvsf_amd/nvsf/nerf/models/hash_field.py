@@ -166,8 +166,12 @@ class HashGrid4D(nn.Module):
         x = x.float().contiguous()
         M = x.shape[0]
         out = torch.empty(M, 24, dtype=torch.float16 if fp16_regime else torch.float32, device=x.device)
-        off = offset.float().contiguous() if offset is not None else None
-        _hip.call("nvsf_hashgrid4d_dynamic_fwd", _hip.ptr(x), x.shape[1], _hip.ptr(off), off.shape[1] if off is not None else 0,
+        off = None
+        if offset is not None:  # rows of a wider buffer (e.g. the padded output of the fused flow MLP) are read in place
+            off = offset.float()
+            if off.dim() != 2 or off.stride(1) != 1:
+                off = off.contiguous()
+        _hip.call("nvsf_hashgrid4d_dynamic_fwd", _hip.ptr(x), x.shape[1], None if off is None else _hip.ptr_rows(off), off.stride(0) if off is not None else 0,
                   int(offset_col), M, h_tables, h_scales, h_res, h_off, h_time, 1 if k1 == k2 else 0, 1 if fp16_regime else 0, _hip.ptr(out))
         return out
 

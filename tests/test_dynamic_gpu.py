@@ -167,6 +167,32 @@ def test_hashgrid4d_fused_training_path_equals_the_per_slice_path(dev, t_val, mo
     assert n_grad == (3 if t_val in (0.0, 1.0) else 6)
 
 
+@pytest.mark.parametrize("flow_scale,t_val", [(1e-3, 0.5), (0.05, 0.5), (0.05, 0.0), (0.05, 1.0)])
+def test_fused_dynamic_features_equal_the_separate_launches(dev, flow_scale, t_val, monkeypatch):
+    """The no-grad density query with in-kernel `x + flow` for the neighbour hash grids and in-place neighbour coordinates,
+    against the launch-by-launch form -- bit for bit, with small and with large flows, first / last frame included."""
+    from nvsf.nerf.models.network_dynamic import NeRFNetwork
+    torch.manual_seed(4)
+    m = NeRFNetwork(time_resolution=4, num_frames=16, bound=2.0, min_resolution=16, base_resolution=32, max_resolution=512,
+                    log2_hashmap_size=13).to(dev).eval()
+    with torch.no_grad():
+        m.flow_net.mlp[-1].weight.normal_(0, flow_scale * 30.0)
+        for p in m.flow_net.grid_enc.parameters():
+            p.uniform_(-0.5, 0.5)
+    x = (torch.rand(20000, 3, device=dev) * 2 - 1) * 1.9
+    t = torch.tensor([[t_val]], device=dev)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("NVSF_DYNAMIC_FUSED", mode)
+        with torch.no_grad():
+            feats = m._dynamic_features(m._unit_cube(x), t, True)
+            dens = m.density(x, t, cal_lidar_color=True)
+        outs[mode] = [f.float() for f in feats] + [dens["sigma"], dens["geo_feat"].float()]
+    assert float((m.flow_net(torch.cat([m._unit_cube(x), t.expand(x.shape[0], 1)], -1)).abs().mean())) > 0.1 * flow_scale
+    for a, b in zip(outs["1"], outs["0"]):
+        assert torch.equal(a, b)
+
+
 def test_flow_mlp_fused_training_path_against_fp32_autograd(dev):
     """flow_field.FlowMlpFn (the Linear layers on the fused MFMA forward / backward kernels, used by the loss-scaled training
     step) against torch's fp32 Linear stack: values and all gradients at fp16 accuracy."""
