@@ -41,8 +41,8 @@ MFMA_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--num-rays", type=int, default=4096)
     ap.add_argument("--num-rays-lidar", type=int, default=4096)
     ap.add_argument("--num-steps", type=int, default=768)
@@ -446,7 +446,7 @@ def main():
             line["invalid"] = "NVSF_BENCH_SAME_DEVICE=1: all ranks shared cuda:0 (control-flow check only)"
         if not args.no_kernel_breakdown:
             rows = kernel_breakdown(model, {"lidar": (tl[0][0], tl[1][0], True), "camera": (tc[0][0], tc[1][0], False)}, T,
-                                    max(5, args.steps))
+                                    min(max(5, args.steps), 40))
             line["kernels"] = rows
             pick = max(rows, key=lambda r: r["ms"])  # the dominant launch of the step
             line["roofline"] = {"kernel": pick["kernel"], "bound": pick["bound"], "achieved": pick["achieved"], "peak": pick["peak"],
