@@ -1,0 +1,54 @@
+"""bench.py's output contract, checked without a GPU: argument defaults, the PMC-traffic lookup, and the keys / consistency of
+the last committed bench line (profiles/*_bench_line.json is written by `python bench.py` on the MI355X box)."""
+import glob
+import importlib.util
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("nvsf_bench", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_defaults_and_traffic_lookup(monkeypatch):
+    b = _bench()
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = b.parse()
+    assert a.gpus == 1 and a.steps >= 20 and a.warmup >= 5 and a.num_rays == 4096 and a.num_rays_lidar == 4096 and a.num_steps == 768
+    assert b.HBM_PEAK_GBS == 8000.0 and b.MFMA_PEAK_TFLOPS == 2500.0
+    t = b.pmc_traffic("density_encode_sliced[camera]")
+    assert t["traffic"] is not None and t["traffic"] > 1e8 and "profiles/" in t["traffic_source"]
+    assert b.pmc_traffic("render_uniform[lidar]")["traffic"] > 1e8
+    assert b.pmc_traffic("no_such_kernel[lidar]")["traffic"] is None
+
+
+def test_committed_bench_line_follows_the_contract():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_line.json")))
+    assert files
+    d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "rays/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    rays = (d["config"]["num_rays"] + d["config"]["num_rays_lidar"]) * d["n_gpus"]
+    assert abs(d["value"] - rays / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6  # value = whole-job rays / time
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["traffic"] is None or r["traffic"] > 0
+    # achieved = algorithmic bytes per launch / live launch duration
+    if r["bound"] == "hbm":
+        per_unit = float(r["algorithmic"].split()[0])
+        assert abs(r["achieved"] - per_unit * r["units_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-6
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "rays/s" and c["sample"]
+    for leg in ("occupancy", "dynamic", "train", "raymarching", "field_ops"):
+        assert leg in d, leg
+    for row in d["raymarching"]["kernels"] + d["field_ops"]["kernels"] + d["kernels"]:
+        assert row["ms"] > 0 and row["frac"] > 0 and row["bound"] in ("hbm", "mfma")
