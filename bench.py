@@ -340,7 +340,19 @@ def dynamic_leg(dev, n_rays, T, steps):
     dt32 = timed("torch")
     out = {"metric": "rendered rays/sec (LiDAR+cam), dynamic 4-D field", "value": 2 * n_rays / dt, "ms_per_step": dt * 1e3,
            "flow_mlp": "fp16 MFMA (fused kernel)", "fp32_flow_mlp": {"value": 2 * n_rays / dt32, "ms_per_step": dt32 * 1e3},
+           "scene_flow": "fresh initialisation: |flow| ~ 1e-8 of the unit cube, i.e. a static scene -- the neighbour-frame evaluations re-use "
+                         "the base evaluation's gathers at every level (k_hash_dynamic3)",
            "num_rays": n_rays, "num_rays_lidar": n_rays, "num_steps": T, "parameters_M": sum(p.numel() for p in m.parameters()) / 1e6}
+    # the other end: every sample moving by ~8e-4 of the unit cube (~0.3 m per frame at the KITTI-360 scale), 25 finest cells:
+    # the neighbours gather their own entries at almost every level
+    saved = {k: v.clone() for k, v in m.flow_net.state_dict().items()}
+    with torch.no_grad():
+        for p in m.flow_net.grid_enc.parameters():
+            p.uniform_(-0.5, 0.5)
+        m.flow_net.mlp[-1].weight.normal_(0, 6e-3)
+    dtm = timed("fused")
+    out["moving_scene"] = {"value": 2 * n_rays / dtm, "ms_per_step": dtm * 1e3, "mean_abs_flow": 8e-4}
+    m.flow_net.load_state_dict(saved)
     # the multimodal training step on the same model (what main_nvsf.py trains): fwd + bwd + Adam, loss-scaled
     from nvsf.nerf.train_step import RenderTrainStep
     g = torch.Generator(device="cpu").manual_seed(3)

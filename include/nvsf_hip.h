@@ -215,6 +215,18 @@ int nvsf_hashgrid4d_dynamic_fwd(const float* x, uint32_t x_stride, const float* 
                                 const uint32_t* h_res, const uint32_t* h_offsets, const float* h_time, int same_slice,
                                 int mode, void* out, nvsf_stream_t stream);
 
+/* The three space-time evaluations of one density query in one launch (ref: network_dynamic.py:220-271: hash_encoder(x, t)
+ * in the fp32 regime and hash_encoder.forward_dynamic(x + flow, t_neighbour) twice in the fp16 regime).  h_tables_f16: 18
+ * device pointers = for evaluation e = 0, 1, 2 the lo slice of pair 0,1,2 then the hi slice of pair 0,1,2; h_time: 18 floats
+ * = per evaluation {blend_lo, blend_hi, w0..w3}; h_flags: 9 ints = per evaluation {enabled, same_slice, shares the slice
+ * tables of evaluation 0}.  offsets fp32 [M, off_stride >= 6]: columns 0..2 warp evaluation 1, columns 3..5 evaluation 2.
+ * out0 fp32 [M,24]; out1 / out2 fp16 [M,24].  Bit-identical to three nvsf_hashgrid4d_dynamic_fwd calls: a neighbour whose
+ * cell at a level equals the base cell (and whose slices are the base slices) re-uses the base evaluation's gathers. */
+int nvsf_hashgrid4d_dynamic3_fwd(const float* x, uint32_t x_stride, const float* offsets, uint32_t off_stride, uint32_t M,
+                                 const void* const* h_tables_f16, const float* h_scales, const uint32_t* h_res,
+                                 const uint32_t* h_offsets, const float* h_time, const int* h_flags, float* out0, void* out1,
+                                 void* out2, nvsf_stream_t stream);
+
 /* Table gradients of nvsf_hashgrid4d_dynamic_fwd, regime 0 (ref: what autograd derives for HashGridT.forward,
  * hash_field.py:76-88, summed over the three planes of HashGrid4D.forward_dynamic :148-159): one launch for the three
  * coordinate pairs and both time slices.  grad_out fp32 [M, 24]; h_grad_tables_f32: 6 device pointers to fp32 buffers

@@ -29,8 +29,8 @@ struct PlaneSet {
 
 __device__ __forceinline__ float r16(float v) { return (float)(_Float16)v; }  // round-trip through fp16
 
-template <int MODE>
-__device__ __forceinline__ float blend_reduce(const float (&f_lo)[kF], const float (&f_hi)[kF], const PlaneSet& ps) {
+template <int MODE, typename PS>
+__device__ __forceinline__ float blend_reduce(const float (&f_lo)[kF], const float (&f_hi)[kF], const PS& ps) {
     float feat[kF];
 #pragma unroll
     for (int i = 0; i < kF; ++i) {
@@ -93,6 +93,159 @@ __global__ __launch_bounds__(kBlock) void k_hash_dynamic(const float* __restrict
         const size_t o = (size_t)(blockIdx.x * kSamplesPerBlock + row) * kOut + col;
         if (MODE == 0) reinterpret_cast<float*>(out)[o] = stage[row][col];
         else reinterpret_cast<_Float16*>(out)[o] = (_Float16)stage[row][col];
+    }
+}
+
+// The three space-time evaluations of one density query (network_dynamic.py:220-271) in one launch: features at (x, t) in
+// regime 0 and at the flow-warped positions (x + f1, t1), (x + f2, t2) of the neighbour frames in regime 1.  The warped
+// positions are fractions of a cell away from x at the coarse levels (and everywhere the scene is static), and the
+// neighbour frames usually fall between the same two time slices as t: whenever a neighbour's cell at a level equals the
+// base cell and its slices are the base slices, the 2 x 4 table entries the base evaluation has just gathered (kept as
+// raw 8-byte values, 16 registers) are re-used and only the weights differ; otherwise the neighbour gathers its own.
+// Same gathers / same arithmetic per evaluation as three k_hash_dynamic launches: bit-identical outputs.
+struct TimeSet {  // what differs between the evaluations: the two slices and the time weights
+    const _Float16* table_lo[3];
+    const _Float16* table_hi[3];
+    float blend_lo, blend_hi;
+    float lag[4];
+    int same_slice;
+};
+struct PlaneSet3 {
+    TimeSet ev[3];
+    GridMeta meta[3];  // per pair (shared by the evaluations)
+    int enabled[3];    // ev[0] always; ev[1], ev[2]: neighbour present
+    int share[3];      // ev[e] reads the same slice tables as ev[0] (same k1, k2): its cells may re-use ev[0]'s gathers
+};
+
+typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void gather_quad(const float (&xy)[2], const _Float16* __restrict__ table, float scale, uint32_t res, uint32_t row0,
+                                            uint32_t hsize, uint32_t (&cell)[2], float (&frac)[2], u2_t (&raw)[4]) {
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const float pos = fmaf(scale, xy[d], 0.5f);
+        const float fl = floorf(pos);
+        frac[d] = pos - fl;
+        cell[d] = (uint32_t)(int32_t)fl;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const uint32_t cc[2] = {cell[0] + (uint32_t)(c & 1), cell[1] + (uint32_t)((c >> 1) & 1)};
+        raw[c] = *reinterpret_cast<const u2_t*>(table + ((size_t)row0 + grid_row<2>(cc, res, hsize)) * kF);
+    }
+}
+// encode_level<2, 4>'s arithmetic on already gathered entries: acc[f] = fma(w_c, v_c[f], acc[f]) over the corners in order
+__device__ __forceinline__ void blend_quad(const u2_t (&raw)[4], const float (&frac)[2], float (&acc)[kF]) {
+#pragma unroll
+    for (int f = 0; f < kF; ++f) acc[f] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float wc = 1.0f;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) wc = wc * ((c & (1 << d)) ? frac[d] : (1.0f - frac[d]));
+        const h4_t v = __builtin_bit_cast(h4_t, raw[c]);
+#pragma unroll
+        for (int f = 0; f < kF; ++f) acc[f] = fmaf(wc, (float)v[f], acc[f]);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_hash_dynamic3(const float* __restrict__ x, uint32_t x_stride, const float* __restrict__ off,
+                                                          uint32_t off_stride, uint32_t M, PlaneSet3 ps, float* __restrict__ out0,
+                                                          _Float16* __restrict__ out1, _Float16* __restrict__ out2) {
+    __shared__ float stage[3][kSamplesPerBlock][3 * kPlaneLevels + 1];
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const uint32_t m = blockIdx.x * kSamplesPerBlock + lane;
+    const uint32_t mm = m < M ? m : M - 1;
+    float p[3][3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float xd = x[(size_t)mm * x_stride + d];
+        p[0][d] = xd;
+        p[1][d] = ps.enabled[1] ? xd + off[(size_t)mm * off_stride + d] : xd;
+        p[2][d] = ps.enabled[2] ? xd + off[(size_t)mm * off_stride + 3 + d] : xd;
+    }
+    for (int item = wave; item < 3 * kPlaneLevels; item += 4) {
+        const int pl = item / kPlaneLevels, l = item - pl * kPlaneLevels;
+        const int ia = pl == 2 ? 1 : 0, ib = pl == 0 ? 1 : 2;
+        const GridMeta& g = ps.meta[pl];
+        const float scale = g.scale[l];
+        const uint32_t res = g.res[l], row0 = g.offset[l], rows = g.offset[l + 1] - g.offset[l];
+        // ---- base evaluation: gathers kept
+        uint32_t cell0[2];
+        float frac0[2];
+        u2_t lo0[4], hi0[4];
+        {
+            const float xy[2] = {p[0][ia], p[0][ib]};
+            gather_quad(xy, ps.ev[0].table_lo[pl], scale, res, row0, rows, cell0, frac0, lo0);
+            if (!ps.ev[0].same_slice) {
+                uint32_t c_[2];
+                float f_[2];
+                gather_quad(xy, ps.ev[0].table_hi[pl], scale, res, row0, rows, c_, f_, hi0);
+            }
+            float f_lo[kF], f_hi[kF];
+            blend_quad(lo0, frac0, f_lo);
+#pragma unroll
+            for (int i = 0; i < kF; ++i) f_lo[i] = r16(f_lo[i]);
+            if (!ps.ev[0].same_slice) {
+                blend_quad(hi0, frac0, f_hi);
+#pragma unroll
+                for (int i = 0; i < kF; ++i) f_hi[i] = r16(f_hi[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < kF; ++i) f_hi[i] = 0.0f;
+            }
+            stage[0][lane][item] = blend_reduce<0>(f_lo, f_hi, ps.ev[0]);
+        }
+        // ---- neighbour evaluations (regime 1)
+#pragma unroll
+        for (int e = 1; e < 3; ++e) {
+            if (!ps.enabled[e]) continue;
+            const TimeSet& pe = ps.ev[e];
+            const float xy[2] = {e == 1 ? p[1][ia] : p[2][ia], e == 1 ? p[1][ib] : p[2][ib]};
+            uint32_t cell[2];
+            float frac[2];
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const float pos = fmaf(scale, xy[d], 0.5f);
+                const float fl = floorf(pos);
+                frac[d] = pos - fl;
+                cell[d] = (uint32_t)(int32_t)fl;
+            }
+            u2_t lo[4], hi[4];
+            const bool reuse = ps.share[e] && cell[0] == cell0[0] && cell[1] == cell0[1];
+            if (reuse) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { lo[c] = lo0[c]; hi[c] = hi0[c]; }
+            } else {
+                uint32_t c_[2];
+                float f_[2];
+                gather_quad(xy, pe.table_lo[pl], scale, res, row0, rows, c_, f_, lo);
+                if (!pe.same_slice) gather_quad(xy, pe.table_hi[pl], scale, res, row0, rows, c_, f_, hi);
+            }
+            float f_lo[kF], f_hi[kF];
+            blend_quad(lo, frac, f_lo);
+#pragma unroll
+            for (int i = 0; i < kF; ++i) f_lo[i] = r16(f_lo[i]);
+            if (!pe.same_slice) {
+                blend_quad(hi, frac, f_hi);
+#pragma unroll
+                for (int i = 0; i < kF; ++i) f_hi[i] = r16(f_hi[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < kF; ++i) f_hi[i] = 0.0f;
+            }
+            stage[e][lane][item] = blend_reduce<1>(f_lo, f_hi, pe);
+        }
+    }
+    __syncthreads();
+    const uint32_t n_rows = min((uint32_t)kSamplesPerBlock, M - blockIdx.x * kSamplesPerBlock);
+    constexpr int kOut = 3 * kPlaneLevels;
+    for (uint32_t c = threadIdx.x; c < n_rows * kOut; c += kBlock) {
+        const uint32_t row = c / kOut, col = c - row * kOut;
+        const size_t o = (size_t)(blockIdx.x * kSamplesPerBlock + row) * kOut + col;
+        out0[o] = stage[0][row][col];
+        if (ps.enabled[1]) out1[o] = (_Float16)stage[1][row][col];
+        if (ps.enabled[2]) out2[o] = (_Float16)stage[2][row][col];
     }
 }
 
@@ -275,5 +428,45 @@ NVSF_API int nvsf_hashgrid4d_dynamic_bwd(const float* x, uint32_t x_stride, uint
     const unsigned long long waves = (items + 3) / 4;
     hipLaunchKernelGGL(k_hash_dynamic_bwd, dim3((uint32_t)((waves + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, stream, x, x_stride, M,
                        grad_out, pg, run);
+    return nvsf_launch_status();
+}
+
+// The three evaluations of one density query.  h_tables_f16: 18 device pointers = for evaluation e = 0, 1, 2: lo slice of pair 0,1,2 then
+// hi slice of pair 0,1,2; h_time: 18 floats = per evaluation {blend_lo, blend_hi, w0, w1, w2, w3}; h_flags: 9 ints = per evaluation
+// {enabled, same_slice, shares the slice tables of evaluation 0}.  out0 fp32 [M,24] (regime 0), out1 / out2 fp16 [M,24] (regime 1).
+// offsets fp32 [M, off_stride >= 6]: columns 0..2 warp evaluation 1, columns 3..5 evaluation 2.
+NVSF_API int nvsf_hashgrid4d_dynamic3_fwd(const float* x, uint32_t x_stride, const float* offsets, uint32_t off_stride, uint32_t M,
+                                          const void* const* h_tables_f16, const float* h_scales, const uint32_t* h_res,
+                                          const uint32_t* h_offsets, const float* h_time, const int* h_flags, float* out0, void* out1,
+                                          void* out2, hipStream_t stream) {
+    if (M == 0) return NVSF_OK;
+    REQUIRE(x && h_tables_f16 && h_time && h_flags && out0 && x_stride >= 3);
+    PlaneSet3 ps;
+    for (int p = 0; p < 3; ++p) {
+        const int st = fill_meta(ps.meta[p], kPlaneLevels, h_scales + p * kPlaneLevels, h_res + p * kPlaneLevels, h_offsets + p * (kPlaneLevels + 1));
+        if (st != NVSF_OK) return st;
+    }
+    for (int e = 0; e < 3; ++e) {
+        ps.enabled[e] = e == 0 ? 1 : h_flags[3 * e];
+        ps.share[e] = h_flags[3 * e + 2];
+        TimeSet& pe = ps.ev[e];
+        pe.same_slice = h_flags[3 * e + 1];
+        for (int p = 0; p < 3; ++p) {
+            pe.table_lo[p] = reinterpret_cast<const _Float16*>(h_tables_f16[6 * e + p]);
+            pe.table_hi[p] = reinterpret_cast<const _Float16*>(h_tables_f16[6 * e + 3 + p]);
+            if (ps.enabled[e]) {
+                REQUIRE(pe.table_lo[p] && (pe.same_slice || pe.table_hi[p]));
+                REQUIRE((reinterpret_cast<uintptr_t>(pe.table_lo[p]) & 7u) == 0 && (reinterpret_cast<uintptr_t>(pe.table_hi[p]) & 7u) == 0);
+            }
+        }
+        pe.blend_lo = h_time[6 * e]; pe.blend_hi = h_time[6 * e + 1];
+        for (int i = 0; i < 4; ++i) pe.lag[i] = h_time[6 * e + 2 + i];
+        if (e > 0 && ps.enabled[e]) {
+            REQUIRE(offsets && off_stride >= 6 && (e == 1 ? out1 : out2));
+            if (ps.share[e]) REQUIRE(pe.same_slice == ps.ev[0].same_slice);
+        }
+    }
+    hipLaunchKernelGGL(k_hash_dynamic3, dim3(cdiv(M, kSamplesPerBlock)), dim3(kBlock), 0, stream, x, x_stride, offsets, off_stride, M, ps, out0,
+                       reinterpret_cast<_Float16*>(out1), reinterpret_cast<_Float16*>(out2));
     return nvsf_launch_status();
 }

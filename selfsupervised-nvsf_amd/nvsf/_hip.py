@@ -43,6 +43,7 @@ SIGNATURES = {
     "nvsf_planes_fwd": [_P, _U, _P, _U, _U, _P, _I, _P, _P],
     "nvsf_planes_bwd": [_P, _U, _P, _U, _U, _P, _I, _P, _P, _P, _P],
     "nvsf_hashgrid4d_dynamic_fwd": [_P, _U, _P, _U, _U, _U, _P, _P, _P, _P, _P, _I, _I, _P],
+    "nvsf_hashgrid4d_dynamic3_fwd": [_P, _U, _P, _U, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "nvsf_hashgrid4d_dynamic_bwd": [_P, _U, _U, _P, _P, _P, _P, _I, _P, _P],
     "nvsf_hashgrid3d_lagrange_fwd": [_P, _U, _U, _P, _U, _U, _P, _P, _P, _P, _P],
     "nvsf_density_dynamic_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _U, _P, _P, _P, _P],
@@ -119,6 +120,10 @@ def host_f32(values):
 
 def host_u32(values):
     return (ctypes.c_uint32 * len(values))(*[int(v) for v in values])
+
+
+def host_i32(values):
+    return (ctypes.c_int * len(values))(*[int(v) for v in values])
 
 
 def call(name, *args):

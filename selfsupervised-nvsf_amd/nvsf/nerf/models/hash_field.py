@@ -175,6 +175,69 @@ class HashGrid4D(nn.Module):
                   int(offset_col), M, h_tables, h_scales, h_res, h_off, h_time, 1 if k1 == k2 else 0, 1 if fp16_regime else 0, _hip.ptr(out))
         return out
 
+    def training_fused3(self, x, t, t_host, flow, frame_idx, num_frames):
+        """With autograd recording: (hash_d, hash_1, hash_2) of one density query from one forward launch + the fused
+        table-gradient kernel (HashDyn3Fn), or None when the fused training path does not apply."""
+        first = self.hash_dynamic[0]
+        if not (torch.is_grad_enabled() and torch.is_tensor(t) and t.dim() > 0 and not x.requires_grad and first.n_levels == 8
+                and first.n_features_per_level == 4 and first.num_basis == 4 and os.environ.get("NVSF_HASH4D_TRAIN", "fused") == "fused"):
+            return None
+        idx = np.float32(t_host) * np.float32(first.time_resolution - 1)
+        k1, k2 = int(math.floor(idx)), int(math.ceil(idx))
+        nb = []
+        for col, frame in ((0, frame_idx + 1), (3, frame_idx - 1)):
+            nb.append((torch.tensor(frame / num_frames), float(np.float32(frame / num_frames)), col) if 0 <= frame <= num_frames - 1 else None)
+        if nb[0] is None and nb[1] is None:
+            return None
+        params = [pl.hash_t[k1].params for pl in self.hash_dynamic] + [pl.hash_t[k2].params for pl in self.hash_dynamic]
+        return HashDyn3Fn.apply(self, x, t, t_host, k1, k2, flow, nb[0], nb[1], *params)
+
+    def forward_dynamic3(self, x, t, t_host, offsets, neighbours):
+        """No-autograd: the dynamic features of one density query in one launch (csrc/hashgrid4d.hip, k_hash_dynamic3):
+        at (x, t) [fp32 regime] and, for each entry (t_n 0-dim tensor, its host value, first offset column) | None of
+        `neighbours`, at (x + offsets[:, col:col+3], t_n) [fp16 regime].  Returns (hash_d, hash_1 | None, hash_2 | None),
+        bit-identical to the separate forward_dynamic calls."""
+        from nvsf import _hip
+        import ctypes
+        first = self.hash_dynamic[0]
+        R = first.time_resolution
+        if first.n_levels != 8 or first.n_features_per_level != 4 or first.num_basis != 4:
+            raise NotImplementedError("fused HashGridT kernel: 8 levels x 4 features, 4 Lagrange nodes")
+        assert neighbours[0] is None or neighbours[0][2] == 0
+        assert neighbours[1] is None or neighbours[1][2] == 3
+        evals = [(t, t_host)] + [None if n is None else (n[0], n[1]) for n in neighbours]
+        tables, h_time, flags, base = [], [], [], None
+        for e, ev in enumerate(evals):
+            if ev is None:
+                tables += [0] * 6
+                h_time += [0.0] * 6
+                flags += [0, 0, 0]
+                continue
+            te, te_host = ev
+            idx = np.float32(te_host) * np.float32(R - 1)
+            k1, k2 = int(math.floor(idx)), int(math.ceil(idx))
+            on_device = torch.is_tensor(te) and te.is_cuda
+            lag = lagrange_weights_host(te_host, 4, reciprocal_division=on_device)
+            tables += [pl.hash_t[k1].table_f16().data_ptr() for pl in self.hash_dynamic] + [pl.hash_t[k2].table_f16().data_ptr() for pl in self.hash_dynamic]
+            h_time += [float(np.float32(k2) - idx), float(idx - np.float32(k1))] + lag
+            if e == 0:
+                base = (k1, k2)
+            flags += [1, 1 if k1 == k2 else 0, 1 if (k1, k2) == base else 0]
+        specs = [pl.hash_t[0].spec for pl in self.hash_dynamic]
+        x = x.float().contiguous()
+        M, dev = x.shape[0], x.device
+        off = offsets.float()
+        if off.dim() != 2 or off.stride(1) != 1:
+            off = off.contiguous()
+        out0 = torch.empty(M, 24, dtype=torch.float32, device=dev)
+        out1 = torch.empty(M, 24, dtype=torch.float16, device=dev) if neighbours[0] is not None else None
+        out2 = torch.empty(M, 24, dtype=torch.float16, device=dev) if neighbours[1] is not None else None
+        _hip.call("nvsf_hashgrid4d_dynamic3_fwd", _hip.ptr(x), x.shape[1], _hip.ptr_rows(off), off.stride(0), M, (ctypes.c_void_p * 18)(*tables),
+                  _hip.host_f32([v for s in specs for v in s.scales]), _hip.host_u32([v for s in specs for v in s.res]),
+                  _hip.host_u32([v for s in specs for v in s.offsets]), _hip.host_f32(h_time), _hip.host_i32(flags), _hip.ptr(out0),
+                  _hip.ptr(out1), _hip.ptr(out2))
+        return out0, out1, out2
+
     def forward(self, x, t, t_host=None):
         static, dynamic = self.forward_static(x), self.forward_dynamic(x, t, t_host)
         return [static, dynamic] if self.decompose else torch.cat([static, dynamic], dim=-1)
@@ -195,6 +258,10 @@ class HashDynFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
+        return HashDynFn._backward(ctx, grad_out)
+
+    @staticmethod
+    def _backward(ctx, grad_out):
         from nvsf import _hip
         import ctypes
         (x,) = ctx.saved_tensors
@@ -218,3 +285,24 @@ class HashDynFn(torch.autograd.Function):
         if same:  # the same parameter tensors were passed twice: the whole gradient goes to the first occurrence
             grads = grads + [None, None, None]
         return (None, None, None, None, None, None, *grads)
+
+
+class HashDyn3Fn(torch.autograd.Function):
+    """The three space-time evaluations of one density query with autograd on the first: (hash_d, hash_1, hash_2) from ONE
+    forward launch (k_hash_dynamic3); the neighbour outputs carry no gradient, as in the reference (network_dynamic.py:244-262
+    evaluates them under no_grad), the table gradients of hash_d come from the fused backward kernel."""
+
+    @staticmethod
+    def forward(ctx, enc, x, t, t_host, k1, k2, offsets, nb1, nb2, *params):
+        x = x.float().contiguous()
+        out0, out1, out2 = enc.forward_dynamic3(x, t, t_host, offsets.detach(), [nb1, nb2])
+        ctx.save_for_backward(x)
+        ctx.enc, ctx.t, ctx.t_host, ctx.k1, ctx.k2 = enc, t, t_host, k1, k2
+        outs = [out0, out1 if out1 is not None else out0.new_zeros(0), out2 if out2 is not None else out0.new_zeros(0)]
+        ctx.mark_non_differentiable(outs[1], outs[2])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, grad_out, _g1, _g2):
+        g = HashDynFn._backward(ctx, grad_out)  # (None x 6, *grads)
+        return (None,) * 9 + tuple(g[6:])

@@ -89,18 +89,26 @@ class NeRFNetwork(NeRFRenderer):
 
         if not torch.is_grad_enabled() and t.shape[0] == 1 and os.environ.get("NVSF_DYNAMIC_FUSED", "1") != "0":
             return self._dynamic_features_fused(x, t, t_host, frame_idx, hash_enc, planes_enc)
-        hash_s, hash_d = hash_enc(x, t, t_host)
         t_col = t.repeat(x.shape[0], 1) if t.shape[0] == 1 else t
         xt = torch.cat([x, t_col], dim=-1)
         plane_s, plane_d = planes_enc(xt)
         flow = self.flow_net(xt, t_host)
+        fused3 = hash_enc.training_fused3(x, t, t_host, flow, frame_idx, self.num_frames)
+        if fused3 is not None:
+            hash_s = hash_enc.forward_static(x)
+            hash_d, hash_1f, hash_2f = fused3
+        else:
+            hash_s, hash_d = hash_enc(x, t, t_host)
 
         def neighbour(offset, frame):
             """dynamic features at the flow-warped position in an adjacent frame (:242-271)"""
             xn = x + offset
             tn = torch.tensor(frame / self.num_frames)
-            with torch.no_grad():
-                hn = hash_enc.forward_dynamic(xn, tn, float(np.float32(frame / self.num_frames)))
+            if fused3 is not None:
+                hn = hash_1f if frame > frame_idx else hash_2f
+            else:
+                with torch.no_grad():
+                    hn = hash_enc.forward_dynamic(xn, tn, float(np.float32(frame / self.num_frames)))
             # the reference builds this column on the host and copies it (t1.repeat(N, 1).to(device), :250): a pageable
             # multi-megabyte H2D copy that also drains the stream; the same fp32 value is written on the device instead
             t_coln = torch.full((xn.shape[0], 1), float(tn), dtype=torch.float32, device=xn.device)
@@ -125,13 +133,18 @@ class NeRFNetwork(NeRFRenderer):
         xt = torch.cat([x, t.float().expand(x.shape[0], 1)], dim=-1)
         plane_s, plane_d = planes_enc(xt)
         flow = self.flow_net(xt, t_host)
-        hash_s, hash_d = hash_enc(x, t, t_host)
-        out = [plane_s, plane_d, plane_d, plane_d, hash_s, hash_d, hash_d, hash_d]
+        hash_s = hash_enc.forward_static(x)
+        nb = []
+        for col, frame in ((0, frame_idx + 1), (3, frame_idx - 1)):
+            # 0-dim CPU tensor as in the reference (:244, :260): the fp16 regime of HashGridT
+            nb.append((torch.tensor(frame / F), float(np.float32(frame / F)), col) if 0 <= frame <= F - 1 else None)
+        # ONE launch for the three space-time evaluations: a neighbour re-uses the base gathers wherever its cell coincides
+        hash_d, hash_1, hash_2 = hash_enc.forward_dynamic3(x, t, t_host, flow, nb)
+        out = [plane_s, plane_d, plane_d, plane_d, hash_s, hash_d, hash_d if hash_1 is None else hash_1, hash_d if hash_2 is None else hash_2]
         for slot, col, frame in ((0, 0, frame_idx + 1), (1, 3, frame_idx - 1)):
             if not 0 <= frame <= F - 1:
                 continue
-            tn = torch.tensor(frame / F)  # 0-dim CPU tensor as in the reference (:244, :260): the fp16 regime of HashGridT
-            out[6 + slot] = hash_enc.forward_dynamic(x, tn, float(np.float32(frame / F)), offset=flow, offset_col=col)
+            tn = nb[slot][0]
             xtn = torch.empty_like(xt)
             torch.add(x, flow[:, col:col + 3], out=xtn[:, :3])
             xtn[:, 3] = float(tn)

@@ -10,6 +10,11 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 m = NeRFNetwork(time_resolution=8, num_frames=S.NUM_FRAMES, bound=S.BOUND, min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH).to(dev).eval()
 print("params (M):", sum(p.numel() for p in m.parameters()) / 1e6)
+if os.environ.get("FLOW_SCALE"):  # scene flow of this magnitude (unit cube units) instead of the ~0 of a fresh initialisation
+    with torch.no_grad():
+        for p in m.flow_net.grid_enc.parameters():
+            p.uniform_(-0.5, 0.5)
+        m.flow_net.mlp[-1].weight.normal_(0, float(os.environ["FLOW_SCALE"]) * 0.6)
 rng = np.random.default_rng(0)
 N, T = int(os.environ.get("N", 2048)), int(os.environ.get("T", 768))
 lo, ld = S.lidar_rays(N, rng); co, cd = S.camera_rays(N, rng)
@@ -24,4 +29,8 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 K = 5
 for _ in range(K): step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
+with torch.no_grad():
+    xs = torch.rand(100000, 3, device=dev)
+    fl = m.flow_net(torch.cat([xs, torch.full((100000, 1), 0.5, device=dev)], -1), 0.5)
+print(f"mean |flow| = {float(fl.abs().mean()):.2e} (finest / coarsest space-time cell: {1/32768:.1e} / {1/512:.1e})")
 print(f"RD forward: {dt*1e3:.2f} ms/step, {2*N/dt:.0f} rays/s, peak mem {torch.cuda.max_memory_allocated()/2**30:.2f} GiB")
