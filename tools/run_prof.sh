@@ -22,6 +22,7 @@ timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCL
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_train -- python3 $R/tools/bench_train.py > $O/kt_train.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_occ -- python3 $R/tools/bench_occupancy.py > $O/kt_occ.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_dyn -- python3 $R/tools/bench_dynamic.py > $O/kt_dyn.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_dyn_train -- python3 $R/tools/bench_train_dynamic.py > $O/kt_dyn_train.log 2>&1
 # 7. roofline tools of the extension kernels and the stand-alone operators
 timeout 600 python3 $R/tools/bench_raymarching.py > $O/raymarching.json 2> $O/raymarching.log
 timeout 600 python3 $R/tools/bench_field_ops.py > $O/field_ops.json 2> $O/field_ops.log
