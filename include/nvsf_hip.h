@@ -247,11 +247,12 @@ int nvsf_hashgrid3d_lagrange_fwd(const float* x, uint32_t x_stride, uint32_t M, 
  * neighbour features (0.5, 0.25, 0.25), concatenation to 120 features, sigma_net (120 -> 64 -> 16).
  * plane_* fp32 [M,32]; hash_s fp16 [M,32]; hash_d fp32 [M,24]; hash_1/hash_2 [M,24] fp16 (flag != 0) or fp32.
  * Either out_h fp32 [M,16] (the 16 network outputs) or, when out_h is NULL, sigmas fp32 [M] = exp(h0) and
- * geo fp16 [M,16] = (h1..h15, 1.0).  All pointers 16-byte aligned. */
+ * geo fp16 [M,16] = (h1..h15, 1.0).  All pointers 16-byte aligned.  * x_f16_out (optional, fp16 [M,128]): the assembled, rounded network input incl. the ones padding -- what a training step
+ * keeps for nvsf_mlp_bwd. */
 int nvsf_density_dynamic_fwd(const float* plane_s, const float* plane_d, const float* plane_1, const float* plane_2,
                              const void* hash_s_f16, const float* hash_d, const void* hash_1, int hash_1_is_f16,
                              const void* hash_2, int hash_2_is_f16, uint32_t M, const void* sigma_weights_f16,
-                             float* out_h, float* sigmas, void* geo_f16, nvsf_stream_t stream);
+                             float* out_h, float* sigmas, void* geo_f16, void* x_f16_out, nvsf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Section 4: fused kernels of the uniform-sampling render (BASELINE config 2 hot path).

@@ -40,7 +40,7 @@ __device__ __forceinline__ float r16(float v) { return (float)(_Float16)v; }
 template <int ROT>
 __global__ __launch_bounds__(kBlock) void k_density_dynamic(DynFeat f, uint32_t M, const _Float16* __restrict__ w_sigma,
                                                             float* __restrict__ out_h, float* __restrict__ sigmas,
-                                                            _Float16* __restrict__ geo) {
+                                                            _Float16* __restrict__ geo, _Float16* __restrict__ x_out) {
     const int lane = lane_id(), g = lane >> 4, sl = lane & 15;
     half8_t w0[kHidTiles][4];
 #pragma unroll
@@ -84,6 +84,10 @@ __global__ __launch_bounds__(kBlock) void k_density_dynamic(DynFeat f, uint32_t 
 #pragma unroll
             for (int j = 0; j < 8; ++j) xf[3][j] = (_Float16)1.0f;  // columns 120..127: tcnn pads the network input with ones
         }
+        if (x_out && m_raw < M) {  // the assembled, rounded network input (training keeps it for the backward pass)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) *reinterpret_cast<half8_t*>(x_out + m * 128 + 32 * s + 8 * g) = xf[s];
+        }
         float4_t acc[kHidTiles];
 #pragma unroll
         for (int t = 0; t < kHidTiles; ++t) {
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void k_density_dynamic(DynFeat f, uint32_t 
 NVSF_API int nvsf_density_dynamic_fwd(const float* plane_s, const float* plane_d, const float* plane_1, const float* plane_2,
                                       const void* hash_s_f16, const float* hash_d, const void* hash_1, int hash_1_is_f16, const void* hash_2,
                                       int hash_2_is_f16, uint32_t M, const void* sigma_weights_f16, float* out_h, float* sigmas,
-                                      void* geo_f16, hipStream_t stream) {
+                                      void* geo_f16, void* x_f16_out, hipStream_t stream) {
     if (M == 0) return NVSF_OK;
     REQUIRE(plane_s && plane_d && plane_1 && plane_2 && hash_s_f16 && hash_d && hash_1 && hash_2 && sigma_weights_f16);
     REQUIRE(out_h || (sigmas && geo_f16));
@@ -131,10 +135,12 @@ NVSF_API int nvsf_density_dynamic_fwd(const float* plane_s, const float* plane_d
     const uint32_t n_tiles = (M + 15) / 16;
     const uint32_t blocks = n_tiles / kWavesPerBlock + 1 < 2048u ? n_tiles / kWavesPerBlock + 1 : 2048u;
     const _Float16* w = reinterpret_cast<const _Float16*>(sigma_weights_f16);
+    REQUIRE((reinterpret_cast<uintptr_t>(x_f16_out) & 15u) == 0);
+    _Float16* xo = reinterpret_cast<_Float16*>(x_f16_out);
     if (out_h)
-        hipLaunchKernelGGL(k_density_dynamic<0>, dim3(blocks), dim3(kBlock), 0, stream, f, M, w, out_h, (float*)nullptr, (_Float16*)nullptr);
+        hipLaunchKernelGGL(k_density_dynamic<0>, dim3(blocks), dim3(kBlock), 0, stream, f, M, w, out_h, (float*)nullptr, (_Float16*)nullptr, xo);
     else
         hipLaunchKernelGGL(k_density_dynamic<1>, dim3(blocks), dim3(kBlock), 0, stream, f, M, w, (float*)nullptr, sigmas,
-                           reinterpret_cast<_Float16*>(geo_f16));
+                           reinterpret_cast<_Float16*>(geo_f16), xo);
     return nvsf_launch_status();
 }

@@ -156,6 +156,12 @@ class NeRFNetwork(NeRFRenderer):
         if not torch.is_grad_enabled():
             # fused tail (csrc/density_dynamic.hip): neighbour blend + concatenation + density MLP in one kernel
             h = self._density_tail_fused(plane_s, plane_d, plane_1, plane_2, hash_s, hash_d, hash_1, hash_2)
+        elif (os.environ.get("NVSF_DENSITY_TAIL_TRAIN", "fused") == "fused" and self.sigma_net.spec.in_cols == 128
+              and self.sigma_net.spec.n_hidden == 1 and hash_s.dtype == torch.float16 and plane_s.dtype == torch.float32
+              and hash_d.dtype == torch.float32 and not hash_1.requires_grad and not hash_2.requires_grad):
+            # neighbour blend + concatenation + density MLP as ONE forward launch that also leaves the rounded network input
+            # for the fused MLP backward; no [M,120] fp32 concatenation, no blend temporaries, in either direction
+            h = DensityTailFn.apply(self, plane_s, plane_d, plane_1, plane_2, hash_s, hash_d, hash_1, hash_2, self.sigma_net.params)
         else:
             plane_d = 0.5 * plane_d + 0.25 * (plane_1 + plane_2)
             hash_d = 0.5 * hash_d + 0.25 * (hash_1 + hash_2)
@@ -177,7 +183,7 @@ class NeRFNetwork(NeRFRenderer):
             image = ops.heads_uniform(weights, geo, rays_d, weights_sum, False, self.color_net.weights_f16(), None, bg_host)
         return z_vals, weights, weights_sum, depth, image
 
-    def _density_tail_fused(self, plane_s, plane_d, plane_1, plane_2, hash_s, hash_d, hash_1, hash_2, sigma_geo=False):
+    def _density_tail_fused(self, plane_s, plane_d, plane_1, plane_2, hash_s, hash_d, hash_1, hash_2, sigma_geo=False, keep_input=False):
         from nvsf import _hip
         if self.sigma_net.spec.in_cols != 128 or self.sigma_net.spec.n_hidden != 1:
             raise NotImplementedError("fused density tail: 120 features, one hidden layer")
@@ -190,11 +196,12 @@ class NeRFNetwork(NeRFRenderer):
         if sigma_geo:
             sigmas = torch.empty(M, dtype=torch.float32, device=dev)
             geo = torch.empty(M, 16, dtype=torch.float16, device=dev)
-            _hip.call("nvsf_density_dynamic_fwd", *args, None, _hip.ptr(sigmas), _hip.ptr(geo))
+            _hip.call("nvsf_density_dynamic_fwd", *args, None, _hip.ptr(sigmas), _hip.ptr(geo), None)
             return sigmas, geo
         h = torch.empty(M, 16, dtype=torch.float32, device=dev)
-        _hip.call("nvsf_density_dynamic_fwd", *args, _hip.ptr(h), None, None)
-        return h
+        x16 = torch.empty(M, 128, dtype=torch.float16, device=dev) if keep_input else None
+        _hip.call("nvsf_density_dynamic_fwd", *args, _hip.ptr(h), None, None, _hip.ptr(x16))
+        return (h, x16) if keep_input else h
 
     def color(self, x, d, cal_lidar_color=False, mask=None, geo_feat=None, **kwargs):
         dense_mask = None
@@ -230,3 +237,45 @@ class NeRFNetwork(NeRFRenderer):
             params.append({"params": self.encoder_bg.parameters(), "lr": lr})
             params.append({"params": self.bg_net.parameters(), "lr": lr})
         return params
+
+
+class DensityTailFn(torch.autograd.Function):
+    """h = sigma_net([plane_s | 0.5 plane_d + 0.25 (plane_1 + plane_2) | hash_s | 0.5 hash_d + 0.25 (hash_1 + hash_2)])
+    (network_dynamic.py:273-287) with autograd: forward = csrc/density_dynamic.hip (also writes the rounded input),
+    backward = nvsf_mlp_bwd on that input; the input gradient is handed back slice by slice with the blend factors."""
+
+    @staticmethod
+    def forward(ctx, net, plane_s, plane_d, plane_1, plane_2, hash_s, hash_d, hash_1, hash_2, params):
+        h, x16 = net._density_tail_fused(plane_s.detach(), plane_d.detach(), plane_1.detach(), plane_2.detach(), hash_s.detach(),
+                                         hash_d.detach(), hash_1.detach(), hash_2.detach(), keep_input=True)
+        ctx.save_for_backward(x16, net.sigma_net.weights_f16())
+        ctx.spec = net.sigma_net.spec
+        ctx.hash_s_dtype = hash_s.dtype
+        return h
+
+    @staticmethod
+    def backward(ctx, grad_h):
+        x16, w16 = ctx.saved_tensors
+        spec = ctx.spec
+        need = ctx.needs_input_grad
+        need_x = any(need[1:9])
+        grad_x, gw = ops.mlp_backward(x16[:, :spec.n_in], w16, spec, grad_h, need_grad_x=need_x)
+        out = [None] * 10
+        if need_x:
+            g_pd = grad_x[:, 32:64]
+            quarter = 0.25 * g_pd if (need[3] or need[4]) else None
+            if need[1]:
+                out[1] = grad_x[:, 0:32]
+            if need[2]:
+                out[2] = 0.5 * g_pd
+            if need[3]:
+                out[3] = quarter
+            if need[4]:
+                out[4] = quarter
+            if need[5]:
+                out[5] = grad_x[:, 64:96].to(ctx.hash_s_dtype)
+            if need[6]:
+                out[6] = 0.5 * grad_x[:, 96:120]
+        if need[9]:
+            out[9] = gw
+        return tuple(out)

@@ -193,6 +193,46 @@ def test_fused_dynamic_features_equal_the_separate_launches(dev, flow_scale, t_v
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("t_val", [0.4, 0.0])  # interior frame (two neighbours) / first frame (one neighbour aliases the current frame)
+def test_density_tail_training_path_equals_the_operator_path(dev, t_val, monkeypatch):
+    """DensityTailFn (blend + concatenation + density MLP in one forward launch, fused MLP backward, gradient handed back per
+    input with the blend factors) against the operator path (torch blends, torch.cat, tcnn.Network autograd): density outputs
+    and every parameter gradient of a density query."""
+    from nvsf.nerf.models.network_dynamic import NeRFNetwork
+    x = (torch.rand(6000, 3, generator=torch.Generator().manual_seed(1)) * 2 - 1).to(dev) * 1.9
+    t = torch.tensor([[t_val]], device=dev)
+    res = {}
+    for mode in ("fused", "ops"):
+        monkeypatch.setenv("NVSF_DENSITY_TAIL_TRAIN", mode)
+        torch.manual_seed(4)
+        m = NeRFNetwork(time_resolution=4, num_frames=16, bound=2.0, min_resolution=16, base_resolution=32, max_resolution=512,
+                        log2_hashmap_size=13).to(dev)
+        with torch.no_grad():
+            for n_, p in m.named_parameters():
+                if "hash" in n_ and p.numel() > 1000:
+                    p.uniform_(-0.5, 0.5)
+        d = m.density(x, t, cal_lidar_color=True)
+        g = torch.Generator().manual_seed(2)
+        ws, wg = torch.randn(d["sigma"].shape, generator=g).to(dev), torch.randn(d["geo_feat"].shape, generator=g).to(dev)
+        ((d["sigma"] * ws).sum() + (d["geo_feat"].float() * wg).sum()).backward()
+        res[mode] = (d["sigma"].detach().clone(), d["geo_feat"].detach().float().clone(),
+                     {n_: p.grad.clone() for n_, p in m.named_parameters() if p.grad is not None})
+    torch.testing.assert_close(res["fused"][0], res["ops"][0], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(res["fused"][1], res["ops"][1], rtol=1e-5, atol=1e-6)
+    assert set(res["fused"][2]) == set(res["ops"][2])
+    n = 0
+    for name, gr in res["ops"][2].items():
+        gf = res["fused"][2][name]
+        scale = float(gr.abs().max())
+        if scale == 0.0:
+            assert not gf.any(), name
+            continue
+        # the hash features' gradient passes through fp16 in the operator path and stays fp32 in the fused one
+        assert float((gf - gr).abs().max()) <= 2e-2 * scale and float((gf - gr).abs().mean()) <= 2e-3 * scale, name
+        n += 1
+    assert n >= 20
+
+
 def test_flow_mlp_fused_training_path_against_fp32_autograd(dev):
     """flow_field.FlowMlpFn (the Linear layers on the fused MFMA forward / backward kernels, used by the loss-scaled training
     step) against torch's fp32 Linear stack: values and all gradients at fp16 accuracy."""
