@@ -3,6 +3,8 @@ time -> bias-free MLP 32 -> 64 -> 64 -> 6 (forward and backward flow).  Same con
 (`grid_enc.params`, `mlp.<i>.weight`) and arithmetic as /root/reference/nvsf/nerf/models/flow_field.py:41-133.
 The three small dense layers are `nn.Linear` modules as in the reference (same state_dict keys; last layer
 initialised N(0, 1e-3), :103); with autograd they run through torch, without it on the fused MFMA MLP kernel."""
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -40,8 +42,14 @@ class FlowField(nn.Module):
         `t_host` (the value of t, if the caller already has it on the host) avoids a device->host read."""
         t = xt[0, 3]
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            feat = self.grid_enc.encode_columns(xt, (0, 1, 2)).float()
-            red = lagrange_reduce(feat, t, self.n_levels, self.n_features_per_level, self.num_basis)
+            if (os.environ.get("NVSF_FLOW_GRID_TRAIN", "fused") == "fused" and self.n_features_per_level == 8 and self.num_basis == 4
+                    and not xt.requires_grad):
+                # grid lookup + Lagrange reduction as the fused forward kernel, the table gradient straight from dL/d(reduced)
+                t_h = float(t) if t_host is None else t_host
+                red = FlowGridFn.apply(self, xt.float().contiguous(), t_h, self.grid_enc.params)
+            else:
+                feat = self.grid_enc.encode_columns(xt, (0, 1, 2)).float()
+                red = lagrange_reduce(feat, t, self.n_levels, self.n_features_per_level, self.num_basis)
             if self.mlp_mode() == "fused" and self._fused_mlp_ok():
                 # the mixed-precision training run: the Linear layers on the fused MFMA forward / backward kernels (what
                 # autocast makes of them in the reference's Trainer), instead of three fp32 GEMMs + two ReLU launches forward
@@ -49,17 +57,10 @@ class FlowField(nn.Module):
                 lin = [m for m in self.mlp if isinstance(m, nn.Linear)]
                 return FlowMlpFn.apply(red, lin[0].weight, lin[1].weight, lin[2].weight)
             return self.mlp(red)
-        from nvsf import _hip
-        from nvsf.nerf.models.hash_field import lagrange_weights_host
         if self.n_features_per_level != 8 or self.num_basis != 4:
             raise NotImplementedError("fused flow grid kernel: 8 features per level, 4 Lagrange nodes")
         t_host = float(t) if t_host is None else t_host
-        spec = self.grid_enc.spec
-        xt = xt.float().contiguous()
-        M = xt.shape[0]
-        red = torch.empty(M, 2 * spec.L, dtype=torch.float32, device=xt.device)
-        _hip.call("nvsf_hashgrid3d_lagrange_fwd", _hip.ptr(xt), xt.shape[1], M, _hip.ptr(self.grid_enc.table_f16()), spec.L, spec.F,
-                  spec.h_scales, spec.h_res, spec.h_offsets, _hip.host_f32(lagrange_weights_host(t_host, 4, xt.is_cuda)), _hip.ptr(red))
+        red = self._grid_lagrange(xt.float().contiguous(), t_host)
         if self.mlp_mode() == "fused" and self._fused_mlp_ok():
             # NVSF_FLOW_MLP=fused (opt-in): the three bias-free layers on the fused MFMA MLP kernel -- fp16 operands, fp32
             # accumulation, i.e. what the reference's Linear layers compute under the Trainer's autocast, 6x faster than
@@ -67,6 +68,17 @@ class FlowField(nn.Module):
             # this repo is pinned against is fp32; the default therefore stays on torch.  Columns 6..15 are padding.
             return ops.mlp_forward(red, self._mlp_weights_f16(), self._mlp_spec)[:, :6]
         return self.mlp(red)
+
+    def _grid_lagrange(self, xt, t_host):
+        """[M, >=3] positions -> fp32 [M, 2 L]: 3-D grid lookup + cubic Lagrange reduction over the 4 feature chunks (one kernel)."""
+        from nvsf import _hip
+        from nvsf.nerf.models.hash_field import lagrange_weights_host
+        spec = self.grid_enc.spec
+        M = xt.shape[0]
+        red = torch.empty(M, 2 * spec.L, dtype=torch.float32, device=xt.device)
+        _hip.call("nvsf_hashgrid3d_lagrange_fwd", _hip.ptr(xt), xt.shape[1], M, _hip.ptr(self.grid_enc.table_f16()), spec.L, spec.F,
+                  spec.h_scales, spec.h_res, spec.h_offsets, _hip.host_f32(lagrange_weights_host(t_host, 4, xt.is_cuda)), _hip.ptr(red))
+        return red
 
     def mlp_mode(self):
         """"torch" (fp32 Linear layers, the form the CPU fixtures pin) or "fused" (fp16 MFMA kernels = the reference under
@@ -120,3 +132,27 @@ class FlowMlpFn(torch.autograd.Function):
         grad_x, gw = ops.mlp_backward(x, w16, spec, grad_out, need_grad_x=ctx.needs_input_grad[0])
         g0, g1, g2 = spec.split(gw)
         return grad_x, g0.view(s0), g1.view(s1), g2[:s2[0]].contiguous().view(s2)
+
+
+class FlowGridFn(torch.autograd.Function):
+    """reduced = Lagrange_t(grid(x)) for the flow field with autograd on the grid table: forward = the fused kernel of the
+    no-grad path; backward expands dL/d(reduced) [M, 2L] to dL/d(features) [M, 8L] (feature 2i+e of a level gets w_i times
+    the gradient of reduced column e) and scatters it with the hash-grid backward kernel."""
+
+    @staticmethod
+    def forward(ctx, field, xt, t_host, params):
+        ctx.save_for_backward(xt)
+        ctx.field, ctx.t_host = field, t_host
+        return field._grid_lagrange(xt, t_host)
+
+    @staticmethod
+    def backward(ctx, grad_red):
+        from nvsf.nerf.models.hash_field import lagrange_weights_host
+        (xt,) = ctx.saved_tensors
+        field = ctx.field
+        spec = field.grid_enc.spec
+        w = torch.tensor(lagrange_weights_host(ctx.t_host, 4, xt.is_cuda), dtype=torch.float32, device=xt.device)
+        M = xt.shape[0]
+        g_feat = (grad_red.float().view(M, spec.L, 1, 2) * w.view(1, 1, 4, 1)).reshape(M, spec.L * 8)
+        grad_table = ops.hashgrid_backward(xt, (0, 1, 2), spec, g_feat)
+        return None, None, None, grad_table

@@ -188,7 +188,8 @@ def test_fused_dynamic_features_equal_the_separate_launches(dev, flow_scale, t_v
             feats = m._dynamic_features(m._unit_cube(x), t, True)
             dens = m.density(x, t, cal_lidar_color=True)
         outs[mode] = [f.float() for f in feats] + [dens["sigma"], dens["geo_feat"].float()]
-    assert float((m.flow_net(torch.cat([m._unit_cube(x), t.expand(x.shape[0], 1)], -1)).abs().mean())) > 0.1 * flow_scale
+    with torch.no_grad():
+        assert float(m.flow_net(torch.cat([m._unit_cube(x), t.expand(x.shape[0], 1)], -1)).abs().mean()) > 0.1 * flow_scale
     for a, b in zip(outs["1"], outs["0"]):
         assert torch.equal(a, b)
 
@@ -231,6 +232,31 @@ def test_density_tail_training_path_equals_the_operator_path(dev, t_val, monkeyp
         assert float((gf - gr).abs().max()) <= 2e-2 * scale and float((gf - gr).abs().mean()) <= 2e-3 * scale, name
         n += 1
     assert n >= 20
+
+
+def test_flow_grid_training_path_equals_the_operator_path(dev, monkeypatch):
+    """FlowGridFn (fused grid + Lagrange forward kernel, table gradient straight from dL/d(reduced)) against encoder ->
+    .float() -> lagrange_reduce through autograd: flows and the gradient of the grid table and of the Linear layers."""
+    from nvsf.nerf.models.flow_field import FlowField
+    xt = torch.cat([torch.rand(7000, 3, generator=torch.Generator().manual_seed(3)), torch.full((7000, 1), 0.43)], -1).to(dev)
+    res = {}
+    for mode in ("fused", "ops"):
+        monkeypatch.setenv("NVSF_FLOW_GRID_TRAIN", mode)
+        torch.manual_seed(6)
+        flow = FlowField(n_levels=16, n_features_per_level=8, base_resolution=32, max_resolution=1024, log2_hashmap_size=13).to(dev)
+        with torch.no_grad():
+            flow.grid_enc.params.uniform_(-0.5, 0.5)
+            flow.mlp[-1].weight.normal_(0, 0.2)
+        out = flow(xt)
+        w = torch.randn(out.shape, generator=torch.Generator().manual_seed(7)).to(dev) * 64.0  # what a loss scaler would supply
+        (out * w).sum().backward()
+        res[mode] = (out.detach().clone(), {n: p.grad.clone() for n, p in flow.named_parameters()})
+    torch.testing.assert_close(res["fused"][0], res["ops"][0], rtol=1e-5, atol=1e-7)
+    for name, gr in res["ops"][1].items():
+        gf = res["fused"][1][name]
+        scale = float(gr.abs().max())
+        # the operator path rounds dL/d(features) to fp16 on its way into the encoder, the fused path keeps fp32
+        assert float((gf - gr).abs().max()) <= 5e-3 * scale, name
 
 
 def test_flow_mlp_fused_training_path_against_fp32_autograd(dev):
