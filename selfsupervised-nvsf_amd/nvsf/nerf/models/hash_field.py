@@ -275,15 +275,19 @@ class HashDynFn(torch.autograd.Function):
         h_res = _hip.host_u32([v for s in specs for v in s.res])
         h_off = _hip.host_u32([v for s in specs for v in s.offsets])
         same = k1 == k2
-        grads = [torch.zeros(s.n_params, dtype=torch.float32, device=x.device) for s in specs]
-        if not same:
-            grads += [torch.zeros(s.n_params, dtype=torch.float32, device=x.device) for s in specs]
-        ptrs = [g.data_ptr() for g in grads] + ([0, 0, 0] if same else [])
+        # The two slices of a pair see the same cells and corner weights; their gradients differ by the scalar blend factors
+        # only (dL/dtable_lo = blend_lo G, dL/dtable_hi = blend_hi G with G = sum g lag_i w_c).  G is scattered ONCE -- half the
+        # atomics, which are what bounds this pass -- and scaled into the two gradients afterwards (tables of ~1 M floats).
+        acc = [torch.zeros(s.n_params, dtype=torch.float32, device=x.device) for s in specs]
+        ptrs = [g.data_ptr() for g in acc] + [0, 0, 0]
         g_out = grad_out.float().contiguous()
-        _hip.call("nvsf_hashgrid4d_dynamic_bwd", _hip.ptr(x), x.shape[1], x.shape[0], h_scales, h_res, h_off, h_time, 1 if same else 0,
+        _hip.call("nvsf_hashgrid4d_dynamic_bwd", _hip.ptr(x), x.shape[1], x.shape[0], h_scales, h_res, h_off, h_time, 1,
                   _hip.ptr(g_out), (ctypes.c_void_p * 6)(*ptrs))
         if same:  # the same parameter tensors were passed twice: the whole gradient goes to the first occurrence
-            grads = grads + [None, None, None]
+            grads = acc + [None, None, None]
+        else:
+            b_lo, b_hi = float(np.float32(k2) - idx), float(idx - np.float32(k1))
+            grads = [g * b_lo for g in acc] + [g * b_hi for g in acc]
         return (None, None, None, None, None, None, *grads)
 
 
