@@ -152,7 +152,12 @@ class FlowGridFn(torch.autograd.Function):
         field = ctx.field
         spec = field.grid_enc.spec
         w = torch.tensor(lagrange_weights_host(ctx.t_host, 4, xt.is_cuda), dtype=torch.float32, device=xt.device)
-        M = xt.shape[0]
-        g_feat = (grad_red.float().view(M, spec.L, 1, 2) * w.view(1, 1, 4, 1)).reshape(M, spec.L * 8)
-        grad_table = ops.hashgrid_backward(xt, (0, 1, 2), spec, g_feat)
+        # feature 2i+e of a level receives w_i * dL/d(reduced column e): the four chunks of an entry get the same scattered sum
+        # up to the scalar w_i.  Scatter G[row][e] = sum g_e w_corner ONCE on a 2-feature view of the grid (a quarter of the
+        # atomics, which bound this pass) and expand to the 8 features afterwards.
+        import copy
+        spec2 = copy.copy(spec)
+        spec2.F, spec2.n_params, spec2.n_output_dims = 2, spec.n_rows * 2, spec.L * 2
+        G = ops.hashgrid_backward(xt, (0, 1, 2), spec2, grad_red.float().contiguous())
+        grad_table = (G.view(-1, 1, 2) * w.view(1, 4, 1)).reshape(-1)
         return None, None, None, grad_table
