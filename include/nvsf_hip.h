@@ -215,6 +215,14 @@ int nvsf_hashgrid4d_dynamic_fwd(const float* x, uint32_t x_stride, const float* 
                                 const uint32_t* h_res, const uint32_t* h_offsets, const float* h_time, int same_slice,
                                 int mode, void* out, nvsf_stream_t stream);
 
+/* Scalar form of the space-time table gradient: the four features of an entry are the four Lagrange chunks and the two
+ * slices of a pair see the same cells, so dL/dtable[slice][row][i] = lag_i * blend_slice * G[row] with one scattered sum
+ * G[row] = sum over samples of grad_out[pair][level] * w_corner.  h_sums_f32: 3 device pointers (one per pair) to fp32
+ * [rows] buffers, G is ADDED to them; the caller expands G (a sixteenth of the atomic floats of nvsf_hashgrid4d_dynamic_bwd). */
+int nvsf_hashgrid4d_dynamic_bwd_scalar(const float* x, uint32_t x_stride, uint32_t M, const float* h_scales, const uint32_t* h_res,
+                                       const uint32_t* h_offsets, const float* grad_out, void* const* h_sums_f32,
+                                       nvsf_stream_t stream);
+
 /* The three space-time evaluations of one density query in one launch (ref: network_dynamic.py:220-271: hash_encoder(x, t)
  * in the fp32 regime and hash_encoder.forward_dynamic(x + flow, t_neighbour) twice in the fp16 regime).  h_tables_f16: 18
  * device pointers = for evaluation e = 0, 1, 2 the lo slice of pair 0,1,2 then the hi slice of pair 0,1,2; h_time: 18 floats

@@ -348,6 +348,62 @@ __global__ __launch_bounds__(kBlock) void k_hash_dynamic_bwd(const float* __rest
     if (acc != 0.0f) atomicAdd(dst, acc);
 }
 
+// The scalar form of the same gradient: the four features of a table entry are the four Lagrange chunks, so their gradients
+// are lag_i * blend * G[row] with ONE scattered sum G[row] = sum_samples g[pair][level] * w_corner per entry (and per pair,
+// shared by the two slices).  Items = (chunk, pair, level) on 4 lanes (lane = corner), 16 items per wave: a sixteenth of the
+// atomic floats and a quarter of the atomic instructions of k_hash_dynamic_bwd; the host expands G to the slice gradients.
+struct PlaneSums {
+    float* g[3];       // per pair: fp32 [rows]
+    GridMeta meta[3];
+};
+__global__ __launch_bounds__(kBlock) void k_hash_dynamic_bwd_scalar(const float* __restrict__ x, uint32_t x_stride, uint32_t M,
+                                                                    const float* __restrict__ grad_out, PlaneSums pg, uint32_t run) {
+    const int lane = lane_id();
+    const int sub = lane >> 2, c = lane & 3;
+    constexpr uint32_t per_chunk = 3u * kPlaneLevels;
+    const unsigned long long item = ((unsigned long long)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 16ull + (unsigned)sub;
+    const uint32_t chunk = (uint32_t)(item / per_chunk), rest = (uint32_t)(item - (unsigned long long)chunk * per_chunk);
+    const uint32_t pl = rest / kPlaneLevels, l = rest % kPlaneLevels;
+    const unsigned long long first = (unsigned long long)chunk * run;
+    if (first >= M) return;
+    const uint32_t m0 = (uint32_t)first, m1 = (uint32_t)(first + run < M ? first + run : M);
+    const GridMeta& g = pg.meta[pl];
+    const float scale = g.scale[l];
+    const uint32_t res = g.res[l], row0 = g.offset[l], hsize = g.offset[l + 1] - row0;
+    float* table = pg.g[pl];
+    const uint32_t ca = pl == 2 ? 1u : 0u, cb = pl == 0 ? 1u : 2u;
+    float acc = 0.0f;
+    uint32_t cur0 = 0u, cur1 = 0u;
+    bool have = false;
+    float* dst = table;
+    float xa_n = x[(size_t)m0 * x_stride + ca], xb_n = x[(size_t)m0 * x_stride + cb];
+    float g_n = grad_out[(size_t)m0 * (3 * kPlaneLevels) + pl * kPlaneLevels + l];
+    for (uint32_t m = m0; m < m1; ++m) {
+        const float xa = xa_n, xb = xb_n, go = g_n;
+        if (m + 1 < m1) {
+            xa_n = x[(size_t)(m + 1) * x_stride + ca];
+            xb_n = x[(size_t)(m + 1) * x_stride + cb];
+            g_n = grad_out[(size_t)(m + 1) * (3 * kPlaneLevels) + pl * kPlaneLevels + l];
+        }
+        if (go == 0.0f) continue;
+        const float pa = fmaf(scale, xa, 0.5f), pb = fmaf(scale, xb, 0.5f);
+        const float fa = floorf(pa), fb = floorf(pb);
+        const float ra = pa - fa, rb = pb - fb;
+        const uint32_t ia = (uint32_t)(int32_t)fa, ib = (uint32_t)(int32_t)fb;
+        const float w = ((c & 1) ? ra : (1.0f - ra)) * ((c & 2) ? rb : (1.0f - rb));
+        if (!(have && ia == cur0 && ib == cur1)) {
+            if (acc != 0.0f) atomicAdd(dst, acc);
+            acc = 0.0f;
+            have = true;
+            cur0 = ia; cur1 = ib;
+            const uint32_t cc[2] = {ia + (uint32_t)(c & 1), ib + (uint32_t)((c >> 1) & 1)};
+            dst = table + ((size_t)row0 + grid_row<2>(cc, res, hsize));
+        }
+        acc += w * go;
+    }
+    if (acc != 0.0f) atomicAdd(dst, acc);
+}
+
 int fill_meta(GridMeta& meta, uint32_t L, const float* scales, const uint32_t* res, const uint32_t* offsets) {
     if (L == 0 || L > (uint32_t)kMaxLevels || !scales || !res || !offsets) return NVSF_ERR_INVALID_ARG;
     for (uint32_t l = 0; l < L; ++l) {
@@ -468,5 +524,26 @@ NVSF_API int nvsf_hashgrid4d_dynamic3_fwd(const float* x, uint32_t x_stride, con
     }
     hipLaunchKernelGGL(k_hash_dynamic3, dim3(cdiv(M, kSamplesPerBlock)), dim3(kBlock), 0, stream, x, x_stride, offsets, off_stride, M, ps, out0,
                        reinterpret_cast<_Float16*>(out1), reinterpret_cast<_Float16*>(out2));
+    return nvsf_launch_status();
+}
+
+// Scalar table-gradient sums of the space-time encoder: h_sums_f32 = 3 device pointers (one per pair) to fp32 [rows] buffers; the sum
+// G[row] = sum over samples of grad_out[pair][level] * w_corner is ADDED to them.  dL/dtable[slice][row][i] = lag_i * blend_slice * G[row].
+NVSF_API int nvsf_hashgrid4d_dynamic_bwd_scalar(const float* x, uint32_t x_stride, uint32_t M, const float* h_scales, const uint32_t* h_res,
+                                                const uint32_t* h_offsets, const float* grad_out, void* const* h_sums_f32, hipStream_t stream) {
+    if (M == 0) return NVSF_OK;
+    REQUIRE(x && grad_out && h_sums_f32 && x_stride >= 3);
+    PlaneSums pg;
+    for (int p = 0; p < 3; ++p) {
+        pg.g[p] = reinterpret_cast<float*>(h_sums_f32[p]);
+        REQUIRE(pg.g[p]);
+        const int st = fill_meta(pg.meta[p], kPlaneLevels, h_scales + p * kPlaneLevels, h_res + p * kPlaneLevels, h_offsets + p * (kPlaneLevels + 1));
+        if (st != NVSF_OK) return st;
+    }
+    const uint32_t run = M >= (1u << 20) ? 128u : 32u;
+    const unsigned long long items = (unsigned long long)cdiv(M, run) * 3ull * kPlaneLevels;
+    const unsigned long long waves = (items + 15) / 16;
+    hipLaunchKernelGGL(k_hash_dynamic_bwd_scalar, dim3((uint32_t)((waves + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, stream, x, x_stride,
+                       M, grad_out, pg, run);
     return nvsf_launch_status();
 }

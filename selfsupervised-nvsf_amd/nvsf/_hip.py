@@ -44,6 +44,7 @@ SIGNATURES = {
     "nvsf_planes_bwd": [_P, _U, _P, _U, _U, _P, _I, _P, _P, _P, _P],
     "nvsf_hashgrid4d_dynamic_fwd": [_P, _U, _P, _U, _U, _U, _P, _P, _P, _P, _P, _I, _I, _P],
     "nvsf_hashgrid4d_dynamic3_fwd": [_P, _U, _P, _U, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "nvsf_hashgrid4d_dynamic_bwd_scalar": [_P, _U, _U, _P, _P, _P, _P, _P],
     "nvsf_hashgrid4d_dynamic_bwd": [_P, _U, _U, _P, _P, _P, _P, _I, _P, _P],
     "nvsf_hashgrid3d_lagrange_fwd": [_P, _U, _U, _P, _U, _U, _P, _P, _P, _P, _P],
     "nvsf_density_dynamic_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _U, _P, _P, _P, _P, _P],
