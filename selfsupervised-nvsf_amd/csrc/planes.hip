@@ -183,8 +183,12 @@ __global__ __launch_bounds__(kBlock) void k_planes_bwd_runs(const float* __restr
                                                             PlaneMeta meta, int want, const float* __restrict__ g_static,
                                                             const float* __restrict__ g_dynamic, float* __restrict__ g_planes,
                                                             uint32_t run) {
+    // taps of 32 samples x 3 planes of an item: {nw, ne, sw, se, i00, i01, i10, i11}.  All 32 lanes of an item would compute
+    // the same taps; instead lane k computes those of sample k of a round of 32 and the round then reads them back as
+    // broadcasts (the tap arithmetic was 3/4 of this kernel's instructions).
+    __shared__ uint32_t s_taps[kBlock / 32][32][3][8];
     const int lane = lane_id();
-    const int half = lane >> 5, tex = (lane >> 3) & 3, ch = lane & 7;
+    const int half = lane >> 5, k32 = lane & 31, tex = (lane >> 3) & 3, ch = lane & 7;
     const uint32_t n_grp = (want & 1 ? 1u : 0u) + (want & 2 ? 1u : 0u);
     const unsigned long long item = ((unsigned long long)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) * 2ull + (unsigned)half;
     const uint32_t per_chunk = meta.n_scales * n_grp;
@@ -198,42 +202,61 @@ __global__ __launch_bounds__(kBlock) void k_planes_bwd_runs(const float* __restr
     const float* gbase = grp == 0 ? g_static : g_dynamic;
     const uint32_t stride = meta.n_scales * kC;
     const int pairs[3] = {grp == 0 ? 0 : 2, grp == 0 ? 1 : 4, grp == 0 ? 3 : 5};
+    uint32_t (*taps)[3][8] = s_taps[(threadIdx.x >> 5)];
     float acc[3] = {0.0f, 0.0f, 0.0f};
     uint32_t cur[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};  // i00 of the quad being summed (identifies the quad)
     uint32_t dst[3] = {0u, 0u, 0u};
     const uint32_t n_rows = m1 - m0;
-    for (uint32_t r = 0; r < run; ++r) {  // uniform trip count over the wave
-        const bool row_ok = r < n_rows;
-        const uint32_t m = row_ok ? m0 + r : (M - 1);
-        const float4 p4 = reinterpret_cast<const float4*>(xt)[m];
-        const float p[4] = {p4.x, p4.y, p4.z, p4.w};
-        const float g = row_ok ? gbase[(size_t)m * stride + ss * kC + ch] : 0.0f;
-        float v[3], w[3];
-        uint32_t idx[3], quad[3];
+    for (uint32_t r0 = 0; r0 < run; r0 += 32) {  // uniform trip count over the wave
+        {   // lane k32: taps of row r0 + k32
+            const uint32_t r = r0 + (uint32_t)k32;
+            const uint32_t m = r < n_rows ? m0 + r : (M - 1);
+            const float4 p4 = reinterpret_cast<const float4*>(xt)[m];
+            const float p[4] = {p4.x, p4.y, p4.z, p4.w};
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int a = kPa[pairs[j]], b = kPb[pairs[j]];
-            const Tap t = make_tap(p[a], p[b], meta.res[ss][a], meta.res[ss][b]);
-            idx[j] = tex == 0 ? t.i00 : tex == 1 ? t.i01 : tex == 2 ? t.i10 : t.i11;
-            w[j] = tex == 0 ? t.nw : tex == 1 ? t.ne : tex == 2 ? t.sw : t.se;
-            quad[j] = t.i00;
-            float part = planes[meta.off[ss][pairs[j]] + (size_t)idx[j] * kC + ch] * w[j];
-            part += __shfl_xor(part, 8);
-            part += __shfl_xor(part, 16);
-            v[j] = part;  // interpolated value of plane j, channel ch (in all four texel lanes)
-        }
-        if (!row_ok) continue;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const float gv = g * (v[(j + 1) % 3] * v[(j + 2) % 3]);
-            if (quad[j] != cur[j]) {
-                if (acc[j] != 0.0f) atomicAdd(g_planes + dst[j], acc[j]);
-                acc[j] = 0.0f;
-                cur[j] = quad[j];
-                dst[j] = meta.off[ss][pairs[j]] + idx[j] * kC + ch;
+            for (int j = 0; j < 3; ++j) {
+                const int a = kPa[pairs[j]], b = kPb[pairs[j]];
+                const Tap t = make_tap(p[a], p[b], meta.res[ss][a], meta.res[ss][b]);
+                uint32_t* o = taps[k32][j];
+                o[0] = __builtin_bit_cast(uint32_t, t.nw); o[1] = __builtin_bit_cast(uint32_t, t.ne);
+                o[2] = __builtin_bit_cast(uint32_t, t.sw); o[3] = __builtin_bit_cast(uint32_t, t.se);
+                o[4] = t.i00; o[5] = t.i01; o[6] = t.i10; o[7] = t.i11;
             }
-            acc[j] += gv * w[j];
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t k = 0; k < 32u; ++k) {
+            const uint32_t r = r0 + k;
+            const bool row_ok = r < n_rows;
+            const uint32_t m = row_ok ? m0 + r : (M - 1);
+            const float g = row_ok ? gbase[(size_t)m * stride + ss * kC + ch] : 0.0f;
+            float v[3], w[3];
+            uint32_t idx[3], quad[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                w[j] = __builtin_bit_cast(float, taps[k][j][tex]);
+                idx[j] = taps[k][j][4 + tex];
+                quad[j] = taps[k][j][4];
+                float part = planes[meta.off[ss][pairs[j]] + (size_t)idx[j] * kC + ch] * w[j];
+                part += __shfl_xor(part, 8);
+                part += __shfl_xor(part, 16);
+                v[j] = part;  // interpolated value of plane j, channel ch (in all four texel lanes)
+            }
+            if (!row_ok) continue;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float gv = g * (v[(j + 1) % 3] * v[(j + 2) % 3]);
+                if (quad[j] != cur[j]) {
+                    if (acc[j] != 0.0f) atomicAdd(g_planes + dst[j], acc[j]);
+                    acc[j] = 0.0f;
+                    cur[j] = quad[j];
+                    dst[j] = meta.off[ss][pairs[j]] + idx[j] * kC + ch;
+                }
+                acc[j] += gv * w[j];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // the taps are overwritten by the next round
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j)
