@@ -930,7 +930,7 @@ __device__ __forceinline__ half8_t occ_fragment(int f, int lane, const _Float16*
 }
 
 template <bool LIDAR>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_render_occupancy_lds(OccRays rr, const _Float16* __restrict__ table, uint32_t table_bytes,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_render_occupancy_lds(OccRays rr, const _Float16* __restrict__ table, uint32_t table_bytes,
                                                                  GridMeta meta, uint32_t first_hashed, const _Float16* __restrict__ w_sigma,
                                                                  const _Float16* __restrict__ w_a, const _Float16* __restrict__ w_b,
                                                                  float density_scale, float T_thresh, float bg0, float bg1, float bg2,
