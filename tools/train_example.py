@@ -1,0 +1,105 @@
+"""End-to-end example of the multimodal training loop around the hot path (BASELINE config 4), one process per GPU:
+
+    python tools/train_example.py --root /path/to/kitti360_nvsf --sequence 1908 [--dynamic] [--steps 200]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 tools/train_example.py ...
+
+Data: the reference's on-disk formats (transforms_{seq}_{split}.json + range-image .npy + images; nvsf/nerf/dataset/formats.py).
+Without --root a small synthetic data set in those formats is written to a temporary directory first.
+Every step renders one frame per rank (frames are sharded over the ranks, nvsf/frame_shard.py), then ONE bucketed RCCL
+all-reduce of the gradients, then Adam under the loss scaler (nvsf/nerf/train_step.py).  Reports loss, PSNR and range RMSE.
+"""
+import argparse
+import os
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "selfsupervised-nvsf_amd"))
+
+import numpy as np
+import torch
+
+
+def synthetic_dataset(root, seq, n_frames=8, H=94, W=352, Hl=66, Wl=1030, seed=0):
+    """A box-shaped toy scene in the reference's formats: constant-colour images, a range image of a sphere of radius 30 m."""
+    from nvsf.nerf.dataset import formats as F
+    rng = np.random.default_rng(seed)
+    d = os.path.join(root, "train", seq)
+    os.makedirs(d, exist_ok=True)
+    frames = []
+    for i in range(n_frames):
+        pose = np.eye(4)
+        pose[:3, 3] = [0.2 * i, 0.0, 0.0]
+        img = np.full((H, W, 3), 120 + 10 * i, np.uint8)
+        pc = np.zeros((Hl, Wl, 3), np.float32)
+        pc[..., 1] = rng.random((Hl, Wl)) * 0.5
+        pc[..., 2] = 30.0
+        pc[rng.random((Hl, Wl)) < 0.1, 2] = 0.0
+        np.save(os.path.join(d, f"img_{i:04d}.npy"), img)
+        np.save(os.path.join(d, f"pano_{i:04d}.npy"), pc)
+        frames.append({"frame_id": 1908 + i, "file_path": f"train/{seq}/img_{i:04d}.npy", "transform_matrix": pose,
+                       "lidar_file_path": f"train/{seq}/pano_{i:04d}.npy", "lidar2world": pose})
+    K = np.array([[552.55 / 4, 0, W / 2], [0, 552.55 / 4, H / 2], [0, 0, 1]])
+    F.write_transforms(F.transforms_path(root, seq, "train"), w=W, h=H, w_lidar=Wl, h_lidar=Hl, K=K, frame_start=1908, frame_end=1908 + n_frames - 1,
+                       num_frames=n_frames, frames=frames)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--root", default=None)
+    ap.add_argument("--sequence", default="1908")
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--num-rays", type=int, default=4096)
+    ap.add_argument("--num-steps", type=int, default=768)
+    ap.add_argument("--dynamic", action="store_true", help="the reference's space-time model instead of the static hash field")
+    args = ap.parse_args()
+    world, rank, local = int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    from nvsf import frame_shard, synthetic as S
+    from nvsf.nerf.dataset.formats import FrameSet
+    from nvsf.nerf.train_step import RenderTrainStep, psnr, depth_rmse
+    root = args.root
+    if root is None:
+        root = os.path.join(tempfile.gettempdir(), "nvsf_synthetic")
+        if rank == 0:
+            synthetic_dataset(root, args.sequence)
+        if world > 1:
+            dist.barrier()
+    scale = S.SCALE if hasattr(S, "SCALE") else 0.010851959895748291
+    data = FrameSet(root, args.sequence, "train", scale, num_rays=args.num_rays, num_rays_lidar=args.num_rays, device=dev)
+    torch.manual_seed(0)  # identical initial replicas
+    if args.dynamic:
+        from nvsf.nerf.models.network_dynamic import NeRFNetwork
+        model = NeRFNetwork(time_resolution=8, num_frames=data.meta["num_frames"], bound=S.BOUND, min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR,
+                            lidar_max_depth=S.LIDAR_MAX_DEPTH).to(dev)
+    else:
+        from nvsf.nerf.models.network_static import NeRFNetworkStatic
+        model = NeRFNetworkStatic(bound=S.BOUND, min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH,
+                                  num_frames=data.meta["num_frames"]).to(dev)
+    trainer = RenderTrainStep(model, iters=args.steps, num_steps=args.num_steps)
+    n = len(data)
+    for it in range(args.steps):
+        perm = np.random.default_rng(it // max(1, n // world)).permutation(n)  # the same permutation on every rank
+        frame = int(perm[(it * world + rank) % n])
+        batch = data.train_batch([frame])
+        loss, parts, n_coll = trainer.step(batch)
+        if rank == 0 and (it % 10 == 0 or it == args.steps - 1):
+            print(f"step {it:4d}  frame {frame:3d}  loss {float(loss):.4f}  " + "  ".join(f"{k} {float(v):.4f}" for k, v in parts.items())
+                  + f"  all-reduces/step {n_coll}", flush=True)
+    model.eval()
+    with torch.no_grad():
+        b = data.train_batch([0])
+        r = model.render(b["rays_o_lidar"], b["rays_d_lidar"], b["time"], cal_lidar_color=True, num_steps=args.num_steps)
+        c = model.render(b["rays_o"], b["rays_d"], b["time"], num_steps=args.num_steps, bg_color=1)
+    if rank == 0:
+        print(f"frame 0: PSNR {psnr(c['image'], b['gt_rgb']):.2f} dB, range RMSE {depth_rmse(r['depth_lidar'] * b['gt_raydrop'], b['gt_depth'], scale):.2f} m")
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
