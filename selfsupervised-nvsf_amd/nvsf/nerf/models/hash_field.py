@@ -25,8 +25,28 @@ from torch import nn
 import tinycudann as tcnn
 
 
+_HOST_TIME_CACHE = {}  # id(tensor) -> (weakref, version, value): the last few time tensors read back
+
+
 def _host_time(t):
-    return float(t) if not torch.is_tensor(t) else float(t.detach().reshape(-1)[0])
+    """The value of the frame time on the host.  A device tensor costs a device->host read that drains the stream; a staged
+    render (renderer_dynamic.py:286-316: a frame in ~130 ray chunks) or a benchmark loop passes the SAME tensor object again
+    and again, so the value is remembered per tensor object for as long as that object is alive and unmodified (same
+    `_version`).  Another tensor -- even at the same address -- is read again."""
+    if not torch.is_tensor(t):
+        return float(t)
+    if not t.is_cuda:
+        return float(t.detach().reshape(-1)[0])
+    import weakref
+    hit = _HOST_TIME_CACHE.get(id(t))
+    if hit is not None and hit[0]() is t and hit[1] == t._version:
+        return hit[2]
+    value = float(t.detach().reshape(-1)[0])
+    if len(_HOST_TIME_CACHE) >= 16:
+        for k in [k for k, v in _HOST_TIME_CACHE.items() if v[0]() is None] or list(_HOST_TIME_CACHE)[:8]:
+            _HOST_TIME_CACHE.pop(k, None)
+    _HOST_TIME_CACHE[id(t)] = (weakref.ref(t), t._version, value)
+    return value
 
 
 def lagrange_weights_host(t_host, num_basis, reciprocal_division):

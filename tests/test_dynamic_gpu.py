@@ -348,3 +348,17 @@ def test_network_trains_end_to_end(dev, net):
     before = m.sigma_net.params.detach().clone()
     opt.step()
     assert not torch.equal(before, m.sigma_net.params.detach())
+
+
+def test_host_time_cache_follows_the_tensor_object(dev):
+    from nvsf.nerf.models.hash_field import _host_time
+    t = torch.tensor([[0.25]], device=dev)
+    assert _host_time(t) == 0.25 and _host_time(t) == 0.25
+    t.fill_(0.75)  # in-place change: the version moves, the value is read again
+    assert _host_time(t) == 0.75
+    u = torch.tensor([[0.5]], device=dev)
+    assert _host_time(u) == 0.5 and _host_time(t) == 0.75
+    del t
+    v = torch.tensor([[0.125]], device=dev)  # may re-use the freed address / id: must not see the old value
+    assert _host_time(v) == 0.125
+    assert _host_time(0.3) == 0.3 and _host_time(torch.tensor(0.4)) == pytest.approx(0.4)
