@@ -1,21 +1,28 @@
-"""`trunc_exp` (ref: /root/reference/nvsf/nerf/activation.py:6-20): exp in fp32 forward; the backward
-multiplies by exp(clamp(x, -15, 15)) so large logits cannot overflow the gradient."""
+"""`trunc_exp`, the density activation (ref: /root/reference/nvsf/nerf/activation.py:6-20): sigma = exp(h) evaluated in
+fp32; towards h the gradient is multiplied by exp(clamp(h, -15, 15)), so a large logit cannot overflow it.
+
+exp is monotonic, hence exp(clamp(h, -15, 15)) == clamp(exp(h), exp(-15), exp(15)): the backward re-uses the saved OUTPUT
+and needs no second exp kernel over the [M] logits (the fixture of the reference's own function pins values and gradients
+bit for bit, tests/test_oracle_cpu.py::test_trunc_exp_golden)."""
 import torch
-from torch.autograd import Function
+
+_LO = float(torch.exp(torch.tensor(-15.0, dtype=torch.float32)))
+_HI = float(torch.exp(torch.tensor(15.0, dtype=torch.float32)))
 
 
-class _TruncExp(Function):
+class TruncatedExp(torch.autograd.Function):
     @staticmethod
-    @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
-    def forward(ctx, x):
-        ctx.save_for_backward(x)
-        return torch.exp(x)
+    def forward(ctx, logits):
+        sigma = torch.exp(logits.float())  # fp32 whatever the autocast state (the reference: custom_fwd(cast_inputs=float32))
+        ctx.save_for_backward(sigma)
+        ctx.in_dtype = logits.dtype
+        return sigma
 
     @staticmethod
-    @torch.amp.custom_bwd(device_type="cuda")
-    def backward(ctx, g):
-        (x,) = ctx.saved_tensors
-        return g * torch.exp(torch.clamp(x, -15.0, 15.0))
+    def backward(ctx, grad_sigma):
+        (sigma,) = ctx.saved_tensors
+        return (grad_sigma * sigma.clamp(_LO, _HI)).to(ctx.in_dtype)
 
 
-trunc_exp = _TruncExp.apply
+def trunc_exp(logits):
+    return TruncatedExp.apply(logits)
