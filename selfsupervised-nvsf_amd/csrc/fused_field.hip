@@ -494,6 +494,138 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     }
 }
 
+// pass A, pair form: TWO lanes per sample (lane = 2 * sample + x-bit), 32 samples per wave.  A lane gathers the four corners
+// with its x-bit of both levels, so every gather instruction fetches BOTH x-neighbours of 32 samples: they are adjacent table
+// entries on dense levels and for even cells on hashed ones, i.e. one L1 line look-up instead of two -- and the look-ups (one
+// line per clock and CU) are what bounds this pass.  The partner's four values of "its" level arrive by a quad swap (DPP);
+// the even lane blends the slice's first level, the odd lane the second, each with all eight corners in the specification's
+// order: bit-identical features.
+template <int F>
+__device__ __forceinline__ void slice_issue_half(const SliceLevel<F>& lv, __amdgpu_buffer_rsrc_t rsrc, const float (&x)[3], uint32_t xb,
+                                                 float (&frac)[3], uint32_t (&raw)[4]) {
+    uint32_t c[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float pos = fmaf(lv.scale, x[d], 0.5f);
+        const float fl = floorf(pos);
+        frac[d] = pos - fl;
+        c[d] = (uint32_t)(int32_t)fl;
+    }
+    uint32_t idx[4];
+    if (!lv.hashed) {  // block-uniform
+        const uint32_t b00 = c[0] + c[1] * lv.res + c[2] * lv.res2;
+        const uint32_t base[4] = {b00, b00 + lv.res, b00 + lv.res2, b00 + lv.res + lv.res2};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const uint32_t v = base[p] + xb;
+            idx[p] = v >= lv.rows ? v - lv.rows : v;
+        }
+    } else {
+        const uint32_t hy0 = c[1] * 2654435761u, hy1 = hy0 + 2654435761u;
+        const uint32_t hz0 = c[2] * 805459861u, hz1 = hz0 + 805459861u;
+        const uint32_t yz[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+        const uint32_t mask = lv.rows - 1u;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) idx[p] = ((c[0] + xb) ^ yz[p]) & mask;
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) raw[p] = gather_raw<F>(rsrc, lv.boff + idx[p] * (uint32_t)(F * sizeof(_Float16)));
+}
+
+__device__ __forceinline__ uint32_t quad_swap(uint32_t v) {  // value of the neighbouring lane (lane ^ 1)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false);
+}
+
+template <int F, bool UNIFORM_RAY>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_encode_sliced_pairs(RayBatch rb, const _Float16* __restrict__ table, uint32_t table_bytes,
+                                                                GridMeta meta, uint32_t L, uint32_t first_hashed, uint32_t M,
+                                                                float* __restrict__ z_vals, uint2* __restrict__ feat) {
+    static_assert(F == 2, "F = 2 only");
+    const uint32_t slice = blockIdx.x & 7u, sb = blockIdx.x >> 3, n_sb = gridDim.x >> 3;
+    const uint32_t grp = slice >> 1;
+    const uint32_t lvl[2] = {(slice & 1u) ? grp + 4u : grp, (slice & 1u) ? grp + 8u : grp + 12u};
+    SliceLevel<F> lv[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const uint32_t l = lvl[a];
+        lv[a].scale = meta.scale[l];
+        lv[a].res = meta.res[l];
+        lv[a].res2 = meta.res[l] * meta.res[l];
+        lv[a].boff = meta.offset[l] * (uint32_t)(F * sizeof(_Float16));
+        lv[a].rows = meta.offset[l + 1] - meta.offset[l];
+        lv[a].hashed = l >= first_hashed;
+    }
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(table), 0, (int)table_bytes, 0x00020000);
+    const int lane = lane_id();
+    const uint32_t xb = (uint32_t)(lane & 1), half_lane = (uint32_t)(lane >> 1);
+    const uint32_t n_units = (M + 31u) / 32u;
+    const uint32_t wave = sb * kWavesPerBlock + (threadIdx.x >> 6), wave_count = n_sb * kWavesPerBlock;
+    struct Unit {
+        uint32_t s, n;
+        bool in_range;
+        float near, far, lin, noise, o[3], d[3];
+    };
+    auto fetch = [&](uint32_t unit) {
+        Unit u;
+        const uint32_t s_raw = unit * 32u + half_lane;
+        u.in_range = s_raw < M;
+        u.s = u.in_range ? s_raw : M - 1u;
+        if constexpr (UNIFORM_RAY) u.n = __builtin_amdgcn_readfirstlane((unit * 32u) / rb.T);  // T % 32 == 0: scalar ray loads
+        else u.n = u.s / rb.T;
+        const uint32_t i = u.s - u.n * rb.T;
+        u.near = rb.nears[u.n];
+        u.far = rb.fars[u.n];
+        u.lin = rb.lin[i];
+        u.noise = rb.noise ? rb.noise[u.s] : 0.5f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            u.o[k] = rb.rays_o[3 * (size_t)u.n + k];
+            u.d[k] = rb.rays_d[3 * (size_t)u.n + k];
+        }
+        return u;
+    };
+    if (wave >= n_units) return;
+    Unit cur = fetch(wave);
+    for (uint32_t unit = wave; unit < n_units; unit += wave_count) {
+        const uint32_t next = unit + wave_count < n_units ? unit + wave_count : unit;
+        const Unit nxt = fetch(next);
+        const float range = cur.far - cur.near;
+        float z = cur.near + range * cur.lin;
+        if (rb.noise) z = z + (cur.noise - 0.5f) * (range / (float)rb.T);
+        float x[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float p = cur.o[k] + cur.d[k] * z;
+            p = fminf(fmaxf(p, rb.lo[k]), rb.hi[k]);
+            x[k] = (p + rb.bound) * rb.inv_extent;
+        }
+        float frac[2][3];
+        uint32_t half_raw[2][4];
+        slice_issue_half<F>(lv[0], rsrc, x, xb, frac[0], half_raw[0]);
+        slice_issue_half<F>(lv[1], rsrc, x, xb, frac[1], half_raw[1]);
+        // the even lane finishes level 0 of the slice, the odd lane level 1: each sends the partner the half it does not need
+        uint32_t raw[8];
+        float fr[3];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const uint32_t own = xb ? half_raw[1][p] : half_raw[0][p];
+            const uint32_t send = xb ? half_raw[0][p] : half_raw[1][p];
+            const uint32_t recv = quad_swap(send);
+            raw[2 * p] = xb ? recv : own;
+            raw[2 * p + 1] = xb ? own : recv;
+        }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) fr[d] = xb ? frac[1][d] : frac[0][d];
+        const uint32_t mine = slice_blend(fr, raw);
+        const uint32_t other = quad_swap(mine);
+        if (cur.in_range && xb == 0u) {
+            feat[(size_t)slice * M + cur.s] = make_uint2(mine, other);
+            if (slice == 0u) z_vals[cur.s] = z;
+        }
+        cur = nxt;
+    }
+}
+
 // pass B: 32 encoded features per sample (scratch planes) -> sigma MLP -> sigma, geo.
 template <int F>
 __global__ __launch_bounds__(kBlock) void k_density_from_features(const uint2* __restrict__ feat, uint32_t M, uint32_t L,
@@ -1411,7 +1543,19 @@ static int density_uniform_impl(const float* rays_o, const float* rays_d, const 
         const uint32_t units = (M + 63u) / 64u;
         uint32_t per_slice = (units + kWavesPerBlock - 1) / kWavesPerBlock;
         if (per_slice > 512u) per_slice = 512u;  // 32 CUs per XCD x 8 resident workgroups x 2 (measured: 256 -> 512 gains 1.5 %)
+        const char* enc_env = getenv("NVSF_ENCODE_SLICED");  // "lanes": one lane per sample (first form); default: two lanes per sample
+        const bool pairs = !(enc_env && enc_env[0] == 'l');
         if (!(sliced_passes & 1u)) {
+        } else if (pairs) {
+            const uint32_t units32 = (M + 31u) / 32u;
+            uint32_t ps = (units32 + kWavesPerBlock - 1) / kWavesPerBlock;
+            if (ps > 512u) ps = 512u;
+            if (T % 32u == 0u)
+                hipLaunchKernelGGL((k_encode_sliced_pairs<2, true>), dim3(8u * ps), dim3(kBlock), 0, stream, rb, tb, (uint32_t)table_bytes, meta, L,
+                                   first_hashed, M, z_vals, fp);
+            else
+                hipLaunchKernelGGL((k_encode_sliced_pairs<2, false>), dim3(8u * ps), dim3(kBlock), 0, stream, rb, tb, (uint32_t)table_bytes, meta,
+                                   L, first_hashed, M, z_vals, fp);
         } else if (T % 64u == 0u)
             hipLaunchKernelGGL((k_encode_sliced<2, true>), dim3(8u * per_slice), dim3(kBlock), 0, stream, rb, tb, (uint32_t)table_bytes, meta, L,
                                first_hashed, M, z_vals, fp);
