@@ -9,8 +9,8 @@ Only what sits directly around the hot path, restated from the reference:
     (main_nvsf.py:350-362), under the GradScaler of the reference's fp16 run (trainer.py:119, 1332-1334);
   * PSNR (nvsf/lib/error_matrices.py:48-57) and depth RMSE in metres (error_matrices.py:263-285).
 Across GPUs the step is frame-sharded: every rank renders its own frame, then ONE bucketed gradient all-reduce
-(nvsf/frame_shard.py).  The reference's Trainer (logging, EMA, checkpoints, UNet refinement, error maps, chamfer and
-flow losses) is out of scope.
+(nvsf/frame_shard.py).  Checkpoints use the reference's dict (utils.py:622-747).  The reference's Trainer (logging, EMA, UNet
+refinement, error maps, chamfer and flow losses) is out of scope.
 """
 import math
 
@@ -93,6 +93,44 @@ class RenderTrainStep:
         self.sched.step()
         self.global_step += 1
         return loss.detach(), {k: v.detach() for k, v in parts.items()}, n_coll
+
+    def checkpoint_state(self, epoch=0, stats=None, full=True):
+        """The dict Trainer.save_checkpoint writes with torch.save (nvsf/nerf/utils.py:622-648): epoch, global_step, stats,
+        model and -- for a `full` checkpoint -- optimizer, lr_scheduler, scaler (no EMA here)."""
+        state = {"epoch": epoch, "global_step": self.global_step, "stats": stats if stats is not None else {}}
+        if full:
+            state["optimizer"] = self.opt.state_dict()
+            state["lr_scheduler"] = self.sched.state_dict()
+            state["scaler"] = self.scaler.state_dict()
+        state["model"] = self.model.state_dict()
+        return state
+
+    def save_checkpoint(self, path, epoch=0, stats=None, full=True):
+        torch.save(self.checkpoint_state(epoch, stats, full), path)
+
+    def load_checkpoint(self, checkpoint, model_only=False):
+        """Trainer.load_checkpoint (nvsf/nerf/utils.py:682-747): a bare state_dict loads strictly; a checkpoint dict loads its
+        model with strict=False (the reference's files carry three unused sub-modules), then global_step / optimizer /
+        lr_scheduler / scaler where present.  checkpoint: path or the loaded dict.  Returns (missing_keys, unexpected_keys,
+        epoch)."""
+        if not isinstance(checkpoint, dict):
+            checkpoint = torch.load(checkpoint, map_location=next(self.model.parameters()).device)
+        if "model" not in checkpoint:
+            self.model.load_state_dict(checkpoint)
+            return [], [], None
+        missing, unexpected = self.model.load_state_dict(checkpoint["model"], strict=False)
+        if model_only:
+            return list(missing), list(unexpected), checkpoint.get("epoch")
+        if "global_step" in checkpoint:
+            self.global_step = checkpoint["global_step"]
+        # the reference swallows a failure to restore these three (optimiser groups of another model layout) and trains on
+        for key, obj in (("optimizer", self.opt), ("lr_scheduler", self.sched), ("scaler", self.scaler)):
+            if key in checkpoint:
+                try:
+                    obj.load_state_dict(checkpoint[key])
+                except Exception:  # noqa: BLE001 -- reference behaviour: warn and continue
+                    pass
+        return list(missing), list(unexpected), checkpoint.get("epoch")
 
 
 def psnr(pred, truth):

@@ -32,3 +32,42 @@ def test_state_dict_schema_matches_reference():
     assert float(m.planes_encoder_camera.planes[2][4][0, 0, 0, 0]) == 0.25
     groups = m.get_params(1e-2)
     assert len(groups) == 11 and [g["lr"] for g in groups][6] == 1e-3  # flow net at 0.1 x lr (network_dynamic.py:345)
+
+
+def test_checkpoint_dict_round_trip(tmp_path):
+    """save -> load through the reference's checkpoint dict (utils.py:622-747): same keys, parameters, optimiser moments,
+    schedule position and step count; a bare state_dict and a `model_only` load behave as the reference's."""
+    import golden_dynamic as GD
+    from nvsf import synthetic as S
+    from nvsf.nerf.models.network_dynamic import NeRFNetwork
+    from nvsf.nerf.train_step import RenderTrainStep
+
+    def make(seed):
+        torch.manual_seed(seed)
+        m = NeRFNetwork(min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH, **GD.SMALL)
+        return RenderTrainStep(m, lr=1e-2, iters=100, fp16=False)
+
+    a = make(1)
+    for p in a.model.parameters():  # one optimiser step with synthetic gradients (no render on CPU)
+        p.grad = torch.full_like(p, 1e-3)
+    a.opt.step(); a.sched.step(); a.global_step = 7
+    path = tmp_path / "run_ep0003.pth"
+    a.save_checkpoint(path, epoch=3, stats={"results": [0.5], "checkpoints": [str(path)]})
+    disk = torch.load(path, weights_only=False)
+    assert set(disk) == {"epoch", "global_step", "stats", "optimizer", "lr_scheduler", "scaler", "model"}
+    assert set(a.checkpoint_state(full=False)) == {"epoch", "global_step", "stats", "model"}
+
+    b = make(2)
+    missing, unexpected, epoch = b.load_checkpoint(str(path))
+    assert missing == [] and unexpected == [] and epoch == 3 and b.global_step == 7
+    for (k, v), (k2, v2) in zip(a.model.state_dict().items(), b.model.state_dict().items()):
+        assert k == k2 and torch.equal(v, v2)
+    sa, sb = a.opt.state_dict()["state"], b.opt.state_dict()["state"]
+    assert sa.keys() == sb.keys() and all(torch.equal(sa[i]["exp_avg"], sb[i]["exp_avg"]) for i in sa)
+    assert b.sched.last_epoch == a.sched.last_epoch and b.opt.param_groups[0]["lr"] == a.opt.param_groups[0]["lr"]
+
+    c = make(3)
+    assert c.load_checkpoint(disk, model_only=True)[2] == 3 and c.global_step == 0
+    c.load_checkpoint(a.model.state_dict())  # bare state_dict: strict
+    assert torch.equal(c.model.sigma_net_lidar.params if hasattr(c.model, "sigma_net_lidar") else next(c.model.parameters()),
+                       a.model.sigma_net_lidar.params if hasattr(a.model, "sigma_net_lidar") else next(a.model.parameters()))
