@@ -19,7 +19,8 @@ One JSON line on stdout (rank 0): metric / value / ... plus
   occupancy / dynamic / train   secondary legs (BASELINE configs 3, 5, 4), never `value`
   raymarching   the raymarching-extension kernels (rows a1-a9) against the HBM roofline at non-latency-bound sizes
   field_ops     the stand-alone field operators (rows a12-a17) against their rooflines on the config-2 sample batches
-  cpu_baseline  the CPU oracle (oracle/, scalar C port, 1 thread) on a bounded sample of the same workload
+  cpu_baseline  the CPU oracle (oracle/, scalar C port) on a bounded sample of the same workload: one core, and the rays
+                split over a thread pool on all host cores (`cores` = threads used; `one_core` beside it)
 """
 import argparse
 import json
@@ -46,6 +47,7 @@ def parse():
     ap.add_argument("--num-rays", type=int, default=4096)
     ap.add_argument("--num-rays-lidar", type=int, default=4096)
     ap.add_argument("--num-steps", type=int, default=768)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the multi-core cpu_baseline leg (0 = the host's cores, at most 16; 1 = skip it)")
     ap.add_argument("--cpu-rays", type=int, default=320, help="rays per modality in the cpu_baseline sample (~10 s of CPU work; 0 = skip)")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the occupancy-grid (config 3) and dynamic-field (config 5) legs")
@@ -168,14 +170,19 @@ def pmc_traffic(kernel_label):
     return {"traffic": None}
 
 
-def cpu_baseline(model, T, n_rays, seed=1234):
-    """Times the scalar CPU oracle on `n_rays` LiDAR + `n_rays` camera rays of the same workload (1 thread)."""
+def cpu_baseline(model, T, n_rays, seed=1234, threads=1):
+    """Times the scalar CPU oracle on `n_rays` LiDAR + `n_rays` camera rays of the same workload.  threads > 1: the rays of
+    each batch are split into `threads` contiguous chunks rendered by a thread pool (rays are independent; the C oracle is
+    called through ctypes, which releases the GIL; the numpy glue between the calls holds it)."""
     import oracle_lib as O
+    from concurrent.futures import ThreadPoolExecutor
     from nvsf import synthetic as S
     rng = np.random.default_rng(seed)
     f16 = lambda net: net.params.detach().cpu().numpy().astype(np.float16)
     lin = torch.linspace(0.0, 1.0, T).numpy()
     aabb = np.array([-S.BOUND] * 3 + [S.BOUND] * 3, np.float32)
+    threads = max(1, min(int(threads), n_rays))
+    pool = ThreadPoolExecutor(threads) if threads > 1 else None
     t0 = time.perf_counter()
     for lidar in (True, False):
         o, d = (S.lidar_rays if lidar else S.camera_rays)(n_rays, rng)
@@ -185,13 +192,26 @@ def cpu_baseline(model, T, n_rays, seed=1234):
             nears, fars = np.full(n_rays, model.min_near_lidar, np.float32), np.full(n_rays, model.lidar_max_depth, np.float32)
         else:
             nears, fars = O.near_far_from_aabb(o, d, aabb, model.min_near)
-        O.render_static(o, d, nears, fars, lin, None, float(S.BOUND), table, enc.spec, f16(model.sigma_net), lidar,
-                        f16(model.raydrop_net) if lidar else f16(model.color_net), f16(model.intensity_net) if lidar else None,
-                        np.ones(3, np.float32), k_scale=model._k_scale())
+        w_sigma = f16(model.sigma_net)
+        w_a = f16(model.raydrop_net) if lidar else f16(model.color_net)
+        w_b = f16(model.intensity_net) if lidar else None
+
+        def chunk(lo_hi):
+            a, b = lo_hi
+            return O.render_static(o[a:b], d[a:b], nears[a:b], fars[a:b], lin, None, float(S.BOUND), table, enc.spec, w_sigma, lidar,
+                                   w_a, w_b, np.ones(3, np.float32), k_scale=model._k_scale())
+        edges = np.linspace(0, n_rays, threads + 1).astype(int)
+        spans = [(int(a), int(b)) for a, b in zip(edges[:-1], edges[1:]) if b > a]
+        if pool is None:
+            chunk(spans[0])
+        else:
+            list(pool.map(chunk, spans))
     dt = time.perf_counter() - t0
-    return {"value": 2 * n_rays / dt, "unit": "rays/s", "cores": 1, "kind": "port",
+    if pool is not None:
+        pool.shutdown()
+    return {"value": 2 * n_rays / dt, "unit": "rays/s", "cores": threads, "kind": "port",
             "sample": f"{n_rays} LiDAR + {n_rays} camera rays x {T} samples, same field, scalar C oracle (oracle/*.c) + numpy glue, "
-                      f"{dt:.1f} s wall"}
+                      f"{threads} thread(s), {dt:.1f} s wall"}
 
 
 def train_leg(model, tl, tc, tm, T, steps, dev, dist):
@@ -467,7 +487,13 @@ def main():
             line["roofline"].update(pmc_traffic(pick["kernel"]))
             line["kernel_ms_sum"] = sum(r["ms"] for r in rows)
         if args.cpu_rays > 0 and world == 1:
-            line["cpu_baseline"] = cpu_baseline(model, T, args.cpu_rays)
+            base = cpu_baseline(model, T, args.cpu_rays)  # one core: the scalar port as it is
+            threads = min(args.cpu_threads if args.cpu_threads > 0 else (os.cpu_count() or 1), 16)  # a 1-GPU box's CPU share
+            if threads > 1:  # and on the host's cores: the same port, rays split over a thread pool
+                multi = cpu_baseline(model, T, args.cpu_rays * min(threads, 8), threads=threads)
+                base, single = multi, base
+                base["one_core"] = {"value": single["value"], "sample": single["sample"]}
+            line["cpu_baseline"] = base
         if not args.no_extra_legs and world == 1:  # secondary figures for BASELINE configs 3 and 5 (never `value`)
             line["occupancy"] = occupancy_leg(NeRFNetworkStatic, dev, args.num_rays, 10)
             line["dynamic"] = dynamic_leg(dev, args.num_rays, T, 3)
