@@ -10,35 +10,7 @@
 namespace {
 constexpr int kBlock = 256;
 
-template <bool X_F16>
-__device__ __forceinline__ half8_t load_x_frag(const void* __restrict__ x, size_t row, uint32_t x_stride, int k0, int n_in,
-                                               int in_cols, bool vec_ok) {
-    half8_t v;
-    if (k0 + 8 <= n_in && vec_ok) {
-        if constexpr (X_F16) {
-            v = *reinterpret_cast<const half8_t*>(reinterpret_cast<const _Float16*>(x) + row * x_stride + k0);
-        } else {
-            const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(x) + row * x_stride + k0);
-            const float4 a = p[0], b = p[1];
-            v[0] = (_Float16)a.x; v[1] = (_Float16)a.y; v[2] = (_Float16)a.z; v[3] = (_Float16)a.w;
-            v[4] = (_Float16)b.x; v[5] = (_Float16)b.y; v[6] = (_Float16)b.z; v[7] = (_Float16)b.w;
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = k0 + j;
-            float e = k < in_cols ? 1.0f : 0.0f;
-            if (k < n_in) {
-                if constexpr (X_F16) e = (float)reinterpret_cast<const _Float16*>(x)[row * x_stride + k];
-                else e = reinterpret_cast<const float*>(x)[row * x_stride + k];
-            }
-            v[j] = (_Float16)e;
-        }
-    }
-    return v;
-}
-
-template <int IN_STEPS, int N_HIDDEN, bool X_F16>
+template <int IN_STEPS, int N_HIDDEN, bool X_F16, bool FAST>
 __global__ __launch_bounds__(kBlock) void k_mlp_fwd(const void* __restrict__ x, uint32_t M, uint32_t n_in, uint32_t x_stride,
                                                     const _Float16* __restrict__ weights, uint32_t in_cols,
                                                     float* __restrict__ out, uint32_t out_stride, int vec_ok) {
@@ -60,6 +32,8 @@ __global__ __launch_bounds__(kBlock) void k_mlp_fwd(const void* __restrict__ x, 
     OutLayerW wout;
     wout.load(wp, lane);
 
+    XTail tail;
+    if constexpr (FAST) tail.init(32 * (IN_STEPS - 1) + 8 * g, (int)n_in, (int)in_cols);
     const uint32_t n_tiles = (M + 15) / 16;
     const uint32_t wave_global = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
     const uint32_t wave_count = gridDim.x * (kBlock / kWave);
@@ -67,8 +41,8 @@ __global__ __launch_bounds__(kBlock) void k_mlp_fwd(const void* __restrict__ x, 
         const uint32_t m = tile * 16 + sl;
         const size_t row = m < M ? m : M - 1;
         half8_t xf[IN_STEPS];
-#pragma unroll
-        for (int s = 0; s < IN_STEPS; ++s) xf[s] = load_x_frag<X_F16>(x, row, x_stride, 32 * s + 8 * g, (int)n_in, (int)in_cols, vec_ok != 0);
+        issue_x_row<IN_STEPS, X_F16, FAST>(xf, x, row, x_stride, g, (int)n_in, (int)in_cols, vec_ok != 0, tail);
+        if constexpr (FAST) xf[IN_STEPS - 1] = tail.apply(xf[IN_STEPS - 1]);
         float4_t acc[kHidTiles];
 #pragma unroll
         for (int t = 0; t < kHidTiles; ++t) {
@@ -109,10 +83,12 @@ NVSF_API int nvsf_mlp_fwd(const void* x, int x_is_f16, uint32_t M, uint32_t n_in
     const uint32_t blocks = n_tiles / 4 + 1 < 2048u ? n_tiles / 4 + 1 : 2048u;
     const _Float16* w = reinterpret_cast<const _Float16*>(weights_f16);
     float* o = out_f32;
-#define LAUNCH(S, H, XF)                                                                                                   \
-    hipLaunchKernelGGL((k_mlp_fwd<S, H, XF>), dim3(blocks), dim3(kBlock), 0, stream, x, M, n_in, x_stride, w, in_cols, o, \
+    const bool fast = x_rows_fast(n_in, x_stride, vec_ok);
+#define LAUNCH(S, H, XF, FA)                                                                                                   \
+    hipLaunchKernelGGL((k_mlp_fwd<S, H, XF, FA>), dim3(blocks), dim3(kBlock), 0, stream, x, M, n_in, x_stride, w, in_cols, o, \
                        out_stride, vec_ok)
-#define BY_X(S, H) do { if (x_is_f16) LAUNCH(S, H, true); else LAUNCH(S, H, false); } while (0)
+#define BY_F(S, H, XF) do { if (fast) LAUNCH(S, H, XF, true); else LAUNCH(S, H, XF, false); } while (0)
+#define BY_X(S, H) do { if (x_is_f16) BY_F(S, H, true); else BY_F(S, H, false); } while (0)
 #define BY_H(S)                                       \
     do {                                              \
         if (n_hidden == 1) BY_X(S, 1);                \

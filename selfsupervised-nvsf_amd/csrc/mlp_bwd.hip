@@ -22,40 +22,16 @@ constexpr int kBlock = 256;
 constexpr int kWavesPerBlock = kBlock / kWave;
 constexpr int kPitch = 72;  // halfs per LDS row of the transposed staging: 64 samples + 8 (16-B aligned, spreads the banks)
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope fence, i.e. s_waitcnt vmcnt(0):
+// it would drain the next iteration's prefetched global loads (and this iteration's dX stores) at every staging step.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ int kappa(int s, int g, int j) { return 16 * (2 * s + (j >> 2)) + 4 * g + (j & 3); }
 
 // fp32 accumulator tiles (2s, 2s+1) -> B fragment of k-step s, no activation (cf. relu_pack)
 __device__ __forceinline__ half8_t plain_pack(float4_t a, float4_t b) {
     const float8_t v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     return __builtin_convertvector(v, half8_t);
-}
-
-template <bool X_F16>
-__device__ __forceinline__ half8_t load_x_frag_b(const void* __restrict__ x, size_t row, uint32_t x_stride, int k0, int n_in, int in_cols,
-                                                 bool vec_ok) {
-    half8_t v;
-    if (k0 + 8 <= n_in && vec_ok) {
-        if constexpr (X_F16) {
-            v = *reinterpret_cast<const half8_t*>(reinterpret_cast<const _Float16*>(x) + row * x_stride + k0);
-        } else {
-            const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(x) + row * x_stride + k0);
-            const float4 a = p[0], b = p[1];
-            v[0] = (_Float16)a.x; v[1] = (_Float16)a.y; v[2] = (_Float16)a.z; v[3] = (_Float16)a.w;
-            v[4] = (_Float16)b.x; v[5] = (_Float16)b.y; v[6] = (_Float16)b.z; v[7] = (_Float16)b.w;
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = k0 + j;
-            float e = k < in_cols ? 1.0f : 0.0f;
-            if (k < n_in) {
-                if constexpr (X_F16) e = (float)reinterpret_cast<const _Float16*>(x)[row * x_stride + k];
-                else e = reinterpret_cast<const float*>(x)[row * x_stride + k];
-            }
-            v[j] = (_Float16)e;
-        }
-    }
-    return v;
 }
 
 template <int IN_STEPS, int N_HIDDEN>
@@ -114,12 +90,12 @@ __device__ __forceinline__ void relu_mask(float4_t (&gacc)[kHidTiles], const hal
             if (!(h[t >> 1][(t & 1) * 4 + r] > (_Float16)0.0f)) gacc[t][r] = 0.0f;
 }
 
-template <int IN_STEPS, int N_HIDDEN, bool X_F16>
+template <int IN_STEPS, int N_HIDDEN, bool X_F16, bool FAST>
 __global__ __launch_bounds__(kBlock) void k_mlp_bwd(const void* __restrict__ x, uint32_t M, uint32_t n_in, uint32_t x_stride,
                                                     const _Float16* __restrict__ weights, uint32_t in_cols,
                                                     const float* __restrict__ grad_out, uint32_t n_out, uint32_t go_stride, float grad_scale,
                                                     float* __restrict__ grad_x, uint32_t gx_stride, float* __restrict__ grad_w, int vec_ok,
-                                                    uint32_t gx_col0, int gx_accumulate) {
+                                                    uint32_t gx_col0, int gx_accumulate, int go_vec) {
     using FR = BwdFrags<IN_STEPS, N_HIDDEN>;
     constexpr int IN_TILES = FR::IN_TILES;
     __shared__ half8_t s_frag[FR::kCount * kWave];
@@ -149,15 +125,53 @@ __global__ __launch_bounds__(kBlock) void k_mlp_bwd(const void* __restrict__ x, 
         return *reinterpret_cast<const half8_t*>(arr + (size_t)(row0 + c) * kPitch + 32 * ks + 8 * g);
     };
 
-    for (uint32_t it = 0; it < n_iters; ++it) {
+    // operands of one iteration: the x fragments and the raw output gradients of this lane's sample.  Those of iteration
+    // it + 1 are requested before iteration it computes (two resident workgroups per CU cannot hide a dependent global
+    // load per iteration by themselves).
+    XTail tail;
+    if constexpr (FAST) tail.init(32 * (IN_STEPS - 1) + 8 * g, (int)n_in, (int)in_cols);
+    struct Operands {
+        half8_t xf[IN_STEPS];
+        float go[8];
+        uint32_t m;
+        bool valid;
+    };
+    auto fetch = [&](uint32_t it, Operands& op) {
         const uint32_t tile = (it * gridDim.x + blockIdx.x) * kWavesPerBlock + (uint32_t)w;
-        const uint32_t m = tile * 16 + (uint32_t)c;
-        const bool valid = tile < n_tiles && m < M;
-        const size_t row = valid ? m : (M - 1);
-        // ---- forward recompute
+        op.m = tile * 16 + (uint32_t)c;
+        op.valid = tile < n_tiles && op.m < M;
+        const size_t row = op.valid ? op.m : (M - 1);
+        issue_x_row<IN_STEPS, X_F16, FAST>(op.xf, x, row, x_stride, g, (int)n_in, (int)in_cols, vec_ok != 0, tail);
+        const float* go_row = grad_out + row * go_stride;
+        if (go_vec) {  // 16 outputs, 16-byte aligned rows: two 16-byte loads for the lanes that hold outputs (g < 2)
+            const float4* p = reinterpret_cast<const float4*>(go_row) + 2 * (g & 1);
+            const float4 a = p[0], b = p[1];
+            op.go[0] = a.x; op.go[1] = a.y; op.go[2] = a.z; op.go[3] = a.w;
+            op.go[4] = b.x; op.go[5] = b.y; op.go[6] = b.z; op.go[7] = b.w;
+        } else {  // element loads with the column clamped into the row, issued back to back
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t o = 8 * (g & 1) + j;
+                op.go[j] = go_row[o < n_out ? o : n_out - 1];
+            }
+        }
+    };
+    // the wide variants have no registers to spare for a second set of operands at two waves per SIMD: they fetch in place
+    constexpr bool kPrefetch = FAST || IN_STEPS <= 2;
+    Operands next;
+    if (kPrefetch && n_iters) fetch(0, next);
+
+    for (uint32_t it = 0; it < n_iters; ++it) {
+        if (!kPrefetch) fetch(it, next);
+        const Operands cur = next;
+        if (kPrefetch && it + 1 < n_iters) fetch(it + 1, next);
+        const uint32_t m = cur.m;
+        const bool valid = cur.valid;
         half8_t xf[IN_STEPS];
 #pragma unroll
-        for (int s = 0; s < IN_STEPS; ++s) xf[s] = load_x_frag_b<X_F16>(x, row, x_stride, 32 * s + 8 * g, (int)n_in, (int)in_cols, vec_ok != 0);
+        for (int s = 0; s < IN_STEPS; ++s) xf[s] = cur.xf[s];
+        if constexpr (FAST) xf[IN_STEPS - 1] = tail.apply(xf[IN_STEPS - 1]);
+        // ---- forward recompute
         float4_t acc[kHidTiles];
 #pragma unroll
         for (int t = 0; t < kHidTiles; ++t) {
@@ -180,14 +194,9 @@ __global__ __launch_bounds__(kBlock) void k_mlp_bwd(const void* __restrict__ x, 
         }
         const half8_t(&h_last)[kHidSteps] = N_HIDDEN == 2 ? h1 : h0;
         // ---- output gradient -> B fragment (natural order of the 16 outputs, zero beyond n_out, scaled)
-        half8_t go = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (valid && g < 2) {
+        half8_t go;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const uint32_t o = 8 * g + j;
-                if (o < n_out) go[j] = (_Float16)(grad_out[(size_t)m * go_stride + o] * grad_scale);
-            }
-        }
+        for (int j = 0; j < 8; ++j) go[j] = (valid && g < 2 && 8u * g + j < n_out) ? (_Float16)(cur.go[j] * grad_scale) : (_Float16)0.0f;
         // ---- data path backward
         float4_t gacc[kHidTiles];
 #pragma unroll
@@ -218,9 +227,17 @@ __global__ __launch_bounds__(kBlock) void k_mlp_bwd(const void* __restrict__ x, 
                     float4_t a = {0, 0, 0, 0};
 #pragma unroll
                     for (int s = 0; s < kHidSteps; ++s) a = mfma16(frag[(FR::kB0 + 2 * ti + s) * kWave], gp0[s], a);
-                    if (valid) {
-                        const uint32_t k0 = 16 * ti + 4 * g;
-                        float* row_x = grad_x + (size_t)m * gx_stride;
+                    const uint32_t k0 = 16 * ti + 4 * g;
+                    float* row_x = grad_x + (size_t)m * gx_stride;
+                    if constexpr (FAST) {  // 16-byte aligned window: this lane's four columns as one store (the last group may
+                                           // reach into the row's alignment padding)
+                        if (valid && k0 >= gx_col0 && k0 < n_in) {
+                            float4_t* p = reinterpret_cast<float4_t*>(row_x + (k0 - gx_col0));
+                            float4_t v = a * inv_scale;
+                            if (gx_accumulate) v += *p;
+                            *p = v;
+                        }
+                    } else if (valid) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const uint32_t k = k0 + r;
@@ -243,10 +260,10 @@ __global__ __launch_bounds__(kBlock) void k_mlp_bwd(const void* __restrict__ x, 
         for (int s = 0; s < kHidSteps; ++s)
 #pragma unroll
             for (int j = 0; j < 8; ++j) s_a[(size_t)kappa(s, g, j) * kPitch + col] = h_last[s][j];
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) dwo = mfma16(t_frag(s_g, 0, ks), t_frag(s_a, 16 * w, ks), dwo);
-        __syncthreads();
+        lds_barrier();
         // (2) hidden layer: dW1[o][k] = sum_s dP1[s][o] * h0[s][k]
         if constexpr (N_HIDDEN == 2) {
 #pragma unroll
@@ -256,14 +273,14 @@ __global__ __launch_bounds__(kBlock) void k_mlp_bwd(const void* __restrict__ x, 
                     s_g[(size_t)kappa(s, g, j) * kPitch + col] = gp_last[s][j];
                     s_a[(size_t)kappa(s, g, j) * kPitch + col] = h0[s][j];
                 }
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const half8_t a = t_frag(s_g, 16 * w, ks);
 #pragma unroll
                 for (int tk = 0; tk < kHidTiles; ++tk) dw1[tk] = mfma16(a, t_frag(s_a, 16 * tk, ks), dw1[tk]);
             }
-            __syncthreads();
+            lds_barrier();
         }
         // (3) first layer: dW0[o][k] = sum_s dP0[s][o] * x[s][k]
 #pragma unroll
@@ -274,14 +291,14 @@ __global__ __launch_bounds__(kBlock) void k_mlp_bwd(const void* __restrict__ x, 
         for (int s = 0; s < IN_STEPS; ++s)
 #pragma unroll
             for (int j = 0; j < 8; ++j) s_a[(size_t)(32 * s + 8 * g + j) * kPitch + col] = xf[s][j];
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const half8_t a = t_frag(s_g, 16 * w, ks);
 #pragma unroll
             for (int tk = 0; tk < IN_TILES; ++tk) dw0[tk] = mfma16(a, t_frag(s_a, 16 * tk, ks), dw0[tk]);
         }
-        __syncthreads();
+        lds_barrier();
     }
     // ---- flush: accumulator element (row 4g + r, column c) of tile (to, tk)
     float* gw0 = grad_w;
@@ -322,16 +339,23 @@ NVSF_API int nvsf_mlp_bwd(const void* x, int x_is_f16, uint32_t M, uint32_t n_in
     const int in_steps = (int)((in_cols + 31) / 32);
     const size_t esz = x_is_f16 ? 2 : 4;
     const int vec_ok = ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) && ((x_stride * esz) % 16 == 0);
+    const int go_vec = n_out == 16 && go_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(grad_out) & 15u) == 0;
     const uint32_t n_tiles = (M + 15) / 16;
     uint32_t blocks = (n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
     const char* cap_env = getenv("NVSF_MLP_BWD_BLOCKS");
     const uint32_t cap = cap_env ? (uint32_t)atoi(cap_env) : 512u;  // 256 CUs x 2 resident workgroups; fewer workgroups = fewer flush atomics
     if (blocks > cap) blocks = cap;
     const _Float16* w = reinterpret_cast<const _Float16*>(weights_f16);
-#define LAUNCH(S, H, XF)                                                                                                          \
-    hipLaunchKernelGGL((k_mlp_bwd<S, H, XF>), dim3(blocks), dim3(kBlock), 0, stream, x, M, n_in, x_stride, w, in_cols, grad_out, \
-                       n_out, go_stride, grad_scale, grad_x, gx_stride, grad_weights_f32, vec_ok, gx_col0, gx_accumulate)
-#define BY_X(S, H) do { if (x_is_f16) LAUNCH(S, H, true); else LAUNCH(S, H, false); } while (0)
+    // FAST: 16-byte loads of x (mlp_device.h) and 16-byte stores of dX (window and rows aligned to four floats, rows wide
+    // enough for the last group of four)
+    const bool gx_vec = !grad_x || (gx_col0 % 4 == 0 && gx_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(grad_x) & 15u) == 0 &&
+                                    (n_in - gx_col0 + 3u) / 4u * 4u <= gx_stride);
+    const bool fast = x_rows_fast(n_in, x_stride, vec_ok) && gx_vec;
+#define LAUNCH(S, H, XF, FA)                                                                                                          \
+    hipLaunchKernelGGL((k_mlp_bwd<S, H, XF, FA>), dim3(blocks), dim3(kBlock), 0, stream, x, M, n_in, x_stride, w, in_cols, grad_out, \
+                       n_out, go_stride, grad_scale, grad_x, gx_stride, grad_weights_f32, vec_ok, gx_col0, gx_accumulate, go_vec)
+#define BY_F(S, H, XF) do { if (fast) LAUNCH(S, H, XF, true); else LAUNCH(S, H, XF, false); } while (0)
+#define BY_X(S, H) do { if (x_is_f16) BY_F(S, H, true); else BY_F(S, H, false); } while (0)
 #define BY_H(S) do { if (n_hidden == 1) BY_X(S, 1); else BY_X(S, 2); } while (0)
     switch (in_steps) {
         case 1: BY_H(1); break;

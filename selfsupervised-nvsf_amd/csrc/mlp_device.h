@@ -17,6 +17,8 @@
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef float float4_t __attribute__((ext_vector_type(4)));
+typedef short short8_t __attribute__((ext_vector_type(8)));
+typedef float float8_t __attribute__((ext_vector_type(8)));
 
 constexpr int kHidden = 64;            // width of every hidden layer on this path
 constexpr int kHidTiles = kHidden / 16;  // 16-row output tiles per hidden layer
@@ -46,13 +48,103 @@ __device__ __forceinline__ half8_t load_w_chained(const _Float16* __restrict__ W
     return v;
 }
 
+// ---- network input -> B fragments -------------------------------------------------------------------------------
+// Lane (g, c) of k-step s holds columns 32s + 8g .. +7 of its sample's row, rounded to fp16; columns n_in .. in_cols-1
+// read as 1.0 (tcnn pads the network input with ones), anything beyond as 0.  in_cols is n_in rounded up to 16, so
+// padding can only occur in the LAST k-step.
+//
+// Fast form (rows 16-byte aligned and at least round_up(n_in, 8) columns wide -- every buffer of this package): one 16-byte
+// load per k-step and lane, no condition anywhere; the last k-step loads from a per-lane column fixed before the loop
+// (its own slice, or column 0 where the slice is padding only) and is patched with two per-lane bit masks,
+// (v & keep) | pad.  `issue` only loads, `finish` patches: a kernel can request the next tile before it computes the
+// current one without a wait in between.
+typedef uint32_t uint4_t __attribute__((ext_vector_type(4)));
+
+struct XTail {
+    uint4_t keep, pad;
+    int koff;
+    __device__ __forceinline__ void init(int k0, int n_in, int in_cols) {
+        const int n_keep = n_in - k0 < 0 ? 0 : (n_in - k0 > 8 ? 8 : n_in - k0);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            uint32_t kp = 0, pd = 0;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int j = 2 * d + e, k = k0 + j;
+                if (j < n_keep) kp |= 0xFFFFu << (16 * e);
+                else if (k < in_cols) pd |= 0x3C00u << (16 * e);  // fp16 1.0
+            }
+            keep[d] = kp;
+            pad[d] = pd;
+        }
+        koff = n_keep > 0 ? k0 : 0;
+    }
+    __device__ __forceinline__ half8_t apply(half8_t v) const {
+        return __builtin_bit_cast(half8_t, (__builtin_bit_cast(uint4_t, v) & keep) | pad);
+    }
+};
+
+inline __host__ __device__ bool x_rows_fast(uint32_t n_in, uint32_t x_stride, int vec_ok) {
+    return vec_ok != 0 && (n_in + 7u) / 8u * 8u <= x_stride;
+}
+
+template <bool X_F16>
+__device__ __forceinline__ half8_t load_x_vec(const void* __restrict__ x, size_t row, uint32_t x_stride, int k0) {
+    if constexpr (X_F16) {
+        return *reinterpret_cast<const half8_t*>(reinterpret_cast<const _Float16*>(x) + row * x_stride + k0);
+    } else {
+        const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(x) + row * x_stride + k0);
+        const float4 a = p[0], b = p[1];
+        const float8_t v = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        return __builtin_convertvector(v, half8_t);
+    }
+}
+
+// General form (any stride / alignment): element loads with the column clamped into the row, issued back to back, padding
+// selected afterwards.
+template <bool X_F16>
+__device__ __forceinline__ half8_t load_x_frag(const void* __restrict__ x, size_t row, uint32_t x_stride, int k0, int n_in, int in_cols,
+                                               bool vec_ok) {
+    half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (k0 < n_in) {
+        if (vec_ok && k0 + 8 <= n_in) {
+            v = load_x_vec<X_F16>(x, row, x_stride, k0);
+        } else {
+            const int last = n_in - 1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + j < last ? k0 + j : last;
+                if constexpr (X_F16) v[j] = reinterpret_cast<const _Float16*>(x)[row * x_stride + k];
+                else v[j] = (_Float16) reinterpret_cast<const float*>(x)[row * x_stride + k];
+            }
+        }
+    }
+    if (k0 + 8 > n_in) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (k0 + j >= n_in) v[j] = k0 + j < in_cols ? (_Float16)1.0f : (_Float16)0.0f;
+    }
+    return v;
+}
+
+template <int IN_STEPS, bool X_F16, bool FAST>
+__device__ __forceinline__ void issue_x_row(half8_t (&xf)[IN_STEPS], const void* __restrict__ x, size_t row, uint32_t x_stride, int g, int n_in,
+                                            int in_cols, bool vec_ok, const XTail& tail) {
+    if constexpr (FAST) {
+#pragma unroll
+        for (int s = 0; s + 1 < IN_STEPS; ++s) xf[s] = load_x_vec<X_F16>(x, row, x_stride, 32 * s + 8 * g);
+        xf[IN_STEPS - 1] = load_x_vec<X_F16>(x, row, x_stride, tail.koff);
+    } else {
+#pragma unroll
+        for (int s = 0; s < IN_STEPS; ++s) xf[s] = load_x_frag<X_F16>(x, row, x_stride, 32 * s + 8 * g, n_in, in_cols, vec_ok);
+    }
+}
+
 // ReLU + round to fp16 of two accumulator tiles (2s, 2s+1) -> B fragment of k-step s of the next layer.
 // Order: round to fp16 first (v_cvt_pk_f16_f32, two values per instruction), then clamp the packed halves with
 // an INTEGER max against 0 (v_pk_max_i16): an fp16 with the sign bit set is a negative int16.  Rounding is
 // sign-preserving and monotonic, so this equals fp16(max(x, 0)) for every finite x, and it avoids both the
 // per-value fp32 v_max and the canonicalising v_max hipcc puts in front of fmaxf on MFMA results.
-typedef short short8_t __attribute__((ext_vector_type(8)));
-typedef float float8_t __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ half8_t relu_pack(float4_t a, float4_t b) {
     // a VECTOR fp32 -> fp16 conversion selects gfx950's v_cvt_pk_f16_f32 (two values per instruction, round-to-nearest-even)

@@ -187,7 +187,8 @@ def mlp_backward(x, weights_f16, spec, grad_out, need_grad_x=True, grad_scale=ML
     M = x.shape[0]
     grad_w = torch.zeros(spec.n_params, dtype=torch.float32, device=x.device)
     if grad_x is None and need_grad_x:
-        grad_x = torch.empty(M, spec.n_in - gx_col0, dtype=torch.float32, device=x.device)
+        n_gx = spec.n_in - gx_col0  # rows padded to four floats: the kernel then stores 16 bytes per lane
+        grad_x = torch.empty(M, (n_gx + 3) // 4 * 4, dtype=torch.float32, device=x.device)[:, :n_gx]
     _hip.call("nvsf_mlp_bwd", _hip.ptr_rows(x), 1 if x.dtype == torch.float16 else 0, M, spec.n_in, x.stride(0), _hip.ptr(weights_f16),
               spec.in_cols, spec.hidden, spec.n_hidden, spec.out_cols, _hip.ptr_rows(grad_out), grad_out.shape[1], grad_out.stride(0),
               float(grad_scale), None if grad_x is None else _hip.ptr_rows(grad_x), 0 if grad_x is None else grad_x.stride(0),

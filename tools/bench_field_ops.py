@@ -112,7 +112,7 @@ def field_op_rooflines(dev, n_rays=4096, T=768, seed=0):
                          f"{flops} FLOP/sample; {2 * spec.in_cols + 64} B/sample (fp16 rows in, fp32 logits out)"))
         if n_hidden <= 2:
             g = torch.randn(M, n_out, device=dev) * 0.01
-            gx = torch.empty(M, n_in, device=dev)
+            gx = torch.empty(M, (n_in + 3) // 4 * 4, device=dev)[:, :n_in]  # 16-byte aligned rows, as ops.mlp_backward allocates them
             ms = _time_ms(lambda: ops.mlp_backward(x, w16, spec, g, grad_x=gx), 5)
             nbytes = 2 * spec.in_cols + 4 * n_out + 4 * n_in
             rows.append(_mlp(f"mlp_bwd[{name}]", ms, 3 * flops, nbytes, M,
