@@ -163,6 +163,18 @@ int nvsf_freq_encode(const float* x, uint32_t M, uint32_t n_dims, uint32_t n_fre
  * dirs01 fp32 [M,3] in [0,1] -> out fp16 [M, out_stride >= 16]. */
 int nvsf_sh4_encode(const float* dirs01, uint32_t M, void* out_f16, uint32_t out_stride, nvsf_stream_t stream);
 
+/* ref: backward of `sigma = trunc_exp(h[..., 0]); geo_feat = h[..., 1:]` (network_dynamic.py:284-287, activation.py:6-20) as
+ * one pass: grad_h[m][0] = grad_sigma[m] * clamp(sigma[m], sigma_lo, sigma_hi), grad_h[m][1 + j] = grad_geo[m][j] (j < n_geo <= 15),
+ * remaining columns of the 16 zero.  grad_sigma / grad_geo may be NULL (read as zeros).  grad_h fp32 [M, gh_stride >= 16],
+ * 16-byte aligned rows. */
+int nvsf_sigma_geo_bwd(const float* grad_sigma, const float* sigma, const float* grad_geo, uint32_t gg_stride, uint32_t n_geo,
+                       uint32_t M, float* grad_h, uint32_t gh_stride, float sigma_lo, float sigma_hi, nvsf_stream_t stream);
+
+/* ref: the `.to(half)` / `torch.cat([d, geo_feat], dim=-1)` glue of network_dynamic.py:310-325 for one column block:
+ * dst[m][j] = fp16(src[m][j]), j < n_cols, between row-strided views (src fp32, or fp16 when src_is_f16). */
+int nvsf_cast_cols_f16(const void* src, int src_is_f16, uint32_t M, uint32_t n_cols, uint32_t src_stride, void* dst_f16,
+                       uint32_t dst_stride, nvsf_stream_t stream);
+
 /* ref: tcnn.Network("FullyFusedMLP") network_dynamic.py:125-135,138-161,180-189.
  * x [M, x_stride] fp32 (x_is_f16 == 0) or fp16; weights fp16 = W0 [hidden][in_cols] ++ (n_hidden-1) x
  * [hidden][hidden] ++ W_out [out_cols][hidden]; columns n_in..in_cols-1 of the input read as 1.0.

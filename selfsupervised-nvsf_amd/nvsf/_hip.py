@@ -38,6 +38,8 @@ SIGNATURES = {
     "nvsf_hashgrid_bwd": [_P, _U, _U, _P, _U, _U, _U, _P, _P, _P, _P, _I, _U, _P],
     "nvsf_freq_encode": [_P, _U, _U, _U, _P, _U],
     "nvsf_sh4_encode": [_P, _U, _P, _U],
+    "nvsf_sigma_geo_bwd": [_P, _P, _P, _U, _U, _U, _P, _U, _F, _F],
+    "nvsf_cast_cols_f16": [_P, _I, _U, _U, _U, _P, _U],
     "nvsf_mlp_fwd": [_P, _I, _U, _U, _U, _P, _U, _U, _U, _U, _P, _U],
     "nvsf_mlp_bwd": [_P, _I, _U, _U, _U, _P, _U, _U, _U, _U, _P, _U, _U, _F, _P, _U, _P, _U, _I],
     "nvsf_planes_fwd": [_P, _U, _P, _U, _U, _P, _I, _P, _P],

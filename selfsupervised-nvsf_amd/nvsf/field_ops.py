@@ -145,13 +145,15 @@ def _rows(x):
     return x
 
 
-def mlp_forward(x, weights_f16, spec):
-    """x [M, n_in] (fp32 or fp16) -> fp32 [M, out_cols] (fp16 operands, fp32 accumulate, output not rounded)."""
+def mlp_forward(x, weights_f16, spec, out=None):
+    """x [M, n_in] (fp32 or fp16) -> fp32 [M, out_cols] (fp16 operands, fp32 accumulate, output not rounded).
+    `out`: optional fp32 destination, 16-byte aligned rows of >= out_cols columns (e.g. a column block of a wider buffer)."""
     x = _rows(x)
     M = x.shape[0]
-    out = torch.empty(M, spec.out_cols, dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty(M, spec.out_cols, dtype=torch.float32, device=x.device)
     _hip.call("nvsf_mlp_fwd", _hip.ptr_rows(x), 1 if x.dtype == torch.float16 else 0, M, spec.n_in, x.stride(0), _hip.ptr(weights_f16),
-              spec.in_cols, spec.hidden, spec.n_hidden, spec.out_cols, _hip.ptr(out), out.stride(0))
+              spec.in_cols, spec.hidden, spec.n_hidden, spec.out_cols, _hip.ptr_rows(out), out.stride(0))
     return out
 
 
@@ -231,14 +233,21 @@ class HeadsFn(Function):
     def forward(ctx, buf, n_enc, geo, params_a, w16_a, spec, params_b=None, w16_b=None):
         n_geo = geo.shape[1]
         assert n_enc + n_geo == spec.n_in and buf.shape[1] >= spec.n_in and buf.dtype == torch.float16
-        buf[:, n_enc:n_enc + n_geo] = geo
+        cast_cols_f16(geo, buf[:, n_enc:n_enc + n_geo])
         u = buf[:, :spec.n_in]
-        outs = [mlp_forward(u, w16_a, spec)[:, :spec.n_out]]
-        if w16_b is not None:
-            outs.append(mlp_forward(u, w16_b, spec)[:, :spec.n_out])
         ctx.save_for_backward(buf, w16_a, w16_b)
         ctx.spec, ctx.n_enc, ctx.n_geo, ctx.geo_dtype = spec, n_enc, n_geo, geo.dtype
-        return outs[0] if len(outs) == 1 else torch.cat(outs, dim=-1)
+        if w16_b is None:
+            return mlp_forward(u, w16_a, spec)[:, :spec.n_out]
+        # both heads write their 16-column logit blocks side by side; [raydrop | intensity] is a strided view of the
+        # leading columns of the two blocks (no torch.cat pass over the samples)
+        M = buf.shape[0]
+        blocks = torch.empty(M, 2 * spec.out_cols, dtype=torch.float32, device=buf.device)
+        mlp_forward(u, w16_a, spec, out=blocks[:, :spec.out_cols])
+        mlp_forward(u, w16_b, spec, out=blocks[:, spec.out_cols:])
+        if spec.n_out == 1:
+            return blocks.view(M, 2, spec.out_cols)[:, :, 0]
+        return blocks.view(M, 2, spec.out_cols)[:, :, :spec.n_out].reshape(M, 2 * spec.n_out)
 
     @staticmethod
     def backward(ctx, grad_h):
@@ -308,6 +317,54 @@ class MlpFn(Function):
         grad_params = torch.cat([t.reshape(-1) for t in reversed(grads)]) if ctx.needs_input_grad[1] else None
         grad_x = g[:, :spec.n_in].to(x.dtype) if ctx.needs_input_grad[0] else None
         return grad_x, grad_params, None, None
+
+
+def cast_cols_f16(src, dst):
+    """dst[:, j] = fp16(src[:, j]) for row-strided 2-D views (src fp32 / fp16, dst fp16): one streaming kernel instead of
+    torch's strided element-wise copy."""
+    if src.dtype not in (torch.float16, torch.float32) or src.dim() != 2 or (src.shape[1] > 1 and src.stride(1) != 1):
+        src = src.float().contiguous()
+    M, n = src.shape
+    _hip.call("nvsf_cast_cols_f16", _hip.ptr_rows(src), 1 if src.dtype == torch.float16 else 0, M, n, src.stride(0), _hip.ptr_rows(dst),
+              dst.stride(0))
+    return dst
+
+
+class DensityFn(Function):
+    """(sigma, geo_feat) = split(MLP(encode(x01)))  --  `NeRFNetwork.density` of a static hash field as ONE autograd node
+    (network_dynamic.py:213-287 without the space-time terms: hash grid -> sigma_net -> trunc_exp / slice).
+
+    Same forward kernels as the operator chain (HashGridFn -> MlpFn -> trunc_exp); what changes is the backward: the
+    gradient of the logits is assembled by one streaming kernel (nvsf_sigma_geo_bwd) instead of autograd's zero-fill /
+    strided-copy / add chain for the two slices, and the MLP's input gradient goes to the table scatter in fp32 as it
+    leaves nvsf_mlp_bwd (the operator chain rounds it to fp16 in between, a pass over [M, 32])."""
+
+    @staticmethod
+    def forward(ctx, x01, table_params, table_f16, grid_spec, mlp_params, mlp_w16, mlp_spec, sigma_lo, sigma_hi):
+        x01 = x01.float().contiguous()
+        feat = hashgrid_forward(x01, (0, 1, 2), table_f16, grid_spec)
+        h = mlp_forward(feat, mlp_w16, mlp_spec)
+        sigma = torch.exp(h[:, 0])
+        ctx.save_for_backward(x01, feat, sigma, mlp_w16)
+        ctx.grid_spec, ctx.mlp_spec, ctx.clamp = grid_spec, mlp_spec, (float(sigma_lo), float(sigma_hi))
+        return sigma, h[:, 1:mlp_spec.n_out]
+
+    @staticmethod
+    def backward(ctx, g_sigma, g_geo):
+        x01, feat, sigma, mlp_w16 = ctx.saved_tensors
+        spec, M = ctx.mlp_spec, x01.shape[0]
+        if g_sigma is not None:
+            g_sigma = g_sigma.float().contiguous()
+        if g_geo is not None and (g_geo.dtype != torch.float32 or g_geo.stride(1) != 1):
+            g_geo = g_geo.float().contiguous()
+        grad_h = torch.empty(M, 16, dtype=torch.float32, device=x01.device)
+        _hip.call("nvsf_sigma_geo_bwd", None if g_sigma is None else _hip.ptr(g_sigma), _hip.ptr(sigma),
+                  None if g_geo is None else _hip.ptr_rows(g_geo), 0 if g_geo is None else g_geo.stride(0), spec.n_out - 1, M,
+                  _hip.ptr(grad_h), 16, ctx.clamp[0], ctx.clamp[1])
+        need_table = ctx.needs_input_grad[1]
+        grad_feat, grad_w = mlp_backward(feat, mlp_w16, spec, grad_h[:, :spec.n_out], need_grad_x=need_table)
+        grad_table = hashgrid_backward(x01, (0, 1, 2), ctx.grid_spec, grad_feat) if need_table else None
+        return None, grad_table, None, None, (grad_w if ctx.needs_input_grad[4] else None), None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------

@@ -19,6 +19,7 @@ import torch
 
 import tinycudann as tcnn
 from nvsf import field_ops as ops
+from nvsf.nerf import activation
 from nvsf.nerf.activation import trunc_exp
 from nvsf.nerf.models.renderer_dynamic import NeRFRenderer
 
@@ -55,7 +56,14 @@ class NeRFNetworkStatic(NeRFRenderer):
     def density(self, x, t=None, cal_lidar_color=False, **kwargs):
         x = (x + self.bound) / (2 * self.bound)
         enc = self.hash_encoder_lidar if cal_lidar_color else self.hash_encoder_camera
-        h = self.sigma_net(enc(x))
+        net = self.sigma_net
+        if (x.is_cuda and x.dim() == 2 and enc.spec.D == 3 and net.spec.n_hidden <= 2 and net.spec.hidden == 64
+                and net.spec.out_cols == 16 and os.environ.get("NVSF_DENSITY_FN", "fused") != "chain"):
+            # one autograd node for encode -> MLP -> trunc_exp / slice (ops.DensityFn): same forward kernels, leaner backward
+            sigma, geo = ops.DensityFn.apply(x, enc.params, enc.table_f16(), enc.spec, net.params, net.weights_f16(), net.spec,
+                                             activation._LO, activation._HI)
+            return {"sigma": sigma, "geo_feat": geo}
+        h = net(enc(x))
         return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
 
     def color(self, x, d, cal_lidar_color=False, mask=None, geo_feat=None, **kwargs):

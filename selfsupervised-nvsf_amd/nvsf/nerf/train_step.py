@@ -48,6 +48,9 @@ class RenderTrainStep:
         self.scaler = torch.amp.GradScaler("cuda", enabled=bool(fp16) and torch.cuda.is_available())
         if fp16 and hasattr(model, "flow_net"):
             model.flow_net.flow_mlp_mode = "fused"  # the flow MLP as autocast runs it: fp16 MFMA kernels (flow_field.FlowMlpFn)
+        # torch's default (multi-tensor) Adam: its fused=True variant was tried for the ~45 launches it saves per step and trains
+        # measurably worse under this eps = 1e-15 / GradScaler setting (tests/test_train_step_gpu.py: loss 0.289 -> 0.258
+        # after 120 steps against 0.227)
         self.opt = torch.optim.Adam(model.get_params(lr), betas=(0.9, 0.99), eps=1e-15)
         self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, lambda it: 0.1 ** min(it / iters, 1))
         self.iters, self.num_steps = iters, num_steps

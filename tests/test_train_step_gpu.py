@@ -56,3 +56,46 @@ def test_training_reduces_loss_and_metrics(dev):
     assert abs(p - ref) < 1e-9
     r = depth_rmse(rl["depth_lidar"], batch["gt_depth"], S.SCALE)
     assert 0.0 <= r < 80.0
+
+
+def test_density_fn_equals_operator_chain(dev, monkeypatch):
+    """ops.DensityFn (encode -> MLP -> trunc_exp / slice as one autograd node; logit gradient assembled by nvsf_sigma_geo_bwd,
+    feature gradient handed to the table scatter in fp32) against the operator chain HashGridFn -> MlpFn -> trunc_exp."""
+    from nvsf import synthetic as S
+    from nvsf.nerf.models.network_static import NeRFNetworkStatic
+    torch.manual_seed(3)
+    m = NeRFNetworkStatic(bound=S.BOUND, min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH,
+                          log2_hashmap_size=15).to(dev)
+    with torch.no_grad():
+        m.hash_encoder_lidar.params.copy_(torch.randn_like(m.hash_encoder_lidar.params) * 0.3)
+    M = 5000  # not a multiple of the kernels' tiles
+    x = (torch.rand(M, 3, device=dev) * 2 - 1) * S.BOUND
+    w_sigma, w_geo = torch.randn(M, device=dev), torch.randn(M, 15, device=dev)
+
+    def run(mode):
+        monkeypatch.setenv("NVSF_DENSITY_FN", mode)
+        for p in m.parameters():
+            p.grad = None
+        out = m.density(x, None, cal_lidar_color=True)
+        # loss scaled like a GradScaler step: the chain rounds the feature gradient to fp16 on its way to the table
+        loss = 64.0 * ((out["sigma"] * w_sigma).sum() + (out["geo_feat"].float() * w_geo).sum())
+        loss.backward()
+        return (out["sigma"].detach().clone(), out["geo_feat"].detach().float().clone(), m.hash_encoder_lidar.params.grad.clone(),
+                m.sigma_net.params.grad.clone())
+
+    s1, g1, gt1, gw1 = run("fused")
+    s0, g0, gt0, gw0 = run("chain")
+    assert torch.equal(s1, s0) and torch.equal(g1, g0)  # same forward kernels
+    assert float((gw1 - gw0).abs().max()) <= 1e-3 * float(gw0.abs().max())  # same kernel and operands: atomic order only
+    # table gradient: fp32 feature gradients against the chain's fp16-rounded ones (2^-11 relative per contribution)
+    assert float((gt1 - gt0).abs().max()) <= 2e-3 * float(gt0.abs().max())
+    assert float(gt0.abs().max()) > 0 and int((gt1 != 0).sum()) >= int((gt0 != 0).sum())
+
+    # sigma-only and geo-only graphs (the other gradient arrives as None)
+    monkeypatch.setenv("NVSF_DENSITY_FN", "fused")
+    for sel in ("sigma", "geo_feat"):
+        for p in m.parameters():
+            p.grad = None
+        out = m.density(x, None, cal_lidar_color=True)
+        (64.0 * out[sel].float().sum()).backward()
+        assert torch.isfinite(m.hash_encoder_lidar.params.grad).all() and float(m.hash_encoder_lidar.params.grad.abs().max()) > 0
