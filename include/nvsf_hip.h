@@ -175,6 +175,11 @@ int nvsf_sigma_geo_bwd(const float* grad_sigma, const float* sigma, const float*
 int nvsf_cast_cols_f16(const void* src, int src_is_f16, uint32_t M, uint32_t n_cols, uint32_t src_stride, void* dst_f16,
                        uint32_t dst_stride, nvsf_stream_t stream);
 
+/* ref: the per-sample direction encoding of network_dynamic.py:310-312,319-321 for samples that share their ray's direction
+ * (renderer_dynamic.py:198-200 expands rays_d over the T samples): dst[n * T + t][j] = src[n][j], j < n_cols; fp16 rows. */
+int nvsf_repeat_rows_f16(const void* src_f16, uint32_t N, uint32_t n_cols, uint32_t src_stride, uint32_t T, void* dst_f16,
+                         uint32_t dst_stride, nvsf_stream_t stream);
+
 /* ref: tcnn.Network("FullyFusedMLP") network_dynamic.py:125-135,138-161,180-189.
  * x [M, x_stride] fp32 (x_is_f16 == 0) or fp16; weights fp16 = W0 [hidden][in_cols] ++ (n_hidden-1) x
  * [hidden][hidden] ++ W_out [out_cols][hidden]; columns n_in..in_cols-1 of the input read as 1.0.

@@ -5,7 +5,9 @@
 //                        grad_geo[:, j] -- one pass instead of two zero-fills, two strided copies, an add, a clamp and a mul
 //   nvsf_cast_cols_f16   dst[:, j] = fp16(src[:, j]) between row-strided 2-D views (geometry features into the aligned
 //                        input buffer of the heads, ops.HeadsFn)
-// Both are HBM-stream bound: 132 B and 6 B per element respectively.
+//   nvsf_repeat_rows_f16 dst[n * T + t][:] = src[n][:]: a per-ray fp16 row (direction encoding) broadcast to the T samples of
+//                        the ray -- the encoders then run once per ray instead of once per sample
+// All are HBM-stream bound: 132 B per row, 6 B and 2 B (written) per element respectively.
 #include "common.h"
 
 namespace {
@@ -37,6 +39,20 @@ __global__ __launch_bounds__(kBlock) void k_cast_cols(const void* __restrict__ s
     else v = (_Float16) reinterpret_cast<const float*>(src)[(size_t)m * src_stride + c];
     dst[(size_t)m * dst_stride + c] = v;
 }
+
+// one thread per (destination row, group of VEC halves)
+template <int VEC>
+__global__ __launch_bounds__(kBlock) void k_repeat_rows(const _Float16* __restrict__ src, uint32_t n_cols, uint32_t src_stride, uint32_t T,
+                                                        unsigned long long total, _Float16* __restrict__ dst, uint32_t dst_stride) {
+    const unsigned long long idx = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= total) return;
+    const uint32_t groups = n_cols / VEC;
+    const unsigned long long row = idx / groups;
+    const uint32_t grp = (uint32_t)(idx - row * groups), n = (uint32_t)(row / T);
+    typedef _Float16 vec_t __attribute__((ext_vector_type(VEC)));
+    *reinterpret_cast<vec_t*>(dst + row * dst_stride + (size_t)grp * VEC) =
+        *reinterpret_cast<const vec_t*>(src + (size_t)n * src_stride + (size_t)grp * VEC);
+}
 }  // namespace
 
 #define REQUIRE(cond) do { if (!(cond)) return NVSF_ERR_INVALID_ARG; } while (0)
@@ -59,5 +75,25 @@ NVSF_API int nvsf_cast_cols_f16(const void* src, int src_is_f16, uint32_t M, uin
     _Float16* dst = reinterpret_cast<_Float16*>(dst_f16);
     if (src_is_f16) hipLaunchKernelGGL(k_cast_cols<true>, dim3(cdiv(total, kBlock)), dim3(kBlock), 0, stream, src, M, n_cols, src_stride, dst, dst_stride);
     else hipLaunchKernelGGL(k_cast_cols<false>, dim3(cdiv(total, kBlock)), dim3(kBlock), 0, stream, src, M, n_cols, src_stride, dst, dst_stride);
+    return nvsf_launch_status();
+}
+
+NVSF_API int nvsf_repeat_rows_f16(const void* src_f16, uint32_t N, uint32_t n_cols, uint32_t src_stride, uint32_t T, void* dst_f16,
+                                  uint32_t dst_stride, hipStream_t stream) {
+    if (N == 0 || T == 0 || n_cols == 0) return NVSF_OK;
+    REQUIRE(src_f16 && dst_f16 && src_stride >= n_cols && dst_stride >= n_cols);
+    const _Float16* src = reinterpret_cast<const _Float16*>(src_f16);
+    _Float16* dst = reinterpret_cast<_Float16*>(dst_f16);
+    const bool vec8 = n_cols % 8 == 0 && src_stride % 8 == 0 && dst_stride % 8 == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0;
+    const unsigned long long rows = (unsigned long long)N * T;
+    if (vec8) {
+        const unsigned long long total = rows * (n_cols / 8);
+        REQUIRE((total + kBlock - 1) / kBlock < (1ull << 31));
+        hipLaunchKernelGGL(k_repeat_rows<8>, dim3(cdiv(total, kBlock)), dim3(kBlock), 0, stream, src, n_cols, src_stride, T, total, dst, dst_stride);
+    } else {
+        const unsigned long long total = rows * n_cols;
+        REQUIRE((total + kBlock - 1) / kBlock < (1ull << 31));
+        hipLaunchKernelGGL(k_repeat_rows<1>, dim3(cdiv(total, kBlock)), dim3(kBlock), 0, stream, src, n_cols, src_stride, T, total, dst, dst_stride);
+    }
     return nvsf_launch_status();
 }

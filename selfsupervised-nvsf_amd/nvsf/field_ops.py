@@ -198,21 +198,30 @@ def mlp_backward(x, weights_f16, spec, grad_out, need_grad_x=True, grad_scale=ML
     return grad_x, grad_w
 
 
-def heads(model, d01, geo_feat, cal_lidar_color):
+def heads(model, d01, geo_feat, cal_lidar_color, ray_dirs01=None):
     """Logits of the per-sample heads of `model` (a NeRFNetwork / NeRFNetworkStatic): [M, 2] = [raydrop, intensity] for
-    LiDAR samples, [M, 3] colour logits otherwise.  d01: directions mapped to [0, 1]; geo_feat: [M, geo_feat_dim]."""
+    LiDAR samples, [M, 3] colour logits otherwise.  d01: directions mapped to [0, 1]; geo_feat: [M, geo_feat_dim].
+    ray_dirs01 [N, 3] (with M = N * T, sample rows ordered ray by ray): the directions per RAY instead of d01 -- the
+    encoding is then evaluated N times and broadcast to the samples (same values: every sample of a ray has its direction)."""
     if cal_lidar_color:
         net_a, net_b, enc = model.raydrop_net, model.intensity_net, model.view_encoder_lidar
     else:
         net_a, net_b, enc = model.color_net, None, model.view_encoder_camera
     spec = net_a.spec
-    M = d01.shape[0]
-    buf = torch.empty(M, spec.in_cols, dtype=torch.float16, device=d01.device)
+    M = geo_feat.shape[0]
+    buf = torch.empty(M, spec.in_cols, dtype=torch.float16, device=geo_feat.device)
     with torch.no_grad():
+        src = d01 if ray_dirs01 is None else ray_dirs01
+        n_enc_cols = enc.n_output_dims
+        dst = buf if ray_dirs01 is None else torch.empty(src.shape[0], (n_enc_cols + 7) // 8 * 8, dtype=torch.float16, device=buf.device)
         if enc.otype == "Frequency":
-            freq_encode(d01, enc.n_frequencies, out=buf)
+            freq_encode(src, enc.n_frequencies, out=dst)
         else:
-            sh4_encode(d01, out=buf)
+            sh4_encode(src, out=dst)
+        if ray_dirs01 is not None:
+            N = src.shape[0]
+            assert M % N == 0
+            _hip.call("nvsf_repeat_rows_f16", _hip.ptr(dst), N, n_enc_cols, dst.stride(0), M // N, _hip.ptr(buf), buf.stride(0))
     if net_b is None:
         return HeadsFn.apply(buf, enc.n_output_dims, geo_feat, net_a.params, net_a.weights_f16(), spec)
     return HeadsFn.apply(buf, enc.n_output_dims, geo_feat, net_a.params, net_a.weights_f16(), spec, net_b.params, net_b.weights_f16())

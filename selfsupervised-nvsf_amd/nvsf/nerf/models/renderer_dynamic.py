@@ -248,8 +248,9 @@ class NeRFRenderer(nn.Module):
             dirs = rays_d.view(-1, 1, 3).expand(N, T, 3)
             mask = weights > ops.W_THRESH
             extra = {k: v.view(N * T, -1) for k, v in density_outputs.items() if k != "sigma"}
+            # ray_dirs: the per-ray rows `dirs` repeats -- lets the heads encode each direction once (ops.heads)
             rgbs = self.color(xyzs.view(-1, 3), dirs.reshape(-1, 3), cal_lidar_color=cal_lidar_color, mask=mask.reshape(-1),
-                              **extra)
+                              ray_dirs=rays_d, **extra)
             bg_dev = torch.tensor(bg_host, dtype=torch.float32, device=rays_o.device) if bg_host is not None else None
             image = ops.CompositeImageFn.apply(weights, rgbs.view(N, T, self.out_dim), weights_sum, bg_dev)
         if per_ray_bg is not None:

@@ -181,3 +181,24 @@ def test_heads_fn_equals_the_cat_formulation(dev, lidar):
     assert float((got[1] - ref[1]).abs().max()) <= 2e-3 * s  # two heads summed in fp32 inside the kernel vs by torch
     for a, b in zip(got[2:], ref[2:]):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max()))
+
+
+def test_heads_per_ray_direction_encoding(dev):
+    """ops.heads with ray_dirs01 (encode each ray's direction once, nvsf_repeat_rows_f16 broadcasts it to the samples) gives
+    the logits of the per-sample encoding bit for bit, for both head families."""
+    import torch
+    from nvsf import field_ops as ops, synthetic as S
+    from nvsf.nerf.models.network_static import NeRFNetworkStatic
+    torch.manual_seed(5)
+    m = NeRFNetworkStatic(bound=S.BOUND, min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH,
+                          log2_hashmap_size=14).to(dev)
+    N, T = 37, 19
+    rays = torch.nn.functional.normalize(torch.randn(N, 3, device=dev), dim=-1)
+    d01_ray = (rays + 1) / 2
+    d01 = d01_ray.view(N, 1, 3).expand(N, T, 3).reshape(-1, 3)
+    geo = torch.randn(N * T, 15, device=dev)
+    for lidar in (True, False):
+        a = ops.heads(m, d01, geo, lidar)
+        b = ops.heads(m, None, geo, lidar, ray_dirs01=d01_ray)
+        assert a.shape == b.shape == (N * T, 2 if lidar else 3)
+        assert torch.equal(a, b)
