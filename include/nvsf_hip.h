@@ -180,6 +180,14 @@ int nvsf_cast_cols_f16(const void* src, int src_is_f16, uint32_t M, uint32_t n_c
 int nvsf_repeat_rows_f16(const void* src_f16, uint32_t N, uint32_t n_cols, uint32_t src_stride, uint32_t T, void* dst_f16,
                          uint32_t dst_stride, nvsf_stream_t stream);
 
+/* ref: `torch.cat([view_encoder(d), geo_feat], dim=-1)` of network_dynamic.py:310-325 for samples ordered ray by ray, as the
+ * padded fp16 input rows of the heads: dst[n * T + t] = [enc_ray[n][0 .. n_enc) | fp16(geo[n * T + t][0 .. n_geo)) | 1.0 ...] up to
+ * in_cols columns (tcnn pads the network input with ones).  n_enc, in_cols, enc_stride, dst_stride multiples of 8; 16-byte
+ * aligned enc_ray / dst; geo fp32, or fp16 when geo_is_f16. */
+int nvsf_heads_input_f16(const void* enc_ray_f16, uint32_t N, uint32_t n_enc, uint32_t enc_stride, uint32_t T, const void* geo,
+                         int geo_is_f16, uint32_t n_geo, uint32_t geo_stride, void* dst_f16, uint32_t in_cols, uint32_t dst_stride,
+                         nvsf_stream_t stream);
+
 /* ref: tcnn.Network("FullyFusedMLP") network_dynamic.py:125-135,138-161,180-189.
  * x [M, x_stride] fp32 (x_is_f16 == 0) or fp16; weights fp16 = W0 [hidden][in_cols] ++ (n_hidden-1) x
  * [hidden][hidden] ++ W_out [out_cols][hidden]; columns n_in..in_cols-1 of the input read as 1.0.

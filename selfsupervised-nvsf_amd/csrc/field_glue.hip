@@ -5,6 +5,8 @@
 //                        grad_geo[:, j] -- one pass instead of two zero-fills, two strided copies, an add, a clamp and a mul
 //   nvsf_cast_cols_f16   dst[:, j] = fp16(src[:, j]) between row-strided 2-D views (geometry features into the aligned
 //                        input buffer of the heads, ops.HeadsFn)
+//   nvsf_heads_input_f16 whole input rows of the per-sample heads, [ray's direction encoding | geometry features | ones], in one
+//                        pass of 16-byte stores (what the two kernels below do in two passes that each leave partial lines)
 //   nvsf_repeat_rows_f16 dst[n * T + t][:] = src[n][:]: a per-ray fp16 row (direction encoding) broadcast to the T samples of
 //                        the ray -- the encoders then run once per ray instead of once per sample
 // All are HBM-stream bound: 132 B per row, 6 B and 2 B (written) per element respectively.
@@ -14,6 +16,7 @@ namespace {
 constexpr int kBlock = 256;
 typedef float float4_t __attribute__((ext_vector_type(4)));
 
+// general form: one thread per row
 __global__ __launch_bounds__(kBlock) void k_sigma_geo_bwd(const float* __restrict__ grad_sigma, const float* __restrict__ sigma,
                                                           const float* __restrict__ grad_geo, uint32_t gg_stride, uint32_t n_geo, uint32_t M,
                                                           float* __restrict__ grad_h, uint32_t gh_stride, float lo, float hi) {
@@ -28,30 +31,107 @@ __global__ __launch_bounds__(kBlock) void k_sigma_geo_bwd(const float* __restric
     for (int q = 0; q < 4; ++q) out[q] = float4_t{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
 }
 
-template <bool SRC_F16>
+// 16-float, 16-byte aligned geometry-gradient rows (what ops.HeadsFn hands back): four lanes per row, one 16-byte load and
+// one 16-byte store each; the shift by one column comes from the left neighbour's last element (wave shuffle).
+__global__ __launch_bounds__(kBlock) void k_sigma_geo_bwd_rows16(const float* __restrict__ grad_sigma, const float* __restrict__ sigma,
+                                                                 const float* __restrict__ grad_geo, uint32_t gg_stride, uint32_t n_geo,
+                                                                 uint32_t M, float* __restrict__ grad_h, uint32_t gh_stride, float lo, float hi) {
+    const uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t m_raw = idx >> 2, q = idx & 3u;
+    const uint32_t m = m_raw < M ? m_raw : M - 1;
+    float4_t v = *reinterpret_cast<const float4_t*>(grad_geo + (size_t)m * gg_stride + 4 * q);
+#pragma unroll
+    for (uint32_t e = 0; e < 4; ++e)
+        if (4 * q + e >= n_geo) v[e] = 0.0f;  // alignment padding of the source row
+    const float prev = __shfl_up(v[3], 1);
+    float first = prev;
+    if (q == 0) first = grad_sigma ? grad_sigma[m] * fminf(fmaxf(sigma[m], lo), hi) : 0.0f;
+    if (m_raw < M) *reinterpret_cast<float4_t*>(grad_h + (size_t)m * gh_stride + 4 * q) = float4_t{first, v[0], v[1], v[2]};
+}
+
+// PITCH lanes per row (PITCH = power of two >= n_cols): a wave reads whole rows side by side
+template <bool SRC_F16, int PITCH>
 __global__ __launch_bounds__(kBlock) void k_cast_cols(const void* __restrict__ src, uint32_t M, uint32_t n_cols, uint32_t src_stride,
                                                       _Float16* __restrict__ dst, uint32_t dst_stride) {
-    const size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (idx >= (size_t)M * n_cols) return;
-    const uint32_t m = (uint32_t)(idx / n_cols), c = (uint32_t)(idx - (size_t)m * n_cols);
+    const uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t m, c;
+    if constexpr (PITCH > 0) { m = idx / PITCH; c = idx % PITCH; }
+    else { m = idx / n_cols; c = idx - m * n_cols; }
+    if (m >= M || c >= n_cols) return;
     _Float16 v;
     if constexpr (SRC_F16) v = reinterpret_cast<const _Float16*>(src)[(size_t)m * src_stride + c];
     else v = (_Float16) reinterpret_cast<const float*>(src)[(size_t)m * src_stride + c];
     dst[(size_t)m * dst_stride + c] = v;
 }
 
-// one thread per (destination row, group of VEC halves)
+// a workgroup belongs to one source row n (blockIdx.x / blocks_per_row: scalar arithmetic); its threads cover
+// (t, group of VEC halves) of that row's T copies
 template <int VEC>
-__global__ __launch_bounds__(kBlock) void k_repeat_rows(const _Float16* __restrict__ src, uint32_t n_cols, uint32_t src_stride, uint32_t T,
-                                                        unsigned long long total, _Float16* __restrict__ dst, uint32_t dst_stride) {
-    const unsigned long long idx = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
-    if (idx >= total) return;
-    const uint32_t groups = n_cols / VEC;
-    const unsigned long long row = idx / groups;
-    const uint32_t grp = (uint32_t)(idx - row * groups), n = (uint32_t)(row / T);
+__global__ __launch_bounds__(kBlock) void k_repeat_rows(const _Float16* __restrict__ src, uint32_t groups, uint32_t src_stride, uint32_t T,
+                                                        uint32_t blocks_per_row, _Float16* __restrict__ dst, uint32_t dst_stride) {
+    const uint32_t n = blockIdx.x / blocks_per_row, b = blockIdx.x - n * blocks_per_row;
+    const uint32_t i = b * kBlock + threadIdx.x;
+    const uint32_t t = i / groups, grp = i - t * groups;
+    if (t >= T) return;
     typedef _Float16 vec_t __attribute__((ext_vector_type(VEC)));
-    *reinterpret_cast<vec_t*>(dst + row * dst_stride + (size_t)grp * VEC) =
+    *reinterpret_cast<vec_t*>(dst + ((size_t)n * T + t) * dst_stride + (size_t)grp * VEC) =
         *reinterpret_cast<const vec_t*>(src + (size_t)n * src_stride + (size_t)grp * VEC);
+}
+
+// Whole input rows of the per-sample heads in one pass: [direction encoding of the sample's ray | geometry features | ones]
+// as 16-byte stores (a row written in pieces by different launches reaches HBM as partial lines).  A workgroup belongs to one
+// ray; a thread owns (sample t of the ray, group of 8 columns).
+template <bool GEO_F16>
+__global__ __launch_bounds__(kBlock) void k_heads_input(const _Float16* __restrict__ enc_ray, uint32_t n_enc, uint32_t enc_stride, uint32_t T,
+                                                        uint32_t blocks_per_ray, const void* __restrict__ geo, uint32_t n_geo, uint32_t geo_stride,
+                                                        int geo_vec, _Float16* __restrict__ dst, uint32_t in_cols, uint32_t dst_stride) {
+    typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+    const uint32_t n = blockIdx.x / blocks_per_ray, b = blockIdx.x - n * blocks_per_ray;
+    const uint32_t groups = in_cols / 8;
+    const uint32_t i = b * kBlock + threadIdx.x;
+    const uint32_t t = i / groups, gi = i - t * groups;
+    if (t >= T) return;
+    const size_t m = (size_t)n * T + t;
+    const uint32_t col0 = 8 * gi;
+    half8_t v;
+    if (col0 < n_enc) {  // n_enc is a multiple of 8: a group is encoding or it is not
+        v = *reinterpret_cast<const half8_t*>(enc_ray + (size_t)n * enc_stride + col0);
+    } else {
+        const uint32_t j0 = col0 - n_enc;
+        float e[8];
+        if (j0 < n_geo) {
+            if constexpr (GEO_F16) {
+                const _Float16* g = reinterpret_cast<const _Float16*>(geo) + m * geo_stride + j0;
+                if (geo_vec) {
+                    const half8_t h = *reinterpret_cast<const half8_t*>(g);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) e[k] = (float)h[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) e[k] = (float)g[j0 + k < n_geo ? k : 0];
+                }
+            } else {
+                const float* g = reinterpret_cast<const float*>(geo) + m * geo_stride + j0;
+                if (geo_vec == 1) {
+                    const float4_t a = *reinterpret_cast<const float4_t*>(g), c = *reinterpret_cast<const float4_t*>(g + 4);
+                    e[0] = a[0]; e[1] = a[1]; e[2] = a[2]; e[3] = a[3]; e[4] = c[0]; e[5] = c[1]; e[6] = c[2]; e[7] = c[3];
+                } else if (geo_vec == 2) {  // rows start one float past a 16-byte boundary (columns 1.. of an aligned matrix:
+                                            // geo_feat = h[:, 1:]): aligned loads from the boundary, elements shifted by one
+                    const float* gb = g - 1;
+                    const float4_t a = *reinterpret_cast<const float4_t*>(gb), c = *reinterpret_cast<const float4_t*>(gb + 4);
+                    float4_t d = {0, 0, 0, 0};
+                    if (j0 + 8 < n_geo) d = *reinterpret_cast<const float4_t*>(gb + 8);
+                    e[0] = a[1]; e[1] = a[2]; e[2] = a[3]; e[3] = c[0]; e[4] = c[1]; e[5] = c[2]; e[6] = c[3]; e[7] = d[0];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) e[k] = g[j0 + k < n_geo ? k : 0];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (j0 + k < n_geo) ? (_Float16)e[k] : (_Float16)1.0f;
+    }
+    *reinterpret_cast<half8_t*>(dst + m * dst_stride + col0) = v;
 }
 }  // namespace
 
@@ -62,8 +142,13 @@ NVSF_API int nvsf_sigma_geo_bwd(const float* grad_sigma, const float* sigma, con
     if (M == 0) return NVSF_OK;
     REQUIRE(grad_h && gh_stride >= 16 && gh_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(grad_h) & 15u) == 0);
     REQUIRE(n_geo <= 15 && (!grad_geo || gg_stride >= n_geo) && (!grad_sigma || sigma));
-    hipLaunchKernelGGL(k_sigma_geo_bwd, dim3(cdiv(M, kBlock)), dim3(kBlock), 0, stream, grad_sigma, sigma, grad_geo, gg_stride, n_geo, M,
-                       grad_h, gh_stride, sigma_lo, sigma_hi);
+    const bool rows16 = grad_geo && gg_stride % 4 == 0 && gg_stride >= 16 && (reinterpret_cast<uintptr_t>(grad_geo) & 15u) == 0 && M < (1u << 30);
+    if (rows16)
+        hipLaunchKernelGGL(k_sigma_geo_bwd_rows16, dim3(cdiv(4ull * M, kBlock)), dim3(kBlock), 0, stream, grad_sigma, sigma, grad_geo, gg_stride,
+                           n_geo, M, grad_h, gh_stride, sigma_lo, sigma_hi);
+    else
+        hipLaunchKernelGGL(k_sigma_geo_bwd, dim3(cdiv(M, kBlock)), dim3(kBlock), 0, stream, grad_sigma, sigma, grad_geo, gg_stride, n_geo, M,
+                           grad_h, gh_stride, sigma_lo, sigma_hi);
     return nvsf_launch_status();
 }
 
@@ -71,10 +156,13 @@ NVSF_API int nvsf_cast_cols_f16(const void* src, int src_is_f16, uint32_t M, uin
                                 uint32_t dst_stride, hipStream_t stream) {
     if (M == 0 || n_cols == 0) return NVSF_OK;
     REQUIRE(src && dst_f16 && src_stride >= n_cols && dst_stride >= n_cols);
-    const unsigned long long total = (unsigned long long)M * n_cols;
     _Float16* dst = reinterpret_cast<_Float16*>(dst_f16);
-    if (src_is_f16) hipLaunchKernelGGL(k_cast_cols<true>, dim3(cdiv(total, kBlock)), dim3(kBlock), 0, stream, src, M, n_cols, src_stride, dst, dst_stride);
-    else hipLaunchKernelGGL(k_cast_cols<false>, dim3(cdiv(total, kBlock)), dim3(kBlock), 0, stream, src, M, n_cols, src_stride, dst, dst_stride);
+    const uint32_t pitch = n_cols <= 16 ? 16u : (n_cols <= 32 ? 32u : (n_cols <= 64 ? 64u : 0u));
+    const unsigned long long total = (unsigned long long)M * (pitch ? pitch : n_cols);
+    REQUIRE(total < (1ull << 32));
+#define CAST(SF, P) hipLaunchKernelGGL((k_cast_cols<SF, P>), dim3(cdiv(total, kBlock)), dim3(kBlock), 0, stream, src, M, n_cols, src_stride, dst, dst_stride)
+#define CAST_P(SF) do { if (pitch == 16u) CAST(SF, 16); else if (pitch == 32u) CAST(SF, 32); else if (pitch == 64u) CAST(SF, 64); else CAST(SF, 0); } while (0)
+    if (src_is_f16) CAST_P(true); else CAST_P(false);
     return nvsf_launch_status();
 }
 
@@ -85,15 +173,41 @@ NVSF_API int nvsf_repeat_rows_f16(const void* src_f16, uint32_t N, uint32_t n_co
     const _Float16* src = reinterpret_cast<const _Float16*>(src_f16);
     _Float16* dst = reinterpret_cast<_Float16*>(dst_f16);
     const bool vec8 = n_cols % 8 == 0 && src_stride % 8 == 0 && dst_stride % 8 == 0 && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0;
-    const unsigned long long rows = (unsigned long long)N * T;
-    if (vec8) {
-        const unsigned long long total = rows * (n_cols / 8);
-        REQUIRE((total + kBlock - 1) / kBlock < (1ull << 31));
-        hipLaunchKernelGGL(k_repeat_rows<8>, dim3(cdiv(total, kBlock)), dim3(kBlock), 0, stream, src, n_cols, src_stride, T, total, dst, dst_stride);
-    } else {
-        const unsigned long long total = rows * n_cols;
-        REQUIRE((total + kBlock - 1) / kBlock < (1ull << 31));
-        hipLaunchKernelGGL(k_repeat_rows<1>, dim3(cdiv(total, kBlock)), dim3(kBlock), 0, stream, src, n_cols, src_stride, T, total, dst, dst_stride);
-    }
+    const uint32_t groups = vec8 ? n_cols / 8 : n_cols;
+    const unsigned long long per_row = (unsigned long long)T * groups;
+    REQUIRE(per_row < (1ull << 31));
+    const uint32_t blocks_per_row = cdiv(per_row, kBlock);
+    REQUIRE((unsigned long long)N * blocks_per_row < (1ull << 31));
+    if (vec8) hipLaunchKernelGGL(k_repeat_rows<8>, dim3(N * blocks_per_row), dim3(kBlock), 0, stream, src, groups, src_stride, T, blocks_per_row, dst, dst_stride);
+    else hipLaunchKernelGGL(k_repeat_rows<1>, dim3(N * blocks_per_row), dim3(kBlock), 0, stream, src, groups, src_stride, T, blocks_per_row, dst, dst_stride);
+    return nvsf_launch_status();
+}
+
+NVSF_API int nvsf_heads_input_f16(const void* enc_ray_f16, uint32_t N, uint32_t n_enc, uint32_t enc_stride, uint32_t T, const void* geo,
+                                  int geo_is_f16, uint32_t n_geo, uint32_t geo_stride, void* dst_f16, uint32_t in_cols, uint32_t dst_stride,
+                                  hipStream_t stream) {
+    if (N == 0 || T == 0) return NVSF_OK;
+    REQUIRE(enc_ray_f16 && geo && dst_f16);
+    REQUIRE(n_enc % 8 == 0 && enc_stride % 8 == 0 && enc_stride >= n_enc && (reinterpret_cast<uintptr_t>(enc_ray_f16) & 15u) == 0);
+    REQUIRE(in_cols % 8 == 0 && n_enc + n_geo <= in_cols && dst_stride >= in_cols && dst_stride % 8 == 0 && (reinterpret_cast<uintptr_t>(dst_f16) & 15u) == 0);
+    REQUIRE(geo_stride >= n_geo);
+    const size_t esz = geo_is_f16 ? 2 : 4;
+    // 8 source columns per thread as 16-byte loads: aligned rows, wide enough for the last group of 8
+    int geo_vec = (reinterpret_cast<uintptr_t>(geo) & 15u) == 0 && (geo_stride * esz) % 16 == 0 && (n_geo + 7u) / 8u * 8u <= geo_stride;
+    // fp32 rows that begin one float past a 16-byte boundary, wide enough for every group's aligned 8-float window
+    if (!geo_vec && !geo_is_f16 && (reinterpret_cast<uintptr_t>(geo) & 15u) == 4 && geo_stride % 4 == 0 && (n_geo + 1u + 7u) / 8u * 8u <= geo_stride)
+        geo_vec = 2;
+    const unsigned long long per_ray = (unsigned long long)T * (in_cols / 8);
+    REQUIRE(per_ray < (1ull << 31));
+    const uint32_t blocks_per_ray = cdiv(per_ray, kBlock);
+    REQUIRE((unsigned long long)N * blocks_per_ray < (1ull << 31));
+    const _Float16* enc = reinterpret_cast<const _Float16*>(enc_ray_f16);
+    _Float16* dst = reinterpret_cast<_Float16*>(dst_f16);
+    if (geo_is_f16)
+        hipLaunchKernelGGL(k_heads_input<true>, dim3(N * blocks_per_ray), dim3(kBlock), 0, stream, enc, n_enc, enc_stride, T, blocks_per_ray, geo, n_geo,
+                           geo_stride, geo_vec, dst, in_cols, dst_stride);
+    else
+        hipLaunchKernelGGL(k_heads_input<false>, dim3(N * blocks_per_ray), dim3(kBlock), 0, stream, enc, n_enc, enc_stride, T, blocks_per_ray, geo, n_geo,
+                           geo_stride, geo_vec, dst, in_cols, dst_stride);
     return nvsf_launch_status();
 }

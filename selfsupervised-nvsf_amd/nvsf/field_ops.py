@@ -218,13 +218,17 @@ def heads(model, d01, geo_feat, cal_lidar_color, ray_dirs01=None):
             freq_encode(src, enc.n_frequencies, out=dst)
         else:
             sh4_encode(src, out=dst)
-        if ray_dirs01 is not None:
-            N = src.shape[0]
-            assert M % N == 0
-            _hip.call("nvsf_repeat_rows_f16", _hip.ptr(dst), N, n_enc_cols, dst.stride(0), M // N, _hip.ptr(buf), buf.stride(0))
+    enc_ray = None
+    if ray_dirs01 is not None:
+        assert M % src.shape[0] == 0
+        if n_enc_cols % 8 == 0:
+            enc_ray = dst  # HeadsFn writes whole rows (encoding | geometry | ones) in one pass
+        else:
+            _hip.call("nvsf_repeat_rows_f16", _hip.ptr(dst), src.shape[0], n_enc_cols, dst.stride(0), M // src.shape[0], _hip.ptr(buf),
+                      buf.stride(0))
     if net_b is None:
-        return HeadsFn.apply(buf, enc.n_output_dims, geo_feat, net_a.params, net_a.weights_f16(), spec)
-    return HeadsFn.apply(buf, enc.n_output_dims, geo_feat, net_a.params, net_a.weights_f16(), spec, net_b.params, net_b.weights_f16())
+        return HeadsFn.apply(buf, enc.n_output_dims, geo_feat, net_a.params, net_a.weights_f16(), spec, None, None, enc_ray)
+    return HeadsFn.apply(buf, enc.n_output_dims, geo_feat, net_a.params, net_a.weights_f16(), spec, net_b.params, net_b.weights_f16(), enc_ray)
 
 
 class HeadsFn(Function):
@@ -239,10 +243,16 @@ class HeadsFn(Function):
     afterwards."""
 
     @staticmethod
-    def forward(ctx, buf, n_enc, geo, params_a, w16_a, spec, params_b=None, w16_b=None):
+    def forward(ctx, buf, n_enc, geo, params_a, w16_a, spec, params_b=None, w16_b=None, enc_ray=None):
         n_geo = geo.shape[1]
         assert n_enc + n_geo == spec.n_in and buf.shape[1] >= spec.n_in and buf.dtype == torch.float16
-        cast_cols_f16(geo, buf[:, n_enc:n_enc + n_geo])
+        if enc_ray is not None:  # per-ray encoding [N, >= n_enc] fp16: rows assembled whole (nvsf_heads_input_f16)
+            g = geo if (geo.dtype in (torch.float16, torch.float32) and geo.stride(1) == 1) else geo.float().contiguous()
+            N = enc_ray.shape[0]
+            _hip.call("nvsf_heads_input_f16", _hip.ptr(enc_ray), N, n_enc, enc_ray.stride(0), buf.shape[0] // N, _hip.ptr_rows(g),
+                      1 if g.dtype == torch.float16 else 0, n_geo, g.stride(0), _hip.ptr(buf), spec.in_cols, buf.stride(0))
+        else:
+            cast_cols_f16(geo, buf[:, n_enc:n_enc + n_geo])
         u = buf[:, :spec.n_in]
         ctx.save_for_backward(buf, w16_a, w16_b)
         ctx.spec, ctx.n_enc, ctx.n_geo, ctx.geo_dtype = spec, n_enc, n_geo, geo.dtype
@@ -275,7 +285,7 @@ class HeadsFn(Function):
         if grad_geo is not None and grad_geo.dtype != ctx.geo_dtype:
             grad_geo = grad_geo.to(ctx.geo_dtype)
         return (None, None, grad_geo, gw_a if ctx.needs_input_grad[3] else None, None, None,
-                gw_b if (w16_b is not None and ctx.needs_input_grad[6]) else None, None)
+                gw_b if (w16_b is not None and ctx.needs_input_grad[6]) else None, None, None)
 
 
 class MlpFn(Function):

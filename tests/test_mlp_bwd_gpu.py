@@ -202,3 +202,40 @@ def test_heads_per_ray_direction_encoding(dev):
         b = ops.heads(m, None, geo, lidar, ray_dirs01=d01_ray)
         assert a.shape == b.shape == (N * T, 2 if lidar else 3)
         assert torch.equal(a, b)
+
+
+def test_glue_kernels_against_torch(dev):
+    """nvsf_cast_cols_f16 / nvsf_repeat_rows_f16 / nvsf_sigma_geo_bwd on aligned and unaligned layouts against the torch
+    expressions they replace (exact: copies, one fp16 rounding, one fp32 multiply)."""
+    import torch
+    from nvsf import _hip, field_ops as ops
+    from nvsf.nerf import activation
+    torch.manual_seed(11)
+    M = 3001
+    for n_cols, src_w, dtype in ((15, 16, torch.float32), (15, 15, torch.float32), (20, 24, torch.float16), (40, 40, torch.float32),
+                                 (70, 72, torch.float32), (1, 1, torch.float32)):
+        src = torch.randn(M, src_w, device=dev).to(dtype)[:, :n_cols]
+        dst = torch.full((M, n_cols + 9), 7.0, dtype=torch.float16, device=dev)
+        ops.cast_cols_f16(src, dst[:, 3:3 + n_cols])
+        assert torch.equal(dst[:, 3:3 + n_cols], src.half()) and bool((dst[:, :3] == 7).all()) and bool((dst[:, 3 + n_cols:] == 7).all())
+    for n_cols, src_w, dst_w, T in ((72, 72, 96, 19), (16, 16, 32, 7), (15, 16, 21, 5)):
+        N = 53
+        src = torch.randn(N, src_w, device=dev).half()
+        dst = torch.full((N * T, dst_w), 3.0, dtype=torch.float16, device=dev)
+        _hip.call("nvsf_repeat_rows_f16", _hip.ptr(src), N, n_cols, src_w, T, _hip.ptr(dst), dst_w)
+        assert torch.equal(dst[:, :n_cols], src[:, :n_cols].repeat_interleave(T, dim=0)) and bool((dst[:, n_cols:] == 3).all())
+    sigma = torch.exp(torch.randn(M, device=dev) * 8)
+    sigma[:4] = torch.tensor([1e-9, 1e9, 0.0, 1.0], device=dev)
+    gs = torch.randn(M, device=dev)
+    for stride in (16, 15, 20):
+        gg = torch.randn(M, stride, device=dev)
+        for use_gs, use_gg in ((True, True), (True, False), (False, True)):
+            out = torch.full((M, 16), 9.0, device=dev)
+            _hip.call("nvsf_sigma_geo_bwd", _hip.ptr(gs) if use_gs else None, _hip.ptr(sigma), _hip.ptr(gg) if use_gg else None, stride, 15, M,
+                      _hip.ptr(out), 16, activation._LO, activation._HI)
+            ref = torch.zeros(M, 16, device=dev)
+            if use_gs:
+                ref[:, 0] = gs * sigma.clamp(activation._LO, activation._HI)
+            if use_gg:
+                ref[:, 1:] = gg[:, :15]
+            assert torch.equal(out, ref), (stride, use_gs, use_gg)
