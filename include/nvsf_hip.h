@@ -391,6 +391,19 @@ int nvsf_lidar_rays(const float* pose44, const int64_t* inds, uint32_t N, uint32
 int nvsf_camera_rays(const float* pose44, const int64_t* inds, uint32_t N, uint32_t W, float fx, float fy, float cx,
                      float cy, float* rays_o, float* rays_d, nvsf_stream_t stream);
 
+/* ---- 7. optimiser step of the thin trainer ------------------------------------------------------- */
+
+/* ref: torch.optim.Adam(betas=(0.9, 0.99), eps=1e-15) of main_nvsf.py:350-352 under GradScaler (trainer.py:119, 1332-1334).
+ * state4 (device, 4 floats) = {step, 1 - beta1^step, sqrt(1 - beta2^step), skip}.  prepare: skip = found_inf && *found_inf != 0;
+ * step += !skip; corrections recomputed (double).  found_inf may be NULL. */
+int nvsf_adam_prepare(float* state4, const float* found_inf, float beta1, float beta2, nvsf_stream_t stream);
+
+/* One pass over a parameter tensor (all fp32 [n]): g = grad / *grad_scale (grad_scale NULL = 1); exp_avg += (1 - beta1)(g - exp_avg);
+ * exp_avg_sq = beta2 exp_avg_sq + (1 - beta2) g g; param -= lr / state4[1] * exp_avg / (sqrt(exp_avg_sq) / state4[2] + eps).
+ * Nothing is written when state4[3] != 0 (overflow: the step is skipped). */
+int nvsf_adam_update(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr, float beta1,
+                     float beta2, float eps, const float* state4, const float* grad_scale, nvsf_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

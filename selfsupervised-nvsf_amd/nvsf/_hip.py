@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libnvsf_hip.so")
 
 _P, _U, _F, _I = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_float, ctypes.c_int
+_U64 = ctypes.c_uint64
 
 # name -> argument ctypes (the trailing stream argument is appended automatically)
 SIGNATURES = {
@@ -38,6 +39,8 @@ SIGNATURES = {
     "nvsf_hashgrid_bwd": [_P, _U, _U, _P, _U, _U, _U, _P, _P, _P, _P, _I, _U, _P],
     "nvsf_freq_encode": [_P, _U, _U, _U, _P, _U],
     "nvsf_sh4_encode": [_P, _U, _P, _U],
+    "nvsf_adam_prepare": [_P, _P, _F, _F],
+    "nvsf_adam_update": [_P, _P, _P, _P, _U64, _F, _F, _F, _F, _P, _P],
     "nvsf_sigma_geo_bwd": [_P, _P, _P, _U, _U, _U, _P, _U, _F, _F],
     "nvsf_cast_cols_f16": [_P, _I, _U, _U, _U, _P, _U],
     "nvsf_repeat_rows_f16": [_P, _U, _U, _U, _U, _P, _U],

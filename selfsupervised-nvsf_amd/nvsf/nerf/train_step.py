@@ -48,10 +48,17 @@ class RenderTrainStep:
         self.scaler = torch.amp.GradScaler("cuda", enabled=bool(fp16) and torch.cuda.is_available())
         if fp16 and hasattr(model, "flow_net"):
             model.flow_net.flow_mlp_mode = "fused"  # the flow MLP as autocast runs it: fp16 MFMA kernels (flow_field.FlowMlpFn)
-        # torch's default (multi-tensor) Adam: its fused=True variant was tried for the ~45 launches it saves per step and trains
-        # measurably worse under this eps = 1e-15 / GradScaler setting (tests/test_train_step_gpu.py: loss 0.289 -> 0.258
-        # after 120 steps against 0.227)
-        self.opt = torch.optim.Adam(model.get_params(lr), betas=(0.9, 0.99), eps=1e-15)
+        # Adam as one HIP pass per parameter tensor with the scaler's overflow flag consumed on the device (nvsf/nerf/adam.py).
+        # torch's own fused=True variant was tried first: under this eps = 1e-15 / GradScaler setting it trains measurably worse
+        # (tests/test_train_step_gpu.py: loss 0.289 -> 0.258 after 120 steps against 0.227).  NVSF_ADAM=torch: the default
+        # multi-tensor implementation.
+        import os
+        on_gpu = torch.cuda.is_available() and next(model.parameters()).is_cuda
+        if on_gpu and os.environ.get("NVSF_ADAM", "hip") == "hip":
+            from nvsf.nerf.adam import FusedAdam
+            self.opt = FusedAdam(model.get_params(lr), betas=(0.9, 0.99), eps=1e-15)
+        else:
+            self.opt = torch.optim.Adam(model.get_params(lr), betas=(0.9, 0.99), eps=1e-15)
         self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, lambda it: 0.1 ** min(it / iters, 1))
         self.iters, self.num_steps = iters, num_steps
         self.alpha_d, self.alpha_r, self.alpha_i, self.alpha_rgb = alpha_d, alpha_r, alpha_i, alpha_rgb

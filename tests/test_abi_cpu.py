@@ -46,6 +46,8 @@ def test_python_binding_table_matches_header(hip_lib):
                 assert ct is ctypes.c_void_p, (name, decl)
             elif decl.startswith("uint32_t"):
                 assert ct is ctypes.c_uint32, (name, decl)
+            elif decl.startswith("uint64_t"):
+                assert ct is ctypes.c_uint64, (name, decl)
             elif decl.startswith("float"):
                 assert ct is ctypes.c_float, (name, decl)
             elif decl.startswith("int"):

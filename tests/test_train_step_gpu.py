@@ -99,3 +99,70 @@ def test_density_fn_equals_operator_chain(dev, monkeypatch):
         out = m.density(x, None, cal_lidar_color=True)
         (64.0 * out[sel].float().sum()).backward()
         assert torch.isfinite(m.hash_encoder_lidar.params.grad).all() and float(m.hash_encoder_lidar.params.grad.abs().max()) > 0
+
+
+def test_fused_adam_matches_torch_adam(dev):
+    """nvsf.nerf.adam.FusedAdam against torch.optim.Adam (betas 0.9 / 0.99, eps 1e-15, two groups with different lr): plain
+    steps, steps under a GradScaler (device-side unscale), a skipped overflow step, and state_dict exchange both ways."""
+    from nvsf.nerf.adam import FusedAdam
+    torch.manual_seed(0)
+    shapes = [(1000003,), (64, 32), (7,)]
+    mk = lambda: [torch.nn.Parameter(torch.randn(s, device=dev) * 0.1) for s in shapes]
+    a, b = mk(), None
+    torch.manual_seed(0)
+    b = mk()
+    groups = lambda ps: [{"params": ps[:2], "lr": 1e-2}, {"params": ps[2:], "lr": 1e-3}]
+    oa, ob = FusedAdam(groups(a), betas=(0.9, 0.99), eps=1e-15), torch.optim.Adam(groups(b), betas=(0.9, 0.99), eps=1e-15)
+
+    def grads(seed, scale=1.0, poison=False):
+        g = torch.Generator(device=dev).manual_seed(seed)
+        for pa, pb in zip(a, b):
+            gr = torch.randn(pa.shape, device=dev, generator=g) * 1e-3
+            if poison and pa.numel() == 7:
+                gr[3] = float("inf")
+            pa.grad, pb.grad = (gr * scale).clone(), (gr * scale).clone()
+
+    def close():
+        for pa, pb in zip(a, b):
+            # a step moves a parameter by ~lr = 1e-2: agreement to a few ulps of that (1e-2 * 2^-23 = 1.2e-9 each) over the steps
+            assert torch.allclose(pa, pb, rtol=2e-6, atol=2e-7), float((pa - pb).abs().max())
+
+    for s in range(5):
+        grads(s)
+        oa.step(); ob.step()
+    close()
+    # under GradScaler: scaled gradients, one overflowing step in the middle (skipped by both, scale halved by both)
+    sa, sb = torch.amp.GradScaler("cuda", init_scale=1024.0), torch.amp.GradScaler("cuda", init_scale=1024.0)
+    for s in range(5, 11):
+        grads(s, scale=float(sa.get_scale()), poison=(s == 7))
+        sa.scale(torch.zeros((), device=dev)); sb.scale(torch.zeros((), device=dev))  # what scale(loss) does to the scaler's state
+        sa.step(oa); sb.step(ob)
+        sa.update(); sb.update()
+        assert sa.get_scale() == sb.get_scale()
+    close()
+    assert sa.get_scale() == 512.0 and float(oa._dev_state[0]) == 10.0  # 11 calls, one skipped
+    # state dicts: same layout, loadable both ways
+    da, db = oa.state_dict(), ob.state_dict()
+    assert set(da["state"][0]) == set(db["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(da["state"][0]["step"]) == 10.0
+    assert torch.allclose(da["state"][0]["exp_avg_sq"], db["state"][0]["exp_avg_sq"], rtol=1e-5, atol=1e-12)
+    oa.load_state_dict(db); ob.load_state_dict(da)
+    grads(99)
+    oa.step(); ob.step()
+    close()
+
+
+def test_fused_adam_invalidates_fp16_weight_caches(dev):
+    """The forward kernels read fp16 copies of tables / weights cached per parameter version: an optimiser that writes through
+    raw pointers has to bump that version, or the next forward runs on stale weights."""
+    import tinycudann as tcnn
+    from nvsf.nerf.adam import FusedAdam
+    net = tcnn.Network(32, 16, {"otype": "FullyFusedMLP", "activation": "ReLU", "output_activation": "None", "n_neurons": 64,
+                                "n_hidden_layers": 1}).to(dev)
+    opt = FusedAdam(net.parameters(), lr=1e-1, betas=(0.9, 0.99), eps=1e-15)
+    before = net.weights_f16().clone()
+    net.params.grad = torch.ones_like(net.params)
+    v0 = net.params._version
+    opt.step()
+    assert net.params._version > v0
+    after = net.weights_f16()
+    assert not torch.equal(before, after) and torch.equal(after, net.params.detach().half())
