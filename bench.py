@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--cpu-rays", type=int, default=320, help="rays per modality in the cpu_baseline sample (~10 s of CPU work; 0 = skip)")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the occupancy-grid (config 3) and dynamic-field (config 5) legs")
-    ap.add_argument("--train-steps", type=int, default=3, help="extra leg: timed training steps reported under `train` (0 = skip)")
+    ap.add_argument("--train-steps", type=int, default=10, help="extra leg: timed training steps reported under `train` (0 = skip)")
     return ap.parse_args()
 
 
@@ -225,7 +225,7 @@ def train_leg(model, tl, tc, tm, T, steps, dev, dist):
              "gt_intensity": torch.rand(1, n_l, generator=g).to(dev), "gt_rgb": torch.rand(1, n_c, 3, generator=g).to(dev)}
     step = RenderTrainStep(model, num_steps=T)
     n_coll = 0
-    for _ in range(2):
+    for _ in range(5):  # the loss scale settles (overflowing first steps are skipped), optimiser state and allocator pools exist
         step.step(batch)
     torch.cuda.synchronize()
     if dist is not None:
@@ -380,7 +380,7 @@ def dynamic_leg(dev, n_rays, T, steps):
              "gt_depth": torch.rand(1, n_rays, generator=g).to(dev) * 0.5, "gt_raydrop": (torch.rand(1, n_rays, generator=g) > 0.3).float().to(dev),
              "gt_intensity": torch.rand(1, n_rays, generator=g).to(dev), "gt_rgb": torch.rand(1, n_rays, 3, generator=g).to(dev)}
     trainer = RenderTrainStep(m, num_steps=T)
-    for _ in range(2):
+    for _ in range(4):  # loss scale settled, optimiser state and allocator pools in place
         trainer.step(batch)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

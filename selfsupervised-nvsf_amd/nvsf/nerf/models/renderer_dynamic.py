@@ -202,9 +202,13 @@ class NeRFRenderer(nn.Module):
     def _near_far(self, rays_o, rays_d, cal_lidar_color, aabb):
         N = rays_o.shape[0]
         if cal_lidar_color:
-            nears = torch.full((N,), float(self.min_near_lidar), dtype=torch.float32, device=rays_o.device)
-            fars = torch.full((N,), float(self.lidar_max_depth), dtype=torch.float32, device=rays_o.device)
-            return nears, fars
+            # constants (renderer_dynamic.py:140-146): filled once per (N, device, values) and handed out read-only
+            key = (N, rays_o.device, float(self.min_near_lidar), float(self.lidar_max_depth))
+            if getattr(self, "_lidar_range_key", None) != key:
+                self._lidar_range = (torch.full((N,), key[2], dtype=torch.float32, device=rays_o.device),
+                                     torch.full((N,), key[3], dtype=torch.float32, device=rays_o.device))
+                self._lidar_range_key = key
+            return self._lidar_range
         return raymarching.near_far_from_aabb(rays_o, rays_d, aabb, self.min_near)
 
     def run(self, rays_o, rays_d, time, cal_lidar_color=False, num_steps=768, upsample_steps=128, bg_color=None,
