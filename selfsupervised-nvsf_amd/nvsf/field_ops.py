@@ -431,7 +431,9 @@ class PlanesFn(Function):
             off = 0
             for i, shp in enumerate(ctx.shapes):  # channel-last [H, W, C] slices back to the reference layout [1, C, H, W]
                 _, C, H, W = shp
-                g_params[i] = g_planes[off:off + H * W * C].view(H, W, C).permute(2, 0, 1).unsqueeze(0).contiguous()
+                # a strided view: autograd's accumulation (copy into .grad the first time, += afterwards) reads it in place --
+                # materialising it first costs one more small launch per plane and call (144 per step of the space-time model)
+                g_params[i] = g_planes[off:off + H * W * C].view(H, W, C).permute(2, 0, 1).unsqueeze(0)
                 off += H * W * C
         return (g_xt, None, None, None, *g_params)
 
