@@ -66,6 +66,17 @@ def hashgrid_backward(x, cols, spec, grad_out, grad_table=None):
     grad_out = grad_out.contiguous()
     if grad_table is None:
         grad_table = torch.zeros(spec.n_params, dtype=torch.float32, device=x.device)
+    import os
+    variant = os.environ.get("NVSF_HASHGRID_BWD", "corners")
+    if variant == "fixed" and spec.L % max(1, 64 // ((1 << spec.D) * spec.F)) == 0 and (1 << spec.D) * spec.F <= 64:
+        # opt-in: order-independent sums (64-bit fixed-point scatter + one conversion pass) -- bit-reproducible table gradients at
+        # the speed of the fp32 atomics (the integer atomics are ~3 % faster in this kernel, the two extra passes cost that back)
+        acc = torch.empty(spec.n_params, dtype=torch.int64, device=x.device)
+        gmax = torch.empty(1, dtype=torch.int32, device=x.device)
+        _hip.call("nvsf_hashgrid_bwd_fixed", _hip.ptr(x), x.shape[0], x.shape[1], _hip.host_u32(cols), spec.D, spec.L, spec.F, spec.h_scales,
+                  spec.h_res, spec.h_offsets, _hip.ptr(grad_out), 1 if grad_out.dtype == torch.float16 else 0, grad_out.stride(0),
+                  _hip.ptr(acc), _hip.ptr(gmax), _hip.ptr(grad_table))
+        return grad_table
     _hip.call("nvsf_hashgrid_bwd", _hip.ptr(x), x.shape[0], x.shape[1], _hip.host_u32(cols), spec.D, spec.L, spec.F, spec.h_scales,
               spec.h_res, spec.h_offsets, _hip.ptr(grad_out), 1 if grad_out.dtype == torch.float16 else 0, grad_out.stride(0),
               _hip.ptr(grad_table))

@@ -36,6 +36,9 @@ __global__ __launch_bounds__(256) void k_scatter(void* table, uint32_t entries_l
             ((float*)table)[2 * (size_t)e + (lane & 1)] = 1.0f;
         } else if (MODE == 6) {
             if (!(lane & 1)) __hip_atomic_fetch_add((double*)table + e, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (MODE == 8) {  // fixed point: one 64-bit integer per (entry, feature), all lanes active (16-byte entries)
+            unsigned long long* p = (unsigned long long*)table + 2 * (size_t)e + (lane & 1);
+            __hip_atomic_fetch_add(p, 0x100000001ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (MODE == 7) {
             typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
             if (!(lane & 1)) {
@@ -51,7 +54,7 @@ int run(const char* name, void* table, uint32_t entries_log2, int partition) {
     const uint32_t blocks = 256 * 8, iters = 512;  // 8192 waves x 512 wave-instructions x 32 entries = 134 M entry adds
     hipEvent_t a, b;
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-    CK(hipMemset(table, 0, (size_t)8 << entries_log2));
+    CK(hipMemset(table, 0, (size_t)(MODE == 8 ? 16 : 8) << entries_log2));
     hipLaunchKernelGGL(k_scatter<MODE>, dim3(blocks), dim3(256), 0, 0, table, entries_log2, 16u, partition);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(a));
@@ -69,12 +72,13 @@ int run(const char* name, void* table, uint32_t entries_log2, int partition) {
 
 int main() {
     void* table;
-    CK(hipMalloc(&table, (size_t)8 << 24));
+    CK(hipMalloc(&table, (size_t)16 << 24));
     for (uint32_t lg : {19u, 23u}) {  // 4 MB (one level of the hash grid), 64 MB
-        for (int part = 0; part < 2; ++part) {
+        for (int part = 0; part < 1; ++part) {
             if (run<0>("f32 agent", table, lg, part)) return 1;
             if (run<1>("i32 agent", table, lg, part)) return 1;
             if (run<2>("u64 agent", table, lg, part)) return 1;
+            if (run<8>("u64 x2 per entry", table, lg, part)) return 1;
             if (run<6>("f64 agent", table, lg, part)) return 1;
             if (run<7>("pk_f16 agent", table, lg, part)) return 1;
             if (run<3>("f32 workgroup", table, lg, part)) return 1;
