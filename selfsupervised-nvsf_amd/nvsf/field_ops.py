@@ -209,6 +209,37 @@ def mlp_backward(x, weights_f16, spec, grad_out, need_grad_x=True, grad_scale=ML
     return grad_x, grad_w
 
 
+# ---- dense / sparse choice of the per-sample heads without a host sync per call ------------------------------------------------
+# `color` evaluates the heads on all samples (and zeroes the masked ones) when at least a quarter of them pass the weight
+# threshold, otherwise on the gathered subset.  The count that decides this lives on the device.  While a modality stays in the
+# dense regime its count is copied to pinned host memory asynchronously and looked at one call later; only the sparse regime
+# (whose boolean indexing synchronises anyway) reads it immediately.
+def mask_was_dense(model, lidar, mask):
+    st = model.__dict__.setdefault("_mask_regime", {}).setdefault(bool(lidar), {"dense": False, "pending": None})
+    if st["pending"] is not None:
+        host, event, numel = st["pending"]
+        if event.query():  # the copy has landed: adopt the regime it shows
+            st["dense"] = 4 * int(host[0]) >= numel
+            st["pending"] = None
+    if not st["dense"] or not mask.is_cuda:
+        return False
+    if st["pending"] is None:  # keep observing: this batch's count, read by a later call
+        host = st.get("host")
+        if host is None:
+            host = st["host"] = torch.empty(1, dtype=torch.int64).pin_memory()  # allocated once per (model, modality)
+        host.copy_(mask.sum().reshape(1), non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        st["pending"] = (host, event, mask.numel())
+    return True
+
+
+def note_mask_count(model, lidar, n_active, numel):
+    st = model.__dict__.setdefault("_mask_regime", {}).setdefault(bool(lidar), {"dense": False, "pending": None})
+    st["dense"] = 4 * n_active >= numel
+    st["pending"] = None
+
+
 def heads(model, d01, geo_feat, cal_lidar_color, ray_dirs01=None):
     """Logits of the per-sample heads of `model` (a NeRFNetwork / NeRFNetworkStatic): [M, 2] = [raydrop, intensity] for
     LiDAR samples, [M, 3] colour logits otherwise.  d01: directions mapped to [0, 1]; geo_feat: [M, geo_feat_dim].

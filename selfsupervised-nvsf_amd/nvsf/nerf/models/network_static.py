@@ -68,8 +68,14 @@ class NeRFNetworkStatic(NeRFRenderer):
 
     def color(self, x, d, cal_lidar_color=False, mask=None, geo_feat=None, **kwargs):
         dense_mask = None
+        if mask is not None and ops.mask_was_dense(self, cal_lidar_color, mask):
+            # the previous batch of this modality had >= 25 % of its samples above the weight threshold: evaluate all samples and
+            # zero the rest without reading the count back first (values and gradients do not depend on this choice, only the
+            # launch queue does: the read is a host sync that drains it)
+            dense_mask, mask = mask, None
         if mask is not None:
             n_active = int(mask.sum())  # one host sync (the reference's `mask.any()` costs the same)
+            ops.note_mask_count(self, cal_lidar_color, n_active, mask.numel())
             if n_active == 0:
                 return torch.zeros(mask.shape[0], self.out_dim, dtype=x.dtype, device=x.device)
             if 4 * n_active >= mask.numel():

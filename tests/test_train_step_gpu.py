@@ -166,3 +166,39 @@ def test_fused_adam_invalidates_fp16_weight_caches(dev):
     assert net.params._version > v0
     after = net.weights_f16()
     assert not torch.equal(before, after) and torch.equal(after, net.params.detach().half())
+
+
+def test_dense_regime_needs_no_host_sync_and_follows_the_mask(dev):
+    """color(): the dense / sparse choice of the heads uses the previous batch's count while the modality stays dense (no host
+    read per call), falls back to the synchronous read when the observed count drops, and gives the same values either way."""
+    from nvsf import field_ops as ops, synthetic as S
+    from nvsf.nerf.models.network_static import NeRFNetworkStatic
+    torch.manual_seed(2)
+    m = NeRFNetworkStatic(bound=S.BOUND, min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH,
+                          log2_hashmap_size=14).to(dev)
+    m.out_dim = 2  # NeRFRenderer.run sets it per modality (renderer_dynamic.py:131)
+    M = 4096
+    x = torch.rand(M, 3, device=dev) * 2 - 1
+    d = torch.nn.functional.normalize(torch.randn(M, 3, device=dev), dim=-1)
+    geo = torch.randn(M, 15, device=dev)
+    dense = torch.rand(M, device=dev) < 0.8
+    sparse = torch.rand(M, device=dev) < 0.05
+
+    def ref(mask):  # gather / scatter form, no regime state involved
+        out = torch.zeros(M, 2, device=dev)
+        out[mask] = torch.sigmoid(ops.heads(m, (d[mask] + 1) / 2, geo[mask], True)).float()
+        return out
+
+    with torch.no_grad():
+        a = m.color(x, d, cal_lidar_color=True, mask=dense, geo_feat=geo)       # first call: synchronous count, regime := dense
+        assert m._mask_regime[True]["dense"] and torch.equal(a.float(), ref(dense))
+        b = m.color(x, d, cal_lidar_color=True, mask=dense, geo_feat=geo)       # dense regime: no read, count copy in flight
+        assert m._mask_regime[True]["pending"] is not None and torch.equal(b.float(), ref(dense))
+        c = m.color(x, d, cal_lidar_color=True, mask=sparse, geo_feat=geo)      # still treated as dense: all samples, masked
+        assert torch.equal(c.float(), ref(sparse))
+        torch.cuda.synchronize()
+        e = m.color(x, d, cal_lidar_color=True, mask=sparse, geo_feat=geo)      # the count of a sparse batch has landed by now
+        f = m.color(x, d, cal_lidar_color=True, mask=sparse, geo_feat=geo)
+        assert not m._mask_regime[True]["dense"] and torch.equal(e.float(), ref(sparse)) and torch.equal(f.float(), ref(sparse))
+        z = m.color(x, d, cal_lidar_color=True, mask=torch.zeros(M, dtype=torch.bool, device=dev), geo_feat=geo)
+        assert float(z.abs().max()) == 0.0
