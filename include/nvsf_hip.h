@@ -198,6 +198,12 @@ int nvsf_heads_input_f16(const void* enc_ray_f16, uint32_t N, uint32_t n_enc, ui
                          int geo_is_f16, uint32_t n_geo, uint32_t geo_stride, void* dst_f16, uint32_t in_cols, uint32_t dst_stride,
                          nvsf_stream_t stream);
 
+/* ref: `rgbs[mask] = torch.sigmoid(h)` into zeros (network_dynamic.py:325-330) when the heads were evaluated on every sample:
+ * out[m][c] = mask[m] ? 1 / (1 + exp(-logits[m * row_stride + c * col_stride])) : 0; out fp32 [M, C] dense; mask one byte per
+ * row (NULL = all rows). */
+int nvsf_masked_sigmoid(const float* logits, uint32_t row_stride, uint32_t col_stride, const void* mask_u8, uint32_t M, uint32_t C,
+                        float* out, nvsf_stream_t stream);
+
 /* ref: tcnn.Network("FullyFusedMLP") network_dynamic.py:125-135,138-161,180-189.
  * x [M, x_stride] fp32 (x_is_f16 == 0) or fp16; weights fp16 = W0 [hidden][in_cols] ++ (n_hidden-1) x
  * [hidden][hidden] ++ W_out [out_cols][hidden]; columns n_in..in_cols-1 of the input read as 1.0.

@@ -7,6 +7,7 @@
 //                        input buffer of the heads, ops.HeadsFn)
 //   nvsf_heads_input_f16 whole input rows of the per-sample heads, [ray's direction encoding | geometry features | ones], in one
 //                        pass of 16-byte stores (what the two kernels below do in two passes that each leave partial lines)
+//   nvsf_masked_sigmoid  out = mask ? sigmoid(logits) : 0 on a strided logits view (network_dynamic.py:325-330 for the dense case)
 //   nvsf_repeat_rows_f16 dst[n * T + t][:] = src[n][:]: a per-ray fp16 row (direction encoding) broadcast to the T samples of
 //                        the ray -- the encoders then run once per ray instead of once per sample
 // All are HBM-stream bound: 132 B per row, 6 B and 2 B (written) per element respectively.
@@ -133,6 +134,19 @@ __global__ __launch_bounds__(kBlock) void k_heads_input(const _Float16* __restri
     }
     *reinterpret_cast<half8_t*>(dst + m * dst_stride + col0) = v;
 }
+
+// out[m][c] = mask[m] ? sigmoid(logits[m][c]) : 0 for logits with arbitrary row / column strides (the heads' logits are a strided
+// view of their 16-column output blocks); thread = (row, column).
+__global__ __launch_bounds__(kBlock) void k_masked_sigmoid(const float* __restrict__ logits, uint32_t row_stride, uint32_t col_stride,
+                                                           const unsigned char* __restrict__ mask, uint32_t M, uint32_t C,
+                                                           float* __restrict__ out) {
+    const uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t m = idx / C, c = idx - m * C;
+    if (m >= M) return;
+    float v = 0.0f;
+    if (!mask || mask[m]) v = 1.0f / (1.0f + expf(-logits[(size_t)m * row_stride + (size_t)c * col_stride]));
+    out[idx] = v;
+}
 }  // namespace
 
 #define REQUIRE(cond) do { if (!(cond)) return NVSF_ERR_INVALID_ARG; } while (0)
@@ -209,5 +223,14 @@ NVSF_API int nvsf_heads_input_f16(const void* enc_ray_f16, uint32_t N, uint32_t 
     else
         hipLaunchKernelGGL(k_heads_input<false>, dim3(N * blocks_per_ray), dim3(kBlock), 0, stream, enc, n_enc, enc_stride, T, blocks_per_ray, geo, n_geo,
                            geo_stride, geo_vec, dst, in_cols, dst_stride);
+    return nvsf_launch_status();
+}
+
+NVSF_API int nvsf_masked_sigmoid(const float* logits, uint32_t row_stride, uint32_t col_stride, const void* mask_u8, uint32_t M, uint32_t C,
+                                 float* out, hipStream_t stream) {
+    if (M == 0 || C == 0) return NVSF_OK;
+    REQUIRE(logits && out && (unsigned long long)M * C < (1ull << 32));
+    hipLaunchKernelGGL(k_masked_sigmoid, dim3(cdiv((unsigned long long)M * C, kBlock)), dim3(kBlock), 0, stream, logits, row_stride, col_stride,
+                       reinterpret_cast<const unsigned char*>(mask_u8), M, C, out);
     return nvsf_launch_status();
 }

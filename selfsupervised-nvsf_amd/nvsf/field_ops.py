@@ -209,6 +209,28 @@ def mlp_backward(x, weights_f16, spec, grad_out, need_grad_x=True, grad_scale=ML
     return grad_x, grad_w
 
 
+class MaskedSigmoidFn(Function):
+    """out = mask ? sigmoid(logits) : 0, one launch on the strided logits view (torch: a strided sigmoid + a broadcast multiply);
+    the backward is sigmoid's own (g * out * (1 - out) vanishes on masked rows by itself)."""
+
+    @staticmethod
+    def forward(ctx, logits, mask):
+        if logits.dtype != torch.float32 or logits.dim() != 2:
+            logits = logits.float().reshape(logits.shape[0], -1)
+        M, C = logits.shape
+        out = torch.empty(M, C, dtype=torch.float32, device=logits.device)
+        mk = None if mask is None else mask.reshape(-1).to(torch.uint8 if mask.dtype != torch.bool else torch.bool).contiguous()
+        _hip.call("nvsf_masked_sigmoid", logits.data_ptr(), logits.stride(0), logits.stride(1) if C > 1 else 1,
+                  None if mk is None else mk.data_ptr(), M, C, _hip.ptr(out))
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (out,) = ctx.saved_tensors
+        return torch.ops.aten.sigmoid_backward(g.contiguous(), out), None
+
+
 # ---- dense / sparse choice of the per-sample heads without a host sync per call ------------------------------------------------
 # `color` evaluates the heads on all samples (and zeroes the masked ones) when at least a quarter of them pass the weight
 # threshold, otherwise on the gathered subset.  The count that decides this lives on the device.  While a modality stays in the

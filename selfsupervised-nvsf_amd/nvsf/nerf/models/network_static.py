@@ -89,10 +89,13 @@ class NeRFNetworkStatic(NeRFRenderer):
         # values as the reference's torch.cat + tcnn calls (network_dynamic.py:310-325), LiDAR order [raydrop, intensity]
         ray_dirs = kwargs.get("ray_dirs")  # [N, 3] from NeRFRenderer.run: d is these rows, each repeated for its ray's samples
         if mask is None and ray_dirs is not None and d.shape[0] % ray_dirs.shape[0] == 0:
-            h = torch.sigmoid(ops.heads(self, None, geo_feat, cal_lidar_color, ray_dirs01=(ray_dirs + 1) / 2))
+            logits = ops.heads(self, None, geo_feat, cal_lidar_color, ray_dirs01=(ray_dirs + 1) / 2)
         else:
             d = (d + 1) / 2  # the direction encoders expect [0, 1]
-            h = torch.sigmoid(ops.heads(self, d, geo_feat, cal_lidar_color))
+            logits = ops.heads(self, d, geo_feat, cal_lidar_color)
+        if dense_mask is not None and logits.is_cuda:
+            return ops.MaskedSigmoidFn.apply(logits, dense_mask).to(x.dtype)  # sigmoid and mask in one launch
+        h = torch.sigmoid(logits)
         if dense_mask is not None:
             return (h * dense_mask.unsqueeze(-1)).to(x.dtype)
         if mask is None:
