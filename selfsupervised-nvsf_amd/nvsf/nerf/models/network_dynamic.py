@@ -161,7 +161,8 @@ class NeRFNetwork(NeRFRenderer):
               and hash_d.dtype == torch.float32 and not hash_1.requires_grad and not hash_2.requires_grad):
             # neighbour blend + concatenation + density MLP as ONE forward launch that also leaves the rounded network input
             # for the fused MLP backward; no [M,120] fp32 concatenation, no blend temporaries, in either direction
-            h = DensityTailFn.apply(self, plane_s, plane_d, plane_1, plane_2, hash_s, hash_d, hash_1, hash_2, self.sigma_net.params)
+            sigma, geo = DensityTailFn.apply(self, plane_s, plane_d, plane_1, plane_2, hash_s, hash_d, hash_1, hash_2, self.sigma_net.params)
+            return {"sigma": sigma, "geo_feat": geo}
         else:
             plane_d = 0.5 * plane_d + 0.25 * (plane_1 + plane_2)
             hash_d = 0.5 * hash_d + 0.25 * (hash_1 + hash_2)
@@ -261,17 +262,31 @@ class DensityTailFn(torch.autograd.Function):
     def forward(ctx, net, plane_s, plane_d, plane_1, plane_2, hash_s, hash_d, hash_1, hash_2, params):
         h, x16 = net._density_tail_fused(plane_s.detach(), plane_d.detach(), plane_1.detach(), plane_2.detach(), hash_s.detach(),
                                          hash_d.detach(), hash_1.detach(), hash_2.detach(), keep_input=True)
-        ctx.save_for_backward(x16, net.sigma_net.weights_f16())
+        sigma = torch.exp(h[:, 0])  # trunc_exp's forward (activation.py:6-20); its backward is folded into the pass below
+        ctx.save_for_backward(x16, net.sigma_net.weights_f16(), sigma)
         ctx.spec = net.sigma_net.spec
         ctx.hash_s_dtype = hash_s.dtype
-        return h
+        return sigma, h[:, 1:net.sigma_net.spec.n_out]
 
     @staticmethod
-    def backward(ctx, grad_h):
-        x16, w16 = ctx.saved_tensors
+    def backward(ctx, g_sigma, g_geo):
+        from nvsf import _hip
+        from nvsf.nerf import activation
+        x16, w16, sigma = ctx.saved_tensors
         spec = ctx.spec
         need = ctx.needs_input_grad
         need_x = any(need[1:9])
+        # logit gradient [g_sigma * clamp(sigma) | g_geo] in one pass (ops.DensityFn does the same for the static field)
+        M = x16.shape[0]
+        if g_sigma is not None:
+            g_sigma = g_sigma.float().contiguous()
+        if g_geo is not None and (g_geo.dtype != torch.float32 or g_geo.stride(1) != 1):
+            g_geo = g_geo.float().contiguous()
+        grad_h = torch.empty(M, 16, dtype=torch.float32, device=x16.device)
+        _hip.call("nvsf_sigma_geo_bwd", None if g_sigma is None else _hip.ptr(g_sigma), _hip.ptr(sigma),
+                  None if g_geo is None else _hip.ptr_rows(g_geo), 0 if g_geo is None else g_geo.stride(0), spec.n_out - 1, M,
+                  _hip.ptr(grad_h), 16, activation._LO, activation._HI)
+        grad_h = grad_h[:, :spec.n_out]
         grad_x, gw = ops.mlp_backward(x16[:, :spec.n_in], w16, spec, grad_h, need_grad_x=need_x)
         out = [None] * 10
         if need_x:
