@@ -1,7 +1,12 @@
 #!/usr/bin/env python3
 """Benchmark of the NVSF render hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 runs one rank per GPU.  Under a launcher (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`:
+RANK / LOCAL_RANK / WORLD_SIZE in the environment) this process is one of the ranks.  Without one (`python bench.py --gpus N`)
+this process only starts the N ranks itself -- as children of `torch.distributed.run`, BEFORE anything here touches the GPU --
+forwards rank 0's JSON line and exits with the launcher's status.
 
 Workload (BASELINE.json configs[1], "C2"): per step and per GPU one KITTI-360-shaped frame =
 4096 LiDAR rays + 4096 camera rays, 768 uniform samples per ray, static hash grid L=16 F=2 T=2^19
@@ -53,6 +58,35 @@ def parse():
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the occupancy-grid (config 3) and dynamic-field (config 5) legs")
     ap.add_argument("--train-steps", type=int, default=10, help="extra leg: timed training steps reported under `train` (0 = skip)")
     return ap.parse_args()
+
+
+def launch_command(gpus, argv, port):
+    """The launcher invocation `python bench.py --gpus N` turns into when no launcher started it."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(gpus)}", "--master-addr", "127.0.0.1",
+            "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args):
+    """--gpus N > 1 without WORLD_SIZE: start the N ranks as fresh child processes (this parent has not initialised HIP and
+    never does), pass their stderr through, print rank 0's JSON line and return the launcher's exit status."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(launch_command(args.gpus, sys.argv[1:], port), stdout=subprocess.PIPE, text=True, env=env)
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
+    for l in proc.stdout.splitlines():
+        if l not in lines[-1:]:
+            print(l, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    elif proc.returncode == 0:
+        print("bench.py: the ranks exited without a result line", file=sys.stderr)
+        return 1
+    return proc.returncode
 
 
 def event_time_ms(fn, iters):
@@ -248,6 +282,48 @@ def train_leg(model, tl, tc, tm, T, steps, dev, dist):
                     "(corner-parallel run-merging atomics), MLPs (fused data + weight gradients, shared aligned head input) and compositors"}
 
 
+def eval_leg(model, dev, T, frames, dist):
+    """Secondary figure: the reference's evaluation workload -- whole frames, LiDAR 66 x 1030 = 67 980 rays and
+    camera 376 x 1408 = 529 408 rays, generated on the device (csrc/raygen.hip) and rendered with the staged chunk loop
+    (max_ray_batch 4096).  Across ranks a frame's rays are split into contiguous chunks and the outputs all-gathered
+    (frame_shard.render_sharded, what trainer.py:1511-1524 intended): fixed work per frame, i.e. STRONG scaling."""
+    from nvsf import frame_shard, synthetic as S
+    from nvsf.nerf.dataset import dataset_utils as DU
+    pose = torch.eye(4, device=dev)[None]
+    K = torch.tensor([[S.CAM_K[0], 0.0, S.CAM_K[2]], [0.0, S.CAM_K[1], S.CAM_K[3]], [0.0, 0.0, 1.0]])
+    lid = DU.get_lidar_rays(pose, S.LIDAR_FOV[:2], (0.0, S.LIDAR_FOV[2]), S.LIDAR_HW[0], S.LIDAR_HW[1])
+    cam = DU.get_rays(pose, K, S.CAM_HW[0], S.CAM_HW[1])
+    tm = torch.tensor([[0.5]], device=dev)
+
+    def frame():
+        with torch.no_grad():
+            a = frame_shard.render_sharded(model, lid["rays_o"], lid["rays_d"], tm, cal_lidar_color=True, num_steps=T)
+            b = frame_shard.render_sharded(model, cam["rays_o"], cam["rays_d"], tm, cal_lidar_color=False, num_steps=T)
+        return a, b
+    out = frame()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        out = frame()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    world = dist.get_world_size() if dist is not None else 1
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    n = lid["rays_o"].shape[1] + cam["rays_o"].shape[1]
+    ok = bool(out[0]["image_lidar"].shape[1] == lid["rays_o"].shape[1] and out[1]["image"].shape[1] == cam["rays_o"].shape[1]
+              and torch.isfinite(out[0]["depth_lidar"]).all() and torch.isfinite(out[1]["image"]).all())
+    return {"metric": "evaluation frames/sec (LiDAR 66x1030 + camera 376x1408 rays per frame, staged)", "value": frames / dt,
+            "rays_per_s": n * frames / dt, "ms_per_frame": dt / frames * 1e3, "frames": frames, "rays_per_frame": n, "scaling": "strong",
+            "ranks": world, "collective": "all_gather of depth / image chunks" if world > 1 else "none", "outputs_complete_and_finite": ok}
+
+
 def occupancy_leg(model_cls, dev, n_rays, steps):
     """Secondary figure (BASELINE config 3): the config-2 field and ray batches through the occupancy-grid renderer,
     procedural occupancy grid (union of 64 random boxes, ~10 % occupied), max 1024 samples per ray.
@@ -397,7 +473,11 @@ def dynamic_leg(dev, n_rays, T, steps):
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -499,6 +579,10 @@ def main():
             line["dynamic"] = dynamic_leg(dev, args.num_rays, T, 3)
             line["raymarching"] = raymarching_leg(dev)
             line["field_ops"] = field_ops_leg(dev, args.num_rays, T)
+    if not args.no_extra_legs:
+        ev = eval_leg(model, dev, T, 3, dist)
+        if rank == 0:
+            line["eval"] = ev
     if args.train_steps > 0:
         tr = train_leg(model, tl, tc, tm, T, args.train_steps, dev, dist)
         if rank == 0:

@@ -28,6 +28,42 @@ def test_defaults_and_traffic_lookup(monkeypatch):
     assert b.pmc_traffic("no_such_kernel[lidar]")["traffic"] is None
 
 
+def test_gpus_flag_starts_that_many_ranks(monkeypatch):
+    """`python bench.py --gpus N` without a launcher must start N ranks itself (the flag was parsed and ignored)."""
+    import subprocess
+    b = _bench()
+    cmd = b.launch_command(4, ["--gpus", "4", "--steps", "3"], 29999)
+    assert "--nproc-per-node=4" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert os.path.basename(cmd[cmd.index("--master-port") + 2]) == "bench.py"
+    # main(): no WORLD_SIZE + --gpus 3 -> self_launch (and nothing of this process touches the GPU before it)
+    seen = {}
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "3"])
+    monkeypatch.setattr(b, "self_launch", lambda a: seen.setdefault("gpus", a.gpus) and 0)
+    monkeypatch.setattr(b.torch.cuda, "is_available", lambda: (_ for _ in ()).throw(AssertionError("HIP touched before the launch")))
+    try:
+        b.main()
+    except SystemExit as e:
+        assert e.code == 0
+    assert seen == {"gpus": 3}
+    # a launcher whose world size disagrees with --gpus is an error, not a silent 1-rank run
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8"])
+    try:
+        b.main()
+        raise AssertionError("mismatch accepted")
+    except SystemExit as e:
+        assert "WORLD_SIZE=2" in str(e.code)
+    # end to end on a box without a GPU: two ranks come up, each refuses to run without a HIP device, the parent fails loudly
+    import torch
+    if torch.cuda.device_count() == 0:
+        env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True,
+                           text=True, env=env, timeout=300)
+        assert r.returncode != 0 and r.stderr.count("needs a HIP device") >= 2, r.stderr[-2000:]
+        assert not r.stdout.strip()
+
+
 def test_committed_bench_line_follows_the_contract():
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_line.json")))
     assert files

@@ -43,6 +43,20 @@ def _worker(rank, world_size, port, q):
         b, e = FS.ray_chunk(N, rank, world_size)
         gathered = FS.gather_ray_outputs(full[b:e] * 2.0, N)
         ok_rays = torch.equal(gathered, full * 2.0)
+        # --- evaluation render of one frame split over the ranks: every rank gets the whole frame back, in ray order
+        class Stub:
+            calls = []
+
+            def render(self, o, d, time, cal_lidar_color=False, staged=False, max_ray_batch=4096, **kw):
+                assert staged and o.shape[0] == 1 and o.shape == d.shape
+                Stub.calls.append(o.shape[1])
+                k = ("depth_lidar", "image_lidar") if cal_lidar_color else ("depth", "image")
+                return {k[0]: o[..., 0] + d[..., 1], k[1]: torch.stack([o[..., 0], d[..., 2]], -1) * float(time)}
+        o = torch.arange(N * 3, dtype=torch.float32).view(1, N, 3)
+        d = -o
+        out = FS.render_sharded(Stub(), o, d, torch.tensor([[0.5]]), cal_lidar_color=True)
+        ok_rays = ok_rays and Stub.calls == [e - b] and torch.equal(out["depth_lidar"], o[..., 0] + d[..., 1]) \
+            and torch.equal(out["image_lidar"], torch.stack([o[..., 0], d[..., 2]], -1) * 0.5)
         # --- frames
         mine = FS.frames_for_rank(61, epoch=3, rank=rank, world_size=world_size, seed=5)
         objs = [None] * world_size
