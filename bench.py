@@ -252,12 +252,13 @@ def train_leg(model, tl, tc, tm, T, steps, dev, dist):
     """Secondary figure (not `value`): full multimodal training steps (BASELINE config 4 shape) -- both renders with
     gradient, losses, backward through the HIP operators, one bucketed RCCL gradient all-reduce when N > 1, Adam."""
     from nvsf.nerf.train_step import RenderTrainStep
+    from nvsf.synthetic import SCALE as S_SCALE
     n_l, n_c = tl[0].shape[1], tc[0].shape[1]
     g = torch.Generator(device="cpu").manual_seed(3)
     batch = {"rays_o_lidar": tl[0], "rays_d_lidar": tl[1], "rays_o": tc[0], "rays_d": tc[1], "time": tm,
              "gt_depth": torch.rand(1, n_l, generator=g).to(dev) * 0.5, "gt_raydrop": (torch.rand(1, n_l, generator=g) > 0.3).float().to(dev),
              "gt_intensity": torch.rand(1, n_l, generator=g).to(dev), "gt_rgb": torch.rand(1, n_c, 3, generator=g).to(dev)}
-    step = RenderTrainStep(model, num_steps=T)
+    step = RenderTrainStep(model, num_steps=T, scale=S_SCALE)
     n_coll = 0
     for _ in range(5):  # the loss scale settles (overflowing first steps are skipped), optimiser state and allocator pools exist
         step.step(batch)
@@ -278,7 +279,9 @@ def train_leg(model, tl, tc, tm, T, steps, dev, dist):
         dt = float(t.item())
     model.eval()
     return {"metric": "trained rays/sec (LiDAR+cam, fwd+bwd+Adam)", "value": (n_l + n_c) * world * steps / dt, "ms_per_step": dt / steps * 1e3,
-            "steps": steps, "allreduce_collectives_per_step": n_coll, "path": "operator path (autograd) under GradScaler (dense fp16 feature gradients): HIP forward kernels; HIP backward for hash grid "
+            "steps": steps, "allreduce_collectives_per_step": n_coll,
+            "losses": "the reference's Trainer.train_step defaults: per-ray L1 range + MSE ray-drop + MSE intensity summed over rays, chamfer distance of the predicted point cloud, summed MSE RGB",
+            "path": "operator path (autograd) under GradScaler (dense fp16 feature gradients): HIP forward kernels; HIP backward for hash grid "
                     "(corner-parallel run-merging atomics), MLPs (fused data + weight gradients, shared aligned head input) and compositors"}
 
 
@@ -455,7 +458,7 @@ def dynamic_leg(dev, n_rays, T, steps):
     batch = {"rays_o_lidar": tl[0], "rays_d_lidar": tl[1], "rays_o": tc[0], "rays_d": tc[1], "time": tm,
              "gt_depth": torch.rand(1, n_rays, generator=g).to(dev) * 0.5, "gt_raydrop": (torch.rand(1, n_rays, generator=g) > 0.3).float().to(dev),
              "gt_intensity": torch.rand(1, n_rays, generator=g).to(dev), "gt_rgb": torch.rand(1, n_rays, 3, generator=g).to(dev)}
-    trainer = RenderTrainStep(m, num_steps=T)
+    trainer = RenderTrainStep(m, num_steps=T, scale=S.SCALE)
     for _ in range(4):  # loss scale settled, optimiser state and allocator pools in place
         trainer.step(batch)
     torch.cuda.synchronize()

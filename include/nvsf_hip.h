@@ -416,9 +416,16 @@ int nvsf_adam_prepare(float* state4, const float* found_inf, float beta1, float 
 
 /* One pass over a parameter tensor (all fp32 [n]): g = grad / *grad_scale (grad_scale NULL = 1); exp_avg += (1 - beta1)(g - exp_avg);
  * exp_avg_sq = beta2 exp_avg_sq + (1 - beta2) g g; param -= lr / state4[1] * exp_avg / (sqrt(exp_avg_sq) / state4[2] + eps).
- * Nothing is written when state4[3] != 0 (overflow: the step is skipped). */
+ * Nothing is written when state4[3] != 0 (overflow: the step is skipped).
+ * ema_shadow (fp32 [n], may be NULL): shadow -= ema_one_minus_decay * (shadow - param) with the UPDATED parameter, in the same
+ * pass (an every-step exponential moving average of the weights; the reference's per-epoch one is nvsf_ema_update). */
 int nvsf_adam_update(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr, float beta1,
-                     float beta2, float eps, const float* state4, const float* grad_scale, nvsf_stream_t stream);
+                     float beta2, float eps, const float* state4, const float* grad_scale, float* ema_shadow,
+                     float ema_one_minus_decay, nvsf_stream_t stream);
+
+/* ref: torch_ema.ExponentialMovingAverage.update as used by the Trainer (trainer.py:112-114 construction with decay 0.95,
+ * :1420-1421 one update per epoch): shadow -= one_minus_decay * (shadow - param), fp32 [n]. */
+int nvsf_ema_update(float* shadow, const float* param, uint64_t n, float one_minus_decay, nvsf_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -30,32 +30,63 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
-def _stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.abspath(__file__)]
-    return any(os.path.getmtime(d) > t for d in deps)
+OBJDIR = os.path.join(LIBDIR, "obj")
 
 
-def build(force=False, report=False, verbose=True):
-    os.makedirs(LIBDIR, exist_ok=True)
-    if not force and not report and not _stale():
-        return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + sources() + ["-o", LIB + ".tmp"]
+def _headers():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.abspath(__file__)]
+
+
+def _obj(src):
+    return os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
+
+
+def _compile(args):
+    hipcc, src, report = args
+    cmd = [hipcc] + [f for f in FLAGS if f != "-shared"] + ["-c", src, "-o", _obj(src)]
     if report:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     proc = subprocess.run(cmd, capture_output=True, text=True)
-    if proc.returncode != 0:
-        sys.stderr.write(proc.stderr[-8000:])
-        raise RuntimeError(f"hipcc failed ({proc.returncode}) building {LIB}")
+    return src, proc.returncode, proc.stderr
+
+
+def build(force=False, report=False, verbose=True):
+    """One translation unit per .hip file, compiled in parallel into lib/obj/*.o (only the ones older than their source or any
+    csrc header), then linked into libnvsf_hip.so.  Kernels live in anonymous namespaces: no cross-file device linking."""
+    from concurrent.futures import ThreadPoolExecutor
+    os.makedirs(OBJDIR, exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    newest_header = max(os.path.getmtime(h) for h in _headers())
+    srcs = sources()
+    todo = [s for s in srcs if force or report or not os.path.exists(_obj(s))
+            or os.path.getmtime(_obj(s)) < max(os.path.getmtime(s), newest_header)]
+    stale_objs = [o for o in os.listdir(OBJDIR) if o.endswith(".o") and os.path.join(OBJDIR, o) not in {_obj(s) for s in srcs}]
+    for o in stale_objs:
+        os.remove(os.path.join(OBJDIR, o))
+    if not todo and not stale_objs and os.path.exists(LIB) and os.path.getmtime(LIB) >= max(os.path.getmtime(_obj(s)) for s in srcs):
+        return LIB
+    errors, logs = [], []
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        for src, rc, err in pool.map(_compile, [(hipcc, s, report) for s in todo]):
+            logs.append(err)
+            if rc != 0:
+                errors.append((src, err))
+    if errors:
+        for src, err in errors:
+            sys.stderr.write(f"---- {src}\n{err[-6000:]}\n")
+        raise RuntimeError(f"hipcc failed building {[os.path.basename(s) for s, _ in errors]}")
+    link = subprocess.run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-fvisibility=hidden"] + [_obj(s) for s in srcs] + ["-o", LIB + ".tmp"],
+                          capture_output=True, text=True)
+    if link.returncode != 0:
+        sys.stderr.write(link.stderr[-8000:])
+        raise RuntimeError(f"hipcc failed ({link.returncode}) linking {LIB}")
     os.replace(LIB + ".tmp", LIB)
-    warn = [l for l in proc.stderr.splitlines() if "warning:" in l]
+    text = "\n".join(logs)
+    warn = [l for l in text.splitlines() if "warning:" in l]
     if verbose and warn:
         print("\n".join(warn[:40]))
     if report:
-        _print_report(proc.stderr)
+        _print_report(text)
     return LIB
 
 

@@ -13,6 +13,12 @@ from nvsf import _hip
 
 
 class FusedAdam(torch.optim.Optimizer):
+    """Step counters: torch.optim.Adam keeps one `step` per parameter and advances it only when that parameter has a gradient
+    (a LiDAR-only step leaves the camera tables' counters alone).  Here parameters that have so far been updated in exactly the
+    same steps share one device-side counter row [step, 1 - b1^step, sqrt(1 - b2^step), skip]; when a step updates only part of
+    a row's members those members fork into a row of their own (a 16-byte device copy).  All parameters always active -- the
+    usual case -- is one row and one `nvsf_adam_prepare` launch per step; the bias corrections every parameter sees are those of
+    torch.optim.Adam, and `state_dict()` / `load_state_dict()` carry the per-parameter steps losslessly."""
     _step_supports_amp_scaling = True
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
@@ -24,14 +30,52 @@ class FusedAdam(torch.optim.Optimizer):
                                       capturable=False, differentiable=False, fused=None, decoupled_weight_decay=False))
         betas0 = self.param_groups[0]["betas"]
         if any(tuple(g["betas"]) != tuple(betas0) for g in self.param_groups):
-            raise ValueError("FusedAdam keeps one step counter: every group must use the same betas")
-        self._dev_state = None  # device [4]: step, 1 - b1^step, sqrt(1 - b2^step), skip
+            raise ValueError("FusedAdam shares step-counter rows between groups: every group must use the same betas")
+        self._rows = None      # device [R, 4]: step, 1 - b1^step, sqrt(1 - b2^step), skip
+        self._row_of = {}      # parameter -> row index
+        self._n_rows = 0
+        self.ema = None        # optional (shadow tensors by parameter, one_minus_decay): EMA folded into the update pass
 
-    def _device_state(self, device):
-        if self._dev_state is None or self._dev_state.device != device:
-            old = 0.0 if self._dev_state is None else float(self._dev_state[0])
-            self._dev_state = torch.tensor([old, 0.0, 0.0, 0.0], dtype=torch.float32, device=device)
-        return self._dev_state
+    _MAX_ROWS = 64
+
+    def _row_table(self, device):
+        if self._rows is None or self._rows.device != device:
+            old = self._rows
+            self._rows = torch.zeros(self._MAX_ROWS, 4, dtype=torch.float32, device=device)
+            if old is not None:
+                self._rows.copy_(old)
+        return self._rows
+
+    def _assign_rows(self, active, device):
+        """Row of every active parameter for this step; forks rows whose members are only partly active.  Host logic only."""
+        rows = self._row_table(device)
+        members = {}
+        for p, r in self._row_of.items():
+            members.setdefault(r, []).append(p)
+        active_set = set(active)
+        fresh = [p for p in active if p not in self._row_of]
+        for r, ps in members.items():
+            act = [p for p in ps if p in active_set]
+            if act and len(act) < len(ps):  # fork: the active members continue on a copy of the row
+                new = self._new_row()
+                rows[new].copy_(rows[r])
+                for p in act:
+                    self._row_of[p] = new
+        if fresh:
+            # a parameter seen for the first time has step 0: it may share the row of others that are also at step 0 only if
+            # they are all active now, which the fork rule above already guarantees for later steps -- give them a new row
+            new = self._new_row()
+            rows[new].zero_()
+            for p in fresh:
+                self._row_of[p] = new
+        return sorted({self._row_of[p] for p in active})
+
+    def _new_row(self):
+        used = set(self._row_of.values())
+        for r in range(self._MAX_ROWS):
+            if r not in used:
+                return r
+        raise _hip.NvsfHipError("FusedAdam: more than 64 distinct update histories among the parameters")
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -40,15 +84,19 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         grad_scale, found_inf = getattr(self, "grad_scale", None), getattr(self, "found_inf", None)
-        first = next((p for g in self.param_groups for p in g["params"] if p.grad is not None), None)
-        if first is None:
+        active = [p for g in self.param_groups for p in g["params"] if p.grad is not None]
+        if not active:
             return loss
+        first = active[0]
         if not first.is_cuda:
             raise _hip.NvsfHipError("FusedAdam runs on a HIP device (there is no CPU fallback)")
-        st = self._device_state(first.device)
         beta1, beta2 = self.param_groups[0]["betas"]
-        _hip.call("nvsf_adam_prepare", _hip.ptr(st), None if found_inf is None else _hip.ptr(found_inf.float()), float(beta1), float(beta2))
+        rows = self._row_table(first.device)
+        found = None if found_inf is None else _hip.ptr(found_inf.float())
+        for r in self._assign_rows(active, first.device):
+            _hip.call("nvsf_adam_prepare", rows[r].data_ptr(), found, float(beta1), float(beta2))
         scale_ptr = None if grad_scale is None else _hip.ptr(grad_scale.float())
+        shadows, omd = (self.ema if self.ema is not None else ({}, 0.0))
         for group in self.param_groups:
             lr, eps = float(group["lr"]), float(group["eps"])
             if group.get("weight_decay", 0) or group.get("amsgrad", False) or group.get("maximize", False):
@@ -63,8 +111,10 @@ class FusedAdam(torch.optim.Optimizer):
                     state["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                shadow = shadows.get(p)
                 _hip.call("nvsf_adam_update", p.data_ptr(), grad.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(),
-                          p.numel(), lr, float(beta1), float(beta2), eps, _hip.ptr(st), scale_ptr)
+                          p.numel(), lr, float(beta1), float(beta2), eps, rows[self._row_of[p]].data_ptr(), scale_ptr,
+                          None if shadow is None else shadow.data_ptr(), float(omd))
                 # the kernel wrote through the raw pointer: tell autograd (and every cache keyed on `_version`, e.g. the fp16
                 # copies of tables and weights the forward kernels read) that the parameter changed
                 torch.autograd.graph.increment_version(p)
@@ -72,16 +122,39 @@ class FusedAdam(torch.optim.Optimizer):
 
     # ---- torch.optim.Adam-compatible state dicts ---------------------------------------------------------------------------
     def state_dict(self):
-        step = 0.0 if self._dev_state is None else float(self._dev_state[0])  # one device read, at checkpoint time only
+        steps = None if self._rows is None else self._rows[:, 0].cpu()  # one device read, at checkpoint time only
         out = super().state_dict()
-        out["state"] = {k: dict(st, step=torch.tensor(step, dtype=torch.float32)) for k, st in out["state"].items()}
+        index = {}
+        i = 0
+        for g in self.param_groups:  # torch's packing order: parameter ids count up through the groups
+            for p in g["params"]:
+                index[i] = p
+                i += 1
+        state = {}
+        for k, st in out["state"].items():
+            p = index[k]
+            step = float(steps[self._row_of[p]]) if (steps is not None and p in self._row_of) else 0.0
+            state[k] = dict(st, step=torch.tensor(step, dtype=torch.float32))
+        out["state"] = state
         return out
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
-        steps = [float(s.pop("step")) for s in self.state.values() if "step" in s]
-        step = max(steps) if steps else 0.0
+        by_step = {}
+        for p, st in self.state.items():
+            if "step" in st:
+                by_step.setdefault(float(st.pop("step")), []).append(p)
+        self._rows, self._row_of = None, {}
+        if not by_step:
+            return
         dev = next((p.device for g in self.param_groups for p in g["params"] if p.is_cuda), None)
-        self._dev_state = None if dev is None else torch.tensor([step, 0.0, 0.0, 0.0], dtype=torch.float32, device=dev)
-        if dev is None and step:
+        if dev is None:
             raise _hip.NvsfHipError("FusedAdam state needs a HIP device")
+        if len(by_step) > self._MAX_ROWS:
+            raise _hip.NvsfHipError("FusedAdam: more than 64 distinct step counts in the loaded state")
+        table = torch.zeros(self._MAX_ROWS, 4, dtype=torch.float32)
+        for r, (step, ps) in enumerate(sorted(by_step.items())):
+            table[r, 0] = step
+            for p in ps:
+                self._row_of[p] = r
+        self._rows = table.to(dev)

@@ -1,22 +1,29 @@
 """Thin multimodal training step + the two quality metrics of the headline benchmark.
 
-Only what sits directly around the hot path, restated from the reference:
-  * losses of Trainer.train_step (nvsf/nerf/trainer.py:193-219, 276-294, 491-503 with the default CLI weights of
-    nvsf/scripts/main_nvsf.py:84-97): L1 range, MSE ray-drop against label-smoothed targets (smooth 0.2, weight
-    0.01), MSE intensity on returned rays (weight 0.1), MSE RGB, optional URF line-of-sight loss on
-    (weights, z_vals);
+Only what sits directly around the hot path, restated from the reference's `Trainer.train_step`
+(nvsf/nerf/trainer.py:153-656) with the default CLI settings of nvsf/scripts/main_nvsf.py:60-97:
+  * LiDAR: ground truth masked by the ray-drop channel (trainer.py:186-189), predictions masked the same way (:203-206),
+    per-ray L1 range (alpha_d 1) + MSE ray-drop against label-smoothed targets (`--smooth_factor`, default 0.0; alpha_r 0.01)
+    + MSE intensity (alpha_i 0.1), all `reduction="none"` and SUMMED over the rays (main_nvsf.py:205-221, trainer.py:540-543);
+    chamfer distance between the predicted and the true point cloud `rays_d * depth / scale`, `(d1 + d2).mean() * 0.5`
+    (trainer.py:229-233; it IS part of the total at :542), on csrc/chamfer.hip; optional scene-flow loss (`--flow_loss`,
+    trainer.py:236-267: chamfer between the flow-warped point cloud of the frame and its neighbours' clouds + mean |flow|) and
+    URF line-of-sight loss (trainer.py:276-294);
+  * camera: MSE RGB summed over rays and channels (alpha_rgb 1; trainer.py:491-503);
+  * NaN -> 0, Inf -> 1e5 on the scalar (trainer.py:545-546);
   * optimiser: Adam(betas 0.9/0.99, eps 1e-15) on `model.get_params(lr)` and the 0.1^(iter/iters) decay
     (main_nvsf.py:350-362), under the GradScaler of the reference's fp16 run (trainer.py:119, 1332-1334);
+  * EMA of the weights, decay 0.95, updated once per epoch (trainer.py:112-114, 1420-1421; nvsf/nerf/ema.py);
   * PSNR (nvsf/lib/error_matrices.py:48-57) and depth RMSE in metres (error_matrices.py:263-285).
 Across GPUs the step is frame-sharded: every rank renders its own frame, then ONE bucketed gradient all-reduce
-(nvsf/frame_shard.py).  Checkpoints use the reference's dict (utils.py:622-747).  The reference's Trainer (logging, EMA, UNet
-refinement, error maps, chamfer and flow losses) is out of scope.
+(nvsf/frame_shard.py).  Checkpoints use the reference's dict (utils.py:622-747).  Logging, UNet refinement, error maps and the
+structural-regularisation losses on LiDAR patches (patch_size_lidar > 1) of the reference's Trainer are out of scope.
 """
 import math
+import warnings
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from nvsf import frame_shard
 
@@ -39,55 +46,100 @@ def urf_line_of_sight_loss(weights, z_vals, gt_depth, eps):
 
 class RenderTrainStep:
     def __init__(self, model, lr=1e-2, iters=30000, num_steps=768, alpha_d=1.0, alpha_r=0.01, alpha_i=0.1, alpha_rgb=1.0,
-                 smooth_factor=0.2, use_urf_loss=False, bucket_bytes=64 << 20, fp16=True):
+                 smooth_factor=0.0, use_urf_loss=False, bucket_bytes=64 << 20, fp16=True, scale=1.0, chamfer_loss=True,
+                 flow_loss=False, pc_list=None, ema_decay=0.95):
+        """Defaults = the reference's CLI defaults (main_nvsf.py:60-97).  `scale`: the scene scale the chamfer loss divides by
+        (opt.scale); `pc_list`: {frame index: [P, 3] tensor} world-frame point clouds for the scene-flow loss
+        (Trainer.process_pointcloud, trainer.py:1848-1912, builds them from the range images); `ema_decay=None` disables EMA."""
         self.model = model
         # loss scaling of the reference's mixed-precision run (trainer.py:119, 1332-1334: GradScaler(enabled=fp16) -> scale(loss)
         # .backward() -> step -> update; `-L` / `--fp16` in main_nvsf.py:17,43,159).  The encoders hand fp16 features to the
-        # MLPs, so the gradients that travel back between them are fp16 tensors: unscaled, those of a mean-over-rays loss sit
-        # below the fp16 subnormal range and the hash tables receive zeros.
+        # MLPs, so the gradients that travel back between them are fp16 tensors.
         self.scaler = torch.amp.GradScaler("cuda", enabled=bool(fp16) and torch.cuda.is_available())
         if fp16 and hasattr(model, "flow_net"):
             model.flow_net.flow_mlp_mode = "fused"  # the flow MLP as autocast runs it: fp16 MFMA kernels (flow_field.FlowMlpFn)
         # Adam as one HIP pass per parameter tensor with the scaler's overflow flag consumed on the device (nvsf/nerf/adam.py).
         # torch's own fused=True variant was tried first: under this eps = 1e-15 / GradScaler setting it trains measurably worse
-        # (tests/test_train_step_gpu.py: loss 0.289 -> 0.258 after 120 steps against 0.227).  NVSF_ADAM=torch: the default
-        # multi-tensor implementation.
-        import os
+        # (tests/test_train_step_gpu.py: loss 0.289 -> 0.258 after 120 steps against 0.227).
         on_gpu = torch.cuda.is_available() and next(model.parameters()).is_cuda
-        if on_gpu and os.environ.get("NVSF_ADAM", "hip") == "hip":
+        if on_gpu:
             from nvsf.nerf.adam import FusedAdam
             self.opt = FusedAdam(model.get_params(lr), betas=(0.9, 0.99), eps=1e-15)
-        else:
+        else:  # host-side logic tests only (checkpoint schema, gloo): the product path above needs the HIP device
             self.opt = torch.optim.Adam(model.get_params(lr), betas=(0.9, 0.99), eps=1e-15)
         self.sched = torch.optim.lr_scheduler.LambdaLR(self.opt, lambda it: 0.1 ** min(it / iters, 1))
         self.iters, self.num_steps = iters, num_steps
         self.alpha_d, self.alpha_r, self.alpha_i, self.alpha_rgb = alpha_d, alpha_r, alpha_i, alpha_rgb
         self.smooth, self.use_urf, self.bucket_bytes = smooth_factor, use_urf_loss, bucket_bytes
+        self.scale, self.use_chamfer, self.use_flow, self.pc_list = float(scale), bool(chamfer_loss), bool(flow_loss), pc_list or {}
+        self.ema = None
+        if ema_decay is not None and on_gpu:
+            from nvsf.nerf.ema import ExponentialMovingAverage
+            self.ema = ExponentialMovingAverage(model.parameters(), decay=ema_decay)
+        self._cham = None
         self.global_step = 0
 
+    def _chamfer(self, a, b):
+        if self._cham is None:
+            from nvsf.nerf.chamfer3D.dist_chamfer_3D import chamfer_3DDist
+            self._cham = chamfer_3DDist()
+        return self._cham(a, b)
+
+    def flow_loss(self, time):
+        """Scene-flow loss of trainer.py:236-267: the frame's point cloud moved by the predicted forward / backward flow against
+        the next / previous frame's cloud (sum of squared NN distances both ways, x 0.5) + the mean absolute flow."""
+        frame_idx = int(float(time.reshape(-1)[0]) * (self.model.num_frames - 1))
+        pc = self.pc_list.get(frame_idx)
+        if pc is None:
+            return None
+        pc = pc.float().contiguous()
+        pred = self.model.flow(pc, time)
+        total = None
+        for key, other in (("flow_forward", frame_idx + 1), ("flow_backward", frame_idx - 1)):
+            tgt = self.pc_list.get(other)
+            if tgt is None:
+                continue
+            d1, d2, _, _ = self._chamfer((pc + pred[key]).unsqueeze(0), tgt.float().contiguous().unsqueeze(0))
+            term = (d1.sum() + d2.sum()) * 0.5 + pred[key].abs().mean()
+            total = term if total is None else total + term
+        return total
+
     def losses(self, batch):
-        """batch: rays_o_lidar, rays_d_lidar [1,N,3], gt_depth, gt_intensity, gt_raydrop [1,N]; rays_o, rays_d [1,N,3],
-        gt_rgb [1,N,3]; time [1,1]."""
+        """batch: rays_o_lidar, rays_d_lidar [1,N,3] with either images_lidar [1,N,3] = (raydrop, intensity, range) as the
+        reference's loader delivers them or gt_raydrop / gt_intensity / gt_depth [1,N]; rays_o, rays_d [1,N,3] with gt_rgb
+        (or images) [1,N,3]; time [1,1].  Returns (total, parts)."""
         m, out = self.model, {}
-        total = 0.0
         if "rays_o_lidar" in batch:
+            if "images_lidar" in batch:
+                gt_rd, gt_i, gt_d = (batch["images_lidar"][:, :, k] for k in range(3))
+            else:
+                gt_rd, gt_i, gt_d = batch["gt_raydrop"], batch["gt_intensity"], batch["gt_depth"]
+            gt_int, gt_depth = gt_i * gt_rd, gt_d * gt_rd  # trainer.py:187-189
             r = m.render(batch["rays_o_lidar"], batch["rays_d_lidar"], batch["time"], cal_lidar_color=True, perturb=True,
                          num_steps=self.num_steps)
-            gt_rd = batch["gt_raydrop"]
             pred_rd = r["image_lidar"][:, :, 0]
             pred_int = r["image_lidar"][:, :, 1] * gt_rd
             pred_depth = r["depth_lidar"] * gt_rd
-            out["depth"] = self.alpha_d * F.l1_loss(pred_depth, batch["gt_depth"])
-            out["raydrop"] = self.alpha_r * F.mse_loss(pred_rd, gt_rd.clamp(self.smooth, 1 - self.smooth))
-            out["intensity"] = self.alpha_i * F.mse_loss(pred_int, batch["gt_intensity"])
+            out["depth"] = (self.alpha_d * (pred_depth - gt_depth).abs()).sum()
+            out["raydrop"] = (self.alpha_r * (pred_rd - gt_rd.clamp(self.smooth, 1 - self.smooth)) ** 2).sum()
+            out["intensity"] = (self.alpha_i * (pred_int - gt_int) ** 2).sum()
+            if self.use_chamfer:
+                d = batch["rays_d_lidar"]
+                d1, d2, _, _ = self._chamfer(d * pred_depth.unsqueeze(-1) / self.scale, d * gt_depth.unsqueeze(-1) / self.scale)
+                out["chamfer"] = (d1 + d2).mean() * 0.5
+            if self.use_flow:
+                fl = self.flow_loss(batch["time"])
+                if fl is not None:
+                    out["flow"] = fl
             if self.use_urf:
                 eps = 0.02 * 0.1 ** min(self.global_step / self.iters, 1)
-                out["los"] = urf_line_of_sight_loss(r["weights"], r["z_vals"], batch["gt_depth"], eps)
+                out["los"] = urf_line_of_sight_loss(r["weights"], r["z_vals"], gt_depth, eps)
         if "rays_o" in batch:
+            gt_rgb = batch["gt_rgb"] if "gt_rgb" in batch else batch["images"][..., :3]
             r = m.render(batch["rays_o"], batch["rays_d"], batch["time"], perturb=True, num_steps=self.num_steps, bg_color=1)
-            out["rgb"] = self.alpha_rgb * F.mse_loss(r["image"], batch["gt_rgb"])
-        for v in out.values():
-            total = total + v
+            out["rgb"] = (self.alpha_rgb * (r["image"] - gt_rgb) ** 2).sum()
+        total = sum(out.values())
+        total = torch.nan_to_num(total, nan=0.0, posinf=1e5, neginf=1e5)  # trainer.py:545-546 (|inf| -> 1e5)
         return total, out
 
     def step(self, batch):
@@ -104,14 +156,21 @@ class RenderTrainStep:
         self.global_step += 1
         return loss.detach(), {k: v.detach() for k, v in parts.items()}, n_coll
 
+    def end_epoch(self):
+        """What the reference does after the step loop of an epoch (trainer.py:1420-1421): one EMA update."""
+        if self.ema is not None:
+            self.ema.update()
+
     def checkpoint_state(self, epoch=0, stats=None, full=True):
         """The dict Trainer.save_checkpoint writes with torch.save (nvsf/nerf/utils.py:622-648): epoch, global_step, stats,
-        model and -- for a `full` checkpoint -- optimizer, lr_scheduler, scaler (no EMA here)."""
+        model and -- for a `full` checkpoint -- optimizer, lr_scheduler, scaler, ema."""
         state = {"epoch": epoch, "global_step": self.global_step, "stats": stats if stats is not None else {}}
         if full:
             state["optimizer"] = self.opt.state_dict()
             state["lr_scheduler"] = self.sched.state_dict()
             state["scaler"] = self.scaler.state_dict()
+            if self.ema is not None:
+                state["ema"] = self.ema.state_dict()
         state["model"] = self.model.state_dict()
         return state
 
@@ -121,8 +180,9 @@ class RenderTrainStep:
     def load_checkpoint(self, checkpoint, model_only=False):
         """Trainer.load_checkpoint (nvsf/nerf/utils.py:682-747): a bare state_dict loads strictly; a checkpoint dict loads its
         model with strict=False (the reference's files carry three unused sub-modules), then global_step / optimizer /
-        lr_scheduler / scaler where present.  checkpoint: path or the loaded dict.  Returns (missing_keys, unexpected_keys,
-        epoch)."""
+        lr_scheduler / scaler / ema where present.  checkpoint: path or the loaded dict.  Returns (missing_keys, unexpected_keys,
+        epoch); `self.failed_to_load` lists the components whose state could not be restored (each also raises a warning, as
+        the reference logs "[WARN] Failed to load ..." and trains on, utils.py:728-747)."""
         if not isinstance(checkpoint, dict):
             checkpoint = torch.load(checkpoint, map_location=next(self.model.parameters()).device)
         if "model" not in checkpoint:
@@ -133,13 +193,15 @@ class RenderTrainStep:
             return list(missing), list(unexpected), checkpoint.get("epoch")
         if "global_step" in checkpoint:
             self.global_step = checkpoint["global_step"]
-        # the reference swallows a failure to restore these three (optimiser groups of another model layout) and trains on
-        for key, obj in (("optimizer", self.opt), ("lr_scheduler", self.sched), ("scaler", self.scaler)):
-            if key in checkpoint:
+        self.failed_to_load = []
+        for key, obj in (("optimizer", self.opt), ("lr_scheduler", self.sched), ("scaler", self.scaler), ("ema", self.ema)):
+            if key in checkpoint and obj is not None:
                 try:
                     obj.load_state_dict(checkpoint[key])
-                except Exception:  # noqa: BLE001 -- reference behaviour: warn and continue
-                    pass
+                except Exception as e:  # noqa: BLE001 -- reference behaviour: warn and continue
+                    self.failed_to_load.append(key)
+                    warnings.warn(f"[WARN] Failed to load {key} state from the checkpoint ({type(e).__name__}: {e}); "
+                                  f"continuing with a fresh {key}")
         return list(missing), list(unexpected), checkpoint.get("epoch")
 
 

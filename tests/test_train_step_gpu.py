@@ -36,7 +36,7 @@ def test_training_reduces_loss_and_metrics(dev):
             enc.params.copy_(torch.randn(enc.params.shape, generator=g) * 0.2)
     teacher = teacher.to(dev).eval()
     student = NeRFNetworkStatic(**kw).to(dev)
-    step = RenderTrainStep(student, lr=1e-2, iters=400, num_steps=48, use_urf_loss=True)
+    step = RenderTrainStep(student, lr=1e-2, iters=400, num_steps=48, use_urf_loss=True, scale=S.SCALE)
     batch = _batch(S, teacher, dev)
     losses = []
     for _ in range(120):
@@ -45,7 +45,7 @@ def test_training_reduces_loss_and_metrics(dev):
         assert n_coll == 0  # single process: no collective
     first, last = float(np.mean(losses[:5])), float(np.mean(losses[-5:]))
     assert np.isfinite(losses).all() and last < 0.8 * first, (first, last)
-    assert set(parts) == {"depth", "raydrop", "intensity", "los", "rgb"}
+    assert set(parts) == {"depth", "raydrop", "intensity", "chamfer", "los", "rgb"}
     student.eval()
     with torch.no_grad():
         rc = student.render(batch["rays_o"], batch["rays_d"], batch["time"], num_steps=48)
@@ -140,7 +140,8 @@ def test_fused_adam_matches_torch_adam(dev):
         sa.update(); sb.update()
         assert sa.get_scale() == sb.get_scale()
     close()
-    assert sa.get_scale() == 512.0 and float(oa._dev_state[0]) == 10.0  # 11 calls, one skipped
+    assert sa.get_scale() == 512.0 and float(oa._rows[oa._row_of[a[0]], 0]) == 10.0  # 11 calls, one skipped
+    assert len(set(oa._row_of.values())) == 1  # every parameter updated in the same steps: one counter row
     # state dicts: same layout, loadable both ways
     da, db = oa.state_dict(), ob.state_dict()
     assert set(da["state"][0]) == set(db["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(da["state"][0]["step"]) == 10.0
@@ -149,6 +150,139 @@ def test_fused_adam_matches_torch_adam(dev):
     grads(99)
     oa.step(); ob.step()
     close()
+
+
+def test_fused_adam_keeps_a_step_count_per_parameter(dev):
+    """torch.optim.Adam advances `step` only for parameters that received a gradient (LiDAR-only / camera-only
+    steps leave the other modality's tables alone); FusedAdam must apply the same bias corrections and round-trip the steps."""
+    from nvsf.nerf.adam import FusedAdam
+    torch.manual_seed(1)
+    mk = lambda: [torch.nn.Parameter(torch.randn(n, device=dev) * 0.1) for n in (4099, 257, 64)]
+    a = mk()
+    torch.manual_seed(1)
+    b = mk()
+    oa, ob = FusedAdam(a, lr=1e-2, betas=(0.9, 0.99), eps=1e-15), torch.optim.Adam(b, lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    pattern = [(1, 1, 1), (1, 0, 1), (1, 0, 1), (0, 1, 1), (1, 1, 0), (1, 1, 1), (0, 0, 1)]  # which parameters get a gradient
+    for s, act in enumerate(pattern):
+        g = torch.Generator(device=dev).manual_seed(100 + s)
+        for pa, pb, on in zip(a, b, act):
+            gr = torch.randn(pa.shape, device=dev, generator=g) * 1e-3
+            pa.grad, pb.grad = (gr.clone(), gr.clone()) if on else (None, None)
+        oa.step(); ob.step()
+    for pa, pb in zip(a, b):
+        assert torch.allclose(pa, pb, rtol=2e-6, atol=2e-7), float((pa - pb).abs().max())
+    da, db = oa.state_dict(), ob.state_dict()
+    assert [float(da["state"][i]["step"]) for i in range(3)] == [float(db["state"][i]["step"]) for i in range(3)] == [5.0, 4.0, 6.0]
+    # lossless round trip, and torch's state loads with its three different steps
+    oa2 = FusedAdam(a, lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    oa2.load_state_dict(db)
+    assert [float(oa2.state_dict()["state"][i]["step"]) for i in range(3)] == [5.0, 4.0, 6.0]
+    for pa, pb in zip(a, b):
+        pa.grad = torch.full_like(pa, 1e-3)
+        pb.grad = torch.full_like(pb, 1e-3)
+    oa2.step(); ob.step()
+    for pa, pb in zip(a, b):
+        assert torch.allclose(pa, pb, rtol=2e-6, atol=2e-7)
+
+
+def test_ema_matches_torch_ema_rule_and_rides_in_the_adam_pass(dev):
+    """nvsf.nerf.ema.ExponentialMovingAverage: update rule of torch_ema as the reference's Trainer uses it (trainer.py:112-114,
+    1420-1421: decay 0.95 with the (1 + n) / (10 + n) warm-up), store / copy_to / restore, state_dict; and the every-step form
+    folded into nvsf_adam_update."""
+    from nvsf.nerf.adam import FusedAdam
+    from nvsf.nerf.ema import ExponentialMovingAverage
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(n, device=dev)) for n in (100003, 64)]
+    ema = ExponentialMovingAverage(ps, decay=0.95)
+    ref = [p.detach().clone().double() for p in ps]
+    for n in range(1, 15):
+        with torch.no_grad():
+            for p in ps:
+                p.add_(torch.randn_like(p) * 0.1)
+        ema.update()
+        d = min(0.95, (1 + n) / (10 + n))
+        ref = [r - (1 - d) * (r - p.detach().double()) for r, p in zip(ref, ps)]
+    assert ema.num_updates == 14
+    for s, r in zip(ema.shadow_params, ref):
+        assert torch.allclose(s.double(), r, rtol=0, atol=2e-6)
+    cur = [p.detach().clone() for p in ps]
+    ema.store(); ema.copy_to()
+    assert all(torch.equal(p.detach(), s) for p, s in zip(ps, ema.shadow_params))
+    ema.restore()
+    assert all(torch.equal(p.detach(), c) for p, c in zip(ps, cur))
+    sd = ema.state_dict()
+    assert set(sd) == {"decay", "num_updates", "shadow_params", "collected_params"} and sd["decay"] == 0.95
+    # every-step form: shadow after the fused pass == separate update applied to the stepped parameter
+    opt = FusedAdam(ps, lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    ema2 = ExponentialMovingAverage(ps, decay=0.9).attach(opt)
+    before = [s.clone() for s in ema2.shadow_params]
+    for p in ps:
+        p.grad = torch.randn_like(p)
+    ema2.before_step()
+    opt.step()
+    d = min(0.9, 2 / 11)
+    for s, b0, p in zip(ema2.shadow_params, before, ps):
+        assert torch.allclose(s, b0 - (b0 - p.detach()) * (1 - d), rtol=1e-6, atol=1e-7)
+
+
+def test_losses_follow_the_reference_reductions(dev):
+    """RenderTrainStep.losses against a plain-torch restatement of trainer.py:186-233, 491-503, 540-546: ground truth and
+    predictions masked by the ray-drop channel, per-ray terms SUMMED (criteria are reduction="none", main_nvsf.py:205-221),
+    chamfer term (d1 + d2).mean() / 2 on rays_d * depth / scale, smooth_factor default 0."""
+    from nvsf.nerf.train_step import RenderTrainStep
+    N = 700
+    g = torch.Generator().manual_seed(5)
+    rnd = lambda *s: torch.rand(*s, generator=g).to(dev)
+    fake = {"image_lidar": rnd(1, N, 2), "depth_lidar": rnd(1, N) * 0.8, "image": rnd(1, N, 3)}
+
+    class Model(torch.nn.Module):
+        num_frames = 8
+
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(torch.ones(1, device=dev))
+
+        def get_params(self, lr):
+            return [{"params": [self.w], "lr": lr}]
+
+        def render(self, o, d, t, cal_lidar_color=False, **kw):
+            keys = ("image_lidar", "depth_lidar") if cal_lidar_color else ("image",)
+            return {k: fake[k] * self.w for k in keys}
+
+    d = torch.nn.functional.normalize(torch.randn(1, N, 3, generator=g), dim=-1).to(dev)
+    images_lidar = torch.stack([(rnd(1, N) > 0.3).float(), rnd(1, N), rnd(1, N) * 0.8], -1)
+    batch = {"rays_o_lidar": torch.zeros(1, N, 3, device=dev), "rays_d_lidar": d, "images_lidar": images_lidar, "rays_o": torch.zeros(1, N, 3, device=dev),
+             "rays_d": d, "gt_rgb": rnd(1, N, 3), "time": torch.tensor([[0.5]], device=dev)}
+    scale = 0.0108
+    step = RenderTrainStep(Model(), scale=scale, ema_decay=None)
+    assert step.smooth == 0.0
+    total, parts = step.losses(batch)
+    rd, it, dp = images_lidar[..., 0], images_lidar[..., 1] * images_lidar[..., 0], images_lidar[..., 2] * images_lidar[..., 0]
+    pd = fake["depth_lidar"] * rd
+    exp = {"depth": (pd - dp).abs().sum(), "raydrop": 0.01 * ((fake["image_lidar"][..., 0] - rd) ** 2).sum(),
+           "intensity": 0.1 * ((fake["image_lidar"][..., 1] * rd - it) ** 2).sum(), "rgb": ((fake["image"] - batch["gt_rgb"]) ** 2).sum()}
+    a, b = (d * pd[..., None] / scale)[0].double(), (d * dp[..., None] / scale)[0].double()
+    dist = torch.cdist(a, b) ** 2
+    exp["chamfer"] = (dist.min(1).values + dist.min(0).values).mean() * 0.5
+    assert set(parts) == set(exp)
+    for k in exp:
+        assert abs(float(parts[k]) - float(exp[k])) <= 2e-5 * max(1.0, abs(float(exp[k]))), (k, float(parts[k]), float(exp[k]))
+    assert abs(float(total) - sum(float(v) for v in exp.values())) <= 1e-4 * float(total)
+    total.backward()  # the chamfer term back-propagates into the prediction
+    assert torch.isfinite(step.model.w.grad).all() and float(step.model.w.grad.abs()) > 0
+    # scene-flow loss (trainer.py:236-267)
+    pcs = {3: rnd(300, 3), 4: rnd(280, 3), 2: rnd(310, 3)}
+
+    class FlowModel(Model):
+        def flow(self, x, t):
+            return {"flow_forward": 0.01 * self.w * torch.ones_like(x), "flow_backward": -0.02 * self.w * torch.ones_like(x)}
+    fs = RenderTrainStep(FlowModel(), scale=scale, ema_decay=None, flow_loss=True, pc_list=pcs)
+    fl = fs.flow_loss(torch.tensor([[3.4 / 7]], device=dev))  # int(t * (F - 1)) = 3
+    want = 0.0
+    for off, tgt in ((0.01, pcs[4]), (-0.02, pcs[2])):
+        dist = torch.cdist((pcs[3] + off).double(), tgt.double()) ** 2
+        want += float((dist.min(1).values.sum() + dist.min(0).values.sum()) * 0.5) + abs(off)
+    assert abs(float(fl) - want) <= 1e-5 * want
 
 
 def test_fused_adam_invalidates_fp16_weight_caches(dev):
