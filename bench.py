@@ -183,12 +183,19 @@ def pmc_traffic(kernel_label):
     (profiles/*_pmc_traffic.json, produced by tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of
     this same command; counters cannot be collected from inside the timed process).  gfx950 correction: FETCH_SIZE
     counts 64 B per 128-B request, i.e. half the bytes (verified on k_weights_fwd: 12.4 MB reported for 25.2 MB of
-    coalesced reads), so bytes = 2 * FETCH_SIZE + WRITE_SIZE."""
+    coalesced reads), so bytes = 2 * FETCH_SIZE + WRITE_SIZE.  The profile records the digest of the kernel sources it was
+    taken on (build.csrc_digest); a profile of other sources is reported as stale, not used."""
     import glob
+    import build as nvsf_build
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
     if not files:
         return {"traffic": None}
-    ks = json.load(open(files[-1]))["kernels"]
+    prof = json.load(open(files[-1]))
+    if prof.get("csrc_digest") != nvsf_build.csrc_digest():
+        # counters of another build of the kernels say nothing about this one: no figure rather than a stale one
+        return {"traffic": None, "traffic_stale": f"{os.path.relpath(files[-1], ROOT)} was taken on kernel sources {prof.get('csrc_digest', '(unrecorded)')}, "
+                                                  f"this build is {nvsf_build.csrc_digest()}"}
+    ks = prof["kernels"]
     which = "camera" if "camera" in kernel_label else "lidar"
     src = os.path.relpath(files[-1], ROOT) + " (2*FETCH_SIZE + WRITE_SIZE, bytes per launch)"
     base = kernel_label.split("[")[0]
@@ -204,22 +211,24 @@ def pmc_traffic(kernel_label):
     return {"traffic": None}
 
 
-def cpu_baseline(model, T, n_rays, seed=1234, threads=1):
-    """Times the scalar CPU oracle on `n_rays` LiDAR + `n_rays` camera rays of the same workload.  threads > 1: the rays of
-    each batch are split into `threads` contiguous chunks rendered by a thread pool (rays are independent; the C oracle is
-    called through ctypes, which releases the GIL; the numpy glue between the calls holds it)."""
+def cpu_baseline(model, T, rays, n_rays, threads=1):
+    """Times the scalar CPU oracle (an unvectorised C restatement, oracle/*.c) on the first `n_rays` LiDAR and the first `n_rays`
+    camera rays of the timed batches (`rays` = {True: (o, d), False: (o, d)} numpy).  threads > 1: the rays of each batch are
+    split into `threads` contiguous chunks rendered by a thread pool (rays are independent; the C oracle is called through
+    ctypes, which releases the GIL; the numpy glue between the calls holds it).  Returns (figures, oracle outputs per modality):
+    the outputs are what `outputs_match_oracle` compares the GPU's render of the same rays with."""
     import oracle_lib as O
     from concurrent.futures import ThreadPoolExecutor
     from nvsf import synthetic as S
-    rng = np.random.default_rng(seed)
     f16 = lambda net: net.params.detach().cpu().numpy().astype(np.float16)
     lin = torch.linspace(0.0, 1.0, T).numpy()
     aabb = np.array([-S.BOUND] * 3 + [S.BOUND] * 3, np.float32)
     threads = max(1, min(int(threads), n_rays))
     pool = ThreadPoolExecutor(threads) if threads > 1 else None
+    outputs = {}
     t0 = time.perf_counter()
     for lidar in (True, False):
-        o, d = (S.lidar_rays if lidar else S.camera_rays)(n_rays, rng)
+        o, d = (a[:n_rays] for a in rays[lidar])
         enc = model.hash_encoder_lidar if lidar else model.hash_encoder_camera
         table = enc.params.detach().cpu().numpy().astype(np.float16)
         if lidar:
@@ -232,20 +241,35 @@ def cpu_baseline(model, T, n_rays, seed=1234, threads=1):
 
         def chunk(lo_hi):
             a, b = lo_hi
-            return O.render_static(o[a:b], d[a:b], nears[a:b], fars[a:b], lin, None, float(S.BOUND), table, enc.spec, w_sigma, lidar,
-                                   w_a, w_b, np.ones(3, np.float32), k_scale=model._k_scale())
+            r = O.render_static(o[a:b], d[a:b], nears[a:b], fars[a:b], lin, None, float(S.BOUND), table, enc.spec, w_sigma, lidar,
+                                w_a, w_b, np.ones(3, np.float32), k_scale=model._k_scale())
+            return r["image"], r["depth"], r["weights_sum"]
         edges = np.linspace(0, n_rays, threads + 1).astype(int)
         spans = [(int(a), int(b)) for a, b in zip(edges[:-1], edges[1:]) if b > a]
-        if pool is None:
-            chunk(spans[0])
-        else:
-            list(pool.map(chunk, spans))
+        parts = [chunk(spans[0])] if pool is None else list(pool.map(chunk, spans))
+        outputs[lidar] = tuple(np.concatenate([p[i] for p in parts], 0) for i in range(3))
     dt = time.perf_counter() - t0
     if pool is not None:
         pool.shutdown()
-    return {"value": 2 * n_rays / dt, "unit": "rays/s", "cores": threads, "kind": "port",
-            "sample": f"{n_rays} LiDAR + {n_rays} camera rays x {T} samples, same field, scalar C oracle (oracle/*.c) + numpy glue, "
-                      f"{threads} thread(s), {dt:.1f} s wall"}
+    return ({"value": 2 * n_rays / dt, "unit": "rays/s", "cores": threads, "kind": "port",
+             "sample": f"the first {n_rays} LiDAR + {n_rays} camera rays of the timed batches x {T} samples, same field; scalar (unvectorised) C "
+                       f"restatement of the path (oracle/*.c) + numpy glue, {threads} thread(s), {dt:.1f} s wall"}, outputs)
+
+
+def outputs_match_oracle(out, oracle_outputs, tol=1e-4):
+    """The render the timed loop produced (its last step) against the CPU oracle on the same rays: max |error| of the composited
+    image / depth / weights_sum per modality (north_star: 1e-4 abs)."""
+    res = {"tolerance": tol, "ok": True}
+    for lidar, (img, dep, ws) in oracle_outputs.items():
+        sfx = "_lidar" if lidar else ""
+        n = img.shape[0]
+        errs = {"image" + sfx: float(np.abs(out[0 if lidar else 1]["image" + sfx][0, :n].cpu().numpy() - img).max()),
+                "depth" + sfx: float(np.abs(out[0 if lidar else 1]["depth" + sfx][0, :n].cpu().numpy() - dep).max()),
+                "weights_sum" + sfx: float(np.abs(out[0 if lidar else 1]["weights_sum" + sfx][:n].cpu().numpy() - ws).max())}
+        res.update({"max_abs_err_" + k: v for k, v in errs.items()})
+        res["checked_rays" + sfx] = n
+        res["ok"] = bool(res["ok"] and all(np.isfinite(v) and v <= tol for v in errs.values()))
+    return res
 
 
 def train_leg(model, tl, tc, tm, T, steps, dev, dist):
@@ -570,13 +594,17 @@ def main():
             line["roofline"].update(pmc_traffic(pick["kernel"]))
             line["kernel_ms_sum"] = sum(r["ms"] for r in rows)
         if args.cpu_rays > 0 and world == 1:
-            base = cpu_baseline(model, T, args.cpu_rays)  # one core: the scalar port as it is
+            rays = {True: (lo, ld), False: (co, cd)}
+            n1 = min(args.cpu_rays, args.num_rays, args.num_rays_lidar)
+            base, ref_out = cpu_baseline(model, T, rays, n1)  # one core: the scalar port as it is
             threads = min(args.cpu_threads if args.cpu_threads > 0 else (os.cpu_count() or 1), 16)  # a 1-GPU box's CPU share
             if threads > 1:  # and on the host's cores: the same port, rays split over a thread pool
-                multi = cpu_baseline(model, T, args.cpu_rays * min(threads, 8), threads=threads)
+                multi, ref_out = cpu_baseline(model, T, rays, min(args.cpu_rays * min(threads, 8), args.num_rays, args.num_rays_lidar), threads=threads)
                 base, single = multi, base
                 base["one_core"] = {"value": single["value"], "sample": single["sample"]}
             line["cpu_baseline"] = base
+            # the cpu_baseline leg's renders double as the checker of the timed outputs (the oracle is never on the timed path)
+            line["outputs_match_oracle"] = outputs_match_oracle(out, ref_out)
         if not args.no_extra_legs and world == 1:  # secondary figures for BASELINE configs 3 and 5 (never `value`)
             line["occupancy"] = occupancy_leg(NeRFNetworkStatic, dev, args.num_rays, 10)
             line["dynamic"] = dynamic_leg(dev, args.num_rays, T, 3)

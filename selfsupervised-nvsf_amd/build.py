@@ -26,6 +26,18 @@ FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fvisibility=hidden", "-fPIC
          "-Wno-unused-function", "-mllvm", "-amdgpu-mfma-vgpr-form", f"--offload-arch={ARCH}"]
 
 
+def csrc_digest():
+    """sha1 over the kernel sources (csrc/*.hip, *.h) and the compile flags: identifies the build that a profile was taken on
+    (bench.py reports PMC traffic only for profiles whose digest matches the running sources)."""
+    import hashlib
+    h = hashlib.sha1(" ".join(FLAGS).encode())
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 

@@ -164,3 +164,42 @@ def test_density_grid_maintenance(dev, setup):
     mm.iter_density = 16
     mm.update_extra_state(t, cal_lidar_color=True)  # partial update path
     assert mm.iter_density == 17 and torch.isfinite(mm.density_grid).all()
+
+
+@pytest.mark.parametrize("lidar", [True, False])
+def test_config3_full_size_matches_oracle(dev, lidar):
+    """BASELINE config 3 as stated: the config-2 field (L16 F2, log2_hashmap_size 19), occupancy grid, at most 1024 samples per
+    ray, early termination at T < 1e-4 -- the whole 4096-ray batch through the one-launch kernel, 48 of its rays against the
+    oracle's survivor loop (march_rays -> field -> composite_rays)."""
+    from nvsf import synthetic as S
+    from nvsf.nerf.models.network_static import NeRFNetworkStatic
+    torch.manual_seed(0)
+    m = NeRFNetworkStatic(bound=S.BOUND, min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH)
+    assert m.hash_encoder_lidar.spec.log2_hashmap_size == 19 and m.hash_encoder_lidar.spec.L == 16
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        for enc in (m.hash_encoder_lidar, m.hash_encoder_camera):
+            enc.params.copy_(torch.randn(enc.params.shape, generator=g) * 0.1)
+        m.sigma_net.params.mul_(2.0)
+    m = m.to(dev).enable_occupancy_grid().to(dev).eval()
+    rng = np.random.default_rng(0)
+    grid = S.boxes_density_grid(rng, cascades=m.cascade, H=m.grid_size, n_boxes=64)
+    m.set_density_grid(_t(grid, dev), thresh=0.5)
+    bits = O.packbits(grid, 0.5)
+    N, K, max_steps = 4096, 48, 1024
+    o, d = (S.lidar_rays if lidar else S.camera_rays)(N, rng)
+    with torch.no_grad():
+        out = m.render(_t(o, dev)[None], _t(d, dev)[None], torch.tensor([[0.5]], device=dev), cal_lidar_color=lidar, max_steps=max_steps,
+                       T_thresh=1e-4, fused=True)
+    pick = np.sort(rng.choice(N, K, replace=False))
+    nears, fars = _near_far(m, S, o[pick], d[pick], lidar)
+    ref = O.render_occupancy_infer(o[pick], d[pick], nears, fars, bits, float(S.BOUND), m.cascade, m.grid_size, max_steps, 0.0, _field(m, lidar),
+                                   lidar, T_thresh=1e-4)
+    sfx = "_lidar" if lidar else ""
+    assert float(ref["weights_sum"].max()) > 0.05
+    close = lambda a, b: np.abs(a - b) <= 1e-4
+    ws_ok = close(out["weights_sum" + sfx].cpu().numpy()[pick], ref["weights_sum"])
+    # a ray whose transmittance lands within float noise of T_thresh may take one more sample on one side only
+    assert ws_ok.mean() >= 0.97, ws_ok.mean()
+    assert (close(out["depth" + sfx][0].cpu().numpy()[pick], ref["depth"]) | ~ws_ok).all()
+    assert (close(out["image" + sfx][0].cpu().numpy()[pick], ref["image"]).all(-1) | ~ws_ok).all()

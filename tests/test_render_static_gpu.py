@@ -135,3 +135,30 @@ def test_perturb_and_staged_and_bg(dev):
         ref_p = _oracle(m, o, d, False, T, noise=noise.cpu().numpy())
         assert np.array_equal(p["z_vals"].cpu().numpy(), ref_p["z_vals"])
         np.testing.assert_allclose(p["image"][0].cpu().numpy(), ref_p["image"], atol=1e-4, rtol=0)
+
+
+@pytest.mark.parametrize("lidar", [True, False])
+def test_headline_shape_matches_oracle(dev, lidar):
+    """BASELINE config 2 at its full size -- 4096 rays x 768 samples per modality, L16 F2 T2^19 tables with a non-trivial
+    density field -- through the path `model.render` selects by itself at that size (N * T >= 2^18: the XCD-sliced encode pass
+    + tail for the camera batch, the one-launch gather kernel for the LiDAR batch; exactly what bench.py times).  The oracle
+    renders 64 of the 4096 rays (rays are independent); 1e-4 abs on depth / image, z_vals bit-exact."""
+    from nvsf import field_ops as ops, synthetic as S
+    m = _model(dev, 0.1)
+    rng = np.random.default_rng(21)
+    N, T, K = 4096, 768, 64
+    o, d = (S.lidar_rays if lidar else S.camera_rays)(N, rng)
+    enc = m.hash_encoder_lidar if lidar else m.hash_encoder_camera
+    ray_length = float(m.lidar_max_depth - m.min_near_lidar) if lidar else 2.0 * float(m.bound)
+    assert ops.prefer_sliced(enc.spec, N, T, ray_length, float(m.bound)) == (not lidar)  # the bench's path choice
+    with torch.no_grad():
+        out = m.render(_t(o, dev)[None], _t(d, dev)[None], torch.tensor([[0.5]], device=dev), cal_lidar_color=lidar, num_steps=T)
+    pick = np.sort(rng.choice(N, K, replace=False))
+    ref = _oracle(m, o[pick], d[pick], lidar, T)
+    sfx = "_lidar" if lidar else ""
+    assert np.array_equal(out["z_vals"].cpu().numpy()[pick], ref["z_vals"])
+    assert float(ref["weights_sum"].max()) > 0.5 and float(ref["weights_sum"].min()) < 0.999  # a non-trivial field
+    np.testing.assert_allclose(out["weights"].cpu().numpy()[pick], ref["weights"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(out["weights_sum" + sfx].cpu().numpy()[pick], ref["weights_sum"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(out["depth" + sfx][0].cpu().numpy()[pick], ref["depth"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(out["image" + sfx][0].cpu().numpy()[pick], ref["image"], atol=1e-4, rtol=0)

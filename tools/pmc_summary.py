@@ -6,7 +6,10 @@ launched with alternating workloads (LiDAR, camera).
 
 Kernels named after --alternating (default: k_weights_fwd) are launched once per batch kind in LiDAR, camera order;
 the others are launched for one batch kind only in bench.py's step (fused density: LiDAR; sliced density: camera)."""
-import csv, json, sys, collections
+import csv, json, os, sys, collections
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "selfsupervised-nvsf_amd"))
+import build as nvsf_build
 
 
 def load(path, counter):
@@ -40,7 +43,7 @@ if "--alternating" in args:
     args = args[:i]
 fetch, write, out_path = args
 f, w = load(fetch, "FETCH_SIZE"), load(write, "WRITE_SIZE")
-out = {"units": "KB per launch (rocprofv3 FETCH_SIZE / WRITE_SIZE; gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x, 4-byte gathers uncalibrated)", "kernels": {}}
+out = {"csrc_digest": nvsf_build.csrc_digest(), "units": "KB per launch (rocprofv3 FETCH_SIZE / WRITE_SIZE; gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x, 4-byte gathers uncalibrated)", "kernels": {}}
 for name in f:
     s = short(name)
     if not s:
