@@ -44,4 +44,4 @@ def test_frameset_collate_and_train_step(tmp_path):
     m = NeRFNetworkStatic(bound=2.0, min_near=0.01, min_near_lidar=0.01, lidar_max_depth=0.9).to(dev)
     step = RenderTrainStep(m, num_steps=32)
     loss, parts, _ = step.step(fs.train_batch([2]))
-    assert torch.isfinite(loss) and set(parts) == {"depth", "raydrop", "intensity", "rgb"}
+    assert torch.isfinite(loss) and set(parts) == {"depth", "raydrop", "intensity", "chamfer", "rgb"}
