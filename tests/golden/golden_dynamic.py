@@ -130,4 +130,96 @@ def gen_network(mods, out_dir):
     print("network_dynamic.npz", len(out), "arrays")
 
 
-GENERATORS = {"planes": gen_planes, "hash4d": gen_hash4d, "network": gen_network}
+GRAD_CASES = (("first", 0.0), ("mid", 0.5), ("last", 1.0))
+GRAD_N, GRAD_T = 32, 24
+BIG = 1 << 20       # tensors above this size (the flow field's 30 M-entry grid) are stored as a signature, see grad_signature
+N_BUCKETS = 4093
+
+
+def reference_losses(out, gt, lidar, alpha_d=1.0, alpha_r=0.01, alpha_i=0.1, alpha_rgb=1.0, smooth=0.0):
+    """The loss terms of Trainer.train_step that reach the renderer, restated for the fixture generator AND the GPU test
+    (trainer.py:186-219: masked L1 range + MSE ray-drop + MSE intensity, criteria with reduction="none" summed at :540-543;
+    :491-503: MSE RGB).  `gt`: images_lidar [1,N,3] = (raydrop, intensity, range) or the RGB targets [1,N,3]."""
+    if lidar:
+        gt_rd = gt[:, :, 0]
+        gt_int, gt_depth = gt[:, :, 1] * gt_rd, gt[:, :, 2] * gt_rd
+        pred_rd = out["image_lidar"][:, :, 0]
+        pred_int = out["image_lidar"][:, :, 1] * gt_rd
+        pred_depth = out["depth_lidar"] * gt_rd
+        loss = alpha_d * (pred_depth - gt_depth).abs() + alpha_r * (pred_rd - gt_rd.clamp(smooth, 1 - smooth)) ** 2 \
+            + alpha_i * (pred_int - gt_int) ** 2
+        return loss.sum()
+    return (alpha_rgb * (out["image"] - gt) ** 2).sum()
+
+
+def grad_case_inputs(tag, lidar, synth):
+    """Rays, jitter and targets of one gradient case (deterministic; shared by the generator and the GPU test)."""
+    rng = np.random.default_rng(zlib.crc32(f"{tag}/{int(lidar)}".encode()) % 100000)
+    o, d = (synth.lidar_rays if lidar else synth.camera_rays)(GRAD_N, rng)
+    noise = rng.random((GRAD_N, GRAD_T)).astype(np.float32)
+    if lidar:
+        gt = np.stack([(rng.random(GRAD_N) > 0.3).astype(np.float32), rng.random(GRAD_N).astype(np.float32),
+                       (rng.random(GRAD_N) * 0.8).astype(np.float32)], -1)[None]
+    else:
+        gt = rng.random((1, GRAD_N, 3)).astype(np.float32)
+    return o, d, noise, gt
+
+
+def grad_signature(g):
+    """Compact fingerprint of the gradient of a very large table (fp64 sums): 4093 bucket sums (entry index mod 4093), L1 and
+    L2 norm, number of non-zeros, and the 256 largest entries with their indices."""
+    g = np.asarray(g, np.float64).reshape(-1)
+    buckets = np.bincount(np.arange(g.size) % N_BUCKETS, weights=g, minlength=N_BUCKETS)
+    top = np.argsort(-np.abs(g))[:256]
+    return {"buckets": buckets.astype(np.float32), "l1": np.float64(np.abs(g).sum()), "l2": np.float64(np.sqrt((g * g).sum())),
+            "nnz": np.int64(np.count_nonzero(g)), "top_idx": top.astype(np.int64), "top_val": g[top].astype(np.float32)}
+
+
+def gen_network_grads(mods, out_dir):
+    """Parameter gradients of the reference's own NeRFNetwork.render + Trainer losses (network_dynamic.py:213-332 under
+    autograd: which neighbour terms carry gradient is decided by the reference's code, :242-271), LiDAR and camera batch at
+    the first / a middle / the last frame, training mode with jitter (perturb=True: the jitter the reference draws with
+    torch.rand is replayed from the fixture)."""
+    import sys
+    S = sys.modules["make_golden_synth"]
+    nd = mods["network"]
+    net = nd.NeRFNetwork(min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH, **SMALL).train()
+    init_by_name(net)
+    out = {}
+    real_rand = torch.rand
+    for tag, tv in GRAD_CASES:
+        for lidar in (True, False):
+            o, d, noise, gt = grad_case_inputs(tag, lidar, S)
+            for p in net.parameters():
+                p.grad = None
+            torch.rand = lambda *a, **k: torch.from_numpy(noise)  # renderer_dynamic.py:163-164 draws rand(z_vals.shape)
+            try:
+                res = net.render(torch.from_numpy(o)[None], torch.from_numpy(d)[None], torch.tensor([[tv]], dtype=torch.float32),
+                                 cal_lidar_color=lidar, num_steps=GRAD_T, perturb=True, staged=False)
+            finally:
+                torch.rand = real_rand
+            loss = reference_losses(res, torch.from_numpy(gt), lidar)
+            loss.backward()
+            key = f"{tag}_{'lidar' if lidar else 'cam'}"
+            out[f"{key}/loss"] = np.float32(loss.item())
+            sfx = "_lidar" if lidar else ""
+            out[f"{key}/image"], out[f"{key}/depth"] = res["image" + sfx][0].detach().numpy(), res["depth" + sfx][0].detach().numpy()
+            n_with = 0
+            for name, p in net.named_parameters():
+                if p.grad is None or p.numel() == 0:
+                    continue
+                g = p.grad.detach().float().numpy()
+                if not np.any(g):
+                    continue
+                if g.size > BIG:
+                    for sk, sv in grad_signature(g).items():
+                        out[f"{key}/gradsig/{name}/{sk}"] = sv
+                else:
+                    out[f"{key}/grad/{name}"] = g
+                n_with += 1
+            print(key, "loss", float(loss), "tensors with gradient:", n_with)
+    np.savez_compressed(os.path.join(out_dir, "network_dynamic_grads.npz"), **out)
+    print("network_dynamic_grads.npz", len(out), "arrays")
+
+
+GENERATORS = {"planes": gen_planes, "hash4d": gen_hash4d, "network": gen_network, "network_grads": gen_network_grads}
