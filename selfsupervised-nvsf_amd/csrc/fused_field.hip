@@ -1482,6 +1482,220 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FROM_FEA
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Tail of the level-sliced path, two MFMA tiles (32 samples) per iteration.
+//
+// k_render_uniform<*, true> walks a ray one 16-sample tile at a time: a single dependent chain per wave (fragment read ->
+// 4 MFMAs -> pack -> 2 MFMAs -> exp -> scan -> shuffles -> 4 -> pack -> 8 -> pack -> 2 MFMAs -> sigmoid) with four waves per
+// SIMD to cover it, and every MFMA re-reads its 1 KB weight fragment from LDS (20 KB per tile and wave for the camera
+// field: per CU as many LDS cycles as MFMA cycles).  Here a wave takes tiles 2j and 2j+1 of its ray together: every
+// fragment is read ONCE and feeds two MFMAs (half the LDS traffic), and the two tiles are independent chains up to the
+// transmittance carry, which enters only at the scan (tile 2j+1 scans with tile 2j's carry).  Arithmetic per tile is that
+// of k_render_uniform (same scans over 16 lanes, same MFMA chains): bit-identical outputs.
+template <bool LIDAR>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_render_tail2(
+    RayBatch rb, const uint2* __restrict__ feat, const _Float16* __restrict__ w_sigma, const _Float16* __restrict__ w_a,
+    const _Float16* __restrict__ w_b, float k_scale, float w_thresh, float bg0, float bg1, float bg2, int use_bg,
+    const float* __restrict__ z_vals, float* __restrict__ weights, float* __restrict__ weights_sum, float* __restrict__ depth,
+    float* __restrict__ image) {
+    using FR = OccFrags<LIDAR>;
+    constexpr int IN_STEPS = FR::IN_STEPS;
+    constexpr int C = LIDAR ? 2 : 3;
+    __shared__ half8_t s_frag[FR::kCount * kWave];
+    const int lane = lane_id(), g = lane >> 4, c = lane & 15;
+    for (int f = (int)(threadIdx.x >> 6); f < FR::kCount; f += kWavesPerBlock) s_frag[f * kWave + lane] = occ_fragment<LIDAR>(f, lane, w_sigma, w_a, w_b);
+    __syncthreads();
+    const uint32_t n = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    if (n >= rb.N) return;
+    const half8_t* frag = s_frag + lane;
+    const uint32_t T = rb.T;
+    const size_t M = (size_t)rb.N * T;
+
+    const float rd0 = rb.rays_d[3 * (size_t)n], rd1 = rb.rays_d[3 * (size_t)n + 1], rd2 = rb.rays_d[3 * (size_t)n + 2];
+    const float d0 = (rd0 + 1.0f) / 2.0f, d1 = (rd1 + 1.0f) / 2.0f, d2 = (rd2 + 1.0f) / 2.0f;
+    half8_t xf[IN_STEPS];
+    if constexpr (!LIDAR) {
+        float sh[16];
+        sh4_basis(d0, d1, d2, sh);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xf[0][j] = (_Float16)(g == 0 ? sh[j] : sh[8 + j]);
+    } else {
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; j += 2) {
+                const int k = 32 * s + 8 * g + j;
+                float sn = 1.0f, cs = 1.0f;
+                if (k < 72) {
+                    const int i = k / 24, f = (k - 24 * i) >> 1;
+                    freq_pair(i == 0 ? d0 : (i == 1 ? d1 : d2), f, sn, cs);
+                }
+                xf[s][j] = (_Float16)sn;
+                xf[s][j + 1] = (_Float16)cs;
+            }
+    }
+    const bool takes_geo = LIDAR ? (g == 1 || g == 2) : (g >= 2);
+    const int src_a = (c + 16 * (LIDAR ? 2 * (g - 1) : 2 * (g - 2))) & 63, src_b = (src_a + 16) & 63;
+    // one head on both tiles: every fragment read feeds two MFMAs
+    auto head2 = [&](int base, const half8_t (&x_last)[2], float4_t (&out)[2]) {
+        float4_t acc[2][kHidTiles];
+#pragma unroll
+        for (int t = 0; t < kHidTiles; ++t) {
+            float4_t a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < IN_STEPS; ++s) {
+                const half8_t w = frag[(base + t * IN_STEPS + s) * kWave];
+                a0 = mfma16(w, s == IN_STEPS - 1 ? x_last[0] : xf[s], a0);
+                a1 = mfma16(w, s == IN_STEPS - 1 ? x_last[1] : xf[s], a1);
+            }
+            acc[0][t] = a0;
+            acc[1][t] = a1;
+        }
+        half8_t h[2][kHidSteps];
+        pack_hidden(acc[0], h[0]);
+        pack_hidden(acc[1], h[1]);
+#pragma unroll
+        for (int t = 0; t < kHidTiles; ++t) {
+            float4_t a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < kHidSteps; ++s) {
+                const half8_t w = frag[(base + 4 * IN_STEPS + 2 * t + s) * kWave];
+                a0 = mfma16(w, h[0][s], a0);
+                a1 = mfma16(w, h[1][s], a1);
+            }
+            acc[0][t] = a0;
+            acc[1][t] = a1;
+        }
+        pack_hidden(acc[0], h[0]);
+        pack_hidden(acc[1], h[1]);
+        float4_t a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < kHidSteps; ++s) {
+            const half8_t w = frag[(base + 4 * IN_STEPS + 8 + s) * kWave];
+            a0 = mfma16(w, h[0][s], a0);
+            a1 = mfma16(w, h[1][s], a1);
+        }
+        out[0] = a0;
+        out[1] = a1;
+    };
+
+    const float sample_dist = (rb.fars[n] - rb.nears[n]) / (float)T;
+    const size_t row0 = (size_t)n * T;
+    const uint2* plane0 = feat + (size_t)(2 * g) * M + row0;
+    const uint2* plane1 = feat + (size_t)(2 * g + 1) * M + row0;
+    const float* zrow = z_vals + row0;
+    float carry = 1.0f, ws = 0.0f, dp = 0.0f, img[C];
+#pragma unroll
+    for (int k = 0; k < C; ++k) img[k] = 0.0f;
+    typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
+    for (uint32_t i0 = 0; i0 < T; i0 += 32) {
+        bool valid[2];
+        uint32_t idx[2];
+        float z[2], z_next[2];
+        half8_t feat8[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t i = i0 + 16u * u + (uint32_t)c;
+            valid[u] = i < T;
+            idx[u] = valid[u] ? i : T - 1u;
+            z[u] = zrow[idx[u]];
+            z_next[u] = idx[u] + 1u < T ? zrow[idx[u] + 1u] : z[u];
+            const uint2 p0 = plane0[idx[u]], p1 = plane1[idx[u]];
+            const u4_t packed = {p0.x, p1.x, p1.y, p0.y};
+            feat8[u] = __builtin_bit_cast(half8_t, packed);
+        }
+        // ---- sigma MLP on both tiles
+        float4_t o[2];
+        {
+            float4_t acc[2][kHidTiles];
+#pragma unroll
+            for (int tt = 0; tt < kHidTiles; ++tt) {
+                const half8_t w = frag[(FR::kSigma + tt) * kWave];
+                acc[0][tt] = mfma16(w, feat8[0], float4_t{0, 0, 0, 0});
+                acc[1][tt] = mfma16(w, feat8[1], float4_t{0, 0, 0, 0});
+            }
+            half8_t h[2][kHidSteps];
+            pack_hidden(acc[0], h[0]);
+            pack_hidden(acc[1], h[1]);
+            float4_t a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+#pragma unroll
+            for (int sx = 0; sx < kHidSteps; ++sx) {
+                const half8_t w = frag[(FR::kSigma + 4 + sx) * kWave];
+                a0 = mfma16(w, h[0][sx], a0);
+                a1 = mfma16(w, h[1][sx], a1);
+            }
+            o[0] = a0;
+            o[1] = a1;
+        }
+        // ---- alpha compositing, tile by tile in sample order (renderer_dynamic.py:176-194); lanes g == 3 hold sigma of sample c
+        float w0[2];
+        bool on[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t i = i0 + 16u * u + (uint32_t)c;
+            const float delta = (i + 1u < T) ? z_next[u] - z[u] : sample_dist;
+            float alpha = 0.0f;
+            if (g == 3 && valid[u]) alpha = 1.0f - expf(-delta * k_scale * expf(o[u][3]));
+            const float om = (g == 3 && valid[u]) ? (1.0f - alpha + 1e-15f) : 1.0f;
+            const float incl = row16_scan_mul(om, c);
+            float excl = __shfl_up(incl, 1, 16);
+            if (c == 0) excl = 1.0f;
+            const float w = alpha * (carry * excl);  // zero outside lane group 3
+            carry = carry * __shfl(incl, 63, 64);
+            if (g == 3 && valid[u]) weights[row0 + idx[u]] = w;
+            ws += w;
+            dp += w * z[u];
+            w0[u] = __shfl(w, 48 + c, 64);  // weight of sample c, for the lanes that hold its colour (g == 0)
+            on[u] = w0[u] > w_thresh;
+        }
+        // ---- heads on the samples that carry weight
+        if (__ballot(on[0] || on[1])) {
+            half8_t x_last[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const uint32_t p0 = pack_h2(o[u][0], o[u][1]), p1 = pack_h2(o[u][2], g == 3 ? 1.0f : o[u][3]);
+                u4_t gv;
+                gv[0] = (uint32_t)__shfl((int)p0, src_a);
+                gv[1] = (uint32_t)__shfl((int)p1, src_a);
+                gv[2] = (uint32_t)__shfl((int)p0, src_b);
+                gv[3] = (uint32_t)__shfl((int)p1, src_b);
+                x_last[u] = takes_geo ? __builtin_bit_cast(half8_t, gv) : xf[IN_STEPS - 1];
+            }
+            float4_t oa[2];
+            head2(FR::kHead, x_last, oa);
+            if constexpr (LIDAR) {
+                float4_t ob[2];
+                head2(FR::kHead + FR::kPerHead, x_last, ob);
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (g == 0 && on[u]) {
+                        img[0] += w0[u] * sigmoid_f32(oa[u][0]);
+                        img[1] += w0[u] * sigmoid_f32(ob[u][0]);
+                    }
+            } else {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (g == 0 && on[u]) {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) img[k] += w0[u] * sigmoid_f32(oa[u][k]);
+                    }
+            }
+        }
+    }
+    ws = wave_sum(ws);
+    dp = wave_sum(dp);
+#pragma unroll
+    for (int k = 0; k < C; ++k) img[k] = wave_sum(img[k]);
+    if (lane == 0) {
+        weights_sum[n] = ws;
+        depth[n] = dp;
+        const float bg[3] = {bg0, bg1, bg2};
+        const float rest = use_bg ? 1.0f - ws : 0.0f;
+#pragma unroll
+        for (int k = 0; k < C; ++k) image[(size_t)n * C + k] = use_bg ? img[k] + rest * bg[k] : img[k];
+    }
+}
+
 int fill_meta(GridMeta& meta, uint32_t L, const float* scales, const uint32_t* res, const uint32_t* offsets) {
     if (L == 0 || L > (uint32_t)kMaxLevels || !scales || !res || !offsets) return NVSF_ERR_INVALID_ARG;
     for (uint32_t l = 0; l < L; ++l) {
@@ -1736,8 +1950,14 @@ NVSF_API int nvsf_render_uniform_fwd(const float* rays_o, const float* rays_d, c
 #define LAUNCH_RU(LD, FF)                                                                                                             \
     hipLaunchKernelGGL((k_render_uniform<LD, FF>), grid_dim, block, 0, stream, rb, tb, (uint32_t)table_bytes, meta, first_hashed, fp, ws, wa, \
                        wb, k_scale, w_thresh, b0, b1, b2, use_bg, z_vals, weights, weights_sum, depth, image)
-    if (lidar) { if (fp) LAUNCH_RU(true, true); else LAUNCH_RU(true, false); }
-    else { if (fp) LAUNCH_RU(false, true); else LAUNCH_RU(false, false); }
+#define LAUNCH_TAIL(LD)                                                                                                               \
+    hipLaunchKernelGGL((k_render_tail2<LD>), grid_dim, block, 0, stream, rb, fp, ws, wa, wb, k_scale, w_thresh, b0, b1, b2, use_bg, z_vals, \
+                       weights, weights_sum, depth, image)
+    const char* tail_env = getenv("NVSF_RENDER_TAIL");  // "1": one tile per iteration (k_render_uniform<*, true>), A/B timing only
+    const bool tail2 = !(tail_env && tail_env[0] == '1');
+    if (lidar) { if (fp) { if (tail2) LAUNCH_TAIL(true); else LAUNCH_RU(true, true); } else LAUNCH_RU(true, false); }
+    else { if (fp) { if (tail2) LAUNCH_TAIL(false); else LAUNCH_RU(false, true); } else LAUNCH_RU(false, false); }
+#undef LAUNCH_TAIL
 #undef LAUNCH_RU
     return nvsf_launch_status();
 }

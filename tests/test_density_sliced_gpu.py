@@ -91,3 +91,30 @@ def test_prefer_sliced_choice_and_rejections(dev):
     table = torch.zeros(small.n_params, dtype=torch.float16, device=dev)
     with pytest.raises(_hip.NvsfHipError):
         ops.density_uniform(o, d, nears, fars, 16, m._aabb_host, float(m.bound), table, small, m.sigma_net.weights_f16(), sliced=True)
+
+
+@pytest.mark.parametrize("lidar", [True, False])
+@pytest.mark.parametrize("N,T,noise", [(64, 128, False), (37, 100, True), (3, 16, False), (200, 768, True), (5, 7, False), (9, 48, False)])
+def test_two_tile_tail_equals_one_tile_tail_and_gather_render(dev, lidar, N, T, noise, monkeypatch):
+    """The sliced render's tail kernel takes two MFMA tiles per iteration (k_render_tail2: every weight fragment read from LDS
+    feeds two MFMAs).  Per-tile arithmetic is that of the one-tile kernel, so all five outputs are bit-identical -- also for
+    ragged T (last pair half empty, T < 16) -- and equal to the one-launch gather render up to its own fp32 scan order."""
+    from nvsf import field_ops as ops
+    m = _model(dev, 0.1)
+    rng = np.random.default_rng(23)
+    o, d, nears, fars = _batch(m, dev, lidar, N, rng)
+    nz = torch.rand(N, T, device=dev) if noise else None
+    enc = m.hash_encoder_lidar if lidar else m.hash_encoder_camera
+    heads = (m.raydrop_net.weights_f16(), m.intensity_net.weights_f16()) if lidar else (m.color_net.weights_f16(), None)
+    args = (o, d, nears, fars, T, m._aabb_host, float(m.bound), enc.table_f16(), enc.spec, m.sigma_net.weights_f16(), lidar, heads[0], heads[1],
+            m._k_scale(), None if lidar else [1.0, 0.5, 0.25], nz)
+    two = ops.render_uniform(*args, sliced=True)
+    monkeypatch.setenv("NVSF_RENDER_TAIL", "1")
+    one = ops.render_uniform(*args, sliced=True)
+    monkeypatch.delenv("NVSF_RENDER_TAIL")
+    for x, y, name in zip(two, one, ("z_vals", "weights", "weights_sum", "depth", "image")):
+        assert torch.equal(x, y), name
+    gather = ops.render_uniform(*args, sliced=False)
+    assert torch.equal(two[0], gather[0]) and torch.equal(two[1], gather[1])
+    for x, y in zip(two[2:], gather[2:]):
+        assert float((x - y).abs().max()) <= 2e-6
