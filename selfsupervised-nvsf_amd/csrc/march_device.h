@@ -199,15 +199,17 @@ struct ChainWalker {
     int j, nb;      // next member of the batch to examine, members in the batch (j >= nb: batch exhausted)
     float pending;  // exit parameter of an empty cell whose skip runs past the end of a batch (-inf: none)
     float t;        // member 0 of the NEXT batch
+    float t_batch;  // member 0 of the CURRENT batch (fill_batch(t_batch, ...) regenerates its members)
     bool done;      // next_samples(): the ray is finished
     __device__ __forceinline__ void init(float t0) {
-        t = t0; j = 64; nb = 64; pending = -INFINITY; done = false;
+        t = t0; t_batch = t0; j = 64; nb = 64; pending = -INFINITY; done = false;
         bt = bx = by = bz = bdt = bexit = 0.0f;
         bocc = false;
     }
     __device__ __forceinline__ unsigned long long batch_mask() const { return nb >= 64 ? ~0ull : (1ull << nb) - 1ull; }
     __device__ __forceinline__ void refill(const Marcher& m, int lane) {
         const float t0 = t;
+        t_batch = t0;
         m.fill_batch(t0, lane, bt, nb, t);
         Marcher::Cell c;
         bocc = m.classify_cell(bt, bx, by, bz, bdt, c);

@@ -200,6 +200,175 @@ __global__ __launch_bounds__(kBlock) void k_march_write_wave(const float* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// march_rays_train in ONE launch (nvsf_march_rays_train_ws).
+//
+// The three-launch form classifies every chain member twice (count pass, write pass: ~150 VALU instructions per 64 members
+// each) because the sample ranges are only known after the scan.  Here a wave counts its ray ONCE and keeps, per batch that
+// holds samples, the batch's first chain parameter and its 64-bit sample mask in LDS (16 bytes); the ranges come from a
+// chained scan over the workgroups inside the same launch ("decoupled look-back": a workgroup publishes the sum of its four
+// rays, then its inclusive prefix once it has seen its predecessors'), after which the wave replays its records -- members by
+// the closed form of Marcher::fill_batch, positions by the marcher's own clamp(o + t d) -- and stores the samples.  No second
+// classification, no scan launch; the count phase of some waves overlaps the store phase of others.
+// Order of the packed samples: ray-index order, exactly as the three-launch form and the CPU oracle (the reference's order
+// depends on the arrival order of its atomics, raymarching.cu:445-446).
+// Inter-workgroup protocol (cdna_hip_programming.md Guideline 16, recipe R2): a workgroup's identity is a ticket drawn from
+// an atomic counter, so every predecessor of a running workgroup is itself running (no assumption about dispatch order);
+// each flag is ONE naturally aligned 8-byte {status, value} granule written by a single agent-scope atomic store and read
+// by agent-scope atomic loads -- no other data crosses workgroups.  Every spin is bounded (kMarchSpinLimit polls); on a
+// timeout the launch still terminates and reports through counter[1] = -1.
+constexpr int kMarchRecCap = 48;           // records per ray kept in LDS; a ray with more sample-bearing batches re-marches when writing
+constexpr uint32_t kMarchSpinLimit = 1u << 22;
+struct MarchRec { float t0; uint32_t nb; unsigned long long S; };
+
+__device__ __forceinline__ void march_store_batch(const Marcher& m, float bt, float bx, float by, float bz, float bdt, unsigned long long S,
+                                                  int lane, uint32_t offset, uint32_t& step, float& last_t, float* __restrict__ xyzs,
+                                                  float* __restrict__ dirs, float* __restrict__ deltas) {
+    const float t_after = bt + bdt;
+    const unsigned long long lower = S & ((1ull << lane) - 1ull);  // samples of this batch before this lane
+    const int prev_lane = lower ? 63 - __builtin_clzll(lower) : lane;
+    const float prev_after = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(prev_lane << 2, __builtin_bit_cast(int, t_after)));
+    if ((S >> lane) & 1ull) {
+        const size_t s = (size_t)offset + step + (uint32_t)__builtin_popcountll(lower);
+        xyzs[3 * s] = bx; xyzs[3 * s + 1] = by; xyzs[3 * s + 2] = bz;
+        dirs[3 * s] = m.dx; dirs[3 * s + 1] = m.dy; dirs[3 * s + 2] = m.dz;
+        deltas[2 * s] = bdt; deltas[2 * s + 1] = t_after - (lower ? prev_after : last_t);
+    }
+    last_t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t_after), 63 - __builtin_clzll(S)));
+    step += (uint32_t)__builtin_popcountll(S);
+}
+
+__global__ __launch_bounds__(kBlock) void k_march_train_onepass(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                                const uint8_t* __restrict__ grid, float bound, float dt_gamma,
+                                                                uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                                                                const float* __restrict__ nears, const float* __restrict__ fars,
+                                                                const float* __restrict__ noises, int* __restrict__ rays,
+                                                                int* __restrict__ counter, unsigned long long* __restrict__ ws,
+                                                                float* __restrict__ xyzs, float* __restrict__ dirs,
+                                                                float* __restrict__ deltas, int serial) {
+    constexpr int kRays = kBlock / kWave;
+    __shared__ uint32_t s_lut[kSpreadLutMax];
+    __shared__ MarchRec s_rec[kRays][kMarchRecCap];
+    __shared__ uint32_t s_cnt[kRays];
+    __shared__ uint32_t s_block, s_excl;
+    fill_spread_lut(s_lut, H);
+    if (threadIdx.x == 0) s_block = atomicAdd(reinterpret_cast<unsigned int*>(ws), 1u);  // ticket = this workgroup's position in the scan
+    __syncthreads();
+    const uint32_t b = s_block, n_blocks = gridDim.x;
+    const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
+    const uint32_t n = __builtin_amdgcn_readfirstlane(b * kRays + (uint32_t)wid);
+    unsigned long long* flags = ws + 1;
+    constexpr unsigned long long kAggregate = 1ull << 32, kInclusive = 2ull << 32;
+
+    // ---- phase 1: count the ray once; remember where its samples are
+    Marcher m;
+    float far = 0.0f, t_start = 0.0f;
+    uint32_t count = 0, nrec = 0;
+    if (n < N) {
+        m.init(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, grid, bound, dt_gamma, max_steps, C, H);
+        m.lut = s_lut;
+        far = fars[n];
+        t_start = nears[n];
+        t_start += m.step_len(t_start) * noises[n];
+        ChainWalker w;
+        w.init(t_start);
+        while (count < max_steps) {
+            const unsigned long long S = w.next_samples(m, far, lane, max_steps - count, serial != 0);
+            if (!S) break;
+            if (nrec < (uint32_t)kMarchRecCap && lane == 0) {
+                MarchRec r;
+                r.t0 = w.t_batch; r.nb = (uint32_t)w.nb; r.S = S;
+                s_rec[wid][nrec] = r;
+            }
+            ++nrec;
+            count += (uint32_t)__builtin_popcountll(S);
+        }
+    }
+    if (lane == 0) s_cnt[wid] = count;
+    __syncthreads();
+
+    // ---- phase 2: exclusive prefix of this workgroup's rays (chained scan over the tickets)
+    if (wid == 0) {
+        uint32_t agg = 0;
+#pragma unroll
+        for (int r = 0; r < kRays; ++r) agg += s_cnt[r];
+        uint32_t excl = 0;
+        if (b == 0) {
+            excl = (uint32_t)counter[0];
+        } else {
+            if (lane == 0) __hip_atomic_store(&flags[b], kAggregate | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int base = (int)b - 1;
+            uint32_t running = 0, polls = 0;
+            bool ok = false;
+            while (!ok && polls < kMarchSpinLimit) {
+                const int i = base - lane;
+                unsigned long long f = 3ull << 32;  // lanes before the first workgroup: ignored
+                if (i >= 0) f = __hip_atomic_load(&flags[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t status = (uint32_t)(f >> 32), value = (uint32_t)f;
+                const unsigned long long incl = __ballot(status == 2u), empty = __ballot(status == 0u);
+                if (incl) {
+                    const int p = __builtin_ctzll(incl);  // the nearest predecessor that knows its inclusive prefix
+                    if (empty & ((1ull << p) - 1ull)) { ++polls; __builtin_amdgcn_s_sleep(1); continue; }
+                    running += wave_sum(lane <= p ? value : 0u);
+                    ok = true;
+                } else if (empty) {
+                    ++polls;
+                    __builtin_amdgcn_s_sleep(1);
+                } else {  // 64 aggregates: take them all and look further back (workgroup 0 always publishes an inclusive prefix)
+                    running += wave_sum(value);
+                    base -= 64;
+                }
+            }
+            excl = running;
+            if (!ok && lane == 0) counter[1] = -1;  // bounded spin expired: the launch terminates, the result is marked invalid
+        }
+        if (lane == 0) {
+            __hip_atomic_store(&flags[b], kInclusive | (unsigned long long)(excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_excl = excl;
+            if (b == n_blocks - 1u) {  // the last ticket closes the call: counter as the three-launch form leaves it
+                counter[0] = (int)(excl + agg);
+                if (counter[1] >= 0) counter[1] += (int)N;
+            }
+        }
+    }
+    __syncthreads();
+    if (n >= N) return;
+    uint32_t offset = s_excl;
+    for (int r = 0; r < wid; ++r) offset += s_cnt[r];
+    if (lane == 0) {
+        rays[3 * (size_t)n + 0] = (int)n;
+        rays[3 * (size_t)n + 1] = (int)offset;
+        rays[3 * (size_t)n + 2] = (int)count;
+    }
+    if (count == 0 || offset + count > M) return;
+
+    // ---- phase 3: store the samples
+    float last_t = t_start;
+    uint32_t step = 0;
+    if (nrec <= (uint32_t)kMarchRecCap) {
+        for (uint32_t r = 0; r < nrec; ++r) {
+            const MarchRec rec = s_rec[wid][r];
+            float bt, tn;
+            int nb;
+            m.fill_batch(rec.t0, lane, bt, nb, tn);
+            // the sample description of Marcher::classify_cell: position clamped to the box, step length of the member
+            const float bx = clamp_med3(m.ox + bt * m.dx, -m.bound, m.bound);
+            const float by = clamp_med3(m.oy + bt * m.dy, -m.bound, m.bound);
+            const float bz = clamp_med3(m.oz + bt * m.dz, -m.bound, m.bound);
+            const float bdt = m.dt_gamma == 0.0f ? m.dt_const : m.step_len(bt);
+            march_store_batch(m, bt, bx, by, bz, bdt, rec.S, lane, offset, step, last_t, xyzs, dirs, deltas);
+        }
+    } else {  // more sample-bearing batches than LDS records: march again, as the three-launch write pass does
+        ChainWalker w;
+        w.init(t_start);
+        while (step < count) {
+            const unsigned long long S = w.next_samples(m, far, lane, count - step, serial != 0);
+            if (!S) break;
+            march_store_batch(m, w.bt, w.bx, w.by, w.bz, w.bdt, S, lane, offset, step, last_t, xyzs, dirs, deltas);
+        }
+    }
+}
+
 // pass 2: one workgroup; exclusive scan of the counts in ray order, reserving [counter[0], +total).
 // A thread takes kScanPer consecutive rays per round (4096 rays per round: one round at the BASELINE batch size).
 constexpr uint32_t kScanPer = 4;
@@ -624,6 +793,25 @@ NVSF_API int nvsf_march_rays_train(const float* rays_o, const float* rays_d, con
     hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(1024), 0, stream, N, rays, counter);
     hipLaunchKernelGGL(k_march_write_wave, wgrid, dim3(kBlock), 0, stream, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M,
                        nears, fars, noises, rays, xyzs, dirs, deltas, serial);
+    return nvsf_launch_status();
+}
+
+NVSF_API size_t nvsf_march_rays_train_ws_bytes(uint32_t N) { return 8u * (size_t)(1u + cdiv(N, kBlock / kWave)); }
+
+NVSF_API int nvsf_march_rays_train_ws(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
+                                      uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
+                                      const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays, int32_t* counter,
+                                      const float* noises, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (N == 0) return NVSF_OK;
+    REQUIRE(rays_o && rays_d && grid && nears && fars && xyzs && dirs && deltas && rays && counter && noises && workspace);
+    REQUIRE(C >= 1 && C <= 8 && H >= 2 && H <= 1024 && max_steps >= 1);
+    REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7u) == 0 && workspace_bytes >= nvsf_march_rays_train_ws_bytes(N));
+    const char* variant = getenv("NVSF_MARCH");
+    const int serial = variant && variant[0] == 's';  // "serial": the batch walked member by member (tests, A/B)
+    if (hipMemsetAsync(workspace, 0, nvsf_march_rays_train_ws_bytes(N), stream) != hipSuccess) return (int)hipGetLastError();
+    hipLaunchKernelGGL(k_march_train_onepass, dim3(cdiv(N, kBlock / kWave)), dim3(kBlock), 0, stream, rays_o, rays_d, grid, bound, dt_gamma,
+                       max_steps, N, C, H, M, nears, fars, noises, rays, counter, reinterpret_cast<unsigned long long*>(workspace), xyzs, dirs,
+                       deltas, serial);
     return nvsf_launch_status();
 }
 

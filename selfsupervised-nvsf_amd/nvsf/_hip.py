@@ -24,6 +24,7 @@ SIGNATURES = {
     "nvsf_morton3D_invert": [_P, _U, _P],
     "nvsf_packbits": [_P, _U, _F, _P],
     "nvsf_march_rays_train": [_P, _P, _P, _F, _F, _U, _U, _U, _U, _U, _P, _P, _P, _P, _P, _P, _P, _P],
+    "nvsf_march_rays_train_ws": [_P, _P, _P, _F, _F, _U, _U, _U, _U, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t],
     "nvsf_composite_rays_train_forward": [_P, _P, _P, _P, _U, _U, _F, _P, _P, _P],
     "nvsf_composite_rays_train_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _F, _P, _P],
     "nvsf_march_rays": [_U, _U, _P, _P, _P, _P, _F, _F, _U, _U, _U, _P, _P, _P, _P, _P, _P, _P],
@@ -94,6 +95,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError here == header / library mismatch
         fn.argtypes = list(argtypes) + [_P]
         fn.restype = ctypes.c_int
+    lib.nvsf_march_rays_train_ws_bytes.restype = ctypes.c_size_t
+    lib.nvsf_march_rays_train_ws_bytes.argtypes = [_U]
     lib.nvsf_version.restype = ctypes.c_char_p
     lib.nvsf_version.argtypes = []
     _lib = lib
@@ -102,6 +105,11 @@ def load():
 
 def version():
     return load().nvsf_version().decode()
+
+
+def march_ws_bytes(n_rays):
+    """Scratch bytes nvsf_march_rays_train_ws needs for `n_rays` rays."""
+    return int(load().nvsf_march_rays_train_ws_bytes(int(n_rays)))
 
 
 def ptr(t):

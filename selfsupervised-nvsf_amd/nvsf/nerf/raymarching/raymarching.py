@@ -13,6 +13,8 @@ Host-side contract kept from the reference wrappers:
 Differences: kernels run on PyTorch's *current* stream (the reference uses the legacy default stream),
 launch failures raise, and the packed sample order is deterministic (ray order).
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -145,7 +147,19 @@ class _march_rays_train(Function):
             step_counter = torch.zeros(2, dtype=torch.int32, device=dev)
         noises = torch.rand(N, dtype=dt, device=dev) if perturb else torch.zeros(N, dtype=dt, device=dev)
 
+        # one-launch form (nvsf_march_rays_train_ws: counts once, chained scan inside the launch); the reference-shaped
+        # three-launch entry point nvsf_march_rays_train gives the same outputs bit for bit (NVSF_MARCH_ENTRY=ref selects it)
+        use_ws = N > 0 and os.environ.get("NVSF_MARCH_ENTRY", "ws") != "ref"
+        ws_bytes = _hip.march_ws_bytes(N) if use_ws else 0
+        workspace = torch.empty(ws_bytes // 8, dtype=torch.int64, device=dev) if use_ws else None
+
         def launch():
+            if use_ws:
+                _hip.call("nvsf_march_rays_train_ws", _hip.ptr(rays_o), _hip.ptr(rays_d), _hip.ptr(density_bitfield), float(bound),
+                          float(dt_gamma), int(max_steps), N, int(C), int(H), M, _hip.ptr(nears), _hip.ptr(fars), _hip.ptr(xyzs),
+                          _hip.ptr(dirs), _hip.ptr(deltas), _hip.ptr(rays), _hip.ptr(step_counter), _hip.ptr(noises), _hip.ptr(workspace),
+                          ws_bytes)
+                return
             _hip.call("nvsf_march_rays_train", _hip.ptr(rays_o), _hip.ptr(rays_d), _hip.ptr(density_bitfield), float(bound),
                       float(dt_gamma), int(max_steps), N, int(C), int(H), M, _hip.ptr(nears), _hip.ptr(fars), _hip.ptr(xyzs),
                       _hip.ptr(dirs), _hip.ptr(deltas), _hip.ptr(rays), _hip.ptr(step_counter), _hip.ptr(noises))

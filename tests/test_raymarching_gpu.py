@@ -122,6 +122,75 @@ def test_march_rays_train(rm, dev, scene, n, max_steps, dt_gamma, perturb_seed, 
     assert not xyzs[m:].any()
 
 
+def _march_ws(dev, to, td, tb, tn, tf, tz, n, max_steps, dt_gamma, M, counter0=(0, 0)):
+    from nvsf import _hip
+    xyzs = torch.zeros(M, 3, device=dev); dirs = torch.zeros(M, 3, device=dev); deltas = torch.zeros(M, 2, device=dev)
+    rays = torch.empty(n, 3, dtype=torch.int32, device=dev)
+    counter = torch.tensor(list(counter0), dtype=torch.int32, device=dev)
+    nb = _hip.march_ws_bytes(n)
+    ws = torch.full((nb // 8,), -1, dtype=torch.int64, device=dev)  # garbage on entry: the entry point clears it
+    _hip.call("nvsf_march_rays_train_ws", _hip.ptr(to), _hip.ptr(td), _hip.ptr(tb), 2.0, float(dt_gamma), max_steps, n, 2, 128, M,
+              _hip.ptr(tn), _hip.ptr(tf), _hip.ptr(xyzs), _hip.ptr(dirs), _hip.ptr(deltas), _hip.ptr(rays), _hip.ptr(counter), _hip.ptr(tz),
+              _hip.ptr(ws), nb)
+    return counter.cpu(), rays.cpu(), xyzs.cpu(), dirs.cpu(), deltas.cpu()
+
+
+@pytest.mark.parametrize("n,max_steps,dt_gamma,perturb_seed", [(4096, 1024, 0.0, None), (1000, 256, 1.0 / 128, 7), (1, 64, 0.0, None), (7, 33, 0.0, 3)])
+def test_march_rays_train_ws_matches_oracle(rm, dev, scene, n, max_steps, dt_gamma, perturb_seed):
+    """nvsf_march_rays_train_ws (one launch: count once, chained scan over the workgroups, replay of the recorded sample
+    masks) against the oracle: counter, rays (ray-index order), positions, directions, step sizes bit for bit."""
+    o, d = _rays(n, 6, "lidar" if n == 1000 else "cam")
+    aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
+    nears, fars = O.near_far_from_aabb(o, d, aabb, 0.02)
+    noises = np.zeros(n, np.float32) if perturb_seed is None else np.random.default_rng(perturb_seed).random(n).astype(np.float32)
+    M = n * max_steps
+    xr, dr, lr, rr, cr = O.march_rays_train(o, d, scene["bits"], 2.0, dt_gamma, max_steps, 2, 128, M, nears, fars, noises)
+    T = lambda a: _t(a, dev)
+    counter, rays, xyzs, dirs, deltas = _march_ws(dev, T(o), T(d), T(scene["bits"]), T(nears), T(fars), T(noises), n, max_steps, dt_gamma, M)
+    assert np.array_equal(counter.numpy(), cr) and np.array_equal(rays.numpy(), rr)
+    m = int(cr[0])
+    assert np.array_equal(xyzs.numpy()[:m], xr[:m]) and np.array_equal(dirs.numpy()[:m], dr[:m]) and np.array_equal(deltas.numpy()[:m], lr[:m])
+    assert not xyzs[m:].any()
+
+
+@pytest.mark.parametrize("kind", ["random10", "random50", "dense", "empty", "scene", "stripes"])
+@pytest.mark.parametrize("dt_gamma,max_steps", [(0.0, 1024), (0.0, 300), (1.0 / 256, 512), (0.0, 4096)])
+def test_march_rays_train_ws_equals_three_launch_form(rm, dev, scene, kind, dt_gamma, max_steps):
+    """Same outputs as nvsf_march_rays_train on grids that stress the skip logic, with a pre-loaded counter, with a sample
+    buffer too small for the batch (rays beyond M are recorded but write nothing), and -- "stripes" at 4096 steps: one sample
+    every other batch -- with more sample-bearing batches per ray than the kernel keeps records for (the re-march path)."""
+    from nvsf import _hip
+    n = 3000 if max_steps == 4096 else 6000
+    rng = np.random.default_rng(11)
+    if kind == "scene":
+        bits = scene["bits"]
+    elif kind == "stripes":  # thin occupied slabs: many batches that each hold a few samples
+        g = np.zeros((2, 128 ** 3), bool)
+        idx = np.arange(128 ** 3)
+        g[:, (idx % 7) == 0] = True
+        bits = np.packbits(g.reshape(-1), bitorder="little")
+    else:
+        p = {"random10": 0.1, "random50": 0.5, "dense": 1.0, "empty": 0.0}[kind]
+        bits = np.packbits(rng.random(2 * 128 ** 3) < p, bitorder="little")
+    o, d = _rays(n, 12, "cam")
+    o[: n // 2] *= 3.0
+    aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
+    nears, fars = O.near_far_from_aabb(o, d, aabb, 0.02)
+    noises = rng.random(n).astype(np.float32)
+    T = lambda a: _t(a, dev)
+    to, td, tb, tn, tf, tz = T(o), T(d), T(bits), T(nears), T(fars), T(noises)
+    for M, c0 in ((n * max_steps, (0, 0)), (n * max_steps // 8, (40, 3))):
+        xyzs = torch.zeros(M, 3, device=dev); dirs = torch.zeros(M, 3, device=dev); deltas = torch.zeros(M, 2, device=dev)
+        rays = torch.empty(n, 3, dtype=torch.int32, device=dev); counter = torch.tensor(list(c0), dtype=torch.int32, device=dev)
+        _hip.call("nvsf_march_rays_train", _hip.ptr(to), _hip.ptr(td), _hip.ptr(tb), 2.0, float(dt_gamma), max_steps, n, 2, 128, M,
+                  _hip.ptr(tn), _hip.ptr(tf), _hip.ptr(xyzs), _hip.ptr(dirs), _hip.ptr(deltas), _hip.ptr(rays), _hip.ptr(counter), _hip.ptr(tz))
+        ref = (counter.cpu(), rays.cpu(), xyzs.cpu(), dirs.cpu(), deltas.cpu())
+        got = _march_ws(dev, to, td, tb, tn, tf, tz, n, max_steps, dt_gamma, M, c0)
+        assert (int(ref[0][0]) > c0[0]) == (kind != "empty")
+        for a, b, name in zip(ref, got, ("counter", "rays", "xyzs", "dirs", "deltas")):
+            assert torch.equal(a, b), (name, kind, M)
+
+
 @pytest.mark.parametrize("kind", ["random10", "random50", "dense", "empty", "scene"])
 @pytest.mark.parametrize("dt_gamma,max_steps", [(0.0, 1024), (0.0, 300), (1.0 / 256, 512)])
 def test_march_rays_train_wave_forms_equal_the_thread_form(rm, dev, scene, kind, dt_gamma, max_steps, monkeypatch):
