@@ -413,6 +413,31 @@ def cast_cols_f16(src, dst):
     return dst
 
 
+# ---- table-gradient scatter beside the rest of backward -------------------------------------------------------------------------
+# The table scatter (k_hashgrid_bwd_corners) runs at the memory-side float-atomic rate (2.95 ms per config-2 batch)
+# with the vector and matrix pipes idle; the MLP backward kernels of the OTHER modality's branch are MFMA / LDS work.  DensityFn
+# therefore issues the scatter on a side stream: the main stream goes on with the next branch of backward and only the consumers
+# of the table gradient (gradient all-reduce, overflow check, optimiser) wait for it (`sync_side_streams`).
+# Only a caller that synchronises afterwards turns this on (`SCATTER_OVERLAP = True` around backward, then `sync_side_streams()`:
+# nvsf.nerf.train_step.RenderTrainStep.step); everywhere else the scatter stays on the calling stream.
+_SIDE_STREAMS = {}
+SCATTER_OVERLAP = False
+GRAD_SINK = None  # frame_shard.GradBuckets of the running step (multi-rank): table gradients are scattered into its views
+
+
+def side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
+def sync_side_streams():
+    """The calling stream waits for every table scatter issued so far."""
+    for s in _SIDE_STREAMS.values():
+        torch.cuda.current_stream(s.device).wait_stream(s)
+
+
 class DensityFn(Function):
     """(sigma, geo_feat) = split(MLP(encode(x01)))  --  `NeRFNetwork.density` of a static hash field as ONE autograd node
     (network_dynamic.py:213-287 without the space-time terms: hash grid -> sigma_net -> trunc_exp / slice).
@@ -430,6 +455,7 @@ class DensityFn(Function):
         sigma = torch.exp(h[:, 0])
         ctx.save_for_backward(x01, feat, sigma, mlp_w16)
         ctx.grid_spec, ctx.mlp_spec, ctx.clamp = grid_spec, mlp_spec, (float(sigma_lo), float(sigma_hi))
+        ctx.table_param = table_params
         return sigma, h[:, 1:mlp_spec.n_out]
 
     @staticmethod
@@ -446,7 +472,30 @@ class DensityFn(Function):
                   _hip.ptr(grad_h), 16, ctx.clamp[0], ctx.clamp[1])
         need_table = ctx.needs_input_grad[1]
         grad_feat, grad_w = mlp_backward(feat, mlp_w16, spec, grad_h[:, :spec.n_out], need_grad_x=need_table)
-        grad_table = hashgrid_backward(x01, (0, 1, 2), ctx.grid_spec, grad_feat) if need_table else None
+        grad_table = None
+        if need_table:
+            if not (SCATTER_OVERLAP and x01.is_cuda):
+                sink = GRAD_SINK
+                view = sink.view_for(ctx.table_param) if sink is not None else None
+                if view is not None:
+                    hashgrid_backward(x01, (0, 1, 2), ctx.grid_spec, grad_feat, grad_table=view.view(-1))
+                    sink.mark_ready(ctx.table_param)
+                else:
+                    grad_table = hashgrid_backward(x01, (0, 1, 2), ctx.grid_spec, grad_feat)
+            else:
+                main, side = torch.cuda.current_stream(x01.device), side_stream(x01.device)
+                side.wait_stream(main)
+                sink, view = GRAD_SINK, None
+                if sink is not None:
+                    view = sink.view_for(ctx.table_param)
+                with torch.cuda.stream(side):
+                    x01.record_stream(side)
+                    grad_feat.record_stream(side)
+                    if view is not None:  # multi-rank step: scatter into the (zeroed) bucket view, then the bucket may go out
+                        hashgrid_backward(x01, (0, 1, 2), ctx.grid_spec, grad_feat, grad_table=view.view(-1))
+                        sink.mark_ready(ctx.table_param)
+                    else:
+                        grad_table = hashgrid_backward(x01, (0, 1, 2), ctx.grid_spec, grad_feat)
         return None, grad_table, None, None, (grad_w if ctx.needs_input_grad[4] else None), None, None, None, None
 
 

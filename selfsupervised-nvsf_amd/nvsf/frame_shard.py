@@ -75,43 +75,151 @@ def render_sharded(model, rays_o, rays_d, time, cal_lidar_color=False, max_ray_b
 
 
 def allreduce_gradients(params, bucket_bytes=64 << 20):
-    """Averages the gradients of `params` over all ranks with as few, as large all-reduces as `bucket_bytes` allows.
-
-    xGMI is point-to-point (7 links x ~153 GB/s per GPU): ring all-reduce time is set by the per-link rate, so a few
-    large buckets (64 MiB default; the whole model is ~190-375 MB of gradients) beat many small ones.  A parameter
-    whose gradient is None on this rank (e.g. the camera tables in a LiDAR-only step) contributes zeros, so every
-    rank issues identical collectives."""
+    """Averages the gradients of `params` over all ranks AFTER backward has finished, in as few, as large all-reduces as
+    `bucket_bytes` allows (one-shot form; `GradBuckets` is the overlapped form the training step uses).  A parameter without a
+    gradient on this rank contributes zeros; a parameter without a gradient on EVERY rank keeps `grad = None`, so the optimiser
+    skips it exactly as a single process would."""
     rank, ws = world()
     params = [p for p in params if p.requires_grad]
     if ws == 1 or not params:
         return 0
-    n_collectives = 0
-    bucket, size = [], 0
+    gb = GradBuckets(params, bucket_bytes, hooks=False)
+    had = [p.grad for p in params]
+    gb.begin_step()
+    for p, g in zip(params, had):
+        if g is not None:
+            p.grad.copy_(g)
+            gb.mark_ready(p)
+    return gb.finish()
 
-    def flush():
-        nonlocal bucket, size, n_collectives
-        if not bucket:
+
+class GradBuckets:
+    """Gradient storage of a frame-sharded training step and its ONE collective per bucket, overlapped with backward.
+
+    * Every bucket is one flat fp32 tensor; `p.grad` of its parameters are views into it (set by `begin_step`, which also zeroes
+      the buckets), so autograd accumulates in place and a bucket is all-reduced as it stands -- no `torch.cat` / `.float()`
+      staging copies of 190-375 MB of gradients after backward.
+    * Buckets follow the order in which gradients become final in backward (the reverse of the order the parameters are
+      given in, which is the order `get_params` lists them: tables first, heads last), so the heads' bucket is reduced while
+      the table gradients are still being scattered.  A post-accumulate-grad hook counts a bucket's parameters; the last one
+      launches `all_reduce(bucket, async_op=True)` -- RCCL over xGMI on a GPU node.  xGMI is point-to-point (7 links x ~153
+      GB/s per GPU): ring time is set by the per-link rate, so buckets are few and large (64 MiB; a 49 MB table is its own).
+    * `finish()` launches what has not been launched (parameters unused on this rank), reduces the per-parameter "somebody
+      produced a gradient" flags, waits, averages, and sets `p.grad = None` for parameters no rank touched -- Adam then skips
+      them, exactly as in a single process (a zero gradient would still move them by their momentum)."""
+
+    def __init__(self, params, bucket_bytes=64 << 20, hooks=True):
+        self.params = [p for p in params if p.requires_grad]
+        self.ws = world()[1]
+        order = list(reversed(self.params))
+        self.buckets, cur, size = [], [], 0
+        for p in order:
+            nbytes = p.numel() * 4
+            if cur and size + nbytes > bucket_bytes:
+                self.buckets.append(cur)
+                cur, size = [], 0
+            cur.append(p)
+            size += nbytes
+        if cur:
+            self.buckets.append(cur)
+        self.flat, self.views, self.bucket_of = [], {}, {}
+        for b, ps in enumerate(self.buckets):
+            flat = torch.zeros(sum(p.numel() for p in ps), dtype=torch.float32, device=ps[0].device)
+            off = 0
+            for p in ps:
+                if p.dtype != torch.float32:
+                    raise TypeError("GradBuckets: fp32 parameters")
+                self.views[p] = flat[off:off + p.numel()].view_as(p)
+                self.bucket_of[p] = b
+                off += p.numel()
+            self.flat.append(flat)
+        self._index = {p: i for i, p in enumerate(self.params)}
+        self._flags = torch.zeros(len(self.params), dtype=torch.float32, device=self.params[0].device)
+        self._pending, self._next, self._handles, self._fired = [], 0, [], set()
+        self._events = [[] for _ in self.buckets]
+        self._cuda = self.params[0].is_cuda
+        self._comm = torch.cuda.Stream(device=self.params[0].device) if (self._cuda and self.ws > 1) else None
+        self.n_collectives = 0
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] if hooks else []
+
+    def close(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    def begin_step(self):
+        self._pending = [len(ps) for ps in self.buckets]
+        self._next = 0
+        self._handles, self._fired, self.n_collectives = [], set(), 0
+        self._events = [[] for _ in self.buckets]
+        for flat in self.flat:
+            flat.zero_()
+        for p in self.params:
+            p.grad = self.views[p]
+        if self._cuda:  # kernels that scatter a gradient straight into its bucket view ask for it here (field_ops.DensityFn)
+            from nvsf import field_ops
+            field_ops.GRAD_SINK = self
+
+    def view_for(self, p):
+        return self.views.get(p)
+
+    def _on_grad(self, p):
+        if p.grad is not None and p.grad.data_ptr() != self.views[p].data_ptr():  # autograd replaced the view: fold it back in
+            self.views[p].copy_(p.grad)
+            p.grad = self.views[p]
+        self.mark_ready(p)
+
+    def mark_ready(self, p):
+        """The gradient of `p` (in its bucket view) is final.  Called by the hook, or by a kernel wrapper that scattered straight
+        into the view (field_ops.DensityFn on its side stream: the collective is then issued from that stream)."""
+        if p in self._fired:
             return
-        flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in bucket])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat.div_(ws)
-        off = 0
-        for p in bucket:
-            n = p.numel()
-            g = flat[off:off + n].view_as(p).to(p.dtype)
-            if p.grad is None:
-                p.grad = g.clone()
-            else:
-                p.grad.copy_(g)
-            off += n
-        n_collectives += 1
-        bucket, size = [], 0
+        self._fired.add(p)
+        b = self.bucket_of[p]
+        if self._comm is not None:  # gradients are produced on the main stream or on the table-scatter side stream: the
+            ev = torch.cuda.Event()  # collective (issued on its own stream) waits for exactly the producers of its bucket
+            ev.record()
+            self._events[b].append(ev)
+        self._pending[b] -= 1
+        self._launch_ready()
 
-    for p in params:
-        nbytes = p.numel() * 4
-        if bucket and size + nbytes > bucket_bytes:
-            flush()
-        bucket.append(p)
-        size += nbytes
-    flush()
-    return n_collectives
+    def _launch_ready(self, force=False):
+        """Collectives are matched across ranks by their sequence, so buckets are issued strictly in bucket order: bucket b goes
+        out once it is complete AND every bucket before it has gone out (a rank on which some parameter never receives a
+        gradient issues the rest in `finish`, in the same order)."""
+        while self._next < len(self.buckets) and (force or self._pending[self._next] == 0):
+            b = self._next
+            self._next += 1
+            if self.ws > 1:
+                if self._comm is not None:
+                    if force:  # a bucket closed by `finish`: everything queued on the calling stream so far belongs to it
+                        self._comm.wait_stream(torch.cuda.current_stream())
+                    for ev in self._events[b]:
+                        self._comm.wait_event(ev)
+                    with torch.cuda.stream(self._comm):
+                        self._handles.append(dist.all_reduce(self.flat[b], op=dist.ReduceOp.SUM, async_op=True))
+                else:
+                    self._handles.append(dist.all_reduce(self.flat[b], op=dist.ReduceOp.SUM, async_op=True))
+                self.n_collectives += 1
+
+    def finish(self):
+        if self._cuda:
+            from nvsf import field_ops
+            field_ops.GRAD_SINK = None
+            field_ops.sync_side_streams()
+        self._launch_ready(force=True)
+        self._flags.zero_()
+        if self._fired:
+            self._flags[[self._index[p] for p in self._fired]] = 1.0
+        if self.ws > 1:
+            self._handles.append(dist.all_reduce(self._flags, op=dist.ReduceOp.MAX, async_op=True))
+            self.n_collectives += 1
+            for h in self._handles:
+                h.wait()
+            for flat in self.flat:
+                flat.div_(self.ws)
+        touched = self._flags.tolist() if self.ws > 1 else [1.0 if p in self._fired else 0.0 for p in self.params]
+        for p, t in zip(self.params, touched):
+            if t == 0.0:
+                p.grad = None
+        return self.n_collectives

@@ -78,6 +78,11 @@ class RenderTrainStep:
             self.ema = ExponentialMovingAverage(model.parameters(), decay=ema_decay)
         self._cham = None
         self.global_step = 0
+        self.scatter_overlap = True  # table scatters on a side stream beside the rest of backward (field_ops.DensityFn)
+        # more than one rank: gradients live in flat buckets that are all-reduced while backward still runs (frame_shard.GradBuckets)
+        self.buckets = None
+        if frame_shard.world()[1] > 1:
+            self.buckets = frame_shard.GradBuckets([p for g in self.opt.param_groups for p in g["params"]], bucket_bytes)
 
     def _chamfer(self, a, b):
         if self._cham is None:
@@ -144,12 +149,29 @@ class RenderTrainStep:
 
     def step(self, batch):
         self.model.train()
-        self.opt.zero_grad(set_to_none=True)
+        if self.buckets is not None:
+            self.buckets.begin_step()
+        else:
+            self.opt.zero_grad(set_to_none=True)
         loss, parts = self.losses(batch)
-        self.scaler.scale(loss).backward()
+        overlap = loss.is_cuda and self.scatter_overlap
+        if overlap:
+            from nvsf import field_ops
+            field_ops.SCATTER_OVERLAP = True
+        try:
+            self.scaler.scale(loss).backward()
+        finally:
+            if overlap:
+                field_ops.SCATTER_OVERLAP = False
         # the all-reduce is linear: it runs on the scaled gradients (an inf / nan on one rank reaches every rank, so all of
-        # them skip the step together); scaler.step unscales, checks and steps
-        n_coll = frame_shard.allreduce_gradients([p for g in self.opt.param_groups for p in g["params"]], self.bucket_bytes)
+        # them skip the step together); scaler.step unscales, checks and steps.  Buckets go out during backward (hooks); finish()
+        # closes the rest, waits and averages.  The table scatters run on a side stream: their consumers wait here.
+        if self.buckets is not None:
+            n_coll = self.buckets.finish()
+        else:
+            n_coll = 0
+            if overlap:
+                field_ops.sync_side_streams()
         self.scaler.step(self.opt)
         self.scaler.update()
         self.sched.step()

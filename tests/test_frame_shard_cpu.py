@@ -37,6 +37,22 @@ def _worker(rank, world_size, port, q):
         expect = [(1 + 2) * (i + 1) / 2.0 for i in range(5)]
         expect[2] = (1 * 3 + 0) / 2.0
         ok_grad = all(torch.allclose(p.grad, torch.full_like(p, e)) for p, e in zip(params[:5], expect)) and params[5].grad is None
+        # --- the overlapped form used by the training step: hooks launch a bucket's all-reduce during backward, gradients live
+        # in flat bucket views, a parameter NO rank produced a gradient for ends with grad None (same training with
+        # any number of ranks), and the results equal the one-shot path
+        torch.manual_seed(1)
+        w = [torch.nn.Parameter(torch.randn(n)) for n in (300, 5, 70000, 11)]
+        gb = FS.GradBuckets(w, bucket_bytes=2048)
+        x = torch.arange(1.0, 4.0) * (rank + 1)
+        gb.begin_step()
+        loss = (w[0][:3] * x).sum() + (w[2][:3] * x * 2).sum() + ((w[3][:3] * x * 3).sum() if rank == 0 else 0.0)  # w[1] unused everywhere
+        loss.backward()
+        n_over = gb.finish()
+        exp0 = torch.zeros(300); exp0[:3] = torch.arange(1.0, 4.0) * 1.5
+        exp3 = torch.zeros(11); exp3[:3] = torch.arange(1.0, 4.0) * 1.5  # only rank 0 contributes: (3 x + 0) / 2
+        ok_grad = ok_grad and torch.allclose(w[0].grad, exp0) and torch.allclose(w[2].grad[:3], exp0[:3] * 2) and w[1].grad is None \
+            and torch.allclose(w[3].grad, exp3) and w[0].grad.data_ptr() == gb.views[w[0]].data_ptr() and n_over >= 3
+        gb.close()
         # --- rays: ragged chunks, gather restores the original order
         N = 4099
         full = torch.arange(N * 3, dtype=torch.float32).view(N, 3)

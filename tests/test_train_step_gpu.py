@@ -338,3 +338,38 @@ def test_dense_regime_needs_no_host_sync_and_follows_the_mask(dev):
         assert not m._mask_regime[True]["dense"] and torch.equal(e.float(), ref(sparse)) and torch.equal(f.float(), ref(sparse))
         z = m.color(x, d, cal_lidar_color=True, mask=torch.zeros(M, dtype=torch.bool, device=dev), geo_feat=geo)
         assert float(z.abs().max()) == 0.0
+
+
+def test_side_stream_scatter_gives_the_same_step(dev):
+    """RenderTrainStep issues the table scatters of DensityFn.backward on a side stream (they are atomic-bound; the MLP backward
+    of the other modality runs beside them).  Same gradients as with everything on one stream (fp32 atomics: order-dependent
+    in the last bits only), and the step's consumers see completed gradients."""
+    from nvsf import synthetic as S
+    from nvsf.nerf.models.network_static import NeRFNetworkStatic
+    from nvsf.nerf.train_step import RenderTrainStep
+    kw = dict(bound=S.BOUND, min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH, log2_hashmap_size=15)
+    torch.manual_seed(4)
+    teacher = NeRFNetworkStatic(**kw)
+    with torch.no_grad():
+        for enc in (teacher.hash_encoder_lidar, teacher.hash_encoder_camera):
+            enc.params.normal_(0.0, 0.2)
+    teacher = teacher.to(dev).eval()
+    batch = _batch(S, teacher, dev, n=700, T=64, seed=2)
+    grads = {}
+    for overlap in (False, True):
+        torch.manual_seed(9)
+        m = NeRFNetworkStatic(**kw).to(dev)
+        step = RenderTrainStep(m, num_steps=64, scale=S.SCALE, ema_decay=None)
+        step.scatter_overlap = overlap
+        step.scaler = torch.amp.GradScaler("cuda", init_scale=64.0, growth_interval=10 ** 6)  # no skipped steps, same scale both ways
+        torch.manual_seed(10)  # the jitter of perturb=True
+        step.step(batch)
+        grads[overlap] = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.numel() and p.grad is not None}
+        step.step(batch)  # and the next step starts from completed state (no stale / half-written gradient buffers)
+        torch.cuda.synchronize()
+        assert all(torch.isfinite(p).all() for p in m.parameters())
+    assert set(grads[False]) == set(grads[True]) and len(grads[True]) == 6
+    for n in grads[False]:
+        a, b = grads[False][n], grads[True][n]
+        assert float(a.abs().max()) > 0
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()), n  # same kernels and operands: fp32 atomic order only
