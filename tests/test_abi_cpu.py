@@ -19,7 +19,7 @@ def _declared():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     decls = {}
-    for m in re.finditer(r"\b(?:int|const char\*)\s+(nvsf_[A-Za-z0-9_]+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+    for m in re.finditer(r"\b(?:int|size_t|const char\*)\s+(nvsf_[A-Za-z0-9_]+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
         args = [a.strip() for a in m.group(2).replace("\n", " ").split(",")]
         decls[m.group(1)] = [] if args == ["void"] else args
     return decls
@@ -36,7 +36,9 @@ def test_library_exports_every_declared_symbol(hip_lib):
 def test_python_binding_table_matches_header(hip_lib):
     from nvsf import _hip
     decls = _declared()
-    assert set(_hip.SIGNATURES) == set(decls) - {"nvsf_version"}
+    helpers = {"nvsf_version", "nvsf_march_rays_train_ws_bytes"}  # no stream argument: bound by hand in _hip.load()
+    assert set(_hip.SIGNATURES) == set(decls) - helpers
+    assert _hip.march_ws_bytes(4096) == 8 * (1 + 1024)
     for name, argtypes in _hip.SIGNATURES.items():
         c_args = decls[name]
         assert c_args[-1].startswith("nvsf_stream_t"), name
@@ -48,6 +50,8 @@ def test_python_binding_table_matches_header(hip_lib):
                 assert ct is ctypes.c_uint32, (name, decl)
             elif decl.startswith("uint64_t"):
                 assert ct is ctypes.c_uint64, (name, decl)
+            elif decl.startswith("size_t"):
+                assert ct is ctypes.c_size_t, (name, decl)
             elif decl.startswith("float"):
                 assert ct is ctypes.c_float, (name, decl)
             elif decl.startswith("int"):
