@@ -124,55 +124,28 @@ def kernel_breakdown(model, batches, T, iters):
         else:
             head_a, head_b, head_flops, bg = model.color_net.weights_f16(), None, 14336, [1.0, 1.0, 1.0]
         sigma_flops = 2 * (32 * 64 + 64 * 16)
-        if os.environ.get("NVSF_RENDER_UNIFORM", "fused") != "split":
-            # the launches model.render issues: one wave-per-ray kernel for the whole render; on the level-sliced path the
-            # encode pass (levels partitioned over the XCDs) runs first and the render kernel reads its feature planes
-            rargs = dargs + (lidar, head_a, head_b, model._k_scale(), bg)
-            full = lambda: ops.render_uniform(*rargs, sliced=sliced)
-            z, w, ws, dp, img = full()
-            active = float((w > ops.W_THRESH).float().mean())
-            flops = sigma_flops + head_flops * active
-            if sliced:
-                bufs = ops.render_uniform(*rargs, sliced=True, _stage="encode")
-                t_a = event_time_ms(lambda: ops.render_uniform(*rargs, sliced=True, _stage="encode", _buffers=bufs), iters)
-                t_b = event_time_ms(lambda: ops.render_uniform(*rargs, sliced=True, _stage="tail", _buffers=bufs), iters)
-                rows.append(dict(kernel=f"density_encode_sliced[{name}]", ms=t_a, bound="hbm", unit="GB/s", achieved=580.0 * M / t_a / 1e6,
-                                 peak=HBM_PEAK_GBS, per_unit="580 B/sample (512 gathered + 64 features + 4 z written)", units=M))
-                rows.append(dict(kernel=f"render_uniform_tail[{name}]", ms=t_b, bound="mfma", unit="TFLOP/s", achieved=flops * M / t_b / 1e9,
-                                 peak=MFMA_PEAK_TFLOPS, units=M,
-                                 per_unit=f"{sigma_flops} + {head_flops} x active fraction {active:.3f} FLOP/sample (sigma MLP, compositing, heads); "
-                                          "76 B/sample of HBM traffic (64 features + 4 z read, 4 weights written)"))
-            else:
-                t = event_time_ms(full, iters)
-                rows.append(dict(kernel=f"render_uniform[{name}]", ms=t, bound="hbm", unit="GB/s", achieved=520.0 * M / t / 1e6, peak=HBM_PEAK_GBS,
-                                 units=M, per_unit="520 B/sample (512 gathered + 4 z + 4 weights written); gather, sigma MLP, compositing and heads "
-                                                   f"in one launch ({flops:.0f} FLOP/sample = {flops * M / t / 1e9:.0f} TFLOP/s)"))
-            continue
-        dens = lambda: ops.density_uniform(*dargs, sliced=sliced)
-        z, sig, geo = dens()
-        comp = lambda: ops.CompositeWeightsFn.apply(sig, z, nears, fars, model._k_scale())
-        w, ws, dp = comp()
-        heads = lambda: ops.heads_uniform(w, geo, d, ws, lidar, head_a, head_b, bg)
+        # the launches model.render issues: one wave-per-ray kernel for the whole render; on the level-sliced path the
+        # encode pass (levels partitioned over the XCDs) runs first and the render kernel reads its feature planes
+        rargs = dargs + (lidar, head_a, head_b, model._k_scale(), bg)
+        full = lambda: ops.render_uniform(*rargs, sliced=sliced)
+        z, w, ws, dp, img = full()
         active = float((w > ops.W_THRESH).float().mean())
-        t_d, t_c, t_h = event_time_ms(dens, iters), event_time_ms(comp, iters), event_time_ms(heads, iters)
+        flops = sigma_flops + head_flops * active
         if sliced:
-            # two launches (levels partitioned over the XCDs + streaming MLP pass), timed separately on shared buffers;
-            # the 64 B/sample scratch round trip is extra traffic of this formulation and is counted in its bytes
-            bufs = ops.density_uniform(*dargs, sliced=True, _buffers=(z, sig, geo, torch.empty(enc.spec.L, M, dtype=torch.int32, device=o.device)))
-            t_a = event_time_ms(lambda: ops.density_uniform(*dargs, sliced=True, _passes=1, _buffers=bufs), iters)
-            t_b = event_time_ms(lambda: ops.density_uniform(*dargs, sliced=True, _passes=2, _buffers=bufs), iters)
+            bufs = ops.render_uniform(*rargs, sliced=True, _stage="encode")
+            t_a = event_time_ms(lambda: ops.render_uniform(*rargs, sliced=True, _stage="encode", _buffers=bufs), iters)
+            t_b = event_time_ms(lambda: ops.render_uniform(*rargs, sliced=True, _stage="tail", _buffers=bufs), iters)
             rows.append(dict(kernel=f"density_encode_sliced[{name}]", ms=t_a, bound="hbm", unit="GB/s", achieved=580.0 * M / t_a / 1e6,
                              peak=HBM_PEAK_GBS, per_unit="580 B/sample (512 gathered + 64 features + 4 z written)", units=M))
-            rows.append(dict(kernel=f"density_from_features[{name}]", ms=t_b, bound="hbm", unit="GB/s", achieved=100.0 * M / t_b / 1e6,
-                             peak=HBM_PEAK_GBS, per_unit="100 B/sample (64 features read; 32 geo + 4 sigma written)", units=M))
+            rows.append(dict(kernel=f"render_uniform_tail[{name}]", ms=t_b, bound="mfma", unit="TFLOP/s", achieved=flops * M / t_b / 1e9,
+                             peak=MFMA_PEAK_TFLOPS, units=M,
+                             per_unit=f"{sigma_flops} + {head_flops} x active fraction {active:.3f} FLOP/sample (sigma MLP, compositing, heads); "
+                                      "76 B/sample of HBM traffic (64 features + 4 z read, 4 weights written)"))
         else:
-            rows.append(dict(kernel=f"density_uniform[{name}]", ms=t_d, bound="hbm", unit="GB/s", achieved=588.0 * M / t_d / 1e6,
-                             peak=HBM_PEAK_GBS, per_unit="588 B/sample", units=M))
-        rows.append(dict(kernel=f"composite_weights[{name}]", ms=t_c, bound="hbm", unit="GB/s", achieved=12.0 * M / t_c / 1e6,
-                         peak=HBM_PEAK_GBS, per_unit="12 B/sample (sigma, z read; weights written)", units=M))
-        rows.append(dict(kernel=f"heads_uniform[{name}]", ms=t_h, bound="mfma", unit="TFLOP/s",
-                         achieved=head_flops * M * active / t_h / 1e9, peak=MFMA_PEAK_TFLOPS,
-                         per_unit=f"{head_flops} FLOP/sample x active fraction {active:.3f}", units=M))
+            t = event_time_ms(full, iters)
+            rows.append(dict(kernel=f"render_uniform[{name}]", ms=t, bound="hbm", unit="GB/s", achieved=520.0 * M / t / 1e6, peak=HBM_PEAK_GBS,
+                             units=M, per_unit="520 B/sample (512 gathered + 4 z + 4 weights written); gather, sigma MLP, compositing and heads "
+                                               f"in one launch ({flops:.0f} FLOP/sample = {flops * M / t / 1e9:.0f} TFLOP/s)"))
     for r in rows:
         r["frac"] = r["achieved"] / r["peak"]
     return rows

@@ -168,16 +168,6 @@ int nvsf_hashgrid_bwd(const float* x, uint32_t M, uint32_t x_stride, const uint3
                       const void* grad_out, int grad_is_f16, uint32_t go_stride, float* grad_table_f32,
                       nvsf_stream_t stream);
 
-/* Same gradient with order-independent sums: the scatter accumulates in a 64-bit fixed-point table (integer atomics; scale
- * 2^shift chosen per call from max |grad_out| so that M adders cannot overflow) and a second pass adds it to grad_table_f32.
- * Two calls on the same inputs give bit-identical results.  acc_i64: device scratch of h_offsets[L]*F 64-bit words, gmax_bits:
- * device scratch of one uint32 (both cleared by the call).  A non-finite grad_out yields NaN in every element of grad_table_f32.
- * Requires L % (64 / (2^D F)) == 0 (else NVSF_ERR_UNSUPPORTED: use nvsf_hashgrid_bwd). */
-int nvsf_hashgrid_bwd_fixed(const float* x, uint32_t M, uint32_t x_stride, const uint32_t* cols, uint32_t D, uint32_t L,
-                            uint32_t F, const float* h_scales, const uint32_t* h_res, const uint32_t* h_offsets,
-                            const void* grad_out, int grad_is_f16, uint32_t go_stride, void* acc_i64, uint32_t* gmax_bits,
-                            float* grad_table_f32, nvsf_stream_t stream);
-
 /* ref: tcnn.Encoding("Frequency") network_dynamic.py:108-114.  x fp32 [M,n_dims] ->
  * out fp16 [M, out_stride >= 2*n_dims*n_freq], out[i*2K+2k] = sin(2^k pi x_i), [..+1] = cos. */
 int nvsf_freq_encode(const float* x, uint32_t M, uint32_t n_dims, uint32_t n_freq, void* out_f16,

@@ -26,13 +26,14 @@ FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fvisibility=hidden", "-fPIC
          "-Wno-unused-function", "-mllvm", "-amdgpu-mfma-vgpr-form", f"--offload-arch={ARCH}"]
 
 
-def csrc_digest():
-    """sha1 over the kernel sources (csrc/*.hip, *.h) and the compile flags: identifies the build that a profile was taken on
-    (bench.py reports PMC traffic only for profiles whose digest matches the running sources)."""
+def csrc_digest(unit="fused_field.hip"):
+    """sha1 over one translation unit of the kernels -- by default the one that holds the render kernels of the headline
+    benchmark -- every csrc header, and the compile flags: identifies the build a profile was taken on (bench.py reports PMC
+    traffic only from a profile whose digest matches the running sources)."""
     import hashlib
     h = hashlib.sha1(" ".join(FLAGS).encode())
     for f in sorted(os.listdir(CSRC)):
-        if f.endswith((".hip", ".h")):
+        if f == unit or f.endswith(".h"):
             h.update(f.encode())
             h.update(open(os.path.join(CSRC, f), "rb").read())
     return h.hexdigest()[:16]

@@ -416,85 +416,7 @@ __device__ __forceinline__ uint32_t slice_blend(const float (&frac)[3], const ui
     return __builtin_bit_cast(uint32_t, o);
 }
 
-// pass A: grid = 8 * blocks_per_slice; a wave encodes 64 consecutive samples (one per lane) for the slice's two levels.
-template <int F, bool UNIFORM_RAY>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_encode_sliced(RayBatch rb, const _Float16* __restrict__ table, uint32_t table_bytes, GridMeta meta,
-                                                          uint32_t L, uint32_t first_hashed, uint32_t M,
-                                                          float* __restrict__ z_vals, uint2* __restrict__ feat) {
-    static_assert(F == 2, "F = 2 only");
-    const uint32_t slice = blockIdx.x & 7u, sb = blockIdx.x >> 3, n_sb = gridDim.x >> 3;
-    const uint32_t grp = slice >> 1;
-    const uint32_t lvl[2] = {(slice & 1u) ? grp + 4u : grp, (slice & 1u) ? grp + 8u : grp + 12u};
-    SliceLevel<F> lv[2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const uint32_t l = lvl[a];
-        lv[a].scale = meta.scale[l];
-        lv[a].res = meta.res[l];
-        lv[a].res2 = meta.res[l] * meta.res[l];
-        lv[a].boff = meta.offset[l] * (uint32_t)(F * sizeof(_Float16));
-        lv[a].rows = meta.offset[l + 1] - meta.offset[l];
-        lv[a].hashed = l >= first_hashed;
-    }
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(table), 0, (int)table_bytes, 0x00020000);
-    const int lane = lane_id();
-    const uint32_t n_units = (M + 63u) / 64u;
-    const uint32_t wave = sb * kWavesPerBlock + (threadIdx.x >> 6), wave_count = n_sb * kWavesPerBlock;
-    // The ray record and lin[] of the NEXT unit are fetched while the current unit's gathers are in flight.
-    struct Unit {
-        uint32_t s, n;
-        bool in_range;
-        float near, far, lin, noise, o[3], d[3];
-    };
-    auto fetch = [&](uint32_t unit) {
-        Unit u;
-        const uint32_t s_raw = unit * 64u + (uint32_t)lane;
-        u.in_range = s_raw < M;
-        u.s = u.in_range ? s_raw : M - 1u;
-        if constexpr (UNIFORM_RAY) u.n = __builtin_amdgcn_readfirstlane((unit * 64u) / rb.T);  // T % 64 == 0: scalar ray loads
-        else u.n = u.s / rb.T;
-        const uint32_t i = u.s - u.n * rb.T;
-        u.near = rb.nears[u.n];
-        u.far = rb.fars[u.n];
-        u.lin = rb.lin[i];
-        u.noise = rb.noise ? rb.noise[u.s] : 0.5f;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            u.o[k] = rb.rays_o[3 * (size_t)u.n + k];
-            u.d[k] = rb.rays_d[3 * (size_t)u.n + k];
-        }
-        return u;
-    };
-    if (wave >= n_units) return;
-    Unit cur = fetch(wave);
-    for (uint32_t unit = wave; unit < n_units; unit += wave_count) {
-        const uint32_t next = unit + wave_count < n_units ? unit + wave_count : unit;
-        const Unit nxt = fetch(next);
-        const float range = cur.far - cur.near;
-        float z = cur.near + range * cur.lin;
-        if (rb.noise) z = z + (cur.noise - 0.5f) * (range / (float)rb.T);
-        float x[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            float p = cur.o[k] + cur.d[k] * z;
-            p = fminf(fmaxf(p, rb.lo[k]), rb.hi[k]);
-            x[k] = (p + rb.bound) * rb.inv_extent;
-        }
-        float frac[2][3];
-        uint32_t raw[2][8];
-        slice_issue<F>(lv[0], rsrc, x, frac[0], raw[0]);
-        slice_issue<F>(lv[1], rsrc, x, frac[1], raw[1]);
-        const uint32_t f0 = slice_blend(frac[0], raw[0]);
-        const uint32_t f1 = slice_blend(frac[1], raw[1]);
-        if (cur.in_range) {
-            feat[(size_t)slice * M + cur.s] = make_uint2(f0, f1);
-            if (slice == 0u) z_vals[cur.s] = z;
-        }
-        cur = nxt;
-    }
-}
-
-// pass A, pair form: TWO lanes per sample (lane = 2 * sample + x-bit), 32 samples per wave.  A lane gathers the four corners
+// pass A: grid = 8 * blocks_per_slice; TWO lanes per sample (lane = 2 * sample + x-bit), 32 samples per wave.  A lane gathers the four corners
 // with its x-bit of both levels, so every gather instruction fetches BOTH x-neighbours of 32 samples: they are adjacent table
 // entries on dense levels and for even cells on hashed ones, i.e. one L1 line look-up instead of two -- and the look-ups (one
 // line per clock and CU) are what bounds this pass.  The partner's four values of "its" level arrive by a quad swap (DPP);
@@ -861,171 +783,11 @@ __device__ __forceinline__ uint32_t pack_h2(float a, float b) {
     return __builtin_bit_cast(uint32_t, v);
 }
 
-template <bool LIDAR>
-__global__ __launch_bounds__(kBlock) void k_render_occupancy(OccRays rr, const _Float16* __restrict__ table, uint32_t table_bytes, GridMeta meta,
-                                                             uint32_t first_hashed, const _Float16* __restrict__ w_sigma,
-                                                             const _Float16* __restrict__ w_a, const _Float16* __restrict__ w_b,
-                                                             float density_scale, float T_thresh, float bg0, float bg1, float bg2,
-                                                             float* __restrict__ weights_sum, float* __restrict__ depth,
-                                                             float* __restrict__ image) {
-    constexpr int F = 2, Q = 8 / F;
-    constexpr int IN_STEPS = LIDAR ? 3 : 1;
-    __shared__ float s_scale[kMaxLevels];
-    __shared__ uint32_t s_res[kMaxLevels], s_off[kMaxLevels + 1];
-    if (threadIdx.x < kMaxLevels) {
-        s_scale[threadIdx.x] = meta.scale[threadIdx.x];
-        s_res[threadIdx.x] = meta.res[threadIdx.x];
-    }
-    if (threadIdx.x <= kMaxLevels) s_off[threadIdx.x] = meta.offset[threadIdx.x];
-    __syncthreads();
-    const uint32_t n = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
-    if (n >= rr.N) return;
-    const int lane = lane_id(), g = lane >> 4, sl = lane & 15;
 
-    DensityCtx<F> cx;
-    cx.g = g;
-    cx.first_hashed = first_hashed;
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        const int l = 4 * q + g;
-        cx.lv.scale[q] = s_scale[l];
-        cx.lv.res[q] = s_res[l];
-        cx.lv.res2[q] = s_res[l] * s_res[l];
-        cx.lv.boff[q] = s_off[l] * (uint32_t)(F * sizeof(_Float16));
-        cx.lv.rows[q] = s_off[l + 1] - s_off[l];
-    }
-#pragma unroll
-    for (int t = 0; t < kHidTiles; ++t) {
-        const _Float16* row = w_sigma + (size_t)(16 * t + sl) * 32;
-#pragma unroll
-        for (int q = 0; q < Q; ++q)
-#pragma unroll
-            for (int f = 0; f < F; ++f) cx.w0[t][q * F + f] = row[(4 * q + g) * F + f];
-    }
-    cx.wout.load(w_sigma + kHidden * 32, lane, 1);
-    cx.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(table), 0, (int)table_bytes, 0x00020000);
-
-    // direction encoding of the ray -> ray-constant operands of the heads (as in k_heads_uniform)
-    const float rd0 = rr.rays_d[3 * (size_t)n], rd1 = rr.rays_d[3 * (size_t)n + 1], rd2 = rr.rays_d[3 * (size_t)n + 2];
-    const float d0 = (rd0 + 1.0f) / 2.0f, d1 = (rd1 + 1.0f) / 2.0f, d2 = (rd2 + 1.0f) / 2.0f;
-    half8_t xf[IN_STEPS];
-    if constexpr (!LIDAR) {
-        float sh[16];
-        sh4_basis(d0, d1, d2, sh);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) xf[0][j] = (_Float16)(g == 0 ? sh[j] : sh[8 + j]);
-    } else {
-#pragma unroll
-        for (int s = 0; s < 3; ++s)
-#pragma unroll
-            for (int j = 0; j < 8; j += 2) {
-                const int k = 32 * s + 8 * g + j;
-                float sn = 1.0f, cs = 1.0f;
-                if (k < 72) {
-                    const int i = k / 24, f = (k - 24 * i) >> 1;
-                    freq_pair(i == 0 ? d0 : (i == 1 ? d1 : d2), f, sn, cs);
-                }
-                xf[s][j] = (_Float16)sn;
-                xf[s][j + 1] = (_Float16)cs;
-            }
-    }
-    HeadW<IN_STEPS> net_a;
-    net_a.load(w_a, lane, xf);
-    const half8_t x_base = xf[IN_STEPS - 1];
-    const bool takes_geo = LIDAR ? (g == 1 || g == 2) : (g >= 2);
-    const int src_a = sl + 16 * (LIDAR ? 2 * (g - 1) : 2 * (g - 2)), src_b = src_a + 16;  // lanes holding geo rows 8h..8h+3, +4..+7
-
-    const float o3[3] = {rr.rays_o[3 * (size_t)n], rr.rays_o[3 * (size_t)n + 1], rr.rays_o[3 * (size_t)n + 2]};
-    const float dd[3] = {rd0, rd1, rd2};
-    Marcher m;
-    m.init(o3, dd, rr.grid, rr.bound, rr.dt_gamma, rr.max_steps, rr.C, rr.H);
-    const float far = rr.fars[n];
-    float t = rr.nears[n];
-    float last_t = t, t_comp = t;
-    float ws = 0.0f, dep = 0.0f, col[3] = {0.0f, 0.0f, 0.0f};
-    uint32_t total = 0;
-    const float extent = 2.0f * rr.bound;
-    bool alive = true;
-    while (alive) {
-        // ---- march: up to 16 samples; every lane walks the ray, lane (g, sl) keeps sample sl
-        uint32_t count = 0;
-        float sx = 0.0f, sy = 0.0f, sz = 0.0f, sdt = 0.0f, sd1 = 0.0f;
-        while (t < far && count < 16u && total + count < rr.max_steps) {
-            float x, y, z, dt;
-            if (m.probe(t, x, y, z, dt)) {
-                t += dt;
-                const float d1s = t - last_t;
-                last_t = t;
-                if (count == (uint32_t)sl) { sx = x; sy = y; sz = z; sdt = dt; sd1 = d1s; }
-                ++count;
-            }
-        }
-        const uint32_t cnt = __builtin_amdgcn_readfirstlane(count);
-        if (cnt == 0u) break;
-        // ---- field on the tile (lanes sl >= cnt evaluate the box centre; their results are never read)
-        const float x01[3] = {(sx + rr.bound) / extent, (sy + rr.bound) / extent, (sz + rr.bound) / extent};
-        const float4_t o = density_eval<F, 4>(cx, x01);
-        const float sigma = expf(o[3]) * density_scale;  // meaningful in lanes g == 3
-        const uint32_t p0 = pack_h2(o[0], o[1]), p1 = pack_h2(o[2], g == 3 ? 1.0f : o[3]);
-        typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
-        u4_t gv;
-        gv[0] = (uint32_t)__shfl((int)p0, src_a & 63);
-        gv[1] = (uint32_t)__shfl((int)p1, src_a & 63);
-        gv[2] = (uint32_t)__shfl((int)p0, src_b & 63);
-        gv[3] = (uint32_t)__shfl((int)p1, src_b & 63);
-        const half8_t x_last = takes_geo ? __builtin_bit_cast(half8_t, gv) : x_base;
-        float c[3] = {0.0f, 0.0f, 0.0f};  // colour of sample sl, meaningful in lanes g == 0
-        {
-            const float4_t oa = net_a.apply(x_last);
-            if constexpr (LIDAR) {
-                c[0] = sigmoid_f32(oa[0]);
-                HeadW<IN_STEPS> net_b;  // second head: weights fetched per tile (registers are the scarce resource here)
-                net_b.load(w_b, lane, xf);
-                const float4_t ob = net_b.apply(x_last);
-                c[1] = sigmoid_f32(ob[0]);
-            } else {
-                c[0] = sigmoid_f32(oa[0]); c[1] = sigmoid_f32(oa[1]); c[2] = sigmoid_f32(oa[2]);
-            }
-        }
-        // ---- composite the tile in order (composite_rays, raymarching.cu:966-1053)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            if ((uint32_t)i < cnt && alive) {
-                const float s_i = readlane_f32(sigma, 48 + i);
-                const float dt_i = readlane_f32(sdt, i), d1_i = readlane_f32(sd1, i);
-                const float alpha = 1.0f - expf(-s_i * dt_i);
-                const float T = 1.0f - ws;
-                const float w = alpha * T;
-                ws += w;
-                t_comp += d1_i;
-                dep += w * t_comp;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) col[k] += w * readlane_f32(c[k], i);
-                if (T < T_thresh) alive = false;
-            }
-        }
-        total += cnt;
-        if (cnt < 16u) alive = false;
-    }
-    if (lane == 0) {
-        weights_sum[n] = ws;
-        depth[n] = dep;
-        if constexpr (LIDAR) {
-            image[2 * (size_t)n] = col[0];
-            image[2 * (size_t)n + 1] = col[1];
-        } else {
-            const float rest = 1.0f - ws;
-            image[3 * (size_t)n] = col[0] + rest * bg0;
-            image[3 * (size_t)n + 1] = col[1] + rest * bg1;
-            image[3 * (size_t)n + 2] = col[2] + rest * bg2;
-        }
-    }
-}
-
-// Second formulation of the same kernel: every MLP weight fragment lives in LDS in MFMA-operand order ([fragment][lane]
-// x 16 B, conflict-free ds_read_b128) instead of registers.  The kernel is latency-bound (a serial march per ray), so
-// what counts is how many rays are resident: 226 / 256 VGPRs (2 / 1 waves per SIMD) become ~128 (4 per SIMD, all 4096
-// rays of a batch in flight at once).  Arithmetic and operand order are those of k_render_occupancy.
+// Every MLP weight fragment lives in LDS in MFMA-operand order ([fragment][lane] x 16 B, conflict-free ds_read_b128) instead of
+// registers.  The kernel is latency-bound (a serial march per ray), so what counts is how many rays are resident: with the
+// fragments in registers it needs 226 / 256 VGPRs (2 / 1 waves per SIMD), with LDS fragments ~128 (4 per SIMD, all 4096 rays of
+// a batch in flight at once).
 template <bool LIDAR>
 struct OccFrags {
     static constexpr int IN_STEPS = LIDAR ? 3 : 1;
@@ -1273,7 +1035,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 4))) 
 // compositing -> masked heads -> image, 16 samples (one MFMA tile) at a time in sample order.  sigma and the geometry
 // features never reach HBM (the three-kernel form writes and re-reads 48 B per sample); only z_vals and weights, which
 // NeRFRenderer.run returns, are stored.  FROM_FEATURES = true is the tail of the level-sliced path: the encoded
-// features come from the scratch planes of k_encode_sliced instead of gathers.  Weight fragments in LDS as in
+// features come from the scratch planes of k_encode_sliced_pairs instead of gathers.  Weight fragments in LDS as in
 // k_render_occupancy_lds; arithmetic of the encode / MLPs / sigmoid identical to the separate kernels, the
 // transmittance product is scanned per 16 samples instead of per 64 (differences at the 1e-7 level).
 __device__ __forceinline__ float row16_scan_mul(float v, int c) {
@@ -1754,41 +1516,28 @@ static int density_uniform_impl(const float* rays_o, const float* rays_d, const 
         REQUIRE(feat_scratch && (reinterpret_cast<uintptr_t>(feat_scratch) & 15u) == 0);
         const uint32_t M = (uint32_t)total;
         uint2* fp = reinterpret_cast<uint2*>(feat_scratch);
-        const uint32_t units = (M + 63u) / 64u;
-        uint32_t per_slice = (units + kWavesPerBlock - 1) / kWavesPerBlock;
-        if (per_slice > 512u) per_slice = 512u;  // 32 CUs per XCD x 8 resident workgroups x 2 (measured: 256 -> 512 gains 1.5 %)
-        const char* enc_env = getenv("NVSF_ENCODE_SLICED");  // "lanes": one lane per sample (first form); default: two lanes per sample
-        const bool pairs = !(enc_env && enc_env[0] == 'l');
-        if (!(sliced_passes & 1u)) {
-        } else if (pairs) {
+        if (sliced_passes & 1u) {
             const uint32_t units32 = (M + 31u) / 32u;
             uint32_t ps = (units32 + kWavesPerBlock - 1) / kWavesPerBlock;
-            if (ps > 512u) ps = 512u;
+            if (ps > 512u) ps = 512u;  // 32 CUs per XCD x 8 resident workgroups x 2 (measured: 256 -> 512 gains 1.5 %)
             if (T % 32u == 0u)
                 hipLaunchKernelGGL((k_encode_sliced_pairs<2, true>), dim3(8u * ps), dim3(kBlock), 0, stream, rb, tb, (uint32_t)table_bytes, meta, L,
                                    first_hashed, M, z_vals, fp);
             else
                 hipLaunchKernelGGL((k_encode_sliced_pairs<2, false>), dim3(8u * ps), dim3(kBlock), 0, stream, rb, tb, (uint32_t)table_bytes, meta,
                                    L, first_hashed, M, z_vals, fp);
-        } else if (T % 64u == 0u)
-            hipLaunchKernelGGL((k_encode_sliced<2, true>), dim3(8u * per_slice), dim3(kBlock), 0, stream, rb, tb, (uint32_t)table_bytes, meta, L,
-                               first_hashed, M, z_vals, fp);
-        else
-            hipLaunchKernelGGL((k_encode_sliced<2, false>), dim3(8u * per_slice), dim3(kBlock), 0, stream, rb, tb, (uint32_t)table_bytes, meta, L,
-                               first_hashed, M, z_vals, fp);
+        }
         const uint32_t tiles = (M + 15u) / 16u;
         uint32_t bb = (tiles + 4u * kWavesPerBlock - 1u) / (4u * kWavesPerBlock);
         if (bb > 4096u) bb = 4096u;
         if (sliced_passes & 2u) hipLaunchKernelGGL(k_density_from_features<2>, dim3(bb), dim3(kBlock), 0, stream, fp, M, L, ws, sigmas, gp);
         return nvsf_launch_status();
     }
-    const char* variant = getenv("NVSF_DENSITY_KERNEL");  // "1" forces the first formulation (A/B timing)
-    const bool use_v2 = F == 2 && monotone && table_bytes < (1ull << 31) && !(variant && variant[0] == '1');
+    const bool use_v2 = F == 2 && monotone && table_bytes < (1ull << 31);  // else: the generic first formulation (any F with L F = 32)
     if (use_v2) {
-        const bool seg = (T % 16u == 0u) && !(variant && variant[0] == '2');  // "2" = v2 with the generic tile loop
+        const bool seg = T % 16u == 0u;
         if (seg) {
-            const char* st_env = getenv("NVSF_DENSITY_SEG_TILES");
-            const uint32_t seg_tiles = st_env ? (uint32_t)atoi(st_env) : 4u;  // 4 tiles = one round of the 4 waves (measured best)
+            const uint32_t seg_tiles = 4u;  // 4 tiles = one round of the 4 waves (measured best)
             const unsigned long long units = (unsigned long long)N * ((T / 16 + seg_tiles - 1) / seg_tiles);
             const uint32_t segb = (uint32_t)(units < 3072ull ? units : 3072ull);  // 256 CUs x 3 workgroups (VGPR-limited residency) x 4
             hipLaunchKernelGGL((k_density_uniform_v2<2, true, 4>), dim3(segb), dim3(kBlock), 0, stream, rb, tb, (uint32_t)table_bytes, meta,
@@ -1884,22 +1633,12 @@ NVSF_API int nvsf_render_occupancy_fwd(const float* rays_o, const float* rays_d,
     const _Float16* wb = reinterpret_cast<const _Float16*>(head_b_weights_f16);
     const float b0 = h_bg_color ? h_bg_color[0] : 0.0f, b1 = h_bg_color ? h_bg_color[1] : 0.0f, b2 = h_bg_color ? h_bg_color[2] : 0.0f;
     const dim3 grid_dim(cdiv(N, kWavesPerBlock)), block(kBlock);
-    const char* variant = getenv("NVSF_OCC_KERNEL");  // "reg": weights in registers (first formulation, A/B timing)
-    if (!(variant && variant[0] == 'r')) {
-        if (lidar)
-            hipLaunchKernelGGL(k_render_occupancy_lds<true>, grid_dim, block, 0, stream, rr, tb, (uint32_t)table_bytes, meta, first_hashed, ws,
-                               wa, wb, density_scale, T_thresh, b0, b1, b2, weights_sum, depth, image);
-        else
-            hipLaunchKernelGGL(k_render_occupancy_lds<false>, grid_dim, block, 0, stream, rr, tb, (uint32_t)table_bytes, meta, first_hashed, ws,
-                               wa, wb, density_scale, T_thresh, b0, b1, b2, weights_sum, depth, image);
-        return nvsf_launch_status();
-    }
     if (lidar)
-        hipLaunchKernelGGL(k_render_occupancy<true>, grid_dim, block, 0, stream, rr, tb, (uint32_t)table_bytes, meta, first_hashed, ws, wa, wb,
-                           density_scale, T_thresh, b0, b1, b2, weights_sum, depth, image);
+        hipLaunchKernelGGL(k_render_occupancy_lds<true>, grid_dim, block, 0, stream, rr, tb, (uint32_t)table_bytes, meta, first_hashed, ws,
+                           wa, wb, density_scale, T_thresh, b0, b1, b2, weights_sum, depth, image);
     else
-        hipLaunchKernelGGL(k_render_occupancy<false>, grid_dim, block, 0, stream, rr, tb, (uint32_t)table_bytes, meta, first_hashed, ws, wa, wb,
-                           density_scale, T_thresh, b0, b1, b2, weights_sum, depth, image);
+        hipLaunchKernelGGL(k_render_occupancy_lds<false>, grid_dim, block, 0, stream, rr, tb, (uint32_t)table_bytes, meta, first_hashed, ws,
+                           wa, wb, density_scale, T_thresh, b0, b1, b2, weights_sum, depth, image);
     return nvsf_launch_status();
 }
 

@@ -342,8 +342,7 @@ NVSF_API int nvsf_mlp_bwd(const void* x, int x_is_f16, uint32_t M, uint32_t n_in
     const int go_vec = n_out == 16 && go_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(grad_out) & 15u) == 0;
     const uint32_t n_tiles = (M + 15) / 16;
     uint32_t blocks = (n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
-    const char* cap_env = getenv("NVSF_MLP_BWD_BLOCKS");
-    const uint32_t cap = cap_env ? (uint32_t)atoi(cap_env) : 768u;  // 256 CUs x 3 resident workgroups of the narrow variants (2 of the wide ones: measured equal at 512 and 768); fewer workgroups = fewer flush atomics
+    const uint32_t cap = 768u;  // 256 CUs x 3 resident workgroups of the narrow variants (2 of the wide ones: measured equal at 512 and 768); fewer workgroups = fewer flush atomics
     if (blocks > cap) blocks = cap;
     const _Float16* w = reinterpret_cast<const _Float16*>(weights_f16);
     // FAST: 16-byte loads of x (mlp_device.h) and 16-byte stores of dX (window and rows aligned to four floats, rows wide

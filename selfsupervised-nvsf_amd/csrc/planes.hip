@@ -319,9 +319,7 @@ NVSF_API int nvsf_planes_bwd(const float* xt, uint32_t M, const float* planes_cl
         hipLaunchKernelGGL(k_planes_bwd, dim3(cdiv(M, kBlock)), dim3(kBlock), 0, stream, xt, M, planes_cl, meta, want, grad_static,
                            grad_dynamic, static_cast<float*>(nullptr), grad_xt);
     if (grad_planes_cl) {
-        const char* run_env = getenv("NVSF_PLANES_BWD_RUN");
-        const uint32_t run = run_env ? (uint32_t)atoi(run_env) : 128u;
-        REQUIRE(run >= 1);
+        const uint32_t run = 128u;  // rows per item
         const uint32_t n_grp = ((want & 1) ? 1u : 0u) + ((want & 2) ? 1u : 0u);
         const unsigned long long items = (unsigned long long)cdiv(M, run) * n_scales * n_grp;
         const unsigned long long waves = (items + 1) / 2;

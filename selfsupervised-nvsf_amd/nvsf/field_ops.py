@@ -2,8 +2,7 @@
 
 Thin, allocation-only wrappers over the C ABI (include/nvsf_hip.h sections 2-4) plus the autograd glue
 the trainer needs.  No arithmetic of the hot path happens in Python: every function here ends in a HIP
-kernel launch on the current stream, forward and backward (the only torch.matmul left is the GEMM-chain
-backward kept for MLP shapes nvsf_mlp_bwd is not built for, which no model of this package instantiates).
+kernel launch on the current stream, forward and backward.
 """
 import math
 
@@ -66,17 +65,6 @@ def hashgrid_backward(x, cols, spec, grad_out, grad_table=None):
     grad_out = grad_out.contiguous()
     if grad_table is None:
         grad_table = torch.zeros(spec.n_params, dtype=torch.float32, device=x.device)
-    import os
-    variant = os.environ.get("NVSF_HASHGRID_BWD", "corners")
-    if variant == "fixed" and spec.L % max(1, 64 // ((1 << spec.D) * spec.F)) == 0 and (1 << spec.D) * spec.F <= 64:
-        # opt-in: order-independent sums (64-bit fixed-point scatter + one conversion pass) -- bit-reproducible table gradients at
-        # the speed of the fp32 atomics (the integer atomics are ~3 % faster in this kernel, the two extra passes cost that back)
-        acc = torch.empty(spec.n_params, dtype=torch.int64, device=x.device)
-        gmax = torch.empty(1, dtype=torch.int32, device=x.device)
-        _hip.call("nvsf_hashgrid_bwd_fixed", _hip.ptr(x), x.shape[0], x.shape[1], _hip.host_u32(cols), spec.D, spec.L, spec.F, spec.h_scales,
-                  spec.h_res, spec.h_offsets, _hip.ptr(grad_out), 1 if grad_out.dtype == torch.float16 else 0, grad_out.stride(0),
-                  _hip.ptr(acc), _hip.ptr(gmax), _hip.ptr(grad_table))
-        return grad_table
     _hip.call("nvsf_hashgrid_bwd", _hip.ptr(x), x.shape[0], x.shape[1], _hip.host_u32(cols), spec.D, spec.L, spec.F, spec.h_scales,
               spec.h_res, spec.h_offsets, _hip.ptr(grad_out), 1 if grad_out.dtype == torch.float16 else 0, grad_out.stride(0),
               _hip.ptr(grad_table))
@@ -165,23 +153,6 @@ def mlp_forward(x, weights_f16, spec, out=None):
         out = torch.empty(M, spec.out_cols, dtype=torch.float32, device=x.device)
     _hip.call("nvsf_mlp_fwd", _hip.ptr_rows(x), 1 if x.dtype == torch.float16 else 0, M, spec.n_in, x.stride(0), _hip.ptr(weights_f16),
               spec.in_cols, spec.hidden, spec.n_hidden, spec.out_cols, _hip.ptr_rows(out), out.stride(0))
-    return out
-
-
-def _weight_grad(g, a, rows_per_slice=4096):
-    """dW = g^T a for g [M, out], a [M, in] with M in the millions and out, in <= 128: a GEMM whose reduction
-    dimension is the sample count.  Issued as a batched GEMM over row slices (split-K) with an fp32 sum of the
-    partial products -- a single [out x M] @ [M x in] call leaves most of the chip idle."""
-    M = g.shape[0]
-    n_slices = M // rows_per_slice
-    if n_slices < 8:
-        return (g.t() @ a).float()
-    body = n_slices * rows_per_slice
-    gs = g[:body].view(n_slices, rows_per_slice, g.shape[1])
-    as_ = a[:body].view(n_slices, rows_per_slice, a.shape[1])
-    out = torch.bmm(gs.transpose(1, 2), as_).float().sum(0)
-    if body < M:
-        out = out + (g[body:].t() @ a[body:]).float()
     return out
 
 
@@ -367,39 +338,13 @@ class MlpFn(Function):
     def backward(ctx, grad_out):
         x, weights_f16 = ctx.saved_tensors
         spec = ctx.spec
-        if spec.n_hidden <= 2 and spec.hidden == 64 and spec.out_cols == 16:
-            grad_x, grad_w = mlp_backward(x, weights_f16, spec, grad_out, need_grad_x=ctx.needs_input_grad[0])
-            if grad_x is not None and grad_x.dtype != x.dtype:
-                grad_x = grad_x.to(x.dtype)
-            return grad_x, (grad_w if ctx.needs_input_grad[1] else None), None, None
-        return MlpFn._backward_gemm(ctx, grad_out)
-
-    @staticmethod
-    def _backward_gemm(ctx, grad_out):
-        """Shapes nvsf_mlp_bwd is not built for (3 hidden layers): the chain of plain fp16 GEMMs through torch.matmul
-        (dW_l = dY_l^T A_{l-1}, dA_{l-1} = dY_l W_l), hidden activations recomputed from the saved input.  Also the
-        independent formulation the kernel is tested against (tests/test_field_gpu.py)."""
-        x, weights_f16 = ctx.saved_tensors
-        spec = ctx.spec
-        mats = spec.split(weights_f16)
-        M = x.shape[0]
-        a0 = torch.ones(M, spec.in_cols, dtype=torch.float16, device=x.device)
-        a0[:, :spec.n_in] = x.to(torch.float16)
-        acts = [a0]
-        for W in mats[:-1]:
-            acts.append(torch.relu(acts[-1] @ W.t()))
-        g = torch.zeros(M, spec.out_cols, dtype=torch.float16, device=x.device)
-        g[:, :spec.n_out] = grad_out.to(torch.float16)
-        grads = []
-        for li in range(len(mats) - 1, -1, -1):
-            grads.append(_weight_grad(g, acts[li]))
-            if li > 0 or ctx.needs_input_grad[0]:
-                g = g @ mats[li]
-                if li > 0:
-                    g = g * (acts[li] > 0)
-        grad_params = torch.cat([t.reshape(-1) for t in reversed(grads)]) if ctx.needs_input_grad[1] else None
-        grad_x = g[:, :spec.n_in].to(x.dtype) if ctx.needs_input_grad[0] else None
-        return grad_x, grad_params, None, None
+        if not (spec.n_hidden <= 2 and spec.hidden == 64 and spec.out_cols == 16):
+            raise _hip.NvsfHipError("nvsf_mlp_bwd is built for 64-wide MLPs with one or two hidden layers and <= 16 outputs "
+                                    "(every network of the reference's model); there is no fallback")
+        grad_x, grad_w = mlp_backward(x, weights_f16, spec, grad_out, need_grad_x=ctx.needs_input_grad[0])
+        if grad_x is not None and grad_x.dtype != x.dtype:
+            grad_x = grad_x.to(x.dtype)
+        return grad_x, (grad_w if ctx.needs_input_grad[1] else None), None, None
 
 
 def cast_cols_f16(src, dst):

@@ -300,18 +300,12 @@ class HashDynFn(torch.autograd.Function):
         # atomics, which are what bounds this pass -- and scaled into the two gradients afterwards (tables of ~1 M floats).
         g_out = grad_out.float().contiguous()
         lag_t = torch.tensor(lag, dtype=torch.float32, device=x.device)
-        if os.environ.get("NVSF_HASH4D_BWD", "scalar") == "scalar":
-            # ... and the four features of an entry are the four Lagrange chunks: dL/dtable[row][i] = lag_i * blend * G[row] with ONE
-            # scalar sum per entry (nvsf_hashgrid4d_dynamic_bwd_scalar), expanded here
-            sums = [torch.zeros(s.n_rows, dtype=torch.float32, device=x.device) for s in specs]
-            _hip.call("nvsf_hashgrid4d_dynamic_bwd_scalar", _hip.ptr(x), x.shape[1], x.shape[0], h_scales, h_res, h_off, _hip.ptr(g_out),
-                      (ctypes.c_void_p * 3)(*[g.data_ptr() for g in sums]))
-            acc = [(g.view(-1, 1) * lag_t.view(1, 4)).reshape(-1) for g in sums]
-        else:
-            acc = [torch.zeros(s.n_params, dtype=torch.float32, device=x.device) for s in specs]
-            ptrs = [g.data_ptr() for g in acc] + [0, 0, 0]
-            _hip.call("nvsf_hashgrid4d_dynamic_bwd", _hip.ptr(x), x.shape[1], x.shape[0], h_scales, h_res, h_off, h_time, 1,
-                      _hip.ptr(g_out), (ctypes.c_void_p * 6)(*ptrs))
+        # ... and the four features of an entry are the four Lagrange chunks: dL/dtable[row][i] = lag_i * blend * G[row] with ONE
+        # scalar sum per entry (nvsf_hashgrid4d_dynamic_bwd_scalar), expanded here
+        sums = [torch.zeros(s.n_rows, dtype=torch.float32, device=x.device) for s in specs]
+        _hip.call("nvsf_hashgrid4d_dynamic_bwd_scalar", _hip.ptr(x), x.shape[1], x.shape[0], h_scales, h_res, h_off, _hip.ptr(g_out),
+                  (ctypes.c_void_p * 3)(*[g.data_ptr() for g in sums]))
+        acc = [(g.view(-1, 1) * lag_t.view(1, 4)).reshape(-1) for g in sums]
         if same:  # the same parameter tensors were passed twice: the whole gradient goes to the first occurrence
             grads = acc + [None, None, None]
         else:

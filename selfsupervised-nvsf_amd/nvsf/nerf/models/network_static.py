@@ -110,7 +110,7 @@ class NeRFNetworkStatic(NeRFRenderer):
         # host-side estimate of far - near: exact for LiDAR (constant range), the box side for camera rays (AABB exit)
         ray_length = float(self.lidar_max_depth - self.min_near_lidar) if cal_lidar_color else 2.0 * float(self.bound)
         sliced = ops.prefer_sliced(enc.spec, rays_o.shape[0], T, ray_length, float(self.bound))
-        if ops.render_uniform_eligible(enc.spec) and os.environ.get("NVSF_RENDER_UNIFORM", "fused") != "split":
+        if ops.render_uniform_eligible(enc.spec):
             # one launch per batch (plus the encode pass of the level-sliced path): sigma / geo never reach HBM
             if cal_lidar_color:
                 head_a, head_b = self.raydrop_net.weights_f16(), self.intensity_net.weights_f16()

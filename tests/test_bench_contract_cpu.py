@@ -4,6 +4,7 @@ import glob
 import importlib.util
 import json
 import os
+import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -66,7 +67,10 @@ def test_gpus_flag_starts_that_many_ranks(monkeypatch):
         env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True,
                            text=True, env=env, timeout=300)
-        assert r.returncode != 0 and r.stderr.count("needs a HIP device") >= 2, r.stderr[-2000:]
+        # (the launcher stops the other rank as soon as the first one fails: it either printed the same refusal or shows up in
+        # the launcher's failure report as rank 1)
+        assert r.returncode != 0 and "needs a HIP device" in r.stderr, r.stderr[-2000:]
+        assert r.stderr.count("needs a HIP device") >= 2 or re.search(r"rank\s*: 1 \(local_rank: 1\)", r.stderr), r.stderr[-2000:]
         assert not r.stdout.strip()
 
 
@@ -93,4 +97,4 @@ def test_committed_bench_line_follows_the_contract():
     for leg in ("occupancy", "dynamic", "train", "raymarching", "field_ops"):
         assert leg in d, leg
     for row in d["raymarching"]["kernels"] + d["field_ops"]["kernels"] + d["kernels"]:
-        assert row["ms"] > 0 and row["frac"] > 0 and row["bound"] in ("hbm", "mfma")
+        assert row["ms"] > 0 and row["frac"] > 0 and row["bound"] in ("hbm", "mfma", "l1")  # l1: L2-resident gathers (secondary rows only)

@@ -66,7 +66,6 @@ def test_planes_backward_run_merging_equals_per_sample_atomics(dev, dynamic_only
     for variant in ("runs", "atomic"):
         if variant == "atomic":
             monkeypatch.setenv("NVSF_PLANES_BWD", "atomic")
-        monkeypatch.setenv("NVSF_PLANES_BWD_RUN", "64")
         torch.manual_seed(0)
         enc = Planes4D(resolution=[32, 32, 32, 8], multiscale_res=[1, 2, 4, 8]).to(dev)
         xt = _t(xt_np, dev).requires_grad_()

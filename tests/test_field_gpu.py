@@ -82,14 +82,12 @@ def test_hashgrid_backward(ops, dev):
 
 
 @pytest.mark.parametrize("D,L,F,log2_T,base,top", [(3, 16, 2, 14, 16, 512), (3, 8, 4, 12, 16, 256), (3, 16, 8, 12, 32, 2048), (2, 8, 4, 10, 16, 256)])
-@pytest.mark.parametrize("variant", ["fixed", "corners", "runs", "atomic"])
+@pytest.mark.parametrize("variant", ["corners", "atomic"])
 def test_hashgrid_backward_kernels_agree_with_the_oracle(ops, dev, D, L, F, log2_T, base, top, variant, monkeypatch):
-    """The four formulations of the table gradient (corner-parallel run merging with fp32 atomics = default, the same into a
-    64-bit fixed-point table, one thread per (chunk, level), one thread per (row, level)) on ray-ordered rows -- long runs inside
-    one cell at the coarse levels, a new cell per row at the fine ones -- with zero-gradient rows and zero features mixed in,
-    fp32 and fp16 gradients."""
+    """The production form of the table gradient (corner-parallel run merging) and the plain one-thread-per-(row, level) kernel
+    (fallback shape + test reference) on ray-ordered rows -- long runs inside one cell at the coarse levels, a new cell per
+    row at the fine ones -- with zero-gradient rows and zero features mixed in, fp32 and fp16 gradients."""
     monkeypatch.setenv("NVSF_HASHGRID_BWD", variant)
-    monkeypatch.setenv("NVSF_HASHGRID_BWD_RUN", "32")
     spec = _spec(ops, D, L, F, log2_T, base, top)
     rng = np.random.default_rng(D * 100 + L + F)
     n_rays, T = 37, 97  # M is not a multiple of the chunk length
@@ -274,11 +272,9 @@ def test_compositor_backward_matches_torch_autograd(ops, dev):
     np.testing.assert_allclose(sd.grad.cpu().numpy(), s64.grad.numpy(), atol=2e-5, rtol=2e-3)
 
 
-def test_hashgrid_backward_fixed_point_is_reproducible_and_scale_free(ops, dev, monkeypatch):
-    """NVSF_HASHGRID_BWD=fixed (64-bit fixed-point scatter): bit-identical between runs, accumulates into the caller's table,
-    exact power-of-two covariance (gradients scaled by 2^k give the table gradient scaled by 2^k, for tiny and huge magnitudes:
-    the fixed-point scale follows max |grad|), zero gradients are a no-op, a non-finite gradient poisons the whole table."""
-    monkeypatch.setenv("NVSF_HASHGRID_BWD", "fixed")
+def test_hashgrid_backward_accumulates_and_ignores_zero_gradients(ops, dev):
+    """nvsf_hashgrid_bwd ADDS into the caller's table (the multi-rank step scatters straight into its gradient bucket) and a
+    zero gradient is a no-op."""
     spec = _spec(ops, 3, 16, 2, 15, 16, 1024)
     rng = np.random.default_rng(5)
     n_rays, T = 61, 128
@@ -287,19 +283,8 @@ def test_hashgrid_backward_fixed_point_is_reproducible_and_scale_free(ops, dev, 
     x = _t(np.clip(o + d * np.linspace(0, 0.3, T).reshape(1, T, 1), 0, 1).reshape(-1, 3).astype(np.float32), dev)
     go = torch.randn(x.shape[0], 32, device=dev)
     a = ops.hashgrid_backward(x, (0, 1, 2), spec, go)
-    b = ops.hashgrid_backward(x, (0, 1, 2), spec, go)
-    assert torch.equal(a, b) and float(a.abs().max()) > 0
-    monkeypatch.setenv("NVSF_HASHGRID_BWD", "corners")
-    c = ops.hashgrid_backward(x, (0, 1, 2), spec, go)
-    monkeypatch.setenv("NVSF_HASHGRID_BWD", "fixed")
-    assert float((a - c).abs().max()) <= 1e-4 * float(c.abs().max())
-    for k in (-40, -20, 20, 60):
-        s = ops.hashgrid_backward(x, (0, 1, 2), spec, go * 2.0 ** k)
-        assert torch.equal(s, a * 2.0 ** k), k
     base = torch.full((spec.n_params,), 3.0, device=dev)
     acc = ops.hashgrid_backward(x, (0, 1, 2), spec, go, grad_table=base.clone())
-    assert torch.allclose(acc, a + 3.0, rtol=0, atol=1e-5) and torch.equal(acc[a == 0], base[a == 0])
+    assert float(a.abs().max()) > 0 and torch.allclose(acc, a + 3.0, rtol=0, atol=1e-4) and torch.equal(acc[a == 0], base[a == 0])
     z = ops.hashgrid_backward(x, (0, 1, 2), spec, torch.zeros_like(go), grad_table=base.clone())
     assert torch.equal(z, base)
-    bad = go.clone(); bad[17, 5] = float("inf")
-    assert bool(torch.isnan(ops.hashgrid_backward(x, (0, 1, 2), spec, bad)).all())

@@ -1,8 +1,7 @@
 """nvsf_mlp_bwd (fused data + weight gradients of the width-64 MLPs) against two independent formulations:
   * exact small-integer arithmetic (every product and sum representable: a transposed / permuted MFMA fragment
     or a wrong LDS transpose cannot pass), evaluated in numpy float64;
-  * fp32 torch autograd of the same network on random data (tolerances of the fp16 operand rounding), and the
-    fp16 GEMM chain kept in field_ops.MlpFn._backward_gemm.
+  * fp32 torch autograd of the same network on random data (tolerances of the fp16 operand rounding).
 Shapes: every (in_cols, n_hidden) the models instantiate (32/1, 32/2, 96/2, 128/1) plus ragged inputs and sizes."""
 import types
 
@@ -84,16 +83,11 @@ def test_mlp_bwd_random_vs_fp32_autograd(dev, n_in, n_out, n_hidden, M):
     gx_ref = xr.grad
     # fp16 rounding of activations / gradients: relative error ~1e-3 per element, ReLU gates of near-zero units may flip
     sw, sx = float(gw_ref.abs().max()), float(gx_ref.abs().max())
-    ctx = types.SimpleNamespace(saved_tensors=(x, w16), spec=spec, needs_input_grad=(True, True, False, False))
-    gx_g, gw_g, _, _ = ops.MlpFn._backward_gemm(ctx, g_out)
-    # measured: kernel vs GEMM chain 2-4e-4 of the largest entry; either of them vs fp32 up to 3e-2 (fp16 activations)
+    # measured: kernel vs an fp16 GEMM chain 2-4e-4 of the largest entry; either of them vs fp32 up to 3e-2 (fp16 activations)
     assert float((gw - gw_ref).abs().max()) < 5e-2 * sw
     assert float(((gw - gw_ref).abs() <= 1e-2 * sw).float().mean()) > 0.99
     assert float(((gx - gx_ref).abs() <= 2e-2 * sx).float().mean()) > 0.995
     assert float((gx - gx_ref).abs().mean()) < 2e-3 * sx
-    # and the fp16 GEMM chain (same operand precision): much closer
-    assert float((gw - gw_g).abs().max()) < 2e-3 * sw
-    assert float((gx - gx_g.float()).abs().mean()) < 1e-3 * sx
 
 
 def test_mlp_bwd_accumulates_and_rejects(dev):
