@@ -111,6 +111,100 @@ __global__ __launch_bounds__(kBlock) void k_planes_fwd(const float* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Forward along the rays (the form nvsf_planes_fwd / nvsf_planes_multi_fwd launch; k_planes_fwd above is its test reference).
+//
+// k_planes_fwd gathers four 32-byte texels per (sample, scale, plane): 3 KB per sample, from a table that sits in L2, i.e.
+// the kernel runs at the rate of the vector L1's data path (64 B/clk/CU) no matter how often neighbouring samples ask for
+// the same texels -- and rows of the input are consecutive samples of a ray, 0.02 - 0.33 texels apart.  Here an item =
+// (chunk of kRun consecutive rows, evaluation) is walked IN ORDER by 8 adjacent lanes (lane = scale x channel half): a lane
+// keeps the four half-texels (4 x 16 B) of the current cell of each of its three planes in registers and gathers again
+// only when that plane's cell changes -- 4 x to 16 x fewer gather instructions on camera / LiDAR rays.  Per sample the
+// eight lanes of an item store one whole 128-byte output row.  Same tap arithmetic, same interpolation and product order
+// per channel as k_planes_fwd: bit-identical features (tests/test_dynamic_gpu.py).
+//
+// An "evaluation" is one group of three planes (static xy, xz, yz | dynamic xt, yt, zt) at positions x (+ an offset read
+// from another buffer: the scene flow of the neighbour frames, network_dynamic.py:242-271) with the time either taken from
+// column 3 of the positions or given as a scalar -- so the three dynamic evaluations of a density query and the static one
+// are ONE launch and no [M,4] position copies are built for the neighbours.
+constexpr int kRun = 64;
+constexpr int kMaxEval = 4;
+struct PlaneEvals {
+    const float* x;            // [M, x_stride] positions in [0,1]
+    uint32_t x_stride;
+    int n;
+    int grp[kMaxEval];         // 0: static planes (pairs 0, 1, 3), 1: time planes (pairs 2, 4, 5)
+    const float* off[kMaxEval];  // optional offsets added to x (fp32 add, as torch.add): row stride / first column below
+    uint32_t off_stride[kMaxEval], off_col[kMaxEval];
+    float t[kMaxEval];         // time coordinate ...
+    int t_from_x[kMaxEval];    // ... unless taken from column 3 of x
+    float* out[kMaxEval];      // [M, n_scales * 8]
+};
+
+__global__ __launch_bounds__(kBlock) void k_planes_fwd_runs(PlaneEvals ev, uint32_t M, const float* __restrict__ planes, PlaneMeta meta) {
+    __shared__ uint32_t s_res[kMaxScales][4], s_off[kMaxScales][6];
+    if (threadIdx.x < kMaxScales * 4) s_res[threadIdx.x >> 2][threadIdx.x & 3] = meta.res[threadIdx.x >> 2][threadIdx.x & 3];
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + kMaxScales * 6) {
+        const uint32_t i = threadIdx.x - 64;
+        s_off[i / 6][i % 6] = meta.off[i / 6][i % 6];
+    }
+    __syncthreads();
+    const uint32_t lanes_per_item = 2u * meta.n_scales;  // 8 for the reference's four scales (launcher: n_scales in {1, 2, 4})
+    const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t item = tid / lanes_per_item, li = tid - item * lanes_per_item;
+    const uint32_t s = li >> 1, half = li & 1u;
+    const uint32_t n_chunks = (M + kRun - 1) / kRun;
+    const uint32_t chunk = item / (uint32_t)ev.n, e = item - chunk * (uint32_t)ev.n;  // the evaluations of a chunk are neighbours
+    if (chunk >= n_chunks) return;
+    const int grp = ev.grp[e];
+    const int pairs[3] = {grp == 0 ? 0 : 2, grp == 0 ? 1 : 4, grp == 0 ? 3 : 5};
+    uint32_t W[3], H[3];
+    const float* base[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        W[j] = s_res[s][kPa[pairs[j]]];
+        H[j] = s_res[s][kPb[pairs[j]]];
+        base[j] = planes + s_off[s][pairs[j]] + half * 4u;
+    }
+    const float* off = ev.off[e];
+    const uint32_t off_stride = ev.off_stride[e], off_col = ev.off_col[e];
+    const bool t_from_x = ev.t_from_x[e] != 0;
+    const float t_const = ev.t[e];
+    float* out = ev.out[e] + (size_t)s * kC + half * 4u;
+    const uint32_t stride = meta.n_scales * kC;
+    uint32_t key[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+    float4 tex[3][4];
+    const uint32_t m0 = chunk * kRun, m1 = m0 + kRun < M ? m0 + kRun : M;
+    for (uint32_t m = m0; m < m1; ++m) {
+        const float* px = ev.x + (size_t)m * ev.x_stride;
+        float p[4] = {px[0], px[1], px[2], t_from_x ? px[3] : t_const};
+        if (off) {
+            const float* po = off + (size_t)m * off_stride + off_col;
+            p[0] = p[0] + po[0]; p[1] = p[1] + po[1]; p[2] = p[2] + po[2];
+        }
+        float4 f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const Tap t = make_tap(p[kPa[pairs[j]]], p[kPb[pairs[j]]], W[j], H[j]);
+            if (t.i00 != key[j]) {  // (X0, Y0) fixes all four taps: gather the cell's half-texels again
+                key[j] = t.i00;
+                tex[j][0] = *reinterpret_cast<const float4*>(base[j] + (size_t)t.i00 * kC);
+                tex[j][1] = *reinterpret_cast<const float4*>(base[j] + (size_t)t.i01 * kC);
+                tex[j][2] = *reinterpret_cast<const float4*>(base[j] + (size_t)t.i10 * kC);
+                tex[j][3] = *reinterpret_cast<const float4*>(base[j] + (size_t)t.i11 * kC);
+            }
+            float4 v;
+            v.x = ((tex[j][0].x * t.nw + tex[j][1].x * t.ne) + tex[j][2].x * t.sw) + tex[j][3].x * t.se;
+            v.y = ((tex[j][0].y * t.nw + tex[j][1].y * t.ne) + tex[j][2].y * t.sw) + tex[j][3].y * t.se;
+            v.z = ((tex[j][0].z * t.nw + tex[j][1].z * t.ne) + tex[j][2].z * t.sw) + tex[j][3].z * t.se;
+            v.w = ((tex[j][0].w * t.nw + tex[j][1].w * t.ne) + tex[j][2].w * t.sw) + tex[j][3].w * t.se;
+            if (j == 0) f = v;
+            else { f.x = f.x * v.x; f.y = f.y * v.y; f.z = f.z * v.z; f.w = f.w * v.w; }
+        }
+        *reinterpret_cast<float4*>(out + (size_t)m * stride) = f;
+    }
+}
+
 // Backward: one thread = one sample (loops over scales so that grad_xt needs no atomics); plane gradients are
 // fp32 atomics into the channel-last gradient buffer.
 __global__ __launch_bounds__(kBlock) void k_planes_bwd(const float* __restrict__ xt, uint32_t M, const float* __restrict__ planes,
@@ -294,8 +388,46 @@ NVSF_API int nvsf_planes_fwd(const float* xt, uint32_t M, const float* planes_cl
     PlaneMeta meta;
     const int st = fill_plane_meta(meta, n_scales, h_res);
     if (st != NVSF_OK) return st;
-    hipLaunchKernelGGL(k_planes_fwd, dim3(cdiv(M, kBlock), n_scales), dim3(kBlock), 0, stream, xt, M, planes_cl, meta, want, out_static,
-                       out_dynamic);
+    const char* variant = getenv("NVSF_PLANES_FWD");  // "sample": one thread per (sample, scale) -- the first formulation, test reference
+    const bool runs_ok = n_scales == 1 || n_scales == 2 || n_scales == 4;
+    if ((variant && variant[0] == 's') || !runs_ok) {
+        hipLaunchKernelGGL(k_planes_fwd, dim3(cdiv(M, kBlock), n_scales), dim3(kBlock), 0, stream, xt, M, planes_cl, meta, want, out_static,
+                           out_dynamic);
+        return nvsf_launch_status();
+    }
+    PlaneEvals ev = {};
+    ev.x = xt; ev.x_stride = 4; ev.n = 0;
+    for (int grp = 0; grp < 2; ++grp) {
+        if (!(want & (1 << grp))) continue;
+        ev.grp[ev.n] = grp; ev.off[ev.n] = nullptr; ev.t_from_x[ev.n] = 1; ev.out[ev.n] = grp == 0 ? out_static : out_dynamic;
+        ++ev.n;
+    }
+    const unsigned long long threads = (unsigned long long)cdiv(M, kRun) * ev.n * 2u * n_scales;
+    hipLaunchKernelGGL(k_planes_fwd_runs, dim3((uint32_t)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, ev, M, planes_cl, meta);
+    return nvsf_launch_status();
+}
+
+NVSF_API int nvsf_planes_multi_fwd(const float* x, uint32_t x_stride, uint32_t M, const float* planes_cl, uint32_t n_scales, uint32_t C,
+                                   const uint32_t* h_res, uint32_t n_evals, const int* h_group, const float* const* h_offsets,
+                                   const uint32_t* h_offset_stride, const uint32_t* h_offset_col, const float* h_time,
+                                   float* const* h_out, hipStream_t stream) {
+    if (M == 0 || n_evals == 0) return NVSF_OK;
+    REQUIRE(x && planes_cl && h_group && h_offsets && h_offset_stride && h_offset_col && h_time && h_out && x_stride >= 3);
+    REQUIRE(n_evals <= (uint32_t)kMaxEval && (reinterpret_cast<uintptr_t>(planes_cl) & 15u) == 0);
+    if (C != (uint32_t)kC || !(n_scales == 1 || n_scales == 2 || n_scales == 4)) return NVSF_ERR_UNSUPPORTED;
+    PlaneMeta meta;
+    const int st = fill_plane_meta(meta, n_scales, h_res);
+    if (st != NVSF_OK) return st;
+    PlaneEvals ev = {};
+    ev.x = x; ev.x_stride = x_stride; ev.n = (int)n_evals;
+    for (uint32_t e = 0; e < n_evals; ++e) {
+        REQUIRE((h_group[e] == 0 || h_group[e] == 1) && h_out[e] && (reinterpret_cast<uintptr_t>(h_out[e]) & 15u) == 0);
+        REQUIRE(!h_offsets[e] || h_offset_stride[e] >= h_offset_col[e] + 3);
+        ev.grp[e] = h_group[e]; ev.off[e] = h_offsets[e]; ev.off_stride[e] = h_offset_stride[e]; ev.off_col[e] = h_offset_col[e];
+        ev.t[e] = h_time[e]; ev.t_from_x[e] = 0; ev.out[e] = h_out[e];
+    }
+    const unsigned long long threads = (unsigned long long)cdiv(M, kRun) * ev.n * 2u * n_scales;
+    hipLaunchKernelGGL(k_planes_fwd_runs, dim3((uint32_t)((threads + kBlock - 1) / kBlock)), dim3(kBlock), 0, stream, ev, M, planes_cl, meta);
     return nvsf_launch_status();
 }
 

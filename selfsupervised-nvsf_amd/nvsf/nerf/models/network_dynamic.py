@@ -131,7 +131,6 @@ class NeRFNetwork(NeRFRenderer):
         gather latency, and the neighbours' re-gathers hit L1 anyway.)"""
         F = self.num_frames
         xt = torch.cat([x, t.float().expand(x.shape[0], 1)], dim=-1)
-        plane_s, plane_d = planes_enc(xt)
         flow = self.flow_net(xt, t_host)
         hash_s = hash_enc.forward_static(x)
         nb = []
@@ -140,16 +139,18 @@ class NeRFNetwork(NeRFRenderer):
             nb.append((torch.tensor(frame / F), float(np.float32(frame / F)), col) if 0 <= frame <= F - 1 else None)
         # ONE launch for the three space-time evaluations: a neighbour re-uses the base gathers wherever its cell coincides
         hash_d, hash_1, hash_2 = hash_enc.forward_dynamic3(x, t, t_host, flow, nb)
-        out = [plane_s, plane_d, plane_d, plane_d, hash_s, hash_d, hash_d if hash_1 is None else hash_1, hash_d if hash_2 is None else hash_2]
-        for slot, col, frame in ((0, 0, frame_idx + 1), (1, 3, frame_idx - 1)):
-            if not 0 <= frame <= F - 1:
-                continue
-            tn = nb[slot][0]
-            xtn = torch.empty_like(xt)
-            torch.add(x, flow[:, col:col + 3], out=xtn[:, :3])
-            xtn[:, 3] = float(tn)
-            out[2 + slot] = planes_enc.forward_dynamic(xtn)
-        return tuple(out)
+        # ONE launch for the K-planes: static + dynamic at (x, t) + dynamic at the flow-warped positions of the neighbour
+        # frames (x + flow read inside the kernel; the reference builds [M,4] copies, :250-252, :265-267)
+        evals = [(0, None, 0, float(np.float32(t_host))), (1, None, 0, float(np.float32(t_host)))]
+        for n_ in nb:
+            if n_ is not None:
+                evals.append((1, flow, n_[2], float(n_[0])))
+        feats = planes_enc.forward_multi(x, evals)
+        plane_s, plane_d = feats[0], feats[1]
+        rest = iter(feats[2:])
+        plane_1 = next(rest) if nb[0] is not None else plane_d
+        plane_2 = next(rest) if nb[1] is not None else plane_d
+        return (plane_s, plane_d, plane_1, plane_2, hash_s, hash_d, hash_d if hash_1 is None else hash_1, hash_d if hash_2 is None else hash_2)
 
     def density(self, x, t=None, cal_lidar_color=False, **kwargs):
         plane_s, plane_d, plane_1, plane_2, hash_s, hash_d, hash_1, hash_2 = self._dynamic_features(self._unit_cube(x), t, cal_lidar_color)

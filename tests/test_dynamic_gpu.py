@@ -440,3 +440,44 @@ def test_training_graph_gradients_match_reference(dev, net, key):
         # the reference's feature gradients are fp16 tensors: entries whose every contribution lies below 6e-8 are exactly zero
         # there and tiny here (fp32 transport) -- up to 3 % more non-zeros, never fewer
         assert -0.002 * int(ref["nnz"]) <= int(sig["nnz"]) - int(ref["nnz"]) <= 0.03 * int(ref["nnz"])
+
+
+@pytest.mark.parametrize("M,kind", [(64 * 50, "rays"), (1000, "random"), (7, "random"), (64 * 33 + 5, "rays")])
+def test_planes_forward_along_rays_is_bit_identical_and_multi_eval(dev, M, kind, monkeypatch):
+    """k_planes_fwd_runs (items walk consecutive rows and re-gather only when a plane's texel cell changes) against the
+    one-thread-per-(sample, scale) kernel it replaces (NVSF_PLANES_FWD=sample; itself pinned by the reference's fixtures):
+    bit-identical static and dynamic features on ray-ordered and on random rows; and nvsf_planes_multi_fwd (static + dynamic +
+    two flow-warped dynamic evaluations in one launch) equals the separate calls on explicitly built [M,4] inputs."""
+    from nvsf.nerf.models.planes_field import Planes4D
+    torch.manual_seed(3)
+    enc = Planes4D(resolution=[32, 32, 32, 8], multiscale_res=[1, 2, 4, 8]).to(dev)
+    with torch.no_grad():
+        for p in enc.parameters():
+            p.copy_(torch.rand_like(p) + 0.1)
+    rng = np.random.default_rng(M)
+    if kind == "rays":
+        T = 64
+        n_rays = (M + T - 1) // T
+        o = rng.random((n_rays, 1, 3)) * 0.6 + 0.2
+        d = rng.standard_normal((n_rays, 1, 3)); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+        x = np.clip(o + d * np.linspace(0, 0.5, T).reshape(1, T, 1), 0, 1).reshape(-1, 3)[:M]
+    else:
+        x = rng.random((M, 3))
+        x[:3] = [[0, 0, 0], [1, 1, 1], [0.999999, 1e-7, 0.5]][:min(3, M)]
+    x = _t(x.astype(np.float32), dev)
+    tv = 0.37
+    xt = torch.cat([x, torch.full((M, 1), tv, device=dev)], -1)
+    with torch.no_grad():
+        s1, d1 = enc(xt)
+        d_only = enc.forward_dynamic(xt)
+        monkeypatch.setenv("NVSF_PLANES_FWD", "sample")
+        s0, d0 = enc(xt)
+        monkeypatch.delenv("NVSF_PLANES_FWD")
+        assert torch.equal(s1, s0) and torch.equal(d1, d0) and torch.equal(d_only, d0)
+        flow = (torch.rand(M, 8, device=dev) - 0.5) * 0.02  # rows wider than the six flow components (padded MLP output)
+        t1, t2 = 0.4, 0.34375
+        outs = enc.forward_multi(x, [(0, None, 0, float(np.float32(tv))), (1, None, 0, float(np.float32(tv))), (1, flow, 0, t1), (1, flow, 3, t2)])
+        assert torch.equal(outs[0], s0) and torch.equal(outs[1], d0)
+        for o_, col, tn in ((outs[2], 0, t1), (outs[3], 3, t2)):
+            xtn = torch.cat([x + flow[:, col:col + 3], torch.full((M, 1), tn, device=dev)], -1)
+            assert torch.equal(o_, enc.forward_dynamic(xtn))
