@@ -245,11 +245,13 @@ int nvsf_planes_fwd(const float* xt, uint32_t M, const float* planes_cl, uint32_
  * yz) or dynamic (1: xt, yt, zt) plane group at positions x[m, 0:3] (+ h_offsets[e][m, h_offset_col[e] : +3] when that pointer is
  * not NULL: the scene flow towards a neighbour frame, network_dynamic.py:242-271; same fp32 add as torch.add) and time
  * h_time[e]; features go to h_out[e] fp32 [M, n_scales*C] (16-byte aligned).  x fp32 [M, x_stride >= 3] in [0,1].  At most 4
- * evaluations; the h_* arrays are host arrays of n_evals entries.  n_scales in {1, 2, 4}, C = 8. */
+ * evaluations; the h_* arrays are host arrays of n_evals entries.  n_scales = 4 (the reference's configuration), C = 8.
+ * blend != 0: the evaluations must be (static, dynamic, dynamic at neighbour 1, dynamic at neighbour 2); h_out[1] then receives
+ * 0.5 d + 0.25 (d1 + d2) -- the neighbour blend of network_dynamic.py:273 -- and h_out[2], h_out[3] are not written (may be NULL). */
 int nvsf_planes_multi_fwd(const float* x, uint32_t x_stride, uint32_t M, const float* planes_cl, uint32_t n_scales, uint32_t C,
                           const uint32_t* h_res, uint32_t n_evals, const int* h_group, const float* const* h_offsets,
                           const uint32_t* h_offset_stride, const uint32_t* h_offset_col, const float* h_time,
-                          float* const* h_out, nvsf_stream_t stream);
+                          float* const* h_out, int blend, nvsf_stream_t stream);
 
 /* autograd of the above: grad_planes_cl (same layout as planes_cl, fp32 atomics, caller zero-initialises; may be
  * NULL) and grad_xt [M,4] (may be NULL). */

@@ -139,23 +139,51 @@ struct PlaneEvals {
     float t[kMaxEval];         // time coordinate ...
     int t_from_x[kMaxEval];    // ... unless taken from column 3 of x
     float* out[kMaxEval];      // [M, n_scales * 8]
+    int blend;                 // 1: the evaluations are (static, dynamic, dynamic at neighbour 1, dynamic at neighbour 2) and out[1]
+                               // receives 0.5 d + 0.25 (d1 + d2) (network_dynamic.py:273); out[2], out[3] are not written
 };
 
 __global__ __launch_bounds__(kBlock) void k_planes_fwd_runs(PlaneEvals ev, uint32_t M, const float* __restrict__ planes, PlaneMeta meta) {
     __shared__ uint32_t s_res[kMaxScales][4], s_off[kMaxScales][6];
+    // positions of the block's 32 items (x + offset, time), staged once: a row per item, padded by one float4 so that the eight
+    // items of a wave read different banks (the eight lanes of an item read the same word: a broadcast)
+    __shared__ float4 s_pos[kBlock / 8][kRun + 1];
     if (threadIdx.x < kMaxScales * 4) s_res[threadIdx.x >> 2][threadIdx.x & 3] = meta.res[threadIdx.x >> 2][threadIdx.x & 3];
     if (threadIdx.x >= 64 && threadIdx.x < 64 + kMaxScales * 6) {
         const uint32_t i = threadIdx.x - 64;
         s_off[i / 6][i % 6] = meta.off[i / 6][i % 6];
     }
-    __syncthreads();
-    const uint32_t lanes_per_item = 2u * meta.n_scales;  // 8 for the reference's four scales (launcher: n_scales in {1, 2, 4})
+    constexpr uint32_t lanes_per_item = 8;  // four scales x two channel halves (the launcher takes other scale counts elsewhere)
     const uint32_t tid = blockIdx.x * kBlock + threadIdx.x;
-    const uint32_t item = tid / lanes_per_item, li = tid - item * lanes_per_item;
+    const uint32_t item = tid / lanes_per_item, li = tid - item * lanes_per_item, item_local = threadIdx.x / lanes_per_item;
     const uint32_t s = li >> 1, half = li & 1u;
     const uint32_t n_chunks = (M + kRun - 1) / kRun;
-    const uint32_t chunk = item / (uint32_t)ev.n, e = item - chunk * (uint32_t)ev.n;  // the evaluations of a chunk are neighbours
-    if (chunk >= n_chunks) return;
+    uint32_t chunk = item / (uint32_t)ev.n;
+    const uint32_t e = item - chunk * (uint32_t)ev.n;  // the evaluations of a chunk are neighbours
+    const bool active = chunk < n_chunks;
+    if (!active) chunk = 0;
+    {   // stage the item's positions: lane li takes rows li, li + 8, ... (independent loads, all in flight together -- read one
+        // row per step inside the loop instead and every step waits for a dependent global load)
+        const float* soff = ev.off[e];
+        const uint32_t so_stride = ev.off_stride[e], so_col = ev.off_col[e];
+        const bool tx = ev.t_from_x[e] != 0;
+        const float tc = ev.t[e];
+        const uint32_t mb = chunk * kRun;
+        for (uint32_t k = li; k < (uint32_t)kRun; k += lanes_per_item) {
+            const uint32_t m = mb + k;
+            if (active && m < M) {
+                const float* px = ev.x + (size_t)m * ev.x_stride;
+                float4 p = make_float4(px[0], px[1], px[2], tx ? px[3] : tc);
+                if (soff) {
+                    const float* po = soff + (size_t)m * so_stride + so_col;
+                    p.x = p.x + po[0]; p.y = p.y + po[1]; p.z = p.z + po[2];
+                }
+                s_pos[item_local][k] = p;
+            }
+        }
+    }
+    __syncthreads();
+    if (!active) return;
     const int grp = ev.grp[e];
     const int pairs[3] = {grp == 0 ? 0 : 2, grp == 0 ? 1 : 4, grp == 0 ? 3 : 5};
     uint32_t W[3], H[3];
@@ -166,40 +194,74 @@ __global__ __launch_bounds__(kBlock) void k_planes_fwd_runs(PlaneEvals ev, uint3
         H[j] = s_res[s][kPb[pairs[j]]];
         base[j] = planes + s_off[s][pairs[j]] + half * 4u;
     }
-    const float* off = ev.off[e];
-    const uint32_t off_stride = ev.off_stride[e], off_col = ev.off_col[e];
     const bool t_from_x = ev.t_from_x[e] != 0;
     const float t_const = ev.t[e];
     float* out = ev.out[e] + (size_t)s * kC + half * 4u;
     const uint32_t stride = meta.n_scales * kC;
+    // One coordinate axis of make_tap: u = ((p * 2 - 1 + 1) / 2) * (R - 1) clamped into the image, its cell and the two linear
+    // weights (x1 - u, u - x0).  A plane's bilinear weights are products of two axes' weights -- the same products, in the same
+    // order, as make_tap forms them -- so the three planes of a group share three (static) or four (dynamic; the time axis is
+    // constant along the chunk) axis evaluations instead of six.
+    struct Axis { uint32_t c0, c1; float w0, w1; };
+    auto axis = [](float pv, uint32_t R) {
+        Axis a;
+        float u = ((pv * 2.0f - 1.0f + 1.0f) / 2.0f) * (float)(R - 1);
+        u = fminf((float)(R - 1), fmaxf(u, 0.0f));
+        const float f0 = floorf(u), f1 = f0 + 1.0f;
+        a.w0 = f1 - u;
+        a.w1 = u - f0;
+        a.c0 = (uint32_t)f0;
+        a.c1 = a.c0 + 1 < R ? a.c0 + 1 : R - 1;
+        return a;
+    };
+    const Axis at = axis(t_const, s_res[s][3]);  // used by the dynamic group unless the time comes from the rows
     uint32_t key[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
     float4 tex[3][4];
     const uint32_t m0 = chunk * kRun, m1 = m0 + kRun < M ? m0 + kRun : M;
     for (uint32_t m = m0; m < m1; ++m) {
-        const float* px = ev.x + (size_t)m * ev.x_stride;
-        float p[4] = {px[0], px[1], px[2], t_from_x ? px[3] : t_const};
-        if (off) {
-            const float* po = off + (size_t)m * off_stride + off_col;
-            p[0] = p[0] + po[0]; p[1] = p[1] + po[1]; p[2] = p[2] + po[2];
-        }
+        const float4 pp = s_pos[item_local][m - m0];
+        const float p[3] = {pp.x, pp.y, pp.z};
+        Axis ax[4];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) ax[d] = axis(p[d], s_res[s][d]);
+        ax[3] = t_from_x ? axis(pp.w, s_res[s][3]) : at;
         float4 f;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const Tap t = make_tap(p[kPa[pairs[j]]], p[kPb[pairs[j]]], W[j], H[j]);
-            if (t.i00 != key[j]) {  // (X0, Y0) fixes all four taps: gather the cell's half-texels again
-                key[j] = t.i00;
-                tex[j][0] = *reinterpret_cast<const float4*>(base[j] + (size_t)t.i00 * kC);
-                tex[j][1] = *reinterpret_cast<const float4*>(base[j] + (size_t)t.i01 * kC);
-                tex[j][2] = *reinterpret_cast<const float4*>(base[j] + (size_t)t.i10 * kC);
-                tex[j][3] = *reinterpret_cast<const float4*>(base[j] + (size_t)t.i11 * kC);
+            const Axis& A = ax[grp == 0 ? (j == 2 ? 1 : 0) : j];   // pairs (x,y) (x,z) (y,z) | (x,t) (y,t) (z,t): first axis = image x
+            const Axis& B = ax[grp == 0 ? (j == 0 ? 1 : 2) : 3];   //                                            second axis = image y
+            const float nw = A.w0 * B.w0, ne = A.w1 * B.w0, sw = A.w0 * B.w1, se = A.w1 * B.w1;
+            const uint32_t i00 = B.c0 * W[j] + A.c0;
+            if (i00 != key[j]) {  // (X0, Y0) fixes all four taps: gather the cell's half-texels again
+                key[j] = i00;
+                const uint32_t i01 = B.c0 * W[j] + A.c1, i10 = B.c1 * W[j] + A.c0, i11 = B.c1 * W[j] + A.c1;
+                tex[j][0] = *reinterpret_cast<const float4*>(base[j] + (size_t)i00 * kC);
+                tex[j][1] = *reinterpret_cast<const float4*>(base[j] + (size_t)i01 * kC);
+                tex[j][2] = *reinterpret_cast<const float4*>(base[j] + (size_t)i10 * kC);
+                tex[j][3] = *reinterpret_cast<const float4*>(base[j] + (size_t)i11 * kC);
             }
             float4 v;
-            v.x = ((tex[j][0].x * t.nw + tex[j][1].x * t.ne) + tex[j][2].x * t.sw) + tex[j][3].x * t.se;
-            v.y = ((tex[j][0].y * t.nw + tex[j][1].y * t.ne) + tex[j][2].y * t.sw) + tex[j][3].y * t.se;
-            v.z = ((tex[j][0].z * t.nw + tex[j][1].z * t.ne) + tex[j][2].z * t.sw) + tex[j][3].z * t.se;
-            v.w = ((tex[j][0].w * t.nw + tex[j][1].w * t.ne) + tex[j][2].w * t.sw) + tex[j][3].w * t.se;
+            v.x = ((tex[j][0].x * nw + tex[j][1].x * ne) + tex[j][2].x * sw) + tex[j][3].x * se;
+            v.y = ((tex[j][0].y * nw + tex[j][1].y * ne) + tex[j][2].y * sw) + tex[j][3].y * se;
+            v.z = ((tex[j][0].z * nw + tex[j][1].z * ne) + tex[j][2].z * sw) + tex[j][3].z * se;
+            v.w = ((tex[j][0].w * nw + tex[j][1].w * ne) + tex[j][2].w * sw) + tex[j][3].w * se;
             if (j == 0) f = v;
             else { f.x = f.x * v.x; f.y = f.y * v.y; f.z = f.z * v.z; f.w = f.w * v.w; }
+        }
+        if (ev.blend) {
+            // the four evaluations of a chunk sit on 32 adjacent lanes (8 each, same (scale, half) at the same offset): the base
+            // evaluation's lanes fetch the neighbours' features of this row from the lanes 8 and 16 further on
+            const int src1 = (int)((threadIdx.x & 63u) + 8u) & 63, src2 = (int)((threadIdx.x & 63u) + 16u) & 63;
+            float4 a, b;
+            a.x = __shfl(f.x, src1); a.y = __shfl(f.y, src1); a.z = __shfl(f.z, src1); a.w = __shfl(f.w, src1);
+            b.x = __shfl(f.x, src2); b.y = __shfl(f.y, src2); b.z = __shfl(f.z, src2); b.w = __shfl(f.w, src2);
+            if (e == 1u) {
+                f.x = 0.5f * f.x + 0.25f * (a.x + b.x);
+                f.y = 0.5f * f.y + 0.25f * (a.y + b.y);
+                f.z = 0.5f * f.z + 0.25f * (a.z + b.z);
+                f.w = 0.5f * f.w + 0.25f * (a.w + b.w);
+            }
+            if (e >= 2u) continue;
         }
         *reinterpret_cast<float4*>(out + (size_t)m * stride) = f;
     }
@@ -389,7 +451,7 @@ NVSF_API int nvsf_planes_fwd(const float* xt, uint32_t M, const float* planes_cl
     const int st = fill_plane_meta(meta, n_scales, h_res);
     if (st != NVSF_OK) return st;
     const char* variant = getenv("NVSF_PLANES_FWD");  // "sample": one thread per (sample, scale) -- the first formulation, test reference
-    const bool runs_ok = n_scales == 1 || n_scales == 2 || n_scales == 4;
+    const bool runs_ok = n_scales == 4;
     if ((variant && variant[0] == 's') || !runs_ok) {
         hipLaunchKernelGGL(k_planes_fwd, dim3(cdiv(M, kBlock), n_scales), dim3(kBlock), 0, stream, xt, M, planes_cl, meta, want, out_static,
                            out_dynamic);
@@ -410,18 +472,20 @@ NVSF_API int nvsf_planes_fwd(const float* xt, uint32_t M, const float* planes_cl
 NVSF_API int nvsf_planes_multi_fwd(const float* x, uint32_t x_stride, uint32_t M, const float* planes_cl, uint32_t n_scales, uint32_t C,
                                    const uint32_t* h_res, uint32_t n_evals, const int* h_group, const float* const* h_offsets,
                                    const uint32_t* h_offset_stride, const uint32_t* h_offset_col, const float* h_time,
-                                   float* const* h_out, hipStream_t stream) {
+                                   float* const* h_out, int blend, hipStream_t stream) {
     if (M == 0 || n_evals == 0) return NVSF_OK;
     REQUIRE(x && planes_cl && h_group && h_offsets && h_offset_stride && h_offset_col && h_time && h_out && x_stride >= 3);
     REQUIRE(n_evals <= (uint32_t)kMaxEval && (reinterpret_cast<uintptr_t>(planes_cl) & 15u) == 0);
-    if (C != (uint32_t)kC || !(n_scales == 1 || n_scales == 2 || n_scales == 4)) return NVSF_ERR_UNSUPPORTED;
+    if (C != (uint32_t)kC || n_scales != 4) return NVSF_ERR_UNSUPPORTED;
     PlaneMeta meta;
     const int st = fill_plane_meta(meta, n_scales, h_res);
     if (st != NVSF_OK) return st;
     PlaneEvals ev = {};
     ev.x = x; ev.x_stride = x_stride; ev.n = (int)n_evals;
+    ev.blend = blend ? 1 : 0;
+    if (blend) REQUIRE(n_evals == 4 && h_group[0] == 0 && h_group[1] == 1 && h_group[2] == 1 && h_group[3] == 1);
     for (uint32_t e = 0; e < n_evals; ++e) {
-        REQUIRE((h_group[e] == 0 || h_group[e] == 1) && h_out[e] && (reinterpret_cast<uintptr_t>(h_out[e]) & 15u) == 0);
+        REQUIRE((h_group[e] == 0 || h_group[e] == 1) && (h_out[e] || (blend && e >= 2)) && (reinterpret_cast<uintptr_t>(h_out[e]) & 15u) == 0);
         REQUIRE(!h_offsets[e] || h_offset_stride[e] >= h_offset_col[e] + 3);
         ev.grp[e] = h_group[e]; ev.off[e] = h_offsets[e]; ev.off_stride[e] = h_offset_stride[e]; ev.off_col[e] = h_offset_col[e];
         ev.t[e] = h_time[e]; ev.t_from_x[e] = 0; ev.out[e] = h_out[e];

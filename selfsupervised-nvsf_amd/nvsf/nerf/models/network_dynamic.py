@@ -141,15 +141,15 @@ class NeRFNetwork(NeRFRenderer):
         hash_d, hash_1, hash_2 = hash_enc.forward_dynamic3(x, t, t_host, flow, nb)
         # ONE launch for the K-planes: static + dynamic at (x, t) + dynamic at the flow-warped positions of the neighbour
         # frames (x + flow read inside the kernel; the reference builds [M,4] copies, :250-252, :265-267)
-        evals = [(0, None, 0, float(np.float32(t_host))), (1, None, 0, float(np.float32(t_host)))]
+        # ... and the blend 0.5 d + 0.25 (d1 + d2) of :273 is formed inside the kernel: the neighbour features never reach memory.
+        # A missing neighbour (first / last frame) is the base evaluation itself, as in the reference (plane_feat_1 = plane_feat_d).
+        base = (1, None, 0, float(np.float32(t_host)))
+        evals = [(0, None, 0, float(np.float32(t_host))), base]
         for n_ in nb:
-            if n_ is not None:
-                evals.append((1, flow, n_[2], float(n_[0])))
-        feats = planes_enc.forward_multi(x, evals)
-        plane_s, plane_d = feats[0], feats[1]
-        rest = iter(feats[2:])
-        plane_1 = next(rest) if nb[0] is not None else plane_d
-        plane_2 = next(rest) if nb[1] is not None else plane_d
+            evals.append(base if n_ is None else (1, flow, n_[2], float(n_[0])))
+        plane_s, plane_d = planes_enc.forward_multi(x, evals, blend=True)
+        # plane_d is already blended: 0.5 v + 0.25 (v + v) == v exactly, so the density kernel's own blend leaves it unchanged
+        plane_1 = plane_2 = plane_d
         return (plane_s, plane_d, plane_1, plane_2, hash_s, hash_d, hash_d if hash_1 is None else hash_1, hash_d if hash_2 is None else hash_2)
 
     def density(self, x, t=None, cal_lidar_color=False, **kwargs):

@@ -186,7 +186,10 @@ def test_fused_dynamic_features_equal_the_separate_launches(dev, flow_scale, t_v
         with torch.no_grad():
             feats = m._dynamic_features(m._unit_cube(x), t, True)
             dens = m.density(x, t, cal_lidar_color=True)
-        outs[mode] = [f.float() for f in feats] + [dens["sigma"], dens["geo_feat"].float()]
+        f = [v.float() for v in feats]
+        # the fused form blends the K-planes neighbours inside its kernel (plane_d == plane_1 == plane_2 == the blend): compare the
+        # blend network_dynamic.py:273 forms, which is what enters the density MLP either way
+        outs[mode] = [f[0], 0.5 * f[1] + 0.25 * (f[2] + f[3])] + f[4:] + [dens["sigma"], dens["geo_feat"].float()]
     with torch.no_grad():
         assert float(m.flow_net(torch.cat([m._unit_cube(x), t.expand(x.shape[0], 1)], -1)).abs().mean()) > 0.1 * flow_scale
     for a, b in zip(outs["1"], outs["0"]):
@@ -481,3 +484,8 @@ def test_planes_forward_along_rays_is_bit_identical_and_multi_eval(dev, M, kind,
         for o_, col, tn in ((outs[2], 0, t1), (outs[3], 3, t2)):
             xtn = torch.cat([x + flow[:, col:col + 3], torch.full((M, 1), tn, device=dev)], -1)
             assert torch.equal(o_, enc.forward_dynamic(xtn))
+        # blend mode: [static, 0.5 d + 0.25 (d1 + d2)] formed in the kernel == the same expression on the separate outputs
+        evals = [(0, None, 0, float(np.float32(tv))), (1, None, 0, float(np.float32(tv))), (1, flow, 0, t1), (1, flow, 3, t2)]
+        bs, bd = enc.forward_multi(x, evals, blend=True)
+        assert torch.equal(bs, s0) and torch.equal(bd, 0.5 * outs[1] + 0.25 * (outs[2] + outs[3]))
+        assert torch.equal(0.5 * bd + 0.25 * (bd + bd), bd)  # what the density kernel's own blend makes of an already blended input
