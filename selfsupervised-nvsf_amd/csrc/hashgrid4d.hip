@@ -10,6 +10,7 @@
 //   mode 0 ("tensor t"): blend and reduction in fp32, output fp32;
 //   mode 1 ("0-dim t", the flow-warped neighbour frames): every product and every sum is rounded to fp16.
 // Both are reproduced operation by operation (tests/test_dynamic_gpu.py against fixtures from the reference code).
+#include <stdlib.h>
 #include "hashgrid_device.h"
 
 namespace {
@@ -404,6 +405,47 @@ __global__ __launch_bounds__(kBlock) void k_hash_dynamic_bwd_scalar(const float*
     if (acc != 0.0f) atomicAdd(dst, acc);
 }
 
+// The same sums through LDS (the form nvsf_hashgrid4d_dynamic_bwd_scalar launches).  A time-sliced 2-D grid has 2^13 - 2^15
+// rows per level (hash_size_dynamic = [15, 13, 13], hash_field.py:96): ONE level of ONE pair is a 32 - 128 KB table of scalar
+// sums -- it fits the 160 KB of LDS of a CU.  So a workgroup owns (pair, level, slice of the samples), accumulates its slice
+// into an LDS copy of that level with LDS atomics (no memory-side atomic per sample and corner: those cost one 64-byte
+// segment each, 2.96 ms per 1.6 M samples in the run-merging kernel above) and adds the copy to the global sums once, with
+// contiguous atomics (the full-rate shape).  Same products w_corner * g as k_hash_dynamic_bwd_scalar, summed in another order.
+__global__ void k_hash_dynamic_bwd_lds(const float* __restrict__ x, uint32_t x_stride, uint32_t M, const float* __restrict__ grad_out,
+                                       PlaneSums pg, uint32_t pl0, uint32_t chunk_len) {
+    extern __shared__ float s_tab[];
+    const uint32_t pl = pl0 + blockIdx.y / kPlaneLevels, l = blockIdx.y % kPlaneLevels;
+    const GridMeta& g = pg.meta[pl];
+    const float scale = g.scale[l];
+    const uint32_t res = g.res[l], row0 = g.offset[l], hsize = g.offset[l + 1] - row0;
+    for (uint32_t i = threadIdx.x; i < hsize; i += blockDim.x) s_tab[i] = 0.0f;
+    __syncthreads();
+    const uint32_t ca = pl == 2 ? 1u : 0u, cb = pl == 0 ? 1u : 2u;
+    const unsigned long long first = (unsigned long long)blockIdx.x * chunk_len;
+    const uint32_t m0 = (uint32_t)(first < M ? first : M), m1 = (uint32_t)(first + chunk_len < M ? first + chunk_len : M);
+    for (uint32_t m = m0 + threadIdx.x; m < m1; m += blockDim.x) {
+        const float go = grad_out[(size_t)m * (3 * kPlaneLevels) + pl * kPlaneLevels + l];
+        if (go == 0.0f) continue;
+        const float xa = x[(size_t)m * x_stride + ca], xb = x[(size_t)m * x_stride + cb];
+        const float pa = fmaf(scale, xa, 0.5f), pb = fmaf(scale, xb, 0.5f);
+        const float fa = floorf(pa), fb = floorf(pb);
+        const float ra = pa - fa, rb = pb - fb;
+        const uint32_t ia = (uint32_t)(int32_t)fa, ib = (uint32_t)(int32_t)fb;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float w = ((c & 1) ? ra : (1.0f - ra)) * ((c & 2) ? rb : (1.0f - rb));
+            const uint32_t cc[2] = {ia + (uint32_t)(c & 1), ib + (uint32_t)((c >> 1) & 1)};
+            __hip_atomic_fetch_add(&s_tab[grid_row<2>(cc, res, hsize)], w * go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    __syncthreads();
+    float* table = pg.g[pl] + row0;
+    for (uint32_t i = threadIdx.x; i < hsize; i += blockDim.x) {
+        const float v = s_tab[i];
+        if (v != 0.0f) atomicAdd(table + i, v);
+    }
+}
+
 int fill_meta(GridMeta& meta, uint32_t L, const float* scales, const uint32_t* res, const uint32_t* offsets) {
     if (L == 0 || L > (uint32_t)kMaxLevels || !scales || !res || !offsets) return NVSF_ERR_INVALID_ARG;
     for (uint32_t l = 0; l < L; ++l) {
@@ -539,6 +581,35 @@ NVSF_API int nvsf_hashgrid4d_dynamic_bwd_scalar(const float* x, uint32_t x_strid
         REQUIRE(pg.g[p]);
         const int st = fill_meta(pg.meta[p], kPlaneLevels, h_scales + p * kPlaneLevels, h_res + p * kPlaneLevels, h_offsets + p * (kPlaneLevels + 1));
         if (st != NVSF_OK) return st;
+    }
+    // LDS form: one launch per group of pairs with the same level size (pair 0: 2^15 rows = 128 KB of LDS, 1024-thread workgroups;
+    // pairs 1, 2: 2^13 rows = 32 KB).  NVSF_HASH4D_BWD=runs selects the run-merging global-atomic kernel (the test reference; also
+    // taken when a level does not fit LDS or the batch is too small to fill the chip with slices).
+    const char* variant = getenv("NVSF_HASH4D_BWD");
+    uint32_t max_rows[3];
+    bool fits = true;
+    for (int p = 0; p < 3; ++p) {
+        max_rows[p] = 0;
+        for (uint32_t l = 0; l < (uint32_t)kPlaneLevels; ++l) {
+            const uint32_t rows = pg.meta[p].offset[l + 1] - pg.meta[p].offset[l];
+            max_rows[p] = rows > max_rows[p] ? rows : max_rows[p];
+        }
+        fits = fits && max_rows[p] * sizeof(float) <= 128u * 1024u;
+    }
+    if (fits && M >= (1u << 16) && !(variant && variant[0] == 'r')) {
+        int p = 0;
+        while (p < 3) {
+            int q = p + 1;
+            while (q < 3 && max_rows[q] == max_rows[p]) ++q;  // consecutive pairs with equal level size share a launch
+            const uint32_t lds = max_rows[p] * (uint32_t)sizeof(float);
+            const uint32_t threads = lds > 64u * 1024u ? 1024u : 256u;
+            const uint32_t n_slices = lds > 64u * 1024u ? 32u : 64u;
+            const uint32_t chunk_len = (M + n_slices - 1) / n_slices;
+            hipLaunchKernelGGL(k_hash_dynamic_bwd_lds, dim3(n_slices, (uint32_t)(q - p) * kPlaneLevels), dim3(threads), lds, stream, x, x_stride, M,
+                               grad_out, pg, (uint32_t)p, chunk_len);
+            p = q;
+        }
+        return nvsf_launch_status();
     }
     const uint32_t run = M >= (1u << 20) ? 128u : 32u;
     const unsigned long long items = (unsigned long long)cdiv(M, run) * 3ull * kPlaneLevels;

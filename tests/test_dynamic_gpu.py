@@ -489,3 +489,40 @@ def test_planes_forward_along_rays_is_bit_identical_and_multi_eval(dev, M, kind,
         bs, bd = enc.forward_multi(x, evals, blend=True)
         assert torch.equal(bs, s0) and torch.equal(bd, 0.5 * outs[1] + 0.25 * (outs[2] + outs[3]))
         assert torch.equal(0.5 * bd + 0.25 * (bd + bd), bd)  # what the density kernel's own blend makes of an already blended input
+
+
+def test_dynamic_hash_gradient_through_lds_equals_the_run_merging_kernel(dev, monkeypatch):
+    """nvsf_hashgrid4d_dynamic_bwd_scalar: the LDS form (a workgroup accumulates one level of one pair -- 2^13 / 2^15 scalar sums --
+    in LDS and adds it to the global sums once) against the run-merging global-atomic kernel (NVSF_HASH4D_BWD=runs, itself pinned
+    through HashDynFn against the per-slice autograd path above): same sums up to fp32 addition order, on ray-ordered rows, with
+    zero gradients mixed in, accumulating into non-zero buffers."""
+    import ctypes
+    from nvsf import _hip
+    from nvsf.nerf.models.hash_field import HashGrid4D
+    enc = HashGrid4D(time_resolution=4).to(dev)  # reference defaults: 512 -> 32768, hash_size_dynamic [15, 13, 13]
+    specs = [pl.hash_t[0].spec for pl in enc.hash_dynamic]
+    assert [s.n_rows // 8 for s in specs] == [2 ** 15, 2 ** 13, 2 ** 13]
+    rng = np.random.default_rng(8)
+    n_rays, T = 180, 512
+    o = rng.random((n_rays, 1, 3)) * 0.5 + 0.25
+    d = rng.standard_normal((n_rays, 1, 3)); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    x = _t(np.clip(o + d * np.linspace(0, 0.3, T).reshape(1, T, 1), 0, 1).reshape(-1, 3).astype(np.float32), dev)
+    M = x.shape[0]
+    assert M >= 1 << 16
+    g = torch.randn(M, 24, device=dev)
+    g[torch.rand(M, device=dev) < 0.2] = 0.0
+    h_scales = _hip.host_f32([v for s in specs for v in s.scales])
+    h_res = _hip.host_u32([v for s in specs for v in s.res])
+    h_off = _hip.host_u32([v for s in specs for v in s.offsets])
+    out = {}
+    for variant in ("lds", "runs"):
+        if variant == "runs":
+            monkeypatch.setenv("NVSF_HASH4D_BWD", "runs")
+        sums = [torch.full((s.n_rows,), 0.5, dtype=torch.float32, device=dev) for s in specs]
+        _hip.call("nvsf_hashgrid4d_dynamic_bwd_scalar", _hip.ptr(x), 3, M, h_scales, h_res, h_off, _hip.ptr(g),
+                  (ctypes.c_void_p * 3)(*[t.data_ptr() for t in sums]))
+        out[variant] = sums
+    for a, b in zip(out["lds"], out["runs"]):
+        scale = float((b - 0.5).abs().max())
+        assert scale > 0 and float((a - b).abs().max()) <= 2e-5 * scale
+        assert torch.equal(a == 0.5, b == 0.5)  # the same rows are touched
