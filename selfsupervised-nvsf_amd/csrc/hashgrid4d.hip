@@ -423,19 +423,32 @@ __global__ void k_hash_dynamic_bwd_lds(const float* __restrict__ x, uint32_t x_s
     const uint32_t ca = pl == 2 ? 1u : 0u, cb = pl == 0 ? 1u : 2u;
     const unsigned long long first = (unsigned long long)blockIdx.x * chunk_len;
     const uint32_t m0 = (uint32_t)(first < M ? first : M), m1 = (uint32_t)(first + chunk_len < M ? first + chunk_len : M);
-    for (uint32_t m = m0 + threadIdx.x; m < m1; m += blockDim.x) {
-        const float go = grad_out[(size_t)m * (3 * kPlaneLevels) + pl * kPlaneLevels + l];
-        if (go == 0.0f) continue;
-        const float xa = x[(size_t)m * x_stride + ca], xb = x[(size_t)m * x_stride + cb];
-        const float pa = fmaf(scale, xa, 0.5f), pb = fmaf(scale, xb, 0.5f);
-        const float fa = floorf(pa), fb = floorf(pb);
-        const float ra = pa - fa, rb = pb - fb;
-        const uint32_t ia = (uint32_t)(int32_t)fa, ib = (uint32_t)(int32_t)fb;
+    // four samples per thread and round: their (strided, line-per-sample) loads are in flight together
+    constexpr int U = 4;
+    for (uint32_t mb = m0 + threadIdx.x; mb < m1; mb += U * blockDim.x) {
+        float go[U], xa[U], xb[U];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const float w = ((c & 1) ? ra : (1.0f - ra)) * ((c & 2) ? rb : (1.0f - rb));
-            const uint32_t cc[2] = {ia + (uint32_t)(c & 1), ib + (uint32_t)((c >> 1) & 1)};
-            __hip_atomic_fetch_add(&s_tab[grid_row<2>(cc, res, hsize)], w * go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        for (int u = 0; u < U; ++u) {
+            const uint32_t m = mb + (uint32_t)u * blockDim.x;
+            const bool ok = m < m1;
+            const size_t mm = ok ? m : m0;
+            go[u] = ok ? grad_out[mm * (3 * kPlaneLevels) + pl * kPlaneLevels + l] : 0.0f;
+            xa[u] = x[mm * x_stride + ca];
+            xb[u] = x[mm * x_stride + cb];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (go[u] == 0.0f) continue;
+            const float pa = fmaf(scale, xa[u], 0.5f), pb = fmaf(scale, xb[u], 0.5f);
+            const float fa = floorf(pa), fb = floorf(pb);
+            const float ra = pa - fa, rb = pb - fb;
+            const uint32_t ia = (uint32_t)(int32_t)fa, ib = (uint32_t)(int32_t)fb;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float w = ((c & 1) ? ra : (1.0f - ra)) * ((c & 2) ? rb : (1.0f - rb));
+                const uint32_t cc[2] = {ia + (uint32_t)(c & 1), ib + (uint32_t)((c >> 1) & 1)};
+                __hip_atomic_fetch_add(&s_tab[grid_row<2>(cc, res, hsize)], w * go[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
     }
     __syncthreads();
