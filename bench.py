@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--spinup-ms", type=float, default=500.0, help="untimed device spin-up before the W warm-up steps: the same step repeated for "
+                    "this long, so that the clocks have ramped (they take ~50 steps = 40 ms after an idle gap) whatever W is; 0 = none")
     ap.add_argument("--num-rays", type=int, default=4096)
     ap.add_argument("--num-rays-lidar", type=int, default=4096)
     ap.add_argument("--num-steps", type=int, default=768)
@@ -521,20 +523,47 @@ def main():
             b = model.render(tc[0], tc[1], tm, cal_lidar_color=False, num_steps=T)
         return a, b
 
+    # Warm-up = the timed loop's own pattern (the previous step's outputs stay referenced while the next step runs, so the caching
+    # allocator has both sets of output buffers before the clock starts: a hipMalloc inside the timed region costs tens of ms),
+    # and Python's cyclic collector is parked for the timed region (a full collection over torch's object graph is a host stall
+    # of the same order; nothing in the loop creates reference cycles).
+    import gc
+    out = None
+    gc.collect()
+    gc.disable()  # before the spin-up: a collection between warm-up and timing would idle the device for tens of ms
+    t_spin = time.perf_counter()
+    while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms:  # device spin-up (clock ramp), not part of W or K
+        for _ in range(50):  # back to back: an idle gap after every step would keep the device in its low state
+            out = step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    trace = os.environ.get("NVSF_BENCH_TRACE") == "1"
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if trace else None
+    if trace:
+        evs[0].record()
+    t0 = time.perf_counter()
+    host = []
+    for i in range(args.steps):
+        h0 = time.perf_counter()
+        out = step()
+        if trace:
+            host.append(time.perf_counter() - h0)
+            evs[i + 1].record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
+    if trace:
+        g = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
+        print("per-step GPU ms:", " ".join(f"{v:.2f}" for v in g), file=sys.stderr)
+        print("per-step host enqueue ms:", " ".join(f"{v * 1e3:.2f}" for v in host), file=sys.stderr)
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -552,7 +581,7 @@ def main():
                        "num_rays": args.num_rays, "num_rays_lidar": args.num_rays_lidar, "num_steps": T,
                        "hash_grid": "L16 F2 T2^19 base16 max2048", "sigma_mlp": "32-64-16", "heads": "lidar 2x(87-64-64-1), rgb 31-64-64-3",
                        "pass": "forward render (no_grad): one wave-per-ray launch per batch (+ the XCD-sliced encode pass for the camera batch)", "parallelism": f"frame-sharded x{world}, no collective"},
-            "outputs_finite": finite,
+            "outputs_finite": finite, "spinup_ms": args.spinup_ms,
         }
         if same_device:
             line["invalid"] = "NVSF_BENCH_SAME_DEVICE=1: all ranks shared cuda:0 (control-flow check only)"
