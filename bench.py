@@ -105,9 +105,12 @@ def event_time_ms(fn, iters):
 
 
 def kernel_breakdown(model, batches, T, iters):
-    """Times each kernel of the step in isolation (same inputs, same stream) and prices it against its roofline."""
+    """Times each launch of the step IN the step's own launch sequence (LiDAR render, camera encode pass, camera tail, repeated
+    `iters` times with HIP events between the launches on the launch stream) and prices it against its roofline.  A launch timed
+    by repeating it alone back to back reads 5-15 % longer than it runs inside the step (what rocprofv3's kernel trace of the step
+    loop shows): consecutive launches of one kernel contend for the same table lines in the same phase."""
     from nvsf import field_ops as ops
-    rows = []
+    stages = []  # (label, callable, row builder)
     for name, (o, d, lidar) in batches.items():
         N = o.shape[0]
         M = N * T
@@ -126,28 +129,42 @@ def kernel_breakdown(model, batches, T, iters):
         else:
             head_a, head_b, head_flops, bg = model.color_net.weights_f16(), None, 14336, [1.0, 1.0, 1.0]
         sigma_flops = 2 * (32 * 64 + 64 * 16)
-        # the launches model.render issues: one wave-per-ray kernel for the whole render; on the level-sliced path the
-        # encode pass (levels partitioned over the XCDs) runs first and the render kernel reads its feature planes
         rargs = dargs + (lidar, head_a, head_b, model._k_scale(), bg)
-        full = lambda: ops.render_uniform(*rargs, sliced=sliced)
-        z, w, ws, dp, img = full()
+        z, w, ws, dp, img = ops.render_uniform(*rargs, sliced=sliced)
         active = float((w > ops.W_THRESH).float().mean())
         flops = sigma_flops + head_flops * active
         if sliced:
             bufs = ops.render_uniform(*rargs, sliced=True, _stage="encode")
-            t_a = event_time_ms(lambda: ops.render_uniform(*rargs, sliced=True, _stage="encode", _buffers=bufs), iters)
-            t_b = event_time_ms(lambda: ops.render_uniform(*rargs, sliced=True, _stage="tail", _buffers=bufs), iters)
-            rows.append(dict(kernel=f"density_encode_sliced[{name}]", ms=t_a, bound="hbm", unit="GB/s", achieved=580.0 * M / t_a / 1e6,
-                             peak=HBM_PEAK_GBS, per_unit="580 B/sample (512 gathered + 64 features + 4 z written)", units=M))
-            rows.append(dict(kernel=f"render_uniform_tail[{name}]", ms=t_b, bound="mfma", unit="TFLOP/s", achieved=flops * M / t_b / 1e9,
-                             peak=MFMA_PEAK_TFLOPS, units=M,
-                             per_unit=f"{sigma_flops} + {head_flops} x active fraction {active:.3f} FLOP/sample (sigma MLP, compositing, heads); "
-                                      "76 B/sample of HBM traffic (64 features + 4 z read, 4 weights written)"))
+            stages.append((lambda rargs=rargs, bufs=bufs: ops.render_uniform(*rargs, sliced=True, _stage="encode", _buffers=bufs),
+                           lambda t, name=name, M=M: dict(kernel=f"density_encode_sliced[{name}]", ms=t, bound="hbm", unit="GB/s", achieved=580.0 * M / t / 1e6,
+                                                          peak=HBM_PEAK_GBS, per_unit="580 B/sample (512 gathered + 64 features + 4 z written)", units=M)))
+            stages.append((lambda rargs=rargs, bufs=bufs: ops.render_uniform(*rargs, sliced=True, _stage="tail", _buffers=bufs),
+                           lambda t, name=name, M=M, flops=flops, active=active, head_flops=head_flops: dict(
+                               kernel=f"render_uniform_tail[{name}]", ms=t, bound="mfma", unit="TFLOP/s", achieved=flops * M / t / 1e9, peak=MFMA_PEAK_TFLOPS, units=M,
+                               per_unit=f"{sigma_flops} + {head_flops} x active fraction {active:.3f} FLOP/sample (sigma MLP, compositing, heads); "
+                                        "76 B/sample of HBM traffic (64 features + 4 z read, 4 weights written)")))
         else:
-            t = event_time_ms(full, iters)
-            rows.append(dict(kernel=f"render_uniform[{name}]", ms=t, bound="hbm", unit="GB/s", achieved=520.0 * M / t / 1e6, peak=HBM_PEAK_GBS,
-                             units=M, per_unit="520 B/sample (512 gathered + 4 z + 4 weights written); gather, sigma MLP, compositing and heads "
-                                               f"in one launch ({flops:.0f} FLOP/sample = {flops * M / t / 1e9:.0f} TFLOP/s)"))
+            stages.append((lambda rargs=rargs: ops.render_uniform(*rargs, sliced=False),
+                           lambda t, name=name, M=M, flops=flops: dict(
+                               kernel=f"render_uniform[{name}]", ms=t, bound="hbm", unit="GB/s", achieved=520.0 * M / t / 1e6, peak=HBM_PEAK_GBS, units=M,
+                               per_unit="520 B/sample (512 gathered + 4 z + 4 weights written); gather, sigma MLP, compositing and heads "
+                                        f"in one launch ({flops:.0f} FLOP/sample = {flops * M / t / 1e9:.0f} TFLOP/s)")))
+    n = len(stages)
+    for _ in range(10):
+        for fn, _ in stages:
+            fn()
+    torch.cuda.synchronize()
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(n + 1)] for _ in range(iters)]
+    for it in range(iters):
+        evs[it][0].record()
+        for k, (fn, _) in enumerate(stages):
+            fn()
+            evs[it][k + 1].record()
+    torch.cuda.synchronize()
+    rows = []
+    for k, (_, row) in enumerate(stages):
+        t = float(np.median([evs[it][k].elapsed_time(evs[it][k + 1]) for it in range(iters)]))
+        rows.append(row(t))
     for r in rows:
         r["frac"] = r["achieved"] / r["peak"]
     return rows

@@ -22,7 +22,8 @@ def load(path, counter):
 
 
 KEYS = {"k_render_uniformILb1ELb0": "render_uniform<lidar>", "k_render_uniformILb0ELb0": "render_uniform<camera>",
-        "k_render_uniformILb1ELb1": "render_uniform_tail<lidar>", "k_render_uniformILb0ELb1": "render_uniform_tail<camera>",
+        "k_render_tail2ILb1": "render_uniform_tail<lidar>", "k_render_tail2ILb0": "render_uniform_tail<camera>",
+        "k_render_uniformILb1ELb1": "render_uniform_tail1<lidar>", "k_render_uniformILb0ELb1": "render_uniform_tail1<camera>",
         "k_density_uniform_v2": "density_uniform_v2", "k_density_uniformILi": "density_uniform", "k_encode_sliced": "encode_sliced",
         "k_density_from_features": "density_from_features", "heads_uniformILb1": "heads_uniform<lidar>",
         "heads_uniformILb0": "heads_uniform<camera>", "k_weights_fwd": "k_weights_fwd", "k_near_far": "k_near_far"}
@@ -35,7 +36,39 @@ def short(name):
     return None
 
 
+def mfma_summary(counter_csv, kernel_stats_csv, out_path):
+    """python tools/pmc_summary.py --mfma <pmc counter_collection.csv> <kernel-trace kernel_stats.csv> <out.json>: means per launch of
+    the SQ counters of the render kernels; mfma_pipe_util = SQ_VALU_MFMA_BUSY_CYCLES / (kernel-trace duration x 2.4 GHz x 1024 SIMDs),
+    mfma_busy_over_sq_busy = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES x 4 SIMDs per CU-level busy count ... reported raw too)."""
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(counter_csv)):
+        if short(r["Kernel_Name"]):
+            per[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    dur = {r["Name"]: float(r["AverageNs"]) for r in csv.DictReader(open(kernel_stats_csv))}
+    out = {"csrc_digest": nvsf_build.csrc_digest(),
+           "note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_F16 (own pass); "
+                   "means per launch. SQ_INSTS_VALU_MFMA_MOPS_F16 x 512 = FLOP issued; SQ_VALU_MFMA_BUSY_CYCLES / MFMA instructions = 16 cycles per "
+                   "v_mfma_f32_16x16x32_f16; mfma_pipe_util = busy cycles / (kernel-trace duration x 2.4 GHz x 1024 SIMDs); tflops = FLOP / duration.",
+           "kernels": {}}
+    for name, cs in per.items():
+        e = {k: sum(v) / len(v) for k, v in cs.items()}
+        e["label"] = short(name)
+        d = next((v for k, v in dur.items() if k[:60] == name[:60]), None)
+        if d and "SQ_INSTS_VALU_MFMA_MOPS_F16" in e:
+            e["flop"] = e["SQ_INSTS_VALU_MFMA_MOPS_F16"] * 512.0
+            e["avg_duration_ns"] = d
+            e["tflops"] = e["flop"] / d / 1e3
+            e["mfma_pipe_util"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (d * 2.4 * 1024)
+        out["kernels"][name[:90]] = e
+    json.dump(out, open(out_path, "w"), indent=1)
+    for k, e in out["kernels"].items():
+        print(e["label"], {x: round(e[x], 4) for x in ("tflops", "mfma_pipe_util") if x in e})
+
+
 args = sys.argv[1:]
+if args and args[0] == "--mfma":
+    mfma_summary(*args[1:4])
+    sys.exit(0)
 alternating = ["k_weights_fwd"]
 if "--alternating" in args:
     i = args.index("--alternating")

@@ -6,7 +6,7 @@ T=${1:-d}
 O=$R/gpurun_out/$T
 mkdir -p $O
 # 1. two-rank control-flow check on one device (numbers meaningless, tagged invalid)
-NVSF_BENCH_SAME_DEVICE=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29531 bench.py --gpus 2 --steps 5 --warmup 2 --train-steps 2 --no-extra-legs > $O/bench2.log 2>&1
+NVSF_BENCH_SAME_DEVICE=1 timeout 600 python bench.py --gpus 2 --steps 5 --warmup 2 --train-steps 2 --no-extra-legs --cpu-rays 0 > $O/bench2.log 2>&1
 echo "rc2=$?" >> $O/bench2.log
 # 2. default bench line
 timeout 900 python bench.py > $O/bench1.log 2>&1
