@@ -454,8 +454,8 @@ __device__ __forceinline__ void slice_issue_half(const SliceLevel<F>& lv, __amdg
     for (int p = 0; p < 4; ++p) raw[p] = gather_raw<F>(rsrc, lv.boff + idx[p] * (uint32_t)(F * sizeof(_Float16)));
 }
 
-__device__ __forceinline__ uint32_t quad_swap(uint32_t v) {  // value of the neighbouring lane (lane ^ 1)
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, false);
+__device__ __forceinline__ uint32_t quad_swap(uint32_t v) {  // value of the neighbouring lane (lane ^ 1); every lane has a source
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
 }
 
 template <int F, bool UNIFORM_RAY>
@@ -481,20 +481,39 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     const int lane = lane_id();
     const uint32_t xb = (uint32_t)(lane & 1), half_lane = (uint32_t)(lane >> 1);
     const uint32_t n_units = (M + 31u) / 32u;
-    const uint32_t wave = sb * kWavesPerBlock + (threadIdx.x >> 6), wave_count = n_sb * kWavesPerBlock;
+    // wave-uniform bookkeeping in SGPRs: the pass is bound by VALU issue as much as by the L1 look-ups (rocprofv3: VALU active
+    // 81 % of the SIMD cycles), so the unit / ray cursor must not cost vector instructions
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(sb * kWavesPerBlock + (threadIdx.x >> 6)), wave_count = n_sb * kWavesPerBlock;
+    if (wave >= n_units) return;
+    const uint32_t T = rb.T;
     struct Unit {
         uint32_t s, n;
         bool in_range;
         float near, far, lin, noise, o[3], d[3];
     };
-    auto fetch = [&](uint32_t unit) {
+    // UNIFORM_RAY (T % 32 == 0): a unit lies inside one ray; (ray, first sample) advance by a fixed stride without a division
+    uint32_t ray = 0, first = 0, d_ray = 0, d_first = 0;
+    if constexpr (UNIFORM_RAY) {
+        ray = (wave * 32u) / T;
+        first = wave * 32u - ray * T;
+        d_ray = (wave_count * 32u) / T;
+        d_first = wave_count * 32u - d_ray * T;
+    }
+    auto fetch = [&](uint32_t unit, uint32_t n_u, uint32_t i_u) {
         Unit u;
         const uint32_t s_raw = unit * 32u + half_lane;
-        u.in_range = s_raw < M;
-        u.s = u.in_range ? s_raw : M - 1u;
-        if constexpr (UNIFORM_RAY) u.n = __builtin_amdgcn_readfirstlane((unit * 32u) / rb.T);  // T % 32 == 0: scalar ray loads
-        else u.n = u.s / rb.T;
-        const uint32_t i = u.s - u.n * rb.T;
+        uint32_t i;
+        if constexpr (UNIFORM_RAY) {
+            u.in_range = true;  // M % 32 == 0
+            u.s = s_raw;
+            u.n = n_u;
+            i = i_u + half_lane;
+        } else {
+            u.in_range = s_raw < M;
+            u.s = u.in_range ? s_raw : M - 1u;
+            u.n = u.s / T;
+            i = u.s - u.n * T;
+        }
         u.near = rb.nears[u.n];
         u.far = rb.fars[u.n];
         u.lin = rb.lin[i];
@@ -506,14 +525,26 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         }
         return u;
     };
-    if (wave >= n_units) return;
-    Unit cur = fetch(wave);
+    Unit cur = fetch(wave, ray, first);
     for (uint32_t unit = wave; unit < n_units; unit += wave_count) {
-        const uint32_t next = unit + wave_count < n_units ? unit + wave_count : unit;
-        const Unit nxt = fetch(next);
+        const bool more = unit + wave_count < n_units;
+        uint32_t ray_n = ray, first_n = first;
+        if constexpr (UNIFORM_RAY) {
+            if (more) {
+                ray_n = ray + d_ray;
+                first_n = first + d_first;
+                if (first_n >= T) {
+                    first_n -= T;
+                    ray_n += 1u;
+                }
+            }
+        }
+        const Unit nxt = fetch(more ? unit + wave_count : unit, ray_n, first_n);
+        ray = ray_n;
+        first = first_n;
         const float range = cur.far - cur.near;
         float z = cur.near + range * cur.lin;
-        if (rb.noise) z = z + (cur.noise - 0.5f) * (range / (float)rb.T);
+        if (rb.noise) z = z + (cur.noise - 0.5f) * (range / (float)T);
         float x[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -1038,12 +1069,28 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 4))) 
 // features come from the scratch planes of k_encode_sliced_pairs instead of gathers.  Weight fragments in LDS as in
 // k_render_occupancy_lds; arithmetic of the encode / MLPs / sigmoid identical to the separate kernels, the
 // transmittance product is scanned per 16 samples instead of per 64 (differences at the 1e-7 level).
-__device__ __forceinline__ float row16_scan_mul(float v, int c) {
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-        const float u = __shfl_up(v, o, 16);
-        if (c >= o) v *= u;
-    }
+// DPP row_shr:n moves data n lanes up inside a row of 16 lanes (= one MFMA tile column group); lanes without a source keep
+// `old`.  One VALU instruction per step where __shfl_up is an LDS round trip (ds_bpermute_b32 + s_waitcnt): the scan sits on
+// the per-ray critical path of the one-ray-per-wave kernels.
+template <int N>
+__device__ __forceinline__ float row_shr(float old, float v) {
+    static_assert(N >= 1 && N <= 15, "row_shr:1..15");
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x110 + N, 0xF, 0xF, false));
+}
+
+__device__ __forceinline__ float row_shl1(float old, float v) {  // lane c takes lane c + 1 of its row, lane 15 keeps `old`
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), 0x101, 0xF, 0xF, false));
+}
+
+__device__ __forceinline__ float row_first(float v) {  // lane 0 of the row, in every lane of the row (row_newbcast:0)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x150, 0xF, 0xF, false));
+}
+
+__device__ __forceinline__ float row16_scan_mul(float v) {  // inclusive product over the lanes 0..c of each row; x * 1.0f is exact
+    v *= row_shr<1>(1.0f, v);
+    v *= row_shr<2>(1.0f, v);
+    v *= row_shr<4>(1.0f, v);
+    v *= row_shr<8>(1.0f, v);
     return v;
 }
 
@@ -1192,11 +1239,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FROM_FEA
         float alpha = 0.0f;
         if (g == 3 && valid) alpha = 1.0f - expf(-delta * k_scale * expf(o[3]));
         const float om = (g == 3 && valid) ? (1.0f - alpha + 1e-15f) : 1.0f;
-        const float incl = row16_scan_mul(om, c);
-        float excl = __shfl_up(incl, 1, 16);
-        if (c == 0) excl = 1.0f;
+        const float incl = row16_scan_mul(om);
+        const float excl = row_shr<1>(1.0f, incl);
         const float w = alpha * (carry * excl);  // zero outside lane group 3
-        carry = carry * __shfl(incl, 63, 64);
+        carry = carry * readlane_f32(incl, 63);
         if (g == 3 && valid) {
             weights[s] = w;
             if constexpr (!FROM_FEATURES) z_vals[s] = z;
@@ -1204,9 +1250,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FROM_FEA
         ws += w;
         dp += w * z;
         // ---- heads on the samples that carry weight
-        const float w0 = __shfl(w, 48 + c, 64);  // weight of sample c, for the lanes that hold its colour (g == 0)
+        const float w0 = __shfl(w, 48 + c, 64);  // weight of sample c, for the lanes that hold its colour (g == 0); needed after the heads
         const bool on = w0 > w_thresh;
-        if (__ballot(on)) {
+        if (__ballot(w > w_thresh)) {  // w is zero outside lane group 3: the same set of samples
             const uint32_t p0 = pack_h2(o[0], o[1]), p1 = pack_h2(o[2], g == 3 ? 1.0f : o[3]);
             typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
             u4_t gv;
@@ -1350,7 +1396,26 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 #pragma unroll
     for (int k = 0; k < C; ++k) img[k] = 0.0f;
     typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
+    // features / depths of the NEXT pair of tiles are requested before the current pair is worked on: with one ray per wave and
+    // every ray resident (4 waves x 1024 SIMDs = 4096 rays) the launch lasts as long as ONE wave's walk along its ray, so
+    // a memory round trip per iteration would sit on the critical path 24 times.
+    struct TileIn {
+        uint2 p0, p1;
+        float z;
+    };
+    auto fetch = [&](uint32_t i0, int u) {
+        const uint32_t i = i0 + 16u * (uint32_t)u + (uint32_t)c;
+        const uint32_t k = i < T ? i : T - 1u;
+        TileIn t;
+        t.p0 = plane0[k];
+        t.p1 = plane1[k];
+        t.z = zrow[k];
+        return t;
+    };
+    TileIn cur[2] = {fetch(0, 0), fetch(0, 1)};
     for (uint32_t i0 = 0; i0 < T; i0 += 32) {
+        const uint32_t j0 = i0 + 32u < T ? i0 + 32u : i0;  // last iteration: an in-range dummy, never used
+        const TileIn nxt[2] = {fetch(j0, 0), fetch(j0, 1)};
         bool valid[2];
         uint32_t idx[2];
         float z[2], z_next[2];
@@ -1360,12 +1425,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             const uint32_t i = i0 + 16u * u + (uint32_t)c;
             valid[u] = i < T;
             idx[u] = valid[u] ? i : T - 1u;
-            z[u] = zrow[idx[u]];
-            z_next[u] = idx[u] + 1u < T ? zrow[idx[u] + 1u] : z[u];
-            const uint2 p0 = plane0[idx[u]], p1 = plane1[idx[u]];
-            const u4_t packed = {p0.x, p1.x, p1.y, p0.y};
+            z[u] = cur[u].z;
+            const u4_t packed = {cur[u].p0.x, cur[u].p1.x, cur[u].p1.y, cur[u].p0.y};
             feat8[u] = __builtin_bit_cast(half8_t, packed);
         }
+        // depth of the following sample: lane c + 1 of the tile, lane 0 of the next tile for c == 15 (the same fp32 words the
+        // one-tile kernel loads as z_vals[s + 1]); only read where i + 1 < T
+        z_next[0] = row_shl1(row_first(z[1]), z[0]);
+        z_next[1] = row_shl1(row_first(nxt[0].z), z[1]);
         // ---- sigma MLP on both tiles
         float4_t o[2];
         {
@@ -1390,7 +1457,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             o[1] = a1;
         }
         // ---- alpha compositing, tile by tile in sample order (renderer_dynamic.py:176-194); lanes g == 3 hold sigma of sample c
-        float w0[2];
+        float w0[2], wt[2];
         bool on[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -1399,19 +1466,19 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             float alpha = 0.0f;
             if (g == 3 && valid[u]) alpha = 1.0f - expf(-delta * k_scale * expf(o[u][3]));
             const float om = (g == 3 && valid[u]) ? (1.0f - alpha + 1e-15f) : 1.0f;
-            const float incl = row16_scan_mul(om, c);
-            float excl = __shfl_up(incl, 1, 16);
-            if (c == 0) excl = 1.0f;
+            const float incl = row16_scan_mul(om);
+            const float excl = row_shr<1>(1.0f, incl);
             const float w = alpha * (carry * excl);  // zero outside lane group 3
-            carry = carry * __shfl(incl, 63, 64);
+            carry = carry * readlane_f32(incl, 63);
             if (g == 3 && valid[u]) weights[row0 + idx[u]] = w;
             ws += w;
             dp += w * z[u];
-            w0[u] = __shfl(w, 48 + c, 64);  // weight of sample c, for the lanes that hold its colour (g == 0)
+            wt[u] = w;
+            w0[u] = __shfl(w, 48 + c, 64);  // weight of sample c, for the lanes that hold its colour (g == 0); needed after the heads
             on[u] = w0[u] > w_thresh;
         }
-        // ---- heads on the samples that carry weight
-        if (__ballot(on[0] || on[1])) {
+        // ---- heads on the samples that carry weight (the test reads the weights where they are: zero outside lane group 3)
+        if (__ballot(wt[0] > w_thresh || wt[1] > w_thresh)) {
             half8_t x_last[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -1443,6 +1510,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                     }
             }
         }
+        cur[0] = nxt[0];
+        cur[1] = nxt[1];
     }
     ws = wave_sum(ws);
     dp = wave_sum(dp);
