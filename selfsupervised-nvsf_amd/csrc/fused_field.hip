@@ -142,14 +142,30 @@ struct DensityCtx {
     __amdgpu_buffer_rsrc_t rsrc;
     uint32_t first_hashed;
     int g;
+    const uint4* lds_lv;  // LDS_LV form of density_encode: {scale, res, byte offset, rows} of level 4q + g at [4 q] (the per-ray
+                          // render kernels re-read the 16 B per step instead of holding 20 VGPRs across their long tile loop)
 };
 
 // One 16-sample tile: hash-grid encode of x in [0,1]^3 (per lane) -> this lane's B fragment of the sigma MLP
 // (levels {g, g+4, g+8, g+12} of sample lane & 15).
-template <int F, int QG>
+template <int F, int QG, bool LDS_LV = false>
 __device__ __forceinline__ half8_t density_encode(const DensityCtx<F>& cx, const float (&x)[3]) {
     constexpr int Q = 8 / F;
-    const LaneLevels<F>& lv = cx.lv;
+    LaneLevels<F> lv_local;
+    if constexpr (LDS_LV) {
+        const uint4* lds_lv = cx.lds_lv;
+        asm volatile("" : "+v"(lds_lv));  // re-read per call: hoisted out of the tile loop the constants would pin 20 VGPRs
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const uint4 v = lds_lv[4 * q];
+            lv_local.scale[q] = __builtin_bit_cast(float, v.x);
+            lv_local.res[q] = v.y;
+            lv_local.res2[q] = v.y * v.y;
+            lv_local.boff[q] = v.z;
+            lv_local.rows[q] = v.w;
+        }
+    }
+    const LaneLevels<F>& lv = LDS_LV ? lv_local : cx.lv;
     const uint32_t first_hashed = cx.first_hashed;
     const int g = cx.g;
     // phase 1: cell / fraction per level, issue all 8*Q gathers
@@ -822,10 +838,12 @@ __device__ __forceinline__ uint32_t pack_h2(float a, float b) {
 template <bool LIDAR>
 struct OccFrags {
     static constexpr int IN_STEPS = LIDAR ? 3 : 1;
+    static constexpr int kHeads = LIDAR ? 2 : 1;
     static constexpr int kSigma = 0;                           // 4 x W0 (permuted columns), 2 x W_out (rows rotated by one)
-    static constexpr int kHead = 6;                            // per head: 4*IN_STEPS first layer, 8 hidden, 2 output
-    static constexpr int kPerHead = 4 * IN_STEPS + 8 + 2;
-    static constexpr int kCount = kHead + (LIDAR ? 2 : 1) * kPerHead;
+    static constexpr int kHead = 6;                            // per head: the LAST k-step of the first layer (4), 8 hidden, 2 output
+    static constexpr int kPerHead = 4 + 8 + 2;
+    static constexpr int kCount = kHead + kHeads * kPerHead;
+    static constexpr int kPre = kHeads * 16;                   // float4 per wave: the per-ray part of the first layer (ray_head_constants)
 };
 
 template <bool LIDAR>
@@ -848,10 +866,35 @@ __device__ __forceinline__ half8_t occ_fragment(int f, int lane, const _Float16*
     int r = f - FR::kHead;
     const _Float16* W = w_a;
     if (r >= FR::kPerHead) { r -= FR::kPerHead; W = w_b; }
-    if (r < 4 * IN_STEPS) return load_w_natural(W, 32 * IN_STEPS, r / IN_STEPS, r % IN_STEPS, lane);
-    r -= 4 * IN_STEPS;
+    if (r < 4) return load_w_natural(W, 32 * IN_STEPS, r, IN_STEPS - 1, lane);
+    r -= 4;
     if (r < 8) return load_w_chained(W + kHidden * 32 * IN_STEPS, r >> 1, r & 1, lane);
     return load_w_chained(W + kHidden * 32 * IN_STEPS + kHidden * kHidden, 0, r - 8, lane);
+}
+
+// The first IN_STEPS - 1 k-steps of a head's first layer see the encoded ray direction only (LiDAR: 64 of the 96 inputs):
+// every sample of the ray adds the same 64 partial sums.  They are formed ONCE per ray by the same MFMA chain the per-tile
+// form runs (step 0, then step 1 on its result; all 16 columns equal), parked as 64 floats per head in LDS, and enter the
+// per-tile MFMA of the last step as its accumulator input: the same additions in the same order, bit-identical, with a third
+// of the first layer's MFMAs, a third of its weight fragments in LDS (50 -> 34 KB for the LiDAR field) and 8 VGPRs less.
+template <bool LIDAR>
+__device__ __forceinline__ void ray_head_constants(const half8_t* xf, const _Float16* __restrict__ w_a, const _Float16* __restrict__ w_b, int lane,
+                                                   float4_t* pre) {
+    using FR = OccFrags<LIDAR>;
+    constexpr int IN_STEPS = FR::IN_STEPS;
+    if constexpr (IN_STEPS > 1) {
+#pragma unroll
+        for (int h = 0; h < FR::kHeads; ++h) {
+            const _Float16* W = h ? w_b : w_a;
+#pragma unroll
+            for (int t = 0; t < kHidTiles; ++t) {
+                float4_t c = {0, 0, 0, 0};
+#pragma unroll
+                for (int s = 0; s < IN_STEPS - 1; ++s) c = mfma16(load_w_natural(W, 32 * IN_STEPS, t, s, lane), xf[s], c);
+                if ((lane & 15) == 0) pre[(h * 4 + t) * 4 + (lane >> 4)] = c;
+            }
+        }
+    }
 }
 
 template <bool LIDAR>
@@ -867,6 +910,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 4))) 
     __shared__ float s_scale[kMaxLevels];
     __shared__ uint32_t s_res[kMaxLevels], s_off[kMaxLevels + 1];
     __shared__ half8_t s_frag[FR::kCount * kWave];
+    __shared__ float4_t s_pre[kWavesPerBlock * FR::kPre];
     constexpr uint32_t kLutH = 128;  // Morton bit-spread table for grids up to 128^3 (the reference's size); larger: computed
     __shared__ uint32_t s_lut[kLutH];
     if (threadIdx.x < kMaxLevels) {
@@ -922,15 +966,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 4))) 
     const bool takes_geo = LIDAR ? (g == 1 || g == 2) : (g >= 2);
     const int src_a = (sl + 16 * (LIDAR ? 2 * (g - 1) : 2 * (g - 2))) & 63, src_b = (src_a + 16) & 63;
 
-    // one head on a tile: first layer over the k-steps in order (bit-identical to the ray-constant factoring), two more layers
-    auto head = [&](int base, const half8_t& x_last) {
+    float4_t* pre = s_pre + (threadIdx.x >> 6) * FR::kPre;
+    ray_head_constants<LIDAR>(xf, w_a, w_b, lane, pre);
+    // one head on a tile: last k-step of the first layer on top of the ray's constants, two more layers
+    auto head = [&](int hd, const half8_t& x_last) {
+        const int base = FR::kHead + hd * FR::kPerHead;
         float4_t acc[kHidTiles];
 #pragma unroll
         for (int t = 0; t < kHidTiles; ++t) {
             float4_t c = {0, 0, 0, 0};
-#pragma unroll
-            for (int s = 0; s < IN_STEPS; ++s) c = mfma16(frag[(base + t * IN_STEPS + s) * kWave], s == IN_STEPS - 1 ? x_last : xf[s], c);
-            acc[t] = c;
+            if constexpr (IN_STEPS > 1) c = pre[(hd * 4 + t) * 4 + g];
+            acc[t] = mfma16(frag[(base + t) * kWave], x_last, c);
         }
         half8_t h[kHidSteps];
         pack_hidden(acc, h);
@@ -938,13 +984,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 4))) 
         for (int t = 0; t < kHidTiles; ++t) {
             float4_t c = {0, 0, 0, 0};
 #pragma unroll
-            for (int s = 0; s < kHidSteps; ++s) c = mfma16(frag[(base + 4 * IN_STEPS + 2 * t + s) * kWave], h[s], c);
+            for (int s = 0; s < kHidSteps; ++s) c = mfma16(frag[(base + 4 + 2 * t + s) * kWave], h[s], c);
             acc[t] = c;
         }
         pack_hidden(acc, h);
         float4_t c = {0, 0, 0, 0};
 #pragma unroll
-        for (int s = 0; s < kHidSteps; ++s) c = mfma16(frag[(base + 4 * IN_STEPS + 8 + s) * kWave], h[s], c);
+        for (int s = 0; s < kHidSteps; ++s) c = mfma16(frag[(base + 4 + 8 + s) * kWave], h[s], c);
         return c;
     };
 
@@ -1019,9 +1065,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 4))) 
         gv[3] = (uint32_t)__shfl((int)p1, src_b);
         const half8_t x_last = takes_geo ? __builtin_bit_cast(half8_t, gv) : xf[IN_STEPS - 1];
         float c[3] = {0.0f, 0.0f, 0.0f};  // colour of sample sl, meaningful in lanes g == 0
-        const float4_t oa = head(FR::kHead, x_last);
+        const float4_t oa = head(0, x_last);
         if constexpr (LIDAR) {
-            const float4_t ob = head(FR::kHead + FR::kPerHead, x_last);
+            const float4_t ob = head(1, x_last);
             c[0] = sigmoid_f32(oa[0]);
             c[1] = sigmoid_f32(ob[0]);
         } else {
@@ -1095,23 +1141,23 @@ __device__ __forceinline__ float row16_scan_mul(float v) {  // inclusive product
 }
 
 template <bool LIDAR, bool FROM_FEATURES>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FROM_FEATURES ? 4 : 3, 4))) void k_render_uniform(
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_render_uniform(
     RayBatch rb, const _Float16* __restrict__ table, uint32_t table_bytes, GridMeta meta, uint32_t first_hashed,
     const uint2* __restrict__ feat, const _Float16* __restrict__ w_sigma, const _Float16* __restrict__ w_a, const _Float16* __restrict__ w_b,
     float k_scale, float w_thresh, float bg0, float bg1, float bg2, int use_bg, float* __restrict__ z_vals, float* __restrict__ weights,
     float* __restrict__ weights_sum, float* __restrict__ depth, float* __restrict__ image) {
     using FR = OccFrags<LIDAR>;
-    constexpr int F = 2, Q = 8 / F;
+    constexpr int F = 2;
     constexpr int IN_STEPS = FR::IN_STEPS;
     constexpr int C = LIDAR ? 2 : 3;
-    __shared__ float s_scale[kMaxLevels];
-    __shared__ uint32_t s_res[kMaxLevels], s_off[kMaxLevels + 1];
+    __shared__ uint4 s_lv[kMaxLevels];
     __shared__ half8_t s_frag[FR::kCount * kWave];
+    __shared__ float4_t s_pre[kWavesPerBlock * FR::kPre];
     if (threadIdx.x < kMaxLevels) {
-        s_scale[threadIdx.x] = meta.scale[threadIdx.x];
-        s_res[threadIdx.x] = meta.res[threadIdx.x];
+        const uint32_t l = threadIdx.x;
+        s_lv[l] = make_uint4(__builtin_bit_cast(uint32_t, meta.scale[l]), meta.res[l], meta.offset[l] * (uint32_t)(F * sizeof(_Float16)),
+                             meta.offset[l + 1] - meta.offset[l]);
     }
-    if (threadIdx.x <= kMaxLevels) s_off[threadIdx.x] = meta.offset[threadIdx.x];
     const int lane = lane_id(), g = lane >> 4, c = lane & 15;
     for (int f = (int)(threadIdx.x >> 6); f < FR::kCount; f += kWavesPerBlock) s_frag[f * kWave + lane] = occ_fragment<LIDAR>(f, lane, w_sigma, w_a, w_b);
     __syncthreads();
@@ -1125,15 +1171,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FROM_FEA
     if constexpr (!FROM_FEATURES) {
         cx.g = g;
         cx.first_hashed = first_hashed;
-#pragma unroll
-        for (int q = 0; q < Q; ++q) {
-            const int l = 4 * q + g;
-            cx.lv.scale[q] = s_scale[l];
-            cx.lv.res[q] = s_res[l];
-            cx.lv.res2[q] = s_res[l] * s_res[l];
-            cx.lv.boff[q] = s_off[l] * (uint32_t)(F * sizeof(_Float16));
-            cx.lv.rows[q] = s_off[l + 1] - s_off[l];
-        }
+        cx.lds_lv = s_lv + g;
         cx.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(table), 0, (int)table_bytes, 0x00020000);
     }
     const float rd0 = rb.rays_d[3 * (size_t)n], rd1 = rb.rays_d[3 * (size_t)n + 1], rd2 = rb.rays_d[3 * (size_t)n + 2];
@@ -1161,29 +1199,31 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FROM_FEA
     }
     const bool takes_geo = LIDAR ? (g == 1 || g == 2) : (g >= 2);
     const int src_a = (c + 16 * (LIDAR ? 2 * (g - 1) : 2 * (g - 2))) & 63, src_b = (src_a + 16) & 63;
-    auto head = [&](int base, const half8_t& x_last) {
+    float4_t* pre = s_pre + (threadIdx.x >> 6) * FR::kPre;
+    ray_head_constants<LIDAR>(xf, w_a, w_b, lane, pre);
+    auto head = [&](int hd, const half8_t& x_last) {
+        const int base = FR::kHead + hd * FR::kPerHead;
         float4_t acc[kHidTiles];
 #pragma unroll
         for (int t = 0; t < kHidTiles; ++t) {
-            float4_t a = {0, 0, 0, 0};
-#pragma unroll
-            for (int s = 0; s < IN_STEPS; ++s) a = mfma16(frag[(base + t * IN_STEPS + s) * kWave], s == IN_STEPS - 1 ? x_last : xf[s], a);
-            acc[t] = a;
+            float4_t c = {0, 0, 0, 0};
+            if constexpr (IN_STEPS > 1) c = pre[(hd * 4 + t) * 4 + g];
+            acc[t] = mfma16(frag[(base + t) * kWave], x_last, c);
         }
         half8_t h[kHidSteps];
         pack_hidden(acc, h);
 #pragma unroll
         for (int t = 0; t < kHidTiles; ++t) {
-            float4_t a = {0, 0, 0, 0};
+            float4_t c = {0, 0, 0, 0};
 #pragma unroll
-            for (int s = 0; s < kHidSteps; ++s) a = mfma16(frag[(base + 4 * IN_STEPS + 2 * t + s) * kWave], h[s], a);
-            acc[t] = a;
+            for (int s = 0; s < kHidSteps; ++s) c = mfma16(frag[(base + 4 + 2 * t + s) * kWave], h[s], c);
+            acc[t] = c;
         }
         pack_hidden(acc, h);
-        float4_t a = {0, 0, 0, 0};
+        float4_t c = {0, 0, 0, 0};
 #pragma unroll
-        for (int s = 0; s < kHidSteps; ++s) a = mfma16(frag[(base + 4 * IN_STEPS + 8 + s) * kWave], h[s], a);
-        return a;
+        for (int s = 0; s < kHidSteps; ++s) c = mfma16(frag[(base + 4 + 8 + s) * kWave], h[s], c);
+        return c;
     };
 
     const float near = rb.nears[n], range = rb.fars[n] - near;
@@ -1219,7 +1259,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FROM_FEA
             x[0] = (fminf(fmaxf(ox + rd0 * z, rb.lo[0]), rb.hi[0]) + rb.bound) * rb.inv_extent;
             x[1] = (fminf(fmaxf(oy + rd1 * z, rb.lo[1]), rb.hi[1]) + rb.bound) * rb.inv_extent;
             x[2] = (fminf(fmaxf(oz + rd2 * z, rb.lo[2]), rb.hi[2]) + rb.bound) * rb.inv_extent;
-            feat8 = density_encode<F, 4>(cx, x);
+            feat8 = density_encode<F, 4, true>(cx, x);
         }
         // ---- sigma MLP
         float4_t o;
@@ -1261,9 +1301,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(FROM_FEA
             gv[2] = (uint32_t)__shfl((int)p0, src_b);
             gv[3] = (uint32_t)__shfl((int)p1, src_b);
             const half8_t x_last = takes_geo ? __builtin_bit_cast(half8_t, gv) : xf[IN_STEPS - 1];
-            const float4_t oa = head(FR::kHead, x_last);
+            const float4_t oa = head(0, x_last);
             if constexpr (LIDAR) {
-                const float4_t ob = head(FR::kHead + FR::kPerHead, x_last);
+                const float4_t ob = head(1, x_last);
                 if (g == 0 && on) {
                     img[0] += w0 * sigmoid_f32(oa[0]);
                     img[1] += w0 * sigmoid_f32(ob[0]);
@@ -1310,6 +1350,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     constexpr int IN_STEPS = FR::IN_STEPS;
     constexpr int C = LIDAR ? 2 : 3;
     __shared__ half8_t s_frag[FR::kCount * kWave];
+    __shared__ float4_t s_pre[kWavesPerBlock * FR::kPre];
     const int lane = lane_id(), g = lane >> 4, c = lane & 15;
     for (int f = (int)(threadIdx.x >> 6); f < FR::kCount; f += kWavesPerBlock) s_frag[f * kWave + lane] = occ_fragment<LIDAR>(f, lane, w_sigma, w_a, w_b);
     __syncthreads();
@@ -1344,20 +1385,19 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     }
     const bool takes_geo = LIDAR ? (g == 1 || g == 2) : (g >= 2);
     const int src_a = (c + 16 * (LIDAR ? 2 * (g - 1) : 2 * (g - 2))) & 63, src_b = (src_a + 16) & 63;
+    float4_t* pre = s_pre + (threadIdx.x >> 6) * FR::kPre;
+    ray_head_constants<LIDAR>(xf, w_a, w_b, lane, pre);
     // one head on both tiles: every fragment read feeds two MFMAs
-    auto head2 = [&](int base, const half8_t (&x_last)[2], float4_t (&out)[2]) {
+    auto head2 = [&](int hd, const half8_t (&x_last)[2], float4_t (&out)[2]) {
+        const int base = FR::kHead + hd * FR::kPerHead;
         float4_t acc[2][kHidTiles];
 #pragma unroll
         for (int t = 0; t < kHidTiles; ++t) {
-            float4_t a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
-#pragma unroll
-            for (int s = 0; s < IN_STEPS; ++s) {
-                const half8_t w = frag[(base + t * IN_STEPS + s) * kWave];
-                a0 = mfma16(w, s == IN_STEPS - 1 ? x_last[0] : xf[s], a0);
-                a1 = mfma16(w, s == IN_STEPS - 1 ? x_last[1] : xf[s], a1);
-            }
-            acc[0][t] = a0;
-            acc[1][t] = a1;
+            float4_t c = {0, 0, 0, 0};
+            if constexpr (IN_STEPS > 1) c = pre[(hd * 4 + t) * 4 + g];
+            const half8_t w = frag[(base + t) * kWave];
+            acc[0][t] = mfma16(w, x_last[0], c);
+            acc[1][t] = mfma16(w, x_last[1], c);
         }
         half8_t h[2][kHidSteps];
         pack_hidden(acc[0], h[0]);
@@ -1367,7 +1407,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             float4_t a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
 #pragma unroll
             for (int s = 0; s < kHidSteps; ++s) {
-                const half8_t w = frag[(base + 4 * IN_STEPS + 2 * t + s) * kWave];
+                const half8_t w = frag[(base + 4 + 2 * t + s) * kWave];
                 a0 = mfma16(w, h[0][s], a0);
                 a1 = mfma16(w, h[1][s], a1);
             }
@@ -1379,7 +1419,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         float4_t a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
 #pragma unroll
         for (int s = 0; s < kHidSteps; ++s) {
-            const half8_t w = frag[(base + 4 * IN_STEPS + 8 + s) * kWave];
+            const half8_t w = frag[(base + 4 + 8 + s) * kWave];
             a0 = mfma16(w, h[0][s], a0);
             a1 = mfma16(w, h[1][s], a1);
         }
@@ -1491,10 +1531,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                 x_last[u] = takes_geo ? __builtin_bit_cast(half8_t, gv) : xf[IN_STEPS - 1];
             }
             float4_t oa[2];
-            head2(FR::kHead, x_last, oa);
+            head2(0, x_last, oa);
             if constexpr (LIDAR) {
                 float4_t ob[2];
-                head2(FR::kHead + FR::kPerHead, x_last, ob);
+                head2(1, x_last, ob);
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
                     if (g == 0 && on[u]) {
