@@ -153,11 +153,11 @@ __device__ __forceinline__ half8_t density_encode(const DensityCtx<F>& cx, const
     constexpr int Q = 8 / F;
     LaneLevels<F> lv_local;
     if constexpr (LDS_LV) {
-        const uint4* lds_lv = cx.lds_lv;
-        asm volatile("" : "+v"(lds_lv));  // re-read per call: hoisted out of the tile loop the constants would pin 20 VGPRs
+        uint32_t again = 0;
+        asm volatile("" : "+v"(again));  // re-read per call: hoisted out of the tile loop the constants would pin 20 VGPRs
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
-            const uint4 v = lds_lv[4 * q];
+            const uint4 v = cx.lds_lv[4 * q + again];
             lv_local.scale[q] = __builtin_bit_cast(float, v.x);
             lv_local.res[q] = v.y;
             lv_local.res2[q] = v.y * v.y;
@@ -905,19 +905,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 4))) 
                                                                  float* __restrict__ weights_sum, float* __restrict__ depth,
                                                                  float* __restrict__ image) {
     using FR = OccFrags<LIDAR>;
-    constexpr int F = 2, Q = 8 / F;
+    constexpr int F = 2;
     constexpr int IN_STEPS = FR::IN_STEPS;
-    __shared__ float s_scale[kMaxLevels];
-    __shared__ uint32_t s_res[kMaxLevels], s_off[kMaxLevels + 1];
+    __shared__ uint4 s_lv[kMaxLevels];
     __shared__ half8_t s_frag[FR::kCount * kWave];
     __shared__ float4_t s_pre[kWavesPerBlock * FR::kPre];
     constexpr uint32_t kLutH = 128;  // Morton bit-spread table for grids up to 128^3 (the reference's size); larger: computed
     __shared__ uint32_t s_lut[kLutH];
     if (threadIdx.x < kMaxLevels) {
-        s_scale[threadIdx.x] = meta.scale[threadIdx.x];
-        s_res[threadIdx.x] = meta.res[threadIdx.x];
+        const uint32_t l = threadIdx.x;
+        s_lv[l] = make_uint4(__builtin_bit_cast(uint32_t, meta.scale[l]), meta.res[l], meta.offset[l] * (uint32_t)(F * sizeof(_Float16)),
+                             meta.offset[l + 1] - meta.offset[l]);
     }
-    if (threadIdx.x <= kMaxLevels) s_off[threadIdx.x] = meta.offset[threadIdx.x];
     if (threadIdx.x < kLutH) s_lut[threadIdx.x] = spread3(threadIdx.x);
     const int lane = lane_id(), g = lane >> 4, sl = lane & 15;
     for (int f = (int)(threadIdx.x >> 6); f < FR::kCount; f += kWavesPerBlock) s_frag[f * kWave + lane] = occ_fragment<LIDAR>(f, lane, w_sigma, w_a, w_b);
@@ -929,15 +928,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 4))) 
     DensityCtx<F> cx;  // level constants + table descriptor; the weight members stay unused (LDS fragments instead)
     cx.g = g;
     cx.first_hashed = first_hashed;
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-        const int l = 4 * q + g;
-        cx.lv.scale[q] = s_scale[l];
-        cx.lv.res[q] = s_res[l];
-        cx.lv.res2[q] = s_res[l] * s_res[l];
-        cx.lv.boff[q] = s_off[l] * (uint32_t)(F * sizeof(_Float16));
-        cx.lv.rows[q] = s_off[l + 1] - s_off[l];
-    }
+    cx.lds_lv = s_lv + g;
     cx.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(table), 0, (int)table_bytes, 0x00020000);
 
     const float rd0 = rr.rays_d[3 * (size_t)n], rd1 = rr.rays_d[3 * (size_t)n + 1], rd2 = rr.rays_d[3 * (size_t)n + 2];
@@ -1039,7 +1030,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 4))) 
         const uint32_t cnt = __builtin_amdgcn_readfirstlane(count);
         if (cnt == 0u) break;
         const float x01[3] = {(sx + rr.bound) / extent, (sy + rr.bound) / extent, (sz + rr.bound) / extent};
-        const half8_t feat = density_encode<F, 4>(cx, x01);
+        const half8_t feat = density_encode<F, 4, true>(cx, x01);
         float4_t o;
         {
             float4_t acc1[kHidTiles];
