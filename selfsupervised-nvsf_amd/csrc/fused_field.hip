@@ -1340,10 +1340,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     using FR = OccFrags<LIDAR>;
     constexpr int IN_STEPS = FR::IN_STEPS;
     constexpr int C = LIDAR ? 2 : 3;
-    __shared__ half8_t s_frag[FR::kCount * kWave];
+    constexpr int kOut1 = FR::kCount;  // the sigma net's output layer once more, rows rotated by 5 instead of 1 (tile 2j + 1, see below)
+    __shared__ half8_t s_frag[(FR::kCount + kHidSteps) * kWave];
     __shared__ float4_t s_pre[kWavesPerBlock * FR::kPre];
     const int lane = lane_id(), g = lane >> 4, c = lane & 15;
-    for (int f = (int)(threadIdx.x >> 6); f < FR::kCount; f += kWavesPerBlock) s_frag[f * kWave + lane] = occ_fragment<LIDAR>(f, lane, w_sigma, w_a, w_b);
+    for (int f = (int)(threadIdx.x >> 6); f < FR::kCount + kHidSteps; f += kWavesPerBlock)
+        s_frag[f * kWave + lane] = f < FR::kCount ? occ_fragment<LIDAR>(f, lane, w_sigma, w_a, w_b) : load_w_chained(w_sigma + kHidden * 32, 0, f - FR::kCount, lane, 5);
     __syncthreads();
     const uint32_t n = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
     if (n >= rb.N) return;
@@ -1376,6 +1378,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     }
     const bool takes_geo = LIDAR ? (g == 1 || g == 2) : (g >= 2);
     const int src_a = (c + 16 * (LIDAR ? 2 * (g - 1) : 2 * (g - 2))) & 63, src_b = (src_a + 16) & 63;
+    const int src_a1 = (src_a + 48) & 63, src_b1 = (src_b + 48) & 63;  // tile 2j + 1: its output rows sit one lane group lower
     float4_t* pre = s_pre + (threadIdx.x >> 6) * FR::kPre;
     ray_head_constants<LIDAR>(xf, w_a, w_b, lane, pre);
     // one head on both tiles: every fragment read feeds two MFMAs
@@ -1480,45 +1483,56 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             float4_t a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
 #pragma unroll
             for (int sx = 0; sx < kHidSteps; ++sx) {
-                const half8_t w = frag[(FR::kSigma + 4 + sx) * kWave];
-                a0 = mfma16(w, h[0][sx], a0);
-                a1 = mfma16(w, h[1][sx], a1);
+                a0 = mfma16(frag[(FR::kSigma + 4 + sx) * kWave], h[0][sx], a0);
+                a1 = mfma16(frag[(kOut1 + sx) * kWave], h[1][sx], a1);
             }
             o[0] = a0;
             o[1] = a1;
         }
-        // ---- alpha compositing, tile by tile in sample order (renderer_dynamic.py:176-194); lanes g == 3 hold sigma of sample c
-        float w0[2], wt[2];
+        // ---- alpha compositing of both tiles in one pass (renderer_dynamic.py:176-194).  The output layer of tile 2j + 1 ran with its
+        // rows rotated by 5, so the density logit of its sample c sits in lane group 2 where tile 2j has it in lane group 3: the two
+        // exponentials, the 16-lane scan and the weights are formed once for 32 samples (rows of 16 lanes scan independently), and
+        // tile 2j + 1 continues from tile 2j's transmittance: the same products in the same order as tile by tile.
+        float w0[2];
         bool on[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const uint32_t i = i0 + 16u * u + (uint32_t)c;
-            const float delta = (i + 1u < T) ? z_next[u] - z[u] : sample_dist;
+        float w;
+        {
+            const bool hi = g == 3;
+            const float lg = hi ? o[0][3] : o[1][3], zz = hi ? z[0] : z[1], zn = hi ? z_next[0] : z_next[1];
+            const uint32_t i = i0 + (hi ? 0u : 16u) + (uint32_t)c;
+            const bool live = g >= 2 && i < T;
+            const float delta = (i + 1u < T) ? zn - zz : sample_dist;
             float alpha = 0.0f;
-            if (g == 3 && valid[u]) alpha = 1.0f - expf(-delta * k_scale * expf(o[u][3]));
-            const float om = (g == 3 && valid[u]) ? (1.0f - alpha + 1e-15f) : 1.0f;
+            if (live) alpha = 1.0f - expf(-delta * k_scale * expf(lg));
+            const float om = live ? (1.0f - alpha + 1e-15f) : 1.0f;
             const float incl = row16_scan_mul(om);
             const float excl = row_shr<1>(1.0f, incl);
-            const float w = alpha * (carry * excl);  // zero outside lane group 3
-            carry = carry * readlane_f32(incl, 63);
-            if (g == 3 && valid[u]) weights[row0 + idx[u]] = w;
-            ws += w;
-            dp += w * z[u];
-            wt[u] = w;
-            w0[u] = __shfl(w, 48 + c, 64);  // weight of sample c, for the lanes that hold its colour (g == 0); needed after the heads
-            on[u] = w0[u] > w_thresh;
+            const float carry1 = carry * readlane_f32(incl, 63);  // transmittance in front of tile 2j + 1
+            w = alpha * ((hi ? carry : carry1) * excl);  // zero outside lane groups 2, 3
+            carry = carry1 * readlane_f32(incl, 47);
+            if (live) weights[row0 + i] = w;
+            w0[0] = __shfl(w, 48 + c, 64);  // weights of sample c of either tile, for the lanes that hold its colour (g == 0)
+            w0[1] = __shfl(w, 32 + c, 64);
+            on[0] = w0[0] > w_thresh;
+            on[1] = w0[1] > w_thresh;
+            // sums in lane group 0, tile 2j before tile 2j + 1 per lane as in the one-tile kernel (bit-identical totals)
+            const float a0 = g == 0 ? w0[0] : 0.0f, a1 = g == 0 ? w0[1] : 0.0f;
+            ws += a0;
+            dp += a0 * z[0];
+            ws += a1;
+            dp += a1 * z[1];
         }
-        // ---- heads on the samples that carry weight (the test reads the weights where they are: zero outside lane group 3)
-        if (__ballot(wt[0] > w_thresh || wt[1] > w_thresh)) {
+        // ---- heads on the samples that carry weight (the test reads the weights where they are: zero outside lane groups 2, 3)
+        if (__ballot(w > w_thresh)) {
             half8_t x_last[2];
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const uint32_t p0 = pack_h2(o[u][0], o[u][1]), p1 = pack_h2(o[u][2], g == 3 ? 1.0f : o[u][3]);
+                const uint32_t p0 = pack_h2(o[u][0], o[u][1]), p1 = pack_h2(o[u][2], g == 3 - u ? 1.0f : o[u][3]);
                 u4_t gv;
-                gv[0] = (uint32_t)__shfl((int)p0, src_a);
-                gv[1] = (uint32_t)__shfl((int)p1, src_a);
-                gv[2] = (uint32_t)__shfl((int)p0, src_b);
-                gv[3] = (uint32_t)__shfl((int)p1, src_b);
+                gv[0] = (uint32_t)__shfl((int)p0, u ? src_a1 : src_a);
+                gv[1] = (uint32_t)__shfl((int)p1, u ? src_a1 : src_a);
+                gv[2] = (uint32_t)__shfl((int)p0, u ? src_b1 : src_b);
+                gv[3] = (uint32_t)__shfl((int)p1, u ? src_b1 : src_b);
                 x_last[u] = takes_geo ? __builtin_bit_cast(half8_t, gv) : xf[IN_STEPS - 1];
             }
             float4_t oa[2];
