@@ -119,64 +119,79 @@ __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_corners(const float* __
     auto flush = [&](float* dst, float acc) { atomicAdd(dst, acc); };
     constexpr int G = (1 << D) * F;  // lanes per item
     constexpr int IPW = kWave / G;   // items per wave
+    constexpr int B = 8;             // rows requested together: a walk with ONE row in flight lasts a memory round trip per row
     static_assert(G <= kWave && kWave % G == 0, "2^D x F must divide the wave");
     const int lane = lane_id();
     const int sub = lane / G, r = lane - sub * G, c = r / F, f = r - c * F;
-    const unsigned long long item = ((unsigned long long)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) * IPW + (unsigned)sub;
-    const uint32_t chunk = (uint32_t)(item / L), l = (uint32_t)(item - (unsigned long long)chunk * L);
+    // the IPW items of a wave are consecutive levels of ONE chunk of rows (host: L % IPW == 0): the rows are wave-uniform,
+    // their positions come through the scalar cache, only the gradient element differs per lane
+    const unsigned long long item0 = ((unsigned long long)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) * IPW;
+    const uint32_t chunk = __builtin_amdgcn_readfirstlane((uint32_t)(item0 / L));
+    const uint32_t l = __builtin_amdgcn_readfirstlane((uint32_t)(item0 - (unsigned long long)chunk * L)) + (uint32_t)sub;
     const unsigned long long first = (unsigned long long)chunk * run;
     if (first >= M) return;
     const uint32_t m0 = (uint32_t)first, m1 = (uint32_t)(first + run < M ? first + run : M);
     const float scale = meta.scale[l];
     const uint32_t res = meta.res[l], row0 = meta.offset[l], hsize = meta.offset[l + 1] - row0;
+    const uint32_t gcol = l * F + (uint32_t)f;
     float acc = 0.0f;
     uint32_t cur[D];
     bool have = false;
 #pragma unroll
     for (int d = 0; d < D; ++d) cur[d] = 0u;
     float* dst = grad_table;
-    auto load_row = [&](uint32_t m, float (&xs)[D], float& g) {
-        const float* px = x + (size_t)m * x_stride;
-        xs[0] = px[c0];
-        xs[1] = px[c1];
-        if constexpr (D == 3) xs[2] = px[c2];
-        if constexpr (GRAD_F16) g = (float)reinterpret_cast<const _Float16*>(grad_out)[(size_t)m * go_stride + l * F + f];
-        else g = reinterpret_cast<const float*>(grad_out)[(size_t)m * go_stride + l * F + f];
+    struct Rows {
+        float xs[B][D], g[B];
     };
-    float xs_n[D], g_n;
-    load_row(m0, xs_n, g_n);
-    for (uint32_t m = m0; m < m1; ++m) {
-        float xs[D];
+    auto load_rows = [&](uint32_t m, Rows& rw) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) xs[d] = xs_n[d];
-        const float g = g_n;
-        if (m + 1 < m1) load_row(m + 1, xs_n, g_n);  // next row in flight while this one is processed
-        if (g == 0.0f) continue;                     // this lane's feature has nothing to add (its sum keeps its cell)
-        float w = 1.0f;
-        uint32_t cell[D];
-        bool same = have;
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const float pos = fmaf(scale, xs[d], 0.5f);
-            const float fl = floorf(pos);
-            const float frac = pos - fl;
-            cell[d] = (uint32_t)(int32_t)fl;
-            same = same && (cell[d] == cur[d]);
-            w = w * ((c & (1 << d)) ? frac : (1.0f - frac));
+        for (int j = 0; j < B; ++j) {
+            const uint32_t mj = m + (uint32_t)j < m1 ? m + (uint32_t)j : m1 - 1u;  // uniform; rows past the end are not consumed
+            const float* px = x + (size_t)mj * x_stride;
+            rw.xs[j][0] = px[c0];
+            rw.xs[j][1] = px[c1];
+            if constexpr (D == 3) rw.xs[j][2] = px[c2];
+            if constexpr (GRAD_F16) rw.g[j] = (float)reinterpret_cast<const _Float16*>(grad_out)[(size_t)mj * go_stride + gcol];
+            else rw.g[j] = reinterpret_cast<const float*>(grad_out)[(size_t)mj * go_stride + gcol];
         }
-        if (!same) {
-            if (acc != 0.0f) flush(dst, acc);
-            acc = 0.0f;
-            have = true;
-            uint32_t cc[D];
+    };
+    Rows nxt;
+    load_rows(m0, nxt);
+    for (uint32_t m = m0; m < m1; m += B) {
+        const Rows rw = nxt;
+        if (m + B < m1) load_rows(m + B, nxt);  // next batch in flight while this one is walked
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
-                cur[d] = cell[d];
-                cc[d] = cell[d] + ((c >> d) & 1u);
+        for (int j = 0; j < B; ++j) {
+            if (m + (uint32_t)j >= m1) break;  // uniform
+            const float g = rw.g[j];
+            if (g != 0.0f) {  // else: this lane's feature has nothing to add (its sum keeps its cell)
+                float w = 1.0f;
+                uint32_t cell[D];
+                bool same = have;
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const float pos = fmaf(scale, rw.xs[j][d], 0.5f);
+                    const float fl = floorf(pos);
+                    const float frac = pos - fl;
+                    cell[d] = (uint32_t)(int32_t)fl;
+                    same = same && (cell[d] == cur[d]);
+                    w = w * ((c & (1 << d)) ? frac : (1.0f - frac));
+                }
+                if (!same) {
+                    if (acc != 0.0f) flush(dst, acc);
+                    acc = 0.0f;
+                    have = true;
+                    uint32_t cc[D];
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {
+                        cur[d] = cell[d];
+                        cc[d] = cell[d] + ((c >> d) & 1u);
+                    }
+                    dst = grad_table + ((size_t)row0 + grid_row<D>(cc, res, hsize)) * F + f;
+                }
+                acc += w * g;
             }
-            dst = grad_table + ((size_t)row0 + grid_row<D>(cc, res, hsize)) * F + f;
         }
-        acc += w * g;
     }
     if (acc != 0.0f) flush(dst, acc);
 }

@@ -137,6 +137,7 @@ class GradBuckets:
         self._flags = torch.zeros(len(self.params), dtype=torch.float32, device=self.params[0].device)
         self._pending, self._next, self._handles, self._fired = [], 0, [], set()
         self._events = [[] for _ in self.buckets]
+        self._hold, self._held = False, []
         self._cuda = self.params[0].is_cuda
         self._comm = torch.cuda.Stream(device=self.params[0].device) if (self._cuda and self.ws > 1) else None
         self.n_collectives = 0
@@ -152,6 +153,7 @@ class GradBuckets:
         self._next = 0
         self._handles, self._fired, self.n_collectives = [], set(), 0
         self._events = [[] for _ in self.buckets]
+        self._hold, self._held = False, []
         for flat in self.flat:
             flat.zero_()
         for p in self.params:
@@ -169,9 +171,26 @@ class GradBuckets:
             p.grad = self.views[p]
         self.mark_ready(p)
 
+    def hold(self, on):
+        """A step made of several backward passes (train_step.RenderTrainStep: LiDAR pass, then camera pass): while `on`, a
+        gradient that arrives is only noted -- a parameter both passes reach is final after the last one.  `release_held()` after
+        the last pass marks what the later passes did not touch."""
+        self._hold = bool(on)
+
+    def release_held(self):
+        held, self._held, self._hold = self._held, [], False
+        if held and self._cuda:
+            from nvsf import field_ops
+            field_ops.sync_side_streams()  # held scatters ran on the side stream; the events below are recorded on this one
+        for p in held:
+            self.mark_ready(p)
+
     def mark_ready(self, p):
         """The gradient of `p` (in its bucket view) is final.  Called by the hook, or by a kernel wrapper that scattered straight
         into the view (field_ops.DensityFn on its side stream: the collective is then issued from that stream)."""
+        if self._hold:
+            self._held.append(p)
+            return
         if p in self._fired:
             return
         self._fired.add(p)

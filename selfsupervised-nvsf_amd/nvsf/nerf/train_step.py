@@ -47,10 +47,15 @@ def urf_line_of_sight_loss(weights, z_vals, gt_depth, eps):
 class RenderTrainStep:
     def __init__(self, model, lr=1e-2, iters=30000, num_steps=768, alpha_d=1.0, alpha_r=0.01, alpha_i=0.1, alpha_rgb=1.0,
                  smooth_factor=0.0, use_urf_loss=False, bucket_bytes=64 << 20, fp16=True, scale=1.0, chamfer_loss=True,
-                 flow_loss=False, pc_list=None, ema_decay=0.95):
+                 flow_loss=False, pc_list=None, ema_decay=0.95, split_backward=True, ray_chunks=1):
         """Defaults = the reference's CLI defaults (main_nvsf.py:60-97).  `scale`: the scene scale the chamfer loss divides by
         (opt.scale); `pc_list`: {frame index: [P, 3] tensor} world-frame point clouds for the scene-flow loss
-        (Trainer.process_pointcloud, trainer.py:1848-1912, builds them from the range images); `ema_decay=None` disables EMA."""
+        (Trainer.process_pointcloud, trainer.py:1848-1912, builds them from the range images); `ema_decay=None` disables EMA.
+        `split_backward`: the LiDAR terms and the camera term of the loss are sums over disjoint ray sets, so their gradients add:
+        the step runs LiDAR forward + backward, then camera forward + backward, and the LiDAR table scatter (the longest kernel
+        of the step, on its side stream) overlaps the whole camera pass instead of the tail of one joint backward.  Same
+        gradients (test_train_step_gpu.py); the reference's `nan_to_num` of the total is applied per modality, which differs
+        only when a loss is not finite (then that modality contributes no gradient; GradScaler skips such a step anyway)."""
         self.model = model
         # loss scaling of the reference's mixed-precision run (trainer.py:119, 1332-1334: GradScaler(enabled=fp16) -> scale(loss)
         # .backward() -> step -> update; `-L` / `--fp16` in main_nvsf.py:17,43,159).  The encoders hand fp16 features to the
@@ -79,10 +84,35 @@ class RenderTrainStep:
         self._cham = None
         self.global_step = 0
         self.scatter_overlap = True  # table scatters on a side stream beside the rest of backward (field_ops.DensityFn)
+        self.split_backward = bool(split_backward)
+        self.ray_chunks = max(1, int(ray_chunks))
         # more than one rank: gradients live in flat buckets that are all-reduced while backward still runs (frame_shard.GradBuckets)
         self.buckets = None
         if frame_shard.world()[1] > 1:
             self.buckets = frame_shard.GradBuckets([p for g in self.opt.param_groups for p in g["params"]], bucket_bytes)
+
+    def _render(self, rays_o, rays_d, time, **kw):
+        """model.render on `ray_chunks` slices of the batch, results concatenated.  Each slice is its own autograd sub-graph, and
+        backward walks them one after the other (last slice first), so the table scatter of a slice (side stream) runs beside the
+        backward of the next slice, and the activations of one slice at a time are alive (peak memory 1.9 -> 1.4 GiB at 4
+        slices).  Measured on one MI355X it does NOT shorten the step (10.6 ms at 1 slice, 10.9 at 2, 12.7 at 4): the scatter
+        saturates the memory-side atomic path -- read-modify-write of a 64-B segment per 8-16 useful bytes, about 5 TB/s of
+        HBM traffic -- and whatever runs beside it is slowed by what it gains.  Default 1; a memory knob, not a speed knob.
+        Per-ray results do not depend on the slicing; only the order in which the fp32 table gradients are added changes."""
+        N = rays_o.shape[1]
+        k = min(self.ray_chunks, max(1, N // 256))
+        if k <= 1:
+            return self.model.render(rays_o, rays_d, time, **kw)
+        cuts = [N * i // k for i in range(k + 1)]
+        outs = [self.model.render(rays_o[:, a:b], rays_d[:, a:b], time, **kw) for a, b in zip(cuts[:-1], cuts[1:])]
+        merged = {}
+        for key, v in outs[0].items():
+            if not torch.is_tensor(v):
+                merged[key] = v
+                continue
+            dim = 1 if (v.dim() >= 2 and v.shape[0] == 1 and v.shape[1] == cuts[1] - cuts[0]) else 0
+            merged[key] = torch.cat([o[key] for o in outs], dim=dim)
+        return merged
 
     def _chamfer(self, a, b):
         if self._cham is None:
@@ -120,8 +150,8 @@ class RenderTrainStep:
             else:
                 gt_rd, gt_i, gt_d = batch["gt_raydrop"], batch["gt_intensity"], batch["gt_depth"]
             gt_int, gt_depth = gt_i * gt_rd, gt_d * gt_rd  # trainer.py:187-189
-            r = m.render(batch["rays_o_lidar"], batch["rays_d_lidar"], batch["time"], cal_lidar_color=True, perturb=True,
-                         num_steps=self.num_steps)
+            r = self._render(batch["rays_o_lidar"], batch["rays_d_lidar"], batch["time"], cal_lidar_color=True, perturb=True,
+                             num_steps=self.num_steps)
             pred_rd = r["image_lidar"][:, :, 0]
             pred_int = r["image_lidar"][:, :, 1] * gt_rd
             pred_depth = r["depth_lidar"] * gt_rd
@@ -141,19 +171,15 @@ class RenderTrainStep:
                 out["los"] = urf_line_of_sight_loss(r["weights"], r["z_vals"], gt_depth, eps)
         if "rays_o" in batch:
             gt_rgb = batch["gt_rgb"] if "gt_rgb" in batch else batch["images"][..., :3]
-            r = m.render(batch["rays_o"], batch["rays_d"], batch["time"], perturb=True, num_steps=self.num_steps, bg_color=1)
+            r = self._render(batch["rays_o"], batch["rays_d"], batch["time"], perturb=True, num_steps=self.num_steps, bg_color=1)
             out["rgb"] = (self.alpha_rgb * (r["image"] - gt_rgb) ** 2).sum()
         total = sum(out.values())
         total = torch.nan_to_num(total, nan=0.0, posinf=1e5, neginf=1e5)  # trainer.py:545-546 (|inf| -> 1e5)
         return total, out
 
-    def step(self, batch):
-        self.model.train()
-        if self.buckets is not None:
-            self.buckets.begin_step()
-        else:
-            self.opt.zero_grad(set_to_none=True)
-        loss, parts = self.losses(batch)
+    CAMERA_KEYS = ("rays_o", "rays_d", "gt_rgb", "images")
+
+    def _backward(self, loss):
         overlap = loss.is_cuda and self.scatter_overlap
         if overlap:
             from nvsf import field_ops
@@ -163,6 +189,30 @@ class RenderTrainStep:
         finally:
             if overlap:
                 field_ops.SCATTER_OVERLAP = False
+        return overlap
+
+    def step(self, batch):
+        self.model.train()
+        if self.buckets is not None:
+            self.buckets.begin_step()
+        else:
+            self.opt.zero_grad(set_to_none=True)
+        if self.split_backward and "rays_o_lidar" in batch and "rays_o" in batch:
+            lidar = {k: v for k, v in batch.items() if k not in self.CAMERA_KEYS}
+            camera = {k: v for k, v in batch.items() if k in self.CAMERA_KEYS or k == "time"}
+            loss, parts, overlap = None, {}, False
+            for first, sub in ((True, lidar), (False, camera)):
+                if self.buckets is not None:  # parameters both passes reach (the sigma MLP) are final only after the second
+                    self.buckets.hold(first)
+                part_loss, part = self.losses(sub)
+                overlap = self._backward(part_loss) or overlap
+                loss = part_loss.detach() if loss is None else loss + part_loss.detach()
+                parts.update(part)
+            if self.buckets is not None:
+                self.buckets.release_held()
+        else:
+            loss, parts = self.losses(batch)
+            overlap = self._backward(loss)
         # the all-reduce is linear: it runs on the scaled gradients (an inf / nan on one rank reaches every rank, so all of
         # them skip the step together); scaler.step unscales, checks and steps.  Buckets go out during backward (hooks); finish()
         # closes the rest, waits and averages.  The table scatters run on a side stream: their consumers wait here.
@@ -171,6 +221,7 @@ class RenderTrainStep:
         else:
             n_coll = 0
             if overlap:
+                from nvsf import field_ops
                 field_ops.sync_side_streams()
         self.scaler.step(self.opt)
         self.scaler.update()

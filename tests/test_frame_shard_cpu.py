@@ -52,6 +52,17 @@ def _worker(rank, world_size, port, q):
         exp3 = torch.zeros(11); exp3[:3] = torch.arange(1.0, 4.0) * 1.5  # only rank 0 contributes: (3 x + 0) / 2
         ok_grad = ok_grad and torch.allclose(w[0].grad, exp0) and torch.allclose(w[2].grad[:3], exp0[:3] * 2) and w[1].grad is None \
             and torch.allclose(w[3].grad, exp3) and w[0].grad.data_ptr() == gb.views[w[0]].data_ptr() and n_over >= 3
+        # --- a step made of two backward passes (LiDAR pass, camera pass): a parameter both passes reach must be reduced after the
+        # second one, and what only the first pass touched is released afterwards
+        gb.begin_step()
+        gb.hold(True)
+        ((w[0][:3] * x).sum() + (w[2][:3] * x).sum()).backward()
+        gb.hold(False)
+        ((w[2][:3] * x).sum() + ((w[3][:3] * x * 3).sum() if rank == 0 else 0.0)).backward()
+        gb.release_held()
+        gb.finish()
+        ok_grad = ok_grad and torch.allclose(w[0].grad, exp0) and torch.allclose(w[2].grad[:3], exp0[:3] * 2) and w[1].grad is None \
+            and torch.allclose(w[3].grad, exp3)
         gb.close()
         # --- rays: ragged chunks, gather restores the original order
         N = 4099

@@ -373,3 +373,37 @@ def test_side_stream_scatter_gives_the_same_step(dev):
         a, b = grads[False][n], grads[True][n]
         assert float(a.abs().max()) > 0
         assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()), n  # same kernels and operands: fp32 atomic order only
+
+
+def test_split_backward_gives_the_same_gradients(dev):
+    """RenderTrainStep(split_backward=True) runs LiDAR forward + backward, then camera forward + backward (the LiDAR table scatter
+    then overlaps the whole camera pass).  The loss terms are sums over disjoint ray sets: same loss, same gradients as one joint
+    backward (the sigma MLP, which both passes reach, adds its two contributions in either order)."""
+    from nvsf import synthetic as S
+    from nvsf.nerf.models.network_static import NeRFNetworkStatic
+    from nvsf.nerf.train_step import RenderTrainStep
+    kw = dict(bound=S.BOUND, min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH, log2_hashmap_size=15)
+    torch.manual_seed(4)
+    teacher = NeRFNetworkStatic(**kw)
+    with torch.no_grad():
+        for enc in (teacher.hash_encoder_lidar, teacher.hash_encoder_camera):
+            enc.params.normal_(0.0, 0.2)
+    teacher = teacher.to(dev).eval()
+    batch = _batch(S, teacher, dev, n=700, T=64, seed=2)
+    grads, losses = {}, {}
+    for split in (False, True):
+        torch.manual_seed(9)
+        m = NeRFNetworkStatic(**kw).to(dev)
+        step = RenderTrainStep(m, num_steps=64, scale=S.SCALE, ema_decay=None, split_backward=split)
+        step.scaler = torch.amp.GradScaler("cuda", init_scale=64.0, growth_interval=10 ** 6)
+        torch.manual_seed(10)
+        loss, parts, _ = step.step(batch)
+        torch.cuda.synchronize()
+        losses[split] = (float(loss), {k: float(v) for k, v in parts.items()})
+        grads[split] = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.numel() and p.grad is not None}
+    assert set(losses[False][1]) == set(losses[True][1]) == {"depth", "raydrop", "intensity", "chamfer", "rgb"}
+    assert abs(losses[False][0] - losses[True][0]) <= 1e-6 * abs(losses[False][0])
+    assert set(grads[False]) == set(grads[True]) and len(grads[True]) == 6
+    for n in grads[False]:
+        a, b = grads[False][n], grads[True][n]
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()), n
