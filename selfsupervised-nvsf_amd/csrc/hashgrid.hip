@@ -51,6 +51,86 @@ __global__ __launch_bounds__(kBlock) void k_hashgrid_fwd(const float* __restrict
     }
 }
 
+// Forward of an all-hashed F = 4 grid with 8 levels (the static hash of the space-time field: T = 2^19, 512 -> 32768), ONE LEVEL
+// PER XCD.  The generic kernel above walks the 8 levels of 64 samples inside one workgroup: every XCD's 4 MiB L2 sees all
+// 32 MB of tables, nearly every corner is an L2 miss served by the Infinity Cache (measured 0.88-1.30 ms per 3.1 M samples).
+// Here workgroup b works on level b % 8 for a share of ALL samples -- workgroups are dealt to the XCDs round-robin, so an XCD
+// keeps gathering from the same 4 MB level, which stays in its L2.  Two lanes per sample (lane = 2 * sample + x-bit), as in the
+// sliced pass of fused_field.hip: a gather instruction fetches both x-neighbours of 32 samples (the same 16-B pair for even
+// cells).  The even lane blends features 0, 1, the odd lane features 2, 3, each over all eight corners in the specification's
+// order (the partner's half of every entry arrives by a quad swap): the same fma chain as encode_level<3, 4>, bit-identical
+// features.  If the dispatcher placed workgroups differently the result is the same, only slower.
+__device__ __forceinline__ uint32_t lane_swap(uint32_t v) {  // value of lane ^ 1
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+}
+
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_hashgrid_fwd_levels8(
+    const float* __restrict__ x, uint32_t M, uint32_t x_stride, const _Float16* __restrict__ table, uint32_t table_bytes, GridMeta meta,
+    _Float16* __restrict__ out, uint32_t out_stride) {
+    const uint32_t level = blockIdx.x & 7u, sb = blockIdx.x >> 3, n_sb = gridDim.x >> 3;
+    const float scale = meta.scale[level];
+    const uint32_t boff = meta.offset[level] * 8u, mask = meta.offset[level + 1] - meta.offset[level] - 1u;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(table), 0, (int)table_bytes, 0x00020000);
+    const int lane = lane_id();
+    const uint32_t xb = (uint32_t)(lane & 1), half_lane = (uint32_t)(lane >> 1);
+    const uint32_t n_units = (M + 31u) / 32u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(sb * (kBlock / kWave) + (threadIdx.x >> 6)), wave_count = n_sb * (kBlock / kWave);
+    if (wave >= n_units) return;
+    auto fetch = [&](uint32_t unit, float (&p)[3]) {
+        const uint32_t s = unit * 32u + half_lane, sc = s < M ? s : M - 1u;
+        const float* px = x + (size_t)sc * x_stride;
+        p[0] = px[0];
+        p[1] = px[1];
+        p[2] = px[2];
+    };
+    float nxt[3];
+    fetch(wave, nxt);
+    for (uint32_t unit = wave; unit < n_units; unit += wave_count) {
+        float xs[3] = {nxt[0], nxt[1], nxt[2]};
+        fetch(unit + wave_count < n_units ? unit + wave_count : unit, nxt);
+        float frac[3];
+        uint32_t c[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float pos = fmaf(scale, xs[d], 0.5f);
+            const float fl = floorf(pos);
+            frac[d] = pos - fl;
+            c[d] = (uint32_t)(int32_t)fl;
+        }
+        const uint32_t hy0 = c[1] * 2654435761u, hy1 = hy0 + 2654435761u;
+        const uint32_t hz0 = c[2] * 805459861u, hz1 = hz0 + 805459861u;
+        const uint32_t yz[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+        typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+        u2v raw[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) raw[p] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, boff + ((((c[0] + xb) ^ yz[p]) & mask) << 3), 0, 0);
+        // this lane's feature pair of all eight corners: its own corners' dword, and the partner's (the corners with the other x-bit)
+        uint32_t mine[8];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const uint32_t own = xb ? raw[p][1] : raw[p][0], send = xb ? raw[p][0] : raw[p][1];
+            const uint32_t recv = lane_swap(send);
+            mine[2 * p] = xb ? recv : own;
+            mine[2 * p + 1] = xb ? own : recv;
+        }
+        const float wx[2] = {1.0f - frac[0], frac[0]}, wy[2] = {1.0f - frac[1], frac[1]}, wz[2] = {1.0f - frac[2], frac[2]};
+        float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float w = (wx[k & 1] * wy[(k >> 1) & 1]) * wz[k >> 2];
+            const h2_t v = __builtin_bit_cast(h2_t, mine[k]);
+            a0 = fmaf(w, (float)v[0], a0);
+            a1 = fmaf(w, (float)v[1], a1);
+        }
+        h2_t o;
+        o[0] = (_Float16)a0;
+        o[1] = (_Float16)a1;
+        const uint32_t packed = __builtin_bit_cast(uint32_t, o), other = lane_swap(packed);
+        const uint32_t s = unit * 32u + half_lane;
+        if (xb == 0u && s < M) *reinterpret_cast<uint2*>(out + (size_t)s * out_stride + 4u * level) = make_uint2(packed, other);
+    }
+}
+
 // Table gradient: one thread per (sample, level); fp32 atomics into grad_table.
 template <int D, int F, bool GRAD_F16>
 __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd(const float* __restrict__ x, uint32_t M, uint32_t x_stride, uint32_t c0,
@@ -234,6 +314,25 @@ NVSF_API int nvsf_hashgrid_fwd(const float* x, uint32_t M, uint32_t x_stride, co
     const int st = fill_meta(meta, L, h_scales, h_res, h_offsets);
     if (st != NVSF_OK) return st;
     const uint32_t c0 = cols[0], c1 = cols[1], c2 = D == 3 ? cols[2] : 0;
+    {   // eight hashed levels of F = 4 on a batch large enough to fill the chip: one level per XCD (k_hashgrid_fwd_levels8)
+        bool sliced = D == 3 && F == 4 && L == 8 && c0 == 0 && c1 == 1 && c2 == 2 && M >= (1u << 16) && out_stride % 4 == 0 &&
+                      (reinterpret_cast<uintptr_t>(out_f16) & 7u) == 0 && (unsigned long long)h_offsets[L] * 8ull < (1ull << 31);
+        for (uint32_t l = 0; l < L && sliced; ++l) {
+            const unsigned long long cells = (unsigned long long)h_res[l] * h_res[l] * h_res[l];
+            const uint32_t rows = h_offsets[l + 1] - h_offsets[l];
+            sliced = cells > rows && (rows & (rows - 1u)) == 0u;  // hashed, power-of-two table
+        }
+        const char* variant = getenv("NVSF_HASHGRID_FWD");  // "generic": the one-workgroup-per-64-samples kernel (the test reference)
+        if (sliced && !(variant && variant[0] == 'g')) {
+            const uint32_t units = (M + 31u) / 32u;
+            uint32_t ps = (units + kBlock / kWave - 1) / (kBlock / kWave);
+            if (ps > 512u) ps = 512u;
+            hipLaunchKernelGGL(k_hashgrid_fwd_levels8, dim3(8u * ps), dim3(kBlock), 0, stream, x, M, x_stride,
+                               reinterpret_cast<const _Float16*>(table_f16), (uint32_t)(h_offsets[L] * 8u), meta,
+                               reinterpret_cast<_Float16*>(out_f16), out_stride);
+            return nvsf_launch_status();
+        }
+    }
     const size_t lds = (size_t)kSamplesPerBlock * (L * F / 2 + 1) * sizeof(uint32_t);
 #define CALL(DD, FF)                                                                                                        \
     hipLaunchKernelGGL((k_hashgrid_fwd<DD, FF>), dim3(cdiv(M, kSamplesPerBlock)), dim3(kBlock), lds, stream, x, M, x_stride, c0, \

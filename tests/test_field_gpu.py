@@ -57,6 +57,27 @@ def test_hashgrid_forward_bit_exact(ops, dev, case):
     assert np.array_equal(got.view(np.uint16), ref.view(np.uint16))
 
 
+def test_hashgrid_forward_one_level_per_xcd_is_bit_identical(ops, dev, monkeypatch):
+    """Eight hashed F = 4 levels on a large batch take k_hashgrid_fwd_levels8 (one level per XCD, two lanes per sample).  Same fma
+    chains as the generic kernel: equal bit for bit, also on a ragged batch, boundary samples and a strided input; a sample of
+    the rows is checked against the oracle."""
+    spec = _spec(ops, 3, 8, 4, 19, 512, 32768)
+    rng = np.random.default_rng(7)
+    M = (1 << 16) + 4099
+    x = rng.random((M, 4)).astype(np.float32)
+    x[:6, :3] = np.array([[0, 0, 0], [1, 1, 1], [0, 1, 0], [0.5, 0.5, 0.5], [1e-7, 1 - 1e-7, 0.25], [0.999999, 0.000001, 0.5]], np.float32)
+    table = (rng.standard_normal(spec.n_params) * 0.5).astype(np.float16)
+    xd, td = _t(x, dev), _t(table, dev)
+    got = ops.hashgrid_forward(xd, (0, 1, 2), td, spec)
+    monkeypatch.setenv("NVSF_HASHGRID_FWD", "generic")
+    ref = ops.hashgrid_forward(xd, (0, 1, 2), td, spec)
+    monkeypatch.delenv("NVSF_HASHGRID_FWD")
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
+    rows = np.concatenate([np.arange(64), rng.integers(0, M, 400), np.arange(M - 40, M)])
+    exp = O.hashgrid_fwd(x[rows], (0, 1, 2), table, spec)
+    assert np.array_equal(got.cpu().numpy()[rows].view(np.uint16), exp.view(np.uint16))
+
+
 def test_hashgrid_level_table_matches_published_rules(ops):
     spec = _spec(ops, 3, 16, 2, 19, 16, 2048)
     assert spec.res[0] == 16 and spec.res[-1] == 2048
