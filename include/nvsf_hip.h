@@ -247,7 +247,8 @@ int nvsf_planes_fwd(const float* xt, uint32_t M, const float* planes_cl, uint32_
  * h_time[e]; features go to h_out[e] fp32 [M, n_scales*C] (16-byte aligned).  x fp32 [M, x_stride >= 3] in [0,1].  At most 4
  * evaluations; the h_* arrays are host arrays of n_evals entries.  n_scales = 4 (the reference's configuration), C = 8.
  * blend != 0: the evaluations must be (static, dynamic, dynamic at neighbour 1, dynamic at neighbour 2); h_out[1] then receives
- * 0.5 d + 0.25 (d1 + d2) -- the neighbour blend of network_dynamic.py:273 -- and h_out[2], h_out[3] are not written (may be NULL). */
+ * 0.5 d + 0.25 (d1 + d2) -- the neighbour blend of network_dynamic.py:273 -- and h_out[2], h_out[3] are not written (may be NULL).
+ * blend == 2: as blend == 1, and h_out[0], h_out[1] are fp16 [M, n_scales * C] rows (the values rounded to nearest even). */
 int nvsf_planes_multi_fwd(const float* x, uint32_t x_stride, uint32_t M, const float* planes_cl, uint32_t n_scales, uint32_t C,
                           const uint32_t* h_res, uint32_t n_evals, const int* h_group, const float* const* h_offsets,
                           const uint32_t* h_offset_stride, const uint32_t* h_offset_col, const float* h_time,
@@ -318,6 +319,14 @@ int nvsf_density_dynamic_fwd(const float* plane_s, const float* plane_d, const f
                              const void* hash_s_f16, const float* hash_d, const void* hash_1, int hash_1_is_f16,
                              const void* hash_2, int hash_2_is_f16, uint32_t M, const void* sigma_weights_f16,
                              float* out_h, float* sigmas, void* geo_f16, void* x_f16_out, nvsf_stream_t stream);
+
+/* The same tail fed by nvsf_planes_multi_fwd(..., blend = 2): plane_s and the already blended dynamic plane features as
+ * fp16 [M,32] rows (the blend of network_dynamic.py:273 formed by the producer, rounded as this kernel would round it).
+ * Bit-identical outputs; 256 B per sample less memory traffic. */
+int nvsf_density_dynamic_f16planes_fwd(const void* plane_s_f16, const void* plane_d_blended_f16, const void* hash_s_f16,
+                                       const float* hash_d, const void* hash_1, int hash_1_is_f16, const void* hash_2,
+                                       int hash_2_is_f16, uint32_t M, const void* sigma_weights_f16, float* out_h,
+                                       float* sigmas, void* geo_f16, void* x_f16_out, nvsf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Section 4: fused kernels of the uniform-sampling render (BASELINE config 2 hot path).

@@ -139,7 +139,7 @@ struct PlaneEvals {
     float t[kMaxEval];         // time coordinate ...
     int t_from_x[kMaxEval];    // ... unless taken from column 3 of x
     float* out[kMaxEval];      // [M, n_scales * 8]
-    int blend;                 // 1: the evaluations are (static, dynamic, dynamic at neighbour 1, dynamic at neighbour 2) and out[1]
+    int blend;                 // 2: as 1 with fp16 output rows; 1: the evaluations are (static, dynamic, dynamic at neighbour 1, dynamic at neighbour 2) and out[1]
                                // receives 0.5 d + 0.25 (d1 + d2) (network_dynamic.py:273); out[2], out[3] are not written
 };
 
@@ -263,7 +263,14 @@ __global__ __launch_bounds__(kBlock) void k_planes_fwd_runs(PlaneEvals ev, uint3
             }
             if (e >= 2u) continue;
         }
-        *reinterpret_cast<float4*>(out + (size_t)m * stride) = f;
+        if (ev.blend == 2) {  // fp16 rows [M, n_scales * 8]: what the density kernel rounds the features to anyway
+            typedef _Float16 half4_v __attribute__((ext_vector_type(4)));
+            half4_v h;
+            h[0] = (_Float16)f.x; h[1] = (_Float16)f.y; h[2] = (_Float16)f.z; h[3] = (_Float16)f.w;
+            *reinterpret_cast<half4_v*>(reinterpret_cast<_Float16*>(ev.out[e]) + (size_t)m * stride + (size_t)s * kC + half * 4u) = h;
+        } else {
+            *reinterpret_cast<float4*>(out + (size_t)m * stride) = f;
+        }
     }
 }
 
@@ -482,7 +489,7 @@ NVSF_API int nvsf_planes_multi_fwd(const float* x, uint32_t x_stride, uint32_t M
     if (st != NVSF_OK) return st;
     PlaneEvals ev = {};
     ev.x = x; ev.x_stride = x_stride; ev.n = (int)n_evals;
-    ev.blend = blend ? 1 : 0;
+    ev.blend = blend == 2 ? 2 : (blend ? 1 : 0);
     if (blend) REQUIRE(n_evals == 4 && h_group[0] == 0 && h_group[1] == 1 && h_group[2] == 1 && h_group[3] == 1);
     for (uint32_t e = 0; e < n_evals; ++e) {
         REQUIRE((h_group[e] == 0 || h_group[e] == 1) && (h_out[e] || (blend && e >= 2)) && (reinterpret_cast<uintptr_t>(h_out[e]) & 15u) == 0);

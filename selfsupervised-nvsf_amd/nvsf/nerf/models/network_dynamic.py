@@ -147,7 +147,8 @@ class NeRFNetwork(NeRFRenderer):
         evals = [(0, None, 0, float(np.float32(t_host))), base]
         for n_ in nb:
             evals.append(base if n_ is None else (1, flow, n_[2], float(n_[0])))
-        plane_s, plane_d = planes_enc.forward_multi(x, evals, blend=True)
+        # fp16 rows: the density kernel rounds its inputs to fp16 and (fp16)(0.5 v + 0.25 (v + v)) == (fp16)v, so the producer rounds
+        plane_s, plane_d = planes_enc.forward_multi(x, evals, blend=True, out_f16=True)
         # plane_d is already blended: 0.5 v + 0.25 (v + v) == v exactly, so the density kernel's own blend leaves it unchanged
         plane_1 = plane_2 = plane_d
         return (plane_s, plane_d, plane_1, plane_2, hash_s, hash_d, hash_d if hash_1 is None else hash_1, hash_d if hash_2 is None else hash_2)
@@ -192,17 +193,23 @@ class NeRFNetwork(NeRFRenderer):
         M, dev = plane_s.shape[0], plane_s.device
         c = lambda a: a.contiguous()
         hash_d = hash_d.float()
-        args = [_hip.ptr(c(plane_s)), _hip.ptr(c(plane_d)), _hip.ptr(c(plane_1)), _hip.ptr(c(plane_2)), _hip.ptr(c(hash_s)), _hip.ptr(c(hash_d)),
-                _hip.ptr(c(hash_1)), 1 if hash_1.dtype == torch.float16 else 0, _hip.ptr(c(hash_2)), 1 if hash_2.dtype == torch.float16 else 0,
-                M, _hip.ptr(self.sigma_net.weights_f16())]
+        entry = "nvsf_density_dynamic_fwd"
+        planes = [_hip.ptr(c(plane_s)), _hip.ptr(c(plane_d)), _hip.ptr(c(plane_1)), _hip.ptr(c(plane_2))]
+        if plane_s.dtype == torch.float16:  # rows of forward_multi(..., out_f16=True): plane_d is the blend already
+            if plane_d.dtype != torch.float16 or plane_1 is not plane_d or plane_2 is not plane_d:
+                raise ValueError("fp16 plane rows come blended (plane_1 = plane_2 = plane_d)")
+            entry, planes = "nvsf_density_dynamic_f16planes_fwd", planes[:2]
+        args = planes + [_hip.ptr(c(hash_s)), _hip.ptr(c(hash_d)),
+                         _hip.ptr(c(hash_1)), 1 if hash_1.dtype == torch.float16 else 0, _hip.ptr(c(hash_2)), 1 if hash_2.dtype == torch.float16 else 0,
+                         M, _hip.ptr(self.sigma_net.weights_f16())]
         if sigma_geo:
             sigmas = torch.empty(M, dtype=torch.float32, device=dev)
             geo = torch.empty(M, 16, dtype=torch.float16, device=dev)
-            _hip.call("nvsf_density_dynamic_fwd", *args, None, _hip.ptr(sigmas), _hip.ptr(geo), None)
+            _hip.call(entry, *args, None, _hip.ptr(sigmas), _hip.ptr(geo), None)
             return sigmas, geo
         h = torch.empty(M, 16, dtype=torch.float32, device=dev)
         x16 = torch.empty(M, 128, dtype=torch.float16, device=dev) if keep_input else None
-        _hip.call("nvsf_density_dynamic_fwd", *args, _hip.ptr(h), None, None, _hip.ptr(x16))
+        _hip.call(entry, *args, _hip.ptr(h), None, None, _hip.ptr(x16))
         return (h, x16) if keep_input else h
 
     def color(self, x, d, cal_lidar_color=False, mask=None, geo_feat=None, **kwargs):

@@ -61,14 +61,15 @@ class Planes4D(nn.Module):
         return ops.PlanesFn.apply(xt, self._channel_last(), self._res_host, want, *self._flat_params())
 
     @torch.no_grad()
-    def forward_multi(self, x, evals, blend=False):
+    def forward_multi(self, x, evals, blend=False, out_f16=False):
         """Several evaluations of one position set in ONE launch, without autograd (nvsf_planes_multi_fwd): `evals` is a list of
         (group, offsets, offset_col, time) with group 0 = static / 1 = dynamic planes, offsets = None or an fp32 [M, >= col + 3]
         tensor added to x[:, :3] (the scene flow towards a neighbour frame), time = the frame time as a Python float.  Returns the
         list of fp32 [M, n_output_dims / 2] feature matrices.  Same values as forward_static / forward_dynamic on
         cat([x + offsets[:, col:col+3], time]).  blend=True: `evals` = (static, dynamic, dynamic at neighbour 1, dynamic at
         neighbour 2) and the result is [static, 0.5 d + 0.25 (d1 + d2)] (the blend of network_dynamic.py:273, formed in the kernel:
-        the neighbour features never reach memory)."""
+        the neighbour features never reach memory).  out_f16 (with blend): the two results as fp16 rows, rounded as the density
+        kernel rounds its inputs (nvsf_density_dynamic_f16planes_fwd reads them)."""
         import ctypes
         from nvsf import _hip
         x = x.float()
@@ -76,7 +77,9 @@ class Planes4D(nn.Module):
             x = x.contiguous()
         M, n = x.shape[0], len(evals)
         width = self.n_output_dims // 2
-        outs = [torch.empty(M, width, dtype=torch.float32, device=x.device) for _ in (evals[:2] if blend else evals)]
+        if out_f16 and not blend:
+            raise ValueError("forward_multi: out_f16 needs blend=True")
+        outs = [torch.empty(M, width, dtype=torch.float16 if out_f16 else torch.float32, device=x.device) for _ in (evals[:2] if blend else evals)]
         offs = []
         for _, o, _, _ in evals:
             if o is not None and (o.dtype != torch.float32 or o.dim() != 2 or o.stride(1) != 1):
@@ -87,7 +90,7 @@ class Planes4D(nn.Module):
                   (ctypes.c_void_p * n)(*[None if o is None else o.data_ptr() for o in offs]),
                   _hip.host_u32([0 if o is None else o.stride(0) for o in offs]), _hip.host_u32([e[2] for e in evals]),
                   _hip.host_f32([e[3] for e in evals]), (ctypes.c_void_p * n)(*([t.data_ptr() for t in outs] + [None] * (n - len(outs)))),
-                  1 if blend else 0)
+                  (2 if out_f16 else 1) if blend else 0)
         return outs
 
     def forward_static(self, input):

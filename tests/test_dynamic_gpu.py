@@ -187,9 +187,10 @@ def test_fused_dynamic_features_equal_the_separate_launches(dev, flow_scale, t_v
             feats = m._dynamic_features(m._unit_cube(x), t, True)
             dens = m.density(x, t, cal_lidar_color=True)
         f = [v.float() for v in feats]
-        # the fused form blends the K-planes neighbours inside its kernel (plane_d == plane_1 == plane_2 == the blend): compare the
-        # blend network_dynamic.py:273 forms, which is what enters the density MLP either way
-        outs[mode] = [f[0], 0.5 * f[1] + 0.25 * (f[2] + f[3])] + f[4:] + [dens["sigma"], dens["geo_feat"].float()]
+        # the fused form blends the K-planes neighbours inside its kernel (plane_d == plane_1 == plane_2 == the blend) and hands the
+        # plane features over as fp16 rows: compare the blend network_dynamic.py:273 forms, rounded to fp16 as the density MLP
+        # takes it either way
+        outs[mode] = [f[0].half(), (0.5 * f[1] + 0.25 * (f[2] + f[3])).half()] + f[4:] + [dens["sigma"], dens["geo_feat"].float()]
     with torch.no_grad():
         assert float(m.flow_net(torch.cat([m._unit_cube(x), t.expand(x.shape[0], 1)], -1)).abs().mean()) > 0.1 * flow_scale
     for a, b in zip(outs["1"], outs["0"]):
@@ -489,6 +490,8 @@ def test_planes_forward_along_rays_is_bit_identical_and_multi_eval(dev, M, kind,
         bs, bd = enc.forward_multi(x, evals, blend=True)
         assert torch.equal(bs, s0) and torch.equal(bd, 0.5 * outs[1] + 0.25 * (outs[2] + outs[3]))
         assert torch.equal(0.5 * bd + 0.25 * (bd + bd), bd)  # what the density kernel's own blend makes of an already blended input
+        hs, hd = enc.forward_multi(x, evals, blend=True, out_f16=True)  # the same two results as fp16 rows
+        assert hs.dtype == torch.float16 and torch.equal(hs, bs.half()) and torch.equal(hd, bd.half())
 
 
 def test_dynamic_hash_gradient_through_lds_equals_the_run_merging_kernel(dev, monkeypatch):
