@@ -448,6 +448,30 @@ int nvsf_adam_update(float* param, const float* grad, float* exp_avg, float* exp
                      float beta2, float eps, const float* state4, const float* grad_scale, float* ema_shadow,
                      float ema_one_minus_decay, nvsf_stream_t stream);
 
+/* ref: the LiDAR terms of Trainer.train_step, nvsf/nerf/trainer.py:187-219 (criteria with reduction = "none", main_nvsf.py:205-221;
+ * summed at trainer.py:540-543) and the point clouds of its chamfer term (trainer.py:229-233), all [N] fp32 unless noted:
+ *   m = gt_raydrop; pred_depth = depth_lidar m; loss_depth = sum alpha_d |pred_depth - gt_range m|;
+ *   loss_raydrop = sum alpha_r (image_lidar[:, 0] - clamp(m, s, 1 - s))^2;  loss_intensity = sum alpha_i (image_lidar[:, 1] m - gt_intensity m)^2;
+ *   pred_points = rays_d pred_depth / scale, gt_points = rays_d gt_range m / scale ([N,3]; both NULL: not formed).
+ * image_lidar [N,2]; the three losses are single device floats; one launch, deterministic sums. */
+int nvsf_lidar_losses_fwd(const float* image_lidar, const float* depth_lidar, const float* gt_raydrop, const float* gt_intensity,
+                          const float* gt_range, const float* rays_d, uint32_t N, float alpha_d, float alpha_r, float alpha_i,
+                          float smooth_factor, float scale, float* loss_depth, float* loss_raydrop, float* loss_intensity,
+                          float* pred_depth, float* pred_points, float* gt_points, nvsf_stream_t stream);
+
+/* Gradients of the above with respect to image_lidar [N,2] and depth_lidar [N], given the gradients of the three sums (device
+ * floats; NULL = 0), of pred_depth ([N] or NULL) and of pred_points ([N,3] or NULL: what nvsf_chamfer_backward returns). */
+int nvsf_lidar_losses_bwd(const float* image_lidar, const float* depth_lidar, const float* gt_raydrop, const float* gt_intensity,
+                          const float* gt_range, const float* rays_d, uint32_t N, float alpha_d, float alpha_r, float alpha_i,
+                          float smooth_factor, float scale, const float* grad_loss_depth, const float* grad_loss_raydrop,
+                          const float* grad_loss_intensity, const float* grad_pred_depth, const float* grad_pred_points,
+                          float* grad_image_lidar, float* grad_depth_lidar, nvsf_stream_t stream);
+
+/* ref: the camera term, trainer.py:491-503: loss = sum alpha (a - b)^2 over n floats (one launch); grad_a = grad_loss 2 alpha (a - b). */
+int nvsf_mse_sum_fwd(const float* a, const float* b, uint32_t n, float alpha, float* loss, nvsf_stream_t stream);
+int nvsf_mse_sum_bwd(const float* a, const float* b, uint32_t n, float alpha, const float* grad_loss, float* grad_a,
+                     nvsf_stream_t stream);
+
 /* ref: torch_ema.ExponentialMovingAverage.update as used by the Trainer (trainer.py:112-114 construction with decay 0.95,
  * :1420-1421 one update per epoch): shadow -= one_minus_decay * (shadow - param), fp32 [n]. */
 int nvsf_ema_update(float* shadow, const float* param, uint64_t n, float one_minus_decay, nvsf_stream_t stream);

@@ -59,6 +59,10 @@ SIGNATURES = {
     "nvsf_hashgrid4d_dynamic_bwd": [_P, _U, _U, _P, _P, _P, _P, _I, _P, _P],
     "nvsf_hashgrid3d_lagrange_fwd": [_P, _U, _U, _P, _U, _U, _P, _P, _P, _P, _P],
     "nvsf_density_dynamic_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _U, _P, _P, _P, _P, _P],
+    "nvsf_lidar_losses_fwd": [_P, _P, _P, _P, _P, _P, _U, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P],
+    "nvsf_lidar_losses_bwd": [_P, _P, _P, _P, _P, _P, _U, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P],
+    "nvsf_mse_sum_fwd": [_P, _P, _U, _F, _P],
+    "nvsf_mse_sum_bwd": [_P, _P, _U, _F, _P, _P],
     "nvsf_density_dynamic_f16planes_fwd": [_P, _P, _P, _P, _P, _I, _P, _I, _U, _P, _P, _P, _P, _P],
     # section 5: ray generation
     "nvsf_lidar_rays": [_P, _P, _U, _U, _U, _F, _F, _F, _P, _P],

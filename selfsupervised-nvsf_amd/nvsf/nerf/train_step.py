@@ -44,6 +44,69 @@ def urf_line_of_sight_loss(weights, z_vals, gt_depth, eps):
     return 0.1 * loss_empty + 0.1 * loss_near
 
 
+class LidarLossFn(torch.autograd.Function):
+    """The LiDAR terms of Trainer.train_step (trainer.py:187-219) as one HIP launch forward and one backward (csrc/losses.hip): at
+    4096 rays each of the ~60 elementwise / reduction launches the expression costs under autograd is a launch latency.
+    Returns (loss_depth, loss_raydrop, loss_intensity, pred_depth [1,N], pred_points [1,N,3], gt_points [1,N,3]); the point clouds
+    are the inputs of the chamfer term (None when `rays_d` is None)."""
+
+    @staticmethod
+    def forward(ctx, image_lidar, depth_lidar, gt_rd, gt_i, gt_d, rays_d, alpha_d, alpha_r, alpha_i, smooth, scale):
+        from nvsf import _hip
+        N, dev = depth_lidar.numel(), depth_lidar.device
+        c = lambda t: t.detach().float().contiguous()
+        img, dep, rd, gi, gd = c(image_lidar), c(depth_lidar), c(gt_rd), c(gt_i), c(gt_d)
+        dirs = c(rays_d) if rays_d is not None else None
+        l = [torch.empty((), dtype=torch.float32, device=dev) for _ in range(3)]
+        pred_depth = torch.empty(1, N, dtype=torch.float32, device=dev)
+        pp = torch.empty(1, N, 3, dtype=torch.float32, device=dev) if dirs is not None else None
+        gp = torch.empty(1, N, 3, dtype=torch.float32, device=dev) if dirs is not None else None
+        _hip.call("nvsf_lidar_losses_fwd", _hip.ptr(img), _hip.ptr(dep), _hip.ptr(rd), _hip.ptr(gi), _hip.ptr(gd), _hip.ptr(dirs), N,
+                  float(alpha_d), float(alpha_r), float(alpha_i), float(smooth), float(scale), _hip.ptr(l[0]), _hip.ptr(l[1]), _hip.ptr(l[2]),
+                  _hip.ptr(pred_depth), _hip.ptr(pp), _hip.ptr(gp))
+        ctx.save_for_backward(img, dep, rd, gi, gd, dirs)
+        ctx.consts = (float(alpha_d), float(alpha_r), float(alpha_i), float(smooth), float(scale), image_lidar.shape, depth_lidar.shape)
+        if gp is not None:
+            ctx.mark_non_differentiable(gp)
+        return l[0], l[1], l[2], pred_depth, pp, gp
+
+    @staticmethod
+    def backward(ctx, g_d, g_r, g_i, g_pd, g_pp, _g_gp):
+        from nvsf import _hip
+        img, dep, rd, gi, gd, dirs = ctx.saved_tensors
+        a_d, a_r, a_i, smooth, scale, shape_img, shape_dep = ctx.consts
+        N = dep.numel()
+        c = lambda t: None if t is None else t.float().contiguous()
+        g_d, g_r, g_i, g_pd, g_pp = c(g_d), c(g_r), c(g_i), c(g_pd), c(g_pp)
+        grad_img, grad_dep = torch.empty_like(img), torch.empty_like(dep)
+        _hip.call("nvsf_lidar_losses_bwd", _hip.ptr(img), _hip.ptr(dep), _hip.ptr(rd), _hip.ptr(gi), _hip.ptr(gd), _hip.ptr(dirs), N,
+                  a_d, a_r, a_i, smooth, scale, _hip.ptr(g_d), _hip.ptr(g_r), _hip.ptr(g_i), _hip.ptr(g_pd), _hip.ptr(g_pp),
+                  _hip.ptr(grad_img), _hip.ptr(grad_dep))
+        return (grad_img.view(shape_img), grad_dep.view(shape_dep)) + (None,) * 9
+
+
+class MseSumFn(torch.autograd.Function):
+    """sum(alpha (a - b)^2) -- the camera term (trainer.py:491-503, summed at :540-543) -- as one launch each way."""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha):
+        from nvsf import _hip
+        a32, b32 = a.detach().float().contiguous(), b.detach().float().contiguous()
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        _hip.call("nvsf_mse_sum_fwd", _hip.ptr(a32), _hip.ptr(b32), a32.numel(), float(alpha), _hip.ptr(out))
+        ctx.save_for_backward(a32, b32)
+        ctx.alpha, ctx.shape = float(alpha), a.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from nvsf import _hip
+        a32, b32 = ctx.saved_tensors
+        grad = torch.empty_like(a32)
+        _hip.call("nvsf_mse_sum_bwd", _hip.ptr(a32), _hip.ptr(b32), a32.numel(), ctx.alpha, _hip.ptr(g.float().contiguous()), _hip.ptr(grad))
+        return grad.view(ctx.shape), None, None
+
+
 class RenderTrainStep:
     def __init__(self, model, lr=1e-2, iters=30000, num_steps=768, alpha_d=1.0, alpha_r=0.01, alpha_i=0.1, alpha_rgb=1.0,
                  smooth_factor=0.0, use_urf_loss=False, bucket_bytes=64 << 20, fp16=True, scale=1.0, chamfer_loss=True,
@@ -149,30 +212,38 @@ class RenderTrainStep:
                 gt_rd, gt_i, gt_d = (batch["images_lidar"][:, :, k] for k in range(3))
             else:
                 gt_rd, gt_i, gt_d = batch["gt_raydrop"], batch["gt_intensity"], batch["gt_depth"]
-            gt_int, gt_depth = gt_i * gt_rd, gt_d * gt_rd  # trainer.py:187-189
             r = self._render(batch["rays_o_lidar"], batch["rays_d_lidar"], batch["time"], cal_lidar_color=True, perturb=True,
                              num_steps=self.num_steps)
-            pred_rd = r["image_lidar"][:, :, 0]
-            pred_int = r["image_lidar"][:, :, 1] * gt_rd
-            pred_depth = r["depth_lidar"] * gt_rd
-            out["depth"] = (self.alpha_d * (pred_depth - gt_depth).abs()).sum()
-            out["raydrop"] = (self.alpha_r * (pred_rd - gt_rd.clamp(self.smooth, 1 - self.smooth)) ** 2).sum()
-            out["intensity"] = (self.alpha_i * (pred_int - gt_int) ** 2).sum()
-            if self.use_chamfer:
-                d = batch["rays_d_lidar"]
-                d1, d2, _, _ = self._chamfer(d * pred_depth.unsqueeze(-1) / self.scale, d * gt_depth.unsqueeze(-1) / self.scale)
-                out["chamfer"] = (d1 + d2).mean() * 0.5
+            if r["depth_lidar"].is_cuda:  # one HIP launch each way for the three sums, the masked range and the chamfer point clouds
+                d = batch["rays_d_lidar"] if self.use_chamfer else None
+                out["depth"], out["raydrop"], out["intensity"], pred_depth, pred_pts, gt_pts = LidarLossFn.apply(
+                    r["image_lidar"], r["depth_lidar"], gt_rd, gt_i, gt_d, d, self.alpha_d, self.alpha_r, self.alpha_i, self.smooth, self.scale)
+                if self.use_chamfer:
+                    d1, d2, _, _ = self._chamfer(pred_pts, gt_pts)
+                    out["chamfer"] = (d1 + d2).mean() * 0.5
+            else:  # host-side logic tests: the same terms as torch expressions
+                gt_int, gt_depth = gt_i * gt_rd, gt_d * gt_rd  # trainer.py:187-189
+                pred_rd = r["image_lidar"][:, :, 0]
+                pred_int = r["image_lidar"][:, :, 1] * gt_rd
+                pred_depth = r["depth_lidar"] * gt_rd
+                out["depth"] = (self.alpha_d * (pred_depth - gt_depth).abs()).sum()
+                out["raydrop"] = (self.alpha_r * (pred_rd - gt_rd.clamp(self.smooth, 1 - self.smooth)) ** 2).sum()
+                out["intensity"] = (self.alpha_i * (pred_int - gt_int) ** 2).sum()
+                if self.use_chamfer:
+                    d = batch["rays_d_lidar"]
+                    d1, d2, _, _ = self._chamfer(d * pred_depth.unsqueeze(-1) / self.scale, d * gt_depth.unsqueeze(-1) / self.scale)
+                    out["chamfer"] = (d1 + d2).mean() * 0.5
             if self.use_flow:
                 fl = self.flow_loss(batch["time"])
                 if fl is not None:
                     out["flow"] = fl
             if self.use_urf:
                 eps = 0.02 * 0.1 ** min(self.global_step / self.iters, 1)
-                out["los"] = urf_line_of_sight_loss(r["weights"], r["z_vals"], gt_depth, eps)
+                out["los"] = urf_line_of_sight_loss(r["weights"], r["z_vals"], gt_d * gt_rd, eps)
         if "rays_o" in batch:
             gt_rgb = batch["gt_rgb"] if "gt_rgb" in batch else batch["images"][..., :3]
             r = self._render(batch["rays_o"], batch["rays_d"], batch["time"], perturb=True, num_steps=self.num_steps, bg_color=1)
-            out["rgb"] = (self.alpha_rgb * (r["image"] - gt_rgb) ** 2).sum()
+            out["rgb"] = MseSumFn.apply(r["image"], gt_rgb, self.alpha_rgb) if r["image"].is_cuda else (self.alpha_rgb * (r["image"] - gt_rgb) ** 2).sum()
         total = sum(out.values())
         total = torch.nan_to_num(total, nan=0.0, posinf=1e5, neginf=1e5)  # trainer.py:545-546 (|inf| -> 1e5)
         return total, out

@@ -407,3 +407,37 @@ def test_split_backward_gives_the_same_gradients(dev):
     for n in grads[False]:
         a, b = grads[False][n], grads[True][n]
         assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()), n
+
+
+def test_fused_loss_kernels_match_the_torch_expressions(dev):
+    """LidarLossFn / MseSumFn (csrc/losses.hip: one launch each way) against the expressions of Trainer.train_step written with torch
+    ops (trainer.py:187-219, 229-233, 491-503): values and the gradients that reach the rendered image / range, including the
+    gradient that comes back through the chamfer point cloud and a range target equal to the prediction (|x| has gradient 0 at 0)."""
+    from nvsf.nerf.train_step import LidarLossFn, MseSumFn
+    g = torch.Generator(device="cpu").manual_seed(5)
+    N = 1500
+    rnd = lambda *s: torch.rand(*s, generator=g).to(dev)
+    img, dep = rnd(1, N, 2).requires_grad_(), rnd(1, N).requires_grad_()
+    gt_rd, gt_i, gt_d, dirs = (rnd(1, N) > 0.4).float(), rnd(1, N), rnd(1, N), torch.nn.functional.normalize(rnd(1, N, 3) - 0.5, dim=-1)
+    with torch.no_grad():
+        gt_d[0, :7] = dep[0, :7]  # zero residuals
+    a_d, a_r, a_i, smooth, scale = 1.0, 0.01, 0.1, 0.1, 0.0125
+    w = rnd(1, N, 3)  # stands for the chamfer gradient
+    got = LidarLossFn.apply(img, dep, gt_rd, gt_i, gt_d, dirs, a_d, a_r, a_i, smooth, scale)
+    total = 3.0 * got[0] + 5.0 * got[1] + 7.0 * got[2] + (got[4] * w).sum() + (got[3] * 0.25).sum()
+    gi, gd = torch.autograd.grad(total, (img, dep))
+    pd = dep * gt_rd
+    ref = [(a_d * (pd - gt_d * gt_rd).abs()).sum(), (a_r * (img[:, :, 0] - gt_rd.clamp(smooth, 1 - smooth)) ** 2).sum(),
+           (a_i * (img[:, :, 1] * gt_rd - gt_i * gt_rd) ** 2).sum()]
+    pts, gpts = dirs * pd.unsqueeze(-1) / scale, dirs * (gt_d * gt_rd).unsqueeze(-1) / scale
+    ri, rd_ = torch.autograd.grad(3.0 * ref[0] + 5.0 * ref[1] + 7.0 * ref[2] + (pts * w).sum() + (pd * 0.25).sum(), (img, dep))
+    for a, b in zip(got[:3], ref):
+        assert abs(float(a) - float(b)) <= 1e-5 * max(1.0, abs(float(b)))
+    assert torch.equal(got[3], pd) and torch.allclose(got[4], pts, rtol=1e-6, atol=0) and torch.allclose(got[5], gpts, rtol=1e-6, atol=0)
+    assert torch.allclose(gi, ri, rtol=1e-5, atol=1e-7) and torch.allclose(gd, rd_, rtol=1e-5, atol=1e-5 * float(rd_.abs().max()))
+    a, b = rnd(1, N, 3).requires_grad_(), rnd(1, N, 3)
+    l = MseSumFn.apply(a, b, 0.7)
+    (ga,) = torch.autograd.grad(l * 2.0, a)
+    lr = (0.7 * (a - b) ** 2).sum()
+    (gr,) = torch.autograd.grad(lr * 2.0, a)
+    assert abs(float(l) - float(lr)) <= 1e-5 * float(lr) and torch.allclose(ga, gr, rtol=1e-6, atol=1e-8)
