@@ -244,7 +244,11 @@ __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_corners(const float* __
         for (int j = 0; j < B; ++j) {
             if (m + (uint32_t)j >= m1) break;  // uniform
             const float g = rw.g[j];
-            if (g != 0.0f) {  // else: this lane's feature has nothing to add (its sum keeps its cell)
+            // a row all of whose features have a zero gradient at this level is skipped (the run is not broken); otherwise the
+            // whole item moves with the row, lanes of a zero feature add 0
+            const unsigned long long nz = __ballot(g != 0.0f);
+            const unsigned long long item_bits = G == 64 ? ~0ull : ((1ull << G) - 1ull);
+            if (((nz >> (sub * G)) & item_bits) != 0ull) {
                 float w = 1.0f;
                 uint32_t cell[D];
                 bool same = have;
@@ -258,8 +262,25 @@ __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_corners(const float* __
                     w = w * ((c & (1 << d)) ? frac : (1.0f - frac));
                 }
                 if (!same) {
-                    if (acc != 0.0f) flush(dst, acc);
-                    acc = 0.0f;
+                    // A step into a neighbouring cell keeps the grid vertices the two cells share (4 of 8 across a face, 2 across
+                    // an edge): their running sums move to the lanes that hold those vertices in the new cell instead of going
+                    // to memory -- the scatter is bound by the number of 64-byte atomic pieces, and on the levels whose cells are
+                    // a few steps long this is where half of them came from.  `take`: this lane's new vertex was vertex `src_c`
+                    // of the old cell; `kept`: this lane's old vertex is a vertex of the new cell (some lane takes its sum).
+                    bool take = have, kept = have;
+                    int src_c = 0;
+#pragma unroll
+                    for (int d = 0; d < D; ++d) {
+                        const int dl = (int)(cell[d] - cur[d]);
+                        const int b = (c >> d) & 1;
+                        const int sb = b + dl, tb = b - dl;
+                        take = take && (sb == 0 || sb == 1);
+                        kept = kept && (tb == 0 || tb == 1);
+                        src_c |= (sb & 1) << d;
+                    }
+                    const float moved = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(((lane - r) + src_c * F + f) << 2, __builtin_bit_cast(int, acc)));
+                    if (!kept && acc != 0.0f) flush(dst, acc);
+                    acc = take ? moved : 0.0f;
                     have = true;
                     uint32_t cc[D];
 #pragma unroll
