@@ -109,7 +109,7 @@ class NeRFNetworkStatic(NeRFRenderer):
         aabb_host = self._aabb_host  # host copy of the (constant) box: no device->host read on the hot path
         # host-side estimate of far - near: exact for LiDAR (constant range), the box side for camera rays (AABB exit)
         ray_length = float(self.lidar_max_depth - self.min_near_lidar) if cal_lidar_color else 2.0 * float(self.bound)
-        sliced = ops.prefer_sliced(enc.spec, rays_o.shape[0], T, ray_length, float(self.bound))
+        sliced = ops.prefer_sliced(enc.spec, rays_o.shape[0], T, ray_length, float(self.bound), coherent=bool(kwargs.get("rays_in_image_order", False)))
         if ops.render_uniform_eligible(enc.spec):
             # one launch per batch (plus the encode pass of the level-sliced path): sigma / geo never reach HBM
             if cal_lidar_color:

@@ -279,8 +279,10 @@ class NeRFRenderer(nn.Module):
         for b in range(B):
             for head in range(0, N, max_ray_batch):
                 tail = min(head + max_ray_batch, N)
+                # rays_in_image_order: a staged call walks a whole frame, chunk = consecutive pixels (trainer.py:1511-1524); a field
+                # may choose its kernel formulation by that (network_static.fused_uniform_render)
                 part = _run(rays_o[b:b + 1, head:tail], rays_d[b:b + 1, head:tail], time[b:b + 1],
-                                cal_lidar_color=cal_lidar_color, **kwargs)
+                                cal_lidar_color=cal_lidar_color, **dict(kwargs, rays_in_image_order=True))
                 depth[b:b + 1, head:tail] = part[keys[0]]
                 image[b:b + 1, head:tail] = part[keys[1]]
         return {keys[0]: depth, keys[1]: image}
