@@ -474,12 +474,25 @@ __device__ __forceinline__ uint32_t quad_swap(uint32_t v) {  // value of the nei
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
 }
 
+// Which workgroups encode which units of which slice.  Workgroup b belongs to group b % 8 (workgroups are dealt to the XCDs
+// round-robin: a group = the workgroups of one XCD); a group works through up to kPlanItems items = (slice, range of units), its own
+// slice first.  The default plan gives every group exactly its slice; slice_plan() moves the tail of the heavy slices to the
+// groups of the light ones (the slices of a camera batch take 0.19 ... 0.37 ms when run alone, and the launch lasts as long as
+// the slowest group).  Which workgroup encodes a unit does not change what is written.
+constexpr int kPlanItems = 3;
+struct SlicePlan {
+    uint32_t n[8];
+    uint32_t slice[8][kPlanItems], begin[8][kPlanItems], end[8][kPlanItems];
+};
+
 template <int F, bool UNIFORM_RAY>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_encode_sliced_pairs(RayBatch rb, const _Float16* __restrict__ table, uint32_t table_bytes,
                                                                 GridMeta meta, uint32_t L, uint32_t first_hashed, uint32_t M,
-                                                                float* __restrict__ z_vals, uint2* __restrict__ feat) {
+                                                                float* __restrict__ z_vals, uint2* __restrict__ feat, SlicePlan plan) {
     static_assert(F == 2, "F = 2 only");
-    const uint32_t slice = blockIdx.x & 7u, sb = blockIdx.x >> 3, n_sb = gridDim.x >> 3;
+    const uint32_t group = blockIdx.x & 7u, sb = blockIdx.x >> 3, n_sb = gridDim.x >> 3;
+    for (uint32_t item = 0; item < plan.n[group]; ++item) {
+    const uint32_t slice = plan.slice[group][item], unit_begin = plan.begin[group][item], unit_end = plan.end[group][item];
     const uint32_t grp = slice >> 1;
     const uint32_t lvl[2] = {(slice & 1u) ? grp + 4u : grp, (slice & 1u) ? grp + 8u : grp + 12u};
     SliceLevel<F> lv[2];
@@ -496,11 +509,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(table), 0, (int)table_bytes, 0x00020000);
     const int lane = lane_id();
     const uint32_t xb = (uint32_t)(lane & 1), half_lane = (uint32_t)(lane >> 1);
-    const uint32_t n_units = (M + 31u) / 32u;
+    const uint32_t n_units = unit_end;
     // wave-uniform bookkeeping in SGPRs: the pass is bound by VALU issue as much as by the L1 look-ups (rocprofv3: VALU active
     // 81 % of the SIMD cycles), so the unit / ray cursor must not cost vector instructions
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(sb * kWavesPerBlock + (threadIdx.x >> 6)), wave_count = n_sb * kWavesPerBlock;
-    if (wave >= n_units) return;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(unit_begin + sb * kWavesPerBlock + (threadIdx.x >> 6)), wave_count = n_sb * kWavesPerBlock;
+    if (wave >= n_units) continue;
     const uint32_t T = rb.T;
     struct Unit {
         uint32_t s, n;
@@ -593,6 +606,56 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         }
         cur = nxt;
     }
+    }
+}
+
+// Static balance of the encode pass (host).  Cost of a slice relative to the VALU work of streaming every sample through one XCD
+// (= 1): its finer level costs fill(l) = 1 + 1.1 (1 - exp(-(c - 0.3) / 0.9)) where c = res_l / T is the number of cells a step
+// crosses at that level on a ray that spans the box -- every look-up of a level with c >~ 1 misses L1 and the CU moves a 128-byte
+// line per look-up (measured alone, levels 9 ... 15 at T = 768: 1.07 1.21 1.47 1.72 1.77 1.85 2.14) -- and the partner level adds
+// 0.16 (dense) or 0.35 (hashed).  Slices above the mean give the tail of their units to the groups of the slices below it,
+// at most kPlanItems - 1 foreign items per group; a foreign item is priced 15 % higher (its levels are not in that XCD's L2).
+static SlicePlan slice_plan(uint32_t n_units, uint32_t T, const uint32_t* h_res, uint32_t first_hashed, bool balance) {
+    SlicePlan plan = {};
+    for (uint32_t g = 0; g < 8; ++g) {
+        plan.n[g] = 1;
+        plan.slice[g][0] = g;
+        plan.begin[g][0] = 0;
+        plan.end[g][0] = n_units;
+    }
+    if (!balance || n_units < 8192u) return plan;
+    double cost[8], mean = 0.0;
+    for (uint32_t p = 0; p < 8; ++p) {
+        const uint32_t grp = p >> 1, la = (p & 1u) ? grp + 4u : grp, lb = (p & 1u) ? grp + 8u : grp + 12u;
+        const double c = (double)h_res[lb] / (double)T;
+        const double fill = 1.0 + 1.1 * (1.0 - exp(-(c > 0.3 ? c - 0.3 : 0.0) / 0.9));
+        cost[p] = fill + (la >= first_hashed ? 0.35 : 0.16);
+        mean += cost[p] / 8.0;
+    }
+    const double penalty = 1.15;  // 1.0 ... 1.3 measure the same
+    double spare[8];
+    for (uint32_t p = 0; p < 8; ++p) spare[p] = mean - cost[p];  // > 0: capacity of group p, < 0: excess of slice p
+    for (int round = 0; round < 8; ++round) {
+        int donor = -1, taker = -1;
+        for (int p = 0; p < 8; ++p) {
+            if (spare[p] < -0.02 && (donor < 0 || spare[p] < spare[donor])) donor = p;
+            if (spare[p] > 0.02 && plan.n[p] < (uint32_t)kPlanItems && (taker < 0 || spare[p] > spare[taker])) taker = p;
+        }
+        if (donor < 0 || taker < 0) break;
+        const double moved = (-spare[donor] < spare[taker] / penalty) ? -spare[donor] : spare[taker] / penalty;  // in donor cost units
+        uint32_t units = (uint32_t)((double)n_units * moved / cost[donor]);
+        units &= ~63u;  // whole rounds of a workgroup's waves
+        const uint32_t have = plan.end[donor][0] - plan.begin[donor][0];
+        if (units == 0u || units + 4096u > have) break;
+        const uint32_t k = plan.n[taker]++;
+        plan.slice[taker][k] = (uint32_t)donor;
+        plan.end[taker][k] = plan.end[donor][0];
+        plan.end[donor][0] -= units;
+        plan.begin[taker][k] = plan.end[donor][0];
+        spare[donor] += moved;
+        spare[taker] -= moved * penalty;
+    }
+    return plan;
 }
 
 // pass B: 32 encoded features per sample (scratch planes) -> sigma MLP -> sigma, geo.
@@ -1634,12 +1697,14 @@ static int density_uniform_impl(const float* rays_o, const float* rays_d, const 
             const uint32_t units32 = (M + 31u) / 32u;
             uint32_t ps = (units32 + kWavesPerBlock - 1) / kWavesPerBlock;
             if (ps > 512u) ps = 512u;  // 32 CUs per XCD x 8 resident workgroups x 2 (measured: 256 -> 512 gains 1.5 %)
+            const char* plan_env = getenv("NVSF_SLICE_PLAN");  // "home": every group its own slice only (A/B timing)
+            const SlicePlan plan = slice_plan(units32, T, h_res, first_hashed, !(plan_env && plan_env[0] == 'h'));
             if (T % 32u == 0u)
                 hipLaunchKernelGGL((k_encode_sliced_pairs<2, true>), dim3(8u * ps), dim3(kBlock), 0, stream, rb, tb, (uint32_t)table_bytes, meta, L,
-                                   first_hashed, M, z_vals, fp);
+                                   first_hashed, M, z_vals, fp, plan);
             else
                 hipLaunchKernelGGL((k_encode_sliced_pairs<2, false>), dim3(8u * ps), dim3(kBlock), 0, stream, rb, tb, (uint32_t)table_bytes, meta,
-                                   L, first_hashed, M, z_vals, fp);
+                                   L, first_hashed, M, z_vals, fp, plan);
         }
         const uint32_t tiles = (M + 15u) / 16u;
         uint32_t bb = (tiles + 4u * kWavesPerBlock - 1u) / (4u * kWavesPerBlock);

@@ -41,6 +41,33 @@ def test_sliced_equals_fused_bitwise(dev, lidar, N, T, noise):
         assert torch.equal(x, y), name
 
 
+@pytest.mark.parametrize("N,T", [(400, 768), (700, 381)])  # T % 32 == 0 (scalar ray cursor) and ragged
+def test_balanced_slice_plan_writes_the_same_planes(dev, N, T, monkeypatch):
+    """Above 8192 units of 32 samples the encode pass moves the tail of the heavy slices (pairs of levels) to the workgroups of
+    the light ones (slice_plan, fused_field.hip).  Who encodes a unit must not change what is written: the planes, z and the
+    sigma MLP's outputs equal those of the home plan (every XCD its own slice) and of the single-launch kernel bit for bit."""
+    from nvsf import field_ops as ops
+    m = _model(dev, 0.1)
+    rng = np.random.default_rng(23)
+    o, d, nears, fars = _batch(m, dev, False, N, rng)
+    enc = m.hash_encoder_camera
+    args = (o, d, nears, fars, T, m._aabb_host, float(m.bound), enc.table_f16(), enc.spec, m.sigma_net.weights_f16())
+    assert (N * T + 31) // 32 >= 8192
+    outs = {}
+    for plan in ("model", "home"):
+        monkeypatch.setenv("NVSF_SLICE_PLAN", plan)
+        bufs = (torch.zeros(N, T, device=dev), torch.zeros(N, T, device=dev), torch.zeros(N, T, 16, dtype=torch.float16, device=dev),
+                torch.zeros(16, N * T, dtype=torch.int32, device=dev))
+        ops.density_uniform(*args, sliced=True, _buffers=bufs)
+        outs[plan] = bufs
+    monkeypatch.delenv("NVSF_SLICE_PLAN")
+    for a, b in zip(outs["model"], outs["home"]):
+        assert torch.equal(a, b)
+    ref = ops.density_uniform(*args, sliced=False)
+    for a, b in zip(outs["model"][:3], ref):
+        assert torch.equal(a, b)
+
+
 def test_sliced_render_matches_oracle(dev, monkeypatch):
     """Whole camera render through the sliced path (forced) against the CPU oracle composition, 1e-4."""
     from nvsf import synthetic as S
