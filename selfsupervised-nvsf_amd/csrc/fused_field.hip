@@ -125,6 +125,15 @@ struct LaneLevels {
     uint32_t res[Q], res2[Q], boff[Q], rows[Q];
 };
 
+// a0 += w * lo(raw), a1 += w * hi(raw) for a table entry of two fp16 features: v_fma_mix_f32 converts the fp16 operand inside
+// the fused multiply-add (exact conversion, one rounding: the same result as fmaf(w, (float)h, a)), one VALU instruction per
+// feature where hipcc emits two conversions + one packed fma per entry -- 3 issue slots against 2, and the gather kernels are
+// bound by VALU issue.
+__device__ __forceinline__ void fma_entry(float w, uint32_t raw, float& a0, float& a1) {
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[0,1,0]" : "+v"(a0) : "v"(w), "v"(raw));
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,1,0]" : "+v"(a1) : "v"(w), "v"(raw));
+}
+
 template <int F>
 __device__ __forceinline__ uint32_t gather_raw(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off);
 template <>
@@ -221,9 +230,7 @@ __device__ __forceinline__ half8_t density_encode(const DensityCtx<F>& cx, const
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const float w = (wx[k & 1] * wy[(k >> 1) & 1]) * wz[k >> 2];
-            const h2_t v = __builtin_bit_cast(h2_t, raw[q][k]);
-            a0 = fmaf(w, (float)v[0], a0);
-            a1 = fmaf(w, (float)v[1], a1);
+            fma_entry(w, raw[q][k], a0, a1);
         }
         xf[q * F] = (_Float16)a0;
         xf[q * F + 1] = (_Float16)a1;
@@ -422,9 +429,7 @@ __device__ __forceinline__ uint32_t slice_blend(const float (&frac)[3], const ui
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const float w = (wx[k & 1] * wy[(k >> 1) & 1]) * wz[k >> 2];
-        const h2_t v = __builtin_bit_cast(h2_t, raw[k]);
-        a0 = fmaf(w, (float)v[0], a0);
-        a1 = fmaf(w, (float)v[1], a1);
+        fma_entry(w, raw[k], a0, a1);
     }
     h2_t o;
     o[0] = (_Float16)a0;
