@@ -232,6 +232,22 @@ int nvsf_mlp_bwd(const void* x, int x_is_f16, uint32_t M, uint32_t n_in, uint32_
                  uint32_t n_out, uint32_t go_stride, float grad_scale, float* grad_x, uint32_t gx_stride,
                  float* grad_weights_f32, uint32_t gx_col0, int gx_accumulate, nvsf_stream_t stream);
 
+/* nvsf_mlp_fwd / nvsf_mlp_bwd on rows with a shared prefix: logical input row r =
+ *   [ prefix[r / rows_per_prefix][0 : prefix_cols] | x[r][0 : n_in - prefix_cols] ]
+ * -- the per-sample heads, whose first 72 (LiDAR) / 16 (camera) inputs are the encoded direction of the sample's RAY
+ * (network_dynamic.py:297-330: torch.cat([d_encoded, geo_feat]) per sample): the direction rows are read once per ray instead of being
+ * copied into every sample's row.  fp16 operands, 16-byte aligned rows, prefix_cols % 8 == 0, rows_per_prefix % 16 == 0; everything else
+ * as in nvsf_mlp_fwd / nvsf_mlp_bwd (gx_col0 and the columns of grad_x refer to the logical row).  Same results as on assembled rows. */
+int nvsf_mlp_fwd_prefix(const void* prefix_f16, uint32_t prefix_stride, uint32_t rows_per_prefix, uint32_t prefix_cols,
+                        const void* x_f16, uint32_t M, uint32_t n_in, uint32_t x_stride, const void* weights_f16, uint32_t in_cols,
+                        uint32_t hidden, uint32_t n_hidden, uint32_t out_cols, float* out_f32, uint32_t out_stride,
+                        nvsf_stream_t stream);
+int nvsf_mlp_bwd_prefix(const void* prefix_f16, uint32_t prefix_stride, uint32_t rows_per_prefix, uint32_t prefix_cols,
+                        const void* x_f16, uint32_t M, uint32_t n_in, uint32_t x_stride, const void* weights_f16, uint32_t in_cols,
+                        uint32_t hidden, uint32_t n_hidden, uint32_t out_cols, const float* grad_out, uint32_t n_out,
+                        uint32_t go_stride, float grad_scale, float* grad_x, uint32_t gx_stride, float* grad_weights_f32,
+                        uint32_t gx_col0, int gx_accumulate, nvsf_stream_t stream);
+
 /* ref: Planes4D.forward / forward_static / forward_dynamic, nvsf/nerf/models/planes_field.py:86-140,196-238
  * (24 F.grid_sample(bilinear, align_corners=True, padding='border') calls + products + concat per call).
  * xt fp32 [M,4] in [0,1] (16-byte aligned); planes_cl: all 6*n_scales planes CHANNEL-LAST [H][W][C] fp32 in

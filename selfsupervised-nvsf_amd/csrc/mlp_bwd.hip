@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kBlock) void k_mlp_bwd(const void* __restrict__ x, 
                                                     const _Float16* __restrict__ weights, uint32_t in_cols,
                                                     const float* __restrict__ grad_out, uint32_t n_out, uint32_t go_stride, float grad_scale,
                                                     float* __restrict__ grad_x, uint32_t gx_stride, float* __restrict__ grad_w, int vec_ok,
-                                                    uint32_t gx_col0, int gx_accumulate, int go_vec) {
+                                                    uint32_t gx_col0, int gx_accumulate, int go_vec, XPrefix pre) {
     using FR = BwdFrags<IN_STEPS, N_HIDDEN>;
     constexpr int IN_TILES = FR::IN_TILES;
     __shared__ half8_t s_frag[FR::kCount * kWave];
@@ -141,7 +141,9 @@ __global__ __launch_bounds__(kBlock) void k_mlp_bwd(const void* __restrict__ x, 
         op.m = tile * 16 + (uint32_t)c;
         op.valid = tile < n_tiles && op.m < M;
         const size_t row = op.valid ? op.m : (M - 1);
-        issue_x_row<IN_STEPS, X_F16, FAST>(op.xf, x, row, x_stride, g, (int)n_in, (int)in_cols, vec_ok != 0, tail);
+        const uint32_t tile_u = __builtin_amdgcn_readfirstlane(tile);
+        const _Float16* prow = pre.a ? pre.row_of((tile_u < n_tiles && tile_u * 16u < M) ? tile_u * 16u : M - 1u) : nullptr;
+        issue_x_row<IN_STEPS, X_F16, FAST>(op.xf, x, row, x_stride, g, (int)n_in, (int)in_cols, vec_ok != 0, tail, prow, pre.split);
         const float* go_row = grad_out + row * go_stride;
         if (go_vec) {  // 16 outputs, 16-byte aligned rows: two 16-byte loads for the lanes that hold outputs (g < 2)
             const float4* p = reinterpret_cast<const float4*>(go_row) + 2 * (g & 1);
@@ -325,13 +327,13 @@ __global__ __launch_bounds__(kBlock) void k_mlp_bwd(const void* __restrict__ x, 
 
 #define REQUIRE(cond) do { if (!(cond)) return NVSF_ERR_INVALID_ARG; } while (0)
 
-NVSF_API int nvsf_mlp_bwd(const void* x, int x_is_f16, uint32_t M, uint32_t n_in, uint32_t x_stride, const void* weights_f16,
-                          uint32_t in_cols, uint32_t hidden, uint32_t n_hidden, uint32_t out_cols, const float* grad_out, uint32_t n_out,
-                          uint32_t go_stride, float grad_scale, float* grad_x, uint32_t gx_stride, float* grad_weights_f32,
-                          uint32_t gx_col0, int gx_accumulate, hipStream_t stream) {
+static int mlp_bwd_impl(const void* x, int x_is_f16, uint32_t M, uint32_t n_in, uint32_t x_stride, const void* weights_f16,
+                        uint32_t in_cols, uint32_t hidden, uint32_t n_hidden, uint32_t out_cols, const float* grad_out, uint32_t n_out,
+                        uint32_t go_stride, float grad_scale, float* grad_x, uint32_t gx_stride, float* grad_weights_f32,
+                        uint32_t gx_col0, int gx_accumulate, XPrefix pre, hipStream_t stream) {
     if (M == 0) return NVSF_OK;
     REQUIRE(x && weights_f16 && grad_out && grad_weights_f32);
-    REQUIRE(n_in >= 1 && n_in <= in_cols && in_cols % 16 == 0 && x_stride >= n_in);
+    REQUIRE(n_in >= 1 && n_in <= in_cols && in_cols % 16 == 0 && x_stride >= n_in - pre.split);
     REQUIRE(n_out >= 1 && n_out <= 16 && go_stride >= n_out && grad_scale > 0.0f);
     REQUIRE(!grad_x || (gx_col0 < n_in && gx_stride >= n_in - gx_col0));
     REQUIRE((reinterpret_cast<uintptr_t>(weights_f16) & 15u) == 0);
@@ -349,10 +351,14 @@ NVSF_API int nvsf_mlp_bwd(const void* x, int x_is_f16, uint32_t M, uint32_t n_in
     // enough for the last group of four)
     const bool gx_vec = !grad_x || (gx_col0 % 4 == 0 && gx_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(grad_x) & 15u) == 0 &&
                                     (n_in - gx_col0 + 3u) / 4u * 4u <= gx_stride);
-    const bool fast = x_rows_fast(n_in, x_stride, vec_ok) && gx_vec;
+    const bool fast = x_rows_fast(n_in - pre.split, x_stride, vec_ok) && gx_vec;
+    if (pre.a) {  // shared-prefix rows (mlp_device.h: XPrefix): aligned fp16 only, whole 8-column groups, a tile inside one group
+        REQUIRE(x_is_f16 && fast && pre.split % 8 == 0 && pre.split < n_in && pre.a_stride >= pre.split && pre.a_stride % 8 == 0);
+        REQUIRE(pre.rows_per_a >= 16 && pre.rows_per_a % 16 == 0 && (reinterpret_cast<uintptr_t>(pre.a) & 15u) == 0);
+    }
 #define LAUNCH(S, H, XF, FA)                                                                                                          \
     hipLaunchKernelGGL((k_mlp_bwd<S, H, XF, FA>), dim3(blocks), dim3(kBlock), 0, stream, x, M, n_in, x_stride, w, in_cols, grad_out, \
-                       n_out, go_stride, grad_scale, grad_x, gx_stride, grad_weights_f32, vec_ok, gx_col0, gx_accumulate, go_vec)
+                       n_out, go_stride, grad_scale, grad_x, gx_stride, grad_weights_f32, vec_ok, gx_col0, gx_accumulate, go_vec, pre)
 #define BY_F(S, H, XF) do { if (fast) LAUNCH(S, H, XF, true); else LAUNCH(S, H, XF, false); } while (0)
 #define BY_X(S, H) do { if (x_is_f16) BY_F(S, H, true); else BY_F(S, H, false); } while (0)
 #define BY_H(S) do { if (n_hidden == 1) BY_X(S, 1); else BY_X(S, 2); } while (0)
@@ -364,4 +370,25 @@ NVSF_API int nvsf_mlp_bwd(const void* x, int x_is_f16, uint32_t M, uint32_t n_in
         default: return NVSF_ERR_UNSUPPORTED;
     }
     return nvsf_launch_status();
+}
+
+NVSF_API int nvsf_mlp_bwd(const void* x, int x_is_f16, uint32_t M, uint32_t n_in, uint32_t x_stride, const void* weights_f16,
+                          uint32_t in_cols, uint32_t hidden, uint32_t n_hidden, uint32_t out_cols, const float* grad_out, uint32_t n_out,
+                          uint32_t go_stride, float grad_scale, float* grad_x, uint32_t gx_stride, float* grad_weights_f32,
+                          uint32_t gx_col0, int gx_accumulate, hipStream_t stream) {
+    const XPrefix none = {nullptr, 0, 1, 0};
+    return mlp_bwd_impl(x, x_is_f16, M, n_in, x_stride, weights_f16, in_cols, hidden, n_hidden, out_cols, grad_out, n_out, go_stride, grad_scale,
+                        grad_x, gx_stride, grad_weights_f32, gx_col0, gx_accumulate, none, stream);
+}
+
+// nvsf_mlp_bwd on rows with a shared prefix (see nvsf_mlp_fwd_prefix); the columns of dL/dx are those of the logical row.
+NVSF_API int nvsf_mlp_bwd_prefix(const void* prefix_f16, uint32_t prefix_stride, uint32_t rows_per_prefix, uint32_t prefix_cols,
+                                 const void* x_f16, uint32_t M, uint32_t n_in, uint32_t x_stride, const void* weights_f16,
+                                 uint32_t in_cols, uint32_t hidden, uint32_t n_hidden, uint32_t out_cols, const float* grad_out,
+                                 uint32_t n_out, uint32_t go_stride, float grad_scale, float* grad_x, uint32_t gx_stride,
+                                 float* grad_weights_f32, uint32_t gx_col0, int gx_accumulate, hipStream_t stream) {
+    REQUIRE(prefix_f16 && prefix_cols > 0);
+    const XPrefix pre = {reinterpret_cast<const _Float16*>(prefix_f16), prefix_stride, rows_per_prefix, prefix_cols};
+    return mlp_bwd_impl(x_f16, 1, M, n_in, x_stride, weights_f16, in_cols, hidden, n_hidden, out_cols, grad_out, n_out, go_stride, grad_scale,
+                        grad_x, gx_stride, grad_weights_f32, gx_col0, gx_accumulate, pre, stream);
 }

@@ -127,10 +127,32 @@ __device__ __forceinline__ half8_t load_x_frag(const void* __restrict__ x, size_
     return v;
 }
 
+// Rows with a shared prefix: the first `split` columns of the network input are the same for `rows_per_a` consecutive rows (the
+// encoded direction of a ray for the T samples of that ray) and live once per group in `a`; `x` then holds the remaining columns
+// only.  The heads read 144 of their 192 input bytes per sample from a row that stays in L1 / L2 instead of from a per-sample copy.
+struct XPrefix {
+    const _Float16* a;  // nullptr: plain rows
+    uint32_t a_stride, rows_per_a, split;
+    __device__ __forceinline__ const _Float16* row_of(uint32_t first_row_of_tile) const {  // wave-uniform: a 16-row tile lies in one group
+        return a + (size_t)(first_row_of_tile / rows_per_a) * a_stride;
+    }
+};
+
 template <int IN_STEPS, bool X_F16, bool FAST>
 __device__ __forceinline__ void issue_x_row(half8_t (&xf)[IN_STEPS], const void* __restrict__ x, size_t row, uint32_t x_stride, int g, int n_in,
-                                            int in_cols, bool vec_ok, const XTail& tail) {
+                                            int in_cols, bool vec_ok, const XTail& tail, const _Float16* __restrict__ prefix_row = nullptr,
+                                            uint32_t split = 0) {
     if constexpr (FAST) {
+        if constexpr (X_F16) {
+            if (prefix_row) {  // wave-uniform
+                const _Float16* xrow = reinterpret_cast<const _Float16*>(x) + row * x_stride;
+                auto at = [&](int col) { return col < (int)split ? prefix_row + col : xrow + (col - (int)split); };
+#pragma unroll
+                for (int s = 0; s + 1 < IN_STEPS; ++s) xf[s] = *reinterpret_cast<const half8_t*>(at(32 * s + 8 * g));
+                xf[IN_STEPS - 1] = *reinterpret_cast<const half8_t*>(at(tail.koff));
+                return;
+            }
+        }
 #pragma unroll
         for (int s = 0; s + 1 < IN_STEPS; ++s) xf[s] = load_x_vec<X_F16>(x, row, x_stride, 32 * s + 8 * g);
         xf[IN_STEPS - 1] = load_x_vec<X_F16>(x, row, x_stride, tail.koff);

@@ -5,6 +5,7 @@ the trainer needs.  No arithmetic of the hot path happens in Python: every funct
 kernel launch on the current stream, forward and backward.
 """
 import math
+import os as _os
 
 import numpy as np
 import torch
@@ -144,13 +145,20 @@ def _rows(x):
     return x
 
 
-def mlp_forward(x, weights_f16, spec, out=None):
+def mlp_forward(x, weights_f16, spec, out=None, prefix=None):
     """x [M, n_in] (fp32 or fp16) -> fp32 [M, out_cols] (fp16 operands, fp32 accumulate, output not rounded).
-    `out`: optional fp32 destination, 16-byte aligned rows of >= out_cols columns (e.g. a column block of a wider buffer)."""
+    `out`: optional fp32 destination, 16-byte aligned rows of >= out_cols columns (e.g. a column block of a wider buffer).
+    `prefix` = (rows fp16 [G, >= n_cols], rows_per_prefix, n_cols): the first n_cols input columns of row r are
+    prefix_rows[r // rows_per_prefix] and x holds the remaining n_in - n_cols columns only (nvsf_mlp_fwd_prefix)."""
     x = _rows(x)
     M = x.shape[0]
     if out is None:
         out = torch.empty(M, spec.out_cols, dtype=torch.float32, device=x.device)
+    if prefix is not None:
+        rows, per, n_cols = prefix
+        _hip.call("nvsf_mlp_fwd_prefix", _hip.ptr_rows(rows), rows.stride(0), int(per), int(n_cols), _hip.ptr_rows(x), M, spec.n_in, x.stride(0),
+                  _hip.ptr(weights_f16), spec.in_cols, spec.hidden, spec.n_hidden, spec.out_cols, _hip.ptr_rows(out), out.stride(0))
+        return out
     _hip.call("nvsf_mlp_fwd", _hip.ptr_rows(x), 1 if x.dtype == torch.float16 else 0, M, spec.n_in, x.stride(0), _hip.ptr(weights_f16),
               spec.in_cols, spec.hidden, spec.n_hidden, spec.out_cols, _hip.ptr_rows(out), out.stride(0))
     return out
@@ -160,7 +168,7 @@ MLP_GRAD_SCALE = 128.0  # fp16 gradients inside nvsf_mlp_bwd are multiplied by t
 
 
 def mlp_backward(x, weights_f16, spec, grad_out, need_grad_x=True, grad_scale=MLP_GRAD_SCALE, grad_x=None, gx_col0=0,
-                 accumulate=False):
+                 accumulate=False, prefix=None):
     """One fused kernel: (x, weights, dL/dout [M, n_out] fp32) -> dL/dx fp32 [M, n_in] (or None), dL/dW fp32 [n_params].
     With `grad_x` given (fp32, unit column stride) the input gradient of columns gx_col0.. is written (or added, with
     `accumulate`) there: grad_x[:, j] = dL/dx[:, gx_col0 + j]."""
@@ -173,6 +181,13 @@ def mlp_backward(x, weights_f16, spec, grad_out, need_grad_x=True, grad_scale=ML
     if grad_x is None and need_grad_x:
         n_gx = spec.n_in - gx_col0  # rows padded to four floats: the kernel then stores 16 bytes per lane
         grad_x = torch.empty(M, (n_gx + 3) // 4 * 4, dtype=torch.float32, device=x.device)[:, :n_gx]
+    if prefix is not None:  # rows with a shared prefix (see mlp_forward)
+        rows, per, n_cols = prefix
+        _hip.call("nvsf_mlp_bwd_prefix", _hip.ptr_rows(rows), rows.stride(0), int(per), int(n_cols), _hip.ptr_rows(x), M, spec.n_in, x.stride(0),
+                  _hip.ptr(weights_f16), spec.in_cols, spec.hidden, spec.n_hidden, spec.out_cols, _hip.ptr_rows(grad_out), grad_out.shape[1],
+                  grad_out.stride(0), float(grad_scale), None if grad_x is None else _hip.ptr_rows(grad_x), 0 if grad_x is None else grad_x.stride(0),
+                  _hip.ptr(grad_w), int(gx_col0), 1 if accumulate else 0)
+        return grad_x, grad_w
     _hip.call("nvsf_mlp_bwd", _hip.ptr_rows(x), 1 if x.dtype == torch.float16 else 0, M, spec.n_in, x.stride(0), _hip.ptr(weights_f16),
               spec.in_cols, spec.hidden, spec.n_hidden, spec.out_cols, _hip.ptr_rows(grad_out), grad_out.shape[1], grad_out.stride(0),
               float(grad_scale), None if grad_x is None else _hip.ptr_rows(grad_x), 0 if grad_x is None else grad_x.stride(0),
@@ -244,11 +259,15 @@ def heads(model, d01, geo_feat, cal_lidar_color, ray_dirs01=None):
         net_a, net_b, enc = model.color_net, None, model.view_encoder_camera
     spec = net_a.spec
     M = geo_feat.shape[0]
-    buf = torch.empty(M, spec.in_cols, dtype=torch.float16, device=geo_feat.device)
+    n_enc_cols = enc.n_output_dims
+    # per-ray direction rows read by the MLP kernels themselves (shared-prefix rows): no [M, in_cols] input matrix at all
+    prefix_mode = (ray_dirs01 is not None and n_enc_cols % 8 == 0 and M % ray_dirs01.shape[0] == 0 and (M // ray_dirs01.shape[0]) % 16 == 0
+                   and spec.n_in - n_enc_cols <= 16 and spec.n_hidden <= 2 and _os.environ.get("NVSF_HEADS_INPUT") != "rows")  # "rows": the
+    # assembled [M, in_cols] input (test reference)
+    buf = None if prefix_mode else torch.empty(M, spec.in_cols, dtype=torch.float16, device=geo_feat.device)
     with torch.no_grad():
         src = d01 if ray_dirs01 is None else ray_dirs01
-        n_enc_cols = enc.n_output_dims
-        dst = buf if ray_dirs01 is None else torch.empty(src.shape[0], (n_enc_cols + 7) // 8 * 8, dtype=torch.float16, device=buf.device)
+        dst = buf if ray_dirs01 is None else torch.empty(src.shape[0], (n_enc_cols + 7) // 8 * 8, dtype=torch.float16, device=geo_feat.device)
         if enc.otype == "Frequency":
             freq_encode(src, enc.n_frequencies, out=dst)
         else:
@@ -280,7 +299,26 @@ class HeadsFn(Function):
     @staticmethod
     def forward(ctx, buf, n_enc, geo, params_a, w16_a, spec, params_b=None, w16_b=None, enc_ray=None):
         n_geo = geo.shape[1]
+        if buf is None:  # shared-prefix rows: x = [geometry | ones] fp16 [M, 16], the encoding stays one row per ray
+            assert enc_ray is not None and n_enc + n_geo == spec.n_in
+            g = geo if (geo.dtype in (torch.float16, torch.float32) and geo.stride(1) == 1) else geo.float().contiguous()
+            N, M = enc_ray.shape[0], geo.shape[0]
+            x16 = torch.empty(M, 16, dtype=torch.float16, device=geo.device)
+            _hip.call("nvsf_heads_input_f16", _hip.ptr(enc_ray), N, 0, enc_ray.stride(0), M // N, _hip.ptr_rows(g),
+                      1 if g.dtype == torch.float16 else 0, n_geo, g.stride(0), _hip.ptr(x16), 16, 16)
+            prefix = (enc_ray, M // N, n_enc)
+            ctx.save_for_backward(x16, w16_a, w16_b, enc_ray)
+            ctx.spec, ctx.n_enc, ctx.n_geo, ctx.geo_dtype, ctx.prefix_rows = spec, n_enc, n_geo, geo.dtype, M // N
+            if w16_b is None:
+                return mlp_forward(x16, w16_a, spec, prefix=prefix)[:, :spec.n_out]
+            blocks = torch.empty(M, 2 * spec.out_cols, dtype=torch.float32, device=geo.device)
+            mlp_forward(x16, w16_a, spec, out=blocks[:, :spec.out_cols], prefix=prefix)
+            mlp_forward(x16, w16_b, spec, out=blocks[:, spec.out_cols:], prefix=prefix)
+            if spec.n_out == 1:
+                return blocks.view(M, 2, spec.out_cols)[:, :, 0]
+            return blocks.view(M, 2, spec.out_cols)[:, :, :spec.n_out].reshape(M, 2 * spec.n_out)
         assert n_enc + n_geo == spec.n_in and buf.shape[1] >= spec.n_in and buf.dtype == torch.float16
+        ctx.prefix_rows = None
         if enc_ray is not None:  # per-ray encoding [N, >= n_enc] fp16: rows assembled whole (nvsf_heads_input_f16)
             g = geo if (geo.dtype in (torch.float16, torch.float32) and geo.stride(1) == 1) else geo.float().contiguous()
             N = enc_ray.shape[0]
@@ -305,18 +343,24 @@ class HeadsFn(Function):
 
     @staticmethod
     def backward(ctx, grad_h):
-        buf, w16_a, w16_b = ctx.saved_tensors
+        prefix = None
+        if ctx.prefix_rows is not None:
+            buf, w16_a, w16_b, enc_ray = ctx.saved_tensors
+            prefix = (enc_ray, ctx.prefix_rows, ctx.n_enc)
+            u = buf
+        else:
+            buf, w16_a, w16_b = ctx.saved_tensors
+            u = buf[:, :ctx.spec.n_in]
         spec, n_enc, n_geo = ctx.spec, ctx.n_enc, ctx.n_geo
-        u = buf[:, :spec.n_in]
         grad_h = grad_h.float().contiguous()
         M = buf.shape[0]
         need_geo = ctx.needs_input_grad[2]
         grad_geo = torch.empty(M, (n_geo + 3) // 4 * 4, dtype=torch.float32, device=buf.device)[:, :n_geo] if need_geo else None
-        _, gw_a = mlp_backward(u, w16_a, spec, grad_h[:, :spec.n_out], need_grad_x=need_geo, grad_x=grad_geo, gx_col0=n_enc)
+        _, gw_a = mlp_backward(u, w16_a, spec, grad_h[:, :spec.n_out], need_grad_x=need_geo, grad_x=grad_geo, gx_col0=n_enc, prefix=prefix)
         gw_b = None
         if w16_b is not None:
             _, gw_b = mlp_backward(u, w16_b, spec, grad_h[:, spec.n_out:2 * spec.n_out], need_grad_x=need_geo, grad_x=grad_geo,
-                                   gx_col0=n_enc, accumulate=True)
+                                   gx_col0=n_enc, accumulate=True, prefix=prefix)
         if grad_geo is not None and grad_geo.dtype != ctx.geo_dtype:
             grad_geo = grad_geo.to(ctx.geo_dtype)
         return (None, None, grad_geo, gw_a if ctx.needs_input_grad[3] else None, None, None,

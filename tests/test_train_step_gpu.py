@@ -441,3 +441,36 @@ def test_fused_loss_kernels_match_the_torch_expressions(dev):
     lr = (0.7 * (a - b) ** 2).sum()
     (gr,) = torch.autograd.grad(lr * 2.0, a)
     assert abs(float(l) - float(lr)) <= 1e-5 * float(lr) and torch.allclose(ga, gr, rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize("lidar", [True, False])
+def test_heads_on_shared_prefix_rows_equal_assembled_rows(dev, lidar, monkeypatch):
+    """ops.heads with per-ray directions lets the MLP kernels read the ray's encoded direction from ONE row per ray
+    (nvsf_mlp_fwd_prefix / nvsf_mlp_bwd_prefix) instead of from an assembled [M, in_cols] matrix (NVSF_HEADS_INPUT=rows): the
+    operands are the same fp16 values, so the logits are equal bit for bit; parameter and geometry gradients equal up to the
+    order of the fp32 atomics of the weight gradients."""
+    from nvsf import field_ops as ops, synthetic as S
+    from nvsf.nerf.models.network_static import NeRFNetworkStatic
+    torch.manual_seed(3)
+    m = NeRFNetworkStatic(bound=S.BOUND, min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH, log2_hashmap_size=12).to(dev)
+    N, T = 37, 48
+    g = torch.Generator(device="cpu").manual_seed(8)
+    dirs01 = torch.rand(N, 3, generator=g).to(dev)
+    geo0 = (torch.randn(N * T, 16, generator=g).to(dev))[:, 1:]  # the unaligned fp32 view the density MLP's output gives
+    w = torch.randn(N * T, 2 if lidar else 3, generator=g).to(dev)
+    nets = (m.raydrop_net, m.intensity_net) if lidar else (m.color_net,)
+    res = {}
+    for mode in ("prefix", "rows"):
+        if mode == "rows":
+            monkeypatch.setenv("NVSF_HEADS_INPUT", "rows")
+        geo = geo0.clone().requires_grad_()
+        for n in nets:
+            n.params.grad = None
+        out = ops.heads(m, None, geo, lidar, ray_dirs01=dirs01)
+        (out * w).sum().backward()
+        res[mode] = (out.detach().clone(), geo.grad.clone(), [n.params.grad.clone() for n in nets])
+    monkeypatch.delenv("NVSF_HEADS_INPUT")
+    assert torch.equal(res["prefix"][0], res["rows"][0])
+    assert torch.allclose(res["prefix"][1], res["rows"][1], rtol=1e-5, atol=1e-6 * float(res["rows"][1].abs().max()))
+    for a, b in zip(res["prefix"][2], res["rows"][2]):
+        assert float(b.abs().max()) > 0 and float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())
