@@ -150,20 +150,75 @@ __device__ __forceinline__ void blend_quad(const u2_t (&raw)[4], const float (&f
     }
 }
 
+// Two lanes per sample (lane = 2 * sample + x-bit, 32 samples per pass, two passes per item): a lane gathers the two corners with
+// its x-bit of a slice, so a gather instruction fetches BOTH x-neighbours of 32 samples -- the same 16-byte pair for even cells,
+// the same 128-byte line otherwise -- and the kernel, which is bound by the L1 look-ups of its ~200 eight-byte gathers per sample,
+// makes half of them.  The even lane blends features 0, 1 of all four corners, the odd lane features 2, 3 (the partner's halves
+// arrive by a quad swap), each in the corner order of encode_level<2, 4>; the odd lane then hands its two rounded features per
+// slice to the even lane, which runs blend_reduce as the one-lane form does: bit-identical outputs.
+__device__ __forceinline__ uint32_t pair_swap(uint32_t v) {  // value of lane ^ 1
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1 /* quad_perm [1,0,3,2] */, 0xF, 0xF, true);
+}
+__device__ __forceinline__ float pair_swap_f(float v) { return __builtin_bit_cast(float, pair_swap(__builtin_bit_cast(uint32_t, v))); }
+
+// this lane's two corners (x-bit xb, y = 0, 1) of the cell of xy
+__device__ __forceinline__ void gather_pair(const float (&xy)[2], uint32_t xb, const _Float16* __restrict__ table, float scale, uint32_t res,
+                                            uint32_t row0, uint32_t hsize, uint32_t (&cell)[2], float (&frac)[2], u2_t (&raw)[2]) {
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        const float pos = fmaf(scale, xy[d], 0.5f);
+        const float fl = floorf(pos);
+        frac[d] = pos - fl;
+        cell[d] = (uint32_t)(int32_t)fl;
+    }
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+        const uint32_t cc[2] = {cell[0] + xb, cell[1] + (uint32_t)y};
+        raw[y] = *reinterpret_cast<const u2_t*>(table + ((size_t)row0 + grid_row<2>(cc, res, hsize)) * kF);
+    }
+}
+// features (2 xb, 2 xb + 1) of the cell, blended over the four corners in encode_level's order, rounded to fp16 as the slice encoders return them
+__device__ __forceinline__ void blend_pair(const u2_t (&raw)[2], uint32_t xb, const float (&frac)[2], float (&f)[2]) {
+    uint32_t mine[4];  // this lane's feature pair of corner c = x + 2 y
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+        const uint32_t own = xb ? raw[y][1] : raw[y][0], send = xb ? raw[y][0] : raw[y][1];
+        const uint32_t recv = pair_swap(send);
+        mine[2 * y] = xb ? recv : own;
+        mine[2 * y + 1] = xb ? own : recv;
+    }
+    f[0] = f[1] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float wc = 1.0f;
+#pragma unroll
+        for (int d = 0; d < 2; ++d) wc = wc * ((c & (1 << d)) ? frac[d] : (1.0f - frac[d]));
+        const h2_t v = __builtin_bit_cast(h2_t, mine[c]);
+        f[0] = fmaf(wc, (float)v[0], f[0]);
+        f[1] = fmaf(wc, (float)v[1], f[1]);
+    }
+    f[0] = r16(f[0]);
+    f[1] = r16(f[1]);
+}
+
 __global__ __launch_bounds__(kBlock) void k_hash_dynamic3(const float* __restrict__ x, uint32_t x_stride, const float* __restrict__ off,
                                                           uint32_t off_stride, uint32_t M, PlaneSet3 ps, float* __restrict__ out0,
                                                           _Float16* __restrict__ out1, _Float16* __restrict__ out2) {
     __shared__ float stage[3][kSamplesPerBlock][3 * kPlaneLevels + 1];
     const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
-    const uint32_t m = blockIdx.x * kSamplesPerBlock + lane;
-    const uint32_t mm = m < M ? m : M - 1;
-    float p[3][3];
+    const uint32_t xb = (uint32_t)(lane & 1);
+    float p[2][3][3];  // [pass][evaluation][axis]
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        const float xd = x[(size_t)mm * x_stride + d];
-        p[0][d] = xd;
-        p[1][d] = ps.enabled[1] ? xd + off[(size_t)mm * off_stride + d] : xd;
-        p[2][d] = ps.enabled[2] ? xd + off[(size_t)mm * off_stride + 3 + d] : xd;
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t m = blockIdx.x * kSamplesPerBlock + 32u * h + (uint32_t)(lane >> 1);
+        const uint32_t mm = m < M ? m : M - 1;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float xd = x[(size_t)mm * x_stride + d];
+            p[h][0][d] = xd;
+            p[h][1][d] = ps.enabled[1] ? xd + off[(size_t)mm * off_stride + d] : xd;
+            p[h][2][d] = ps.enabled[2] ? xd + off[(size_t)mm * off_stride + 3 + d] : xd;
+        }
     }
     for (int item = wave; item < 3 * kPlaneLevels; item += 4) {
         const int pl = item / kPlaneLevels, l = item - pl * kPlaneLevels;
@@ -171,71 +226,66 @@ __global__ __launch_bounds__(kBlock) void k_hash_dynamic3(const float* __restric
         const GridMeta& g = ps.meta[pl];
         const float scale = g.scale[l];
         const uint32_t res = g.res[l], row0 = g.offset[l], rows = g.offset[l + 1] - g.offset[l];
-        // ---- base evaluation: gathers kept
-        uint32_t cell0[2];
-        float frac0[2];
-        u2_t lo0[4], hi0[4];
-        {
-            const float xy[2] = {p[0][ia], p[0][ib]};
-            gather_quad(xy, ps.ev[0].table_lo[pl], scale, res, row0, rows, cell0, frac0, lo0);
-            if (!ps.ev[0].same_slice) {
-                uint32_t c_[2];
-                float f_[2];
-                gather_quad(xy, ps.ev[0].table_hi[pl], scale, res, row0, rows, c_, f_, hi0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = 32 * h + (lane >> 1);
+            // ---- base evaluation: gathers kept
+            uint32_t cell0[2];
+            float frac0[2];
+            u2_t lo0[2], hi0[2];
+            {
+                const float xy[2] = {p[h][0][ia], p[h][0][ib]};
+                gather_pair(xy, xb, ps.ev[0].table_lo[pl], scale, res, row0, rows, cell0, frac0, lo0);
+                if (!ps.ev[0].same_slice) {
+                    uint32_t c_[2];
+                    float f_[2];
+                    gather_pair(xy, xb, ps.ev[0].table_hi[pl], scale, res, row0, rows, c_, f_, hi0);
+                } else {
+                    hi0[0] = lo0[0];
+                    hi0[1] = lo0[1];
+                }
+                float a[2], b[2] = {0.0f, 0.0f};
+                blend_pair(lo0, xb, frac0, a);
+                if (!ps.ev[0].same_slice) blend_pair(hi0, xb, frac0, b);
+                // features 2, 3 come from the odd lane; the even lane reduces
+                const float a2 = pair_swap_f(a[0]), a3 = pair_swap_f(a[1]), b2 = pair_swap_f(b[0]), b3 = pair_swap_f(b[1]);
+                const float f_lo[kF] = {a[0], a[1], a2, a3}, f_hi[kF] = {b[0], b[1], b2, b3};
+                if (xb == 0u) stage[0][row][item] = blend_reduce<0>(f_lo, f_hi, ps.ev[0]);
             }
-            float f_lo[kF], f_hi[kF];
-            blend_quad(lo0, frac0, f_lo);
+            // ---- neighbour evaluations (regime 1)
 #pragma unroll
-            for (int i = 0; i < kF; ++i) f_lo[i] = r16(f_lo[i]);
-            if (!ps.ev[0].same_slice) {
-                blend_quad(hi0, frac0, f_hi);
+            for (int e = 1; e < 3; ++e) {
+                if (!ps.enabled[e]) continue;
+                const TimeSet& pe = ps.ev[e];
+                const float xy[2] = {p[h][e][ia], p[h][e][ib]};
+                uint32_t cell[2];
+                float frac[2];
 #pragma unroll
-                for (int i = 0; i < kF; ++i) f_hi[i] = r16(f_hi[i]);
-            } else {
+                for (int d = 0; d < 2; ++d) {
+                    const float pos = fmaf(scale, xy[d], 0.5f);
+                    const float fl = floorf(pos);
+                    frac[d] = pos - fl;
+                    cell[d] = (uint32_t)(int32_t)fl;
+                }
+                u2_t lo[2], hi[2];
+                const bool reuse = ps.share[e] && cell[0] == cell0[0] && cell[1] == cell0[1];  // the same for both lanes of a sample
+                if (reuse) {
 #pragma unroll
-                for (int i = 0; i < kF; ++i) f_hi[i] = 0.0f;
+                    for (int y = 0; y < 2; ++y) { lo[y] = lo0[y]; hi[y] = hi0[y]; }
+                } else {
+                    uint32_t c_[2];
+                    float f_[2];
+                    gather_pair(xy, xb, pe.table_lo[pl], scale, res, row0, rows, c_, f_, lo);
+                    if (!pe.same_slice) gather_pair(xy, xb, pe.table_hi[pl], scale, res, row0, rows, c_, f_, hi);
+                    else { hi[0] = lo[0]; hi[1] = lo[1]; }
+                }
+                float a[2], b[2] = {0.0f, 0.0f};
+                blend_pair(lo, xb, frac, a);
+                if (!pe.same_slice) blend_pair(hi, xb, frac, b);
+                const float a2 = pair_swap_f(a[0]), a3 = pair_swap_f(a[1]), b2 = pair_swap_f(b[0]), b3 = pair_swap_f(b[1]);
+                const float f_lo[kF] = {a[0], a[1], a2, a3}, f_hi[kF] = {b[0], b[1], b2, b3};
+                if (xb == 0u) stage[e][row][item] = blend_reduce<1>(f_lo, f_hi, pe);
             }
-            stage[0][lane][item] = blend_reduce<0>(f_lo, f_hi, ps.ev[0]);
-        }
-        // ---- neighbour evaluations (regime 1)
-#pragma unroll
-        for (int e = 1; e < 3; ++e) {
-            if (!ps.enabled[e]) continue;
-            const TimeSet& pe = ps.ev[e];
-            const float xy[2] = {e == 1 ? p[1][ia] : p[2][ia], e == 1 ? p[1][ib] : p[2][ib]};
-            uint32_t cell[2];
-            float frac[2];
-#pragma unroll
-            for (int d = 0; d < 2; ++d) {
-                const float pos = fmaf(scale, xy[d], 0.5f);
-                const float fl = floorf(pos);
-                frac[d] = pos - fl;
-                cell[d] = (uint32_t)(int32_t)fl;
-            }
-            u2_t lo[4], hi[4];
-            const bool reuse = ps.share[e] && cell[0] == cell0[0] && cell[1] == cell0[1];
-            if (reuse) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { lo[c] = lo0[c]; hi[c] = hi0[c]; }
-            } else {
-                uint32_t c_[2];
-                float f_[2];
-                gather_quad(xy, pe.table_lo[pl], scale, res, row0, rows, c_, f_, lo);
-                if (!pe.same_slice) gather_quad(xy, pe.table_hi[pl], scale, res, row0, rows, c_, f_, hi);
-            }
-            float f_lo[kF], f_hi[kF];
-            blend_quad(lo, frac, f_lo);
-#pragma unroll
-            for (int i = 0; i < kF; ++i) f_lo[i] = r16(f_lo[i]);
-            if (!pe.same_slice) {
-                blend_quad(hi, frac, f_hi);
-#pragma unroll
-                for (int i = 0; i < kF; ++i) f_hi[i] = r16(f_hi[i]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < kF; ++i) f_hi[i] = 0.0f;
-            }
-            stage[e][lane][item] = blend_reduce<1>(f_lo, f_hi, pe);
         }
     }
     __syncthreads();
