@@ -12,8 +12,8 @@ src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
 
 def one(pat):
     f = glob.glob(os.path.join(src, pat), recursive=True)
-    assert len(f) == 1, (pat, f)
-    return f[0]
+    assert f, pat
+    return max(f, key=os.path.getmtime)  # a tag run twice leaves both runs' files behind: the newest counts
 
 
 for leg, name in (("kt", "bench"), ("kt_train", "train"), ("kt_occ", "occupancy"), ("kt_dyn", "dynamic"), ("kt_dyn_train", "dynamic_train")):
