@@ -208,6 +208,13 @@ int nvsf_heads_input_f16(const void* enc_ray_f16, uint32_t N, uint32_t n_enc, ui
 int nvsf_masked_sigmoid(const float* logits, uint32_t row_stride, uint32_t col_stride, const void* mask_u8, uint32_t M, uint32_t C,
                         float* out, nvsf_stream_t stream);
 
+/* Backward of the above from its output (aten::sigmoid_backward): grad_in = (grad_out * (1 - out)) * out, n floats. */
+int nvsf_sigmoid_bwd(const float* grad_out, const float* out, uint32_t n, float* grad_in, nvsf_stream_t stream);
+
+/* ref: trunc_exp forward, nvsf/nerf/activation.py:9-11, on one column of a row-strided fp32 matrix: out[m] = exp(h[m][col])
+ * (the density logit of the sigma MLP's [M,16] output, network_dynamic.py:281). */
+int nvsf_exp_col(const float* h, uint32_t row_stride, uint32_t col, uint32_t M, float* out, nvsf_stream_t stream);
+
 /* ref: tcnn.Network("FullyFusedMLP") network_dynamic.py:125-135,138-161,180-189.
  * x [M, x_stride] fp32 (x_is_f16 == 0) or fp16; weights fp16 = W0 [hidden][in_cols] ++ (n_hidden-1) x
  * [hidden][hidden] ++ W_out [out_cols][hidden]; columns n_in..in_cols-1 of the input read as 1.0.

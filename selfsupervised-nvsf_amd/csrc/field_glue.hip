@@ -147,6 +147,19 @@ __global__ __launch_bounds__(kBlock) void k_masked_sigmoid(const float* __restri
     if (!mask || mask[m]) v = 1.0f / (1.0f + expf(-logits[(size_t)m * row_stride + (size_t)c * col_stride]));
     out[idx] = v;
 }
+
+// grad_in = (grad_out * (1 - out)) * out: sigmoid's backward from its output (what aten::sigmoid_backward computes), one pass
+__global__ __launch_bounds__(kBlock) void k_sigmoid_bwd(const float* __restrict__ grad_out, const float* __restrict__ out, uint32_t n,
+                                                        float* __restrict__ grad_in) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) grad_in[i] = (grad_out[i] * (1.0f - out[i])) * out[i];
+}
+
+// out[m] = exp(h[m][col]) for row-strided h: trunc_exp's forward (activation.py:9-11) on the density logit column of the sigma MLP's output
+__global__ __launch_bounds__(kBlock) void k_exp_col(const float* __restrict__ h, uint32_t row_stride, uint32_t col, uint32_t M, float* __restrict__ out) {
+    const uint32_t m = blockIdx.x * kBlock + threadIdx.x;
+    if (m < M) out[m] = expf(h[(size_t)m * row_stride + col]);
+}
 }  // namespace
 
 #define REQUIRE(cond) do { if (!(cond)) return NVSF_ERR_INVALID_ARG; } while (0)
@@ -232,5 +245,19 @@ NVSF_API int nvsf_masked_sigmoid(const float* logits, uint32_t row_stride, uint3
     REQUIRE(logits && out && (unsigned long long)M * C < (1ull << 32));
     hipLaunchKernelGGL(k_masked_sigmoid, dim3(cdiv((unsigned long long)M * C, kBlock)), dim3(kBlock), 0, stream, logits, row_stride, col_stride,
                        reinterpret_cast<const unsigned char*>(mask_u8), M, C, out);
+    return nvsf_launch_status();
+}
+
+NVSF_API int nvsf_sigmoid_bwd(const float* grad_out, const float* out, uint32_t n, float* grad_in, hipStream_t stream) {
+    if (n == 0) return NVSF_OK;
+    REQUIRE(grad_out && out && grad_in);
+    hipLaunchKernelGGL(k_sigmoid_bwd, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, stream, grad_out, out, n, grad_in);
+    return nvsf_launch_status();
+}
+
+NVSF_API int nvsf_exp_col(const float* h, uint32_t row_stride, uint32_t col, uint32_t M, float* out, hipStream_t stream) {
+    if (M == 0) return NVSF_OK;
+    REQUIRE(h && out && col < row_stride);
+    hipLaunchKernelGGL(k_exp_col, dim3(cdiv(M, kBlock)), dim3(kBlock), 0, stream, h, row_stride, col, M, out);
     return nvsf_launch_status();
 }

@@ -46,6 +46,8 @@ SIGNATURES = {
     "nvsf_sigma_geo_bwd": [_P, _P, _P, _U, _U, _U, _P, _U, _F, _F],
     "nvsf_cast_cols_f16": [_P, _I, _U, _U, _U, _P, _U],
     "nvsf_masked_sigmoid": [_P, _U, _U, _P, _U, _U, _P],
+    "nvsf_sigmoid_bwd": [_P, _P, _U, _P],
+    "nvsf_exp_col": [_P, _U, _U, _U, _P],
     "nvsf_repeat_rows_f16": [_P, _U, _U, _U, _U, _P, _U],
     "nvsf_heads_input_f16": [_P, _U, _U, _U, _U, _P, _I, _U, _U, _P, _U, _U],
     "nvsf_mlp_fwd": [_P, _I, _U, _U, _U, _P, _U, _U, _U, _U, _P, _U],

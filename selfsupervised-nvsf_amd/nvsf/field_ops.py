@@ -214,7 +214,10 @@ class MaskedSigmoidFn(Function):
     @staticmethod
     def backward(ctx, g):
         (out,) = ctx.saved_tensors
-        return torch.ops.aten.sigmoid_backward(g.contiguous(), out), None
+        g = g.float().contiguous()
+        grad = torch.empty_like(out)
+        _hip.call("nvsf_sigmoid_bwd", _hip.ptr(g), _hip.ptr(out), out.numel(), _hip.ptr(grad))
+        return grad, None
 
 
 # ---- dense / sparse choice of the per-sample heads without a host sync per call ------------------------------------------------
@@ -441,7 +444,8 @@ class DensityFn(Function):
         x01 = x01.float().contiguous()
         feat = hashgrid_forward(x01, (0, 1, 2), table_f16, grid_spec)
         h = mlp_forward(feat, mlp_w16, mlp_spec)
-        sigma = torch.exp(h[:, 0])
+        sigma = torch.empty(h.shape[0], dtype=torch.float32, device=h.device)
+        _hip.call("nvsf_exp_col", _hip.ptr(h), h.stride(0), 0, h.shape[0], _hip.ptr(sigma))
         ctx.save_for_backward(x01, feat, sigma, mlp_w16)
         ctx.grid_spec, ctx.mlp_spec, ctx.clamp = grid_spec, mlp_spec, (float(sigma_lo), float(sigma_hi))
         ctx.table_param = table_params
