@@ -474,3 +474,32 @@ def test_heads_on_shared_prefix_rows_equal_assembled_rows(dev, lidar, monkeypatc
     assert torch.allclose(res["prefix"][1], res["rows"][1], rtol=1e-5, atol=1e-6 * float(res["rows"][1].abs().max()))
     for a, b in zip(res["prefix"][2], res["rows"][2]):
         assert float(b.abs().max()) > 0 and float((a - b).abs().max()) <= 1e-4 * float(b.abs().max())
+
+
+def test_step_without_the_chamfer_term_and_with_a_lidar_only_batch(dev):
+    """Option branches of the step: chamfer_loss=False (the loss kernel then forms no point clouds), a LiDAR-only batch (no split, the
+    camera parameters keep grad None and FusedAdam skips them) -- finite losses, the expected parts, parameters move."""
+    from nvsf import synthetic as S
+    from nvsf.nerf.models.network_static import NeRFNetworkStatic
+    from nvsf.nerf.train_step import RenderTrainStep
+    kw = dict(bound=S.BOUND, min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH, log2_hashmap_size=14)
+    torch.manual_seed(6)
+    teacher = NeRFNetworkStatic(**kw)
+    with torch.no_grad():
+        for enc in (teacher.hash_encoder_lidar, teacher.hash_encoder_camera):
+            enc.params.normal_(0.0, 0.2)
+    teacher = teacher.to(dev).eval()
+    batch = _batch(S, teacher, dev, n=300, T=32, seed=5)
+    torch.manual_seed(7)
+    m = NeRFNetworkStatic(**kw).to(dev)
+    step = RenderTrainStep(m, num_steps=32, scale=S.SCALE, ema_decay=None, chamfer_loss=False)
+    step.scaler = torch.amp.GradScaler("cuda", init_scale=64.0, growth_interval=10 ** 6)
+    loss, parts, _ = step.step(batch)
+    assert set(parts) == {"depth", "raydrop", "intensity", "rgb"} and bool(torch.isfinite(loss))
+    before = m.hash_encoder_camera.params.detach().clone()
+    lidar_only = {k: v for k, v in batch.items() if k not in RenderTrainStep.CAMERA_KEYS}
+    loss, parts, _ = step.step(lidar_only)
+    torch.cuda.synchronize()
+    assert set(parts) == {"depth", "raydrop", "intensity"} and bool(torch.isfinite(loss))
+    assert m.hash_encoder_camera.params.grad is None and torch.equal(m.hash_encoder_camera.params, before)
+    assert all(bool(torch.isfinite(p).all()) for p in m.parameters())
