@@ -616,12 +616,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 
 // Static balance of the encode pass (host).  Cost of a slice relative to the VALU work of streaming every sample through one XCD
 // (= 1; 0.16 ms for 3.1 M samples).  With c = res_l / T = the number of cells a step crosses at level l on a ray that spans the
-// box, the finer level of the slice costs fill(c) = 1 + 0.72 clamp((c - 0.3) / 0.72, 0, 1) + 0.17 max(0, c - 1): from c ~ 1 on
+// box, the finer level of the slice costs fill(c) = 1 + 0.72 clamp((c - 0.3) / 0.72, 0, 1) + 0.25 max(0, c - 1): from c ~ 1 on
 // every look-up misses L1 and the CU moves a 128-byte line per look-up (levels 9 ... 15 alone at T = 768: 1.07 1.21 1.47 1.72 1.77
-// 1.85 2.14 measured, 1.08 1.23 1.43 1.72 1.79 1.88 2.00 by this formula); the coarser level adds 0.16, a hashed one 0.16 + 1.6 c
+// 1.85 2.14 measured, 1.08 1.23 1.43 1.72 1.82 1.95 2.14 by this formula); the coarser level adds 0.16, a hashed one 0.16 + 1.6 c
 // (levels 5, 6, 7 as partners: 0.31 0.39 0.47 measured).  Slices above the mean give the tail of their units to the groups of the
-// slices below it, at most kPlanItems - 1 foreign items per group; a foreign item is priced 15 % higher (its levels are not in that
-// XCD's L2; 1.0 ... 1.3 measure the same).  A model, not a measurement: it only decides who encodes what, never what is written.
+// slices below it, at most kPlanItems - 1 foreign items per group; a foreign item is priced 5 % higher (its levels are not in that
+// XCD's L2; 1.0 ... 1.3 measure within 1 %).  A model, not a measurement: it only decides who encodes what, never what is written.
 static SlicePlan slice_plan(uint32_t n_units, uint32_t T, const uint32_t* h_res, uint32_t first_hashed, bool balance) {
     SlicePlan plan = {};
     for (uint32_t g = 0; g < 8; ++g) {
@@ -636,11 +636,11 @@ static SlicePlan slice_plan(uint32_t n_units, uint32_t T, const uint32_t* h_res,
         const uint32_t grp = p >> 1, la = (p & 1u) ? grp + 4u : grp, lb = (p & 1u) ? grp + 8u : grp + 12u;
         const double c = (double)h_res[lb] / (double)T, ca = (double)h_res[la] / (double)T;
         const double ramp = c <= 0.3 ? 0.0 : (c >= 1.02 ? 1.0 : (c - 0.3) / 0.72);
-        const double fill = 1.0 + 0.72 * ramp + 0.17 * (c > 1.0 ? c - 1.0 : 0.0);
+        const double fill = 1.0 + 0.72 * ramp + 0.25 * (c > 1.0 ? c - 1.0 : 0.0);
         cost[p] = fill + (la >= first_hashed ? 0.16 + 1.6 * ca : 0.16);
         mean += cost[p] / 8.0;
     }
-    const double penalty = 1.15;
+    const double penalty = 1.05;
     double spare[8];
     for (uint32_t p = 0; p < 8; ++p) spare[p] = mean - cost[p];  // > 0: capacity of group p, < 0: excess of slice p
     for (int round = 0; round < 8; ++round) {
