@@ -201,171 +201,293 @@ __global__ __launch_bounds__(kBlock) void k_march_write_wave(const float* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// march_rays_train in ONE launch (nvsf_march_rays_train_ws).
+// march_rays_train in ONE launch that classifies every chain member ONCE (nvsf_march_rays_train_ws).
 //
-// The three-launch form classifies every chain member twice (count pass, write pass: ~150 VALU instructions per 64 members
-// each) because the sample ranges are only known after the scan.  Here a wave counts its ray ONCE and keeps, per batch that
-// holds samples, the batch's first chain parameter and its 64-bit sample mask in LDS (16 bytes); the ranges come from a
-// chained scan over the workgroups inside the same launch ("decoupled look-back": a workgroup publishes the sum of its four
-// rays, then its inclusive prefix once it has seen its predecessors'), after which the wave replays its records -- members by
-// the closed form of Marcher::fill_batch, positions by the marcher's own clamp(o + t d) -- and stores the samples.  No second
-// classification, no scan launch; the count phase of some waves overlaps the store phase of others.
+// The reference-shaped three-launch form classifies every chain member twice (count pass, write pass: ~115 VALU instructions per
+// 64 members each) because the sample ranges are only known after the scan.  Here a wave counts its ray once and keeps, per batch
+// that holds samples, a 16-byte record {first chain parameter, members, 64-bit sample mask} and (for the first kMarchBtCap
+// batches) the 64 member parameters in LDS; once the ray's range is known it replays the records -- positions by the marcher's
+// own clamp(o + t d) -- and stores the samples.  No second classification, and the stores of one ticket drain while the next
+// one is counted (counting is VALU-bound, the stores are not).
 // Order of the packed samples: ray-index order, exactly as the three-launch form and the CPU oracle (the reference's order
 // depends on the arrival order of its atomics, raymarching.cu:445-446).
-// Inter-workgroup protocol (cdna_hip_programming.md Guideline 16, recipe R2): a workgroup's identity is a ticket drawn from
-// an atomic counter, so every predecessor of a running workgroup is itself running (no assumption about dispatch order);
-// each flag is ONE naturally aligned 8-byte {status, value} granule written by a single agent-scope atomic store and read
-// by agent-scope atomic loads -- no other data crosses workgroups.  Every spin is bounded (kMarchSpinLimit polls); on a
-// timeout the launch still terminates and reports through counter[1] = -1.
-constexpr int kMarchRecCap = 48;           // records per ray kept in LDS; a ray with more sample-bearing batches re-marches when writing
+//
+// Where the ranges come from.  Workgroups 1.. are WORKERS: they draw tickets (4 consecutive rays, one per wave) from an atomic
+// counter until none are left; per ticket: count, publish the ticket's sum, and -- one ticket LATER, after counting the next one --
+// fetch the ticket's exclusive prefix and store.  Workgroup 0 is the SCANNER: one wave that walks the published sums in ticket
+// order (up to 512 per poll) and publishes every ticket's exclusive prefix.  A worker therefore touches two 8-byte flags per
+// ticket and never adds up anybody else's sums.  (Two earlier forms of this launch let every workgroup look back over its
+// predecessors' sums itself: all workgroups of the chip start together, finish counting together, and each then needs ~2000
+// flags through agent-scope loads that miss the L2s -- 0.15 of 0.30 ms was waiting, and counting the next ticket meanwhile did
+// not help because the look-back itself was the cost.  Count / scan / replay as three launches with the records in global
+// memory: 0.36 ms, the stores no longer overlap the counting.)
+// Inter-workgroup protocol (cdna_hip_programming.md Guideline 16, recipe R2): a ticket is drawn by a RUNNING workgroup, which
+// publishes the ticket's sum without waiting for anything, so the scanner (workgroup 0: dispatched first) only ever waits for
+// running workgroups, and workers only wait for the scanner.  Each flag is ONE naturally aligned 8-byte {status, value} granule
+// written by a single agent-scope atomic store and read by agent-scope atomic loads -- no other data crosses workgroups.  Every
+// spin is bounded (kMarchSpinLimit polls); on a timeout the launch still terminates and reports through counter[1] = -1.
+constexpr int kMarchRecCap = 24;  // records per ray kept in LDS; a ray with more sample-bearing batches re-marches when writing
+constexpr int kMarchBtCap = 8;    // batches per ray whose member parameters stay in LDS (the others come from Marcher::fill_batch again)
+constexpr int kMarchRays = kBlock / kWave;  // rays per ticket: one per wave
 constexpr uint32_t kMarchSpinLimit = 1u << 22;
 struct MarchRec { float t0; uint32_t nb; unsigned long long S; };
 
-__device__ __forceinline__ void march_store_batch(const Marcher& m, float bt, float bx, float by, float bz, float bdt, unsigned long long S,
+// OFF32: 12 * M < 2^32, so sample byte offsets fit 32 bits and the stores take the scalar base + 32-bit lane offset form (no
+// 64-bit multiply-adds per lane).  The per-lane sample index is offset + step + (samples of the batch below the lane); the second
+// delta needs t + dt of the previous sample: the neighbouring lane when the batch's samples are a contiguous run (one DPP move),
+// the lane below found through the mask otherwise.
+struct MarchDirs { float x, y, z; };
+template <bool OFF32>
+__device__ __forceinline__ void march_store_batch(const MarchDirs& dv, float bt, float bx, float by, float bz, float bdt, unsigned long long S,
                                                   int lane, uint32_t offset, uint32_t& step, float& last_t, float* __restrict__ xyzs,
                                                   float* __restrict__ dirs, float* __restrict__ deltas) {
     const float t_after = bt + bdt;
     const unsigned long long lower = S & ((1ull << lane) - 1ull);  // samples of this batch before this lane
-    const int prev_lane = lower ? 63 - __builtin_clzll(lower) : lane;
-    const float prev_after = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(prev_lane << 2, __builtin_bit_cast(int, t_after)));
-    if ((S >> lane) & 1ull) {
-        const size_t s = (size_t)offset + step + (uint32_t)__builtin_popcountll(lower);
-        xyzs[3 * s] = bx; xyzs[3 * s + 1] = by; xyzs[3 * s + 2] = bz;
-        dirs[3 * s] = m.dx; dirs[3 * s + 1] = m.dy; dirs[3 * s + 2] = m.dz;
-        deltas[2 * s] = bdt; deltas[2 * s + 1] = t_after - (lower ? prev_after : last_t);
+    const int first = __builtin_ctzll(S), top = 63 - __builtin_clzll(S);
+    const bool run = (((S >> first) + 1ull) & (S >> first)) == 0ull;  // wave-uniform: the samples are lanes first..top
+    float prev_after;
+    if (run) {
+        prev_after = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t_after), 0x138 /* wave_shr:1 */, 0xF, 0xF, false));
+    } else {
+        const int prev_lane = lower ? 63 - __builtin_clzll(lower) : lane;
+        prev_after = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(prev_lane << 2, __builtin_bit_cast(int, t_after)));
     }
-    last_t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t_after), 63 - __builtin_clzll(S)));
+    if ((S >> lane) & 1ull) {
+        const uint32_t rank = run ? (uint32_t)(lane - first) : (uint32_t)__builtin_popcountll(lower);
+        const float d1 = t_after - (rank ? prev_after : last_t);
+        if (OFF32) {
+            const uint32_t s = offset + step + rank;
+            float* px = reinterpret_cast<float*>(reinterpret_cast<char*>(xyzs) + (size_t)(s * 12u));
+            float* pd = reinterpret_cast<float*>(reinterpret_cast<char*>(dirs) + (size_t)(s * 12u));
+            float* pl = reinterpret_cast<float*>(reinterpret_cast<char*>(deltas) + (size_t)(s * 8u));
+            px[0] = bx; px[1] = by; px[2] = bz;
+            pd[0] = dv.x; pd[1] = dv.y; pd[2] = dv.z;
+            pl[0] = bdt; pl[1] = d1;
+        } else {
+            const size_t s = (size_t)offset + step + rank;
+            xyzs[3 * s] = bx; xyzs[3 * s + 1] = by; xyzs[3 * s + 2] = bz;
+            dirs[3 * s] = dv.x; dirs[3 * s + 1] = dv.y; dirs[3 * s + 2] = dv.z;
+            deltas[2 * s] = bdt; deltas[2 * s + 1] = d1;
+        }
+    }
+    last_t = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t_after), top));
     step += (uint32_t)__builtin_popcountll(S);
 }
 
-__global__ __launch_bounds__(kBlock) void k_march_train_onepass(const float* __restrict__ rays_o, const float* __restrict__ rays_d,
-                                                                const uint8_t* __restrict__ grid, float bound, float dt_gamma,
-                                                                uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
-                                                                const float* __restrict__ nears, const float* __restrict__ fars,
-                                                                const float* __restrict__ noises, int* __restrict__ rays,
-                                                                int* __restrict__ counter, unsigned long long* __restrict__ ws,
-                                                                float* __restrict__ xyzs, float* __restrict__ dirs,
-                                                                float* __restrict__ deltas, int serial) {
-    constexpr int kRays = kBlock / kWave;
-    __shared__ uint32_t s_lut[kSpreadLutMax];
-    __shared__ MarchRec s_rec[kRays][kMarchRecCap];
-    __shared__ uint32_t s_cnt[kRays];
-    __shared__ uint32_t s_block, s_excl;
-    fill_spread_lut(s_lut, H);
-    if (threadIdx.x == 0) s_block = atomicAdd(reinterpret_cast<unsigned int*>(ws), 1u);  // ticket = this workgroup's position in the scan
-    __syncthreads();
-    const uint32_t b = s_block, n_blocks = gridDim.x;
-    const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
-    const uint32_t n = __builtin_amdgcn_readfirstlane(b * kRays + (uint32_t)wid);
-    unsigned long long* flags = ws + 1;
-    constexpr unsigned long long kAggregate = 1ull << 32, kInclusive = 2ull << 32;
+// Everything a wave keeps of a ray between its count and its stores (two per wave: one being counted, one waiting for its range)
+struct MarchRayLds {
+    MarchRec rec[kMarchRecCap];
+    float bt[kMarchBtCap][kWave];
+};
 
-    // ---- phase 1: count the ray once; remember where its samples are
+__device__ __forceinline__ float march_t_start(const Marcher& m, const float* __restrict__ nears, const float* __restrict__ noises, uint32_t n) {
+    const float t = nears[n];
+    return t + m.step_len(t) * noises[n];
+}
+
+// wave = ray n: count it once; remember the sample-bearing batches
+__device__ __forceinline__ void march_count_ray(MarchRayLds& L, int lane, uint32_t n, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                const uint8_t* __restrict__ grid, float bound, float dt_gamma, uint32_t max_steps, uint32_t C,
+                                                uint32_t H, const uint32_t* lut, const float* __restrict__ nears, const float* __restrict__ fars,
+                                                const float* __restrict__ noises, int serial, uint32_t& count, uint32_t& nrec) {
     Marcher m;
-    float far = 0.0f, t_start = 0.0f;
-    uint32_t count = 0, nrec = 0;
-    if (n < N) {
-        m.init(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, grid, bound, dt_gamma, max_steps, C, H);
-        m.lut = s_lut;
-        far = fars[n];
-        t_start = nears[n];
-        t_start += m.step_len(t_start) * noises[n];
-        ChainWalker w;
-        w.init(t_start);
-        while (count < max_steps) {
-            const unsigned long long S = w.next_samples(m, far, lane, max_steps - count, serial != 0);
-            if (!S) break;
-            if (nrec < (uint32_t)kMarchRecCap && lane == 0) {
-                MarchRec r;
-                r.t0 = w.t_batch; r.nb = (uint32_t)w.nb; r.S = S;
-                s_rec[wid][nrec] = r;
-            }
-            ++nrec;
-            count += (uint32_t)__builtin_popcountll(S);
+    m.init(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, grid, bound, dt_gamma, max_steps, C, H);
+    m.lut = lut;
+    const float far = fars[n];
+    ChainWalker w;
+    w.init(march_t_start(m, nears, noises, n));
+    count = 0;
+    nrec = 0;
+    while (count < max_steps) {
+        const unsigned long long S = w.next_samples(m, far, lane, max_steps - count, serial != 0);
+        if (!S) break;
+        if (nrec < (uint32_t)kMarchRecCap && lane == 0) {
+            MarchRec r;
+            r.t0 = w.t_batch; r.nb = (uint32_t)w.nb; r.S = S;
+            L.rec[nrec] = r;
         }
+        if (nrec < (uint32_t)kMarchBtCap) L.bt[nrec][lane] = w.bt;
+        ++nrec;
+        count += (uint32_t)__builtin_popcountll(S);
     }
-    if (lane == 0) s_cnt[wid] = count;
-    __syncthreads();
+}
 
-    // ---- phase 2: exclusive prefix of this workgroup's rays (chained scan over the tickets)
-    if (wid == 0) {
-        uint32_t agg = 0;
-#pragma unroll
-        for (int r = 0; r < kRays; ++r) agg += s_cnt[r];
-        uint32_t excl = 0;
-        if (b == 0) {
-            excl = (uint32_t)counter[0];
-        } else {
-            if (lane == 0) __hip_atomic_store(&flags[b], kAggregate | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int base = (int)b - 1;
-            uint32_t running = 0, polls = 0;
-            bool ok = false;
-            while (!ok && polls < kMarchSpinLimit) {
-                const int i = base - lane;
-                unsigned long long f = 3ull << 32;  // lanes before the first workgroup: ignored
-                if (i >= 0) f = __hip_atomic_load(&flags[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t status = (uint32_t)(f >> 32), value = (uint32_t)f;
-                const unsigned long long incl = __ballot(status == 2u), empty = __ballot(status == 0u);
-                if (incl) {
-                    const int p = __builtin_ctzll(incl);  // the nearest predecessor that knows its inclusive prefix
-                    if (empty & ((1ull << p) - 1ull)) { ++polls; __builtin_amdgcn_s_sleep(1); continue; }
-                    running += wave_sum(lane <= p ? value : 0u);
-                    ok = true;
-                } else if (empty) {
-                    ++polls;
-                    __builtin_amdgcn_s_sleep(1);
-                } else {  // 64 aggregates: take them all and look further back (workgroup 0 always publishes an inclusive prefix)
-                    running += wave_sum(value);
-                    base -= 64;
-                }
-            }
-            excl = running;
-            if (!ok && lane == 0) counter[1] = -1;  // bounded spin expired: the launch terminates, the result is marked invalid
-        }
-        if (lane == 0) {
-            __hip_atomic_store(&flags[b], kInclusive | (unsigned long long)(excl + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_excl = excl;
-            if (b == n_blocks - 1u) {  // the last ticket closes the call: counter as the three-launch form leaves it
-                counter[0] = (int)(excl + agg);
-                if (counter[1] >= 0) counter[1] += (int)N;
-            }
-        }
-    }
-    __syncthreads();
-    if (n >= N) return;
-    uint32_t offset = s_excl;
-    for (int r = 0; r < wid; ++r) offset += s_cnt[r];
+// wave = ray n, whose `count` samples start at `offset`: write rays[n] and replay the records into the sample arrays
+template <bool OFF32>
+__device__ __forceinline__ void march_store_ray(const MarchRayLds& L, uint32_t offset, uint32_t count, uint32_t nrec, int lane, uint32_t n, uint32_t M,
+                                                const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+                                                const uint8_t* __restrict__ grid, float bound, float dt_gamma, uint32_t max_steps, uint32_t C,
+                                                uint32_t H, const uint32_t* lut, const float* __restrict__ nears, const float* __restrict__ fars,
+                                                const float* __restrict__ noises, int* __restrict__ rays, float* __restrict__ xyzs,
+                                                float* __restrict__ dirs, float* __restrict__ deltas, int serial) {
     if (lane == 0) {
         rays[3 * (size_t)n + 0] = (int)n;
         rays[3 * (size_t)n + 1] = (int)offset;
         rays[3 * (size_t)n + 2] = (int)count;
     }
     if (count == 0 || offset + count > M) return;
-
-    // ---- phase 3: store the samples
+    Marcher m;
+    m.init(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, grid, bound, dt_gamma, max_steps, C, H);
+    m.lut = lut;
+    const float t_start = march_t_start(m, nears, noises, n);
     float last_t = t_start;
     uint32_t step = 0;
+    MarchDirs dv = {m.dx, m.dy, m.dz};
+    asm volatile("" : "+v"(dv.x), "+v"(dv.y), "+v"(dv.z));  // three registers for the whole loop instead of three moves per batch
     if (nrec <= (uint32_t)kMarchRecCap) {
         for (uint32_t r = 0; r < nrec; ++r) {
-            const MarchRec rec = s_rec[wid][r];
-            float bt, tn;
-            int nb;
-            m.fill_batch(rec.t0, lane, bt, nb, tn);
+            const MarchRec rec = L.rec[r];
+            float bt;
+            if (r < (uint32_t)kMarchBtCap) {
+                bt = L.bt[r][lane];
+            } else {
+                float tn;
+                int nb;
+                m.fill_batch(rec.t0, lane, bt, nb, tn);
+            }
             // the sample description of Marcher::classify_cell: position clamped to the box, step length of the member
             const float bx = clamp_med3(m.ox + bt * m.dx, -m.bound, m.bound);
             const float by = clamp_med3(m.oy + bt * m.dy, -m.bound, m.bound);
             const float bz = clamp_med3(m.oz + bt * m.dz, -m.bound, m.bound);
             const float bdt = m.dt_gamma == 0.0f ? m.dt_const : m.step_len(bt);
-            march_store_batch(m, bt, bx, by, bz, bdt, rec.S, lane, offset, step, last_t, xyzs, dirs, deltas);
+            march_store_batch<OFF32>(dv, bt, bx, by, bz, bdt, rec.S, lane, offset, step, last_t, xyzs, dirs, deltas);
         }
     } else {  // more sample-bearing batches than LDS records: march again, as the three-launch write pass does
+        const float far = fars[n];
         ChainWalker w;
         w.init(t_start);
         while (step < count) {
             const unsigned long long S = w.next_samples(m, far, lane, count - step, serial != 0);
             if (!S) break;
-            march_store_batch(m, w.bt, w.bx, w.by, w.bz, w.bdt, S, lane, offset, step, last_t, xyzs, dirs, deltas);
+            march_store_batch<OFF32>(dv, w.bt, w.bx, w.by, w.bz, w.bdt, S, lane, offset, step, last_t, xyzs, dirs, deltas);
         }
+    }
+}
+
+// The scanner (one wave): sums[t] = {1, samples of ticket t} in, prefix[t] = {1, samples of the tickets before t} out, in ticket
+// order as far as the published sums reach, kWindows x 64 tickets per poll (the windows are requested together: one memory
+// latency per poll).  Closes the call: counter[0] = total, counter[1] += N -- what the three-launch form leaves.
+__device__ __forceinline__ void march_scanner(const unsigned long long* sums, unsigned long long* prefix, uint32_t n_tickets, uint32_t N, int lane,
+                                              int* __restrict__ counter) {
+    constexpr int kWindows = 8;
+    constexpr unsigned long long kReady = 1ull << 32;
+    uint32_t frontier = 0, running = (uint32_t)counter[0], idle = 0;
+    bool expired = false;
+    while (frontier < n_tickets) {
+        unsigned long long f[kWindows];
+#pragma unroll
+        for (int k = 0; k < kWindows; ++k) {
+            const uint32_t i = frontier + (uint32_t)(64 * k + lane);
+            f[k] = 0ull;
+            if (i < n_tickets) f[k] = __hip_atomic_load(&sums[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        uint32_t advanced = 0;
+        bool open = true;  // wave-uniform: every window so far was published completely
+#pragma unroll
+        for (int k = 0; k < kWindows; ++k) {
+            if (open) {
+                const uint32_t i = frontier + (uint32_t)(64 * k + lane);
+                const bool there = (uint32_t)(f[k] >> 32) == 1u;
+                const unsigned long long missing = ~__ballot(there);
+                const int lead = missing ? __builtin_ctzll(missing) : 64;  // published tickets at the head of the window
+                const uint32_t value = lane < lead ? (uint32_t)f[k] : 0u;
+                const uint32_t incl = wave_scan_add_u32(value);
+                if (lane < lead) __hip_atomic_store(&prefix[i], kReady | (unsigned long long)(running + incl - value), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                running += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                advanced += (uint32_t)lead;
+                open = lead == 64;  // (a window past the last ticket ends the round as well: its flags read as unpublished)
+            }
+        }
+        frontier += advanced;
+        if (advanced) { idle = 0; continue; }
+        if (++idle >= kMarchSpinLimit) { expired = true; break; }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    if (lane == 0) {
+        if (expired) {
+            counter[1] = -1;  // bounded spin expired: the launch terminates, the result is marked invalid
+        } else {
+            counter[0] = (int)running;
+            if (counter[1] >= 0) counter[1] += (int)N;
+        }
+    }
+}
+
+template <bool OFF32>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_march_train_onepass(
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid, float bound, float dt_gamma,
+    uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* __restrict__ nears, const float* __restrict__ fars,
+    const float* __restrict__ noises, int* __restrict__ rays, int* __restrict__ counter, unsigned long long* __restrict__ ws,
+    float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas, int serial_dbg) {
+    const int dbg = serial_dbg >> 1, serial = serial_dbg & 1;
+    const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
+    const uint32_t n_tickets = (N + (uint32_t)kMarchRays - 1u) / (uint32_t)kMarchRays;
+    unsigned int* ticket = reinterpret_cast<unsigned int*>(ws);
+    unsigned long long* sums = ws + 1;
+    unsigned long long* prefix = ws + 1 + n_tickets;
+    if (blockIdx.x == 0) {
+        if (wid == 0) march_scanner(sums, prefix, n_tickets, N, lane, counter);
+        return;
+    }
+    extern __shared__ uint32_t s_lut[];  // H entries
+    __shared__ MarchRayLds s_ray[kMarchRays][2];
+    __shared__ uint32_t s_cnt[2][kMarchRays], s_next[2];  // by parity of the iteration: written before its barrier, read right after it
+    fill_spread_lut(s_lut, H);
+    if (threadIdx.x == 0) s_next[1] = atomicAdd(ticket, 1u);  // ticket = position in the scan
+    __syncthreads();
+    uint32_t b = s_next[1];
+    int cur = 0;
+    bool pending = false;
+    uint32_t pend_n = 0, pend_ticket = 0, pend_before = 0, pend_count = 0, pend_nrec = 0;
+    while (true) {
+        const bool have = b < n_tickets;
+        const uint32_t n = __builtin_amdgcn_readfirstlane(b * (uint32_t)kMarchRays + (uint32_t)wid);
+        uint32_t count = 0, nrec = 0, before = 0;
+        if (have) {
+            if (n < N)
+                march_count_ray(s_ray[wid][cur], lane, n, rays_o, rays_d, grid, bound, dt_gamma, max_steps, C, H, s_lut, nears, fars, noises, serial, count, nrec);
+            if (lane == 0) s_cnt[cur][wid] = count;
+            // the next ticket is drawn late: the scanner works in ticket order, and a ticket drawn long before it is counted holds
+            // everybody's ranges back (drawn before the count: 0.274 ms instead of 0.25)
+            if (threadIdx.x == 0) s_next[cur] = atomicAdd(ticket, 1u);
+            __syncthreads();  // one barrier per ticket: the four counts -> the ticket's sum and every wave's place inside the ticket
+            uint32_t sum = 0;
+#pragma unroll
+            for (int r = 0; r < kMarchRays; ++r) {
+                const uint32_t c = s_cnt[cur][r];
+                before += r < wid ? c : 0u;
+                sum += c;
+            }
+            if (threadIdx.x == 0) __hip_atomic_store(&sums[b], (1ull << 32) | sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (pending) {  // the previous ticket: its predecessors and the scanner had a whole count phase
+            unsigned long long f = 0ull;
+            if (lane == 0) {
+                uint32_t polls = 0;
+                while (true) {
+                    f = __hip_atomic_load(&prefix[pend_ticket], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((uint32_t)(f >> 32) == 1u || ++polls >= kMarchSpinLimit) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            const uint32_t status = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(f >> 32));
+            const uint32_t excl = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)f);
+            if (status != 1u) {
+                if (lane == 0) counter[1] = -1;
+            } else if (!(dbg & 4) && pend_n < N) {
+                march_store_ray<OFF32>(s_ray[wid][cur ^ 1], excl + pend_before, pend_count, pend_nrec, lane, pend_n, M, rays_o, rays_d, grid, bound, dt_gamma,
+                                       max_steps, C, H, s_lut, nears, fars, noises, rays, xyzs, dirs, deltas, serial);
+            }
+        }
+        if (!have) break;
+        pending = true;
+        pend_n = n;
+        pend_ticket = b;
+        pend_before = before;
+        pend_count = count;
+        pend_nrec = nrec;
+        b = s_next[cur];
+        cur ^= 1;
     }
 }
 
@@ -796,7 +918,18 @@ NVSF_API int nvsf_march_rays_train(const float* rays_o, const float* rays_d, con
     return nvsf_launch_status();
 }
 
-NVSF_API size_t nvsf_march_rays_train_ws_bytes(uint32_t N) { return 8u * (size_t)(1u + cdiv(N, kBlock / kWave)); }
+// compute units of the current device (one process drives one GPU): the persistent launch below fills each with 8 workgroups
+static int march_cu_count() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n;
+}
+
+// ticket counter + {sum, exclusive prefix} flag per ticket of kMarchRays rays
+NVSF_API size_t nvsf_march_rays_train_ws_bytes(uint32_t N) { return 8u * (size_t)(1u + 2u * cdiv(N, (uint32_t)kMarchRays)); }
 
 NVSF_API int nvsf_march_rays_train_ws(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
                                       uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
@@ -807,9 +940,13 @@ NVSF_API int nvsf_march_rays_train_ws(const float* rays_o, const float* rays_d, 
     REQUIRE(C >= 1 && C <= 8 && H >= 2 && H <= 1024 && max_steps >= 1);
     REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7u) == 0 && workspace_bytes >= nvsf_march_rays_train_ws_bytes(N));
     const char* variant = getenv("NVSF_MARCH");
-    const int serial = variant && variant[0] == 's';  // "serial": the batch walked member by member (tests, A/B)
+    int serial = variant && variant[0] == 's';  // "serial": the batch walked member by member (tests, A/B)
+    if (const char* dbg = getenv("NVSF_MARCH_DEBUG")) serial |= atoi(dbg) << 1;
     if (hipMemsetAsync(workspace, 0, nvsf_march_rays_train_ws_bytes(N), stream) != hipSuccess) return (int)hipGetLastError();
-    hipLaunchKernelGGL(k_march_train_onepass, dim3(cdiv(N, kBlock / kWave)), dim3(kBlock), 0, stream, rays_o, rays_d, grid, bound, dt_gamma,
+    auto kernel = (unsigned long long)M * 12ull < (1ull << 32) ? k_march_train_onepass<true> : k_march_train_onepass<false>;
+    // the scanner + one worker per ticket until the chip is full (8 workgroups per compute unit)
+    const uint32_t wanted = 1u + cdiv(N, (uint32_t)kMarchRays), resident = 8u * (uint32_t)march_cu_count();
+    hipLaunchKernelGGL(kernel, dim3(wanted < resident ? wanted : resident), dim3(kBlock), H * sizeof(uint32_t), stream, rays_o, rays_d, grid, bound, dt_gamma,
                        max_steps, N, C, H, M, nears, fars, noises, rays, counter, reinterpret_cast<unsigned long long*>(workspace), xyzs, dirs,
                        deltas, serial);
     return nvsf_launch_status();
