@@ -72,11 +72,12 @@ int nvsf_march_rays_train(const float* rays_o, const float* rays_d, const uint8_
                           int32_t* rays, int32_t* counter, const float* noises, nvsf_stream_t stream);
 
 /* The same operator in ONE launch (no second classification of the chain, no scan launch): every wave counts its ray once and
- * keeps the sample masks of its batches on chip, the sample ranges come from a chained scan over the workgroups inside the
- * launch, then the samples are stored.  Same arguments, same outputs bit for bit (ray-index order), plus a caller-owned
- * scratch `workspace` of at least nvsf_march_rays_train_ws_bytes(N) bytes, 8-byte aligned, contents irrelevant on entry
- * (it is cleared on the stream first) and meaningless afterwards.  The reference's signature (raymarching.h:27-44) has no
- * scratch argument, hence the separate entry point; nvsf_march_rays_train stays the reference-shaped one.
+ * keeps the sample masks of its batches on chip; worker workgroups publish the sum of each ticket of four rays, one scanner wave
+ * turns the sums into exclusive prefixes in ticket order, and each ticket is stored while the next one is counted.  Same
+ * arguments, same outputs bit for bit (ray-index order), plus a caller-owned scratch `workspace` of at least
+ * nvsf_march_rays_train_ws_bytes(N) bytes (16 bytes per four rays), 8-byte aligned, contents irrelevant on entry (it is cleared on
+ * the stream first) and meaningless afterwards.  The reference's signature (raymarching.h:27-44) has no scratch argument, hence
+ * the separate entry point; nvsf_march_rays_train stays the reference-shaped one.
  * counter[1] = -1 after the call marks a launch whose bounded inter-workgroup wait expired (outputs invalid). */
 size_t nvsf_march_rays_train_ws_bytes(uint32_t N);
 int nvsf_march_rays_train_ws(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,

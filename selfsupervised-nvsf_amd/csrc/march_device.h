@@ -155,7 +155,8 @@ struct Marcher {
         (void)frexpf(fmaxf(fabsf(x), fmaxf(fabsf(y), fabsf(z))), &e0);
         const int l0 = max(0, min(e0, Cm1));
         int l1 = l1_const;
-        if (dt_gamma != 0.0f) {  // wave-uniform choice
+        if (dt_gamma != 0.0f) {  // wave-uniform choice, kept a branch (the empty asm cannot be speculated): ten instructions per member otherwise
+            asm volatile("");
             (void)frexpf(dt * Hf * 0.5f, &e1);
             l1 = max(0, min(e1, Cm1));
         }
@@ -165,7 +166,11 @@ struct Marcher {
         x = clamp_med3(ox + t * dx, -bound, bound);
         y = clamp_med3(oy + t * dy, -bound, bound);
         z = clamp_med3(oz + t * dz, -bound, bound);
-        dt = dt_gamma == 0.0f ? dt_const : step_len(t);
+        dt = dt_const;
+        if (dt_gamma != 0.0f) {
+            asm volatile("");
+            dt = step_len(t);
+        }
         const int level = level_fast(x, y, z, dt);
         const float p = ldexpf(1.0f, level);
         const bool capped = bound < p;  // mb = fminf(2^level, bound)

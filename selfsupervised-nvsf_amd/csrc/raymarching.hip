@@ -337,6 +337,9 @@ __device__ __forceinline__ void march_store_ray(const MarchRayLds& L, uint32_t o
     if (nrec <= (uint32_t)kMarchRecCap) {
         for (uint32_t r = 0; r < nrec; ++r) {
             const MarchRec rec = L.rec[r];
+            // the record is the same in every lane: as scalars, so that the mask arithmetic of the stores runs on the scalar unit
+            const unsigned long long S = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(rec.S >> 32)) << 32) |
+                                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rec.S);
             float bt;
             if (r < (uint32_t)kMarchBtCap) {
                 bt = L.bt[r][lane];
@@ -349,8 +352,12 @@ __device__ __forceinline__ void march_store_ray(const MarchRayLds& L, uint32_t o
             const float bx = clamp_med3(m.ox + bt * m.dx, -m.bound, m.bound);
             const float by = clamp_med3(m.oy + bt * m.dy, -m.bound, m.bound);
             const float bz = clamp_med3(m.oz + bt * m.dz, -m.bound, m.bound);
-            const float bdt = m.dt_gamma == 0.0f ? m.dt_const : m.step_len(bt);
-            march_store_batch<OFF32>(dv, bt, bx, by, bz, bdt, rec.S, lane, offset, step, last_t, xyzs, dirs, deltas);
+            float bdt = m.dt_const;
+            if (m.dt_gamma != 0.0f) {
+                asm volatile("");
+                bdt = m.step_len(bt);
+            }
+            march_store_batch<OFF32>(dv, bt, bx, by, bz, bdt, S, lane, offset, step, last_t, xyzs, dirs, deltas);
         }
     } else {  // more sample-bearing batches than LDS records: march again, as the three-launch write pass does
         const float far = fars[n];
@@ -418,8 +425,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid, float bound, float dt_gamma,
     uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* __restrict__ nears, const float* __restrict__ fars,
     const float* __restrict__ noises, int* __restrict__ rays, int* __restrict__ counter, unsigned long long* __restrict__ ws,
-    float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas, int serial_dbg) {
-    const int dbg = serial_dbg >> 1, serial = serial_dbg & 1;
+    float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas, int serial) {
     const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
     const uint32_t n_tickets = (N + (uint32_t)kMarchRays - 1u) / (uint32_t)kMarchRays;
     unsigned int* ticket = reinterpret_cast<unsigned int*>(ws);
@@ -474,7 +480,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             const uint32_t excl = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)f);
             if (status != 1u) {
                 if (lane == 0) counter[1] = -1;
-            } else if (!(dbg & 4) && pend_n < N) {
+            } else if (pend_n < N) {
                 march_store_ray<OFF32>(s_ray[wid][cur ^ 1], excl + pend_before, pend_count, pend_nrec, lane, pend_n, M, rays_o, rays_d, grid, bound, dt_gamma,
                                        max_steps, C, H, s_lut, nears, fars, noises, rays, xyzs, dirs, deltas, serial);
             }
@@ -940,8 +946,7 @@ NVSF_API int nvsf_march_rays_train_ws(const float* rays_o, const float* rays_d, 
     REQUIRE(C >= 1 && C <= 8 && H >= 2 && H <= 1024 && max_steps >= 1);
     REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7u) == 0 && workspace_bytes >= nvsf_march_rays_train_ws_bytes(N));
     const char* variant = getenv("NVSF_MARCH");
-    int serial = variant && variant[0] == 's';  // "serial": the batch walked member by member (tests, A/B)
-    if (const char* dbg = getenv("NVSF_MARCH_DEBUG")) serial |= atoi(dbg) << 1;
+    const int serial = variant && variant[0] == 's';  // "serial": the batch walked member by member (tests, A/B)
     if (hipMemsetAsync(workspace, 0, nvsf_march_rays_train_ws_bytes(N), stream) != hipSuccess) return (int)hipGetLastError();
     auto kernel = (unsigned long long)M * 12ull < (1ull << 32) ? k_march_train_onepass<true> : k_march_train_onepass<false>;
     // the scanner + one worker per ticket until the chip is full (8 workgroups per compute unit)

@@ -147,7 +147,7 @@ class _march_rays_train(Function):
             step_counter = torch.zeros(2, dtype=torch.int32, device=dev)
         noises = torch.rand(N, dtype=dt, device=dev) if perturb else torch.zeros(N, dtype=dt, device=dev)
 
-        # one-launch form (nvsf_march_rays_train_ws: counts once, chained scan inside the launch); the reference-shaped
+        # one-launch form (nvsf_march_rays_train_ws: counts once, ranges from a scanner wave inside the launch); the reference-shaped
         # three-launch entry point nvsf_march_rays_train gives the same outputs bit for bit (NVSF_MARCH_ENTRY=ref selects it)
         use_ws = N > 0 and os.environ.get("NVSF_MARCH_ENTRY", "ws") != "ref"
         ws_bytes = _hip.march_ws_bytes(N) if use_ws else 0

@@ -137,7 +137,7 @@ def _march_ws(dev, to, td, tb, tn, tf, tz, n, max_steps, dt_gamma, M, counter0=(
 
 @pytest.mark.parametrize("n,max_steps,dt_gamma,perturb_seed", [(4096, 1024, 0.0, None), (1000, 256, 1.0 / 128, 7), (1, 64, 0.0, None), (7, 33, 0.0, 3)])
 def test_march_rays_train_ws_matches_oracle(rm, dev, scene, n, max_steps, dt_gamma, perturb_seed):
-    """nvsf_march_rays_train_ws (one launch: count once, chained scan over the workgroups, replay of the recorded sample
+    """nvsf_march_rays_train_ws (one launch: count once, ranges from the scanner wave, replay of the recorded sample
     masks) against the oracle: counter, rays (ray-index order), positions, directions, step sizes bit for bit."""
     o, d = _rays(n, 6, "lidar" if n == 1000 else "cam")
     aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
@@ -189,6 +189,34 @@ def test_march_rays_train_ws_equals_three_launch_form(rm, dev, scene, kind, dt_g
         assert (int(ref[0][0]) > c0[0]) == (kind != "empty")
         for a, b, name in zip(ref, got, ("counter", "rays", "xyzs", "dirs", "deltas")):
             assert torch.equal(a, b), (name, kind, M)
+
+
+@pytest.mark.parametrize("p,dt_gamma", [(1.0, 0.0), (0.1, 0.0), (0.5, 1.0 / 256)])
+def test_march_rays_train_ws_more_tickets_than_workgroups(rm, dev, p, dt_gamma):
+    """20 000 rays = 5000 tickets of four rays for at most 2047 worker workgroups: every workgroup takes several tickets (both LDS
+    record buffers in turn, stores one ticket behind the count) and the scanner wave walks more sums than one poll covers.
+    Bit for bit the three-launch form."""
+    from nvsf import _hip
+    n, max_steps = 20000, 256
+    rng = np.random.default_rng(5)
+    bits = np.packbits(rng.random(2 * 128 ** 3) < p, bitorder="little")
+    o, d = _rays(n, 21, "cam")
+    aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
+    nears, fars = O.near_far_from_aabb(o, d, aabb, 0.02)
+    noises = rng.random(n).astype(np.float32)
+    T = lambda a: _t(a, dev)
+    to, td, tb, tn, tf, tz = T(o), T(d), T(bits), T(nears), T(fars), T(noises)
+    M = n * max_steps
+    xyzs = torch.zeros(M, 3, device=dev); dirs = torch.zeros(M, 3, device=dev); deltas = torch.zeros(M, 2, device=dev)
+    rays = torch.empty(n, 3, dtype=torch.int32, device=dev); counter = torch.zeros(2, dtype=torch.int32, device=dev)
+    _hip.call("nvsf_march_rays_train", _hip.ptr(to), _hip.ptr(td), _hip.ptr(tb), 2.0, float(dt_gamma), max_steps, n, 2, 128, M,
+              _hip.ptr(tn), _hip.ptr(tf), _hip.ptr(xyzs), _hip.ptr(dirs), _hip.ptr(deltas), _hip.ptr(rays), _hip.ptr(counter), _hip.ptr(tz))
+    ref = (counter.cpu(), rays.cpu(), xyzs.cpu(), dirs.cpu(), deltas.cpu())
+    assert int(ref[0][0]) > 100000 and int(ref[0][1]) == n
+    for _ in range(2):  # twice: the workspace is cleared by the call itself
+        got = _march_ws(dev, to, td, tb, tn, tf, tz, n, max_steps, dt_gamma, M)
+        for a, b, name in zip(ref, got, ("counter", "rays", "xyzs", "dirs", "deltas")):
+            assert torch.equal(a, b), name
 
 
 @pytest.mark.parametrize("kind", ["random10", "random50", "dense", "empty", "scene"])
