@@ -62,6 +62,18 @@ struct Marcher {
         l1_const = dt_level(dt_const);
         lut = nullptr;
     }
+    // What replaying recorded batches needs (positions, step lengths, fill_batch): no inverse directions, no cell constants.
+    __device__ __forceinline__ void init_replay(const float* o, const float* d, float bound_, float dt_gamma_, uint32_t max_steps, uint32_t C,
+                                                uint32_t H) {
+        ox = o[0]; oy = o[1]; oz = o[2];
+        dx = d[0]; dy = d[1]; dz = d[2];
+        bound = bound_; dt_gamma = dt_gamma_;
+        Hf = (float)H;
+        dt_min = 2.0f * kSqrt3 / (float)max_steps;
+        dt_max = 2.0f * kSqrt3 * (float)(1 << (C - 1)) / Hf;
+        dt_const = step_len(0.0f);
+        lut = nullptr;
+    }
     __device__ __forceinline__ int dt_level(float dt) const {
         int e1;
         (void)frexpf(dt * Hf * 0.5f, &e1);
@@ -119,8 +131,9 @@ struct Marcher {
                 if (s == 0u) break;
                 const int k = lane - filled;  // member index inside the segment (negative: a lane of an earlier segment)
                 const uint32_t ku = (uint32_t)k;
-                const uint32_t mk = k == 0 ? m0 : m0 + s_first + (ku - 1u) * s;
-                const uint32_t mprev = k <= 1 ? m0 : m0 + s_first + (ku - 2u) * s;
+                // (k - 1) * s: k < 64 and s < 2^24, so the 24-bit multiplier (full rate; the 32-bit one runs at a quarter) is exact
+                const uint32_t mk = k == 0 ? m0 : m0 + s_first + __umul24(ku - 1u, s);
+                const uint32_t mprev = k <= 1 ? m0 : mk - s;
                 const bool valid = k >= 0 && (k == 0 || mprev + q < (1u << 24));
                 filled += __builtin_popcountll(__ballot(valid));  // the valid lanes are a run from lane `filled` (m_k increases with k)
                 const float scale = __builtin_bit_cast(float, (uint32_t)(e - 23) << 23);
@@ -181,7 +194,7 @@ struct Marcher {
         c.ny = (int)clamp_med3((y * rmb + 1.0f) * halfH, 0.0f, Hm1);
         c.nz = (int)clamp_med3((z * rmb + 1.0f) * halfH, 0.0f, Hm1);
         const uint32_t mort = spread((uint32_t)c.nx) | (spread((uint32_t)c.ny) << 1) | (spread((uint32_t)c.nz) << 2);
-        const uint32_t cell = H3i ? (uint32_t)level * H3i + mort : (uint32_t)((float)level * H3 + (float)mort);
+        const uint32_t cell = H3i ? __umul24((uint32_t)level, H3i) + mort : (uint32_t)((float)level * H3 + (float)mort);  // level * H^3 < 2^24
         return (grid[cell >> 3] & (1u << (cell & 7u))) != 0;
     }
     __device__ __forceinline__ float cell_exit(float t, float x, float y, float z, const Cell& c) const {
@@ -326,8 +339,12 @@ struct ChainWalker {
         const unsigned long long active = bm & (~0ull << j0);
         const bool in = (active >> lane) & 1ull;
         const bool below = bt < far;
-        if (!__ballot(in && !(bocc && below))) {  // every remaining member is an occupied one below far: all are samples
-            S = active;
+        // No empty member below far among the remaining ones: the walk visits member after member until the first one at or beyond
+        // far (bt does not decrease along the batch, so the members below far are a run from j0) and stops there.
+        const unsigned long long below_m = __ballot(below);
+        if (!(active & below_m & ~__ballot(bocc))) {
+            S = active & below_m;
+            if (active & ~below_m) done = true;
             j = nb;
             return true;
         }
