@@ -360,3 +360,61 @@ def depth_rmse(pred, truth, scale, min_depth=1e-6, max_depth=80.0):
     p, t = (np.asarray(a.detach().cpu() if torch.is_tensor(a) else a, dtype=np.float64) / scale for a in (pred, truth))
     p, t = np.clip(p, min_depth, max_depth), np.clip(t, min_depth, max_depth)
     return float(np.sqrt(np.mean((t - p) ** 2)))
+
+
+def fscore(dist1, dist2, threshold=0.001):
+    """F-score of two point clouds from their SQUARED nearest-neighbour distances [B, n] / [B, m] (nvsf/lib/error_matrices.py:12-26):
+    2 p r / (p + r) with p, r the fractions below `threshold`, 0 where both are 0.  Returns fscore, precision, recall ([B])."""
+    p1 = (dist1 < threshold).float().mean(dim=1)
+    p2 = (dist2 < threshold).float().mean(dim=1)
+    f = 2 * p1 * p2 / (p1 + p2)
+    return torch.nan_to_num(f, nan=0.0), p1, p2
+
+
+def pano_to_lidar(pano, intrinsics, intrinsics_hoz=(180.0, 360.0)):
+    """Range image [H, W] -> points [H * W, 3] in the LiDAR frame, on the device of `pano` (nvsf/lib/convert.py:221-291): pixel (row j,
+    column i) looks along azimuth beta = -(i - W / 2) / W * fov_hoz and elevation alpha = fov_up - j / H * fov (degrees; `intrinsics` =
+    (fov_up, fov), `intrinsics_hoz` = (fov_hoz_up, fov_hoz)); zero-range pixels stay at the origin, as in the reference."""
+    H, W = pano.shape
+    fov_up, fov = (float(v) for v in intrinsics)
+    fov_hoz = float(intrinsics_hoz[1])
+    i = torch.arange(W, dtype=torch.float32, device=pano.device)[None, :]
+    j = torch.arange(H, dtype=torch.float32, device=pano.device)[:, None]
+    beta = -(i - W / 2) / W * fov_hoz / 180 * np.pi
+    alpha = (fov_up - j / H * fov) / 180 * np.pi
+    dirs = torch.stack([torch.cos(alpha) * torch.cos(beta), torch.cos(alpha) * torch.sin(beta), torch.sin(alpha).expand(H, W)], -1)
+    return (dirs * pano.float()[..., None]).reshape(-1, 3)
+
+
+class PointsMeter:
+    """Chamfer distance and F-score of whole rendered range images against the measured ones -- the reference's PointsMeter
+    (nvsf/lib/error_matrices.py:299-356: ranges divided by the scene scale, pano_to_lidar with the sensor's intrinsics,
+    CD = mean d1 + mean d2 over squared distances, F-score at 0.05) with the clouds built on the device and the nearest neighbours
+    from the HIP chamfer kernel (csrc/chamfer.hip), which also serves the training loss."""
+
+    def __init__(self, scale, intrinsics, intrinsics_hoz=(180.0, 360.0), threshold=0.05):
+        self.scale, self.intrinsics, self.intrinsics_hoz, self.threshold = float(scale), intrinsics, intrinsics_hoz, threshold
+        self.clear()
+
+    def clear(self):
+        self.V, self.N = [], 0
+
+    def update(self, preds, truths):
+        """preds, truths: [1, H, W] (or [H, W]) range images in scene units."""
+        from nvsf.nerf.chamfer3D.dist_chamfer_3D import chamfer_3DDist
+        p, t = (a.reshape(a.shape[-2], a.shape[-1]).float() / self.scale for a in (preds, truths))
+        with torch.no_grad():
+            d1, d2, _, _ = chamfer_3DDist()(pano_to_lidar(p, self.intrinsics, self.intrinsics_hoz)[None],
+                                            pano_to_lidar(t, self.intrinsics, self.intrinsics_hoz)[None])
+            cd = d1.mean() + d2.mean()
+            f = fscore(d1, d2, self.threshold)[0][0]
+        self.V.append([float(cd), float(f)])
+        self.N += 1
+
+    def measure(self):
+        assert self.N == len(self.V), "prediction and gt should should be equal"
+        return np.array(self.V).mean(0)
+
+    def report(self):
+        cd, f = self.measure()
+        return f"Points_error(CD, F-score) = {[round(float(cd), 3), round(float(f), 3)]}"

@@ -46,3 +46,38 @@ def test_chamfer_forward_backward(dev, B, n, m):
     ((gd1 * torch.from_numpy(g1).to(dev)).sum() + (gd2 * torch.from_numpy(g2).to(dev)).sum()).backward()
     np.testing.assert_allclose(ta.grad.cpu().numpy(), ga, atol=2e-5, rtol=1e-5)
     np.testing.assert_allclose(tb.grad.cpu().numpy(), gb, atol=2e-5, rtol=1e-5)
+
+
+def test_points_meter_cd_and_fscore(dev):
+    """PointsMeter = the reference's CD / F-score meter (nvsf/lib/error_matrices.py:12-26, 299-356; pano_to_lidar:
+    nvsf/lib/convert.py:221-291) on the HIP chamfer kernel: against a numpy restatement of those formulas (brute-force nearest
+    neighbours in float64), incl. zero-range pixels and a second frame in the running mean."""
+    from nvsf.nerf.train_step import PointsMeter, fscore, pano_to_lidar
+    rng = np.random.default_rng(3)
+    H, W, scale, K, Kh = 16, 96, 0.0125, (10.0, 40.0), (180.0, 360.0)
+
+    def cloud(pano):
+        i, j = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32), indexing="xy")
+        beta = -(i - W / 2) / W * Kh[1] / 180 * np.pi
+        alpha = (K[0] - j / H * K[1]) / 180 * np.pi
+        dirs = np.stack([np.cos(alpha) * np.cos(beta), np.cos(alpha) * np.sin(beta), np.sin(alpha)], -1)
+        return (dirs * pano.reshape(H, W, 1)).reshape(-1, 3)
+
+    meter = PointsMeter(scale, K, Kh)
+    want = []
+    for k in range(2):
+        gt = (rng.uniform(2.0, 60.0, (H, W)) * scale).astype(np.float32)
+        gt[rng.random((H, W)) < 0.1] = 0.0
+        pred = (gt + rng.normal(0, 0.2 * scale, (H, W)) * (rng.random((H, W)) < 0.6)).astype(np.float32)
+        a, b = cloud(pred / np.float32(scale)).astype(np.float64), cloud(gt / np.float32(scale)).astype(np.float64)
+        np.testing.assert_allclose(pano_to_lidar(torch.from_numpy(pred / np.float32(scale)).to(dev), K, Kh).cpu().numpy(), a, atol=2e-5)
+        d = ((a[:, None, :] - b[None, :, :]) ** 2).sum(-1)
+        d1, d2 = d.min(1), d.min(0)
+        p1, p2 = (d1 < 0.05).mean(), (d2 < 0.05).mean()
+        want.append([d1.mean() + d2.mean(), 2 * p1 * p2 / (p1 + p2) if p1 + p2 > 0 else 0.0])
+        meter.update(torch.from_numpy(pred).to(dev)[None], torch.from_numpy(gt).to(dev)[None])
+    got = meter.measure()
+    np.testing.assert_allclose(got, np.mean(want, 0), rtol=2e-4, atol=1e-6)
+    assert 0.0 < got[1] < 1.0 and "Points_error" in meter.report()
+    z = torch.ones(1, 5, device=dev)
+    assert float(fscore(z, z, 0.5)[0]) == 0.0  # nothing below the threshold: 0 / 0 -> 0, as the reference sets it
