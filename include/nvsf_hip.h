@@ -212,6 +212,11 @@ int nvsf_masked_sigmoid(const float* logits, uint32_t row_stride, uint32_t col_s
 /* Backward of the above from its output (aten::sigmoid_backward): grad_in = (grad_out * (1 - out)) * out, n floats. */
 int nvsf_sigmoid_bwd(const float* grad_out, const float* out, uint32_t n, float* grad_in, nvsf_stream_t stream);
 
+/* Population of a sample mask: *count = number of non-zero bytes of x[0..n) (x 16-byte aligned; one launch, *count cleared on the
+ * stream first).  The mask is the reference's `weights > 1e-4` (renderer_dynamic.py:253), whose population decides between the dense
+ * and the gathered evaluation of the per-sample heads. */
+int nvsf_count_nonzero_u8(const void* x, uint64_t n, int64_t* count, nvsf_stream_t stream);
+
 /* ref: trunc_exp forward, nvsf/nerf/activation.py:9-11, on one column of a row-strided fp32 matrix: out[m] = exp(h[m][col])
  * (the density logit of the sigma MLP's [M,16] output, network_dynamic.py:281). */
 int nvsf_exp_col(const float* h, uint32_t row_stride, uint32_t col, uint32_t M, float* out, nvsf_stream_t stream);

@@ -160,6 +160,26 @@ __global__ __launch_bounds__(kBlock) void k_exp_col(const float* __restrict__ h,
     const uint32_t m = blockIdx.x * kBlock + threadIdx.x;
     if (m < M) out[m] = expf(h[(size_t)m * row_stride + col]);
 }
+// number of non-zero bytes of x[0..n): the population of a sample mask (one byte per sample, what `weights > 1e-4` produces).
+// torch's sum over a bool tensor reduces int64 element by element: 0.21 ms for the 3.1 M samples of a batch, twice per training step.
+__global__ __launch_bounds__(kBlock) void k_count_nonzero_u8(const uint8_t* __restrict__ x, unsigned long long n, unsigned long long* __restrict__ out) {
+    const unsigned long long words = n / 16ull;  // 16-byte pieces (the pointer is 16-byte aligned: checked by the launcher)
+    const uint4* x16 = reinterpret_cast<const uint4*>(x);
+    uint32_t count = 0;
+    auto nz = [](uint32_t w) {  // bytes of w that are not zero
+        w |= w >> 4;
+        w |= w >> 2;
+        w |= w >> 1;
+        return (uint32_t)__builtin_popcount(w & 0x01010101u);
+    };
+    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < words; i += (unsigned long long)gridDim.x * kBlock) {
+        const uint4 v = x16[i];
+        count += nz(v.x) + nz(v.y) + nz(v.z) + nz(v.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (uint32_t)(n - words * 16ull)) count += x[words * 16ull + threadIdx.x] != 0;
+    count = wave_sum(count);
+    if (lane_id() == 0 && count) atomicAdd(out, (unsigned long long)count);
+}
 }  // namespace
 
 #define REQUIRE(cond) do { if (!(cond)) return NVSF_ERR_INVALID_ARG; } while (0)
@@ -252,6 +272,18 @@ NVSF_API int nvsf_sigmoid_bwd(const float* grad_out, const float* out, uint32_t 
     if (n == 0) return NVSF_OK;
     REQUIRE(grad_out && out && grad_in);
     hipLaunchKernelGGL(k_sigmoid_bwd, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, stream, grad_out, out, n, grad_in);
+    return nvsf_launch_status();
+}
+
+NVSF_API int nvsf_count_nonzero_u8(const void* x, uint64_t n, int64_t* count, hipStream_t stream) {
+    REQUIRE(count);
+    if (hipMemsetAsync(count, 0, 8, stream) != hipSuccess) return (int)hipGetLastError();
+    if (n == 0) return NVSF_OK;
+    REQUIRE(x && (reinterpret_cast<uintptr_t>(x) & 15u) == 0);
+    const unsigned long long words = n / 16ull;
+    const uint32_t blocks = (uint32_t)(words / kBlock < 1024ull ? words / kBlock + 1ull : 1024ull);
+    hipLaunchKernelGGL(k_count_nonzero_u8, dim3(blocks), dim3(kBlock), 0, stream, static_cast<const uint8_t*>(x), (unsigned long long)n,
+                       reinterpret_cast<unsigned long long*>(count));
     return nvsf_launch_status();
 }
 

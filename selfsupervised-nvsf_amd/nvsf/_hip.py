@@ -48,6 +48,7 @@ SIGNATURES = {
     "nvsf_masked_sigmoid": [_P, _U, _U, _P, _U, _U, _P],
     "nvsf_sigmoid_bwd": [_P, _P, _U, _P],
     "nvsf_exp_col": [_P, _U, _U, _U, _P],
+    "nvsf_count_nonzero_u8": [_P, ctypes.c_uint64, _P],
     "nvsf_repeat_rows_f16": [_P, _U, _U, _U, _U, _P, _U],
     "nvsf_heads_input_f16": [_P, _U, _U, _U, _U, _P, _I, _U, _U, _P, _U, _U],
     "nvsf_mlp_fwd": [_P, _I, _U, _U, _U, _P, _U, _U, _U, _U, _P, _U],

@@ -238,11 +238,22 @@ def mask_was_dense(model, lidar, mask):
         host = st.get("host")
         if host is None:
             host = st["host"] = torch.empty(1, dtype=torch.int64).pin_memory()  # allocated once per (model, modality)
-        host.copy_(mask.sum().reshape(1), non_blocking=True)
+        host.copy_(count_true(mask), non_blocking=True)
         event = torch.cuda.Event()
         event.record()
         st["pending"] = (host, event, mask.numel())
     return True
+
+
+def count_true(mask):
+    """Population of a bool / uint8 mask as a one-element int64 device tensor, one HIP launch (`mask.sum()` is an element-wise int64
+    reduction in torch: 0.21 ms for the 3.1 M samples of a batch)."""
+    mk = mask.reshape(-1)
+    if not mk.is_contiguous() or mk.data_ptr() % 16:
+        mk = mk.clone()
+    out = torch.empty(1, dtype=torch.int64, device=mask.device)
+    _hip.call("nvsf_count_nonzero_u8", mk.data_ptr(), mk.numel(), _hip.ptr(out))
+    return out
 
 
 def note_mask_count(model, lidar, n_active, numel):

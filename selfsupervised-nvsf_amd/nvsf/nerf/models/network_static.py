@@ -74,7 +74,7 @@ class NeRFNetworkStatic(NeRFRenderer):
             # launch queue does: the read is a host sync that drains it)
             dense_mask, mask = mask, None
         if mask is not None:
-            n_active = int(mask.sum())  # one host sync (the reference's `mask.any()` costs the same)
+            n_active = int(ops.count_true(mask)) if mask.is_cuda else int(mask.sum())  # one host sync (the reference's `mask.any()` costs the same)
             ops.note_mask_count(self, cal_lidar_color, n_active, mask.numel())
             if n_active == 0:
                 return torch.zeros(mask.shape[0], self.out_dim, dtype=x.dtype, device=x.device)

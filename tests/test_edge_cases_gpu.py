@@ -91,3 +91,19 @@ def test_loss_and_activation_glue_on_ragged_sizes(dev, n):
     for k in range(3):
         assert abs(float(sums[k]) - float(want[k])) <= 2e-5 * max(1.0, float(want[k])), k
     assert torch.equal(pd, dep * rd)
+
+
+@pytest.mark.parametrize("n", [0, 1, 15, 16, 17, 4097, 3145728 + 5])
+def test_mask_population(dev, n):
+    """nvsf_count_nonzero_u8 (the population of `weights > 1e-4`) against torch, on sizes around its 16-byte pieces, for bool masks
+    and for byte masks whose non-zero values are not 1; an unaligned view goes through a copy in the wrapper."""
+    from nvsf import field_ops as ops
+    g = torch.Generator(device=dev).manual_seed(n + 1)
+    mask = torch.rand(n, device=dev, generator=g) > 0.7
+    assert int(ops.count_true(mask)) == int(mask.sum())
+    if n:
+        bytes_ = torch.randint(0, 256, (n,), dtype=torch.uint8, device=dev, generator=g) * mask.to(torch.uint8)
+        assert int(ops.count_true(bytes_)) == int((bytes_ != 0).sum())
+    if n > 3:
+        assert int(ops.count_true(mask[3:])) == int(mask[3:].sum())
+        assert int(ops.count_true(mask.reshape(1, -1)[:, ::2])) == int(mask[::2].sum())
