@@ -191,6 +191,41 @@ def test_march_rays_train_ws_equals_three_launch_form(rm, dev, scene, kind, dt_g
             assert torch.equal(a, b), (name, kind, M)
 
 
+@pytest.mark.parametrize("C,H,bound", [(3, 64, 4.0), (2, 256, 2.0), (1, 128, 1.0), (4, 128, 8.0)])
+@pytest.mark.parametrize("dt_gamma", [0.0, 1.0 / 128])
+def test_march_rays_train_other_grid_shapes(rm, dev, C, H, bound, dt_gamma):
+    """Cascade counts and resolutions other than the reference's default 2 x 128^3: C H^3 <= 2^24 takes the integer cell index
+    (march_device.h: every value an integer that fp32 holds exactly), 2 x 256^3 the reference's fp32 expression; the level clamp
+    on the integer exponent has to agree with the float clamp for every C.  Both entry points against the oracle, bit for bit."""
+    from nvsf import _hip
+    n, max_steps = 700, 512
+    rng = np.random.default_rng(C * 1000 + H)
+    bits = np.packbits(rng.random(C * H ** 3) < 0.3, bitorder="little")
+    o, d = _rays(n, 31, "cam")
+    o *= np.float32(bound / 2.0)  # the synthetic rays are laid out for bound 2
+    aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
+    nears, fars = O.near_far_from_aabb(o, d, aabb, 0.02)
+    noises = rng.random(n).astype(np.float32)
+    M = n * max_steps
+    xr, dr, lr, rr, cr = O.march_rays_train(o, d, bits, bound, dt_gamma, max_steps, C, H, M, nears, fars, noises)
+    m = int(cr[0])
+    assert m > 10000
+    T = lambda a: _t(a, dev)
+    to, td, tb, tn, tf, tz = T(o), T(d), T(bits), T(nears), T(fars), T(noises)
+    for entry in ("nvsf_march_rays_train", "nvsf_march_rays_train_ws"):
+        xyzs = torch.zeros(M, 3, device=dev); dirs = torch.zeros(M, 3, device=dev); deltas = torch.zeros(M, 2, device=dev)
+        rays = torch.empty(n, 3, dtype=torch.int32, device=dev); counter = torch.zeros(2, dtype=torch.int32, device=dev)
+        extra = ()
+        if entry.endswith("_ws"):
+            nb = _hip.march_ws_bytes(n)
+            ws = torch.empty(nb // 8, dtype=torch.int64, device=dev)
+            extra = (_hip.ptr(ws), nb)
+        _hip.call(entry, _hip.ptr(to), _hip.ptr(td), _hip.ptr(tb), float(bound), float(dt_gamma), max_steps, n, C, H, M, _hip.ptr(tn), _hip.ptr(tf),
+                  _hip.ptr(xyzs), _hip.ptr(dirs), _hip.ptr(deltas), _hip.ptr(rays), _hip.ptr(counter), _hip.ptr(tz), *extra)
+        assert np.array_equal(counter.cpu().numpy(), cr) and np.array_equal(rays.cpu().numpy(), rr), entry
+        assert np.array_equal(xyzs.cpu().numpy()[:m], xr[:m]) and np.array_equal(deltas.cpu().numpy()[:m], lr[:m]), entry
+
+
 @pytest.mark.parametrize("p,dt_gamma", [(1.0, 0.0), (0.1, 0.0), (0.5, 1.0 / 256)])
 def test_march_rays_train_ws_more_tickets_than_workgroups(rm, dev, p, dt_gamma):
     """20 000 rays = 5000 tickets of four rays for at most 2047 worker workgroups: every workgroup takes several tickets (both LDS
