@@ -115,3 +115,17 @@ def test_grid_spec_matches_published_level_rules():
     assert t.n_params == 8 * 2 ** 15 * 4 and t.n_output_dims == 32
     f = GridSpec(3, 16, 8, 18, 32, float(np.exp2(np.log2(8192 / 32) / 15)))    # flow grid (flow_field.py:68-84)
     assert f.n_output_dims == 128 and f.res[0] == 32 and f.res[-1] == 8192 and abs(f.n_params - 30.5e6) < 1.5e6
+
+
+def test_integration_index_lists_every_entry_point():
+    """INTEGRATION.md section 6 is the output of tools/abi_index.py: one row per declaration of include/nvsf_hip.h."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    table = subprocess.run([sys.executable, os.path.join(root, "tools", "abi_index.py")], capture_output=True, text=True, check=True).stdout
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+    rows = [l for l in table.splitlines() if l.startswith("| `nvsf_")]
+    assert {re.match(r"\| `(nvsf_\w+)`", l).group(1) for l in rows} == set(_declared())
+    for l in rows:
+        assert l in doc, l
