@@ -418,3 +418,60 @@ class PointsMeter:
     def report(self):
         cd, f = self.measure()
         return f"Points_error(CD, F-score) = {[round(float(cd), 3), round(float(f), 3)]}"
+
+
+def eval_step(model, data, num_steps, alpha_d=1.0, alpha_r=0.01, alpha_i=0.1, alpha_rgb=1.0, raydrop_thres=0.5, max_ray_batch=4096, **render_kwargs):
+    """Whole-frame evaluation of one frame, the reference's Trainer.eval_step (nvsf/nerf/trainer.py:658-815) without its optional
+    U-Net ray-drop refinement: `data` = FrameSet(..., training=False).collate([i]) -- every pixel of the range image and of the camera
+    image.  Both modalities go through the staged render, a frame's rays split over the ranks (frame_shard.render_sharded); the
+    predicted ray-drop mask (`pred_raydrop > raydrop_thres`, :726) gates predicted intensity and range, the ground truth is gated by
+    its own mask (:695-696); loss = the reference's mean-reduced L1 range + MSE ray-drop + MSE intensity + MSE RGB (:733-737, :795-796;
+    criteria as main_nvsf.py:205-221).  Returns a dict of [B, H, W(, C)] predictions / ground truths and `loss`."""
+    from nvsf import frame_shard
+    out = {}
+    loss = torch.zeros((), device=data["rays_o_lidar"].device)
+    with torch.no_grad():
+        gl = data["images_lidar"]  # [B, H, W, 3] = raydrop, intensity, range
+        B, Hl, Wl, _ = gl.shape
+        gt_raydrop = gl[..., 0]
+        gt_intensity, gt_depth = gl[..., 1] * gt_raydrop, gl[..., 2] * gt_raydrop
+        o = frame_shard.render_sharded(model, data["rays_o_lidar"], data["rays_d_lidar"], data["time"], cal_lidar_color=True, num_steps=num_steps,
+                                       max_ray_batch=max_ray_batch, **render_kwargs)
+        img = o["image_lidar"].reshape(B, Hl, Wl, 2)
+        pred_raydrop, pred_intensity, pred_depth = img[..., 0], img[..., 1], o["depth_lidar"].reshape(B, Hl, Wl)
+        mask = (pred_raydrop > raydrop_thres).to(pred_depth.dtype)
+        pred_intensity, pred_depth = pred_intensity * mask, pred_depth * mask
+        loss = loss + alpha_d * (pred_depth - gt_depth).abs().mean() + alpha_r * ((pred_raydrop - gt_raydrop) ** 2).mean() \
+            + alpha_i * ((pred_intensity - gt_intensity) ** 2).mean()
+        out.update(pred_raydrop=pred_raydrop, pred_intensity=pred_intensity, pred_depth=pred_depth, gt_raydrop=gt_raydrop,
+                   gt_intensity=gt_intensity, gt_depth=gt_depth)
+        gi = data["images"]  # [B, H, W, 3 or 4]
+        _, H, W, C = gi.shape
+        gt_rgb = gi[..., :3] * gi[..., 3:] + (1 - gi[..., 3:]) if C == 4 else gi  # fixed white background (:774-781)
+        c = frame_shard.render_sharded(model, data["rays_o"], data["rays_d"], data["time"], num_steps=num_steps, max_ray_batch=max_ray_batch,
+                                       bg_color=1, **render_kwargs)
+        pred_rgb = c["image"].reshape(B, H, W, 3)
+        loss = loss + alpha_rgb * ((pred_rgb - gt_rgb) ** 2).mean()
+        out.update(pred_rgb=pred_rgb, pred_rgb_depth=c["depth"].reshape(B, H, W), gt_rgb=gt_rgb, loss=loss)
+    return out
+
+
+def evaluate_frames(model, frames, num_steps, indices=None, **eval_kwargs):
+    """The metric half of the reference's evaluate_one_epoch (trainer.py:1458-1560) over a FrameSet opened with training=False:
+    per frame eval_step, then PSNR of the image (error_matrices.py:48-57), range RMSE in metres (:263-285) and chamfer distance /
+    F-score of the range image's point cloud (PointsMeter, :299-356); means over the frames.  Every rank returns the same numbers
+    (the renders are all-gathered)."""
+    was_training = model.training
+    model.eval()
+    points = PointsMeter(frames.scale, frames.intrinsics_lidar, frames.intrinsics_hoz_lidar)
+    ps, rm, ls = [], [], []
+    for i in (range(len(frames)) if indices is None else indices):
+        e = eval_step(model, frames.collate([int(i)]), num_steps, **eval_kwargs)
+        ps.append(psnr(e["pred_rgb"], e["gt_rgb"]))
+        rm.append(depth_rmse(e["pred_depth"], e["gt_depth"], frames.scale))
+        points.update(e["pred_depth"], e["gt_depth"])
+        ls.append(float(e["loss"]))
+    model.train(was_training)
+    cd, fs = points.measure()
+    return {"loss": float(np.mean(ls)), "psnr": float(np.mean(ps)), "depth_rmse_m": float(np.mean(rm)), "chamfer_distance": float(cd),
+            "f_score": float(fs), "frames": len(ps)}

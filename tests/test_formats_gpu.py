@@ -45,3 +45,50 @@ def test_frameset_collate_and_train_step(tmp_path):
     step = RenderTrainStep(m, num_steps=32)
     loss, parts, _ = step.step(fs.train_batch([2]))
     assert torch.isfinite(loss) and set(parts) == {"depth", "raydrop", "intensity", "chamfer", "rgb"}
+
+
+def test_eval_step_and_evaluate_frames(tmp_path):
+    """Whole-frame evaluation (train_step.eval_step / evaluate_frames = Trainer.eval_step, trainer.py:658-815, and the metric half
+    of evaluate_one_epoch, :1458-1560): shapes, the ray-drop gate on predictions and ground truth, the loss recomputed from the
+    returned images, staged chunks smaller than a frame, and the frame means of PSNR / range RMSE / CD / F-score against the
+    stand-alone meters."""
+    from test_formats_cpu import make_dataset
+    from nvsf.nerf.dataset import formats as F
+    from nvsf.nerf.models.network_static import NeRFNetworkStatic
+    from nvsf.nerf.train_step import eval_step, evaluate_frames, psnr, depth_rmse, PointsMeter
+    dev = torch.device("cuda:0")
+    seq, frames, images, pcs, K = make_dataset(str(tmp_path), n_frames=2, H=24, W=32, Hl=16, Wl=64)
+    scale = 0.0108
+    fe = F.FrameSet(str(tmp_path), seq, "train", scale, device=dev, training=False)
+    torch.manual_seed(1)
+    m = NeRFNetworkStatic(bound=2.0, min_near=0.01, min_near_lidar=0.01, lidar_max_depth=0.9).to(dev)
+    with torch.no_grad():
+        for p in m.parameters():
+            if p.dim() == 1 and p.numel() > 10000:
+                p.normal_(0, 0.3)  # tables away from zero so that the heads' outputs vary over the frame
+    data = fe.collate([1])
+    e = eval_step(m, data, 48, max_ray_batch=300)  # 768 camera / 1024 LiDAR rays: several chunks, the last one ragged
+    assert e["pred_rgb"].shape == (1, 24, 32, 3) and e["pred_depth"].shape == (1, 16, 64) and e["pred_raydrop"].shape == (1, 16, 64)
+    gate = e["pred_raydrop"] > 0.5
+    assert float(e["pred_depth"][~gate].abs().max() if (~gate).any() else 0.0) == 0.0
+    assert float(e["pred_intensity"][~gate].abs().max() if (~gate).any() else 0.0) == 0.0
+    gl = data["images_lidar"]
+    assert torch.equal(e["gt_depth"], gl[..., 2] * gl[..., 0]) and torch.equal(e["gt_intensity"], gl[..., 1] * gl[..., 0])
+    want = (e["pred_depth"] - e["gt_depth"]).abs().mean() + 0.01 * ((e["pred_raydrop"] - e["gt_raydrop"]) ** 2).mean() \
+        + 0.1 * ((e["pred_intensity"] - e["gt_intensity"]) ** 2).mean() + ((e["pred_rgb"] - e["gt_rgb"]) ** 2).mean()
+    assert float(e["loss"]) == pytest.approx(float(want), rel=1e-6)
+    whole = eval_step(m, data, 48, max_ray_batch=1 << 20)  # one chunk: the same frame bit for bit
+    for k in ("pred_rgb", "pred_depth", "pred_raydrop", "pred_intensity"):
+        assert torch.equal(e[k], whole[k]), k
+    res = evaluate_frames(m, fe, 48)
+    assert res["frames"] == 2 and all(np.isfinite(v) for v in res.values())
+    pm = PointsMeter(scale, fe.intrinsics_lidar, fe.intrinsics_hoz_lidar)
+    ps, rm = [], []
+    for i in range(2):
+        ei = eval_step(m, fe.collate([i]), 48)
+        ps.append(psnr(ei["pred_rgb"], ei["gt_rgb"]))
+        rm.append(depth_rmse(ei["pred_depth"], ei["gt_depth"], scale))
+        pm.update(ei["pred_depth"], ei["gt_depth"])
+    assert res["psnr"] == pytest.approx(np.mean(ps)) and res["depth_rmse_m"] == pytest.approx(np.mean(rm))
+    assert res["chamfer_distance"] == pytest.approx(pm.measure()[0]) and res["f_score"] == pytest.approx(pm.measure()[1])
+    assert m.training  # evaluate_frames restores the mode it found

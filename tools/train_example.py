@@ -61,7 +61,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
     from nvsf import frame_shard, synthetic as S
     from nvsf.nerf.dataset.formats import FrameSet
-    from nvsf.nerf.train_step import RenderTrainStep, psnr, depth_rmse
+    from nvsf.nerf.train_step import RenderTrainStep
     root = args.root
     if root is None:
         root = os.path.join(tempfile.gettempdir(), "nvsf_synthetic")
@@ -90,13 +90,13 @@ def main():
         if rank == 0 and (it % 10 == 0 or it == args.steps - 1):
             print(f"step {it:4d}  frame {frame:3d}  loss {float(loss):.4f}  " + "  ".join(f"{k} {float(v):.4f}" for k, v in parts.items())
                   + f"  all-reduces/step {n_coll}", flush=True)
-    model.eval()
-    with torch.no_grad():
-        b = data.train_batch([0])
-        r = model.render(b["rays_o_lidar"], b["rays_d_lidar"], b["time"], cal_lidar_color=True, num_steps=args.num_steps)
-        c = model.render(b["rays_o"], b["rays_d"], b["time"], num_steps=args.num_steps, bg_color=1)
+    # whole-frame evaluation (Trainer.eval_step / evaluate_one_epoch): every frame rendered with the staged loop, its rays split over the ranks
+    from nvsf.nerf.train_step import evaluate_frames
+    whole = FrameSet(root, args.sequence, "train", scale, device=dev, training=False)
+    res = evaluate_frames(model, whole, args.num_steps, indices=range(min(len(whole), 4)))
     if rank == 0:
-        print(f"frame 0: PSNR {psnr(c['image'], b['gt_rgb']):.2f} dB, range RMSE {depth_rmse(r['depth_lidar'] * b['gt_raydrop'], b['gt_depth'], scale):.2f} m")
+        print(f"evaluation over {res['frames']} frames: loss {res['loss']:.4f}, PSNR {res['psnr']:.2f} dB, range RMSE {res['depth_rmse_m']:.2f} m, "
+              f"chamfer distance {res['chamfer_distance']:.3f}, F-score {res['f_score']:.3f}")
     if world > 1:
         dist.destroy_process_group()
 
