@@ -459,19 +459,44 @@ def eval_step(model, data, num_steps, alpha_d=1.0, alpha_r=0.01, alpha_i=0.1, al
 def evaluate_frames(model, frames, num_steps, indices=None, **eval_kwargs):
     """The metric half of the reference's evaluate_one_epoch (trainer.py:1458-1560) over a FrameSet opened with training=False:
     per frame eval_step, then PSNR of the image (error_matrices.py:48-57), range RMSE in metres (:263-285) and chamfer distance /
-    F-score of the range image's point cloud (PointsMeter, :299-356); means over the frames.  Every rank returns the same numbers
+    F-score of the range image's point cloud (PointsMeter, :299-356), ray-drop RMSE / accuracy / F1 (RaydropMeter, :378-403) and the
+    intensity MAE (MAEMeter, :139-147); means over the frames.  Every rank returns the same numbers
     (the renders are all-gathered)."""
     was_training = model.training
     model.eval()
     points = PointsMeter(frames.scale, frames.intrinsics_lidar, frames.intrinsics_hoz_lidar)
-    ps, rm, ls = [], [], []
+    ps, rm, ls, rd, mae = [], [], [], [], []
     for i in (range(len(frames)) if indices is None else indices):
         e = eval_step(model, frames.collate([int(i)]), num_steps, **eval_kwargs)
         ps.append(psnr(e["pred_rgb"], e["gt_rgb"]))
         rm.append(depth_rmse(e["pred_depth"], e["gt_depth"], frames.scale))
         points.update(e["pred_depth"], e["gt_depth"])
+        rd.append(raydrop_metrics(e["pred_raydrop"], e["gt_raydrop"], eval_kwargs.get("raydrop_thres", 0.5)))
+        mae.append(intensity_mae(e["pred_intensity"], e["gt_intensity"]))
         ls.append(float(e["loss"]))
     model.train(was_training)
     cd, fs = points.measure()
+    rd = np.array(rd).mean(0)
     return {"loss": float(np.mean(ls)), "psnr": float(np.mean(ps)), "depth_rmse_m": float(np.mean(rm)), "chamfer_distance": float(cd),
-            "f_score": float(fs), "frames": len(ps)}
+            "f_score": float(fs), "raydrop_rmse": float(rd[0]), "raydrop_acc": float(rd[1]), "raydrop_f1": float(rd[2]),
+            "intensity_mae": float(np.mean(mae)), "frames": len(ps)}
+
+
+def raydrop_metrics(pred, truth, ratio=0.5):
+    """RMSE, accuracy and F1 of a predicted ray-drop map against the measured mask (RaydropMeter.update, error_matrices.py:378-403:
+    threshold `ratio`, precision / recall from the confusion counts).  Returns (rmse, acc, f1) as floats."""
+    p, t = (np.asarray(a.detach().cpu() if torch.is_tensor(a) else a, dtype=np.float64) for a in (pred, truth))
+    rmse = float(np.sqrt(((t - p) ** 2).mean()))
+    m = (p > ratio).astype(np.float64)
+    acc = float((m == t).mean())
+    tp, fp, fn = float(((t == 1) & (m == 1)).sum()), float(((t == 0) & (m == 1)).sum()), float(((t == 1) & (m == 0)).sum())
+    with np.errstate(divide="ignore", invalid="ignore"):
+        precision, recall = np.float64(tp) / (tp + fp), np.float64(tp) / (tp + fn)
+        f1 = 2 * (precision * recall) / (precision + recall)
+    return rmse, acc, float(f1)
+
+
+def intensity_mae(pred, truth, intensity_inv_scale=1.0):
+    """Mean absolute intensity error (MAEMeter.update, error_matrices.py:139-147)."""
+    p, t = (np.asarray(a.detach().cpu() if torch.is_tensor(a) else a, dtype=np.float64) for a in (pred, truth))
+    return float(np.abs(t * intensity_inv_scale - p * intensity_inv_scale).mean())

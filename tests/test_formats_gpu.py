@@ -81,7 +81,14 @@ def test_eval_step_and_evaluate_frames(tmp_path):
     for k in ("pred_rgb", "pred_depth", "pred_raydrop", "pred_intensity"):
         assert torch.equal(e[k], whole[k]), k
     res = evaluate_frames(m, fe, 48)
-    assert res["frames"] == 2 and all(np.isfinite(v) for v in res.values())
+    assert res["frames"] == 2 and all(np.isfinite(v) or k == "raydrop_f1" for k, v in res.items())
+    from nvsf.nerf.train_step import raydrop_metrics, intensity_mae
+    t = np.array([[1, 0, 1, 1], [0, 0, 1, 0]], np.float32)
+    p = np.array([[0.9, 0.6, 0.2, 0.7], [0.1, 0.4, 0.8, 0.3]], np.float32)  # TP 3, FP 1, FN 1, TN 3
+    rmse, acc, f1 = raydrop_metrics(torch.from_numpy(p), t)
+    assert acc == pytest.approx(6 / 8) and f1 == pytest.approx(0.75) and rmse == pytest.approx(float(np.sqrt(((t - p) ** 2).mean())))
+    assert intensity_mae(p, t, 2.0) == pytest.approx(float(np.abs(t - p).mean() * 2))
+    assert 0.0 <= res["raydrop_acc"] <= 1.0
     pm = PointsMeter(scale, fe.intrinsics_lidar, fe.intrinsics_hoz_lidar)
     ps, rm = [], []
     for i in range(2):
