@@ -78,13 +78,15 @@ int nvsf_march_rays_train(const float* rays_o, const float* rays_d, const uint8_
  * nvsf_march_rays_train_ws_bytes(N) bytes (16 bytes per four rays), 8-byte aligned, contents irrelevant on entry (it is cleared on
  * the stream first) and meaningless afterwards.  The reference's signature (raymarching.h:27-44) has no scratch argument, hence
  * the separate entry point; nvsf_march_rays_train stays the reference-shaped one.
- * counter[1] = -1 after the call marks a launch whose bounded inter-workgroup wait expired (outputs invalid). */
+ * counter[1] < 0 after the call (its sign bit set) marks a launch whose bounded inter-workgroup wait expired (outputs invalid; the
+ * mark is sticky: later calls on the same counter leave it negative).  `spin_limit` = polls a waiting wave makes before it gives up,
+ * 0 = the library's default (2^22); tests pass 1 to force the expiry path. */
 size_t nvsf_march_rays_train_ws_bytes(uint32_t N);
 int nvsf_march_rays_train_ws(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
                              float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                              const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
                              int32_t* rays, int32_t* counter, const float* noises, void* workspace,
-                             size_t workspace_bytes, nvsf_stream_t stream);
+                             size_t workspace_bytes, uint32_t spin_limit, nvsf_stream_t stream);
 
 /* ref: composite_rays_train_forward, raymarching.h:45-54, kernel raymarching.cu:577-655.
  * sigmas [M], rgbs [M,3], deltas [M,2], rays [N,3] -> weights_sum, depth [N], image [N,3]

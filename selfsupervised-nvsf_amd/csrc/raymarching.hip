@@ -225,7 +225,7 @@ __global__ __launch_bounds__(kBlock) void k_march_write_wave(const float* __rest
 // publishes the ticket's sum without waiting for anything, so the scanner (workgroup 0: dispatched first) only ever waits for
 // running workgroups, and workers only wait for the scanner.  Each flag is ONE naturally aligned 8-byte {status, value} granule
 // written by a single agent-scope atomic store and read by agent-scope atomic loads -- no other data crosses workgroups.  Every
-// spin is bounded (kMarchSpinLimit polls); on a timeout the launch still terminates and reports through counter[1] = -1.
+// spin is bounded (kMarchSpinLimit polls); on a timeout the launch still terminates and reports through counter[1] < 0.
 constexpr int kMarchRecCap = 24;  // records per ray kept in LDS; a ray with more sample-bearing batches re-marches when writing
 constexpr int kMarchBtCap = 8;    // batches per ray whose member parameters stay in LDS (the others come from Marcher::fill_batch again)
 constexpr int kMarchRays = kBlock / kWave;  // rays per ticket: one per wave
@@ -378,7 +378,7 @@ __device__ __forceinline__ void march_store_ray(const MarchRayLds& L, uint32_t o
 // order as far as the published sums reach, kWindows x 64 tickets per poll (the windows are requested together: one memory
 // latency per poll).  Closes the call: counter[0] = total, counter[1] += N -- what the three-launch form leaves.
 __device__ __forceinline__ void march_scanner(const unsigned long long* sums, unsigned long long* prefix, uint32_t n_tickets, uint32_t N, int lane,
-                                              int* __restrict__ counter) {
+                                              int* __restrict__ counter, uint32_t spin_limit) {
     constexpr int kWindows = 8;
     constexpr unsigned long long kReady = 1ull << 32;
     uint32_t frontier = 0, running = (uint32_t)counter[0], idle = 0;
@@ -410,15 +410,18 @@ __device__ __forceinline__ void march_scanner(const unsigned long long* sums, un
         }
         frontier += advanced;
         if (advanced) { idle = 0; continue; }
-        if (++idle >= kMarchSpinLimit) { expired = true; break; }
+        if (++idle >= spin_limit) { expired = true; break; }
         __builtin_amdgcn_s_sleep(2);
     }
     if (lane == 0) {
+        // counter[1]: rays marched so far, NEGATIVE once a bounded spin expired anywhere (the launch terminates, the result is
+        // invalid).  Scanner and workers may finish in any order: the sign bit is set with an atomic OR and the ray count is added
+        // with an atomic ADD, so neither loses the other's update.
         if (expired) {
-            counter[1] = -1;  // bounded spin expired: the launch terminates, the result is marked invalid
+            atomicOr(reinterpret_cast<unsigned int*>(counter + 1), 0x80000000u);
         } else {
             counter[0] = (int)running;
-            if (counter[1] >= 0) counter[1] += (int)N;
+            atomicAdd(reinterpret_cast<unsigned int*>(counter + 1), N);
         }
     }
 }
@@ -428,14 +431,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid, float bound, float dt_gamma,
     uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* __restrict__ nears, const float* __restrict__ fars,
     const float* __restrict__ noises, int* __restrict__ rays, int* __restrict__ counter, unsigned long long* __restrict__ ws,
-    float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas, int serial) {
+    float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas, int serial, uint32_t spin_limit) {
     const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
     const uint32_t n_tickets = (N + (uint32_t)kMarchRays - 1u) / (uint32_t)kMarchRays;
     unsigned int* ticket = reinterpret_cast<unsigned int*>(ws);
     unsigned long long* sums = ws + 1;
     unsigned long long* prefix = ws + 1 + n_tickets;
     if (blockIdx.x == 0) {
-        if (wid == 0) march_scanner(sums, prefix, n_tickets, N, lane, counter);
+        if (wid == 0) march_scanner(sums, prefix, n_tickets, N, lane, counter, spin_limit);
         return;
     }
     extern __shared__ uint32_t s_lut[];  // H entries
@@ -475,14 +478,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
                 uint32_t polls = 0;
                 while (true) {
                     f = __hip_atomic_load(&prefix[pend_ticket], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((uint32_t)(f >> 32) == 1u || ++polls >= kMarchSpinLimit) break;
+                    if ((uint32_t)(f >> 32) == 1u || ++polls >= spin_limit) break;
                     __builtin_amdgcn_s_sleep(2);
                 }
             }
             const uint32_t status = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(f >> 32));
             const uint32_t excl = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)f);
             if (status != 1u) {
-                if (lane == 0) counter[1] = -1;
+                if (lane == 0) atomicOr(reinterpret_cast<unsigned int*>(counter + 1), 0x80000000u);
             } else if (pend_n < N) {
                 march_store_ray<OFF32>(s_ray[wid][cur ^ 1], excl + pend_before, pend_count, pend_nrec, lane, pend_n, M, rays_o, rays_d, grid, bound, dt_gamma,
                                        max_steps, C, H, s_lut, nears, fars, noises, rays, xyzs, dirs, deltas, serial);
@@ -943,7 +946,7 @@ NVSF_API size_t nvsf_march_rays_train_ws_bytes(uint32_t N) { return 8u * (size_t
 NVSF_API int nvsf_march_rays_train_ws(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
                                       uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
                                       const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays, int32_t* counter,
-                                      const float* noises, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                                      const float* noises, void* workspace, size_t workspace_bytes, uint32_t spin_limit, hipStream_t stream) {
     if (N == 0) return NVSF_OK;
     REQUIRE(rays_o && rays_d && grid && nears && fars && xyzs && dirs && deltas && rays && counter && noises && workspace);
     REQUIRE(C >= 1 && C <= 8 && H >= 2 && H <= 1024 && max_steps >= 1);
@@ -956,7 +959,7 @@ NVSF_API int nvsf_march_rays_train_ws(const float* rays_o, const float* rays_d, 
     const uint32_t wanted = 1u + cdiv(N, (uint32_t)kMarchRays), resident = 8u * (uint32_t)march_cu_count();
     hipLaunchKernelGGL(kernel, dim3(wanted < resident ? wanted : resident), dim3(kBlock), H * sizeof(uint32_t), stream, rays_o, rays_d, grid, bound, dt_gamma,
                        max_steps, N, C, H, M, nears, fars, noises, rays, counter, reinterpret_cast<unsigned long long*>(workspace), xyzs, dirs,
-                       deltas, serial);
+                       deltas, serial, spin_limit ? spin_limit : kMarchSpinLimit);
     return nvsf_launch_status();
 }
 

@@ -425,7 +425,51 @@ def cast_cols_f16(src, dst):
 # nvsf.nerf.train_step.RenderTrainStep.step); everywhere else the scatter stays on the calling stream.
 _SIDE_STREAMS = {}
 SCATTER_OVERLAP = False
-GRAD_SINK = None  # frame_shard.GradBuckets of the running step (multi-rank): table gradients are scattered into its views
+GRAD_SINK = None  # where table gradients are scattered: frame_shard.GradBuckets of the running step (multi-rank) or a LocalGradSink
+
+
+class LocalGradSink:
+    """Single-process destination of the side-stream table scatters: the parameter's own `.grad`, zero-filled on the CALLING
+    (main) stream when the first scatter of a step asks for it.  Every scatter of that table then accumulates into this one
+    buffer on the side stream and the autograd node returns no tensor for the table: nothing the autograd engine could clone,
+    add or read on the main stream while the side stream still writes (a table that receives more than one DensityFn.backward
+    per pass -- RenderTrainStep(ray_chunks > 1) -- would otherwise be summed by the engine without any wait on the side stream)."""
+
+    def view_for(self, p):
+        if p.grad is None:
+            p.grad = torch.zeros_like(p, dtype=torch.float32)
+        return p.grad
+
+    def mark_ready(self, p):
+        pass
+
+
+# Scatters a table still has to receive in the running step (counted at DensityFn.forward while counting is on): a sink may only
+# be told that a table's gradient is final -- and send its bucket to the all-reduce -- after the LAST of them.
+_SCATTERS_LEFT = None
+
+
+def begin_scatter_count():
+    global _SCATTERS_LEFT
+    _SCATTERS_LEFT = {}
+
+
+def end_scatter_count():
+    global _SCATTERS_LEFT
+    _SCATTERS_LEFT = None
+
+
+def _scatter_expected(p):
+    if _SCATTERS_LEFT is not None and p is not None:
+        _SCATTERS_LEFT[p] = _SCATTERS_LEFT.get(p, 0) + 1
+
+
+def _scatter_done(p):
+    """True when this was the last outstanding scatter of table `p` in the step (always, outside a counted step)."""
+    if _SCATTERS_LEFT is None or p not in _SCATTERS_LEFT:
+        return True
+    _SCATTERS_LEFT[p] -= 1
+    return _SCATTERS_LEFT[p] <= 0
 
 
 def side_stream(device):
@@ -460,6 +504,8 @@ class DensityFn(Function):
         ctx.save_for_backward(x01, feat, sigma, mlp_w16)
         ctx.grid_spec, ctx.mlp_spec, ctx.clamp = grid_spec, mlp_spec, (float(sigma_lo), float(sigma_hi))
         ctx.table_param = table_params
+        if table_params is not None and table_params.requires_grad and torch.is_grad_enabled():
+            _scatter_expected(table_params)
         return sigma, h[:, 1:mlp_spec.n_out]
 
     @staticmethod
@@ -478,28 +524,33 @@ class DensityFn(Function):
         grad_feat, grad_w = mlp_backward(feat, mlp_w16, spec, grad_h[:, :spec.n_out], need_grad_x=need_table)
         grad_table = None
         if need_table:
+            last = _scatter_done(ctx.table_param)
+            sink = GRAD_SINK
             if not (SCATTER_OVERLAP and x01.is_cuda):
-                sink = GRAD_SINK
                 view = sink.view_for(ctx.table_param) if sink is not None else None
                 if view is not None:
                     hashgrid_backward(x01, (0, 1, 2), ctx.grid_spec, grad_feat, grad_table=view.view(-1))
-                    sink.mark_ready(ctx.table_param)
+                    if last:
+                        sink.mark_ready(ctx.table_param)
                 else:
                     grad_table = hashgrid_backward(x01, (0, 1, 2), ctx.grid_spec, grad_feat)
             else:
+                # Side stream.  The destination is ONE buffer per table and step, obtained (and, the first time, zero-filled) on the
+                # main stream BEFORE the side stream is made to wait for it: a bucket view (multi-rank) or the parameter's .grad
+                # (LocalGradSink).  The node returns no tensor for the table, so the autograd engine never touches the buffer.
+                if sink is None:
+                    raise _hip.NvsfHipError("SCATTER_OVERLAP needs a gradient sink (RenderTrainStep sets field_ops.GRAD_SINK)")
+                view = sink.view_for(ctx.table_param)
+                if view is None:
+                    raise _hip.NvsfHipError("the gradient sink has no buffer for this table")
                 main, side = torch.cuda.current_stream(x01.device), side_stream(x01.device)
                 side.wait_stream(main)
-                sink, view = GRAD_SINK, None
-                if sink is not None:
-                    view = sink.view_for(ctx.table_param)
                 with torch.cuda.stream(side):
                     x01.record_stream(side)
                     grad_feat.record_stream(side)
-                    if view is not None:  # multi-rank step: scatter into the (zeroed) bucket view, then the bucket may go out
-                        hashgrid_backward(x01, (0, 1, 2), ctx.grid_spec, grad_feat, grad_table=view.view(-1))
+                    hashgrid_backward(x01, (0, 1, 2), ctx.grid_spec, grad_feat, grad_table=view.view(-1))
+                    if last:  # the table's gradient is final: its bucket may go out (event recorded on the side stream)
                         sink.mark_ready(ctx.table_param)
-                    else:
-                        grad_table = hashgrid_backward(x01, (0, 1, 2), ctx.grid_spec, grad_feat)
         return None, grad_table, None, None, (grad_w if ctx.needs_input_grad[4] else None), None, None, None, None
 
 

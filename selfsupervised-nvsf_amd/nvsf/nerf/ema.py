@@ -22,7 +22,10 @@ class ExponentialMovingAverage:
             raise ValueError("Decay must be between 0 and 1")
         self.decay = float(decay)
         self.num_updates = 0 if use_num_updates else None
-        self._params = [p for p in parameters if p.requires_grad]
+        # torch_ema keeps a shadow for EVERY parameter it is given (frozen ones included): a reference checkpoint's `shadow_params`
+        # has one tensor per model parameter, and load_state_dict below checks that count.  Frozen parameters never move, so only
+        # their update is skipped.
+        self._params = list(parameters)
         self.shadow_params = [p.detach().clone() for p in self._params]
         self.collected_params = None
         self._optimizer = None
@@ -38,6 +41,8 @@ class ExponentialMovingAverage:
     def update(self):
         one_minus_decay = 1.0 - self._decay_now()
         for s, p in zip(self.shadow_params, self._params):
+            if not p.requires_grad or p.numel() == 0:
+                continue
             if p.dtype != torch.float32 or not p.is_contiguous():
                 raise _hip.NvsfHipError("EMA: fp32 contiguous parameters")
             _hip.call("nvsf_ema_update", _hip.ptr(s), _hip.ptr(p.detach()), p.numel(), float(one_minus_decay))
@@ -52,7 +57,7 @@ class ExponentialMovingAverage:
     def before_step(self):
         if self._optimizer is None:
             raise _hip.NvsfHipError("EMA.before_step(): attach(optimizer) first")
-        self._optimizer.ema = ({p: s for p, s in zip(self._params, self.shadow_params)}, 1.0 - self._decay_now())
+        self._optimizer.ema = ({p: s for p, s in zip(self._params, self.shadow_params) if p.requires_grad}, 1.0 - self._decay_now())
 
     # ---- evaluation under the averaged weights (trainer.py:1475-1477, 1843-1844) --------------------------------------------
     @torch.no_grad()

@@ -13,8 +13,6 @@ Host-side contract kept from the reference wrappers:
 Differences: kernels run on PyTorch's *current* stream (the reference uses the legacy default stream),
 launch failures raise, and the packed sample order is deterministic (ray order).
 """
-import os
-
 import torch
 from torch.autograd import Function
 
@@ -116,13 +114,47 @@ packbits = _packbits.apply
 # ------------------------------------------------------------------------------------------------
 # training
 # ------------------------------------------------------------------------------------------------
+# nvsf_march_rays_train_ws reports a bounded inter-workgroup wait that expired through counter[1] < 0 (include/nvsf_hip.h); its
+# sample arrays are then incomplete.  Calls that read the counter back anyway check the flag in that same read; calls that do not
+# (mean_count > 0: no device->host read, as in the reference) leave an asynchronous copy of the flag here, which the next
+# march_rays_train call -- or check_march_status() -- looks at once its copy event has completed.
+_pending_status = []  # [(pinned int32 [1], event)]
+
+
+def _note_status(step_counter):
+    host = torch.empty(1, dtype=torch.int32).pin_memory()
+    host.copy_(step_counter[1:2], non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    _pending_status.append((host, ev))
+
+
+def check_march_status(wait=False):
+    """Raises NvsfHipError if a march_rays_train launch whose counter was not read back reported an expired wait.
+    wait=True synchronises with the outstanding launches first."""
+    keep, failed = [], False
+    for host, ev in _pending_status:
+        if wait:
+            ev.synchronize()
+        if ev.query():
+            failed = failed or int(host[0]) < 0
+        else:
+            keep.append((host, ev))
+    _pending_status[:] = keep
+    if failed:
+        raise _hip.NvsfHipError("nvsf_march_rays_train_ws: a bounded inter-workgroup wait expired (counter[1] < 0); "
+                                "the samples of that call are invalid")
+
+
 class _march_rays_train(Function):
     @staticmethod
     @_fwd32
     def forward(ctx, rays_o, rays_d, bound, density_bitfield, C, H, nears, fars, step_counter=None, mean_count=-1,
-                perturb=False, align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024):
+                perturb=False, align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024, _entry="ws", _spin_limit=0):
         """Occupancy-grid sample generation.  Returns xyzs [M,3], dirs [M,3], deltas [M,2], rays int32 [N,3]
-        with rays[n] = (ray id, first sample, sample count)."""
+        with rays[n] = (ray id, first sample, sample count).
+        `_entry`, `_spin_limit` (not in the reference's signature) are for tests: "ref" selects the reference-shaped
+        three-launch entry point; a spin limit of 1 forces the one-launch kernel's expiry path."""
         rays_o, rays_d = _rays(rays_o), _rays(rays_d)
         density_bitfield = _dev(density_bitfield).contiguous()
         nears, fars = _dev(nears).contiguous(), _dev(fars).contiguous()
@@ -142,14 +174,17 @@ class _march_rays_train(Function):
         xyzs = alloc(M, 3, dtype=dt, device=dev)
         dirs = alloc(M, 3, dtype=dt, device=dev)
         deltas = alloc(M, 2, dtype=dt, device=dev)
-        rays = torch.empty(N, 3, dtype=torch.int32, device=dev)
+        # `rays` is written for every ray by a launch that completes; zeros, so that a launch that gives up (counter[1] < 0) on the
+        # path without a host read leaves (offset 0, count 0) rows -- rays without samples -- not garbage ranges, for the compositor
+        rays = (torch.empty if sliced else torch.zeros)(N, 3, dtype=torch.int32, device=dev)
         if step_counter is None:
             step_counter = torch.zeros(2, dtype=torch.int32, device=dev)
         noises = torch.rand(N, dtype=dt, device=dev) if perturb else torch.zeros(N, dtype=dt, device=dev)
 
         # one-launch form (nvsf_march_rays_train_ws: counts once, ranges from a scanner wave inside the launch); the reference-shaped
-        # three-launch entry point nvsf_march_rays_train gives the same outputs bit for bit (NVSF_MARCH_ENTRY=ref selects it)
-        use_ws = N > 0 and os.environ.get("NVSF_MARCH_ENTRY", "ws") != "ref"
+        # three-launch entry point nvsf_march_rays_train gives the same outputs bit for bit (_entry="ref" selects it)
+        use_ws = N > 0 and _entry != "ref"
+        check_march_status()
         ws_bytes = _hip.march_ws_bytes(N) if use_ws else 0
         workspace = torch.empty(ws_bytes // 8, dtype=torch.int64, device=dev) if use_ws else None
 
@@ -158,7 +193,7 @@ class _march_rays_train(Function):
                 _hip.call("nvsf_march_rays_train_ws", _hip.ptr(rays_o), _hip.ptr(rays_d), _hip.ptr(density_bitfield), float(bound),
                           float(dt_gamma), int(max_steps), N, int(C), int(H), M, _hip.ptr(nears), _hip.ptr(fars), _hip.ptr(xyzs),
                           _hip.ptr(dirs), _hip.ptr(deltas), _hip.ptr(rays), _hip.ptr(step_counter), _hip.ptr(noises), _hip.ptr(workspace),
-                          ws_bytes)
+                          ws_bytes, int(_spin_limit))
                 return
             _hip.call("nvsf_march_rays_train", _hip.ptr(rays_o), _hip.ptr(rays_d), _hip.ptr(density_bitfield), float(bound),
                       float(dt_gamma), int(max_steps), N, int(C), int(H), M, _hip.ptr(nears), _hip.ptr(fars), _hip.ptr(xyzs),
@@ -166,7 +201,10 @@ class _march_rays_train(Function):
         launch()
         if sliced:
             # the one device->host read of the reference (raymarching.py:277); rays[0,1] = counter value before the call
-            m, first = torch.stack([step_counter[0], rays[0, 1]]).tolist() if N > 0 else (int(step_counter[0].item()), 0)
+            m, status, first = torch.stack([step_counter[0], step_counter[1], rays[0, 1]]).tolist() if N > 0 else (int(step_counter[0].item()), 0, 0)
+            if status < 0:
+                raise _hip.NvsfHipError("nvsf_march_rays_train_ws: a bounded inter-workgroup wait expired (counter[1] < 0); "
+                                        "the samples of this call are invalid")
             if first != 0 or m > M:
                 # a pre-loaded counter or rays dropped for lack of room: the written rows are not one prefix -- redo on
                 # cleared buffers (never the case for the renderer, which passes a zeroed counter and M = N * max_steps)
@@ -185,6 +223,8 @@ class _march_rays_train(Function):
                 xyzs[written:].zero_()
                 dirs[written:].zero_()
                 deltas[written:].zero_()
+        elif use_ws:
+            _note_status(step_counter)
         return xyzs, dirs, deltas, rays
 
 

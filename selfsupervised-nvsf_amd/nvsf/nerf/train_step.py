@@ -146,6 +146,7 @@ class RenderTrainStep:
             self.ema = ExponentialMovingAverage(model.parameters(), decay=ema_decay)
         self._cham = None
         self.global_step = 0
+        self.failed_to_load = []  # components of the last load_checkpoint whose state could not be restored
         self.scatter_overlap = True  # table scatters on a side stream beside the rest of backward (field_ops.DensityFn)
         self.split_backward = bool(split_backward)
         self.ray_chunks = max(1, int(ray_chunks))
@@ -252,17 +253,30 @@ class RenderTrainStep:
 
     def _backward(self, loss):
         overlap = loss.is_cuda and self.scatter_overlap
+        local_sink = False
         if overlap:
             from nvsf import field_ops
             field_ops.SCATTER_OVERLAP = True
+            if field_ops.GRAD_SINK is None:  # one process: the side-stream scatters accumulate straight into p.grad
+                field_ops.GRAD_SINK, local_sink = field_ops.LocalGradSink(), True
         try:
             self.scaler.scale(loss).backward()
         finally:
             if overlap:
                 field_ops.SCATTER_OVERLAP = False
+                if local_sink:
+                    field_ops.GRAD_SINK = None
         return overlap
 
     def step(self, batch):
+        from nvsf import field_ops
+        field_ops.begin_scatter_count()  # a table is final after the LAST scatter it receives in this step (ray_chunks > 1: several)
+        try:
+            return self._step(batch)
+        finally:
+            field_ops.end_scatter_count()
+
+    def _step(self, batch):
         self.model.train()
         if self.buckets is not None:
             self.buckets.begin_step()
@@ -333,12 +347,9 @@ class RenderTrainStep:
             self.model.load_state_dict(checkpoint)
             return [], [], None
         missing, unexpected = self.model.load_state_dict(checkpoint["model"], strict=False)
-        if model_only:
-            return list(missing), list(unexpected), checkpoint.get("epoch")
-        if "global_step" in checkpoint:
-            self.global_step = checkpoint["global_step"]
         self.failed_to_load = []
-        for key, obj in (("optimizer", self.opt), ("lr_scheduler", self.sched), ("scaler", self.scaler), ("ema", self.ema)):
+
+        def restore(key, obj):
             if key in checkpoint and obj is not None:
                 try:
                     obj.load_state_dict(checkpoint[key])
@@ -346,6 +357,13 @@ class RenderTrainStep:
                     self.failed_to_load.append(key)
                     warnings.warn(f"[WARN] Failed to load {key} state from the checkpoint ({type(e).__name__}: {e}); "
                                   f"continuing with a fresh {key}")
+        restore("ema", self.ema)  # before the model_only return, as the reference does (utils.py:715-719): evaluation runs under the EMA weights
+        if model_only:
+            return list(missing), list(unexpected), checkpoint.get("epoch")
+        if "global_step" in checkpoint:
+            self.global_step = checkpoint["global_step"]
+        for key, obj in (("optimizer", self.opt), ("lr_scheduler", self.sched), ("scaler", self.scaler)):
+            restore(key, obj)
         return list(missing), list(unexpected), checkpoint.get("epoch")
 
 
@@ -372,9 +390,11 @@ def fscore(dist1, dist2, threshold=0.001):
 
 
 def pano_to_lidar(pano, intrinsics, intrinsics_hoz=(180.0, 360.0)):
-    """Range image [H, W] -> points [H * W, 3] in the LiDAR frame, on the device of `pano` (nvsf/lib/convert.py:221-291): pixel (row j,
+    """Range image [H, W] -> points [n, 3] in the LiDAR frame, on the device of `pano` (nvsf/lib/convert.py:221-291): pixel (row j,
     column i) looks along azimuth beta = -(i - W / 2) / W * fov_hoz and elevation alpha = fov_up - j / H * fov (degrees; `intrinsics` =
-    (fov_up, fov), `intrinsics_hoz` = (fov_hoz_up, fov_hoz)); zero-range pixels stay at the origin, as in the reference."""
+    (fov_up, fov), `intrinsics_hoz` = (fov_hoz_up, fov_hoz)).  Pixels of range exactly 0 (dropped rays, ~30 % of a KITTI-360 frame) give
+    no point -- the reference filters them with `np.where(pano != 0.0)` (convert.py:262-266) before the chamfer distance sees the
+    cloud -- so n <= H * W, in row-major pixel order (one device->host read for the count; this is evaluation code)."""
     H, W = pano.shape
     fov_up, fov = (float(v) for v in intrinsics)
     fov_hoz = float(intrinsics_hoz[1])
@@ -383,7 +403,8 @@ def pano_to_lidar(pano, intrinsics, intrinsics_hoz=(180.0, 360.0)):
     beta = -(i - W / 2) / W * fov_hoz / 180 * np.pi
     alpha = (fov_up - j / H * fov) / 180 * np.pi
     dirs = torch.stack([torch.cos(alpha) * torch.cos(beta), torch.cos(alpha) * torch.sin(beta), torch.sin(alpha).expand(H, W)], -1)
-    return (dirs * pano.float()[..., None]).reshape(-1, 3)
+    pano = pano.float()
+    return (dirs * pano[..., None])[pano != 0.0]
 
 
 class PointsMeter:
@@ -456,47 +477,33 @@ def eval_step(model, data, num_steps, alpha_d=1.0, alpha_r=0.01, alpha_i=0.1, al
     return out
 
 
-def evaluate_frames(model, frames, num_steps, indices=None, **eval_kwargs):
+def evaluate_frames(model, frames, num_steps, indices=None, ema=None, **eval_kwargs):
     """The metric half of the reference's evaluate_one_epoch (trainer.py:1458-1560) over a FrameSet opened with training=False:
-    per frame eval_step, then PSNR of the image (error_matrices.py:48-57), range RMSE in metres (:263-285) and chamfer distance /
-    F-score of the range image's point cloud (PointsMeter, :299-356), ray-drop RMSE / accuracy / F1 (RaydropMeter, :378-403) and the
-    intensity MAE (MAEMeter, :139-147); means over the frames.  Every rank returns the same numbers
-    (the renders are all-gathered)."""
+    per frame eval_step, then the two quality metrics of the headline benchmark -- PSNR of the image (error_matrices.py:48-57), range
+    RMSE in metres (:263-285) -- and chamfer distance / F-score of the range image's point cloud (PointsMeter, :299-356, on
+    csrc/chamfer.hip); means over the frames.  `ema`: the step's ExponentialMovingAverage (RenderTrainStep.ema) -- the reference
+    evaluates under `ema.store(); ema.copy_to()` and `restore()`s afterwards (trainer.py:1475-1477, 1843-1844), so metrics are
+    those of the averaged weights once EMA is on (its default).  Every rank returns the same numbers (the renders are
+    all-gathered).  The reference's other meters (ray-drop accuracy / F1, intensity MAE, SSIM, LPIPS: SURVEY 2 #18) are outside
+    this package's scope; nvsf/nerf/meters_extra.py restates two of them for users who want them beside these."""
     was_training = model.training
     model.eval()
-    points = PointsMeter(frames.scale, frames.intrinsics_lidar, frames.intrinsics_hoz_lidar)
-    ps, rm, ls, rd, mae = [], [], [], [], []
-    for i in (range(len(frames)) if indices is None else indices):
-        e = eval_step(model, frames.collate([int(i)]), num_steps, **eval_kwargs)
-        ps.append(psnr(e["pred_rgb"], e["gt_rgb"]))
-        rm.append(depth_rmse(e["pred_depth"], e["gt_depth"], frames.scale))
-        points.update(e["pred_depth"], e["gt_depth"])
-        rd.append(raydrop_metrics(e["pred_raydrop"], e["gt_raydrop"], eval_kwargs.get("raydrop_thres", 0.5)))
-        mae.append(intensity_mae(e["pred_intensity"], e["gt_intensity"]))
-        ls.append(float(e["loss"]))
-    model.train(was_training)
+    if ema is not None:
+        ema.store()
+        ema.copy_to()
+    try:
+        points = PointsMeter(frames.scale, frames.intrinsics_lidar, frames.intrinsics_hoz_lidar)
+        ps, rm, ls = [], [], []
+        for i in (range(len(frames)) if indices is None else indices):
+            e = eval_step(model, frames.collate([int(i)]), num_steps, **eval_kwargs)
+            ps.append(psnr(e["pred_rgb"], e["gt_rgb"]))
+            rm.append(depth_rmse(e["pred_depth"], e["gt_depth"], frames.scale))
+            points.update(e["pred_depth"], e["gt_depth"])
+            ls.append(float(e["loss"]))
+    finally:
+        if ema is not None:
+            ema.restore()
+        model.train(was_training)
     cd, fs = points.measure()
-    rd = np.array(rd).mean(0)
     return {"loss": float(np.mean(ls)), "psnr": float(np.mean(ps)), "depth_rmse_m": float(np.mean(rm)), "chamfer_distance": float(cd),
-            "f_score": float(fs), "raydrop_rmse": float(rd[0]), "raydrop_acc": float(rd[1]), "raydrop_f1": float(rd[2]),
-            "intensity_mae": float(np.mean(mae)), "frames": len(ps)}
-
-
-def raydrop_metrics(pred, truth, ratio=0.5):
-    """RMSE, accuracy and F1 of a predicted ray-drop map against the measured mask (RaydropMeter.update, error_matrices.py:378-403:
-    threshold `ratio`, precision / recall from the confusion counts).  Returns (rmse, acc, f1) as floats."""
-    p, t = (np.asarray(a.detach().cpu() if torch.is_tensor(a) else a, dtype=np.float64) for a in (pred, truth))
-    rmse = float(np.sqrt(((t - p) ** 2).mean()))
-    m = (p > ratio).astype(np.float64)
-    acc = float((m == t).mean())
-    tp, fp, fn = float(((t == 1) & (m == 1)).sum()), float(((t == 0) & (m == 1)).sum()), float(((t == 1) & (m == 0)).sum())
-    with np.errstate(divide="ignore", invalid="ignore"):
-        precision, recall = np.float64(tp) / (tp + fp), np.float64(tp) / (tp + fn)
-        f1 = 2 * (precision * recall) / (precision + recall)
-    return rmse, acc, float(f1)
-
-
-def intensity_mae(pred, truth, intensity_inv_scale=1.0):
-    """Mean absolute intensity error (MAEMeter.update, error_matrices.py:139-147)."""
-    p, t = (np.asarray(a.detach().cpu() if torch.is_tensor(a) else a, dtype=np.float64) for a in (pred, truth))
-    return float(np.abs(t * intensity_inv_scale - p * intensity_inv_scale).mean())
+            "f_score": float(fs), "frames": len(ps)}

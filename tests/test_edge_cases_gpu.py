@@ -30,7 +30,7 @@ def test_zero_sized_calls_are_noops(dev):
     _hip.call("nvsf_mse_sum_bwd", None, None, 0, 1.0, None, None)
     _hip.call("nvsf_sigmoid_bwd", None, None, 0, None)
     _hip.call("nvsf_exp_col", None, 16, 0, 0, None)
-    _hip.call("nvsf_march_rays_train_ws", None, None, None, 2.0, 0.0, 1024, 0, 2, 128, 0, None, None, None, None, None, None, None, None, None, 0)
+    _hip.call("nvsf_march_rays_train_ws", None, None, None, 2.0, 0.0, 1024, 0, 2, 128, 0, None, None, None, None, None, None, None, None, None, 0, 0)
     assert _hip.march_ws_bytes(0) == 8 and _hip.march_ws_bytes(1) == 24 and _hip.march_ws_bytes(5) == 40
 
 
@@ -49,7 +49,7 @@ def test_rejected_arguments(dev):
     rays = torch.zeros(8, 3, dtype=torch.int32, device=dev)
     ctr = torch.zeros(2, dtype=torch.int32, device=dev)
     bits = torch.zeros(2 * 128 ** 3 // 8, dtype=torch.uint8, device=dev)
-    args = lambda C, H, wsb, wp: (P(x), P(x), P(bits), 2.0, 0.0, 64, 8, C, H, 512, P(x), P(x), P(x), P(x), P(x), P(rays), P(ctr), P(x), wp, wsb)
+    args = lambda C, H, wsb, wp: (P(x), P(x), P(bits), 2.0, 0.0, 64, 8, C, H, 512, P(x), P(x), P(x), P(x), P(x), P(rays), P(ctr), P(x), wp, wsb, 0)
     _raises("nvsf_march_rays_train_ws", *args(2, 128, 8, P(ws)))          # scratch smaller than nvsf_march_rays_train_ws_bytes(8)
     _raises("nvsf_march_rays_train_ws", *args(2, 128, 512, P(ws) + 4))    # not 8-byte aligned
     _raises("nvsf_march_rays_train_ws", *args(9, 128, 512, P(ws)))        # more cascades than the operator is defined for

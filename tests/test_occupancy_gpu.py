@@ -47,6 +47,24 @@ def _near_far(m, S, o, d, lidar):
     return O.near_far_from_aabb(o, d, np.array([-S.BOUND] * 3 + [S.BOUND] * 3, np.float32), m.min_near)
 
 
+def _assert_close_up_to_one_terminal_sample(out, ref, sfx, pick, T_thresh, t_max, min_exact):
+    """1e-4 abs on every ray, except that a ray whose transmittance lands within float noise of T_thresh may take ONE more
+    sample on one side only.  That sample is met with transmittance T ~ T_thresh (the compositor stops after the first sample
+    whose incoming T is below the threshold, raymarching.cu:1015-1040), so its weight alpha * T is at most T_thresh: the exempt
+    rays are bounded by that one weight -- weights_sum and every image channel (colour in [0, 1], background <= 1) by T_thresh,
+    depth by T_thresh * t_max -- on top of the 1e-4."""
+    ws = out["weights_sum" + sfx].cpu().numpy()[pick]
+    dp = out["depth" + sfx][0].cpu().numpy()[pick]
+    im = out["image" + sfx][0].cpu().numpy()[pick]
+    e_ws, e_dp, e_im = np.abs(ws - ref["weights_sum"]), np.abs(dp - ref["depth"]), np.abs(im - ref["image"]).max(-1)
+    exact = (e_ws <= 1e-4) & (e_dp <= 1e-4) & (e_im <= 1e-4)
+    assert exact.mean() >= min_exact, exact.mean()
+    w1 = 1.05 * T_thresh  # one terminal sample's weight (5 % for the noise in T itself)
+    assert (e_ws <= 1e-4 + w1).all(), float(e_ws.max())
+    assert (e_im <= 1e-4 + w1).all(), float(e_im.max())
+    assert (e_dp <= 1e-4 + w1 * t_max).all(), float(e_dp.max())
+
+
 @pytest.mark.parametrize("lidar", [True, False])
 def test_training_mode_matches_oracle_and_backpropagates(dev, setup, lidar):
     m, bits, S = setup
@@ -87,12 +105,7 @@ def test_evaluation_loop_matches_oracle(dev, setup, lidar, fused):
         out = m.render(_t(o, dev)[None], _t(d, dev)[None], torch.tensor([[0.5]], device=dev), cal_lidar_color=lidar, max_steps=max_steps,
                        T_thresh=1e-2, fused=fused)
     sfx = "_lidar" if lidar else ""
-    close = lambda a, b: np.abs(a - b) <= 1e-4
-    ws_ok = close(out["weights_sum" + sfx].cpu().numpy(), ref["weights_sum"])
-    # a ray whose transmittance lands within float noise of T_thresh may run one extra round on one side only
-    assert ws_ok.mean() > 0.99
-    assert (close(out["depth" + sfx][0].cpu().numpy(), ref["depth"]) | ~ws_ok).all()
-    assert (close(out["image" + sfx][0].cpu().numpy(), ref["image"]).all(-1) | ~ws_ok).all()
+    _assert_close_up_to_one_terminal_sample(out, ref, sfx, slice(None), 1e-2, float(fars[fars < 1e30].max()), min_exact=0.99)
 
 
 @pytest.mark.parametrize("lidar", [True, False])
@@ -197,9 +210,4 @@ def test_config3_full_size_matches_oracle(dev, lidar):
                                    lidar, T_thresh=1e-4)
     sfx = "_lidar" if lidar else ""
     assert float(ref["weights_sum"].max()) > 0.05
-    close = lambda a, b: np.abs(a - b) <= 1e-4
-    ws_ok = close(out["weights_sum" + sfx].cpu().numpy()[pick], ref["weights_sum"])
-    # a ray whose transmittance lands within float noise of T_thresh may take one more sample on one side only
-    assert ws_ok.mean() >= 0.97, ws_ok.mean()
-    assert (close(out["depth" + sfx][0].cpu().numpy()[pick], ref["depth"]) | ~ws_ok).all()
-    assert (close(out["image" + sfx][0].cpu().numpy()[pick], ref["image"]).all(-1) | ~ws_ok).all()
+    _assert_close_up_to_one_terminal_sample(out, ref, sfx, pick, 1e-4, float(fars[fars < 1e30].max()), min_exact=0.97)

@@ -122,7 +122,7 @@ def test_march_rays_train(rm, dev, scene, n, max_steps, dt_gamma, perturb_seed, 
     assert not xyzs[m:].any()
 
 
-def _march_ws(dev, to, td, tb, tn, tf, tz, n, max_steps, dt_gamma, M, counter0=(0, 0)):
+def _march_ws(dev, to, td, tb, tn, tf, tz, n, max_steps, dt_gamma, M, counter0=(0, 0), spin_limit=0):
     from nvsf import _hip
     xyzs = torch.zeros(M, 3, device=dev); dirs = torch.zeros(M, 3, device=dev); deltas = torch.zeros(M, 2, device=dev)
     rays = torch.empty(n, 3, dtype=torch.int32, device=dev)
@@ -131,7 +131,7 @@ def _march_ws(dev, to, td, tb, tn, tf, tz, n, max_steps, dt_gamma, M, counter0=(
     ws = torch.full((nb // 8,), -1, dtype=torch.int64, device=dev)  # garbage on entry: the entry point clears it
     _hip.call("nvsf_march_rays_train_ws", _hip.ptr(to), _hip.ptr(td), _hip.ptr(tb), 2.0, float(dt_gamma), max_steps, n, 2, 128, M,
               _hip.ptr(tn), _hip.ptr(tf), _hip.ptr(xyzs), _hip.ptr(dirs), _hip.ptr(deltas), _hip.ptr(rays), _hip.ptr(counter), _hip.ptr(tz),
-              _hip.ptr(ws), nb)
+              _hip.ptr(ws), nb, spin_limit)
     return counter.cpu(), rays.cpu(), xyzs.cpu(), dirs.cpu(), deltas.cpu()
 
 
@@ -219,7 +219,7 @@ def test_march_rays_train_other_grid_shapes(rm, dev, C, H, bound, dt_gamma):
         if entry.endswith("_ws"):
             nb = _hip.march_ws_bytes(n)
             ws = torch.empty(nb // 8, dtype=torch.int64, device=dev)
-            extra = (_hip.ptr(ws), nb)
+            extra = (_hip.ptr(ws), nb, 0)
         _hip.call(entry, _hip.ptr(to), _hip.ptr(td), _hip.ptr(tb), float(bound), float(dt_gamma), max_steps, n, C, H, M, _hip.ptr(tn), _hip.ptr(tf),
                   _hip.ptr(xyzs), _hip.ptr(dirs), _hip.ptr(deltas), _hip.ptr(rays), _hip.ptr(counter), _hip.ptr(tz), *extra)
         assert np.array_equal(counter.cpu().numpy(), cr) and np.array_equal(rays.cpu().numpy(), rr), entry
@@ -397,3 +397,37 @@ def test_empty_inputs(rm, dev):
     n, f = rm.near_far_from_aabb(z3, z3, aabb, 0.1)
     assert n.shape == (0,) and f.shape == (0,)
     assert rm.morton3D(torch.zeros(0, 3, dtype=torch.int32, device=dev)).shape == (0,)
+
+
+def test_march_rays_train_expired_wait_is_reported(rm, dev, scene):
+    """nvsf_march_rays_train_ws with a spin limit of one poll (test-only argument): the scanner finds no published sum at its first
+    look, gives up, and every worker gives up on its prefix -- the launch terminates and marks counter[1] negative (include/nvsf_hip.h).
+    The operator must turn that into an exception: at once when it reads the counter back (force_all_rays / no mean_count), at the
+    next call or check_march_status() when it does not (mean_count > 0), and the un-read path must not hand garbage ranges to the
+    compositor (`rays` rows stay (0, 0, 0))."""
+    from nvsf import _hip
+    n, max_steps = 4096, 256
+    o, d = _rays(n, 11, "cam")
+    aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
+    nears, fars = O.near_far_from_aabb(o, d, aabb, 0.02)
+    T = lambda a: _t(a, dev)
+    to, td, tb, tn, tf = T(o), T(d), T(scene["bits"]), T(nears), T(fars)
+    counter, rays, *_ = _march_ws(dev, to, td, tb, tn, tf, torch.zeros(n, device=dev), n, max_steps, 0.0, n * max_steps, spin_limit=1)
+    assert int(counter[1]) < 0
+    # the flag is sticky: a good launch on the same counter leaves it
+    ctr = torch.tensor([0, -2 ** 31], dtype=torch.int32, device=dev)
+    with pytest.raises(_hip.NvsfHipError, match="expired"):
+        rm.march_rays_train(to, td, 2.0, tb, 2, 128, tn, tf, ctr, -1, False, 128, True, 0, max_steps)
+    # read-back path
+    with pytest.raises(_hip.NvsfHipError, match="expired"):
+        rm.march_rays_train(to, td, 2.0, tb, 2, 128, tn, tf, None, -1, False, 128, True, 0, max_steps, "ws", 1)
+    # no read-back (mean_count > 0): reported by the deferred check; the ranges handed on are empty, not garbage
+    xyzs, dirs, deltas, rays = rm.march_rays_train(to, td, 2.0, tb, 2, 128, tn, tf, None, 4096, False, 128, False, 0, max_steps, "ws", 1)
+    assert not rays.any()
+    with pytest.raises(_hip.NvsfHipError, match="expired"):
+        rm.check_march_status(wait=True)
+    rm.check_march_status(wait=True)  # reported once
+    # and a normal call afterwards is fine
+    out = rm.march_rays_train(to, td, 2.0, tb, 2, 128, tn, tf, None, -1, False, 128, True, 0, max_steps)
+    assert out[0].shape[0] > 0
+    rm.check_march_status(wait=True)

@@ -108,7 +108,7 @@ def raymarching_rooflines(dev, n_rays_march=32768, occupied=1.0, seed=0):
     def march_ws():  # what raymarching.march_rays_train launches: one kernel (+ the memset of the 64 KB scan workspace)
         counter.zero_()
         _hip.call("nvsf_march_rays_train_ws", P(o), P(d), P(bitfield), bound, 0.0, max_steps, N, C, H, M, P(nears), P(fars),
-                  P(xyzs), P(dirs), P(deltas), P(rays), P(counter), P(noises), P(workspace), ws_bytes)
+                  P(xyzs), P(dirs), P(deltas), P(rays), P(counter), P(noises), P(workspace), ws_bytes, 0)
     ms = _time_ms(march_ws, 5)
     assert int(counter[0].item()) == m
     rows.append(_row(f"march_rays_train_ws[{occupied:.0%} occupied]", ms, 48 * N + 32 * m, "48 B/ray + 32 B/sample", m))

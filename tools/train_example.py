@@ -93,7 +93,7 @@ def main():
     # whole-frame evaluation (Trainer.eval_step / evaluate_one_epoch): every frame rendered with the staged loop, its rays split over the ranks
     from nvsf.nerf.train_step import evaluate_frames
     whole = FrameSet(root, args.sequence, "train", scale, device=dev, training=False)
-    res = evaluate_frames(model, whole, args.num_steps, indices=range(min(len(whole), 4)))
+    res = evaluate_frames(model, whole, args.num_steps, indices=range(min(len(whole), 4)), ema=trainer.ema)
     if rank == 0:
         print(f"evaluation over {res['frames']} frames: loss {res['loss']:.4f}, PSNR {res['psnr']:.2f} dB, range RMSE {res['depth_rmse_m']:.2f} m, "
               f"chamfer distance {res['chamfer_distance']:.3f}, F-score {res['f_score']:.3f}")
