@@ -413,11 +413,54 @@ def field_ops_leg(dev, n_rays, T):
             "kernels": field_op_rooflines(dev, n_rays, T)}
 
 
+def dynamic_fixture_check(m, dev, n_rays, T):
+    """Max |image / depth / weights_sum| difference of the fp16-regime render against the reference-generated fixture (24 rays per
+    modality inside full-size batches), parameters by the fixture's name-derived seeds; the model's own parameters are restored."""
+    path = os.path.join(ROOT, "tests", "golden", "network_dynamic_rd.npz")
+    if not os.path.exists(path) or T != 768:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import golden_dynamic as GD
+    from nvsf import synthetic as S
+    g = np.load(path)
+    saved = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    try:
+        GD.init_by_name(m)
+        last = [l for l in m.flow_net.mlp if isinstance(l, torch.nn.Linear)][-1]
+        w0 = last.weight.detach().clone()
+        worst = {}
+        for flow, _ in GD.RD_FLOWS:
+            with torch.no_grad():
+                last.weight.copy_(w0 * float(g[f"flow_gain_{flow}"]))
+            err = 0.0
+            for tag, tv in GD.RD_TIMES:
+                for lidar in (True, False):
+                    o24, d24 = GD.rd_rays(tag, lidar, S)
+                    rng = np.random.default_rng(99)
+                    o, d = (S.lidar_rays if lidar else S.camera_rays)(n_rays - GD.RD_N, rng)
+                    o, d = np.concatenate([o24, o]), np.concatenate([d24, d])
+                    with torch.no_grad():
+                        r = m.render(torch.from_numpy(o).to(dev)[None], torch.from_numpy(d).to(dev)[None],
+                                     torch.tensor([[tv]], dtype=torch.float32, device=dev), cal_lidar_color=lidar, num_steps=T, fp16=True)
+                    sfx, key = ("_lidar" if lidar else ""), f"{flow}/{tag}/{'lidar' if lidar else 'cam'}"
+                    for k in ("image", "depth", "weights_sum"):
+                        ref = g[f"{key}/{k}"]
+                        got = r[k + sfx].reshape(n_rays, -1)[:GD.RD_N].cpu().numpy().reshape(ref.shape)
+                        err = max(err, float(np.abs(got - ref).max()))
+            worst[flow] = err
+        return {"max_abs_err": worst, "tolerance": 1e-4, "ok": bool(max(worst.values()) <= 1e-4), "rays_checked_per_render": GD.RD_N,
+                "renders": 12, "regime": "fp16 flow MLP (fused MFMA kernel)"}
+    finally:
+        m.load_state_dict(saved)
+
+
 def dynamic_leg(dev, n_rays, T, steps):
     """Secondary figure (BASELINE config 5: "dynamic 4D field, fp16 MFMA path"): the reference-default space-time field
     (K-planes + static / dynamic hash grids + flow field, 93.6 M parameters, time_resolution 8), forward render of n_rays
-    LiDAR + n_rays camera rays.  The flow MLP runs on the fused fp16 MFMA kernel (NVSF_FLOW_MLP=fused: what the reference's
-    Linear layers compute under autocast; the fp32 torch form, which the CPU fixtures pin, is reported beside it)."""
+    LiDAR + n_rays camera rays, rendered as the reference's shipped configuration does: `fp16=True` reaches render (the flow MLP then
+    runs on the fused fp16 MFMA kernel = nn.Linear under autocast; the fp32 form is reported beside it).  `outputs_match_fixture`:
+    the same model with the fixture's parameters renders batches of the same size whose first 24 rays are the rays of
+    tests/golden/network_dynamic_rd.npz -- renders of the REFERENCE's NeRFNetwork at this size -- still and moving scene."""
     from nvsf import synthetic as S
     from nvsf.nerf.models.network_dynamic import NeRFNetwork
     torch.manual_seed(0)
@@ -430,29 +473,24 @@ def dynamic_leg(dev, n_rays, T, steps):
     tc = [torch.from_numpy(a).to(dev)[None] for a in (co, cd)]
     tm = torch.tensor([[0.5]], device=dev)
 
-    def step():
+    def step(fp16):
         with torch.no_grad():
-            m.render(tl[0], tl[1], tm, cal_lidar_color=True, num_steps=T)
-            m.render(tc[0], tc[1], tm, cal_lidar_color=False, num_steps=T)
-    def timed(flow_mlp):
-        prev = os.environ.get("NVSF_FLOW_MLP")
-        os.environ["NVSF_FLOW_MLP"] = flow_mlp
-        try:
-            for _ in range(2):
-                step()
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                step()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0) / steps
-        finally:
-            if prev is None:
-                del os.environ["NVSF_FLOW_MLP"]
-            else:
-                os.environ["NVSF_FLOW_MLP"] = prev
-    dt = timed("fused")
-    dt32 = timed("torch")
+            m.render(tl[0], tl[1], tm, cal_lidar_color=True, num_steps=T, fp16=fp16)
+            m.render(tc[0], tc[1], tm, cal_lidar_color=False, num_steps=T, fp16=fp16)
+
+    def timed(fp16):
+        """fp16 = the reference's `--fp16` option as it reaches render through **vars(opt) (trainer.py:200; set by the shipped config,
+        configs/kitti360_1908.txt): the flow MLP on the fused fp16 MFMA kernel.  False: its Linear layers in fp32 (rocBLAS)."""
+        for _ in range(2):
+            step(fp16)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(fp16)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+    dt = timed(True)
+    dt32 = timed(False)
     out = {"metric": "rendered rays/sec (LiDAR+cam), dynamic 4-D field", "value": 2 * n_rays / dt, "ms_per_step": dt * 1e3,
            "flow_mlp": "fp16 MFMA (fused kernel)", "fp32_flow_mlp": {"value": 2 * n_rays / dt32, "ms_per_step": dt32 * 1e3},
            "scene_flow": "fresh initialisation: |flow| ~ 1e-8 of the unit cube, i.e. a static scene -- the neighbour-frame evaluations re-use "
@@ -465,9 +503,10 @@ def dynamic_leg(dev, n_rays, T, steps):
         for p in m.flow_net.grid_enc.parameters():
             p.uniform_(-0.5, 0.5)
         m.flow_net.mlp[-1].weight.normal_(0, 6e-3)
-    dtm = timed("fused")
+    dtm = timed(True)
     out["moving_scene"] = {"value": 2 * n_rays / dtm, "ms_per_step": dtm * 1e3, "mean_abs_flow": 8e-4}
     m.flow_net.load_state_dict(saved)
+    out["outputs_match_fixture"] = dynamic_fixture_check(m, dev, n_rays, T)
     # the multimodal training step on the same model (what main_nvsf.py trains): fwd + bwd + Adam, loss-scaled
     from nvsf.nerf.train_step import RenderTrainStep
     g = torch.Generator(device="cpu").manual_seed(3)

@@ -2,9 +2,12 @@
 time -> bias-free MLP 32 -> 64 -> 64 -> 6 (forward and backward flow).  Same constructor, parameter names
 (`grid_enc.params`, `mlp.<i>.weight`) and arithmetic as /root/reference/nvsf/nerf/models/flow_field.py:41-133.
 The three small dense layers are `nn.Linear` modules as in the reference (same state_dict keys; last layer
-initialised N(0, 1e-3), :103); with autograd they run through torch, without it on the fused MFMA MLP kernel."""
-import os
-
+initialised N(0, 1e-3), :103).  Which arithmetic they run in follows the caller's precision regime, as in the reference:
+fp32 (torch) by default; fp16 operands with fp32 accumulation on the fused MFMA MLP kernels -- what `torch.cuda.amp.autocast`
+makes of a Linear layer -- when the call runs inside an autocast region (the reference's Trainer wraps every step in
+`autocast(enabled=opt.fp16)`, trainer.py:1318, 1491), when `fp16=True` reaches `render` (the reference passes `**vars(self.opt)`,
+trainer.py:200, and its shipped config sets `fp16`: configs/kitti360_1908.txt), or when the module's `flow_mlp_mode` is "fused"
+(RenderTrainStep(fp16=True))."""
 import numpy as np
 import torch
 import torch.nn as nn
@@ -36,21 +39,22 @@ class FlowField(nn.Module):
         self.mlp = nn.Sequential(*layers)
         torch.nn.init.normal_(self.mlp[-1].weight.data, 0, 0.001)
 
-    def forward(self, xt, t_host=None):
+    def forward(self, xt, t_host=None, fp16=None):
         """xt: [N, 4] = (x, y, z, t) in [0, 1]; all rows share one t (the reference reads xt[0, 3], :125).
         Without autograd the grid lookup and the Lagrange reduction are one fused kernel (csrc/hashgrid4d.hip);
-        `t_host` (the value of t, if the caller already has it on the host) avoids a device->host read."""
+        `t_host` (the value of t, if the caller already has it on the host) avoids a device->host read.
+        `fp16`: True / False selects the MLP's arithmetic for this call, None follows the regime (module docstring)."""
         t = xt[0, 3]
+        fused_mlp = self.mlp_mode(fp16) == "fused" and self._fused_mlp_ok()
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            if (os.environ.get("NVSF_FLOW_GRID_TRAIN", "fused") == "fused" and self.n_features_per_level == 8 and self.num_basis == 4
-                    and not xt.requires_grad):
+            if self.grid_train_mode == "fused" and self.n_features_per_level == 8 and self.num_basis == 4 and not xt.requires_grad:
                 # grid lookup + Lagrange reduction as the fused forward kernel, the table gradient straight from dL/d(reduced)
                 t_h = float(t) if t_host is None else t_host
                 red = FlowGridFn.apply(self, xt.float().contiguous(), t_h, self.grid_enc.params)
             else:
                 feat = self.grid_enc.encode_columns(xt, (0, 1, 2)).float()
                 red = lagrange_reduce(feat, t, self.n_levels, self.n_features_per_level, self.num_basis)
-            if self.mlp_mode() == "fused" and self._fused_mlp_ok():
+            if fused_mlp:
                 # the mixed-precision training run: the Linear layers on the fused MFMA forward / backward kernels (what
                 # autocast makes of them in the reference's Trainer), instead of three fp32 GEMMs + two ReLU launches forward
                 # and six GEMMs backward whose weight gradients reduce over millions of rows
@@ -61,11 +65,10 @@ class FlowField(nn.Module):
             raise NotImplementedError("fused flow grid kernel: 8 features per level, 4 Lagrange nodes")
         t_host = float(t) if t_host is None else t_host
         red = self._grid_lagrange(xt.float().contiguous(), t_host)
-        if self.mlp_mode() == "fused" and self._fused_mlp_ok():
-            # NVSF_FLOW_MLP=fused (opt-in): the three bias-free layers on the fused MFMA MLP kernel -- fp16 operands, fp32
-            # accumulation, i.e. what the reference's Linear layers compute under the Trainer's autocast, 6x faster than
-            # the fp32 GEMM + ReLU launches, but only fp16-accurate (4e-5 abs on flows of 1e-2) where the CPU reference
-            # this repo is pinned against is fp32; the default therefore stays on torch.  Columns 6..15 are padding.
+        if fused_mlp:
+            # the fp16 regime: the three bias-free layers as ONE fused MFMA kernel -- fp16 operands, fp32 accumulation, i.e. what the
+            # reference's Linear layers compute under the Trainer's autocast (6x faster than three fp32 GEMM + two ReLU launches;
+            # fp16-accurate: 4e-5 abs on flows of 1e-2 against the fp32 form).  Columns 6..15 are padding.
             return ops.mlp_forward(red, self._mlp_weights_f16(), self._mlp_spec)[:, :6]
         return self.mlp(red)
 
@@ -80,11 +83,16 @@ class FlowField(nn.Module):
                   spec.h_scales, spec.h_res, spec.h_offsets, _hip.host_f32(lagrange_weights_host(t_host, 4, xt.is_cuda)), _hip.ptr(red))
         return red
 
-    def mlp_mode(self):
-        """"torch" (fp32 Linear layers, the form the CPU fixtures pin) or "fused" (fp16 MFMA kernels = the reference under
-        autocast).  NVSF_FLOW_MLP overrides; RenderTrainStep(fp16=True) sets `flow_mlp_mode = "fused"` on the module."""
-        import os
-        return os.environ.get("NVSF_FLOW_MLP", getattr(self, "flow_mlp_mode", "torch"))
+    flow_mlp_mode = "auto"     # "auto": follow the caller's regime; "fused" / "torch": pinned (RenderTrainStep(fp16=True) pins "fused")
+    grid_train_mode = "fused"  # "fused": FlowGridFn; "chain" (tests): encoder + lagrange_reduce under plain autograd
+
+    def mlp_mode(self, fp16=None):
+        """"torch" (fp32 Linear layers) or "fused" (fp16 MFMA kernels = the reference's Linear layers under autocast)."""
+        if fp16 is not None:
+            return "fused" if fp16 else "torch"
+        if self.flow_mlp_mode != "auto":
+            return self.flow_mlp_mode
+        return "fused" if torch.is_autocast_enabled() else "torch"
 
     def _fused_mlp_ok(self):
         lin = [m for m in self.mlp if isinstance(m, nn.Linear)]

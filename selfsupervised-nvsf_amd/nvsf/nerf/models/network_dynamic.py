@@ -80,19 +80,21 @@ class NeRFNetwork(NeRFRenderer):
         f = self.flow_net(torch.cat([x, t], dim=-1))
         return {"flow_forward": f[:, :3], "flow_backward": f[:, 3:]}
 
-    def _dynamic_features(self, x, t, cal_lidar_color):
-        """x in [0,1]^3 -> (plane_s, plane_d, plane_1, plane_2, hash_s, hash_d, hash_1, hash_2), network_dynamic.py:220-271."""
+    def _dynamic_features(self, x, t, cal_lidar_color, fp16=None):
+        """x in [0,1]^3 -> (plane_s, plane_d, plane_1, plane_2, hash_s, hash_d, hash_1, hash_2), network_dynamic.py:220-271.
+        `fp16`: the reference's `--fp16` option as it reaches render through `**vars(self.opt)` (trainer.py:200): the flow MLP's
+        Linear layers then compute in fp16 with fp32 accumulation, as under the Trainer's autocast (flow_field.FlowField.forward)."""
         t_host = _host_time(t)  # the one device->host read of this call
         frame_idx = int(np.float32(t_host) * np.float32(self.num_frames - 1))
         hash_enc = self.hash_encoder_lidar if cal_lidar_color else self.hash_encoder_camera
         planes_enc = self.planes_encoder_lidar if cal_lidar_color else self.planes_encoder_camera
 
         if not torch.is_grad_enabled() and t.shape[0] == 1 and os.environ.get("NVSF_DYNAMIC_FUSED", "1") != "0":
-            return self._dynamic_features_fused(x, t, t_host, frame_idx, hash_enc, planes_enc)
+            return self._dynamic_features_fused(x, t, t_host, frame_idx, hash_enc, planes_enc, fp16)
         t_col = t.repeat(x.shape[0], 1) if t.shape[0] == 1 else t
         xt = torch.cat([x, t_col], dim=-1)
         plane_s, plane_d = planes_enc(xt)
-        flow = self.flow_net(xt, t_host)
+        flow = self.flow_net(xt, t_host, fp16=fp16)
         fused3 = hash_enc.training_fused3(x, t, t_host, flow, frame_idx, self.num_frames)
         if fused3 is not None:
             hash_s = hash_enc.forward_static(x)
@@ -123,7 +125,7 @@ class NeRFNetwork(NeRFRenderer):
             hash_2, plane_2 = neighbour(flow[:, 3:], frame_idx - 1)
         return plane_s, plane_d, plane_1, plane_2, hash_s, hash_d, hash_1, hash_2
 
-    def _dynamic_features_fused(self, x, t, t_host, frame_idx, hash_enc, planes_enc):
+    def _dynamic_features_fused(self, x, t, t_host, frame_idx, hash_enc, planes_enc, fp16=None):
         """The no-autograd form of _dynamic_features: same values, fewer launches and temporaries -- the neighbour hash
         evaluations read `x + flow` inside the kernel instead of from an [M, 3] temporary, the neighbour time columns are
         written once.  (A single K-planes launch for all three positions that keeps the base evaluation's texel quads in
@@ -131,7 +133,7 @@ class NeRFNetwork(NeRFRenderer):
         gather latency, and the neighbours' re-gathers hit L1 anyway.)"""
         F = self.num_frames
         xt = torch.cat([x, t.float().expand(x.shape[0], 1)], dim=-1)
-        flow = self.flow_net(xt, t_host)
+        flow = self.flow_net(xt, t_host, fp16=fp16)
         hash_s = hash_enc.forward_static(x)
         nb = []
         for col, frame in ((0, frame_idx + 1), (3, frame_idx - 1)):
@@ -154,7 +156,8 @@ class NeRFNetwork(NeRFRenderer):
         return (plane_s, plane_d, plane_1, plane_2, hash_s, hash_d, hash_d if hash_1 is None else hash_1, hash_d if hash_2 is None else hash_2)
 
     def density(self, x, t=None, cal_lidar_color=False, **kwargs):
-        plane_s, plane_d, plane_1, plane_2, hash_s, hash_d, hash_1, hash_2 = self._dynamic_features(self._unit_cube(x), t, cal_lidar_color)
+        plane_s, plane_d, plane_1, plane_2, hash_s, hash_d, hash_1, hash_2 = self._dynamic_features(self._unit_cube(x), t, cal_lidar_color,
+                                                                                                     fp16=kwargs.get("fp16"))
         if not torch.is_grad_enabled():
             # fused tail (csrc/density_dynamic.hip): neighbour blend + concatenation + density MLP in one kernel
             h = self._density_tail_fused(plane_s, plane_d, plane_1, plane_2, hash_s, hash_d, hash_1, hash_2)
@@ -177,7 +180,7 @@ class NeRFNetwork(NeRFRenderer):
         never materialised (renderer_dynamic.NeRFRenderer.run dispatches here)."""
         N = rays_o.shape[0]
         z_vals, xyzs = ops.uniform_samples(rays_o, rays_d, nears, fars, T, aabb, noise)
-        feats = self._dynamic_features(self._unit_cube(xyzs.view(-1, 3)), time, cal_lidar_color)
+        feats = self._dynamic_features(self._unit_cube(xyzs.view(-1, 3)), time, cal_lidar_color, fp16=kwargs.get("fp16"))
         sigmas, geo = self._density_tail_fused(*feats, sigma_geo=True)
         weights, weights_sum, depth = ops.CompositeWeightsFn.apply(sigmas.view(N, T), z_vals, nears, fars, self._k_scale())
         if cal_lidar_color:

@@ -425,10 +425,15 @@ class PointsMeter:
         from nvsf.nerf.chamfer3D.dist_chamfer_3D import chamfer_3DDist
         p, t = (a.reshape(a.shape[-2], a.shape[-1]).float() / self.scale for a in (preds, truths))
         with torch.no_grad():
-            d1, d2, _, _ = chamfer_3DDist()(pano_to_lidar(p, self.intrinsics, self.intrinsics_hoz)[None],
-                                            pano_to_lidar(t, self.intrinsics, self.intrinsics_hoz)[None])
-            cd = d1.mean() + d2.mean()
-            f = fscore(d1, d2, self.threshold)[0][0]
+            cp, ct = pano_to_lidar(p, self.intrinsics, self.intrinsics_hoz), pano_to_lidar(t, self.intrinsics, self.intrinsics_hoz)
+            if cp.shape[0] == 0 or ct.shape[0] == 0:
+                # a cloud without points (e.g. every predicted pixel gated off by the ray-drop mask): the reference's means over
+                # an empty distance array are NaN and its F-score 0 / 0 -> 0 (error_matrices.py:12-26, 322-335)
+                cd, f = float("nan"), 0.0
+            else:
+                d1, d2, _, _ = chamfer_3DDist()(cp[None], ct[None])
+                cd = d1.mean() + d2.mean()
+                f = fscore(d1, d2, self.threshold)[0][0]
         self.V.append([float(cd), float(f)])
         self.N += 1
 

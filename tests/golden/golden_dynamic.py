@@ -175,6 +175,34 @@ def grad_signature(g):
             "nnz": np.int64(np.count_nonzero(g)), "top_idx": top.astype(np.int64), "top_val": g[top].astype(np.float32)}
 
 
+FRAGILE_TOL = 2e-3
+
+
+def fragile_rows(x, weights_f16, spec, tol=FRAGILE_TOL):
+    """Rows of a head's input whose gradient depends on a coin flip: a hidden unit with |pre-activation| <= tol.  The inputs of the
+    per-sample heads (geometry features = outputs of the density MLP) agree between two implementations of the specified fp16
+    arithmetic to a few 1e-4 (an fp16 rounding of a hidden activation of the density MLP that falls the other way), which moves a
+    head's pre-activations by up to ~1e-3; a ReLU whose pre-activation is closer to zero than that is "on" on one side and "off"
+    on the other, and the whole input gradient of that sample changes by several per cent of its largest entry.  `x` [M, n_in]
+    (any float dtype; the network sees it rounded to fp16), `weights_f16` the flat fp16 parameters; pre-activations in float64
+    from fp16-rounded operands and fp16-rounded hidden activations."""
+    mats = [m.double().numpy() for m in spec.split(torch.from_numpy(np.asarray(weights_f16, np.float16)))]
+    M = x.shape[0]
+    a = np.ones((M, spec.in_cols), np.float64)
+    a[:, :spec.n_in] = np.asarray(x, np.float32).astype(np.float16).astype(np.float64)
+    flag = np.zeros(M, bool)
+    for W in mats[:-1]:
+        p = a @ W.T
+        flag |= (np.abs(p) <= tol).any(1)
+        a = np.maximum(p, 0.0).astype(np.float16).astype(np.float64)
+    return flag
+
+
+def detach_rows(rgbs, rows):
+    """rgbs with the autograd path of the flagged rows cut (values unchanged): those samples' heads contribute no gradient."""
+    return torch.where(rows.view(-1, 1), rgbs.detach(), rgbs)
+
+
 def gen_network_grads(mods, out_dir):
     """Parameter gradients of the reference's own NeRFNetwork.render + Trainer losses (network_dynamic.py:213-332 under
     autograd: which neighbour terms carry gradient is decided by the reference's code, :242-271), LiDAR and camera batch at
@@ -193,15 +221,39 @@ def gen_network_grads(mods, out_dir):
             for p in net.parameters():
                 p.grad = None
             torch.rand = lambda *a, **k: torch.from_numpy(noise)  # renderer_dynamic.py:163-164 draws rand(z_vals.shape)
+            # The per-sample heads of the fragile rows (see fragile_rows) are cut out of the autograd graph -- in the reference's
+            # render here and, with the same stored row mask, in the GPU test: what is compared is then free of ReLU coin flips.
+            heads = (net.raydrop_net, net.intensity_net) if lidar else (net.color_net,)
+            seen, rows_box = [], {}
+            real_fwd = {h: h.forward for h in heads}
+            real_color = net.color
+
+            def color(x, dd, cal_lidar_color=False, mask=None, **kw):
+                for h in heads:  # record each head's input on its way in
+                    h.forward = (lambda hh: lambda inp: (seen.append((hh, inp.detach().float().numpy().copy())), real_fwd[hh](inp))[1])(h)
+                try:
+                    rgbs = real_color(x, dd, cal_lidar_color=cal_lidar_color, mask=mask, **kw)
+                finally:
+                    for h in heads:
+                        h.forward = real_fwd[h]
+                assert bool(mask.all()) and len(seen) == len(heads)  # every sample passes the weight threshold in these cases
+                rows = np.zeros(rgbs.shape[0], bool)
+                for h, inp in seen:
+                    rows |= fragile_rows(inp, h.params.detach().numpy().astype(np.float16), h.spec)
+                rows_box["rows"] = rows
+                return detach_rows(rgbs, torch.from_numpy(rows))
+            net.color = color
             try:
                 res = net.render(torch.from_numpy(o)[None], torch.from_numpy(d)[None], torch.tensor([[tv]], dtype=torch.float32),
                                  cal_lidar_color=lidar, num_steps=GRAD_T, perturb=True, staged=False)
             finally:
                 torch.rand = real_rand
+                net.color = real_color
             loss = reference_losses(res, torch.from_numpy(gt), lidar)
             loss.backward()
             key = f"{tag}_{'lidar' if lidar else 'cam'}"
             out[f"{key}/loss"] = np.float32(loss.item())
+            out[f"{key}/fragile_rows"] = rows_box["rows"]
             sfx = "_lidar" if lidar else ""
             out[f"{key}/image"], out[f"{key}/depth"] = res["image" + sfx][0].detach().numpy(), res["depth" + sfx][0].detach().numpy()
             n_with = 0
@@ -217,9 +269,75 @@ def gen_network_grads(mods, out_dir):
                 else:
                     out[f"{key}/grad/{name}"] = g
                 n_with += 1
-            print(key, "loss", float(loss), "tensors with gradient:", n_with)
+            print(key, "loss", float(loss), "tensors with gradient:", n_with, "fragile rows:", int(rows_box["rows"].sum()), "of", rows_box["rows"].size)
     np.savez_compressed(os.path.join(out_dir, "network_dynamic_grads.npz"), **out)
     print("network_dynamic_grads.npz", len(out), "arrays")
 
 
-GENERATORS = {"planes": gen_planes, "hash4d": gen_hash4d, "network": gen_network, "network_grads": gen_network_grads}
+# ---- BASELINE config 5 at its stated size: the model main_nvsf.py trains -------------------------------------------------------
+# network_dynamic.py:16-23 + main_nvsf.py:45-52 defaults (L8 F4 T2^19 all levels hashed, base 512 -> max 32768, planes 4 scales of 32,
+# flow grid L16 F8 T2^18) with time_resolution 8 (main_nvsf.py:47) and num_frames 64 (configs/kitti360_1908.txt): 93.6 M parameters.
+RD = dict(time_resolution=8, num_frames=64, bound=2)
+RD_N, RD_T = 24, 768
+RD_TIMES = (("first", 0.0), ("mid", 0.5), ("last", 1.0))
+RD_FLOWS = (("still", 1e-8), ("moving", 8e-4))  # target mean |flow| (unit cube): ~static scene / every sample displaced by ~25 finest cells
+
+
+def rd_rays(tag, lidar, synth):
+    rng = np.random.default_rng(zlib.crc32(f"rd/{tag}/{int(lidar)}".encode()) % 100000)
+    return (synth.lidar_rays if lidar else synth.camera_rays)(RD_N, rng)
+
+
+def rd_set_flow_gain(net, gain):
+    """Scales the last (bias-free, linear) layer of the flow MLP: the flow is linear in it."""
+    last = [m for m in net.flow_net.mlp if isinstance(m, torch.nn.Linear)][-1]
+    with torch.no_grad():
+        last.weight.mul_(float(gain))
+
+
+def gen_network_rd(mods, out_dir):
+    """The reference's own NeRFNetwork at its default size on CPU (`tinycudann` := tcnn_cpu_spec): LiDAR and camera renders of
+    RD_N rays x 768 samples at the first / a middle / the last frame, once with ~zero scene flow (the neighbour-frame evaluations
+    fall into the base evaluation's cells: k_hash_dynamic3's re-use branch) and once with |flow| ~ 8e-4 (every level re-gathers).
+    Stored: rays, flow gains and the renders -- parameters come from init_by_name."""
+    import sys
+    import time as _time
+    S = sys.modules["make_golden_synth"]
+    nd = mods["network"]
+    t0 = _time.time()
+    net = nd.NeRFNetwork(min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH, **RD).eval()
+    init_by_name(net)
+    print("reference NeRFNetwork (defaults):", sum(p.numel() for p in net.parameters()) / 1e6, "M parameters,", round(_time.time() - t0, 1), "s")
+    out = {}
+    rng = np.random.default_rng(77)
+    probe = torch.from_numpy(rng.uniform(-1.9, 1.9, (4096, 3)).astype(np.float32))
+    with torch.no_grad():
+        base = float(net.flow(probe, torch.tensor([[0.5]]))["flow_forward"].abs().mean())
+    gain_now = 1.0
+    for ftag, target in RD_FLOWS:
+        gain = target / base
+        rd_set_flow_gain(net, gain / gain_now)
+        gain_now = gain
+        out[f"flow_gain_{ftag}"] = np.float64(gain)
+        with torch.no_grad():
+            out[f"mean_abs_flow_{ftag}"] = np.float32(net.flow(probe, torch.tensor([[0.5]]))["flow_forward"].abs().mean())
+        for tag, tv in RD_TIMES:
+            for lidar in (True, False):
+                o, d = rd_rays(tag, lidar, S)
+                t1 = _time.time()
+                with torch.no_grad():
+                    res = net.render(torch.from_numpy(o)[None], torch.from_numpy(d)[None], torch.tensor([[tv]], dtype=torch.float32),
+                                     cal_lidar_color=lidar, num_steps=RD_T)
+                sfx = "_lidar" if lidar else ""
+                key = f"{ftag}/{tag}/{'lidar' if lidar else 'cam'}"
+                out[key + "/image"], out[key + "/depth"] = res["image" + sfx][0].numpy(), res["depth" + sfx][0].numpy()
+                out[key + "/weights_sum"] = res["weights_sum" + sfx].numpy()
+                if tag == "mid":
+                    out[key + "/weights"] = res["weights"].numpy().astype(np.float16)  # for locating a difference, not for the bar
+                print(key, "ws", float(res["weights_sum" + sfx].mean()), round(_time.time() - t1, 1), "s")
+    np.savez_compressed(os.path.join(out_dir, "network_dynamic_rd.npz"), **out)
+    print("network_dynamic_rd.npz", len(out), "arrays")
+
+
+GENERATORS = {"planes": gen_planes, "hash4d": gen_hash4d, "network": gen_network, "network_grads": gen_network_grads,
+              "network_rd": gen_network_rd}

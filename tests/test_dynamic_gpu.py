@@ -118,13 +118,13 @@ def test_hashgrid4d_and_flow(dev):
     torch.set_grad_enabled(True)
     np.testing.assert_allclose(out.cpu().numpy(), g["flow"], atol=1e-5, rtol=1e-4)
     # opt-in fp16 MFMA form of the flow MLP (what autocast computes in the reference's Trainer): fp16-level agreement
-    os.environ["NVSF_FLOW_MLP"] = "fused"
-    try:
-        with torch.no_grad():
-            out16 = flow(_t(g["flow_xt"], dev))
-    finally:
-        del os.environ["NVSF_FLOW_MLP"]
-    assert out16.shape == out.shape
+    with torch.no_grad():
+        out16 = flow(_t(g["flow_xt"], dev), fp16=True)  # the reference's --fp16 regime, per call
+        with torch.autocast("cuda", dtype=torch.float16):  # ... or through the Trainer's autocast region (trainer.py:1318, 1491)
+            out_ac = flow(_t(g["flow_xt"], dev))
+        out_off = flow(_t(g["flow_xt"], dev), fp16=False)
+    assert out16.shape == out.shape and torch.equal(out16, out_ac) and torch.equal(out_off, out)
+    assert not torch.equal(out16, out)
     np.testing.assert_allclose(out16.cpu().numpy(), g["flow"], atol=1e-4, rtol=1e-2)
 
 
@@ -244,9 +244,9 @@ def test_flow_grid_training_path_equals_the_operator_path(dev, monkeypatch):
     xt = torch.cat([torch.rand(7000, 3, generator=torch.Generator().manual_seed(3)), torch.full((7000, 1), 0.43)], -1).to(dev)
     res = {}
     for mode in ("fused", "ops"):
-        monkeypatch.setenv("NVSF_FLOW_GRID_TRAIN", mode)
         torch.manual_seed(6)
         flow = FlowField(n_levels=16, n_features_per_level=8, base_resolution=32, max_resolution=1024, log2_hashmap_size=13).to(dev)
+        flow.grid_train_mode = mode  # test-only switch: "ops" = encoder -> .float() -> lagrange_reduce under plain autograd
         with torch.no_grad():
             flow.grid_enc.params.uniform_(-0.5, 0.5)
             flow.mlp[-1].weight.normal_(0, 0.2)
@@ -368,6 +368,9 @@ def test_host_time_cache_follows_the_tensor_object(dev):
 
 
 GRAD_KEYS = [f"{tag}_{mod}" for tag, _ in GD.GRAD_CASES for mod in ("lidar", "cam")]
+# bars of test_training_graph_gradients_match_reference, relative to each tensor's largest entry (max, median over the tensors of
+# the max) and to its L2 norm; SIG_ERR: norms / bucket sums / largest entries of the flow grid's 30 M-entry gradient
+MAX_ERR, L2_ERR, MED_ERR, SIG_ERR = 2e-3, 1.5e-3, 6e-4, 5e-3  # measured on MI355X: worst 8.7e-4 / 7.0e-4 / 3.5e-4
 
 
 @pytest.mark.parametrize("key", GRAD_KEYS)
@@ -379,16 +382,18 @@ def test_training_graph_gradients_match_reference(dev, net, key):
     (golden_dynamic.reference_losses = trainer.py:186-219, 491-503, 540-543).
 
     Tolerances.  Forward (image, depth) 1e-4 abs.  The same parameters must receive a gradient, with the same sparsity.
-    Gradients: the MLPs are ReLU networks with fp16 activations, so a hidden unit whose pre-activation lies within fp16
-    rounding of zero is "on" in one implementation and "off" in the other (measured on the mid_cam case: colour head,
-    sample 72, layer 2, unit 46, pre-activation +4.0e-5 in exact arithmetic, 0 after the fp16 rounding of layer 1 -- the CPU
-    specification and a plain fp32 torch MLP on the same inputs disagree by 7 % of the largest entry of dL/dgeo on that
-    sample while all other samples agree to 1e-4).  Such flips are inherent to tiny-cuda-nn style arithmetic (any two
-    summation orders differ that way); with 768 samples per case a handful of them move a parameter gradient by up to a few
-    per cent of its largest entry.  Hence: relative L2 error <= 2 % and max error <= 6 % of the largest entry for every
-    tensor, AND the median over the tensors of the max error <= 1e-3 for the LiDAR cases (whose gradients are dominated by
-    the range loss, which reaches the parameters through sigma, not through the heads) / 2e-2 for the camera cases (every
-    gradient passes the colour head)."""
+    Gradients.  The MLPs are ReLU networks with fp16 activations.  The geometry features that enter the per-sample heads agree
+    between this implementation and the CPU specification to a few 1e-4 (measured: max 4e-4 -- an fp16 rounding of a hidden
+    activation of the density MLP that falls the other way), which moves a head's pre-activations by up to ~1e-3; a hidden unit
+    whose pre-activation is closer to zero than that is "on" on one side and "off" on the other, and that sample's whole head
+    gradient changes by several per cent (measured on mid_cam: dL/dgeo differs by 7 % of its largest entry on one such sample,
+    1.4 % in L2 over the batch, while dL/dsigma and dL/drgb agree to 2e-4; replacing nvsf_mlp_bwd by the exact fp64 chain rule
+    leaves these figures unchanged: tools/diag_grad_camera.py, tools/diag_grad_inter.py).  So that the comparison cannot hide a
+    real error behind that noise, the fixture stores for every case the rows with a head pre-activation within 2e-3 of zero
+    (golden_dynamic.fragile_rows, evaluated on the reference side) and BOTH sides cut the heads of exactly those rows out of
+    the autograd graph (golden_dynamic.detach_rows around `color`: values unchanged).  What remains -- about half of the rows
+    through the heads, every row through sigma -- is free of coin flips and must agree to the bars below for LiDAR and camera
+    cases alike."""
     import copy
     from nvsf import synthetic as S
     g = np.load(os.path.join(GOLD, "network_dynamic_grads.npz"))
@@ -400,11 +405,16 @@ def test_training_graph_gradients_match_reference(dev, net, key):
     noise_dev = _t(noise, dev)
     real_rand = torch.rand
     torch.rand = lambda *a, **k: noise_dev
+    rows = torch.from_numpy(g[f"{key}/fragile_rows"]).to(dev)
+    assert 0.2 < float(rows.float().mean()) < 0.7  # the comparison keeps a substantial share of the rows through the heads
+    real_color = m.color
+    m.color = lambda *a, **k: GD.detach_rows(real_color(*a, **k), rows)
     try:
         out = m.render(_t(o, dev)[None], _t(d, dev)[None], torch.tensor([[tv]], dtype=torch.float32, device=dev), cal_lidar_color=lidar,
                        num_steps=GD.GRAD_T, perturb=True, staged=False)
     finally:
         torch.rand = real_rand
+        m.color = real_color
     loss = GD.reference_losses(out, _t(gt, dev), lidar)
     sfx = "_lidar" if lidar else ""
     np.testing.assert_allclose(out["image" + sfx][0].detach().cpu().numpy(), g[f"{key}/image"], atol=1e-4, rtol=0)
@@ -429,16 +439,16 @@ def test_training_graph_gradients_match_reference(dev, net, key):
             assert float(np.abs(mine[ref == 0]).max(initial=0.0)) <= 1e-4 * scale, name
     med = float(np.median(list(emax.values())))
     print(key, "median max-err", med, "worst max-err", max(emax.items(), key=lambda kv: kv[1]), "worst L2", max(el2.items(), key=lambda kv: kv[1]))
-    bad = {n: (emax[n], el2[n]) for n in emax if emax[n] > 6e-2 or el2[n] > 2e-2}
+    bad = {n: (emax[n], el2[n]) for n in emax if emax[n] > MAX_ERR or el2[n] > L2_ERR}
     assert not bad, bad
-    assert med <= (1e-3 if lidar else 2e-2), med
+    assert med <= MED_ERR, med
     for name in sorted(sigs):  # the flow field's 30 M-entry grid: fingerprint (bucket sums, norms, largest entries)
         mine = params[name].grad.detach().double().cpu().numpy().reshape(-1)
         sig = GD.grad_signature(mine)
         ref = {k: g[f"{key}/gradsig/{name}/{k}"] for k in ("buckets", "l1", "l2", "nnz", "top_idx", "top_val")}
-        tol = 2e-3 if lidar else 3e-2
+        tol = SIG_ERR
         assert abs(float(sig["l2"]) - float(ref["l2"])) <= tol * float(ref["l2"]) and abs(float(sig["l1"]) - float(ref["l1"])) <= tol * float(ref["l1"])
-        btol = 2e-3 if lidar else 1e-1  # individual sums: the camera cases carry the ReLU-flip noise described above
+        btol = SIG_ERR
         np.testing.assert_allclose(sig["buckets"], ref["buckets"], atol=btol * float(np.abs(ref["buckets"]).max()), rtol=0)
         np.testing.assert_allclose(mine[ref["top_idx"]], ref["top_val"], atol=btol * float(np.abs(ref["top_val"]).max()), rtol=0)
         # the reference's feature gradients are fp16 tensors: entries whose every contribution lies below 6e-8 are exactly zero
