@@ -75,7 +75,7 @@ int nvsf_march_rays_train(const float* rays_o, const float* rays_d, const uint8_
  * keeps the sample masks of its batches on chip; worker workgroups publish the sum of each ticket of four rays, one scanner wave
  * turns the sums into exclusive prefixes in ticket order, and each ticket is stored while the next one is counted.  Same
  * arguments, same outputs bit for bit (ray-index order), plus a caller-owned scratch `workspace` of at least
- * nvsf_march_rays_train_ws_bytes(N) bytes (16 bytes per four rays), 8-byte aligned, contents irrelevant on entry (it is cleared on
+ * nvsf_march_rays_train_ws_bytes(N) bytes (1 KB + 16 bytes per four rays), 8-byte aligned, contents irrelevant on entry (it is cleared on
  * the stream first) and meaningless afterwards.  The reference's signature (raymarching.h:27-44) has no scratch argument, hence
  * the separate entry point; nvsf_march_rays_train stays the reference-shaped one.
  * counter[1] < 0 after the call (its sign bit set) marks a launch whose bounded inter-workgroup wait expired (outputs invalid; the

@@ -1060,7 +1060,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 4))) 
     const float dd[3] = {rd0, rd1, rd2};
     Marcher m;
     m.init(o3, dd, rr.grid, rr.bound, rr.dt_gamma, rr.max_steps, rr.C, rr.H);
-    if (rr.H <= kLutH) m.lut = s_lut;
+    if (rr.H <= kLutH) m.use_lut(s_lut);
     const float far = rr.fars[n];
     float t = rr.nears[n];
     float last_t = t, t_comp = t;

@@ -33,11 +33,14 @@ struct Marcher {
     float bound, rbound, dt_gamma, dt_min, dt_max, rH, H3, Hf, Hm1, Cf;
     float halfH;               // 0.5 * H (exact)
     float dt_const;            // the step when dt_gamma == 0 (then every member has the same step and dt-level)
+    float rdt_const;           // ~1 / dt_const when dt_gamma == 0, else 0 (a guess that is always verified: ChainWalker::walk_parallel)
     int l1_const;
     int Cm1;                   // C - 1
     uint32_t H3i;              // H^3 when the cell index level * H^3 + morton is exact in integers AND in fp32 (all values < 2^24), else 0
     const uint8_t* grid;
-    const uint32_t* lut;       // optional LDS table lut[v] = spread3(v), v < H (fill_spread_lut); nullptr: computed
+    const uint32_t* lut;       // optional LDS table lut[v] = spread3(v), v < H (fill_spread_lut)
+    bool lut_on;               // set together with `lut` (use_lut): a literal at every call site, so the choice folds at compile time --
+                               // a test of the pointer itself does not (three branches and three serialised LDS reads per batch)
 
     __device__ __forceinline__ void init(const float* o, const float* d, const uint8_t* g, float bound_, float dt_gamma_,
                                          uint32_t max_steps, uint32_t C, uint32_t H) {
@@ -59,8 +62,10 @@ struct Marcher {
         while (side < H) side <<= 1;  // morton codes of coordinates < H stay below side^3
         H3i = (unsigned long long)(C - 1) * H * H * H + (unsigned long long)side * side * side <= (1ull << 24) ? H * H * H : 0u;
         dt_const = step_len(0.0f);
+        rdt_const = dt_gamma == 0.0f ? __builtin_amdgcn_rcpf(dt_const) : 0.0f;
         l1_const = dt_level(dt_const);
         lut = nullptr;
+        lut_on = false;
     }
     // What replaying recorded batches needs (positions, step lengths, fill_batch): no inverse directions, no cell constants.
     __device__ __forceinline__ void init_replay(const float* o, const float* d, float bound_, float dt_gamma_, uint32_t max_steps, uint32_t C,
@@ -73,6 +78,7 @@ struct Marcher {
         dt_max = 2.0f * kSqrt3 * (float)(1 << (C - 1)) / Hf;
         dt_const = step_len(0.0f);
         lut = nullptr;
+        lut_on = false;
     }
     __device__ __forceinline__ int dt_level(float dt) const {
         int e1;
@@ -88,7 +94,8 @@ struct Marcher {
         const int l1 = dt_gamma == 0.0f ? l1_const : dt_level(dt);  // wave-uniform choice
         return l0 > l1 ? l0 : l1;
     }
-    __device__ __forceinline__ uint32_t spread(uint32_t v) const { return lut ? lut[v] : spread3(v); }
+    __device__ __forceinline__ void use_lut(const uint32_t* table) { lut = table; lut_on = true; }
+    __device__ __forceinline__ uint32_t spread(uint32_t v) const { return lut_on ? lut[v] : spread3(v); }
     // The parameters visited along a ray form ONE chain t_{k+1} = t_k + step_len(t_k), whether a step is taken because a
     // sample was emitted or while skipping an empty cell (probe() below: both add step_len(t)); next() is its recurrence.
     __device__ __forceinline__ float next(float t) const {
@@ -296,7 +303,7 @@ struct ChainWalker {
                 if (j >= nb) continue;
             }
             unsigned long long S = 0ull;
-            if (serial || !walk_parallel(far, lane, S)) S = walk_serial(far);
+            if (serial || !walk_parallel(far, lane, S, m.rdt_const)) S = walk_serial(far);
             if (S) {
                 if ((uint32_t)__builtin_popcountll(S) > max_n) {
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(S >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)S, 0u));
@@ -333,7 +340,8 @@ struct ChainWalker {
         return S;
     }
     // returns false (state untouched) when the batch needs the serial walk
-    __device__ __forceinline__ bool walk_parallel(float far, int lane, unsigned long long& S) {
+    // rdt: 1 / step when the step is the same for every member (dt_gamma == 0), else 0
+    __device__ __forceinline__ bool walk_parallel(float far, int lane, unsigned long long& S, float rdt) {
         const int j0 = __builtin_amdgcn_readfirstlane(j);
         const unsigned long long bm = batch_mask();
         const unsigned long long active = bm & (~0ull << j0);
@@ -353,15 +361,33 @@ struct ChainWalker {
         uint32_t nxt = stopper ? 255u : 0u;
         if (__ballot(empty && !stopper)) {
             // cnt = number of batch members below this lane's exit parameter (bt is non-decreasing along the batch)
-            const float last = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bt), nb - 1));
-            int lo = 0;
-#pragma unroll
-            for (int step = 32; step >= 1; step >>= 1) {
-                const int probe = lo + step - 1;
-                const float v = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(probe << 2, __builtin_bit_cast(int, bt)));
-                if (probe < nb && v < bexit) lo += step;
+            int cnt = 0;
+            bool found = false;
+            if (rdt > 0.0f) {
+                // Constant step c: member k sits within rounding of bt + (k - lane) c, so the first member at or beyond the exit is
+                // guessed as k* = lane + ceil((bexit - bt) / c) and CHECKED against the members themselves, bt[k* - 1] < bexit <=
+                // bt[k*] (two independent cross-lane reads instead of six dependent ones); any lane whose guess fails sends the
+                // wave to the search below, so the result is the search's in every case.
+                const float e = ceilf((bexit - bt) * rdt);
+                int k = lane + (int)fminf(fmaxf(e, -64.0f), 128.0f);
+                k = k < 0 ? 0 : (k > nb ? nb : k);
+                const float below = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((k > 0 ? k - 1 : 0) << 2, __builtin_bit_cast(int, bt)));
+                const float at = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((k < nb ? k : nb - 1) << 2, __builtin_bit_cast(int, bt)));
+                const bool ok = (k == 0 || below < bexit) && (k == nb || !(at < bexit));
+                cnt = k;
+                found = !__ballot(empty && !stopper && !ok);
             }
-            const int cnt = last < bexit ? nb : lo;
+            if (!found) {
+                const float last = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bt), nb - 1));
+                int lo = 0;
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1) {
+                    const int probe = lo + step - 1;
+                    const float v = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(probe << 2, __builtin_bit_cast(int, bt)));
+                    if (probe < nb && v < bexit) lo += step;
+                }
+                cnt = last < bexit ? nb : lo;
+            }
             const int jump = cnt > lane + 1 ? cnt : lane + 1;
             if (empty && !stopper) nxt = (uint32_t)jump;
         }

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(kBlock) void k_march_count_wave(const float* __rest
     const int lane = lane_id();
     Marcher m;
     m.init(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, grid, bound, dt_gamma, max_steps, C, H);
-    m.lut = s_lut;
+    m.use_lut(s_lut);
     const float far = fars[n];
     float t = nears[n];
     t += m.step_len(t) * noises[n];
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void k_march_write_wave(const float* __rest
     if (count == 0 || offset + count > M) return;
     Marcher m;
     m.init(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, grid, bound, dt_gamma, max_steps, C, H);
-    m.lut = s_lut;
+    m.use_lut(s_lut);
     const float far = fars[n];
     float t = nears[n];
     t += m.step_len(t) * noises[n];
@@ -227,7 +227,7 @@ __global__ __launch_bounds__(kBlock) void k_march_write_wave(const float* __rest
 // written by a single agent-scope atomic store and read by agent-scope atomic loads -- no other data crosses workgroups.  Every
 // spin is bounded (kMarchSpinLimit polls); on a timeout the launch still terminates and reports through counter[1] < 0.
 constexpr int kMarchRecCap = 24;  // records per ray kept in LDS; a ray with more sample-bearing batches re-marches when writing
-constexpr int kMarchBtCap = 8;    // batches per ray whose member parameters stay in LDS (the others come from Marcher::fill_batch again)
+// (template parameter BT) batches per ray whose member parameters stay in LDS; the others come from Marcher::fill_batch again
 constexpr int kMarchRays = kBlock / kWave;  // rays per ticket: one per wave
 constexpr uint32_t kMarchSpinLimit = 1u << 22;
 struct MarchRec { float t0; uint32_t nb; unsigned long long S; };
@@ -277,9 +277,10 @@ __device__ __forceinline__ void march_store_batch(const MarchDirs& dv, float bt,
 }
 
 // Everything a wave keeps of a ray between its count and its stores (two per wave: one being counted, one waiting for its range)
+template <int BT>
 struct MarchRayLds {
     MarchRec rec[kMarchRecCap];
-    float bt[kMarchBtCap][kWave];
+    float bt[BT][kWave];
 };
 
 __device__ __forceinline__ float march_t_start(const Marcher& m, const float* __restrict__ nears, const float* __restrict__ noises, uint32_t n) {
@@ -288,13 +289,14 @@ __device__ __forceinline__ float march_t_start(const Marcher& m, const float* __
 }
 
 // wave = ray n: count it once; remember the sample-bearing batches
-__device__ __forceinline__ void march_count_ray(MarchRayLds& L, int lane, uint32_t n, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
+template <int BT>
+__device__ __forceinline__ void march_count_ray(MarchRayLds<BT>& L, int lane, uint32_t n, const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                 const uint8_t* __restrict__ grid, float bound, float dt_gamma, uint32_t max_steps, uint32_t C,
                                                 uint32_t H, const uint32_t* lut, const float* __restrict__ nears, const float* __restrict__ fars,
                                                 const float* __restrict__ noises, int serial, uint32_t& count, uint32_t& nrec) {
     Marcher m;
     m.init(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, grid, bound, dt_gamma, max_steps, C, H);
-    m.lut = lut;
+    m.use_lut(lut);
     const float far = fars[n];
     ChainWalker w;
     w.init(march_t_start(m, nears, noises, n));
@@ -308,15 +310,15 @@ __device__ __forceinline__ void march_count_ray(MarchRayLds& L, int lane, uint32
             r.t0 = w.t_batch; r.nb = (uint32_t)w.nb; r.S = S;
             L.rec[nrec] = r;
         }
-        if (nrec < (uint32_t)kMarchBtCap) L.bt[nrec][lane] = w.bt;
+        if (nrec < (uint32_t)BT) L.bt[nrec][lane] = w.bt;
         ++nrec;
         count += (uint32_t)__builtin_popcountll(S);
     }
 }
 
 // wave = ray n, whose `count` samples start at `offset`: write rays[n] and replay the records into the sample arrays
-template <bool OFF32>
-__device__ __forceinline__ void march_store_ray(const MarchRayLds& L, uint32_t offset, uint32_t count, uint32_t nrec, int lane, uint32_t n, uint32_t M,
+template <bool OFF32, int BT>
+__device__ __forceinline__ void march_store_ray(const MarchRayLds<BT>& L, uint32_t offset, uint32_t count, uint32_t nrec, int lane, uint32_t n, uint32_t M,
                                                 const float* __restrict__ rays_o, const float* __restrict__ rays_d,
                                                 const uint8_t* __restrict__ grid, float bound, float dt_gamma, uint32_t max_steps, uint32_t C,
                                                 uint32_t H, const uint32_t* lut, const float* __restrict__ nears, const float* __restrict__ fars,
@@ -342,7 +344,7 @@ __device__ __forceinline__ void march_store_ray(const MarchRayLds& L, uint32_t o
             const unsigned long long S = ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(rec.S >> 32)) << 32) |
                                          (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)rec.S);
             float bt;
-            if (r < (uint32_t)kMarchBtCap) {
+            if (r < (uint32_t)BT) {
                 bt = L.bt[r][lane];
             } else {
                 float tn;
@@ -362,7 +364,7 @@ __device__ __forceinline__ void march_store_ray(const MarchRayLds& L, uint32_t o
         }
     } else {  // more sample-bearing batches than LDS records: march again, as the three-launch write pass does
         m.init(rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, grid, bound, dt_gamma, max_steps, C, H);
-        m.lut = lut;
+        m.use_lut(lut);
         const float far = fars[n];
         ChainWalker w;
         w.init(t_start);
@@ -426,26 +428,52 @@ __device__ __forceinline__ void march_scanner(const unsigned long long* sums, un
     }
 }
 
-template <bool OFF32>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_march_train_onepass(
-    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid, float bound, float dt_gamma,
+// Tickets come from kMarchQueues counters, each on a cache line of its own, instead of one: a returning atomic add on ONE
+// address is served at ~90 per microsecond chip-wide (MI355X_MICROARCH.md, price list: dequeue), which 8192 tickets drawn by ~1500
+// workgroups run into (each draw sits in front of the workgroup's barrier).  Queue q hands out tickets q, q + Q, q + 2Q, ...; a
+// workgroup starts at queue blockIdx % Q -- with the round-robin placement of workgroups that is one queue per XCD and an equal
+// number of workgroups per queue -- and moves on to the next queue when its own is exhausted, so every ticket is drawn exactly
+// once, by a running workgroup (the scanner's frontier is the slowest queue's; the queues advance at the same rate).
+// Measured (32 768 rays x 1024 steps, one box): one counter 0.203 / 0.216 ms (dense / 10 % grid), 8 queues 0.191 / 0.205, 16 queues
+// 0.185 / 0.210, 32 queues 0.197 / 0.223 (fewer workgroups per queue: the queues drift apart); with 128-step rays -- two batches
+// per ray, nothing but the scaffolding -- 0.129 -> 0.082 ms.
+constexpr uint32_t kMarchQueues = 8;
+constexpr uint32_t kMarchHeadWords = 16 * kMarchQueues;   // 8-byte words in front of the flags: one 128-byte line per queue
+__device__ __forceinline__ uint32_t march_draw_ticket(unsigned int* heads, uint32_t n_tickets) {
+    const uint32_t q0 = blockIdx.x % kMarchQueues;
+    for (uint32_t k = 0; k < kMarchQueues; ++k) {
+        const uint32_t q = (q0 + k) % kMarchQueues;
+        const unsigned long long b = (unsigned long long)atomicAdd(&heads[32u * q], 1u) * kMarchQueues + q;
+        if (b < n_tickets) return (uint32_t)b;
+    }
+    return 0xFFFFFFFFu;  // every queue is exhausted
+}
+
+// PLAIN: dt_gamma == 0 and the batch-parallel walk -- the reference's defaults -- are compile-time facts of the instance: the
+// step-length recurrences, the per-member dt-level and the serial-walk switch fold away (fewer instructions and fewer live scalars).
+template <bool OFF32, bool PLAIN, int BT>
+__device__ __forceinline__ void march_train_onepass_body(
+    const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid, float bound, float dt_gamma_arg,
     uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* __restrict__ nears, const float* __restrict__ fars,
     const float* __restrict__ noises, int* __restrict__ rays, int* __restrict__ counter, unsigned long long* __restrict__ ws,
-    float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas, int serial, uint32_t spin_limit) {
+    float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas, int serial_arg, uint32_t spin_limit) {
+    const float dt_gamma = PLAIN ? 0.0f : dt_gamma_arg;
+    const int serial = PLAIN ? 0 : serial_arg;
     const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
     const uint32_t n_tickets = (N + (uint32_t)kMarchRays - 1u) / (uint32_t)kMarchRays;
-    unsigned int* ticket = reinterpret_cast<unsigned int*>(ws);
-    unsigned long long* sums = ws + 1;
-    unsigned long long* prefix = ws + 1 + n_tickets;
+    unsigned int* heads = reinterpret_cast<unsigned int*>(ws);
+    unsigned long long* sums = ws + kMarchHeadWords;
+    unsigned long long* prefix = ws + kMarchHeadWords + n_tickets;
     if (blockIdx.x == 0) {
         if (wid == 0) march_scanner(sums, prefix, n_tickets, N, lane, counter, spin_limit);
         return;
     }
     extern __shared__ uint32_t s_lut[];  // H entries
-    __shared__ MarchRayLds s_ray[kMarchRays][2];
-    __shared__ uint32_t s_cnt[2][kMarchRays], s_next[2];  // by parity of the iteration: written before its barrier, read right after it
+    __shared__ MarchRayLds<BT> s_ray[kMarchRays][2];
+    __shared__ uint32_t s_cnt[2][kMarchRays], s_next[2], s_arrived[2];  // by parity of the iteration: written before its barrier, read right after it
     fill_spread_lut(s_lut, H);
-    if (threadIdx.x == 0) s_next[1] = atomicAdd(ticket, 1u);  // ticket = position in the scan
+    if (threadIdx.x < 2) s_arrived[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) s_next[1] = march_draw_ticket(heads, n_tickets);  // ticket = position in the scan
     __syncthreads();
     uint32_t b = s_next[1];
     int cur = 0;
@@ -457,11 +485,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         uint32_t count = 0, nrec = 0, before = 0;
         if (have) {
             if (n < N)
-                march_count_ray(s_ray[wid][cur], lane, n, rays_o, rays_d, grid, bound, dt_gamma, max_steps, C, H, s_lut, nears, fars, noises, serial, count, nrec);
+                march_count_ray<BT>(s_ray[wid][cur], lane, n, rays_o, rays_d, grid, bound, dt_gamma, max_steps, C, H, s_lut, nears, fars, noises, serial, count, nrec);
             if (lane == 0) s_cnt[cur][wid] = count;
             // the next ticket is drawn late: the scanner works in ticket order, and a ticket drawn long before it is counted holds
-            // everybody's ranges back (drawn before the count: 0.274 ms instead of 0.25)
-            if (threadIdx.x == 0) s_next[cur] = atomicAdd(ticket, 1u);
+            // everybody's ranges back (drawn before the count: 0.274 ms instead of 0.25) -- by the wave that finishes its ray FIRST, so
+            // that the draw's round trip runs while the other rays of the ticket are still being counted
+            if (lane == 0 && atomicAdd(&s_arrived[cur], 1u) == 0u) {
+                s_next[cur] = march_draw_ticket(heads, n_tickets);
+                s_arrived[cur ^ 1] = 0u;  // the other parity's counter: last used before the previous barrier, next used after this one
+            }
             __syncthreads();  // one barrier per ticket: the four counts -> the ticket's sum and every wave's place inside the ticket
             uint32_t sum = 0;
 #pragma unroll
@@ -487,7 +519,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
             if (status != 1u) {
                 if (lane == 0) atomicOr(reinterpret_cast<unsigned int*>(counter + 1), 0x80000000u);
             } else if (pend_n < N) {
-                march_store_ray<OFF32>(s_ray[wid][cur ^ 1], excl + pend_before, pend_count, pend_nrec, lane, pend_n, M, rays_o, rays_d, grid, bound, dt_gamma,
+                march_store_ray<OFF32, BT>(s_ray[wid][cur ^ 1], excl + pend_before, pend_count, pend_nrec, lane, pend_n, M, rays_o, rays_d, grid, bound, dt_gamma,
                                        max_steps, C, H, s_lut, nears, fars, noises, rays, xyzs, dirs, deltas, serial);
             }
         }
@@ -502,6 +534,24 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         cur ^= 1;
     }
 }
+
+#define NVSF_MARCH_ONEPASS_KERNEL(NAME, WAVES, BT)                                                                                                  \
+    template <bool OFF32, bool PLAIN>                                                                                                       \
+    __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void NAME(                                     \
+        const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid, float bound, float dt_gamma,  \
+        uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* __restrict__ nears,                                \
+        const float* __restrict__ fars, const float* __restrict__ noises, int* __restrict__ rays, int* __restrict__ counter,                \
+        unsigned long long* __restrict__ ws, float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas, int serial,    \
+        uint32_t spin_limit) {                                                                                                              \
+        march_train_onepass_body<OFF32, PLAIN, BT>(rays_o,       rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, noises, rays,     \
+                                               counter, ws, xyzs, dirs, deltas, serial, spin_limit);                                        \
+    }
+// Six waves per SIMD: 80 registers hold the marcher's state without spills (at eight waves = 64 registers, 12-14 of them went to
+// scratch, whose loads and stores queue behind the sample stores on the wave's memory counter), and six workgroups per compute
+// unit leave LDS for the member parameters of 11 batches per ray (a camera ray through a full grid has ~12).  Measured (32 768
+// rays x 1024 steps, dense grid): 0.233 -> 0.211 ms.
+constexpr uint32_t kMarchWgPerCu = 6;
+NVSF_MARCH_ONEPASS_KERNEL(k_march_train_onepass, 6, 11)
 
 // pass 2: one workgroup; exclusive scan of the counts in ray order, reserving [counter[0], +total).
 // A thread takes kScanPer consecutive rays per round (4096 rays per round: one round at the BASELINE batch size).
@@ -930,7 +980,7 @@ NVSF_API int nvsf_march_rays_train(const float* rays_o, const float* rays_d, con
     return nvsf_launch_status();
 }
 
-// compute units of the current device (one process drives one GPU): the persistent launch below fills each with 8 workgroups
+// compute units of the current device (one process drives one GPU): the persistent launch below fills each with kMarchWgPerCu workgroups
 static int march_cu_count() {
     static const int n = [] {
         int dev = 0, v = 0;
@@ -940,8 +990,8 @@ static int march_cu_count() {
     return n;
 }
 
-// ticket counter + {sum, exclusive prefix} flag per ticket of kMarchRays rays
-NVSF_API size_t nvsf_march_rays_train_ws_bytes(uint32_t N) { return 8u * (size_t)(1u + 2u * cdiv(N, (uint32_t)kMarchRays)); }
+// ticket queue heads (one 128-byte line each) + {sum, exclusive prefix} flag per ticket of kMarchRays rays
+NVSF_API size_t nvsf_march_rays_train_ws_bytes(uint32_t N) { return 8u * (size_t)(kMarchHeadWords + 2u * cdiv(N, (uint32_t)kMarchRays)); }
 
 NVSF_API int nvsf_march_rays_train_ws(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
                                       uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
@@ -954,9 +1004,11 @@ NVSF_API int nvsf_march_rays_train_ws(const float* rays_o, const float* rays_d, 
     const char* variant = getenv("NVSF_MARCH");
     const int serial = variant && variant[0] == 's';  // "serial": the batch walked member by member (tests, A/B)
     if (hipMemsetAsync(workspace, 0, nvsf_march_rays_train_ws_bytes(N), stream) != hipSuccess) return (int)hipGetLastError();
-    auto kernel = (unsigned long long)M * 12ull < (1ull << 32) ? k_march_train_onepass<true> : k_march_train_onepass<false>;
-    // the scanner + one worker per ticket until the chip is full (8 workgroups per compute unit)
-    const uint32_t wanted = 1u + cdiv(N, (uint32_t)kMarchRays), resident = 8u * (uint32_t)march_cu_count();
+    const bool off32 = (unsigned long long)M * 12ull < (1ull << 32), plain = dt_gamma == 0.0f && !serial;
+    auto kernel = off32 ? (plain ? k_march_train_onepass<true, true> : k_march_train_onepass<true, false>)
+                        : (plain ? k_march_train_onepass<false, true> : k_march_train_onepass<false, false>);
+    // the scanner + one worker per ticket until the chip is full (kMarchWgPerCu workgroups per compute unit)
+    const uint32_t wanted = 1u + cdiv(N, (uint32_t)kMarchRays), resident = kMarchWgPerCu * (uint32_t)march_cu_count();
     hipLaunchKernelGGL(kernel, dim3(wanted < resident ? wanted : resident), dim3(kBlock), H * sizeof(uint32_t), stream, rays_o, rays_d, grid, bound, dt_gamma,
                        max_steps, N, C, H, M, nears, fars, noises, rays, counter, reinterpret_cast<unsigned long long*>(workspace), xyzs, dirs,
                        deltas, serial, spin_limit ? spin_limit : kMarchSpinLimit);

@@ -44,8 +44,10 @@ def test_chamfer_forward_backward(dev, B, n, m):
     ga, gb = np.zeros_like(a), np.zeros_like(b)
     lib.oracle_chamfer_backward(_p(a), _p(b), U(B), U(n), U(m), _p(g1), _p(g2), _p(i1), _p(i2), _p(ga), _p(gb))
     ((gd1 * torch.from_numpy(g1).to(dev)).sum() + (gd2 * torch.from_numpy(g2).to(dev)).sum()).backward()
-    np.testing.assert_allclose(ta.grad.cpu().numpy(), ga, atol=2e-5, rtol=1e-5)
-    np.testing.assert_allclose(tb.grad.cpu().numpy(), gb, atol=2e-5, rtol=1e-5)
+    # fp32 sums in the arrival order of the atomics: a point that is the nearest neighbour of ~600 others (n = 5, m = 3000) adds ~600
+    # terms, so the last bits depend on the run (observed: 1.3e-5 relative on an entry of magnitude 129)
+    np.testing.assert_allclose(ta.grad.cpu().numpy(), ga, atol=2e-5, rtol=5e-5)
+    np.testing.assert_allclose(tb.grad.cpu().numpy(), gb, atol=2e-5, rtol=5e-5)
 
 
 def test_points_meter_cd_and_fscore(dev):

@@ -31,7 +31,7 @@ def test_zero_sized_calls_are_noops(dev):
     _hip.call("nvsf_sigmoid_bwd", None, None, 0, None)
     _hip.call("nvsf_exp_col", None, 16, 0, 0, None)
     _hip.call("nvsf_march_rays_train_ws", None, None, None, 2.0, 0.0, 1024, 0, 2, 128, 0, None, None, None, None, None, None, None, None, None, 0, 0)
-    assert _hip.march_ws_bytes(0) == 8 and _hip.march_ws_bytes(1) == 24 and _hip.march_ws_bytes(5) == 40
+    assert _hip.march_ws_bytes(0) == 1024 and _hip.march_ws_bytes(1) == 1040 and _hip.march_ws_bytes(5) == 1056  # 8 queue heads x 128 B + 16 B per ticket of four rays
 
 
 def test_rejected_arguments(dev):
@@ -45,15 +45,16 @@ def test_rejected_arguments(dev):
     _raises("nvsf_mse_sum_bwd", P(x), P(x), 8, 1.0, None, P(x))
     _raises("nvsf_sigmoid_bwd", P(x), None, 8, P(x))
     _raises("nvsf_exp_col", P(x), 4, 4, 8, P(x))  # column outside the row
-    ws = torch.zeros(64, dtype=torch.int64, device=dev)
+    ws = torch.zeros(1024, dtype=torch.int64, device=dev)
     rays = torch.zeros(8, 3, dtype=torch.int32, device=dev)
     ctr = torch.zeros(2, dtype=torch.int32, device=dev)
     bits = torch.zeros(2 * 128 ** 3 // 8, dtype=torch.uint8, device=dev)
     args = lambda C, H, wsb, wp: (P(x), P(x), P(bits), 2.0, 0.0, 64, 8, C, H, 512, P(x), P(x), P(x), P(x), P(x), P(rays), P(ctr), P(x), wp, wsb, 0)
-    _raises("nvsf_march_rays_train_ws", *args(2, 128, 8, P(ws)))          # scratch smaller than nvsf_march_rays_train_ws_bytes(8)
-    _raises("nvsf_march_rays_train_ws", *args(2, 128, 512, P(ws) + 4))    # not 8-byte aligned
-    _raises("nvsf_march_rays_train_ws", *args(9, 128, 512, P(ws)))        # more cascades than the operator is defined for
-    _raises("nvsf_march_rays_train_ws", *args(2, 2048, 512, P(ws)))       # H beyond the spread table
+    assert _hip.march_ws_bytes(8) == 1056
+    _raises("nvsf_march_rays_train_ws", *args(2, 128, 1048, P(ws)))       # scratch smaller than nvsf_march_rays_train_ws_bytes(8)
+    _raises("nvsf_march_rays_train_ws", *args(2, 128, 8000, P(ws) + 4))   # not 8-byte aligned
+    _raises("nvsf_march_rays_train_ws", *args(9, 128, 8192, P(ws)))       # more cascades than the operator is defined for
+    _raises("nvsf_march_rays_train_ws", *args(2, 2048, 8192, P(ws)))      # H beyond the spread table
     assert ctr.tolist() == [0, 0]
 
 
