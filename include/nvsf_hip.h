@@ -411,6 +411,20 @@ int nvsf_render_occupancy_fwd(const float* rays_o, const float* rays_d, const fl
                               const float* h_bg_color, float* weights_sum, float* depth, float* image,
                               nvsf_stream_t stream);
 
+/* The TRAINING forward of the same operator (ops.DensityRaysFn): one launch (feat_scratch NULL) or the two launches of the
+ * level-sliced form (feat_scratch = 4 * L * N * T bytes) that, beside z_vals / sigmas / geo_f16 (same values bit for bit),
+ * keep what the backward needs: x01 [N*T, 3] fp32 = the samples' unit-cube positions ((clip(o + d z) + bound) / (2 bound):
+ * network_dynamic.py:217), feat_rows_f16 [N*T, 32] fp16 = the encoded features in level order (the input rows of the density
+ * MLP: what nvsf_hashgrid_fwd writes) and h32 [N*T, 16] fp32 = the MLP's outputs (h0 = density logit, h1..h15 = geometry
+ * features: what nvsf_mlp_fwd writes).  Replaces nvsf_uniform_samples + the unit-cube normalisation + nvsf_hashgrid_fwd +
+ * nvsf_mlp_fwd + nvsf_exp_col of the operator chain.  Requires L == 16, F == 2. */
+int nvsf_field_density_uniform_train_fwd(const float* rays_o, const float* rays_d, const float* nears, const float* fars,
+                                         const float* lin, const float* noise, const float* h_aabb, float bound, uint32_t N,
+                                         uint32_t T, const void* table_f16, uint32_t L, uint32_t F, const float* h_scales,
+                                         const uint32_t* h_res, const uint32_t* h_offsets, const void* sigma_weights_f16,
+                                         float* z_vals, float* sigmas, void* geo_f16, float* x01, void* feat_rows_f16, float* h32,
+                                         void* feat_scratch, nvsf_stream_t stream);
+
 /* Same operator, same results bit for bit, as two launches with the LEVELS partitioned over the 8 XCDs (each
  * XCD's L2 then holds 2 of the 16 levels): pays when consecutive samples of a ray are several finest-level cells
  * apart, i.e. when the fine levels have no reuse along the ray (camera rays through the whole box).

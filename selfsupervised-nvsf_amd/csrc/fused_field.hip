@@ -255,12 +255,53 @@ __device__ __forceinline__ float4_t density_eval(const DensityCtx<F>& cx, const 
     return cx.wout.apply(h);
 }
 
+// What the TRAINING forward keeps beside sigma / geo / z (ops.DensityRaysFn): the unit-cube position of every sample (the table
+// scatter of the backward reads it), the 32 encoded features as rows in level order (the fused MLP backward recomputes the
+// hidden activations from them) and the 16 network outputs in fp32 (the autograd graph carries the geometry features in fp32).
+struct TrainOut {
+    float* x01;       // [M, 3]
+    _Float16* feat;   // [M, 32], column 2 l + f
+    float* h32;       // [M, 16] = (h0 .. h15)
+};
+
+// lane group g of a tile holds rotated output rows 4g .. 4g+3 = network outputs (4g+1 .. 4g+4) mod 16 of sample s
+__device__ __forceinline__ void store_h32(float* __restrict__ h32, unsigned long long s, int g, const float4_t& o) {
+    float* row = h32 + s * 16;
+    row[4 * g + 1] = o[0];
+    row[4 * g + 2] = o[1];
+    row[4 * g + 3] = o[2];
+    row[(4 * g + 4) & 15] = o[3];
+}
+
 // density_eval + store of sigma / geo / z.
-template <int F, int QG>
+template <int F, int QG, bool TRAIN = false>
 __device__ __forceinline__ void density_tile(const DensityCtx<F>& cx, const float (&x)[3], float z, unsigned long long s, bool in_range,
-                                             float* __restrict__ z_vals, float* __restrict__ sigmas, _Float16* __restrict__ geo) {
+                                             float* __restrict__ z_vals, float* __restrict__ sigmas, _Float16* __restrict__ geo,
+                                             const TrainOut* tr = nullptr) {
     const int g = cx.g;
-    const float4_t o = density_eval<F, QG>(cx, x);
+    float4_t o;
+    if constexpr (TRAIN) {
+        const half8_t xf = density_encode<F, QG>(cx, x);
+        float4_t acc1[kHidTiles];
+#pragma unroll
+        for (int t = 0; t < kHidTiles; ++t) {
+            const float4_t zero = {0, 0, 0, 0};
+            acc1[t] = mfma16(cx.w0[t], xf, zero);
+        }
+        half8_t h[kHidSteps];
+        pack_hidden(acc1, h);
+        o = cx.wout.apply(h);
+        if (in_range) {
+            // fragment element q * F + f of lane group g = feature (4 q + g) * F + f: four 4-byte pieces of the sample's 64-byte row
+            const uint4 pieces = __builtin_bit_cast(uint4, xf);
+            uint32_t* row = reinterpret_cast<uint32_t*>(tr->feat + s * 32);
+            row[g] = pieces.x; row[4 + g] = pieces.y; row[8 + g] = pieces.z; row[12 + g] = pieces.w;
+            store_h32(tr->h32, s, g, o);
+            if (g == 0) { tr->x01[3 * s] = x[0]; tr->x01[3 * s + 1] = x[1]; tr->x01[3 * s + 2] = x[2]; }
+        }
+    } else {
+        o = density_eval<F, QG>(cx, x);
+    }
     if (in_range) {
         half4_t ov;
         ov[0] = (_Float16)o[0]; ov[1] = (_Float16)o[1]; ov[2] = (_Float16)o[2]; ov[3] = (_Float16)o[3];
@@ -276,11 +317,11 @@ __device__ __forceinline__ void density_tile(const DensityCtx<F>& cx, const floa
 // SEG = true (T % 16 == 0): the unit of work is a ray SEGMENT owned by a whole workgroup.  The ray index is
 // block-uniform, so origin / direction / near / far are scalar loads held in SGPRs for the whole segment and the
 // per-lane 64-bit sample -> (ray, step) division disappears.  SEG = false: generic tile loop (any T).
-template <int F, bool SEG, int QG>
+template <int F, bool SEG, int QG, bool TRAIN = false>
 __global__ __launch_bounds__(kBlock) void k_density_uniform_v2(RayBatch rb, const _Float16* __restrict__ table, uint32_t table_bytes,
                                                                GridMeta meta, uint32_t first_hashed, uint32_t seg_tiles,
                                                                const _Float16* __restrict__ w_sigma, float* __restrict__ z_vals,
-                                                               float* __restrict__ sigmas, _Float16* __restrict__ geo) {
+                                                               float* __restrict__ sigmas, _Float16* __restrict__ geo, TrainOut tr = TrainOut()) {
     static_assert(F == 2, "v2 is built for F = 2 (BASELINE config 2); other shapes use k_density_uniform");
     constexpr int Q = 8 / F;
     __shared__ float s_scale[kMaxLevels];
@@ -343,7 +384,7 @@ __global__ __launch_bounds__(kBlock) void k_density_uniform_v2(RayBatch rb, cons
                 x[0] = (fminf(fmaxf(ox + dx * z, rb.lo[0]), rb.hi[0]) + rb.bound) * rb.inv_extent;
                 x[1] = (fminf(fmaxf(oy + dy * z, rb.lo[1]), rb.hi[1]) + rb.bound) * rb.inv_extent;
                 x[2] = (fminf(fmaxf(oz + dz * z, rb.lo[2]), rb.hi[2]) + rb.bound) * rb.inv_extent;
-                density_tile<F, QG>(cx, x, z, s, true, z_vals, sigmas, geo);
+                density_tile<F, QG, TRAIN>(cx, x, z, s, true, z_vals, sigmas, geo, &tr);
             }
         }
     } else {
@@ -364,7 +405,7 @@ __global__ __launch_bounds__(kBlock) void k_density_uniform_v2(RayBatch rb, cons
                 p = fminf(fmaxf(p, rb.lo[k]), rb.hi[k]);
                 x[k] = (p + rb.bound) * rb.inv_extent;
             }
-            density_tile<F, QG>(cx, x, z, s, in_range, z_vals, sigmas, geo);
+            density_tile<F, QG, TRAIN>(cx, x, z, s, in_range, z_vals, sigmas, geo, &tr);
         }
     }
 }
@@ -493,7 +534,8 @@ struct SlicePlan {
 template <int F, bool UNIFORM_RAY>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_encode_sliced_pairs(RayBatch rb, const _Float16* __restrict__ table, uint32_t table_bytes,
                                                                 GridMeta meta, uint32_t L, uint32_t first_hashed, uint32_t M,
-                                                                float* __restrict__ z_vals, uint2* __restrict__ feat, SlicePlan plan) {
+                                                                float* __restrict__ z_vals, uint2* __restrict__ feat, SlicePlan plan,
+                                                                float* __restrict__ x01 = nullptr) {
     static_assert(F == 2, "F = 2 only");
     const uint32_t group = blockIdx.x & 7u, sb = blockIdx.x >> 3, n_sb = gridDim.x >> 3;
     for (uint32_t item = 0; item < plan.n[group]; ++item) {
@@ -607,7 +649,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         const uint32_t other = quad_swap(mine);
         if (cur.in_range && xb == 0u) {
             feat[(size_t)slice * M + cur.s] = make_uint2(mine, other);
-            if (slice == 0u) z_vals[cur.s] = z;
+            if (slice == 0u) {
+                z_vals[cur.s] = z;
+                if (x01) { x01[3 * (size_t)cur.s] = x[0]; x01[3 * (size_t)cur.s + 1] = x[1]; x01[3 * (size_t)cur.s + 2] = x[2]; }
+            }
         }
         cur = nxt;
     }
@@ -667,10 +712,10 @@ static SlicePlan slice_plan(uint32_t n_units, uint32_t T, const uint32_t* h_res,
 }
 
 // pass B: 32 encoded features per sample (scratch planes) -> sigma MLP -> sigma, geo.
-template <int F>
+template <int F, bool TRAIN = false>
 __global__ __launch_bounds__(kBlock) void k_density_from_features(const uint2* __restrict__ feat, uint32_t M, uint32_t L,
                                                                   const _Float16* __restrict__ w_sigma, float* __restrict__ sigmas,
-                                                                  _Float16* __restrict__ geo) {
+                                                                  _Float16* __restrict__ geo, TrainOut tr = TrainOut()) {
     static_assert(F == 2, "F = 2 only");
     const int lane = lane_id(), g = lane >> 4, sl = lane & 15;
     const uint32_t lv4[4] = {(uint32_t)g, (uint32_t)g + 4u, (uint32_t)g + 8u, (uint32_t)g + 12u};  // as in k_density_uniform_v2
@@ -717,6 +762,11 @@ __global__ __launch_bounds__(kBlock) void k_density_from_features(const uint2* _
             pack_hidden(acc1, h);
             const float4_t o = wout.apply(h);
             if (ok[u]) {
+                if constexpr (TRAIN) {  // feature rows in level order (fragment pieces = levels g, g+4, g+8, g+12) and the fp32 outputs
+                    uint32_t* row = reinterpret_cast<uint32_t*>(tr.feat + (size_t)s[u] * 32);
+                    row[g] = packed.x; row[4 + g] = packed.y; row[8 + g] = packed.z; row[12 + g] = packed.w;
+                    store_h32(tr.h32, s[u], g, o);
+                }
                 half4_t ov;
                 ov[0] = (_Float16)o[0]; ov[1] = (_Float16)o[1]; ov[2] = (_Float16)o[2]; ov[3] = (_Float16)o[3];
                 if (g == 3) {
@@ -1662,7 +1712,8 @@ static int density_uniform_impl(const float* rays_o, const float* rays_d, const 
                                 const float* lin, const float* noise, const float* h_aabb, float bound, uint32_t N,
                                 uint32_t T, const void* table_f16, uint32_t L, uint32_t F, const float* h_scales,
                                 const uint32_t* h_res, const uint32_t* h_offsets, const void* sigma_weights_f16,
-                                float* z_vals, float* sigmas, void* geo_f16, void* feat_scratch, uint32_t sliced_passes, hipStream_t stream) {
+                                float* z_vals, float* sigmas, void* geo_f16, void* feat_scratch, uint32_t sliced_passes, hipStream_t stream,
+                                const TrainOut* train = nullptr) {
     if (N == 0 || T == 0) return NVSF_OK;
     REQUIRE(rays_o && rays_d && nears && fars && lin && h_aabb && table_f16 && sigma_weights_f16 && z_vals && sigmas && geo_f16);
     REQUIRE(bound > 0.0f);
@@ -1707,31 +1758,49 @@ static int density_uniform_impl(const float* rays_o, const float* rays_d, const 
             if (ps > 512u) ps = 512u;  // 32 CUs per XCD x 8 resident workgroups x 2 (measured: 256 -> 512 gains 1.5 %)
             const char* plan_env = getenv("NVSF_SLICE_PLAN");  // "home": every group its own slice only (A/B timing)
             const SlicePlan plan = slice_plan(units32, T, h_res, first_hashed, !(plan_env && plan_env[0] == 'h'));
+            float* x01 = train ? train->x01 : nullptr;
             if (T % 32u == 0u)
                 hipLaunchKernelGGL((k_encode_sliced_pairs<2, true>), dim3(8u * ps), dim3(kBlock), 0, stream, rb, tb, (uint32_t)table_bytes, meta, L,
-                                   first_hashed, M, z_vals, fp, plan);
+                                   first_hashed, M, z_vals, fp, plan, x01);
             else
                 hipLaunchKernelGGL((k_encode_sliced_pairs<2, false>), dim3(8u * ps), dim3(kBlock), 0, stream, rb, tb, (uint32_t)table_bytes, meta,
-                                   L, first_hashed, M, z_vals, fp, plan);
+                                   L, first_hashed, M, z_vals, fp, plan, x01);
         }
         const uint32_t tiles = (M + 15u) / 16u;
         uint32_t bb = (tiles + 4u * kWavesPerBlock - 1u) / (4u * kWavesPerBlock);
         if (bb > 4096u) bb = 4096u;
-        if (sliced_passes & 2u) hipLaunchKernelGGL(k_density_from_features<2>, dim3(bb), dim3(kBlock), 0, stream, fp, M, L, ws, sigmas, gp);
+        if (sliced_passes & 2u) {
+            if (train) hipLaunchKernelGGL((k_density_from_features<2, true>), dim3(bb), dim3(kBlock), 0, stream, fp, M, L, ws, sigmas, gp, *train);
+            else hipLaunchKernelGGL((k_density_from_features<2, false>), dim3(bb), dim3(kBlock), 0, stream, fp, M, L, ws, sigmas, gp, TrainOut());
+        }
         return nvsf_launch_status();
     }
     const bool use_v2 = F == 2 && monotone && table_bytes < (1ull << 31);  // else: the generic first formulation (any F with L F = 32)
+    if (train) {
+        if (!use_v2) return NVSF_ERR_UNSUPPORTED;
+        if (T % 16u == 0u) {
+            const uint32_t seg_tiles = 4u;
+            const unsigned long long units = (unsigned long long)N * ((T / 16 + seg_tiles - 1) / seg_tiles);
+            const uint32_t segb = (uint32_t)(units < 3072ull ? units : 3072ull);
+            hipLaunchKernelGGL((k_density_uniform_v2<2, true, 4, true>), dim3(segb), dim3(kBlock), 0, stream, rb, tb, (uint32_t)table_bytes, meta,
+                               first_hashed, seg_tiles, ws, z_vals, sigmas, gp, *train);
+        } else {
+            hipLaunchKernelGGL((k_density_uniform_v2<2, false, 4, true>), dim3(blocks), dim3(kBlock), 0, stream, rb, tb, (uint32_t)table_bytes, meta,
+                               first_hashed, 0u, ws, z_vals, sigmas, gp, *train);
+        }
+        return nvsf_launch_status();
+    }
     if (use_v2) {
         const bool seg = T % 16u == 0u;
         if (seg) {
             const uint32_t seg_tiles = 4u;  // 4 tiles = one round of the 4 waves (measured best)
             const unsigned long long units = (unsigned long long)N * ((T / 16 + seg_tiles - 1) / seg_tiles);
             const uint32_t segb = (uint32_t)(units < 3072ull ? units : 3072ull);  // 256 CUs x 3 workgroups (VGPR-limited residency) x 4
-            hipLaunchKernelGGL((k_density_uniform_v2<2, true, 4>), dim3(segb), dim3(kBlock), 0, stream, rb, tb, (uint32_t)table_bytes, meta,
-                               first_hashed, seg_tiles, ws, z_vals, sigmas, gp);
+            hipLaunchKernelGGL((k_density_uniform_v2<2, true, 4, false>), dim3(segb), dim3(kBlock), 0, stream, rb, tb, (uint32_t)table_bytes, meta,
+                               first_hashed, seg_tiles, ws, z_vals, sigmas, gp, TrainOut());
         } else {
-            hipLaunchKernelGGL((k_density_uniform_v2<2, false, 4>), dim3(blocks), dim3(kBlock), 0, stream, rb, tb, (uint32_t)table_bytes, meta,
-                               first_hashed, 0u, ws, z_vals, sigmas, gp);
+            hipLaunchKernelGGL((k_density_uniform_v2<2, false, 4, false>), dim3(blocks), dim3(kBlock), 0, stream, rb, tb, (uint32_t)table_bytes, meta,
+                               first_hashed, 0u, ws, z_vals, sigmas, gp, TrainOut());
         }
     }
     else if (F == 2) hipLaunchKernelGGL(k_density_uniform<2>, dim3(blocks), dim3(kBlock), 0, stream, rb, tb, meta, ws, z_vals, sigmas, gp);
@@ -1746,6 +1815,21 @@ NVSF_API int nvsf_field_density_uniform_fwd(const float* rays_o, const float* ra
                                             float* z_vals, float* sigmas, void* geo_f16, hipStream_t stream) {
     return density_uniform_impl(rays_o, rays_d, nears, fars, lin, noise, h_aabb, bound, N, T, table_f16, L, F, h_scales, h_res, h_offsets,
                                 sigma_weights_f16, z_vals, sigmas, geo_f16, nullptr, 0u, stream);
+}
+
+NVSF_API int nvsf_field_density_uniform_train_fwd(const float* rays_o, const float* rays_d, const float* nears, const float* fars,
+                                                  const float* lin, const float* noise, const float* h_aabb, float bound, uint32_t N,
+                                                  uint32_t T, const void* table_f16, uint32_t L, uint32_t F, const float* h_scales,
+                                                  const uint32_t* h_res, const uint32_t* h_offsets, const void* sigma_weights_f16,
+                                                  float* z_vals, float* sigmas, void* geo_f16, float* x01, void* feat_rows_f16, float* h32,
+                                                  void* feat_scratch, hipStream_t stream) {
+    if (N == 0 || T == 0) return NVSF_OK;
+    REQUIRE(x01 && feat_rows_f16 && h32 && (reinterpret_cast<uintptr_t>(feat_rows_f16) & 3u) == 0);
+    if (!(L == 16 && F == 2)) return NVSF_ERR_UNSUPPORTED;
+    TrainOut tr;
+    tr.x01 = x01; tr.feat = reinterpret_cast<_Float16*>(feat_rows_f16); tr.h32 = h32;
+    return density_uniform_impl(rays_o, rays_d, nears, fars, lin, noise, h_aabb, bound, N, T, table_f16, L, F, h_scales, h_res, h_offsets,
+                                sigma_weights_f16, z_vals, sigmas, geo_f16, feat_scratch, feat_scratch ? 3u : 0u, stream, &tr);
 }
 
 NVSF_API int nvsf_field_density_uniform_sliced_fwd(const float* rays_o, const float* rays_d, const float* nears, const float* fars,

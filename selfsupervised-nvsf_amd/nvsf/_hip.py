@@ -77,6 +77,7 @@ SIGNATURES = {
     "nvsf_chamfer_backward": [_P, _P, _U, _U, _U, _P, _P, _P, _P, _P, _P],
     # section 4: fused uniform-render kernels
     "nvsf_field_density_uniform_fwd": [_P, _P, _P, _P, _P, _P, _P, _F, _U, _U, _P, _U, _U, _P, _P, _P, _P, _P, _P, _P],
+    "nvsf_field_density_uniform_train_fwd": [_P, _P, _P, _P, _P, _P, _P, _F, _U, _U, _P, _U, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "nvsf_field_density_uniform_sliced_fwd": [_P, _P, _P, _P, _P, _P, _P, _F, _U, _U, _P, _U, _U, _P, _P, _P, _P, _P, _P, _P, _P, _U],
     "nvsf_render_uniform_fwd": [_P, _P, _P, _P, _P, _P, _P, _F, _U, _U, _P, _U, _U, _P, _P, _P, _P, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P,
                                 _P, _P],

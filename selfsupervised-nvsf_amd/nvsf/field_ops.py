@@ -262,11 +262,13 @@ def note_mask_count(model, lidar, n_active, numel):
     st["pending"] = None
 
 
-def heads(model, d01, geo_feat, cal_lidar_color, ray_dirs01=None):
+def heads(model, d01, geo_feat, cal_lidar_color, ray_dirs01=None, geo16=None):
     """Logits of the per-sample heads of `model` (a NeRFNetwork / NeRFNetworkStatic): [M, 2] = [raydrop, intensity] for
     LiDAR samples, [M, 3] colour logits otherwise.  d01: directions mapped to [0, 1]; geo_feat: [M, geo_feat_dim].
     ray_dirs01 [N, 3] (with M = N * T, sample rows ordered ray by ray): the directions per RAY instead of d01 -- the
-    encoding is then evaluated N times and broadcast to the samples (same values: every sample of a ray has its direction)."""
+    encoding is then evaluated N times and broadcast to the samples (same values: every sample of a ray has its direction).
+    geo16: fp16 [M, 16] rows (geometry features, 1.0) that already hold fp16(geo_feat) -- the fused training forward writes them
+    (DensityRaysFn) -- and serve as the MLP kernels' per-sample input as they are."""
     if cal_lidar_color:
         net_a, net_b, enc = model.raydrop_net, model.intensity_net, model.view_encoder_lidar
     else:
@@ -294,9 +296,10 @@ def heads(model, d01, geo_feat, cal_lidar_color, ray_dirs01=None):
         else:
             _hip.call("nvsf_repeat_rows_f16", _hip.ptr(dst), src.shape[0], n_enc_cols, dst.stride(0), M // src.shape[0], _hip.ptr(buf),
                       buf.stride(0))
+    x16 = geo16 if (prefix_mode and geo16 is not None and geo_feat.shape[1] == 15 and tuple(geo16.shape) == (M, 16)) else None
     if net_b is None:
-        return HeadsFn.apply(buf, enc.n_output_dims, geo_feat, net_a.params, net_a.weights_f16(), spec, None, None, enc_ray)
-    return HeadsFn.apply(buf, enc.n_output_dims, geo_feat, net_a.params, net_a.weights_f16(), spec, net_b.params, net_b.weights_f16(), enc_ray)
+        return HeadsFn.apply(buf, enc.n_output_dims, geo_feat, net_a.params, net_a.weights_f16(), spec, None, None, enc_ray, x16)
+    return HeadsFn.apply(buf, enc.n_output_dims, geo_feat, net_a.params, net_a.weights_f16(), spec, net_b.params, net_b.weights_f16(), enc_ray, x16)
 
 
 class HeadsFn(Function):
@@ -311,15 +314,18 @@ class HeadsFn(Function):
     afterwards."""
 
     @staticmethod
-    def forward(ctx, buf, n_enc, geo, params_a, w16_a, spec, params_b=None, w16_b=None, enc_ray=None):
+    def forward(ctx, buf, n_enc, geo, params_a, w16_a, spec, params_b=None, w16_b=None, enc_ray=None, x16_ready=None):
         n_geo = geo.shape[1]
         if buf is None:  # shared-prefix rows: x = [geometry | ones] fp16 [M, 16], the encoding stays one row per ray
             assert enc_ray is not None and n_enc + n_geo == spec.n_in
-            g = geo if (geo.dtype in (torch.float16, torch.float32) and geo.stride(1) == 1) else geo.float().contiguous()
             N, M = enc_ray.shape[0], geo.shape[0]
-            x16 = torch.empty(M, 16, dtype=torch.float16, device=geo.device)
-            _hip.call("nvsf_heads_input_f16", _hip.ptr(enc_ray), N, 0, enc_ray.stride(0), M // N, _hip.ptr_rows(g),
-                      1 if g.dtype == torch.float16 else 0, n_geo, g.stride(0), _hip.ptr(x16), 16, 16)
+            if x16_ready is not None:
+                x16 = x16_ready
+            else:
+                g = geo if (geo.dtype in (torch.float16, torch.float32) and geo.stride(1) == 1) else geo.float().contiguous()
+                x16 = torch.empty(M, 16, dtype=torch.float16, device=geo.device)
+                _hip.call("nvsf_heads_input_f16", _hip.ptr(enc_ray), N, 0, enc_ray.stride(0), M // N, _hip.ptr_rows(g),
+                          1 if g.dtype == torch.float16 else 0, n_geo, g.stride(0), _hip.ptr(x16), 16, 16)
             prefix = (enc_ray, M // N, n_enc)
             ctx.save_for_backward(x16, w16_a, w16_b, enc_ray)
             ctx.spec, ctx.n_enc, ctx.n_geo, ctx.geo_dtype, ctx.prefix_rows = spec, n_enc, n_geo, geo.dtype, M // N
@@ -378,7 +384,7 @@ class HeadsFn(Function):
         if grad_geo is not None and grad_geo.dtype != ctx.geo_dtype:
             grad_geo = grad_geo.to(ctx.geo_dtype)
         return (None, None, grad_geo, gw_a if ctx.needs_input_grad[3] else None, None, None,
-                gw_b if (w16_b is not None and ctx.needs_input_grad[6]) else None, None, None)
+                gw_b if (w16_b is not None and ctx.needs_input_grad[6]) else None, None, None, None)
 
 
 class MlpFn(Function):
@@ -504,54 +510,101 @@ class DensityFn(Function):
         ctx.save_for_backward(x01, feat, sigma, mlp_w16)
         ctx.grid_spec, ctx.mlp_spec, ctx.clamp = grid_spec, mlp_spec, (float(sigma_lo), float(sigma_hi))
         ctx.table_param = table_params
+        ctx.need_table, ctx.need_w = ctx.needs_input_grad[1], ctx.needs_input_grad[4]
         if table_params is not None and table_params.requires_grad and torch.is_grad_enabled():
             _scatter_expected(table_params)
         return sigma, h[:, 1:mlp_spec.n_out]
 
     @staticmethod
     def backward(ctx, g_sigma, g_geo):
-        x01, feat, sigma, mlp_w16 = ctx.saved_tensors
-        spec, M = ctx.mlp_spec, x01.shape[0]
-        if g_sigma is not None:
-            g_sigma = g_sigma.float().contiguous()
-        if g_geo is not None and (g_geo.dtype != torch.float32 or g_geo.stride(1) != 1):
-            g_geo = g_geo.float().contiguous()
-        grad_h = torch.empty(M, 16, dtype=torch.float32, device=x01.device)
-        _hip.call("nvsf_sigma_geo_bwd", None if g_sigma is None else _hip.ptr(g_sigma), _hip.ptr(sigma),
-                  None if g_geo is None else _hip.ptr_rows(g_geo), 0 if g_geo is None else g_geo.stride(0), spec.n_out - 1, M,
-                  _hip.ptr(grad_h), 16, ctx.clamp[0], ctx.clamp[1])
-        need_table = ctx.needs_input_grad[1]
-        grad_feat, grad_w = mlp_backward(feat, mlp_w16, spec, grad_h[:, :spec.n_out], need_grad_x=need_table)
-        grad_table = None
-        if need_table:
-            last = _scatter_done(ctx.table_param)
-            sink = GRAD_SINK
-            if not (SCATTER_OVERLAP and x01.is_cuda):
-                view = sink.view_for(ctx.table_param) if sink is not None else None
-                if view is not None:
-                    hashgrid_backward(x01, (0, 1, 2), ctx.grid_spec, grad_feat, grad_table=view.view(-1))
-                    if last:
-                        sink.mark_ready(ctx.table_param)
-                else:
-                    grad_table = hashgrid_backward(x01, (0, 1, 2), ctx.grid_spec, grad_feat)
+        return (None,) + _density_backward(ctx, g_sigma, g_geo)
+
+
+def _density_backward(ctx, g_sigma, g_geo):
+    """Backward shared by DensityFn and DensityRaysFn: -> (grad_table, None, None, grad_mlp_weights, None, None, None, None)."""
+    x01, feat, sigma, mlp_w16 = ctx.saved_tensors
+    spec, M = ctx.mlp_spec, x01.shape[0]
+    if g_sigma is not None:
+        g_sigma = g_sigma.float().contiguous()
+    if g_geo is not None and (g_geo.dtype != torch.float32 or g_geo.stride(1) != 1):
+        g_geo = g_geo.float().contiguous()
+    grad_h = torch.empty(M, 16, dtype=torch.float32, device=x01.device)
+    _hip.call("nvsf_sigma_geo_bwd", None if g_sigma is None else _hip.ptr(g_sigma), _hip.ptr(sigma),
+              None if g_geo is None else _hip.ptr_rows(g_geo), 0 if g_geo is None else g_geo.stride(0), spec.n_out - 1, M,
+              _hip.ptr(grad_h), 16, ctx.clamp[0], ctx.clamp[1])
+    need_table, need_w = ctx.need_table, ctx.need_w
+    grad_feat, grad_w = mlp_backward(feat, mlp_w16, spec, grad_h[:, :spec.n_out], need_grad_x=need_table)
+    grad_table = None
+    if need_table:
+        last = _scatter_done(ctx.table_param)
+        sink = GRAD_SINK
+        if not (SCATTER_OVERLAP and x01.is_cuda):
+            view = sink.view_for(ctx.table_param) if sink is not None else None
+            if view is not None:
+                hashgrid_backward(x01, (0, 1, 2), ctx.grid_spec, grad_feat, grad_table=view.view(-1))
+                if last:
+                    sink.mark_ready(ctx.table_param)
             else:
-                # Side stream.  The destination is ONE buffer per table and step, obtained (and, the first time, zero-filled) on the
-                # main stream BEFORE the side stream is made to wait for it: a bucket view (multi-rank) or the parameter's .grad
-                # (LocalGradSink).  The node returns no tensor for the table, so the autograd engine never touches the buffer.
-                if sink is None:
-                    raise _hip.NvsfHipError("SCATTER_OVERLAP needs a gradient sink (RenderTrainStep sets field_ops.GRAD_SINK)")
-                view = sink.view_for(ctx.table_param)
-                if view is None:
-                    raise _hip.NvsfHipError("the gradient sink has no buffer for this table")
-                main, side = torch.cuda.current_stream(x01.device), side_stream(x01.device)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    x01.record_stream(side)
-                    grad_feat.record_stream(side)
-                    hashgrid_backward(x01, (0, 1, 2), ctx.grid_spec, grad_feat, grad_table=view.view(-1))
-                    if last:  # the table's gradient is final: its bucket may go out (event recorded on the side stream)
-                        sink.mark_ready(ctx.table_param)
-        return None, grad_table, None, None, (grad_w if ctx.needs_input_grad[4] else None), None, None, None, None
+                grad_table = hashgrid_backward(x01, (0, 1, 2), ctx.grid_spec, grad_feat)
+        else:
+            # Side stream.  The destination is ONE buffer per table and step, obtained (and, the first time, zero-filled) on the
+            # main stream BEFORE the side stream is made to wait for it: a bucket view (multi-rank) or the parameter's .grad
+            # (LocalGradSink).  The node returns no tensor for the table, so the autograd engine never touches the buffer.
+            if sink is None:
+                raise _hip.NvsfHipError("SCATTER_OVERLAP needs a gradient sink (RenderTrainStep sets field_ops.GRAD_SINK)")
+            view = sink.view_for(ctx.table_param)
+            if view is None:
+                raise _hip.NvsfHipError("the gradient sink has no buffer for this table")
+            main, side = torch.cuda.current_stream(x01.device), side_stream(x01.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                x01.record_stream(side)
+                grad_feat.record_stream(side)
+                hashgrid_backward(x01, (0, 1, 2), ctx.grid_spec, grad_feat, grad_table=view.view(-1))
+                if last:  # the table's gradient is final: its bucket may go out (event recorded on the side stream)
+                    sink.mark_ready(ctx.table_param)
+    return grad_table, None, None, (grad_w if need_w else None), None, None, None, None
+
+
+class DensityRaysFn(Function):
+    """The training forward of a static hash field from the RAYS: z_vals [N, T], sigma [N T], geo_feat [N T, 15] (fp32) and --
+    not differentiable -- geo16 [N T, 16] fp16 = (fp16(geo_feat), 1.0), the per-sample input rows of the heads.
+
+    One launch (nvsf_field_density_uniform_train_fwd; two in its level-sliced form) where the operator chain runs the sampler, the
+    unit-cube normalisation (two torch passes over [M, 3]), the hash-grid encoder, the density MLP and the exponential as seven:
+    sample positions are formed in registers, the encoded features go from the gathers into the MFMA operand, and what the
+    backward needs (positions, feature rows, outputs) is written once.  Same values as the chain (same kernels' arithmetic:
+    tests/test_train_step_gpu.py); the backward is DensityFn's."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, nears, fars, T, aabb_host, bound, noise, table_params, table_f16, grid_spec, mlp_params, mlp_w16,
+                mlp_spec, sigma_lo, sigma_hi, sliced):
+        N, dev = rays_o.shape[0], rays_o.device
+        M = N * T
+        z_vals = torch.empty(N, T, dtype=torch.float32, device=dev)
+        sigma = torch.empty(M, dtype=torch.float32, device=dev)
+        geo16 = torch.empty(M, 16, dtype=torch.float16, device=dev)
+        x01 = torch.empty(M, 3, dtype=torch.float32, device=dev)
+        feat = torch.empty(M, 32, dtype=torch.float16, device=dev)
+        h32 = torch.empty(M, 16, dtype=torch.float32, device=dev)
+        planes = torch.empty(grid_spec.L, M, dtype=torch.int32, device=dev) if sliced else None
+        _hip.call("nvsf_field_density_uniform_train_fwd", _hip.ptr(rays_o), _hip.ptr(rays_d), _hip.ptr(nears), _hip.ptr(fars),
+                  _hip.ptr(linspace01(T, dev)), _hip.ptr(noise), _hip.host_f32(aabb_host), float(bound), N, T, _hip.ptr(table_f16),
+                  grid_spec.L, grid_spec.F, grid_spec.h_scales, grid_spec.h_res, grid_spec.h_offsets, _hip.ptr(mlp_w16), _hip.ptr(z_vals),
+                  _hip.ptr(sigma), _hip.ptr(geo16), _hip.ptr(x01), _hip.ptr(feat), _hip.ptr(h32), _hip.ptr(planes))
+        ctx.save_for_backward(x01, feat, sigma, mlp_w16)
+        ctx.grid_spec, ctx.mlp_spec, ctx.clamp = grid_spec, mlp_spec, (float(sigma_lo), float(sigma_hi))
+        ctx.table_param = table_params
+        ctx.need_table, ctx.need_w = ctx.needs_input_grad[8], ctx.needs_input_grad[11]
+        if table_params is not None and table_params.requires_grad and torch.is_grad_enabled():
+            _scatter_expected(table_params)
+        ctx.mark_non_differentiable(z_vals, geo16)
+        return z_vals, sigma, h32[:, 1:mlp_spec.n_out], geo16
+
+    @staticmethod
+    def backward(ctx, _g_z, g_sigma, g_geo, _g_geo16):
+        g = _density_backward(ctx, g_sigma, g_geo)  # (grad_table, None, None, grad_w, ...)
+        return (None,) * 8 + (g[0], None, None, g[3], None, None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -66,7 +66,32 @@ class NeRFNetworkStatic(NeRFRenderer):
         h = net(enc(x))
         return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
 
+    def density_from_rays(self, rays_o, rays_d, nears, fars, T, noise, cal_lidar_color, **kwargs):
+        """Training forward from the rays (NeRFRenderer.run asks for it when gradients are recorded): sampler + unit-cube
+        normalisation + hash grid + density MLP + trunc_exp as ONE autograd node and one launch (ops.DensityRaysFn; two launches in
+        the level-sliced form, chosen as for the no-grad render).  Returns None where the fused kernels are not built (the caller
+        then runs the operator chain through `density`)."""
+        enc = self.hash_encoder_lidar if cal_lidar_color else self.hash_encoder_camera
+        net = self.sigma_net
+        if not (self.fused_train_forward and rays_o.is_cuda and ops.render_uniform_eligible(enc.spec) and net.spec.n_hidden == 1
+                and net.spec.hidden == 64 and net.spec.in_cols == 32 and net.spec.out_cols == 16):
+            return None
+        ray_length = float(self.lidar_max_depth - self.min_near_lidar) if cal_lidar_color else 2.0 * float(self.bound)
+        sliced = ops.prefer_sliced(enc.spec, rays_o.shape[0], T, ray_length, float(self.bound))
+        z_vals, sigma, geo, geo16 = ops.DensityRaysFn.apply(rays_o, rays_d, nears, fars, int(T), self._aabb_host, float(self.bound), noise,
+                                                            enc.params, enc.table_f16(), enc.spec, net.params, net.weights_f16(), net.spec,
+                                                            activation._LO, activation._HI, bool(sliced))
+        return {"z_vals": z_vals, "sigma": sigma, "geo_feat": geo, "geo16": geo16}
+
+    fused_train_forward = True  # False (tests): NeRFRenderer.run takes the operator chain (uniform_samples -> density)
+
     def color(self, x, d, cal_lidar_color=False, mask=None, geo_feat=None, **kwargs):
+        ray_dirs = kwargs.get("ray_dirs")  # [N, 3] from NeRFRenderer.run: d is these rows, each repeated for its ray's samples
+        if d is None:  # the renderer's fused training forward does not expand the directions: done here only if a path needs them
+            d_rows = lambda: ray_dirs.view(-1, 1, 3).expand(ray_dirs.shape[0], geo_feat.shape[0] // ray_dirs.shape[0], 3).reshape(-1, 3)
+        else:
+            d_rows = lambda: d
+        like = geo_feat if x is None else x  # dtype / device of the result
         dense_mask = None
         if mask is not None and ops.mask_was_dense(self, cal_lidar_color, mask):
             # the previous batch of this modality had >= 25 % of its samples above the weight threshold: evaluate all samples and
@@ -77,27 +102,27 @@ class NeRFNetworkStatic(NeRFRenderer):
             n_active = int(ops.count_true(mask)) if mask.is_cuda else int(mask.sum())  # one host sync (the reference's `mask.any()` costs the same)
             ops.note_mask_count(self, cal_lidar_color, n_active, mask.numel())
             if n_active == 0:
-                return torch.zeros(mask.shape[0], self.out_dim, dtype=x.dtype, device=x.device)
+                return torch.zeros(mask.shape[0], self.out_dim, dtype=like.dtype, device=like.device)
             if 4 * n_active >= mask.numel():
                 # most samples are active: evaluate all of them and zero the rest -- same values and gradients as the
                 # gather / scatter form (masked rows are constants), without three index kernels each way
                 dense_mask, mask = mask, None
             else:
-                rgbs = torch.zeros(mask.shape[0], self.out_dim, dtype=x.dtype, device=x.device)
-                d, geo_feat = d[mask], geo_feat[mask]
+                rgbs = torch.zeros(mask.shape[0], self.out_dim, dtype=like.dtype, device=like.device)
+                d, geo_feat = d_rows()[mask], geo_feat[mask]
         # [direction encoding | geo_feat] assembled once in an aligned fp16 buffer shared by the heads (ops.HeadsFn); same
         # values as the reference's torch.cat + tcnn calls (network_dynamic.py:310-325), LiDAR order [raydrop, intensity]
-        ray_dirs = kwargs.get("ray_dirs")  # [N, 3] from NeRFRenderer.run: d is these rows, each repeated for its ray's samples
-        if mask is None and ray_dirs is not None and d.shape[0] % ray_dirs.shape[0] == 0:
-            logits = ops.heads(self, None, geo_feat, cal_lidar_color, ray_dirs01=(ray_dirs + 1) / 2)
+        if mask is None and ray_dirs is not None and geo_feat.shape[0] % ray_dirs.shape[0] == 0:
+            logits = ops.heads(self, None, geo_feat, cal_lidar_color, ray_dirs01=(ray_dirs + 1) / 2, geo16=kwargs.get("geo16"))
         else:
+            d = (d_rows() if mask is None else d)
             d = (d + 1) / 2  # the direction encoders expect [0, 1]
             logits = ops.heads(self, d, geo_feat, cal_lidar_color)
         if dense_mask is not None and logits.is_cuda:
-            return ops.MaskedSigmoidFn.apply(logits, dense_mask).to(x.dtype)  # sigmoid and mask in one launch
+            return ops.MaskedSigmoidFn.apply(logits, dense_mask).to(like.dtype)  # sigmoid and mask in one launch
         h = torch.sigmoid(logits)
         if dense_mask is not None:
-            return (h * dense_mask.unsqueeze(-1)).to(x.dtype)
+            return (h * dense_mask.unsqueeze(-1)).to(like.dtype)
         if mask is None:
             return h
         rgbs[mask] = h.to(rgbs.dtype)

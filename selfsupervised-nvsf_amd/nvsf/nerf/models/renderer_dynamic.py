@@ -245,16 +245,23 @@ class NeRFRenderer(nn.Module):
             z_vals, weights, weights_sum, depth, image = fused(rays_o, rays_d, nears, fars, T, aabb, noise, cal_lidar_color,
                                                                bg_host, time=time, **kwargs)
         else:
-            z_vals, xyzs = ops.uniform_samples(rays_o, rays_d, nears, fars, T, aabb, noise)
-            density_outputs = self.density(xyzs.view(-1, 3), time, cal_lidar_color, **kwargs)
+            density_rays = getattr(self, "density_from_rays", None)
+            density_outputs = density_rays(rays_o, rays_d, nears, fars, T, noise, cal_lidar_color, **kwargs) if density_rays is not None else None
+            if density_outputs is not None:
+                # training forward of a field that samples, encodes and evaluates its density MLP in one launch (network_static):
+                # the [N, T, 3] positions and the expanded directions are never materialised; `color` gets them on request
+                z_vals = density_outputs.pop("z_vals")
+                xyz_arg = dirs_arg = None
+            else:
+                z_vals, xyzs = ops.uniform_samples(rays_o, rays_d, nears, fars, T, aabb, noise)
+                density_outputs = self.density(xyzs.view(-1, 3), time, cal_lidar_color, **kwargs)
+                xyz_arg, dirs_arg = xyzs.view(-1, 3), rays_d.view(-1, 1, 3).expand(N, T, 3).reshape(-1, 3)
             sigma = density_outputs["sigma"].view(N, T)
             weights, weights_sum, depth = ops.CompositeWeightsFn.apply(sigma, z_vals, nears, fars, self._k_scale())
-            dirs = rays_d.view(-1, 1, 3).expand(N, T, 3)
             mask = weights > ops.W_THRESH
             extra = {k: v.view(N * T, -1) for k, v in density_outputs.items() if k != "sigma"}
             # ray_dirs: the per-ray rows `dirs` repeats -- lets the heads encode each direction once (ops.heads)
-            rgbs = self.color(xyzs.view(-1, 3), dirs.reshape(-1, 3), cal_lidar_color=cal_lidar_color, mask=mask.reshape(-1),
-                              ray_dirs=rays_d, **extra)
+            rgbs = self.color(xyz_arg, dirs_arg, cal_lidar_color=cal_lidar_color, mask=mask.reshape(-1), ray_dirs=rays_d, **extra)
             bg_dev = torch.tensor(bg_host, dtype=torch.float32, device=rays_o.device) if bg_host is not None else None
             image = ops.CompositeImageFn.apply(weights, rgbs.view(N, T, self.out_dim), weights_sum, bg_dev)
         if per_ray_bg is not None:

@@ -115,8 +115,8 @@ class RenderTrainStep:
         (opt.scale); `pc_list`: {frame index: [P, 3] tensor} world-frame point clouds for the scene-flow loss
         (Trainer.process_pointcloud, trainer.py:1848-1912, builds them from the range images); `ema_decay=None` disables EMA.
         `split_backward`: the LiDAR terms and the camera term of the loss are sums over disjoint ray sets, so their gradients add:
-        the step runs LiDAR forward + backward, then camera forward + backward, and the LiDAR table scatter (the longest kernel
-        of the step, on its side stream) overlaps the whole camera pass instead of the tail of one joint backward.  Same
+        the step runs camera forward + backward, then LiDAR forward + backward, and the camera table scatter (the longest kernel
+        of the step, on its side stream) overlaps the whole LiDAR pass instead of the tail of one joint backward.  Same
         gradients (test_train_step_gpu.py); the reference's `nan_to_num` of the total is applied per modality, which differs
         only when a loss is not finite (then that modality contributes no gradient; GradScaler skips such a step anyway)."""
         self.model = model
@@ -286,7 +286,10 @@ class RenderTrainStep:
             lidar = {k: v for k, v in batch.items() if k not in self.CAMERA_KEYS}
             camera = {k: v for k, v in batch.items() if k in self.CAMERA_KEYS or k == "time"}
             loss, parts, overlap = None, {}, False
-            for first, sub in ((True, lidar), (False, camera)):
+            # Camera pass first: its table scatter is the longer one (2.85 against 2.07 ms at 4096 + 4096 rays x 768: camera samples
+            # sit in cells of their own at the five finest levels) and, issued first, it runs on the side stream beside the whole
+            # LiDAR pass (forward + backward, 2.7 ms); only the shorter LiDAR scatter is left exposed at the end of the step.
+            for first, sub in ((True, camera), (False, lidar)):
                 if self.buckets is not None:  # parameters both passes reach (the sigma MLP) are final only after the second
                     self.buckets.hold(first)
                 part_loss, part = self.losses(sub)

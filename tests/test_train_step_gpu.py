@@ -391,12 +391,21 @@ def test_split_backward_gives_the_same_gradients(dev):
     teacher = teacher.to(dev).eval()
     batch = _batch(S, teacher, dev, n=700, T=64, seed=2)
     grads, losses = {}, {}
+    noise = {True: torch.rand(700, 64, device=dev), False: torch.rand(700, 64, device=dev)}  # the jitter of each modality, whichever pass runs first
     for split in (False, True):
         torch.manual_seed(9)
         m = NeRFNetworkStatic(**kw).to(dev)
         step = RenderTrainStep(m, num_steps=64, scale=S.SCALE, ema_decay=None, split_backward=split)
         step.scaler = torch.amp.GradScaler("cuda", init_scale=64.0, growth_interval=10 ** 6)
-        torch.manual_seed(10)
+        real_render, real_rand = m.render, torch.rand
+
+        def render(o, d, t, cal_lidar_color=False, _rr=real_render, **k):
+            torch.rand = lambda *a, **kk: noise[bool(cal_lidar_color)]
+            try:
+                return _rr(o, d, t, cal_lidar_color=cal_lidar_color, **k)
+            finally:
+                torch.rand = real_rand
+        m.render = render
         loss, parts, _ = step.step(batch)
         torch.cuda.synchronize()
         losses[split] = (float(loss), {k: float(v) for k, v in parts.items()})
@@ -503,3 +512,95 @@ def test_step_without_the_chamfer_term_and_with_a_lidar_only_batch(dev):
     assert set(parts) == {"depth", "raydrop", "intensity"} and bool(torch.isfinite(loss))
     assert m.hash_encoder_camera.params.grad is None and torch.equal(m.hash_encoder_camera.params, before)
     assert all(bool(torch.isfinite(p).all()) for p in m.parameters())
+
+
+def test_fused_training_forward_equals_operator_chain(dev):
+    """NeRFRenderer.run with gradients recorded takes the static field's one-launch training forward (ops.DensityRaysFn: sampler +
+    unit-cube normalisation + hash grid + density MLP + exp in one kernel, its fp16 geometry rows handed to the heads as they are)
+    instead of the operator chain (uniform_samples -> density -> DensityFn; `fused_train_forward = False`).  Same render, same loss,
+    same gradients (the forward kernels share their arithmetic; table gradients differ by fp32 atomic order only), for the one-launch
+    and for the level-sliced form of the kernel."""
+    from nvsf import synthetic as S, field_ops as ops
+    from nvsf.nerf import activation
+    from nvsf.nerf.models.network_static import NeRFNetworkStatic
+    from nvsf.nerf.train_step import RenderTrainStep
+    kw = dict(bound=S.BOUND, min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH, log2_hashmap_size=15)
+    torch.manual_seed(4)
+    teacher = NeRFNetworkStatic(**kw)
+    with torch.no_grad():
+        for enc in (teacher.hash_encoder_lidar, teacher.hash_encoder_camera):
+            enc.params.normal_(0.0, 0.2)
+    teacher = teacher.to(dev).eval()
+    batch = _batch(S, teacher, dev, n=700, T=64, seed=2)
+    noise = {True: torch.rand(700, 64, device=dev), False: torch.rand(700, 64, device=dev)}
+    res = {}
+    for fused in (False, True):
+        torch.manual_seed(9)
+        m = NeRFNetworkStatic(**kw).to(dev)
+        with torch.no_grad():
+            for enc in (m.hash_encoder_lidar, m.hash_encoder_camera):
+                enc.params.normal_(0.0, 0.3)
+        m.fused_train_forward = fused
+        step = RenderTrainStep(m, num_steps=64, scale=S.SCALE, ema_decay=None)
+        step.scaler = torch.amp.GradScaler("cuda", init_scale=64.0, growth_interval=10 ** 6)
+        real_render, real_rand = m.render, torch.rand
+        outs = {}
+
+        def render(o, d, t, cal_lidar_color=False, _rr=real_render, **k):
+            torch.rand = lambda *a, **kk: noise[bool(cal_lidar_color)]
+            try:
+                r = _rr(o, d, t, cal_lidar_color=cal_lidar_color, **k)
+            finally:
+                torch.rand = real_rand
+            outs[bool(cal_lidar_color)] = {kk: v.detach().clone() for kk, v in r.items()}
+            return r
+        m.render = render
+        loss, parts, _ = step.step(batch)
+        torch.cuda.synchronize()
+        res[fused] = (float(loss), outs, {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.numel() and p.grad is not None})
+    assert abs(res[True][0] - res[False][0]) <= 1e-6 * abs(res[False][0])
+    for lidar in (True, False):
+        for k, v in res[False][1][lidar].items():
+            w = res[True][1][lidar][k]
+            assert v.shape == w.shape, k
+            if k == "z_vals":
+                assert torch.equal(v, w)
+            else:
+                assert float((v - w).abs().max()) <= 5e-6 * max(1.0, float(v.abs().max())), (lidar, k)
+    assert set(res[True][2]) == set(res[False][2]) and len(res[True][2]) == 6
+    for n, a in res[False][2].items():
+        b = res[True][2][n]
+        assert float(a.abs().max()) > 0 and float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), n
+    # the level-sliced form of the training forward (what a camera batch of the full-size field takes): every output bit for bit
+    # the one-launch form's
+    torch.manual_seed(1)
+    big = NeRFNetworkStatic(bound=S.BOUND, min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH).to(dev)
+    with torch.no_grad():
+        big.hash_encoder_camera.params.normal_(0.0, 0.3)
+    enc, net = big.hash_encoder_camera, big.sigma_net
+    rng = np.random.default_rng(7)
+    co, cd = S.camera_rays(300, rng)
+    o, d = torch.from_numpy(co).to(dev), torch.from_numpy(cd).to(dev)
+    from nvsf.nerf.raymarching import raymarching as rm
+    nears, fars = rm.near_far_from_aabb(o, d, big.aabb_train, big.min_near)
+    nz = torch.rand(300, 96, device=dev)
+    got = {}
+    for sliced in (False, True):
+        z, sg, geo, g16 = ops.DensityRaysFn.apply(o, d, nears, fars, 96, big._aabb_host, float(big.bound), nz, enc.params, enc.table_f16(), enc.spec,
+                                                  net.params, net.weights_f16(), net.spec, activation._LO, activation._HI, sliced)
+        node = sg.grad_fn
+        got[sliced] = (z, sg.detach(), geo.detach(), g16, [t.clone() for t in node.saved_tensors[:2]])
+    for a, b in zip(got[False][:4], got[True][:4]):
+        assert torch.equal(a, b)
+    assert torch.equal(got[False][4][0], got[True][4][0]) and torch.equal(got[False][4][1], got[True][4][1])  # x01, feature rows
+    # ... and they are what the stand-alone operators give: positions, encoder rows, MLP outputs
+    zz, xyz = ops.uniform_samples(o, d, nears, fars, 96, big.aabb_train, nz)
+    x01 = ((xyz.view(-1, 3) + big.bound) / (2 * big.bound))
+    assert torch.equal(zz, got[False][0]) and torch.equal(x01, got[False][4][0])
+    feat = ops.hashgrid_forward(x01, (0, 1, 2), enc.table_f16(), enc.spec)
+    assert torch.equal(feat, got[False][4][1])
+    h = ops.mlp_forward(feat, net.weights_f16(), net.spec)
+    # (the fused kernels feed the 32 inputs of the first layer to the MFMA in their own column order -- the hardware's order of
+    # additions inside a 32-wide k-step differs from the stand-alone kernel's: ~1e-4 relative, as between any two fp16 MLP kernels)
+    assert float((h[:, 1:16] - got[False][2]).abs().max()) <= 2e-4 * float(h.abs().max())
+    assert torch.equal(got[False][3][:, :15], got[False][2].half()) and bool((got[False][3][:, 15] == 1).all())
