@@ -77,6 +77,9 @@ def self_launch(args):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver of this pool only supports dmabuf IPC; with the legacy mode RCCL's (and torch's)
+    # cross-process buffer sharing fails with `hipIpcGetMemHandle: invalid argument`.  The image exports it; it is pinned here so
+    # that ranks started from a scrubbed environment still get it (an explicit setting of the caller wins).
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     proc = subprocess.run(launch_command(args.gpus, sys.argv[1:], port), stdout=subprocess.PIPE, text=True, env=env)
     lines = [l for l in proc.stdout.splitlines() if l.startswith("{") and '"metric"' in l]
@@ -289,13 +292,24 @@ def train_leg(model, tl, tc, tm, T, steps, dev, dist):
         dist.barrier()
     dt = time.perf_counter() - t0
     world = dist.get_world_size() if dist is not None else 1
+    per_rank_ms = [dt / steps * 1e3]
+    allreduce = None
     if dist is not None:
+        every = [None] * world
+        dist.all_gather_object(every, dt)
+        per_rank_ms = [float(v) / steps * 1e3 for v in every]
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        if step.buckets is not None:  # the LAST step's bucket all-reduces, device time on the communication stream (this rank)
+            rows = step.buckets.allreduce_ms()
+            allreduce = {"payload_MB": step.buckets.payload_bytes / 1e6, "buckets": len(step.buckets.flat),
+                         "per_bucket": [{"bucket": b, "MB": mb, "ms": ms} for b, mb, ms in rows], "sum_ms": sum(r[2] for r in rows),
+                         "ring_estimate_ms": 2.0 * (world - 1) / world * step.buckets.payload_bytes / 153e9 * 1e3,
+                         "ring_estimate": "2 (W - 1) / W x payload / 153 GB/s (one xGMI link per ring direction; DESIGN.md section 7)"}
     model.eval()
     return {"metric": "trained rays/sec (LiDAR+cam, fwd+bwd+Adam)", "value": (n_l + n_c) * world * steps / dt, "ms_per_step": dt / steps * 1e3,
-            "steps": steps, "allreduce_collectives_per_step": n_coll,
+            "steps": steps, "allreduce_collectives_per_step": n_coll, "per_rank_ms_per_step": per_rank_ms, "allreduce": allreduce,
             "losses": "the reference's Trainer.train_step defaults: per-ray L1 range + MSE ray-drop + MSE intensity summed over rays, chamfer distance of the predicted point cloud, summed MSE RGB",
             "path": "operator path (autograd) under GradScaler (dense fp16 feature gradients): HIP forward kernels; HIP backward for hash grid "
                     "(corner-parallel run-merging atomics), MLPs (fused data + weight gradients, shared aligned head input) and compositors"}
@@ -529,6 +543,26 @@ def dynamic_leg(dev, n_rays, T, steps):
     return out
 
 
+def rank_agreement(dist, nvsf_build):
+    """After rank 0's build + barrier: every rank loads libnvsf_hip.so and reports (nvsf_version(), digest of ALL kernel sources,
+    sha1 of the shared object it mapped); a rank that disagrees with rank 0 ends the run.  Also what each rank believes the world
+    to be (`ranks_seen`: MIN / MAX of get_world_size() and the number of ranks that answered)."""
+    import hashlib
+    from nvsf import _hip
+    mine = {"version": _hip.version(), "csrc_digest": nvsf_build.csrc_digest_all(),
+            "lib_sha1": hashlib.sha1(open(_hip.LIB_PATH, "rb").read()).hexdigest()[:16]}
+    if dist is None:
+        return dict(mine, ranks_agree=True, ranks_seen={"min": 1, "max": 1, "answered": 1})
+    ws = dist.get_world_size()
+    views = [None] * ws
+    dist.all_gather_object(views, dict(mine, world=ws, rank=dist.get_rank()))
+    bad = [v for v in views if any(v[k] != views[0][k] for k in ("version", "csrc_digest", "lib_sha1"))]
+    if bad:
+        raise SystemExit(f"bench.py: ranks disagree about the kernel library: rank 0 {views[0]}, others {bad}")
+    worlds = [v["world"] for v in views]
+    return dict(mine, ranks_agree=True, ranks_seen={"min": min(worlds), "max": max(worlds), "answered": len({v["rank"] for v in views})})
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -559,6 +593,7 @@ def main():
         nvsf_build.build(verbose=False)
     if dist is not None:
         dist.barrier()
+    build_info = rank_agreement(dist, nvsf_build)  # every rank loads the library rank 0 built: same version, same sources
     from nvsf import synthetic as S
     from nvsf.nerf.models.network_static import NeRFNetworkStatic
 
@@ -620,7 +655,11 @@ def main():
         g = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
         print("per-step GPU ms:", " ".join(f"{v:.2f}" for v in g), file=sys.stderr)
         print("per-step host enqueue ms:", " ".join(f"{v * 1e3:.2f}" for v in host), file=sys.stderr)
+    per_rank_ms = [elapsed / args.steps * 1e3]
     if dist is not None:
+        every = [None] * world
+        dist.all_gather_object(every, elapsed)
+        per_rank_ms = [float(v) / args.steps * 1e3 for v in every]
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -638,6 +677,8 @@ def main():
                        "hash_grid": "L16 F2 T2^19 base16 max2048", "sigma_mlp": "32-64-16", "heads": "lidar 2x(87-64-64-1), rgb 31-64-64-3",
                        "pass": "forward render (no_grad): one wave-per-ray launch per batch (+ the XCD-sliced encode pass for the camera batch)", "parallelism": f"frame-sharded x{world}, no collective"},
             "outputs_finite": finite, "spinup_ms": args.spinup_ms,
+            "per_rank_ms_per_step": per_rank_ms, "ranks_seen": build_info["ranks_seen"],
+            "build": {k: build_info[k] for k in ("version", "csrc_digest", "lib_sha1", "ranks_agree")},
         }
         if same_device:
             line["invalid"] = "NVSF_BENCH_SAME_DEVICE=1: all ranks shared cuda:0 (control-flow check only)"

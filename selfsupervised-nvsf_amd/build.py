@@ -39,6 +39,18 @@ def csrc_digest(unit="fused_field.hip"):
     return h.hexdigest()[:16]
 
 
+def csrc_digest_all():
+    """sha1 over EVERY translation unit, every header and the flags: identifies the library as a whole (bench.py checks that all
+    ranks run the same build; profiles of the secondary legs are tagged with it)."""
+    import hashlib
+    h = hashlib.sha1(" ".join(FLAGS).encode())
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith(".hip") or f.endswith(".h"):
+            h.update(f.encode())
+            h.update(open(os.path.join(CSRC, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 

@@ -141,6 +141,8 @@ class GradBuckets:
         self._cuda = self.params[0].is_cuda
         self._comm = torch.cuda.Stream(device=self.params[0].device) if (self._cuda and self.ws > 1) else None
         self.n_collectives = 0
+        self._timing = []  # (bucket, start event, end event) of the last step's bucket all-reduces, on the communication stream
+        self.payload_bytes = sum(f.numel() * 4 for f in self.flat)  # what one step's bucket all-reduces carry (+ 4 B per parameter of flags)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] if hooks else []
 
     def close(self):
@@ -154,6 +156,7 @@ class GradBuckets:
         self._handles, self._fired, self.n_collectives = [], set(), 0
         self._events = [[] for _ in self.buckets]
         self._hold, self._held = False, []
+        self._timing = []
         for flat in self.flat:
             flat.zero_()
         for p in self.params:
@@ -216,10 +219,28 @@ class GradBuckets:
                     for ev in self._events[b]:
                         self._comm.wait_event(ev)
                     with torch.cuda.stream(self._comm):
-                        self._handles.append(dist.all_reduce(self.flat[b], op=dist.ReduceOp.SUM, async_op=True))
+                        # RCCL runs the collective on a stream of its own; work.wait() makes THIS (communication) stream wait for
+                        # it without blocking the host, so the event pair brackets the collective's device time
+                        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        t0.record()
+                        work = dist.all_reduce(self.flat[b], op=dist.ReduceOp.SUM, async_op=True)
+                        work.wait()
+                        t1.record()
+                        self._handles.append(work)
+                        self._timing.append((b, t0, t1))
                 else:
                     self._handles.append(dist.all_reduce(self.flat[b], op=dist.ReduceOp.SUM, async_op=True))
                 self.n_collectives += 1
+
+    def allreduce_ms(self):
+        """Device time of each bucket all-reduce of the LAST step on the communication stream, [(bucket, MB, ms)] -- waits for them.
+        (RCCL on a GPU node; empty on the CPU / gloo path.)  For the scaling record: the ring estimate is
+        2 (W - 1) / W x payload / per-link rate."""
+        out = []
+        for b, t0, t1 in self._timing:
+            t1.synchronize()
+            out.append((b, self.flat[b].numel() * 4 / 1e6, t0.elapsed_time(t1)))
+        return out
 
     def finish(self):
         if self._cuda:

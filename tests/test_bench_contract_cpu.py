@@ -98,3 +98,28 @@ def test_committed_bench_line_follows_the_contract():
         assert leg in d, leg
     for row in d["raymarching"]["kernels"] + d["field_ops"]["kernels"] + d["kernels"]:
         assert row["ms"] > 0 and row["frac"] > 0 and row["bound"] in ("hbm", "mfma", "l1")  # l1: L2-resident gathers (secondary rows only)
+
+
+def test_two_rank_line_carries_what_a_scaling_run_is_checked_by():
+    """The N > 1 control flow of bench.py as it ran on a 1-GPU box (two ranks sharing cuda:0 over gloo, NVSF_BENCH_SAME_DEVICE=1, line
+    tagged `invalid`): the fields the first real 8-GPU run will be checked by must be there -- every rank loaded the same library
+    (version, digest of all kernel sources, sha1 of the shared object), how many ranks each rank saw, every rank's own step time,
+    and for the training leg the gradient all-reduce's payload, bucket times and the ring estimate it is to be compared with."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[3-9]*_bench2_same_device_line.json")))
+    assert files, "no round-3 two-rank line committed"
+    d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and "invalid" in d
+    assert d["ranks_seen"] == {"min": 2, "max": 2, "answered": 2}
+    assert d["build"]["ranks_agree"] is True and len(d["build"]["csrc_digest"]) == 16 and d["build"]["version"].startswith("nvsf_hip")
+    assert len(d["per_rank_ms_per_step"]) == 2 and max(d["per_rank_ms_per_step"]) == pytest_approx(d["ms_per_step"])
+    tr = d["train"]
+    assert len(tr["per_rank_ms_per_step"]) == 2 and tr["allreduce_collectives_per_step"] >= 2
+    ar = tr["allreduce"]
+    assert ar["payload_MB"] > 90 and ar["buckets"] == len(ar["per_bucket"]) and ar["sum_ms"] > 0  # two 24.4 M-entry tables + MLPs, fp32
+    assert abs(sum(b["MB"] for b in ar["per_bucket"]) - ar["payload_MB"]) < 1e-6
+    assert ar["ring_estimate_ms"] == pytest_approx(2.0 * (2 - 1) / 2 * ar["payload_MB"] * 1e6 / 153e9 * 1e3)
+
+
+def pytest_approx(v, rel=1e-6):
+    import pytest
+    return pytest.approx(v, rel=rel)
