@@ -33,6 +33,13 @@ typedef struct ihipStream_t* nvsf_stream_t; /* == hipStream_t */
 /* library / build identification: returns a static string "nvsf_hip <version> gfx950" */
 const char* nvsf_version(void);
 
+/* TEST-ONLY: selects a second formulation of an operator -- the one the tests pin the production form against -- for every later
+ * call of this process: name in {"march", "planes_fwd", "planes_bwd", "hashgrid_fwd", "hashgrid_bwd", "hash4d_bwd", "slice_plan",
+ * "render_tail"}, value 0 = the production form (the default), 1 (march: 1, 2) = the reference form.  Returns the previous value,
+ * or NVSF_ERR_INVALID_ARG.  Not thread-safe; results of either form are the same operator's (bit-identical or within the
+ * tolerances stated in tests/).  No stream argument: nothing is launched. */
+int nvsf_test_variant(const char* name, int value);
+
 /* ------------------------------------------------------------------------------------------------
  * Section 1: the `_raymarching` extension (ref: nvsf/nerf/raymarching/src/raymarching.h:6-96,
  * registered by src/bindings.cpp:5-21).  Argument order follows the reference launchers.

@@ -21,6 +21,22 @@ static inline int nvsf_launch_status() {
 
 static inline unsigned cdiv(unsigned long long a, unsigned b) { return (unsigned)((a + b - 1) / b); }
 
+// Test-only choice of a kernel formulation (include/nvsf_hip.h: nvsf_test_variant; version.hip).  Every operator has ONE production
+// form (value 0) and, where a second formulation is kept as the reference the tests compare it with, that one under value 1 (2).
+// Launchers read a plain int here -- no environment look-ups on the call path.
+enum NvsfVariantKey : int {
+    kVarMarch = 0,      // march_rays_train: 0 wave kernels / one launch, 1 one thread per ray, 2 wave kernels walking a batch member by member
+    kVarPlanesFwd,      // 0 rows walked along the ray, 1 one thread per (sample, scale)
+    kVarPlanesBwd,      // 0 run-merging, 1 one atomic per (sample, texel, channel)
+    kVarHashgridFwd,    // 0 level-per-XCD where eligible, 1 the generic row kernel
+    kVarHashgridBwd,    // 0 corner-parallel run merging, 1 one thread per (row, level)
+    kVarHash4dBwd,      // 0 LDS accumulation, 1 run-merging global atomics
+    kVarSlicePlan,      // 0 balanced slices, 1 every group its own slice
+    kVarRenderTail,     // 0 two tiles per iteration, 1 one tile
+    kVarCount
+};
+int nvsf_variant(int key);
+
 // ---- wave-level primitives (64 lanes) -------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 

@@ -1756,8 +1756,7 @@ static int density_uniform_impl(const float* rays_o, const float* rays_d, const 
             const uint32_t units32 = (M + 31u) / 32u;
             uint32_t ps = (units32 + kWavesPerBlock - 1) / kWavesPerBlock;
             if (ps > 512u) ps = 512u;  // 32 CUs per XCD x 8 resident workgroups x 2 (measured: 256 -> 512 gains 1.5 %)
-            const char* plan_env = getenv("NVSF_SLICE_PLAN");  // "home": every group its own slice only (A/B timing)
-            const SlicePlan plan = slice_plan(units32, T, h_res, first_hashed, !(plan_env && plan_env[0] == 'h'));
+            const SlicePlan plan = slice_plan(units32, T, h_res, first_hashed, nvsf_variant(kVarSlicePlan) == 0);  // 1 (tests): every group its own slice only
             float* x01 = train ? train->x01 : nullptr;
             if (T % 32u == 0u)
                 hipLaunchKernelGGL((k_encode_sliced_pairs<2, true>), dim3(8u * ps), dim3(kBlock), 0, stream, rb, tb, (uint32_t)table_bytes, meta, L,
@@ -1963,8 +1962,7 @@ NVSF_API int nvsf_render_uniform_fwd(const float* rays_o, const float* rays_d, c
 #define LAUNCH_TAIL(LD)                                                                                                               \
     hipLaunchKernelGGL((k_render_tail2<LD>), grid_dim, block, 0, stream, rb, fp, ws, wa, wb, k_scale, w_thresh, b0, b1, b2, use_bg, z_vals, \
                        weights, weights_sum, depth, image)
-    const char* tail_env = getenv("NVSF_RENDER_TAIL");  // "1": one tile per iteration (k_render_uniform<*, true>), A/B timing only
-    const bool tail2 = !(tail_env && tail_env[0] == '1');
+    const bool tail2 = nvsf_variant(kVarRenderTail) == 0;  // 1 (tests): one tile per iteration (k_render_uniform<*, true>)
     if (lidar) { if (fp) { if (tail2) LAUNCH_TAIL(true); else LAUNCH_RU(true, true); } else LAUNCH_RU(true, false); }
     else { if (fp) { if (tail2) LAUNCH_TAIL(false); else LAUNCH_RU(false, true); } else LAUNCH_RU(false, false); }
 #undef LAUNCH_TAIL

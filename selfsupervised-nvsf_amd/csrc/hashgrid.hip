@@ -343,8 +343,7 @@ NVSF_API int nvsf_hashgrid_fwd(const float* x, uint32_t M, uint32_t x_stride, co
             const uint32_t rows = h_offsets[l + 1] - h_offsets[l];
             sliced = cells > rows && (rows & (rows - 1u)) == 0u;  // hashed, power-of-two table
         }
-        const char* variant = getenv("NVSF_HASHGRID_FWD");  // "generic": the one-workgroup-per-64-samples kernel (the test reference)
-        if (sliced && !(variant && variant[0] == 'g')) {
+        if (sliced && nvsf_variant(kVarHashgridFwd) == 0) {  // 1 (tests): the one-workgroup-per-64-samples kernel, the reference form
             const uint32_t units = (M + 31u) / 32u;
             uint32_t ps = (units + kBlock / kWave - 1) / (kBlock / kWave);
             if (ps > 512u) ps = 512u;
@@ -374,10 +373,9 @@ NVSF_API int nvsf_hashgrid_bwd(const float* x, uint32_t M, uint32_t x_stride, co
     const int st = fill_meta(meta, L, h_scales, h_res, h_offsets);
     if (st != NVSF_OK) return st;
     const uint32_t c0 = cols[0], c1 = cols[1], c2 = D == 3 ? cols[2] : 0;
-    // production form: corner-parallel run merging.  NVSF_HASHGRID_BWD=atomic selects the plain one-thread-per-(row, level)
-    // kernel, which is also the fallback for shapes whose 2^D x F lanes do not divide the levels evenly (the test reference)
-    const char* variant = getenv("NVSF_HASHGRID_BWD");
-    if (!(variant && variant[0] == 'a') && L % (kWave / ((1u << D) * F)) == 0) {
+    // production form: corner-parallel run merging.  Variant 1 (tests) selects the plain one-thread-per-(row, level) kernel,
+    // which is also the fallback for shapes whose 2^D x F lanes do not divide the levels evenly
+    if (nvsf_variant(kVarHashgridBwd) == 0 && L % (kWave / ((1u << D) * F)) == 0) {
         const uint32_t run = M >= (1u << 20) ? 128u : 32u;  // rows per item: long runs once there is enough work to fill the chip
         const uint32_t ipw = kWave / ((1u << D) * F);
         const unsigned long long waves = ((unsigned long long)cdiv(M, run) * L + ipw - 1) / ipw;

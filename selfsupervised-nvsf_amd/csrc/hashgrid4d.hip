@@ -646,9 +646,8 @@ NVSF_API int nvsf_hashgrid4d_dynamic_bwd_scalar(const float* x, uint32_t x_strid
         if (st != NVSF_OK) return st;
     }
     // LDS form: one launch per group of pairs with the same level size (pair 0: 2^15 rows = 128 KB of LDS, 1024-thread workgroups;
-    // pairs 1, 2: 2^13 rows = 32 KB).  NVSF_HASH4D_BWD=runs selects the run-merging global-atomic kernel (the test reference; also
+    // pairs 1, 2: 2^13 rows = 32 KB).  Variant 1 (tests) selects the run-merging global-atomic kernel (the reference form; also
     // taken when a level does not fit LDS or the batch is too small to fill the chip with slices).
-    const char* variant = getenv("NVSF_HASH4D_BWD");
     uint32_t max_rows[3];
     bool fits = true;
     for (int p = 0; p < 3; ++p) {
@@ -659,7 +658,7 @@ NVSF_API int nvsf_hashgrid4d_dynamic_bwd_scalar(const float* x, uint32_t x_strid
         }
         fits = fits && max_rows[p] * sizeof(float) <= 128u * 1024u;
     }
-    if (fits && M >= (1u << 16) && !(variant && variant[0] == 'r')) {
+    if (fits && M >= (1u << 16) && nvsf_variant(kVarHash4dBwd) == 0) {
         int p = 0;
         while (p < 3) {
             int q = p + 1;

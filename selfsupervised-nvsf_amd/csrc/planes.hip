@@ -457,9 +457,8 @@ NVSF_API int nvsf_planes_fwd(const float* xt, uint32_t M, const float* planes_cl
     PlaneMeta meta;
     const int st = fill_plane_meta(meta, n_scales, h_res);
     if (st != NVSF_OK) return st;
-    const char* variant = getenv("NVSF_PLANES_FWD");  // "sample": one thread per (sample, scale) -- the first formulation, test reference
     const bool runs_ok = n_scales == 4;
-    if ((variant && variant[0] == 's') || !runs_ok) {
+    if (nvsf_variant(kVarPlanesFwd) != 0 || !runs_ok) {  // 1 (tests): one thread per (sample, scale) -- the first formulation, the reference form
         hipLaunchKernelGGL(k_planes_fwd, dim3(cdiv(M, kBlock), n_scales), dim3(kBlock), 0, stream, xt, M, planes_cl, meta, want, out_static,
                            out_dynamic);
         return nvsf_launch_status();
@@ -512,8 +511,7 @@ NVSF_API int nvsf_planes_bwd(const float* xt, uint32_t M, const float* planes_cl
     PlaneMeta meta;
     const int st = fill_plane_meta(meta, n_scales, h_res);
     if (st != NVSF_OK) return st;
-    const char* variant = getenv("NVSF_PLANES_BWD");  // "atomic": one atomic per (sample, texel, channel) (first formulation; tests, A/B)
-    if (variant && variant[0] == 'a') {
+    if (nvsf_variant(kVarPlanesBwd) != 0) {  // 1 (tests): one atomic per (sample, texel, channel), the first formulation
         hipLaunchKernelGGL(k_planes_bwd, dim3(cdiv(M, kBlock)), dim3(kBlock), 0, stream, xt, M, planes_cl, meta, want, grad_static,
                            grad_dynamic, grad_planes_cl, grad_xt);
         return nvsf_launch_status();

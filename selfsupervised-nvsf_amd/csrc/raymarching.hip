@@ -961,8 +961,8 @@ NVSF_API int nvsf_march_rays_train(const float* rays_o, const float* rays_d, con
     if (N == 0) return NVSF_OK;
     REQUIRE(rays_o && rays_d && grid && nears && fars && xyzs && dirs && deltas && rays && counter && noises);
     REQUIRE(C >= 1 && C <= 8 && H >= 2 && H <= 1024 && max_steps >= 1);
-    const char* variant = getenv("NVSF_MARCH");  // "thread": one thread per ray (first formulation, A/B timing and tests)
-    if (variant && variant[0] == 't') {
+    const int variant = nvsf_variant(kVarMarch);  // tests: 1 = one thread per ray (first formulation), 2 = wave kernels, batch walked member by member
+    if (variant == 1) {
         hipLaunchKernelGGL(k_march_count, dim3(cdiv(N, kBlock)), dim3(kBlock), 0, stream, rays_o, rays_d, grid, bound, dt_gamma,
                            max_steps, N, C, H, nears, fars, noises, rays);
         hipLaunchKernelGGL(k_march_scan, dim3(1), dim3(1024), 0, stream, N, rays, counter);
@@ -970,7 +970,7 @@ NVSF_API int nvsf_march_rays_train(const float* rays_o, const float* rays_d, con
                            max_steps, N, C, H, M, nears, fars, noises, rays, xyzs, dirs, deltas);
         return nvsf_launch_status();
     }
-    const int serial = variant && variant[0] == 's';  // "serial": wave kernels with the batch walked member by member (tests, A/B)
+    const int serial = variant == 2;
     const dim3 wgrid(cdiv(N, kBlock / kWave));
     hipLaunchKernelGGL(k_march_count_wave, wgrid, dim3(kBlock), 0, stream, rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H,
                        nears, fars, noises, rays, serial);
@@ -1001,8 +1001,7 @@ NVSF_API int nvsf_march_rays_train_ws(const float* rays_o, const float* rays_d, 
     REQUIRE(rays_o && rays_d && grid && nears && fars && xyzs && dirs && deltas && rays && counter && noises && workspace);
     REQUIRE(C >= 1 && C <= 8 && H >= 2 && H <= 1024 && max_steps >= 1);
     REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 7u) == 0 && workspace_bytes >= nvsf_march_rays_train_ws_bytes(N));
-    const char* variant = getenv("NVSF_MARCH");
-    const int serial = variant && variant[0] == 's';  // "serial": the batch walked member by member (tests, A/B)
+    const int serial = nvsf_variant(kVarMarch) == 2;  // tests: the batch walked member by member
     if (hipMemsetAsync(workspace, 0, nvsf_march_rays_train_ws_bytes(N), stream) != hipSuccess) return (int)hipGetLastError();
     const bool off32 = (unsigned long long)M * 12ull < (1ull << 32), plain = dt_gamma == 0.0f && !serial;
     auto kernel = off32 ? (plain ? k_march_train_onepass<true, true> : k_march_train_onepass<true, false>)

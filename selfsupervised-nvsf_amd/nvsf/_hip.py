@@ -110,6 +110,8 @@ def load():
     lib.nvsf_march_rays_train_ws_bytes.argtypes = [_U]
     lib.nvsf_version.restype = ctypes.c_char_p
     lib.nvsf_version.argtypes = []
+    lib.nvsf_test_variant.restype = ctypes.c_int
+    lib.nvsf_test_variant.argtypes = [ctypes.c_char_p, ctypes.c_int]
     _lib = lib
     return lib
 

@@ -5,13 +5,13 @@ the trainer needs.  No arithmetic of the hot path happens in Python: every funct
 kernel launch on the current stream, forward and backward.
 """
 import math
-import os as _os
 
 import numpy as np
 import torch
 from torch.autograd import Function
 
 from nvsf import _hip
+from nvsf import testing as _testing
 
 W_THRESH = 1e-4  # colour is only evaluated where the compositing weight exceeds this (renderer_dynamic.py:202)
 
@@ -278,8 +278,8 @@ def heads(model, d01, geo_feat, cal_lidar_color, ray_dirs01=None, geo16=None):
     n_enc_cols = enc.n_output_dims
     # per-ray direction rows read by the MLP kernels themselves (shared-prefix rows): no [M, in_cols] input matrix at all
     prefix_mode = (ray_dirs01 is not None and n_enc_cols % 8 == 0 and M % ray_dirs01.shape[0] == 0 and (M // ray_dirs01.shape[0]) % 16 == 0
-                   and spec.n_in - n_enc_cols <= 16 and spec.n_hidden <= 2 and _os.environ.get("NVSF_HEADS_INPUT") != "rows")  # "rows": the
-    # assembled [M, in_cols] input (test reference)
+                   and spec.n_in - n_enc_cols <= 16 and spec.n_hidden <= 2 and _testing.get("heads_input") == "prefix")  # tests: "rows" =
+    # the assembled [M, in_cols] input
     buf = None if prefix_mode else torch.empty(M, spec.in_cols, dtype=torch.float16, device=geo_feat.device)
     with torch.no_grad():
         src = d01 if ray_dirs01 is None else ray_dirs01
@@ -755,13 +755,12 @@ def prefer_sliced(spec, N, T, ray_length, bound, coherent=False):
     encode pass: LiDAR 0.27 + 0.20 ms tail against 0.36 ms for the one-launch gather form).  `ray_length` is the caller's
     host-side estimate of far - near.  `coherent`: the batch is a run of consecutive pixels of a frame (staged evaluation) --
     neighbouring rays then ask for neighbouring cells and the one-launch gather form finds them in L1 / L2 (measured on whole
-    frames: 51.5 against 62.8 ms per frame, 19.4 against 15.9 frames/s).  NVSF_DENSITY_SLICED=0/1 overrides."""
-    import os
+    frames: 51.5 against 62.8 ms per frame, 19.4 against 15.9 frames/s).  Tests force either form (testing.variant(density_sliced=...))."""
     if not (spec.L == 16 and spec.F == 2 and spec.D == 3 and N * T < 2 ** 32):
         return False
-    forced = os.environ.get("NVSF_DENSITY_SLICED")
+    forced = _testing.get("density_sliced")
     if forced is not None:
-        return forced == "1"
+        return bool(forced)
     if coherent:
         return False
     table_bytes = spec.n_params * 2

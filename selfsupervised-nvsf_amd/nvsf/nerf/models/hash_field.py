@@ -16,13 +16,13 @@ device tensors and branches on `idx1 == idx2` (one device->host sync per plane p
 come from one host copy of t per call.
 """
 import math
-import os
 
 import numpy as np
 import torch
 from torch import nn
 
 import tinycudann as tcnn
+from nvsf import testing
 
 
 _HOST_TIME_CACHE = {}  # id(tensor) -> (weakref, version, value): the last few time tensors read back
@@ -154,7 +154,7 @@ class HashGrid4D(nn.Module):
             first = self.hash_dynamic[0]
             fp32_regime = torch.is_tensor(t) and t.dim() > 0
             if (fp32_regime and not x.requires_grad and first.n_levels == 8 and first.n_features_per_level == 4 and first.num_basis == 4
-                    and os.environ.get("NVSF_HASH4D_TRAIN", "fused") == "fused"):
+                    and testing.get("hash4d_train") == "fused"):
                 # fused forward + fused table-gradient kernel (csrc/hashgrid4d.hip) instead of six per-slice encoder calls,
                 # their blends / Lagrange reductions and six backward launches
                 idx = np.float32(t_host) * np.float32(first.time_resolution - 1)
@@ -200,7 +200,7 @@ class HashGrid4D(nn.Module):
         table-gradient kernel (HashDyn3Fn), or None when the fused training path does not apply."""
         first = self.hash_dynamic[0]
         if not (torch.is_grad_enabled() and torch.is_tensor(t) and t.dim() > 0 and not x.requires_grad and first.n_levels == 8
-                and first.n_features_per_level == 4 and first.num_basis == 4 and os.environ.get("NVSF_HASH4D_TRAIN", "fused") == "fused"):
+                and first.n_features_per_level == 4 and first.num_basis == 4 and testing.get("hash4d_train") == "fused"):
             return None
         idx = np.float32(t_host) * np.float32(first.time_resolution - 1)
         k1, k2 = int(math.floor(idx)), int(math.ceil(idx))

@@ -17,13 +17,13 @@ them is the same tensor algebra as the reference.  Differences, all host-side: `
 (`planes_encoder`, `hash_encoder`, `unet`: network_dynamic.py:47-65,192, excluded from the optimiser at :337-338)
 are not instantiated, so DistributedDataParallel needs no find_unused_parameters.
 """
-import os
 
 import numpy as np
 import torch
 
 import tinycudann as tcnn
 from nvsf import field_ops as ops
+from nvsf import testing
 from nvsf.nerf.activation import trunc_exp
 from nvsf.nerf.models.flow_field import FlowField
 from nvsf.nerf.models.hash_field import HashGrid4D, _host_time
@@ -89,7 +89,7 @@ class NeRFNetwork(NeRFRenderer):
         hash_enc = self.hash_encoder_lidar if cal_lidar_color else self.hash_encoder_camera
         planes_enc = self.planes_encoder_lidar if cal_lidar_color else self.planes_encoder_camera
 
-        if not torch.is_grad_enabled() and t.shape[0] == 1 and os.environ.get("NVSF_DYNAMIC_FUSED", "1") != "0":
+        if not torch.is_grad_enabled() and t.shape[0] == 1 and testing.get("dynamic_fused"):
             return self._dynamic_features_fused(x, t, t_host, frame_idx, hash_enc, planes_enc, fp16)
         t_col = t.repeat(x.shape[0], 1) if t.shape[0] == 1 else t
         xt = torch.cat([x, t_col], dim=-1)
@@ -161,7 +161,7 @@ class NeRFNetwork(NeRFRenderer):
         if not torch.is_grad_enabled():
             # fused tail (csrc/density_dynamic.hip): neighbour blend + concatenation + density MLP in one kernel
             h = self._density_tail_fused(plane_s, plane_d, plane_1, plane_2, hash_s, hash_d, hash_1, hash_2)
-        elif (os.environ.get("NVSF_DENSITY_TAIL_TRAIN", "fused") == "fused" and self.sigma_net.spec.in_cols == 128
+        elif (testing.get("density_tail_train") == "fused" and self.sigma_net.spec.in_cols == 128
               and self.sigma_net.spec.n_hidden == 1 and hash_s.dtype == torch.float16 and plane_s.dtype == torch.float32
               and hash_d.dtype == torch.float32 and not hash_1.requires_grad and not hash_2.requires_grad):
             # neighbour blend + concatenation + density MLP as ONE forward launch that also leaves the rounded network input

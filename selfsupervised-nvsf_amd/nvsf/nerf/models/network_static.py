@@ -12,13 +12,13 @@ Two execution paths, numerically equivalent (tests/test_render_static_gpu.py):
   * operator path (`density` / `color`): stand-alone HIP operators with autograd -- used for training;
   * `fused_uniform_render`: three fused kernels per ray batch -- used whenever no gradient is recorded.
 """
-import os
 
 import numpy as np
 import torch
 
 import tinycudann as tcnn
 from nvsf import field_ops as ops
+from nvsf import testing
 from nvsf.nerf import activation
 from nvsf.nerf.activation import trunc_exp
 from nvsf.nerf.models.renderer_dynamic import NeRFRenderer
@@ -58,7 +58,7 @@ class NeRFNetworkStatic(NeRFRenderer):
         enc = self.hash_encoder_lidar if cal_lidar_color else self.hash_encoder_camera
         net = self.sigma_net
         if (x.is_cuda and x.dim() == 2 and enc.spec.D == 3 and net.spec.n_hidden <= 2 and net.spec.hidden == 64
-                and net.spec.out_cols == 16 and os.environ.get("NVSF_DENSITY_FN", "fused") != "chain"):
+                and net.spec.out_cols == 16 and testing.get("density_fn") == "fused"):
             # one autograd node for encode -> MLP -> trunc_exp / slice (ops.DensityFn): same forward kernels, leaner backward
             sigma, geo = ops.DensityFn.apply(x, enc.params, enc.table_f16(), enc.spec, net.params, net.weights_f16(), net.spec,
                                              activation._LO, activation._HI)

@@ -30,3 +30,32 @@ def dev(hip_lib):
     if not torch.cuda.is_available():
         pytest.fail("gpu-marked test started without a HIP device: there is no CPU fallback for the HIP path")
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def variants(hip_lib):
+    """Test-only selection of reference formulations (nvsf.testing.variant) with set / clear calls; whatever is still selected when
+    the test ends is put back."""
+    import contextlib
+    from nvsf import testing
+
+    class Variants:
+        def __init__(self):
+            self._active = {}
+
+        def set(self, **choices):
+            for name, value in choices.items():
+                self.clear(name)
+                stack = contextlib.ExitStack()
+                stack.enter_context(testing.variant(**{name: value}))
+                self._active[name] = stack
+
+        def clear(self, name):
+            stack = self._active.pop(name, None)
+            if stack is not None:
+                stack.close()
+
+    v = Variants()
+    yield v
+    for name in list(v._active):
+        v.clear(name)

@@ -42,7 +42,7 @@ def test_sliced_equals_fused_bitwise(dev, lidar, N, T, noise):
 
 
 @pytest.mark.parametrize("N,T", [(400, 768), (700, 381)])  # T % 32 == 0 (scalar ray cursor) and ragged
-def test_balanced_slice_plan_writes_the_same_planes(dev, N, T, monkeypatch):
+def test_balanced_slice_plan_writes_the_same_planes(dev, N, T, variants):
     """Above 8192 units of 32 samples the encode pass moves the tail of the heavy slices (pairs of levels) to the workgroups of
     the light ones (slice_plan, fused_field.hip).  Who encodes a unit must not change what is written: the planes, z and the
     sigma MLP's outputs equal those of the home plan (every XCD its own slice) and of the single-launch kernel bit for bit."""
@@ -55,12 +55,12 @@ def test_balanced_slice_plan_writes_the_same_planes(dev, N, T, monkeypatch):
     assert (N * T + 31) // 32 >= 8192
     outs = {}
     for plan in ("model", "home"):
-        monkeypatch.setenv("NVSF_SLICE_PLAN", plan)
+        variants.set(slice_plan={"model": "balanced", "home": "home"}[plan])
         bufs = (torch.zeros(N, T, device=dev), torch.zeros(N, T, device=dev), torch.zeros(N, T, 16, dtype=torch.float16, device=dev),
                 torch.zeros(16, N * T, dtype=torch.int32, device=dev))
         ops.density_uniform(*args, sliced=True, _buffers=bufs)
         outs[plan] = bufs
-    monkeypatch.delenv("NVSF_SLICE_PLAN")
+    variants.clear("slice_plan")
     for a, b in zip(outs["model"], outs["home"]):
         assert torch.equal(a, b)
     ref = ops.density_uniform(*args, sliced=False)
@@ -68,10 +68,10 @@ def test_balanced_slice_plan_writes_the_same_planes(dev, N, T, monkeypatch):
         assert torch.equal(a, b)
 
 
-def test_sliced_render_matches_oracle(dev, monkeypatch):
+def test_sliced_render_matches_oracle(dev, variants):
     """Whole camera render through the sliced path (forced) against the CPU oracle composition, 1e-4."""
     from nvsf import synthetic as S
-    monkeypatch.setenv("NVSF_DENSITY_SLICED", "1")
+    variants.set(density_sliced=True)
     m = _model(dev, 0.1)
     rng = np.random.default_rng(13)
     N, T = 160, 128
@@ -122,7 +122,7 @@ def test_prefer_sliced_choice_and_rejections(dev):
 
 @pytest.mark.parametrize("lidar", [True, False])
 @pytest.mark.parametrize("N,T,noise", [(64, 128, False), (37, 100, True), (3, 16, False), (200, 768, True), (5, 7, False), (9, 48, False)])
-def test_two_tile_tail_equals_one_tile_tail_and_gather_render(dev, lidar, N, T, noise, monkeypatch):
+def test_two_tile_tail_equals_one_tile_tail_and_gather_render(dev, lidar, N, T, noise, variants):
     """The sliced render's tail kernel takes two MFMA tiles per iteration (k_render_tail2: every weight fragment read from LDS
     feeds two MFMAs).  Per-tile arithmetic is that of the one-tile kernel, so all five outputs are bit-identical -- also for
     ragged T (last pair half empty, T < 16) -- and equal to the one-launch gather render up to its own fp32 scan order."""
@@ -136,9 +136,9 @@ def test_two_tile_tail_equals_one_tile_tail_and_gather_render(dev, lidar, N, T, 
     args = (o, d, nears, fars, T, m._aabb_host, float(m.bound), enc.table_f16(), enc.spec, m.sigma_net.weights_f16(), lidar, heads[0], heads[1],
             m._k_scale(), None if lidar else [1.0, 0.5, 0.25], nz)
     two = ops.render_uniform(*args, sliced=True)
-    monkeypatch.setenv("NVSF_RENDER_TAIL", "1")
+    variants.set(render_tail="one")
     one = ops.render_uniform(*args, sliced=True)
-    monkeypatch.delenv("NVSF_RENDER_TAIL")
+    variants.clear("render_tail")
     for x, y, name in zip(two, one, ("z_vals", "weights", "weights_sum", "depth", "image")):
         assert torch.equal(x, y), name
     gather = ops.render_uniform(*args, sliced=False)

@@ -50,7 +50,7 @@ def test_planes4d_forward_backward(dev):
 
 
 @pytest.mark.parametrize("dynamic_only", [False, True])
-def test_planes_backward_run_merging_equals_per_sample_atomics(dev, dynamic_only, monkeypatch):
+def test_planes_backward_run_merging_equals_per_sample_atomics(dev, dynamic_only, variants):
     """The run-merging plane-gradient kernel (default) against the one-atomic-per-(sample, texel, channel) kernel -- itself
     pinned by the reference's autograd above -- on ray-ordered rows (long runs inside one texel quad at the coarse scales,
     a constant time coordinate as in a training step), both `want` forms, M not a multiple of the chunk length."""
@@ -65,7 +65,7 @@ def test_planes_backward_run_merging_equals_per_sample_atomics(dev, dynamic_only
     grads = {}
     for variant in ("runs", "atomic"):
         if variant == "atomic":
-            monkeypatch.setenv("NVSF_PLANES_BWD", "atomic")
+            variants.set(planes_bwd="atomic")
         torch.manual_seed(0)
         enc = Planes4D(resolution=[32, 32, 32, 8], multiscale_res=[1, 2, 4, 8]).to(dev)
         xt = _t(xt_np, dev).requires_grad_()
@@ -129,7 +129,7 @@ def test_hashgrid4d_and_flow(dev):
 
 
 @pytest.mark.parametrize("t_val", [0.37, 0.0, 1.0])  # between two slices / exactly on the first / on the last slice
-def test_hashgrid4d_fused_training_path_equals_the_per_slice_path(dev, t_val, monkeypatch):
+def test_hashgrid4d_fused_training_path_equals_the_per_slice_path(dev, t_val, variants):
     """HashDynFn (fused forward + fused table-gradient kernel) against the per-slice operator path (six tcnn.Encoding calls,
     blend, Lagrange reduction through autograd): same features, same gradients on the same slice parameters, none elsewhere."""
     from nvsf.nerf.models.hash_field import HashGrid4D
@@ -142,7 +142,7 @@ def test_hashgrid4d_fused_training_path_equals_the_per_slice_path(dev, t_val, mo
     t = torch.tensor([[t_val]], dtype=torch.float32, device=dev)
     res = {}
     for mode in ("fused", "ops"):
-        monkeypatch.setenv("NVSF_HASH4D_TRAIN", mode)
+        variants.set(hash4d_train={"fused": "fused", "ops": "slices"}[mode])
         torch.manual_seed(0)
         enc = HashGrid4D(base_resolution=16, max_resolution=512, time_resolution=4, n_levels=8, n_features_per_level=4, log2_hashmap_size=12,
                          hash_size_dynamic=[11, 10, 10]).to(dev)
@@ -167,7 +167,7 @@ def test_hashgrid4d_fused_training_path_equals_the_per_slice_path(dev, t_val, mo
 
 
 @pytest.mark.parametrize("flow_scale,t_val", [(1e-3, 0.5), (0.05, 0.5), (0.05, 0.0), (0.05, 1.0)])
-def test_fused_dynamic_features_equal_the_separate_launches(dev, flow_scale, t_val, monkeypatch):
+def test_fused_dynamic_features_equal_the_separate_launches(dev, flow_scale, t_val, variants):
     """The no-grad density query with in-kernel `x + flow` for the neighbour hash grids and in-place neighbour coordinates,
     against the launch-by-launch form -- bit for bit, with small and with large flows, first / last frame included."""
     from nvsf.nerf.models.network_dynamic import NeRFNetwork
@@ -182,7 +182,7 @@ def test_fused_dynamic_features_equal_the_separate_launches(dev, flow_scale, t_v
     t = torch.tensor([[t_val]], device=dev)
     outs = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("NVSF_DYNAMIC_FUSED", mode)
+        variants.set(dynamic_fused=mode == "1")
         with torch.no_grad():
             feats = m._dynamic_features(m._unit_cube(x), t, True)
             dens = m.density(x, t, cal_lidar_color=True)
@@ -198,7 +198,7 @@ def test_fused_dynamic_features_equal_the_separate_launches(dev, flow_scale, t_v
 
 
 @pytest.mark.parametrize("t_val", [0.4, 0.0])  # interior frame (two neighbours) / first frame (one neighbour aliases the current frame)
-def test_density_tail_training_path_equals_the_operator_path(dev, t_val, monkeypatch):
+def test_density_tail_training_path_equals_the_operator_path(dev, t_val, variants):
     """DensityTailFn (blend + concatenation + density MLP in one forward launch, fused MLP backward, gradient handed back per
     input with the blend factors) against the operator path (torch blends, torch.cat, tcnn.Network autograd): density outputs
     and every parameter gradient of a density query."""
@@ -207,7 +207,7 @@ def test_density_tail_training_path_equals_the_operator_path(dev, t_val, monkeyp
     t = torch.tensor([[t_val]], device=dev)
     res = {}
     for mode in ("fused", "ops"):
-        monkeypatch.setenv("NVSF_DENSITY_TAIL_TRAIN", mode)
+        variants.set(density_tail_train={"fused": "fused", "ops": "chain"}[mode])
         torch.manual_seed(4)
         m = NeRFNetwork(time_resolution=4, num_frames=16, bound=2.0, min_resolution=16, base_resolution=32, max_resolution=512,
                         log2_hashmap_size=13).to(dev)
@@ -237,7 +237,7 @@ def test_density_tail_training_path_equals_the_operator_path(dev, t_val, monkeyp
     assert n >= 20
 
 
-def test_flow_grid_training_path_equals_the_operator_path(dev, monkeypatch):
+def test_flow_grid_training_path_equals_the_operator_path(dev):
     """FlowGridFn (fused grid + Lagrange forward kernel, table gradient straight from dL/d(reduced)) against encoder ->
     .float() -> lagrange_reduce through autograd: flows and the gradient of the grid table and of the Linear layers."""
     from nvsf.nerf.models.flow_field import FlowField
@@ -457,9 +457,9 @@ def test_training_graph_gradients_match_reference(dev, net, key):
 
 
 @pytest.mark.parametrize("M,kind", [(64 * 50, "rays"), (1000, "random"), (7, "random"), (64 * 33 + 5, "rays")])
-def test_planes_forward_along_rays_is_bit_identical_and_multi_eval(dev, M, kind, monkeypatch):
+def test_planes_forward_along_rays_is_bit_identical_and_multi_eval(dev, M, kind, variants):
     """k_planes_fwd_runs (items walk consecutive rows and re-gather only when a plane's texel cell changes) against the
-    one-thread-per-(sample, scale) kernel it replaces (NVSF_PLANES_FWD=sample; itself pinned by the reference's fixtures):
+    one-thread-per-(sample, scale) kernel it replaces (testing.variant(planes_fwd="sample"); itself pinned by the reference's fixtures):
     bit-identical static and dynamic features on ray-ordered and on random rows; and nvsf_planes_multi_fwd (static + dynamic +
     two flow-warped dynamic evaluations in one launch) equals the separate calls on explicitly built [M,4] inputs."""
     from nvsf.nerf.models.planes_field import Planes4D
@@ -484,9 +484,9 @@ def test_planes_forward_along_rays_is_bit_identical_and_multi_eval(dev, M, kind,
     with torch.no_grad():
         s1, d1 = enc(xt)
         d_only = enc.forward_dynamic(xt)
-        monkeypatch.setenv("NVSF_PLANES_FWD", "sample")
+        variants.set(planes_fwd="sample")
         s0, d0 = enc(xt)
-        monkeypatch.delenv("NVSF_PLANES_FWD")
+        variants.clear("planes_fwd")
         assert torch.equal(s1, s0) and torch.equal(d1, d0) and torch.equal(d_only, d0)
         flow = (torch.rand(M, 8, device=dev) - 0.5) * 0.02  # rows wider than the six flow components (padded MLP output)
         t1, t2 = 0.4, 0.34375
@@ -504,9 +504,9 @@ def test_planes_forward_along_rays_is_bit_identical_and_multi_eval(dev, M, kind,
         assert hs.dtype == torch.float16 and torch.equal(hs, bs.half()) and torch.equal(hd, bd.half())
 
 
-def test_dynamic_hash_gradient_through_lds_equals_the_run_merging_kernel(dev, monkeypatch):
+def test_dynamic_hash_gradient_through_lds_equals_the_run_merging_kernel(dev, variants):
     """nvsf_hashgrid4d_dynamic_bwd_scalar: the LDS form (a workgroup accumulates one level of one pair -- 2^13 / 2^15 scalar sums --
-    in LDS and adds it to the global sums once) against the run-merging global-atomic kernel (NVSF_HASH4D_BWD=runs, itself pinned
+    in LDS and adds it to the global sums once) against the run-merging global-atomic kernel (testing.variant(hash4d_bwd="runs"), itself pinned
     through HashDynFn against the per-slice autograd path above): same sums up to fp32 addition order, on ray-ordered rows, with
     zero gradients mixed in, accumulating into non-zero buffers."""
     import ctypes
@@ -530,7 +530,7 @@ def test_dynamic_hash_gradient_through_lds_equals_the_run_merging_kernel(dev, mo
     out = {}
     for variant in ("lds", "runs"):
         if variant == "runs":
-            monkeypatch.setenv("NVSF_HASH4D_BWD", "runs")
+            variants.set(hash4d_bwd="runs")
         sums = [torch.full((s.n_rows,), 0.5, dtype=torch.float32, device=dev) for s in specs]
         _hip.call("nvsf_hashgrid4d_dynamic_bwd_scalar", _hip.ptr(x), 3, M, h_scales, h_res, h_off, _hip.ptr(g),
                   (ctypes.c_void_p * 3)(*[t.data_ptr() for t in sums]))

@@ -57,7 +57,7 @@ def test_hashgrid_forward_bit_exact(ops, dev, case):
     assert np.array_equal(got.view(np.uint16), ref.view(np.uint16))
 
 
-def test_hashgrid_forward_one_level_per_xcd_is_bit_identical(ops, dev, monkeypatch):
+def test_hashgrid_forward_one_level_per_xcd_is_bit_identical(ops, dev, variants):
     """Eight hashed F = 4 levels on a large batch take k_hashgrid_fwd_levels8 (one level per XCD, two lanes per sample).  Same fma
     chains as the generic kernel: equal bit for bit, also on a ragged batch, boundary samples and a strided input; a sample of
     the rows is checked against the oracle."""
@@ -69,9 +69,9 @@ def test_hashgrid_forward_one_level_per_xcd_is_bit_identical(ops, dev, monkeypat
     table = (rng.standard_normal(spec.n_params) * 0.5).astype(np.float16)
     xd, td = _t(x, dev), _t(table, dev)
     got = ops.hashgrid_forward(xd, (0, 1, 2), td, spec)
-    monkeypatch.setenv("NVSF_HASHGRID_FWD", "generic")
+    variants.set(hashgrid_fwd="generic")
     ref = ops.hashgrid_forward(xd, (0, 1, 2), td, spec)
-    monkeypatch.delenv("NVSF_HASHGRID_FWD")
+    variants.clear("hashgrid_fwd")
     assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
     rows = np.concatenate([np.arange(64), rng.integers(0, M, 400), np.arange(M - 40, M)])
     exp = O.hashgrid_fwd(x[rows], (0, 1, 2), table, spec)
@@ -104,11 +104,11 @@ def test_hashgrid_backward(ops, dev):
 
 @pytest.mark.parametrize("D,L,F,log2_T,base,top", [(3, 16, 2, 14, 16, 512), (3, 8, 4, 12, 16, 256), (3, 16, 8, 12, 32, 2048), (2, 8, 4, 10, 16, 256)])
 @pytest.mark.parametrize("variant", ["corners", "atomic"])
-def test_hashgrid_backward_kernels_agree_with_the_oracle(ops, dev, D, L, F, log2_T, base, top, variant, monkeypatch):
+def test_hashgrid_backward_kernels_agree_with_the_oracle(ops, dev, D, L, F, log2_T, base, top, variant, variants):
     """The production form of the table gradient (corner-parallel run merging) and the plain one-thread-per-(row, level) kernel
     (fallback shape + test reference) on ray-ordered rows -- long runs inside one cell at the coarse levels, a new cell per
     row at the fine ones -- with zero-gradient rows and zero features mixed in, fp32 and fp16 gradients."""
-    monkeypatch.setenv("NVSF_HASHGRID_BWD", variant)
+    variants.set(hashgrid_bwd=variant)
     spec = _spec(ops, D, L, F, log2_T, base, top)
     rng = np.random.default_rng(D * 100 + L + F)
     n_rays, T = 37, 97  # M is not a multiple of the chunk length

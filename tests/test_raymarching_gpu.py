@@ -96,8 +96,8 @@ def test_packbits(rm, dev, scene):
 
 @pytest.mark.parametrize("march", ["wave", "serial", "thread"])  # wave-per-ray ChainWalker kernels (default: whole batches decided at once; serial: member by member) / one thread per ray
 @pytest.mark.parametrize("n,max_steps,dt_gamma,perturb_seed", [(4096, 1024, 0.0, None), (1000, 256, 1.0 / 128, 7), (1, 64, 0.0, None)])
-def test_march_rays_train(rm, dev, scene, n, max_steps, dt_gamma, perturb_seed, march, monkeypatch):
-    monkeypatch.setenv("NVSF_MARCH", march)
+def test_march_rays_train(rm, dev, scene, n, max_steps, dt_gamma, perturb_seed, march, variants):
+    variants.set(march=march)
     o, d = _rays(n, 6, "lidar" if n == 1000 else "cam")
     aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
     nears, fars = O.near_far_from_aabb(o, d, aabb, 0.02)
@@ -256,7 +256,7 @@ def test_march_rays_train_ws_more_tickets_than_workgroups(rm, dev, p, dt_gamma):
 
 @pytest.mark.parametrize("kind", ["random10", "random50", "dense", "empty", "scene"])
 @pytest.mark.parametrize("dt_gamma,max_steps", [(0.0, 1024), (0.0, 300), (1.0 / 256, 512)])
-def test_march_rays_train_wave_forms_equal_the_thread_form(rm, dev, scene, kind, dt_gamma, max_steps, monkeypatch):
+def test_march_rays_train_wave_forms_equal_the_thread_form(rm, dev, scene, kind, dt_gamma, max_steps, variants):
     """The one-thread-per-ray kernels are pinned to the oracle above; here the wave kernels (closed-form chain,
     batch-parallel visit decision, and the serial walk) must reproduce them bit for bit on grids that stress the skip
     logic: per-cell random occupancy (a jump every few members), fully occupied, empty, and the blocky test scene."""
@@ -278,7 +278,7 @@ def test_march_rays_train_wave_forms_equal_the_thread_form(rm, dev, scene, kind,
     M = n * max_steps
     out = {}
     for march in ("thread", "wave", "serial"):
-        monkeypatch.setenv("NVSF_MARCH", march)
+        variants.set(march=march)
         xyzs = torch.zeros(M, 3, device=dev); dirs = torch.zeros(M, 3, device=dev); deltas = torch.zeros(M, 2, device=dev)
         rays = torch.empty(n, 3, dtype=torch.int32, device=dev); counter = torch.zeros(2, dtype=torch.int32, device=dev)
         _hip.call("nvsf_march_rays_train", _hip.ptr(to), _hip.ptr(td), _hip.ptr(tb), 2.0, float(dt_gamma), max_steps, n, 2, 128, M,

@@ -59,7 +59,7 @@ def test_training_reduces_loss_and_metrics(dev):
     assert 0.0 <= r < 80.0
 
 
-def test_density_fn_equals_operator_chain(dev, monkeypatch):
+def test_density_fn_equals_operator_chain(dev, variants):
     """ops.DensityFn (encode -> MLP -> trunc_exp / slice as one autograd node; logit gradient assembled by nvsf_sigma_geo_bwd,
     feature gradient handed to the table scatter in fp32) against the operator chain HashGridFn -> MlpFn -> trunc_exp."""
     from nvsf import synthetic as S
@@ -74,7 +74,7 @@ def test_density_fn_equals_operator_chain(dev, monkeypatch):
     w_sigma, w_geo = torch.randn(M, device=dev), torch.randn(M, 15, device=dev)
 
     def run(mode):
-        monkeypatch.setenv("NVSF_DENSITY_FN", mode)
+        variants.set(density_fn=mode)
         for p in m.parameters():
             p.grad = None
         out = m.density(x, None, cal_lidar_color=True)
@@ -93,7 +93,7 @@ def test_density_fn_equals_operator_chain(dev, monkeypatch):
     assert float(gt0.abs().max()) > 0 and int((gt1 != 0).sum()) >= int((gt0 != 0).sum())
 
     # sigma-only and geo-only graphs (the other gradient arrives as None)
-    monkeypatch.setenv("NVSF_DENSITY_FN", "fused")
+    variants.set(density_fn="fused")
     for sel in ("sigma", "geo_feat"):
         for p in m.parameters():
             p.grad = None
@@ -453,9 +453,9 @@ def test_fused_loss_kernels_match_the_torch_expressions(dev):
 
 
 @pytest.mark.parametrize("lidar", [True, False])
-def test_heads_on_shared_prefix_rows_equal_assembled_rows(dev, lidar, monkeypatch):
+def test_heads_on_shared_prefix_rows_equal_assembled_rows(dev, lidar, variants):
     """ops.heads with per-ray directions lets the MLP kernels read the ray's encoded direction from ONE row per ray
-    (nvsf_mlp_fwd_prefix / nvsf_mlp_bwd_prefix) instead of from an assembled [M, in_cols] matrix (NVSF_HEADS_INPUT=rows): the
+    (nvsf_mlp_fwd_prefix / nvsf_mlp_bwd_prefix) instead of from an assembled [M, in_cols] matrix (testing.variant(heads_input="rows")): the
     operands are the same fp16 values, so the logits are equal bit for bit; parameter and geometry gradients equal up to the
     order of the fp32 atomics of the weight gradients."""
     from nvsf import field_ops as ops, synthetic as S
@@ -471,14 +471,14 @@ def test_heads_on_shared_prefix_rows_equal_assembled_rows(dev, lidar, monkeypatc
     res = {}
     for mode in ("prefix", "rows"):
         if mode == "rows":
-            monkeypatch.setenv("NVSF_HEADS_INPUT", "rows")
+            variants.set(heads_input="rows")
         geo = geo0.clone().requires_grad_()
         for n in nets:
             n.params.grad = None
         out = ops.heads(m, None, geo, lidar, ray_dirs01=dirs01)
         (out * w).sum().backward()
         res[mode] = (out.detach().clone(), geo.grad.clone(), [n.params.grad.clone() for n in nets])
-    monkeypatch.delenv("NVSF_HEADS_INPUT")
+    variants.clear("heads_input")
     assert torch.equal(res["prefix"][0], res["rows"][0])
     assert torch.allclose(res["prefix"][1], res["rows"][1], rtol=1e-5, atol=1e-6 * float(res["rows"][1].abs().max()))
     for a, b in zip(res["prefix"][2], res["rows"][2]):

@@ -1,5 +1,4 @@
-"""Times nvsf_march_rays_train_ws alone (32 768 camera rays x 1024 steps; dense and 10 % per-cell random grid), optionally for a
-list of NVSF_MARCH_AB values (temporary A/B switch of the entry point):  python tools/bench_march_only.py [ab ...]"""
+"""Times nvsf_march_rays_train_ws alone (32 768 camera rays x 1024 steps; dense and 10 % per-cell random grid), N_RAYS / MAX_STEPS / OCC (comma list of occupied fractions) / SORT_RAYS from the environment:  python tools/bench_march_only.py"""
 import os
 import sys
 
@@ -42,7 +41,6 @@ def main():
             _hip.call("nvsf_march_rays_train_ws", P(o), P(d), P(bitfield), bound, 0.0, max_steps, N, C, H, M, P(nears), P(fars),
                       P(xyzs), P(dirs), P(deltas), P(rays), P(counter), P(noises), P(workspace), ws_bytes, 0)
         for ab in abs_:
-            os.environ["NVSF_MARCH_AB"] = ab
             for _ in range(3):
                 run()
             torch.cuda.synchronize()
