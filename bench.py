@@ -25,7 +25,8 @@ One JSON line on stdout (rank 0): metric / value / ... plus
   raymarching   the raymarching-extension kernels (rows a1-a9) against the HBM roofline at non-latency-bound sizes
   field_ops     the stand-alone field operators (rows a12-a17) against their rooflines on the config-2 sample batches
   cpu_baseline  the CPU oracle (oracle/, scalar C port) on a bounded sample of the same workload: one core, and the rays
-                split over a thread pool on all host cores (`cores` = threads used; `one_core` beside it)
+                split over a thread pool on all host cores (`cores` = threads used; `one_core` beside it); `torch_cpu` = the
+                vectorised PyTorch-CPU restatement (oracle/torch_cpu_path.py), all threads and one thread
 """
 import argparse
 import json
@@ -249,6 +250,49 @@ def cpu_baseline(model, T, rays, n_rays, threads=1):
     return ({"value": 2 * n_rays / dt, "unit": "rays/s", "cores": threads, "kind": "port",
              "sample": f"the first {n_rays} LiDAR + {n_rays} camera rays of the timed batches x {T} samples, same field; scalar (unvectorised) C "
                        f"restatement of the path (oracle/*.c) + numpy glue, {threads} thread(s), {dt:.1f} s wall"}, outputs)
+
+
+def torch_cpu_baseline(model, T, rays, n_rays):
+    """The vectorised PyTorch-CPU restatement of the path (oracle/torch_cpu_path.py: the reference's own tensor algebra around torch
+    formulations of the tiny-cuda-nn operators -- what BASELINE.md section 3 planned as the CPU figure) on the first `n_rays` rays per
+    modality of the timed batches: all host threads, then one thread on an eighth of the sample (~20 s of CPU work in all)."""
+    import importlib.util
+    from nvsf import synthetic as S
+    spec_ = importlib.util.spec_from_file_location("torch_cpu_path", os.path.join(ROOT, "oracle", "torch_cpu_path.py"))
+    TP = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(TP)
+    import oracle_lib as O
+    f16 = lambda net: net.params.detach().cpu().to(torch.float16)
+    aabb = np.array([-S.BOUND] * 3 + [S.BOUND] * 3, np.float32)
+    prev = torch.get_num_threads()
+
+    def run(n, threads):
+        torch.set_num_threads(threads)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for lidar in (True, False):
+                o, d = (torch.from_numpy(a[:n]) for a in rays[lidar])
+                enc = model.hash_encoder_lidar if lidar else model.hash_encoder_camera
+                if lidar:
+                    nears, fars = torch.full((n,), float(model.min_near_lidar)), torch.full((n,), float(model.lidar_max_depth))
+                else:
+                    nears, fars = (torch.from_numpy(v) for v in O.near_far_from_aabb(rays[lidar][0][:n], rays[lidar][1][:n], aabb, model.min_near))
+                TP.render_static(o, d, nears, fars, T, float(S.BOUND), f16(enc), enc.spec, f16(model.sigma_net), model.sigma_net.spec, lidar,
+                                 f16(model.raydrop_net if lidar else model.color_net), f16(model.intensity_net) if lidar else None,
+                                 (model.raydrop_net if lidar else model.color_net).spec, k_scale=model._k_scale())
+        return time.perf_counter() - t0
+    try:
+        cores = min(os.cpu_count() or 1, 16)
+        run(min(64, n_rays), cores)  # warm-up (thread pool, allocator)
+        dt_all = run(n_rays, cores)
+        n1 = max(32, n_rays // 8)
+        dt_one = run(n1, 1)
+    finally:
+        torch.set_num_threads(prev)
+    return {"value": 2 * n_rays / dt_all, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"the first {n_rays} LiDAR + {n_rays} camera rays of the timed batches x {T} samples, vectorised PyTorch-CPU restatement "
+                      f"(oracle/torch_cpu_path.py), {cores} threads, {dt_all:.1f} s wall",
+            "one_core": {"value": 2 * n1 / dt_one, "sample": f"{n1} + {n1} rays, 1 thread, {dt_one:.1f} s wall"}}
 
 
 def outputs_match_oracle(out, oracle_outputs, tol=1e-4):
@@ -701,6 +745,7 @@ def main():
                 multi, ref_out = cpu_baseline(model, T, rays, min(args.cpu_rays * min(threads, 8), args.num_rays, args.num_rays_lidar), threads=threads)
                 base, single = multi, base
                 base["one_core"] = {"value": single["value"], "sample": single["sample"]}
+            base["torch_cpu"] = torch_cpu_baseline(model, T, rays, min(2 * args.cpu_rays, args.num_rays, args.num_rays_lidar))
             line["cpu_baseline"] = base
             # the cpu_baseline leg's renders double as the checker of the timed outputs (the oracle is never on the timed path)
             line["outputs_match_oracle"] = outputs_match_oracle(out, ref_out)

@@ -379,3 +379,41 @@ def test_constant_step_chain_closed_form():
             t = np.float32(t + np.float32(c))
         checked += len(got)
     assert checked > 1_000_000
+
+
+def test_torch_cpu_path_matches_the_c_oracle():
+    """oracle/torch_cpu_path.py (the vectorised PyTorch-CPU restatement bench.py times as `cpu_baseline.torch_cpu`) renders the same
+    images as the scalar C oracle: 1e-4 on image / depth / weights_sum for a LiDAR and a camera batch of the config-2 field shape
+    (smaller table)."""
+    import importlib.util
+    import sys
+    import torch
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(ROOT, "selfsupervised-nvsf_amd"))
+    from nvsf import field_ops as ops, synthetic as S
+    spec_ = importlib.util.spec_from_file_location("torch_cpu_path", os.path.join(ROOT, "oracle", "torch_cpu_path.py"))
+    TP = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(TP)
+    rng = np.random.default_rng(2)
+    grid = ops.GridSpec(3, 16, 2, 14, 16, float(np.exp2(np.log2(2048 / 16) / 15)))
+    table = (rng.standard_normal(grid.n_params) * 0.3).astype(np.float16)
+    sig, hl, hc = ops.MlpSpec(32, 16, 64, 1), ops.MlpSpec(87, 1, 64, 2), ops.MlpSpec(31, 3, 64, 2)
+    w = lambda sp: np.concatenate([(rng.uniform(-1, 1, a * b) * np.sqrt(6.0 / (a + b))).astype(np.float16) for a, b in sp.shapes])
+    w_sigma, w_rd, w_int, w_col = w(sig), w(hl), w(hl), w(hc)
+    N, T = 48, 96
+    aabb = np.array([-S.BOUND] * 3 + [S.BOUND] * 3, np.float32)
+    for lidar in (True, False):
+        o, d = (S.lidar_rays if lidar else S.camera_rays)(N, rng)
+        if lidar:
+            nears, fars = np.full(N, S.MIN_NEAR, np.float32), np.full(N, S.LIDAR_MAX_DEPTH, np.float32)
+        else:
+            nears, fars = O.near_far_from_aabb(o, d, aabb, S.MIN_NEAR)
+        ref = O.render_static(o, d, nears, fars, torch.linspace(0.0, 1.0, T).numpy(), None, float(S.BOUND), table, grid, w_sigma, lidar,
+                              w_rd if lidar else w_col, w_int if lidar else None, np.ones(3, np.float32))
+        t = torch.from_numpy
+        img, dep, ws = TP.render_static(t(o), t(d), t(nears), t(fars), T, float(S.BOUND), t(table), grid, t(w_sigma), sig, lidar,
+                                        t(w_rd if lidar else w_col), t(w_int) if lidar else None, hl if lidar else hc)
+        assert float(ref["weights_sum"].max()) > 0.05
+        np.testing.assert_allclose(img.numpy(), ref["image"], atol=1e-4, rtol=0)
+        np.testing.assert_allclose(dep.numpy(), ref["depth"], atol=1e-4, rtol=0)
+        np.testing.assert_allclose(ws.numpy(), ref["weights_sum"], atol=1e-4, rtol=0)
