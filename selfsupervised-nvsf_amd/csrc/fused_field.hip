@@ -262,15 +262,32 @@ struct TrainOut {
     float* x01;       // [M, 3]
     _Float16* feat;   // [M, 32], column 2 l + f
     float* h32;       // [M, 16] = (h0 .. h15)
+    uint32_t* tile;   // device side only: this wave's LDS transpose tile (kTrWords dwords)
 };
 
-// lane group g of a tile holds rotated output rows 4g .. 4g+3 = network outputs (4g+1 .. 4g+4) mod 16 of sample s
-__device__ __forceinline__ void store_h32(float* __restrict__ h32, unsigned long long s, int g, const float4_t& o) {
-    float* row = h32 + s * 16;
-    row[4 * g + 1] = o[0];
-    row[4 * g + 2] = o[1];
-    row[4 * g + 3] = o[2];
-    row[(4 * g + 4) & 15] = o[3];
+// The four lane groups of a tile (lanes sl, sl + 16, sl + 32, sl + 48) hold the pieces of sample sl's rows interleaved; both
+// helpers below move them between the lane groups first (ds_bpermute: the LDS pipe is idle in these kernels) so that every lane
+// stores ONE aligned 16-byte piece and a wave instruction writes 16 whole rows -- written as 4-byte pieces the same rows cost the
+// training forward 150 us per 3.1 M samples.  Every lane of the wave must call them (cross-lane reads), `ok` gates the store.
+//
+// lane group g holds rotated output rows 4g .. 4g+3 = network outputs (4g+1 .. 4g+4) mod 16: output 4g comes from group g - 1
+__device__ __forceinline__ void store_h32(float* __restrict__ h32, unsigned long long s, int lane, int g, float o0, float o1, float o2, float o3, bool ok) {
+    const int from = (lane + 48) & 63;  // same sample, previous lane group
+    const float prev = __int_as_float(__builtin_amdgcn_ds_bpermute(from << 2, __float_as_int(o3)));
+    if (ok) *reinterpret_cast<float4*>(h32 + s * 16 + 4 * g) = make_float4(prev, o0, o1, o2);
+}
+
+// lane group g holds the encoded features of levels g, 4+g, 8+g, 12+g as the dwords p.x .. p.w; row dword j = level j, and group g
+// stores dwords 4g .. 4g+3: a 4 x 4 transpose over the lane groups, through a per-wave LDS tile (rows of 20 dwords: 16-byte
+// aligned, at most 2-way bank conflicts)
+constexpr int kTrPitch = 20;
+constexpr int kTrWords = 16 * kTrPitch;  // per wave
+__device__ __forceinline__ void store_feat_row(_Float16* __restrict__ feat, unsigned long long s, int lane, int g, const uint4& p, bool ok,
+                                               uint32_t* tile) {
+    uint32_t* row = tile + (lane & 15) * kTrPitch;
+    row[g] = p.x; row[4 + g] = p.y; row[8 + g] = p.z; row[12 + g] = p.w;
+    const uint4 mine = *reinterpret_cast<const uint4*>(row + 4 * g);  // same wave: LDS operations complete in order
+    if (ok) *reinterpret_cast<uint4*>(feat + s * 32 + 8 * g) = mine;
 }
 
 // density_eval + store of sigma / geo / z.
@@ -291,14 +308,11 @@ __device__ __forceinline__ void density_tile(const DensityCtx<F>& cx, const floa
         half8_t h[kHidSteps];
         pack_hidden(acc1, h);
         o = cx.wout.apply(h);
-        if (in_range) {
-            // fragment element q * F + f of lane group g = feature (4 q + g) * F + f: four 4-byte pieces of the sample's 64-byte row
-            const uint4 pieces = __builtin_bit_cast(uint4, xf);
-            uint32_t* row = reinterpret_cast<uint32_t*>(tr->feat + s * 32);
-            row[g] = pieces.x; row[4 + g] = pieces.y; row[8 + g] = pieces.z; row[12 + g] = pieces.w;
-            store_h32(tr->h32, s, g, o);
-            if (g == 0) { tr->x01[3 * s] = x[0]; tr->x01[3 * s + 1] = x[1]; tr->x01[3 * s + 2] = x[2]; }
-        }
+        // fragment element q * F + f of lane group g = feature (4 q + g) * F + f: four 4-byte pieces of the sample's 64-byte row
+        const int lane = lane_id();
+        store_feat_row(tr->feat, s, lane, g, __builtin_bit_cast(uint4, xf), in_range, tr->tile);
+        store_h32(tr->h32, s, lane, g, o[0], o[1], o[2], o[3], in_range);
+        if (in_range && g == 0) { tr->x01[3 * s] = x[0]; tr->x01[3 * s + 1] = x[1]; tr->x01[3 * s + 2] = x[2]; }
     } else {
         o = density_eval<F, QG>(cx, x);
     }
@@ -356,6 +370,8 @@ __global__ __launch_bounds__(kBlock) void k_density_uniform_v2(RayBatch rb, cons
     }
     cx.wout.load(w_sigma + kHidden * 32, lane, 1);
     cx.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(table), 0, (int)table_bytes, 0x00020000);
+    __shared__ uint32_t s_tr[TRAIN ? kWavesPerBlock * kTrWords : 1];
+    if constexpr (TRAIN) tr.tile = s_tr + (threadIdx.x >> 6) * kTrWords;
 
     const uint32_t wave_global = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     const uint32_t wave_count = gridDim.x * kWavesPerBlock;
@@ -730,6 +746,7 @@ __global__ __launch_bounds__(kBlock) void k_density_from_features(const uint2* _
     }
     OutLayerW wout;
     wout.load(w_sigma + kHidden * 32, lane, 1);
+    __shared__ uint32_t s_tr[TRAIN ? kWavesPerBlock * kTrWords : 1];
     const uint2* plane0 = feat + (size_t)(2 * g) * M;
     const uint2* plane1 = feat + (size_t)(2 * g + 1) * M;
     const uint32_t n_tiles = (M + 15u) / 16u;
@@ -761,12 +778,11 @@ __global__ __launch_bounds__(kBlock) void k_density_from_features(const uint2* _
             half8_t h[kHidSteps];
             pack_hidden(acc1, h);
             const float4_t o = wout.apply(h);
+            if constexpr (TRAIN) {  // feature rows in level order (fragment pieces = levels g, g+4, g+8, g+12) and the fp32 outputs
+                store_feat_row(tr.feat, s[u], lane, g, make_uint4(packed.x, packed.y, packed.z, packed.w), ok[u], s_tr + (threadIdx.x >> 6) * kTrWords);
+                store_h32(tr.h32, s[u], lane, g, o[0], o[1], o[2], o[3], ok[u]);
+            }
             if (ok[u]) {
-                if constexpr (TRAIN) {  // feature rows in level order (fragment pieces = levels g, g+4, g+8, g+12) and the fp32 outputs
-                    uint32_t* row = reinterpret_cast<uint32_t*>(tr.feat + (size_t)s[u] * 32);
-                    row[g] = packed.x; row[4 + g] = packed.y; row[8 + g] = packed.z; row[12 + g] = packed.w;
-                    store_h32(tr.h32, s[u], g, o);
-                }
                 half4_t ov;
                 ov[0] = (_Float16)o[0]; ov[1] = (_Float16)o[1]; ov[2] = (_Float16)o[2]; ov[3] = (_Float16)o[3];
                 if (g == 3) {
