@@ -614,22 +614,23 @@ PLANE_PAIRS = ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))  # itertools.comb
 
 
 class PlanesFn(Function):
-    """(xt [M,4], planes channel-last buffer) -> static [M, S*8] and / or dynamic [M, S*8] features.
-
-    `plane_params` is the flat tuple of the 6*S reference-layout parameters [1, C, H, W]; they only receive
-    the gradient (the forward reads `planes_cl`, their channel-last copy)."""
+    """(xt [M,4], planes_cl: every plane channel-last in one fp32 buffer = Planes4D's parameter) -> static [M, S*8] and / or dynamic
+    [M, S*8] features.  The gradient of `planes_cl` is the buffer the backward kernel scatters into, as it is."""
 
     @staticmethod
-    def forward(ctx, xt, planes_cl, res_host, want, *plane_params):
+    def forward(ctx, xt, planes_cl, res_host, want):
         xt = xt.float().contiguous()
         M, S = xt.shape[0], len(res_host) // 4
         dev = xt.device
+        cl = planes_cl.detach()
+        if cl.dtype != torch.float32 or not cl.is_contiguous():
+            cl = cl.float().contiguous()
         out_s = torch.empty(M, S * 8, dtype=torch.float32, device=dev) if want & 1 else None
         out_d = torch.empty(M, S * 8, dtype=torch.float32, device=dev) if want & 2 else None
-        _hip.call("nvsf_planes_fwd", _hip.ptr(xt), M, _hip.ptr(planes_cl), S, 8, _hip.host_u32(res_host), int(want), _hip.ptr(out_s),
+        _hip.call("nvsf_planes_fwd", _hip.ptr(xt), M, _hip.ptr(cl), S, 8, _hip.host_u32(res_host), int(want), _hip.ptr(out_s),
                   _hip.ptr(out_d))
-        ctx.save_for_backward(xt, planes_cl)
-        ctx.res_host, ctx.want, ctx.shapes = res_host, want, [p.shape for p in plane_params]
+        ctx.save_for_backward(xt, cl)
+        ctx.res_host, ctx.want = res_host, want
         outs = tuple(o for o in (out_s, out_d) if o is not None)
         return outs if len(outs) > 1 else outs[0]
 
@@ -640,23 +641,13 @@ class PlanesFn(Function):
         gi = iter(grads)
         g_s = next(gi).float().contiguous() if want & 1 else None
         g_d = next(gi).float().contiguous() if want & 2 else None
-        need_p = any(ctx.needs_input_grad[4:])
-        need_x = ctx.needs_input_grad[0]
+        need_x, need_p = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         g_planes = torch.zeros_like(planes_cl) if need_p else None
         g_xt = torch.empty_like(xt) if need_x else None
         if need_p or need_x:
             _hip.call("nvsf_planes_bwd", _hip.ptr(xt), xt.shape[0], _hip.ptr(planes_cl), S, 8, _hip.host_u32(ctx.res_host), int(want),
                       _hip.ptr(g_s), _hip.ptr(g_d), _hip.ptr(g_planes), _hip.ptr(g_xt))
-        g_params = [None] * len(ctx.shapes)
-        if need_p:
-            off = 0
-            for i, shp in enumerate(ctx.shapes):  # channel-last [H, W, C] slices back to the reference layout [1, C, H, W]
-                _, C, H, W = shp
-                # a strided view: autograd's accumulation (copy into .grad the first time, += afterwards) reads it in place --
-                # materialising it first costs one more small launch per plane and call (144 per step of the space-time model)
-                g_params[i] = g_planes[off:off + H * W * C].view(H, W, C).permute(2, 0, 1).unsqueeze(0)
-                off += H * W * C
-        return (g_xt, None, None, None, *g_params)
+        return g_xt, g_planes, None, None
 
 
 # ------------------------------------------------------------------------------------------------

@@ -1,6 +1,6 @@
 """K-planes space-time encoder (`Planes4D`) for MI355X.
 
-Same constructor, parameter tree (`planes.<scale>.<pair>` of shape [1, C, res_b, res_a]; time planes initialised
+Same constructor, checkpoint schema (`planes.<scale>.<pair>` of shape [1, C, res_b, res_a]; time planes initialised
 to 1, spatial planes U(0.1, 0.5)), `n_output_dims` and `forward` / `forward_static` / `forward_dynamic` results as
 /root/reference/nvsf/nerf/models/planes_field.py:142-238, so reference checkpoints load unchanged.  The 24
 `F.grid_sample` launches + products + concatenations of the reference are one HIP kernel (csrc/planes.hip) that
@@ -16,6 +16,15 @@ from nvsf import field_ops as ops
 
 
 class Planes4D(nn.Module):
+    """Parameter storage.  The reference keeps 6 x n_scales parameters `planes.<scale>.<pair>` of shape [1, C, res_b, res_a]
+    (planes_field.py:31-52, 172-190).  Here they are ONE parameter, `planes_cl`: every plane channel-last ([H][W][C], one texel =
+    32 contiguous bytes = what the kernels gather), one after the other, fp32.  The kernels read it as it is (no per-step copy of
+    24 permuted planes), the backward kernel's gradient buffer IS its gradient (no per-plane permute + accumulate launches), and
+    the optimiser / EMA / gradient all-reduce see one tensor instead of 24 (the training step of the space-time model made ~200
+    launches per step around the per-plane parameters).  state_dict()/load_state_dict() speak the reference's schema: the
+    `planes.<scale>.<pair>` keys with [1, C, H, W] tensors (hooks below), so reference checkpoints load unchanged and ours load
+    there; `plane(scale, pair)` / `plane_grad(scale, pair)` give [1, C, H, W] views for inspection."""
+
     def __init__(self, grid_dimensions=2, input_dim=4, output_dim=8, resolution=[32, 32, 32, 8], multiscale_res=[1, 2, 4, 8],
                  concat_ms_feat=True, decompose=True, reduction="prod"):
         super().__init__()
@@ -25,40 +34,73 @@ class Planes4D(nn.Module):
         self.multiscale_res, self.concat_ms_feat, self.decompose, self.reduction = multiscale_res, concat_ms_feat, decompose, reduction
         pairs = list(itertools.combinations(range(input_dim), grid_dimensions))
         assert tuple(pairs) == ops.PLANE_PAIRS
-        self.planes = nn.ModuleList()
-        res_host = []
-        for mult in multiscale_res:
+        res_host, self._layout, pieces, off = [], [], [], 0
+        for si, mult in enumerate(multiscale_res):
             reso = [r * mult for r in resolution[:3]] + list(resolution[3:])  # multi-resolution on the spatial axes only
             res_host += reso
-            group = nn.ParameterList()
-            for a, b in pairs:
-                p = nn.Parameter(torch.empty(1, output_dim, reso[b], reso[a]))
+            for pi, (a, b) in enumerate(pairs):
+                p = torch.empty(1, output_dim, reso[b], reso[a])  # the reference's tensor, initialised as the reference does (same RNG stream)
                 if b == 3:
                     nn.init.ones_(p)
                 else:
                     nn.init.uniform_(p, a=0.1, b=0.5)
-                group.append(p)
-            self.planes.append(group)
+                pieces.append(p[0].permute(1, 2, 0).reshape(-1))
+                self._layout.append((si, pi, off, output_dim, reso[b], reso[a]))
+                off += p.numel()
+        self.planes_cl = nn.Parameter(torch.cat(pieces).contiguous())
         self._res_host = tuple(res_host)
         self.n_output_dims = output_dim * len(multiscale_res) * 2
-        self._cl_key, self._cl = None, None
+        self._register_state_dict_hook(Planes4D._export_reference_keys)
+        self._register_load_state_dict_pre_hook(self._import_reference_keys)
 
-    def _flat_params(self):
-        return [p for group in self.planes for p in group]
+    # ---- the reference's per-plane view of the one parameter ---------------------------------------------------------------
+    def _view(self, flat, si, pi):
+        _, _, off, C, H, W = self._layout[si * len(ops.PLANE_PAIRS) + pi]
+        return flat[off:off + C * H * W].view(H, W, C).permute(2, 0, 1).unsqueeze(0)
+
+    def plane(self, si, pi):
+        """[1, C, res_b, res_a] view of plane (scale si, pair pi) -- the tensor the reference calls planes.<si>.<pi>."""
+        return self._view(self.planes_cl.detach(), si, pi)
+
+    def plane_grad(self, si, pi):
+        return None if self.planes_cl.grad is None else self._view(self.planes_cl.grad, si, pi)
+
+    def reference_named_parameters(self, prefix=""):
+        """(name, value view, gradient view or None) under the reference's names."""
+        for si, pi, *_ in self._layout:
+            yield f"{prefix}planes.{si}.{pi}", self.plane(si, pi), self.plane_grad(si, pi)
+
+    @staticmethod
+    def _export_reference_keys(module, state, prefix, local_metadata):
+        flat = state.pop(prefix + "planes_cl")
+        for si, pi, *_ in module._layout:
+            state[f"{prefix}planes.{si}.{pi}"] = module._view(flat, si, pi).contiguous()
+        return state
+
+    def _import_reference_keys(self, state, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        keys = [f"{prefix}planes.{si}.{pi}" for si, pi, *_ in self._layout]
+        if prefix + "planes_cl" in state or not any(k in state for k in keys):
+            return
+        flat = self.planes_cl.detach().clone()
+        for (si, pi, off, C, H, W), k in zip(self._layout, keys):
+            if k in state:
+                t = state.pop(k)
+                if tuple(t.shape) != (1, C, H, W):
+                    error_msgs.append(f"size mismatch for {k}: {tuple(t.shape)} in the checkpoint, {(1, C, H, W)} in the model")
+                    continue
+                flat[off:off + C * H * W] = t.to(flat.device, flat.dtype)[0].permute(1, 2, 0).reshape(-1)
+            elif strict:
+                missing_keys.append(k)
+        state[prefix + "planes_cl"] = flat
 
     def _channel_last(self):
-        """One buffer with every plane as [H][W][C]; rebuilt only when a parameter changed."""
-        params = self._flat_params()
-        key = tuple((p.data_ptr(), p._version) for p in params)
-        if key != self._cl_key:
-            with torch.no_grad():
-                self._cl = torch.cat([p.detach()[0].permute(1, 2, 0).reshape(-1) for p in params]).float().contiguous()
-            self._cl_key = key
-        return self._cl
+        """The buffer the kernels read: the parameter itself."""
+        p = self.planes_cl
+        return p if (p.dtype == torch.float32 and p.is_contiguous()) else p.detach().float().contiguous()
 
     def _encode(self, xt, want):
         xt = xt.reshape(-1, 4)
-        return ops.PlanesFn.apply(xt, self._channel_last(), self._res_host, want, *self._flat_params())
+        return ops.PlanesFn.apply(xt, self.planes_cl, self._res_host, want)
 
     @torch.no_grad()
     def forward_multi(self, x, evals, blend=False, out_f16=False):

@@ -20,10 +20,26 @@ def _seed(name):
     return zlib.crc32(name.encode()) % 100000
 
 
+def reference_named(model):
+    """{reference parameter name: (value, gradient or None)} of a module tree of this repo OR of the reference: this repo's Planes4D
+    keeps its 24 planes in one channel-last parameter (`planes_cl`) and presents them under the reference's `planes.<scale>.<pair>`
+    names as [1, C, H, W] views (Planes4D.reference_named_parameters)."""
+    out = {}
+    flat_owners = {n: m for n, m in model.named_modules() if hasattr(m, "reference_named_parameters")}
+    for name, p in model.named_parameters():
+        owner = name.rsplit(".", 1)[0] if "." in name else ""
+        if name.endswith("planes_cl") and owner in flat_owners:
+            for rname, value, grad in flat_owners[owner].reference_named_parameters(prefix=(owner + "." if owner else "")):
+                out[rname] = (value, grad)
+        else:
+            out[name] = (p, p.grad)
+    return out
+
+
 def init_by_name(model):
-    """Deterministic, structure-revealing parameter values keyed by parameter name."""
+    """Deterministic, structure-revealing parameter values keyed by (reference) parameter name."""
     with torch.no_grad():
-        for name, p in model.named_parameters():
+        for name, (p, _) in reference_named(model).items():
             if p.numel() == 0:
                 continue
             key = name.split("unet")[0]

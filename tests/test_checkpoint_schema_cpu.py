@@ -29,7 +29,7 @@ def test_state_dict_schema_matches_reference():
     missing, unexpected = m.load_state_dict(fake, strict=False)
     assert missing == [] and all(k.startswith(unused) for k in unexpected)
     assert float(m.hash_encoder_lidar.hash_static.params[0]) == 0.25
-    assert float(m.planes_encoder_camera.planes[2][4][0, 0, 0, 0]) == 0.25
+    assert float(m.planes_encoder_camera.plane(2, 4)[0, 0, 0, 0]) == 0.25
     groups = m.get_params(1e-2)
     assert len(groups) == 11 and [g["lr"] for g in groups][6] == 1e-3  # flow net at 0.1 x lr (network_dynamic.py:345)
 
