@@ -195,7 +195,7 @@ template <int D, int F, bool GRAD_F16>
 __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_corners(const float* __restrict__ x, uint32_t M, uint32_t x_stride, uint32_t c0,
                                                                  uint32_t c1, uint32_t c2, uint32_t L, GridMeta meta,
                                                                  const void* __restrict__ grad_out, uint32_t go_stride,
-                                                                 float* __restrict__ grad_table, uint32_t run) {
+                                                                 float* __restrict__ grad_table, uint32_t run, uint32_t l_end) {
     auto flush = [&](float* dst, float acc) { atomicAdd(dst, acc); };
     constexpr int G = (1 << D) * F;  // lanes per item
     constexpr int IPW = kWave / G;   // items per wave
@@ -211,6 +211,10 @@ __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_corners(const float* __
     const unsigned long long first = (unsigned long long)chunk * run;
     if (first >= M) return;
     const uint32_t m0 = (uint32_t)first, m1 = (uint32_t)(first + run < M ? first + run : M);
+    // levels l_end ... are scattered by the binned kernels below: their items idle (zero gradient = skipped row), a wave all of
+    // whose items are such levels leaves
+    const bool live = l < l_end;
+    if (l - (uint32_t)sub >= l_end) return;  // uniform
     const float scale = meta.scale[l];
     const uint32_t res = meta.res[l], row0 = meta.offset[l], hsize = meta.offset[l + 1] - row0;
     const uint32_t gcol = l * F + (uint32_t)f;
@@ -231,7 +235,8 @@ __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_corners(const float* __
             rw.xs[j][0] = px[c0];
             rw.xs[j][1] = px[c1];
             if constexpr (D == 3) rw.xs[j][2] = px[c2];
-            if constexpr (GRAD_F16) rw.g[j] = (float)reinterpret_cast<const _Float16*>(grad_out)[(size_t)mj * go_stride + gcol];
+            if (!live) rw.g[j] = 0.0f;
+            else if constexpr (GRAD_F16) rw.g[j] = (float)reinterpret_cast<const _Float16*>(grad_out)[(size_t)mj * go_stride + gcol];
             else rw.g[j] = reinterpret_cast<const float*>(grad_out)[(size_t)mj * go_stride + gcol];
         }
     };
@@ -295,6 +300,219 @@ __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_corners(const float* __
         }
     }
     if (acc != 0.0f) flush(dst, acc);
+}
+
+// ---- Binned scatter of the FINE levels ----------------------------------------------------------------------------------------------
+// On the levels whose cells are shorter than a ray step every sample sits in a cell of its own: run merging has nothing to merge and
+// the corner-parallel kernel above pays one memory-side atomic (a read-modify-write of a 64-byte segment, ~41 G/s chip-wide) per
+// corner pair -- 93 M of the 110 M atomic pieces of a config-2 camera batch.  These levels take two streaming passes instead:
+//   k_hashgrid_bwd_bin     (sample tiles): every (sample, corner) contribution {row, w_c * g[0..F)} of a level is appended to the bin
+//                          its table row falls into (bin = kBinRows consecutive rows of one level).  A workgroup sorts a tile's pairs by
+//                          bin in LDS (LDS counters -> ranks -> exclusive scan), reserves its slice of every bin with ONE returning
+//                          atomic per bin and copies the sorted pairs out as contiguous runs; it also records max |g| of the level;
+//   k_hashgrid_bwd_reduce  (bins): a workgroup adds the pairs of its bin into an LDS image of the bin and adds the image to the table
+//                          gradient with contiguous atomics (512 pieces per bin instead of one per pair).  The image is 64-bit FIXED
+//                          POINT (value x 2^(36 - exponent of the level's max |g|), ds_add_u64): LDS float atomics run at a quarter
+//                          of the rate of the integer ones on gfx950 (measured: 1.6 ms against 0.38 ms for the five fine levels of a
+//                          camera batch), and integer sums do not depend on the order of the pairs.  |w g| < 2^(e+1) scales below 2^37,
+//                          a row can take 2^26 contributions before the sum leaves 63 bits (the host limits M x 8 to that); the
+//                          resolution 2^(e-36) is 2^-13 ulp of the largest gradient.
+// A bin holds `cap` pairs (1.25 x the mean of a uniform hash + slack); what does not fit is added to the table directly, so the result is
+// the same sum for any input (only slower when the hash is badly skewed).  Same addends as the other kernels, another order.
+template <int F> struct BinCfg {
+    static constexpr int kTile = F <= 2 ? 512 : 256;      // samples per workgroup tile
+    static constexpr int kPairs = kTile * 8;              // (sample, corner) pairs of a tile and level: 4096 / 2048
+    static constexpr int kBinRows = 8192 / F;             // rows per bin: 64 KB of 64-bit sums
+    static constexpr int kBinShift = F <= 2 ? 12 : 11;
+    static constexpr int kMaxBins = 256;                  // rows per level <= 256 bins (checked on the host)
+};
+
+template <int F, bool GRAD_F16>
+__global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_bin(const float* __restrict__ x, uint32_t M, uint32_t x_stride, uint32_t c0, uint32_t c1,
+                                                             uint32_t c2, GridMeta meta, uint32_t l_first, uint32_t n_fine,
+                                                             const void* __restrict__ grad_out, uint32_t go_stride, float* __restrict__ grad_table,
+                                                             uint32_t* __restrict__ cursors, uint32_t* __restrict__ level_max,
+                                                             uint32_t* __restrict__ pair_row, float* __restrict__ pair_val, uint32_t cap,
+                                                             uint32_t nbins) {
+    using C = BinCfg<F>;
+    constexpr int SPT = C::kTile / kBlock;
+    __shared__ uint32_t s_cnt[C::kMaxBins], s_pre[C::kMaxBins], s_gbase[C::kMaxBins], s_total, s_max;
+    __shared__ uint32_t s_row[C::kPairs];
+    __shared__ float s_val[C::kPairs * F];
+    const int tid = (int)threadIdx.x, lane = lane_id();
+    float xs[SPT][3];
+    uint32_t mrow[SPT];
+#pragma unroll
+    for (int s = 0; s < SPT; ++s) {
+        mrow[s] = blockIdx.x * C::kTile + s * kBlock + tid;
+        const uint32_t mm = mrow[s] < M ? mrow[s] : M - 1;
+        const float* px = x + (size_t)mm * x_stride;
+        xs[s][0] = px[c0];
+        xs[s][1] = px[c1];
+        xs[s][2] = px[c2];
+    }
+    for (uint32_t j = 0; j < n_fine; ++j) {
+        const uint32_t l = l_first + j;
+        const float scale = meta.scale[l];
+        const uint32_t res = meta.res[l], row0 = meta.offset[l], hsize = meta.offset[l + 1] - row0;
+        for (int b = tid; b < C::kMaxBins; b += kBlock) s_cnt[b] = 0u;
+        if (tid == 0) s_max = 0u;
+        __syncthreads();
+        float g[SPT][F], frac[SPT][3];
+        uint32_t pk[SPT][8];
+        float gmax = 0.0f;
+#pragma unroll
+        for (int s = 0; s < SPT; ++s) {
+            bool any = false;
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                const size_t at = (size_t)(mrow[s] < M ? mrow[s] : 0u) * go_stride + l * F + f;
+                if constexpr (GRAD_F16) g[s][f] = (float)reinterpret_cast<const _Float16*>(grad_out)[at];
+                else g[s][f] = reinterpret_cast<const float*>(grad_out)[at];
+                if (mrow[s] >= M) g[s][f] = 0.0f;
+                any = any || g[s][f] != 0.0f;
+                gmax = fmaxf(gmax, fabsf(g[s][f]));
+            }
+            uint32_t cell[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const float pos = fmaf(scale, xs[s][d], 0.5f);
+                const float fl = floorf(pos);
+                frac[s][d] = pos - fl;
+                cell[d] = (uint32_t)(int32_t)fl;
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                pk[s][c] = 0xFFFFFFFFu;
+                if (any) {
+                    const uint32_t cc[3] = {cell[0] + (c & 1u), cell[1] + ((c >> 1) & 1u), cell[2] + ((c >> 2) & 1u)};
+                    const uint32_t row = grid_row<3>(cc, res, hsize);
+                    const uint32_t rank = atomicAdd(&s_cnt[row >> C::kBinShift], 1u);
+                    pk[s][c] = row | (rank << 20);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o));
+        if (lane == 0 && gmax > 0.0f) atomicMax(&s_max, __float_as_uint(gmax));  // non-negative floats order like their bit patterns
+        __syncthreads();
+        if (tid < kWave) {  // exclusive scan of the bin counts, one reservation per bin
+            uint32_t run = 0;
+            for (uint32_t b0 = 0; b0 < nbins; b0 += kWave) {
+                const uint32_t b = b0 + (uint32_t)lane;
+                const uint32_t cnt = b < nbins ? s_cnt[b] : 0u;
+                uint32_t incl = cnt;
+#pragma unroll
+                for (int o = 1; o < kWave; o <<= 1) {
+                    const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
+                    if (lane >= o) incl += up;
+                }
+                if (b < nbins) {
+                    s_pre[b] = run + incl - cnt;
+                    s_gbase[b] = cnt ? atomicAdd(&cursors[j * nbins + b], cnt) : 0u;
+                }
+                run += (uint32_t)__shfl((int)incl, kWave - 1);
+            }
+            if (lane == 0) {
+                s_total = run;
+                if (s_max) atomicMax(&level_max[j], s_max);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < SPT; ++s)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                if (pk[s][c] == 0xFFFFFFFFu) continue;
+                const uint32_t row = pk[s][c] & 0xFFFFFu, rank = pk[s][c] >> 20;
+                const uint32_t at = s_pre[row >> C::kBinShift] + rank;
+                const float w = ((1.0f * ((c & 1) ? frac[s][0] : 1.0f - frac[s][0])) * ((c & 2) ? frac[s][1] : 1.0f - frac[s][1])) *
+                                ((c & 4) ? frac[s][2] : 1.0f - frac[s][2]);
+                s_row[at] = row;
+#pragma unroll
+                for (int f = 0; f < F; ++f) s_val[at * F + f] = w * g[s][f];
+            }
+        __syncthreads();
+        const uint32_t total = s_total;
+        for (uint32_t p = (uint32_t)tid; p < total; p += kBlock) {
+            const uint32_t row = s_row[p], b = row >> C::kBinShift;
+            const uint32_t q = s_gbase[b] + (p - s_pre[b]);
+            if (q < cap) {
+                const size_t at = (size_t)(j * nbins + b) * cap + q;
+                pair_row[at] = row;
+                if constexpr (F == 2) {
+                    *reinterpret_cast<float2*>(pair_val + at * 2) = make_float2(s_val[p * 2], s_val[p * 2 + 1]);
+                } else {
+                    *reinterpret_cast<float4*>(pair_val + at * 4) = make_float4(s_val[p * 4], s_val[p * 4 + 1], s_val[p * 4 + 2], s_val[p * 4 + 3]);
+                }
+            } else {  // the bin is full: add straight to the table
+#pragma unroll
+                for (int f = 0; f < F; ++f)
+                    if (s_val[p * F + f] != 0.0f) atomicAdd(grad_table + ((size_t)row0 + row) * F + f, s_val[p * F + f]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+constexpr int kReduceBlock = 512;
+constexpr int kFixedTop = 36;  // the level's largest |g| has its leading bit at 2^36 in the fixed-point image
+template <int F>
+__global__ __launch_bounds__(kReduceBlock) void k_hashgrid_bwd_reduce(const uint32_t* __restrict__ cursors, const uint32_t* __restrict__ level_max,
+                                                                      const uint32_t* __restrict__ pair_row, const float* __restrict__ pair_val,
+                                                                      uint32_t cap, uint32_t nbins, uint32_t split, GridMeta meta, uint32_t l_first,
+                                                                      float* __restrict__ grad_table) {
+    using C = BinCfg<F>;
+    __shared__ unsigned long long s_acc[C::kBinRows * F];
+    const uint32_t bin_id = blockIdx.x / split, part = blockIdx.x - bin_id * split;
+    const uint32_t j = bin_id / nbins, b = bin_id - j * nbins;
+    uint32_t n = cursors[bin_id];
+    n = n < cap ? n : cap;
+    const uint32_t q0 = (uint32_t)((unsigned long long)n * part / split), q1 = (uint32_t)((unsigned long long)n * (part + 1) / split);
+    if (q0 == q1) return;  // uniform
+    // power-of-two scale: the product is exact, the only rounding is the truncation to an integer
+    const int e = (int)((level_max[j] >> 23) & 0xFFu) - 127;
+    const float to_fixed = __builtin_ldexpf(1.0f, kFixedTop - e);
+    for (int i = (int)threadIdx.x; i < C::kBinRows * F; i += kReduceBlock) s_acc[i] = 0ull;
+    __syncthreads();
+    const uint32_t* pr = pair_row + (size_t)bin_id * cap;
+    const float* pv = pair_val + (size_t)bin_id * cap * F;
+    constexpr int U = 4;
+    for (uint32_t q = q0 + threadIdx.x; q < q1; q += kReduceBlock * U) {
+        uint32_t row[U];
+        float v[U][F];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t qq = q + (uint32_t)u * kReduceBlock;
+            row[u] = qq < q1 ? pr[qq] : 0xFFFFFFFFu;
+            if (qq < q1) {
+                if constexpr (F == 2) {
+                    const float2 t = *reinterpret_cast<const float2*>(pv + (size_t)qq * 2);
+                    v[u][0] = t.x, v[u][1] = t.y;
+                } else {
+                    const float4 t = *reinterpret_cast<const float4*>(pv + (size_t)qq * 4);
+                    v[u][0] = t.x, v[u][1] = t.y, v[u][2] = t.z, v[u][3] = t.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (row[u] == 0xFFFFFFFFu) continue;
+            const uint32_t at = (row[u] & (uint32_t)(C::kBinRows - 1)) * F;
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                const long long fx = (long long)(v[u][f] * to_fixed);
+                if (fx != 0) atomicAdd(&s_acc[at + f], (unsigned long long)fx);
+            }
+        }
+    }
+    __syncthreads();
+    const double from_fixed = (double)__builtin_ldexpf(1.0f, e - kFixedTop);
+    float* dst = grad_table + ((size_t)meta.offset[l_first + j] + (size_t)b * C::kBinRows) * F;
+    for (int i = (int)threadIdx.x; i < C::kBinRows * F; i += kReduceBlock) {
+        const long long sum = (long long)s_acc[i];
+        if (sum != 0) atomicAdd(dst + i, (float)((double)sum * from_fixed));
+    }
 }
 
 int fill_meta(GridMeta& meta, uint32_t L, const float* scales, const uint32_t* res, const uint32_t* offsets) {
@@ -363,31 +581,94 @@ NVSF_API int nvsf_hashgrid_fwd(const float* x, uint32_t M, uint32_t x_stride, co
     return nvsf_launch_status();
 }
 
-NVSF_API int nvsf_hashgrid_bwd(const float* x, uint32_t M, uint32_t x_stride, const uint32_t* cols, uint32_t D, uint32_t L, uint32_t F,
-                               const float* h_scales, const uint32_t* h_res, const uint32_t* h_offsets, const void* grad_out,
-                               int grad_is_f16, uint32_t go_stride, float* grad_table_f32, hipStream_t stream) {
+namespace {
+struct BinPlan {
+    uint32_t nbins, cap;
+    size_t cursors_bytes, rows_bytes, vals_bytes;
+};
+// Workspace of the binned scatter: [cursors: n_fine x nbins u32, max |g| bits: 16 u32 | pair rows: n_fine x nbins x cap u32 | pair values: ... x F fp32]
+bool bin_plan(uint32_t M, uint32_t n_fine, uint32_t F, uint32_t rows_per_level, BinPlan& bp) {
+    if ((F != 2 && F != 4) || n_fine == 0 || n_fine > 16) return false;
+    const uint32_t bin_rows = 8192u / F;
+    if ((rows_per_level & (rows_per_level - 1u)) != 0u || rows_per_level < bin_rows || rows_per_level > (1u << 20)) return false;
+    bp.nbins = rows_per_level / bin_rows;
+    if (bp.nbins > 256u || (unsigned long long)M * 8ull > (1ull << 26)) return false;  // 2^26 contributions per row at most (fixed-point headroom)
+    const unsigned long long mean = ((unsigned long long)M * 8ull + bp.nbins - 1) / bp.nbins;
+    const unsigned long long cap = ((mean + mean / 4 + 2048ull) + 63ull) & ~63ull;
+    if (cap * n_fine * bp.nbins >= (1ull << 32)) return false;
+    bp.cap = (uint32_t)cap;
+    bp.cursors_bytes = (((size_t)(n_fine * bp.nbins + 16u) * sizeof(uint32_t)) + 255u) & ~(size_t)255u;  // cursors + max |g| per level
+    bp.rows_bytes = (size_t)n_fine * bp.nbins * cap * sizeof(uint32_t);
+    bp.vals_bytes = (size_t)n_fine * bp.nbins * cap * F * sizeof(float);
+    return true;
+}
+
+int hashgrid_bwd_launch(const float* x, uint32_t M, uint32_t x_stride, const uint32_t* cols, uint32_t D, uint32_t L, uint32_t F,
+                        const float* h_scales, const uint32_t* h_res, const uint32_t* h_offsets, const void* grad_out, int grad_is_f16,
+                        uint32_t go_stride, float* grad_table_f32, uint32_t fine_from, void* workspace, size_t workspace_bytes,
+                        hipStream_t stream) {
     if (M == 0) return NVSF_OK;
-    REQUIRE(x && cols && grad_out && grad_table_f32 && (D == 2 || D == 3) && go_stride >= L * F);
+    REQUIRE(x && cols && grad_out && grad_table_f32 && (D == 2 || D == 3) && go_stride >= L * F && fine_from <= L);
     for (uint32_t d = 0; d < D; ++d) REQUIRE(cols[d] < x_stride);
     GridMeta meta;
     const int st = fill_meta(meta, L, h_scales, h_res, h_offsets);
     if (st != NVSF_OK) return st;
     const uint32_t c0 = cols[0], c1 = cols[1], c2 = D == 3 ? cols[2] : 0;
+    if (nvsf_variant(kVarHashgridBwd) != 0) fine_from = L;  // tests: every level through the plain kernel
+    if (fine_from < L) {  // levels fine_from ... L-1 through the bins
+        REQUIRE(D == 3 && workspace && (reinterpret_cast<uintptr_t>(workspace) & 255u) == 0);
+        const uint32_t n_fine = L - fine_from, rows = h_offsets[fine_from + 1] - h_offsets[fine_from];
+        for (uint32_t l = fine_from; l < L; ++l) {
+            const unsigned long long cells = (unsigned long long)h_res[l] * h_res[l] * h_res[l];
+            REQUIRE(h_offsets[l + 1] - h_offsets[l] == rows && cells > rows);  // hashed levels of one (power-of-two) size
+        }
+        BinPlan bp;
+        REQUIRE(bin_plan(M, n_fine, F, rows, bp));
+        REQUIRE(workspace_bytes >= bp.cursors_bytes + bp.rows_bytes + bp.vals_bytes);
+        uint32_t* cursors = reinterpret_cast<uint32_t*>(workspace);
+        uint32_t* pair_row = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + bp.cursors_bytes);
+        float* pair_val = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + bp.cursors_bytes + bp.rows_bytes);
+        {
+            const hipError_t e = hipMemsetAsync(cursors, 0, bp.cursors_bytes, stream);
+            if (e != hipSuccess) return (int)e;
+        }
+        uint32_t* level_max = cursors + (size_t)n_fine * bp.nbins;
+        const uint32_t split = 4;  // workgroups per bin: 5 levels x 128 bins x 4 >> 256 CUs x 2 resident
+#define CALLB(FF)                                                                                                                      \
+    do {                                                                                                                               \
+        const dim3 bgrid(cdiv(M, (uint32_t)BinCfg<FF>::kTile));                                                                        \
+        if (grad_is_f16)                                                                                                               \
+            hipLaunchKernelGGL((k_hashgrid_bwd_bin<FF, true>), bgrid, dim3(kBlock), 0, stream, x, M, x_stride, c0, c1, c2, meta,       \
+                               fine_from, n_fine, grad_out, go_stride, grad_table_f32, cursors, level_max, pair_row, pair_val, bp.cap, \
+                               bp.nbins);                                                                                              \
+        else                                                                                                                           \
+            hipLaunchKernelGGL((k_hashgrid_bwd_bin<FF, false>), bgrid, dim3(kBlock), 0, stream, x, M, x_stride, c0, c1, c2, meta,      \
+                               fine_from, n_fine, grad_out, go_stride, grad_table_f32, cursors, level_max, pair_row, pair_val, bp.cap, \
+                               bp.nbins);                                                                                              \
+        hipLaunchKernelGGL((k_hashgrid_bwd_reduce<FF>), dim3(n_fine * bp.nbins * split), dim3(kReduceBlock), 0, stream, cursors,       \
+                           level_max, pair_row, pair_val, bp.cap, bp.nbins, split, meta, fine_from, grad_table_f32);                   \
+    } while (0)
+        if (F == 2) CALLB(2);
+        else CALLB(4);
+#undef CALLB
+        if (fine_from == 0) return nvsf_launch_status();
+    }
     // production form: corner-parallel run merging.  Variant 1 (tests) selects the plain one-thread-per-(row, level) kernel,
     // which is also the fallback for shapes whose 2^D x F lanes do not divide the levels evenly
-    if (nvsf_variant(kVarHashgridBwd) == 0 && L % (kWave / ((1u << D) * F)) == 0) {
+    const uint32_t ipw = kWave / ((1u << D) * F);
+    if (nvsf_variant(kVarHashgridBwd) == 0 && (L % ipw == 0 || fine_from < L)) {
         const uint32_t run = M >= (1u << 20) ? 128u : 32u;  // rows per item: long runs once there is enough work to fill the chip
-        const uint32_t ipw = kWave / ((1u << D) * F);
-        const unsigned long long waves = ((unsigned long long)cdiv(M, run) * L + ipw - 1) / ipw;
+        const uint32_t l_items = (fine_from + ipw - 1) / ipw * ipw;  // items of a wave = ipw consecutive levels of one chunk
+        const unsigned long long waves = (unsigned long long)cdiv(M, run) * (l_items / ipw);
         const dim3 cgrid((uint32_t)((waves + kBlock / kWave - 1) / (kBlock / kWave)));
 #define CALLC(DD, FF)                                                                                                                \
     do {                                                                                                                             \
         if (grad_is_f16)                                                                                                             \
-            hipLaunchKernelGGL((k_hashgrid_bwd_corners<DD, FF, true>), cgrid, dim3(kBlock), 0, stream, x, M, x_stride, c0, c1, c2, L, meta, \
-                               grad_out, go_stride, grad_table_f32, run);                                                            \
+            hipLaunchKernelGGL((k_hashgrid_bwd_corners<DD, FF, true>), cgrid, dim3(kBlock), 0, stream, x, M, x_stride, c0, c1, c2, l_items, meta, \
+                               grad_out, go_stride, grad_table_f32, run, fine_from);                                                 \
         else                                                                                                                         \
-            hipLaunchKernelGGL((k_hashgrid_bwd_corners<DD, FF, false>), cgrid, dim3(kBlock), 0, stream, x, M, x_stride, c0, c1, c2, L, meta, \
-                               grad_out, go_stride, grad_table_f32, run);                                                            \
+            hipLaunchKernelGGL((k_hashgrid_bwd_corners<DD, FF, false>), cgrid, dim3(kBlock), 0, stream, x, M, x_stride, c0, c1, c2, l_items, meta, \
+                               grad_out, go_stride, grad_table_f32, run, fine_from);                                                 \
     } while (0)
         DISPATCH_DF(D, F, CALLC);
 #undef CALLC
@@ -407,4 +688,24 @@ NVSF_API int nvsf_hashgrid_bwd(const float* x, uint32_t M, uint32_t x_stride, co
 #undef CALL
     return nvsf_launch_status();
 }
+}  // namespace
 
+NVSF_API int nvsf_hashgrid_bwd(const float* x, uint32_t M, uint32_t x_stride, const uint32_t* cols, uint32_t D, uint32_t L, uint32_t F,
+                               const float* h_scales, const uint32_t* h_res, const uint32_t* h_offsets, const void* grad_out,
+                               int grad_is_f16, uint32_t go_stride, float* grad_table_f32, hipStream_t stream) {
+    return hashgrid_bwd_launch(x, M, x_stride, cols, D, L, F, h_scales, h_res, h_offsets, grad_out, grad_is_f16, go_stride, grad_table_f32, L,
+                               nullptr, 0, stream);
+}
+
+NVSF_API size_t nvsf_hashgrid_bwd_binned_ws_bytes(uint32_t M, uint32_t n_fine, uint32_t F, uint32_t rows_per_level) {
+    BinPlan bp;
+    return bin_plan(M, n_fine, F, rows_per_level, bp) ? bp.cursors_bytes + bp.rows_bytes + bp.vals_bytes : 0;
+}
+
+NVSF_API int nvsf_hashgrid_bwd_binned(const float* x, uint32_t M, uint32_t x_stride, const uint32_t* cols, uint32_t D, uint32_t L, uint32_t F,
+                                      const float* h_scales, const uint32_t* h_res, const uint32_t* h_offsets, const void* grad_out,
+                                      int grad_is_f16, uint32_t go_stride, float* grad_table_f32, uint32_t fine_from, void* workspace,
+                                      size_t workspace_bytes, hipStream_t stream) {
+    return hashgrid_bwd_launch(x, M, x_stride, cols, D, L, F, h_scales, h_res, h_offsets, grad_out, grad_is_f16, go_stride, grad_table_f32,
+                               fine_from, workspace, workspace_bytes, stream);
+}

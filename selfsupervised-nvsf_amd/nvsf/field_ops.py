@@ -60,13 +60,70 @@ def hashgrid_forward(x, cols, table_f16, spec, out=None):
     return out
 
 
-def hashgrid_backward(x, cols, spec, grad_out, grad_table=None):
-    """Scatter-adds d L / d table (fp32 [n_params]) from grad_out ([M, L*F], fp16 or fp32)."""
+RAY_ROWS = None  # samples per ray of the rows being encoded, while a renderer evaluates a field on ray-ordered rows (else None)
+
+
+class ray_ordered_rows:
+    """`with ray_ordered_rows(T):` -- the [M, ...] rows handed to the encoders inside are T consecutive samples per ray.  The
+    autograd nodes of the hash grids record it and choose the form of their table scatter with it (fine_levels_from); values and
+    gradients do not depend on it."""
+
+    def __init__(self, T):
+        self.T = int(T)
+
+    def __enter__(self):
+        global RAY_ROWS
+        self.prev, RAY_ROWS = RAY_ROWS, self.T
+
+    def __exit__(self, *exc):
+        global RAY_ROWS
+        RAY_ROWS = self.prev
+
+
+def _bin_from(spec, M, rows_per_ray):
+    return fine_levels_from(spec, rows_per_ray) if (rows_per_ray and M >= (1 << 18) and M % rows_per_ray == 0) else None
+
+
+_BIN_WS = {}  # (device, stream) -> scratch of the binned scatter; one per stream: side-stream scatters of two tables may overlap
+
+
+def fine_levels_from(spec, rows_per_ray):
+    """First level of the trailing run of hashed, equally sized levels whose cells are shorter than ~1.4 steps of a ray that
+    crosses the unit cube in `rows_per_ray` samples (no two consecutive samples share a cell there, so run merging cannot help
+    and nvsf_hashgrid_bwd_binned pays off); spec.L when there is none or the grid has no binned form."""
+    if rows_per_ray is None or spec.D != 3 or spec.F not in (2, 4):
+        return spec.L
+    rows = [int(spec.offsets[l + 1] - spec.offsets[l]) for l in range(spec.L)]
+    first = spec.L
+    for l in range(spec.L - 1, -1, -1):
+        hashed = int(spec.res[l]) ** 3 > rows[l]
+        if not (hashed and rows[l] == rows[-1] and int(spec.res[l]) >= 0.7 * rows_per_ray):
+            break
+        first = l
+    if first < spec.L and _hip.hashgrid_bwd_ws_bytes(1 << 20, spec.L - first, spec.F, rows[-1]) == 0:
+        return spec.L
+    return first
+
+
+def hashgrid_backward(x, cols, spec, grad_out, grad_table=None, fine_from=None):
+    """Scatter-adds d L / d table (fp32 [n_params]) from grad_out ([M, L*F], fp16 or fp32).  `fine_from` < L sends the levels from
+    there on through the binned scatter (see fine_levels_from)."""
     x = x.contiguous()
     grad_out = grad_out.contiguous()
     if grad_table is None:
         grad_table = torch.zeros(spec.n_params, dtype=torch.float32, device=x.device)
-    _hip.call("nvsf_hashgrid_bwd", _hip.ptr(x), x.shape[0], x.shape[1], _hip.host_u32(cols), spec.D, spec.L, spec.F, spec.h_scales,
+    M = x.shape[0]
+    if fine_from is not None and fine_from < spec.L:
+        need = _hip.hashgrid_bwd_ws_bytes(M, spec.L - fine_from, spec.F, int(spec.offsets[-1] - spec.offsets[-2]))
+        key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
+        ws = _BIN_WS.get(key)
+        if ws is None or ws.numel() < need:
+            ws = _BIN_WS[key] = torch.empty(need, dtype=torch.uint8, device=x.device)
+        _hip.call("nvsf_hashgrid_bwd_binned", _hip.ptr(x), M, x.shape[1], _hip.host_u32(cols), spec.D, spec.L, spec.F, spec.h_scales,
+                  spec.h_res, spec.h_offsets, _hip.ptr(grad_out), 1 if grad_out.dtype == torch.float16 else 0, grad_out.stride(0),
+                  _hip.ptr(grad_table), fine_from, _hip.ptr(ws), ws.numel())
+        return grad_table
+    _hip.call("nvsf_hashgrid_bwd", _hip.ptr(x), M, x.shape[1], _hip.host_u32(cols), spec.D, spec.L, spec.F, spec.h_scales,
               spec.h_res, spec.h_offsets, _hip.ptr(grad_out), 1 if grad_out.dtype == torch.float16 else 0, grad_out.stride(0),
               _hip.ptr(grad_table))
     return grad_table
@@ -80,13 +137,14 @@ class HashGridFn(Function):
         x = x.float().contiguous()
         out = hashgrid_forward(x, cols, table_f16, spec)
         ctx.save_for_backward(x)
-        ctx.spec, ctx.cols = spec, cols
+        ctx.spec, ctx.cols, ctx.rows_per_ray = spec, cols, RAY_ROWS
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         (x,) = ctx.saved_tensors
-        grad_params = hashgrid_backward(x, ctx.cols, ctx.spec, grad_out) if ctx.needs_input_grad[1] else None
+        fine = _bin_from(ctx.spec, x.shape[0], ctx.rows_per_ray)
+        grad_params = hashgrid_backward(x, ctx.cols, ctx.spec, grad_out, fine_from=fine) if ctx.needs_input_grad[1] else None
         return None, grad_params, None, None, None
 
 
@@ -510,6 +568,7 @@ class DensityFn(Function):
         ctx.save_for_backward(x01, feat, sigma, mlp_w16)
         ctx.grid_spec, ctx.mlp_spec, ctx.clamp = grid_spec, mlp_spec, (float(sigma_lo), float(sigma_hi))
         ctx.table_param = table_params
+        ctx.rows_per_ray = RAY_ROWS
         ctx.need_table, ctx.need_w = ctx.needs_input_grad[1], ctx.needs_input_grad[4]
         if table_params is not None and table_params.requires_grad and torch.is_grad_enabled():
             _scatter_expected(table_params)
@@ -535,17 +594,19 @@ def _density_backward(ctx, g_sigma, g_geo):
     need_table, need_w = ctx.need_table, ctx.need_w
     grad_feat, grad_w = mlp_backward(feat, mlp_w16, spec, grad_h[:, :spec.n_out], need_grad_x=need_table)
     grad_table = None
+    # levels whose cells are shorter than a ray step go through the binned scatter (rows are ray-ordered with a known ray length)
+    fine = _bin_from(ctx.grid_spec, M, getattr(ctx, "rows_per_ray", None))
     if need_table:
         last = _scatter_done(ctx.table_param)
         sink = GRAD_SINK
         if not (SCATTER_OVERLAP and x01.is_cuda):
             view = sink.view_for(ctx.table_param) if sink is not None else None
             if view is not None:
-                hashgrid_backward(x01, (0, 1, 2), ctx.grid_spec, grad_feat, grad_table=view.view(-1))
+                hashgrid_backward(x01, (0, 1, 2), ctx.grid_spec, grad_feat, grad_table=view.view(-1), fine_from=fine)
                 if last:
                     sink.mark_ready(ctx.table_param)
             else:
-                grad_table = hashgrid_backward(x01, (0, 1, 2), ctx.grid_spec, grad_feat)
+                grad_table = hashgrid_backward(x01, (0, 1, 2), ctx.grid_spec, grad_feat, fine_from=fine)
         else:
             # Side stream.  The destination is ONE buffer per table and step, obtained (and, the first time, zero-filled) on the
             # main stream BEFORE the side stream is made to wait for it: a bucket view (multi-rank) or the parameter's .grad
@@ -560,7 +621,7 @@ def _density_backward(ctx, g_sigma, g_geo):
             with torch.cuda.stream(side):
                 x01.record_stream(side)
                 grad_feat.record_stream(side)
-                hashgrid_backward(x01, (0, 1, 2), ctx.grid_spec, grad_feat, grad_table=view.view(-1))
+                hashgrid_backward(x01, (0, 1, 2), ctx.grid_spec, grad_feat, grad_table=view.view(-1), fine_from=fine)
                 if last:  # the table's gradient is final: its bucket may go out (event recorded on the side stream)
                     sink.mark_ready(ctx.table_param)
     return grad_table, None, None, (grad_w if need_w else None), None, None, None, None
@@ -596,6 +657,7 @@ class DensityRaysFn(Function):
         ctx.grid_spec, ctx.mlp_spec, ctx.clamp = grid_spec, mlp_spec, (float(sigma_lo), float(sigma_hi))
         ctx.table_param = table_params
         ctx.need_table, ctx.need_w = ctx.needs_input_grad[8], ctx.needs_input_grad[11]
+        ctx.rows_per_ray = T
         if table_params is not None and table_params.requires_grad and torch.is_grad_enabled():
             _scatter_expected(table_params)
         ctx.mark_non_differentiable(z_vals, geo16)

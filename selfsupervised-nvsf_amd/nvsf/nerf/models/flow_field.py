@@ -150,7 +150,7 @@ class FlowGridFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, field, xt, t_host, params):
         ctx.save_for_backward(xt)
-        ctx.field, ctx.t_host = field, t_host
+        ctx.field, ctx.t_host, ctx.rows_per_ray = field, t_host, ops.RAY_ROWS
         return field._grid_lagrange(xt, t_host)
 
     @staticmethod
@@ -166,6 +166,6 @@ class FlowGridFn(torch.autograd.Function):
         import copy
         spec2 = copy.copy(spec)
         spec2.F, spec2.n_params, spec2.n_output_dims = 2, spec.n_rows * 2, spec.L * 2
-        G = ops.hashgrid_backward(xt, (0, 1, 2), spec2, grad_red.float().contiguous())
+        G = ops.hashgrid_backward(xt, (0, 1, 2), spec2, grad_red.float().contiguous(), fine_from=ops._bin_from(spec2, xt.shape[0], ctx.rows_per_ray))
         grad_table = (G.view(-1, 1, 2) * w.view(1, 4, 1)).reshape(-1)
         return None, None, None, grad_table

@@ -254,7 +254,8 @@ class NeRFRenderer(nn.Module):
                 xyz_arg = dirs_arg = None
             else:
                 z_vals, xyzs = ops.uniform_samples(rays_o, rays_d, nears, fars, T, aabb, noise)
-                density_outputs = self.density(xyzs.view(-1, 3), time, cal_lidar_color, **kwargs)
+                with ops.ray_ordered_rows(T):  # rows are T consecutive samples per ray: lets the table scatters pick their form
+                    density_outputs = self.density(xyzs.view(-1, 3), time, cal_lidar_color, **kwargs)
                 xyz_arg, dirs_arg = xyzs.view(-1, 3), rays_d.view(-1, 1, 3).expand(N, T, 3).reshape(-1, 3)
             sigma = density_outputs["sigma"].view(N, T)
             weights, weights_sum, depth = ops.CompositeWeightsFn.apply(sigma, z_vals, nears, fars, self._k_scale())

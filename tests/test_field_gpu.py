@@ -128,6 +128,41 @@ def test_hashgrid_backward_kernels_agree_with_the_oracle(ops, dev, D, L, F, log2
         np.testing.assert_allclose(got, ref, atol=5e-4, rtol=1e-4)  # fp32 atomics: order-dependent rounding
 
 
+@pytest.mark.parametrize("L,F,log2_T,base,top,fine_from", [(16, 2, 14, 16, 512, 12), (16, 2, 14, 16, 512, 5), (8, 4, 12, 16, 256, 4), (8, 4, 13, 64, 1024, 0)])
+def test_hashgrid_backward_binned_levels_agree_with_the_oracle(ops, dev, L, F, log2_T, base, top, fine_from):
+    """nvsf_hashgrid_bwd_binned: the levels from `fine_from` on go through the bins (contributions appended per table chunk, summed in
+    LDS), the others through the run-merging kernel; ray-ordered rows with zero rows / zero features, fp32 and fp16 gradients, M not a
+    multiple of the tile; then a batch whose samples all sit in ONE cell, which overflows the bins (the direct-add path)."""
+    spec = _spec(ops, 3, L, F, log2_T, base, top)
+    rows = np.diff(spec.offsets)
+    assert all(int(spec.res[l]) ** 3 > rows[l] and rows[l] == rows[-1] for l in range(fine_from, L))
+    rng = np.random.default_rng(L + F + fine_from)
+    n_rays, T = 41, 131
+    o = rng.random((n_rays, 1, 3)) * 0.5 + 0.1
+    d = rng.standard_normal((n_rays, 1, 3))
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    x = np.clip(o + d * np.linspace(0.0, 0.35, T).reshape(1, T, 1), 0.0, 1.0).reshape(-1, 3).astype(np.float32)
+    M = x.shape[0]
+    go = rng.standard_normal((M, L * F)).astype(np.float32)
+    go[rng.random(M) < 0.3] = 0.0
+    go[rng.random((M, L * F)) < 0.2] = 0.0
+    for g_in in (go, go.astype(np.float16)):
+        ref = O.hashgrid_bwd(x, (0, 1, 2), spec, g_in.astype(np.float32))
+        got = ops.hashgrid_backward(_t(x, dev), (0, 1, 2), spec, _t(g_in, dev), fine_from=fine_from).cpu().numpy()
+        np.testing.assert_allclose(got, ref, atol=5e-4, rtol=1e-4)
+    # accumulates into the caller's table, twice
+    acc = ops.hashgrid_backward(_t(x, dev), (0, 1, 2), spec, _t(go, dev), fine_from=fine_from)
+    acc = ops.hashgrid_backward(_t(x, dev), (0, 1, 2), spec, _t(go, dev), grad_table=acc, fine_from=fine_from).cpu().numpy()
+    np.testing.assert_allclose(acc, 2 * O.hashgrid_bwd(x, (0, 1, 2), spec, go), atol=1e-3, rtol=1e-4)
+    # every sample in one cell: 8 rows per level receive everything, far beyond a bin's capacity
+    M2 = 20001
+    x2 = (np.array([[0.3141, 0.2718, 0.5772]]) + rng.random((M2, 3)) * 1e-6).astype(np.float32)
+    go2 = (rng.standard_normal((M2, L * F)) * 0.01).astype(np.float32)
+    ref = O.hashgrid_bwd(x2, (0, 1, 2), spec, go2)
+    got = ops.hashgrid_backward(_t(x2, dev), (0, 1, 2), spec, _t(go2, dev), fine_from=fine_from).cpu().numpy()
+    np.testing.assert_allclose(got, ref, atol=2e-4 * float(np.abs(ref).max()), rtol=1e-4)
+
+
 def test_hashgrid_autograd_module(dev):
     import tinycudann as tcnn
     enc = tcnn.Encoding(3, {"otype": "HashGrid", "n_levels": 4, "n_features_per_level": 2, "log2_hashmap_size": 12,
