@@ -323,8 +323,11 @@ def train_leg(model, tl, tc, tm, T, steps, dev, dist):
              "gt_intensity": torch.rand(1, n_l, generator=g).to(dev), "gt_rgb": torch.rand(1, n_c, 3, generator=g).to(dev)}
     step = RenderTrainStep(model, num_steps=T, scale=S_SCALE)
     n_coll = 0
-    for _ in range(5):  # the loss scale settles (overflowing first steps are skipped), optimiser state and allocator pools exist
-        step.step(batch)
+    t_spin, n_spin = time.perf_counter(), 0
+    while n_spin < 5 or (time.perf_counter() - t_spin) < 0.3:  # the loss scale settles (overflowing first steps are skipped), optimiser
+        step.step(batch)                                       # state and allocator pools exist, the clocks are up again after the
+        n_spin += 1                                            # host-side legs before this one (as --spinup-ms for the headline)
+        torch.cuda.synchronize()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -353,10 +356,10 @@ def train_leg(model, tl, tc, tm, T, steps, dev, dist):
                          "ring_estimate": "2 (W - 1) / W x payload / 153 GB/s (one xGMI link per ring direction; DESIGN.md section 7)"}
     model.eval()
     return {"metric": "trained rays/sec (LiDAR+cam, fwd+bwd+Adam)", "value": (n_l + n_c) * world * steps / dt, "ms_per_step": dt / steps * 1e3,
-            "steps": steps, "allreduce_collectives_per_step": n_coll, "per_rank_ms_per_step": per_rank_ms, "allreduce": allreduce,
+            "steps": steps, "untimed_steps": n_spin, "allreduce_collectives_per_step": n_coll, "per_rank_ms_per_step": per_rank_ms, "allreduce": allreduce,
             "losses": "the reference's Trainer.train_step defaults: per-ray L1 range + MSE ray-drop + MSE intensity summed over rays, chamfer distance of the predicted point cloud, summed MSE RGB",
             "path": "operator path (autograd) under GradScaler (dense fp16 feature gradients): HIP forward kernels; HIP backward for hash grid "
-                    "(corner-parallel run-merging atomics), MLPs (fused data + weight gradients, shared aligned head input) and compositors"}
+                    "(fine levels: binned contributions summed in LDS; other levels: corner-parallel run-merging atomics), MLPs (fused data + weight gradients, shared aligned head input) and compositors"}
 
 
 def eval_leg(model, dev, T, frames, dist):

@@ -716,6 +716,20 @@ class PlanesFn(Function):
 # uniform sampler / compositor (renderer_dynamic.py:155-237)
 # ------------------------------------------------------------------------------------------------
 _LIN_CACHE = {}
+_CONST_CACHE = {}
+
+
+def device_constant(values, device):
+    """Small fp32 constant (background colour, Lagrange weights ...) as a device tensor, uploaded ONCE per distinct value:
+    `torch.tensor(list, device=...)` is a synchronous copy from pageable memory -- it blocks the host until the stream has
+    drained, so one such call per render keeps the host from ever running ahead of the device."""
+    key = (tuple(float(v) for v in values), str(device))
+    t = _CONST_CACHE.get(key)
+    if t is None:
+        if len(_CONST_CACHE) > 4096:
+            _CONST_CACHE.clear()
+        t = _CONST_CACHE[key] = torch.tensor(key[0], dtype=torch.float32, device=device)
+    return t
 
 
 def linspace01(T, device):

@@ -159,7 +159,7 @@ class FlowGridFn(torch.autograd.Function):
         (xt,) = ctx.saved_tensors
         field = ctx.field
         spec = field.grid_enc.spec
-        w = torch.tensor(lagrange_weights_host(ctx.t_host, 4, xt.is_cuda), dtype=torch.float32, device=xt.device)
+        w = ops.device_constant(lagrange_weights_host(ctx.t_host, 4, xt.is_cuda), xt.device)
         # feature 2i+e of a level receives w_i * dL/d(reduced column e): the four chunks of an entry get the same scattered sum
         # up to the scalar w_i.  Scatter G[row][e] = sum g_e w_corner ONCE on a 2-feature view of the grid (a quarter of the
         # atomics, which bound this pass) and expand to the 8 features afterwards.

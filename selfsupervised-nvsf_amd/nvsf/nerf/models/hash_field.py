@@ -23,6 +23,7 @@ from torch import nn
 
 import tinycudann as tcnn
 from nvsf import testing
+from nvsf import field_ops as _ops
 
 
 _HOST_TIME_CACHE = {}  # id(tensor) -> (weakref, version, value): the last few time tensors read back
@@ -299,7 +300,7 @@ class HashDynFn(torch.autograd.Function):
         # only (dL/dtable_lo = blend_lo G, dL/dtable_hi = blend_hi G with G = sum g lag_i w_c).  G is scattered ONCE -- half the
         # atomics, which are what bounds this pass -- and scaled into the two gradients afterwards (tables of ~1 M floats).
         g_out = grad_out.float().contiguous()
-        lag_t = torch.tensor(lag, dtype=torch.float32, device=x.device)
+        lag_t = _ops.device_constant(lag, x.device)
         # ... and the four features of an entry are the four Lagrange chunks: dL/dtable[row][i] = lag_i * blend * G[row] with ONE
         # scalar sum per entry (nvsf_hashgrid4d_dynamic_bwd_scalar), expanded here
         sums = [torch.zeros(s.n_rows, dtype=torch.float32, device=x.device) for s in specs]

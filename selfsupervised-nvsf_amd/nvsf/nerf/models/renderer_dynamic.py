@@ -263,7 +263,7 @@ class NeRFRenderer(nn.Module):
             extra = {k: v.view(N * T, -1) for k, v in density_outputs.items() if k != "sigma"}
             # ray_dirs: the per-ray rows `dirs` repeats -- lets the heads encode each direction once (ops.heads)
             rgbs = self.color(xyz_arg, dirs_arg, cal_lidar_color=cal_lidar_color, mask=mask.reshape(-1), ray_dirs=rays_d, **extra)
-            bg_dev = torch.tensor(bg_host, dtype=torch.float32, device=rays_o.device) if bg_host is not None else None
+            bg_dev = ops.device_constant(bg_host, rays_o.device) if bg_host is not None else None
             image = ops.CompositeImageFn.apply(weights, rgbs.view(N, T, self.out_dim), weights_sum, bg_dev)
         if per_ray_bg is not None:
             image = image + (1 - weights_sum).unsqueeze(-1) * per_ray_bg

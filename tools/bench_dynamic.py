@@ -1,5 +1,6 @@
 """Timing of the full space-time field (reference default configuration 'RD': 2048 LiDAR + 2048 camera rays x 768
-samples, hash L8 F4 T2^19 512->32768, time_resolution 8, K-planes 4 scales, flow field) -- forward render, no_grad."""
+samples, hash L8 F4 T2^19 512->32768, time_resolution 8, K-planes 4 scales, flow field) -- forward render, no_grad, in the
+reference's shipped --fp16 regime (render(fp16=True): the flow MLP on the fused fp16 MFMA kernel); FP32=1 for the fp32 flow MLP."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "selfsupervised-nvsf_amd"))
@@ -20,10 +21,11 @@ N, T = int(os.environ.get("N", 2048)), int(os.environ.get("T", 768))
 lo, ld = S.lidar_rays(N, rng); co, cd = S.camera_rays(N, rng)
 tl = [torch.from_numpy(a).to(dev)[None] for a in (lo, ld)]; tc = [torch.from_numpy(a).to(dev)[None] for a in (co, cd)]
 tm = torch.tensor([[0.5]], device=dev)
+FP16 = os.environ.get("FP32", "0") != "1"
 def step():
     with torch.no_grad():
-        m.render(tl[0], tl[1], tm, cal_lidar_color=True, num_steps=T)
-        m.render(tc[0], tc[1], tm, cal_lidar_color=False, num_steps=T)
+        m.render(tl[0], tl[1], tm, cal_lidar_color=True, num_steps=T, fp16=FP16)
+        m.render(tc[0], tc[1], tm, cal_lidar_color=False, num_steps=T, fp16=FP16)
 for _ in range(2): step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 K = 5
@@ -31,6 +33,6 @@ for _ in range(K): step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
 with torch.no_grad():
     xs = torch.rand(100000, 3, device=dev)
-    fl = m.flow_net(torch.cat([xs, torch.full((100000, 1), 0.5, device=dev)], -1), 0.5)
+    fl = m.flow_net(torch.cat([xs, torch.full((100000, 1), 0.5, device=dev)], -1), 0.5, fp16=FP16)
 print(f"mean |flow| = {float(fl.abs().mean()):.2e} (finest / coarsest space-time cell: {1/32768:.1e} / {1/512:.1e})")
 print(f"RD forward: {dt*1e3:.2f} ms/step, {2*N/dt:.0f} rays/s, peak mem {torch.cuda.max_memory_allocated()/2**30:.2f} GiB")
