@@ -481,7 +481,7 @@ def cast_cols_f16(src, dst):
 
 
 # ---- table-gradient scatter beside the rest of backward -------------------------------------------------------------------------
-# The table scatter (k_hashgrid_bwd_corners) runs at the memory-side float-atomic rate (2.95 ms per config-2 batch)
+# The table scatter (coarse levels at the memory-side float-atomic rate, fine levels as two streaming passes: ~2 ms per config-2 batch)
 # with the vector and matrix pipes idle; the MLP backward kernels of the OTHER modality's branch are MFMA / LDS work.  DensityFn
 # therefore issues the scatter on a side stream: the main stream goes on with the next branch of backward and only the consumers
 # of the table gradient (gradient all-reduce, overflow check, optimiser) wait for it (`sync_side_streams`).
