@@ -17,19 +17,42 @@ from nvsf import field_ops as ops
 from nvsf.nerf.models.hash_field import lagrange_reduce
 
 
+class FreqEmbed(nn.Module):
+    """sin / cos embedding of every input column (flow_field.py:17-38): output columns [sin(f_0 pi x) | sin(f_1 pi x) | ... |
+    cos(f_0 pi x) | ...], each block as wide as x; f = linspace(1, n + 1, n) or 2^(0 .. n-1).  An option of FlowField that no
+    configuration of the reference switches on: plain tensor algebra here as there."""
+
+    def __init__(self, num_freqs, linspace=True):
+        super().__init__()
+        self.freqs = torch.linspace(1, num_freqs + 1, steps=num_freqs) if linspace else 2 ** torch.linspace(0, num_freqs - 1, steps=num_freqs)
+
+    def forward(self, x):
+        arg = torch.cat([f * x * torch.pi for f in self.freqs], -1)  # (freq * x) * pi with freq a 0-dim CPU tensor, as in the reference
+        return torch.cat([torch.sin(arg), torch.cos(arg)], -1)
+
+
 class FlowField(nn.Module):
     def __init__(self, input_dim=4, num_layers=3, hidden_dim=64, use_freq=False, num_freqs=6, use_grid=True, num_basis=4,
                  n_levels=16, n_features_per_level=8, base_resolution=32, max_resolution=8192, log2_hashmap_size=18):
         super().__init__()
-        if use_freq or not use_grid:
-            raise NotImplementedError("FlowField: the reference configuration (hash grid, no frequency embedding) is implemented")
+        if not (use_freq or use_grid):
+            raise ValueError("FlowField needs at least one of use_freq / use_grid")
+        if use_freq and use_grid:
+            # the reference's own forward fails for this pair of options: interpT views the grid features with the SUMMED input
+            # width (flow_field.py:121) and the concatenation at :130 raises -- there is no behaviour to reproduce
+            raise NotImplementedError("FlowField(use_freq=True, use_grid=True) does not run in the reference (flow_field.py:121, 130)")
         self.use_freq, self.use_grid = use_freq, use_grid
-        per_level_scale = np.exp2(np.log2(max_resolution / base_resolution) / (n_levels - 1))
-        self.grid_enc = tcnn.Encoding(n_input_dims=3, encoding_config={
-            "otype": "HashGrid", "n_levels": n_levels, "n_features_per_level": n_features_per_level,
-            "log2_hashmap_size": log2_hashmap_size, "base_resolution": base_resolution, "per_level_scale": per_level_scale})
+        self.input_dim = 0
+        if use_freq:
+            self.freq_enc = FreqEmbed(num_freqs=num_freqs)
+            self.input_dim += input_dim * num_freqs * 2
         self.n_levels, self.n_features_per_level, self.num_basis = n_levels, n_features_per_level, num_basis
-        self.input_dim = self.grid_enc.n_output_dims // num_basis
+        if use_grid:
+            per_level_scale = np.exp2(np.log2(max_resolution / base_resolution) / (n_levels - 1))
+            self.grid_enc = tcnn.Encoding(n_input_dims=3, encoding_config={
+                "otype": "HashGrid", "n_levels": n_levels, "n_features_per_level": n_features_per_level,
+                "log2_hashmap_size": log2_hashmap_size, "base_resolution": base_resolution, "per_level_scale": per_level_scale})
+            self.input_dim += self.grid_enc.n_output_dims // num_basis
         layers = []
         for l in range(num_layers):
             last = l == num_layers - 1
@@ -46,14 +69,24 @@ class FlowField(nn.Module):
         `fp16`: True / False selects the MLP's arithmetic for this call, None follows the regime (module docstring)."""
         t = xt[0, 3]
         fused_mlp = self.mlp_mode(fp16) == "fused" and self._fused_mlp_ok()
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            if self.grid_train_mode == "fused" and self.n_features_per_level == 8 and self.num_basis == 4 and not xt.requires_grad:
-                # grid lookup + Lagrange reduction as the fused forward kernel, the table gradient straight from dL/d(reduced)
-                t_h = float(t) if t_host is None else t_host
-                red = FlowGridFn.apply(self, xt.float().contiguous(), t_h, self.grid_enc.params)
+        training = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        h = [self.freq_enc(xt.float())] if self.use_freq else []
+        if self.use_grid:
+            if training:
+                if self.grid_train_mode == "fused" and self.n_features_per_level == 8 and self.num_basis == 4 and not xt.requires_grad:
+                    # grid lookup + Lagrange reduction as the fused forward kernel, the table gradient straight from dL/d(reduced)
+                    t_h = float(t) if t_host is None else t_host
+                    h.append(FlowGridFn.apply(self, xt.float().contiguous(), t_h, self.grid_enc.params))
+                else:
+                    feat = self.grid_enc.encode_columns(xt, (0, 1, 2)).float()
+                    h.append(lagrange_reduce(feat, t, self.n_levels, self.n_features_per_level, self.num_basis))
             else:
-                feat = self.grid_enc.encode_columns(xt, (0, 1, 2)).float()
-                red = lagrange_reduce(feat, t, self.n_levels, self.n_features_per_level, self.num_basis)
+                if self.n_features_per_level != 8 or self.num_basis != 4:
+                    raise NotImplementedError("fused flow grid kernel: 8 features per level, 4 Lagrange nodes")
+                t_host = float(t) if t_host is None else t_host
+                h.append(self._grid_lagrange(xt.float().contiguous(), t_host))
+        red = h[0] if len(h) == 1 else torch.cat(h, dim=-1)
+        if training:
             if fused_mlp:
                 # the mixed-precision training run: the Linear layers on the fused MFMA forward / backward kernels (what
                 # autocast makes of them in the reference's Trainer), instead of three fp32 GEMMs + two ReLU launches forward
@@ -61,15 +94,11 @@ class FlowField(nn.Module):
                 lin = [m for m in self.mlp if isinstance(m, nn.Linear)]
                 return FlowMlpFn.apply(red, lin[0].weight, lin[1].weight, lin[2].weight)
             return self.mlp(red)
-        if self.n_features_per_level != 8 or self.num_basis != 4:
-            raise NotImplementedError("fused flow grid kernel: 8 features per level, 4 Lagrange nodes")
-        t_host = float(t) if t_host is None else t_host
-        red = self._grid_lagrange(xt.float().contiguous(), t_host)
         if fused_mlp:
             # the fp16 regime: the three bias-free layers as ONE fused MFMA kernel -- fp16 operands, fp32 accumulation, i.e. what the
             # reference's Linear layers compute under the Trainer's autocast (6x faster than three fp32 GEMM + two ReLU launches;
             # fp16-accurate: 4e-5 abs on flows of 1e-2 against the fp32 form).  Columns 6..15 are padding.
-            return ops.mlp_forward(red, self._mlp_weights_f16(), self._mlp_spec)[:, :6]
+            return ops.mlp_forward(red.contiguous(), self._mlp_weights_f16(), self._mlp_spec)[:, :6]
         return self.mlp(red)
 
     def _grid_lagrange(self, xt, t_host):

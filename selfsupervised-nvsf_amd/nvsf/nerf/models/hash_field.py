@@ -128,8 +128,8 @@ class HashGrid4D(nn.Module):
     def __init__(self, base_resolution=512, max_resolution=32768, time_resolution=8, n_levels=8, n_features_per_level=4,
                  log2_hashmap_size=19, hash_size_dynamic=[15, 13, 13], decompose=True, reduction="concat"):
         super().__init__()
-        if reduction != "concat":
-            raise NotImplementedError("HashGrid4D: only the 'concat' reduction of the reference configuration is implemented")
+        if reduction not in ("concat", "prod", "sum", "mean"):
+            raise ValueError("Invalid reduction")  # hash_field.py:26-27
         per_level_scale = np.exp2(np.log2(max_resolution / base_resolution) / (n_levels - 1))
         self.hash_static = tcnn.Encoding(n_input_dims=3, encoding_config={
             "otype": "HashGrid", "n_levels": n_levels, "n_features_per_level": n_features_per_level,
@@ -140,7 +140,20 @@ class HashGrid4D(nn.Module):
                       n_features_per_level=n_features_per_level, log2_hashmap_size=hash_size_dynamic[i], cols=pairs[i])
             for i in range(3)])
         self.decompose, self.reduction = decompose, reduction
-        self.n_output_dims = self.hash_static.n_output_dims + self.hash_dynamic[0].n_output_dims * 3
+        self.n_output_dims = self.hash_static.n_output_dims + self.hash_dynamic[0].n_output_dims * (3 if reduction == "concat" else 1)
+
+    def _reduce(self, feat):
+        """The reference's `reduction_func` (hash_field.py:16-27) on the three pair features, which the kernels deliver side by side
+        as [N, 3 * n]: 'concat' is that buffer; 'sum' / 'mean' / 'prod' fold the three chunks in the reference's order and dtype
+        (Python's sum starts from 0 + xy, math.prod from 1 * xy: both exact)."""
+        if self.reduction == "concat":
+            return feat
+        n = self.hash_dynamic[0].n_output_dims
+        xy, xz, yz = feat[:, :n], feat[:, n:2 * n], feat[:, 2 * n:3 * n]
+        if self.reduction == "prod":
+            return (xy * xz) * yz
+        total = (xy + xz) + yz
+        return total / 3 if self.reduction == "mean" else total
 
     def forward_static(self, x):
         return self.hash_static(x)
@@ -161,9 +174,9 @@ class HashGrid4D(nn.Module):
                 idx = np.float32(t_host) * np.float32(first.time_resolution - 1)
                 k1, k2 = int(math.floor(idx)), int(math.ceil(idx))
                 params = [pl.hash_t[k1].params for pl in self.hash_dynamic] + [pl.hash_t[k2].params for pl in self.hash_dynamic]
-                return HashDynFn.apply(self, x, t, t_host, k1, k2, *params)
-            return torch.cat([plane(x, t, t_host) for plane in self.hash_dynamic], dim=-1)
-        return self._forward_dynamic_fused(x, t, t_host, offset, offset_col)
+                return self._reduce(HashDynFn.apply(self, x, t, t_host, k1, k2, *params))
+            return self._reduce(torch.cat([plane(x, t, t_host) for plane in self.hash_dynamic], dim=-1))
+        return self._reduce(self._forward_dynamic_fused(x, t, t_host, offset, offset_col))
 
     def _forward_dynamic_fused(self, x, t, t_host, offset, offset_col):
         from nvsf import _hip
@@ -211,7 +224,7 @@ class HashGrid4D(nn.Module):
         if nb[0] is None and nb[1] is None:
             return None
         params = [pl.hash_t[k1].params for pl in self.hash_dynamic] + [pl.hash_t[k2].params for pl in self.hash_dynamic]
-        return HashDyn3Fn.apply(self, x, t, t_host, k1, k2, flow, nb[0], nb[1], *params)
+        return tuple(o if o is None else self._reduce(o) for o in HashDyn3Fn.apply(self, x, t, t_host, k1, k2, flow, nb[0], nb[1], *params))
 
     def forward_dynamic3(self, x, t, t_host, offsets, neighbours):
         """No-autograd: the dynamic features of one density query in one launch (csrc/hashgrid4d.hip, k_hash_dynamic3):
@@ -257,7 +270,7 @@ class HashGrid4D(nn.Module):
                   _hip.host_f32([v for s in specs for v in s.scales]), _hip.host_u32([v for s in specs for v in s.res]),
                   _hip.host_u32([v for s in specs for v in s.offsets]), _hip.host_f32(h_time), _hip.host_i32(flags), _hip.ptr(out0),
                   _hip.ptr(out1), _hip.ptr(out2))
-        return out0, out1, out2
+        return tuple(o if o is None else self._reduce(o) for o in (out0, out1, out2))
 
     def forward(self, x, t, t_host=None):
         static, dynamic = self.forward_static(x), self.forward_dynamic(x, t, t_host)

@@ -107,6 +107,20 @@ def gen_hash4d(mods, out_dir):
     with torch.no_grad():
         out["flow_xt"] = xt
         out["flow"] = flow(torch.from_numpy(xt)).numpy()
+    # options no configuration of the reference switches on: the other reductions of the three pair features, the frequency embedding
+    with torch.no_grad():
+        for red in ("prod", "sum", "mean"):
+            enc_r = hf.HashGrid4D(base_resolution=16, max_resolution=256, time_resolution=4, n_levels=8, n_features_per_level=4,
+                                  log2_hashmap_size=12, reduction=red)
+            init_by_name(enc_r)  # name-derived seeds: the same tables as `enc`
+            s, d = enc_r(torch.from_numpy(x), torch.tensor([[0.77]], dtype=torch.float32))
+            out[f"dyn_t11_{red}"], out[f"dyn_t0_{red}"] = d.numpy(), enc_r.forward_dynamic(torch.from_numpy(x), torch.tensor(0.77)).numpy()
+        # (use_freq together with use_grid does not run in the reference: interpT views the grid features with the summed width,
+        # flow_field.py:121, and torch.cat at :130 fails)
+        for name, kw in (("freq_only", dict(use_freq=True, use_grid=False)),):
+            fl = ff.FlowField(n_levels=16, n_features_per_level=8, base_resolution=32, max_resolution=8192, log2_hashmap_size=14, **kw)
+            init_by_name(fl)
+            out[f"flow_{name}"] = fl(torch.from_numpy(xt)).numpy()
     np.savez_compressed(os.path.join(out_dir, "hash4d_flow.npz"), **out)
     print("hash4d_flow.npz", {k: v.shape for k, v in out.items() if hasattr(v, "shape") and v.ndim})
 

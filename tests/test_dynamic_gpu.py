@@ -127,6 +127,52 @@ def test_hashgrid4d_and_flow(dev):
     np.testing.assert_allclose(out16.cpu().numpy(), g["flow"], atol=1e-4, rtol=1e-2)
 
 
+def test_constructor_options_outside_the_reference_configuration(dev):
+    """Options of the reference's encoders that no configuration of the reference switches on: HashGrid4D's 'prod' / 'sum' / 'mean'
+    reductions of the three pair features (hash_field.py:16-27, 157-158; both dtype regimes of the time blend, and with autograd
+    recording) and FlowField's frequency embedding instead of the grid (flow_field.py:17-38, 63-66), against outputs of the
+    reference's own modules; use_freq together with use_grid fails in the reference itself and is rejected."""
+    from nvsf.nerf.models.hash_field import HashGrid4D
+    from nvsf.nerf.models.flow_field import FlowField
+    g = np.load(os.path.join(GOLD, "hash4d_flow.npz"))
+    x = _t(g["x"], dev)
+    for red in ("prod", "sum", "mean"):
+        enc = HashGrid4D(base_resolution=16, max_resolution=256, time_resolution=4, n_levels=8, n_features_per_level=4,
+                         log2_hashmap_size=12, reduction=red)
+        GD.init_by_name(enc)
+        enc = enc.to(dev)
+        assert enc.n_output_dims == 40
+        ref = g[f"dyn_t11_{red}"]
+        tol = dict(atol=1e-6 + 1e-5 * float(np.abs(ref).max()), rtol=1e-5)
+        with torch.no_grad():
+            s, d = enc(x, torch.tensor([[0.77]], dtype=torch.float32, device=dev))
+            d0 = enc.forward_dynamic(x, torch.tensor(0.77))
+        assert d.dtype == torch.float32 and d.shape == (600, 8) and d0.dtype == torch.float16
+        np.testing.assert_allclose(d.cpu().numpy(), ref, **tol)
+        ref0 = g[f"dyn_t0_{red}"].astype(np.float32)
+        np.testing.assert_allclose(d0.float().cpu().numpy(), ref0, atol=4e-3 * np.abs(ref0).max(), rtol=0)
+        d_train = enc.forward_dynamic(x, torch.tensor([[0.77]], dtype=torch.float32, device=dev))  # autograd recording: HashDynFn + fold
+        np.testing.assert_allclose(d_train.detach().cpu().numpy(), ref, **tol)
+        d_train.sum().backward()
+        assert any(p.grad is not None and bool(p.grad.abs().sum() > 0) for p in enc.hash_dynamic.parameters())
+    with pytest.raises(ValueError):
+        HashGrid4D(reduction="max")
+    flow = FlowField(n_levels=16, n_features_per_level=8, base_resolution=32, max_resolution=8192, log2_hashmap_size=14, use_freq=True,
+                     use_grid=False)
+    GD.init_by_name(flow)
+    flow = flow.to(dev)
+    assert flow.input_dim == 48 and not hasattr(flow, "grid_enc")
+    xt = _t(g["flow_xt"], dev)
+    with torch.no_grad():
+        out, out16 = flow(xt), flow(xt, fp16=True)
+    np.testing.assert_allclose(out.cpu().numpy(), g["flow_freq_only"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(out16.cpu().numpy(), g["flow_freq_only"], atol=5e-3, rtol=2e-2)  # fp16 operands on flows of ~0.8
+    flow(xt).sum().backward()  # autograd recording: plain Linear layers
+    assert flow.mlp[0].weight.grad is not None
+    with pytest.raises(NotImplementedError):
+        FlowField(use_freq=True, use_grid=True)
+
+
 @pytest.mark.parametrize("t_val", [0.37, 0.0, 1.0])  # between two slices / exactly on the first / on the last slice
 def test_hashgrid4d_fused_training_path_equals_the_per_slice_path(dev, t_val, variants):
     """HashDynFn (fused forward + fused table-gradient kernel) against the per-slice operator path (six tcnn.Encoding calls,

@@ -44,6 +44,9 @@ subprocess.check_call([py, os.path.join(ROOT, "tools", "pmc_summary.py"), f"{dst
                        f"{dst}/{tag}_pmc_traffic.json"])
 subprocess.check_call([py, os.path.join(ROOT, "tools", "pmc_summary.py"), "--mfma", f"{dst}/{tag}_pmc_mfma.csv", f"{dst}/{tag}_bench_kernel_stats.csv",
                        f"{dst}/{tag}_pmc_mfma.json"])
+if glob.glob(os.path.join(src, "pm_train/**/*counter_collection.csv"), recursive=True):
+    subprocess.check_call([py, os.path.join(ROOT, "tools", "pmc_summary.py"), "--train", one("pm_train/**/*counter_collection.csv"),
+                           one("pa_train/**/*counter_collection.csv"), f"{dst}/{tag}_train_kernel_stats.csv", f"{dst}/{tag}_pmc_train.json"])
 d = json.loads(open(f"{dst}/{tag}_bench_line.json").read())
 print(tag, d["value"], d["ms_per_step"], "roofline", d["roofline"]["frac"], "traffic", d["roofline"].get("traffic"))
 print({k: {a: b for a, b in v.items() if a in ("value", "ms_per_step")} for k, v in d.items() if isinstance(v, dict) and k in ("train", "dynamic", "eval")},

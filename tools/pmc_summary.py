@@ -65,9 +65,44 @@ def mfma_summary(counter_csv, kernel_stats_csv, out_path):
         print(e["label"], {x: round(e[x], 4) for x in ("tflops", "mfma_pipe_util") if x in e})
 
 
+def train_summary(mfma_csv, atomics_csv, kernel_stats_csv, out_path):
+    """python tools/pmc_summary.py --train <SQ pass csv> <TCC atomics pass csv> <train kernel_stats.csv> <out.json>: the kernels of the
+    training step (tools/bench_train.py) -- MFMA pipe utilisation of the MLP / fused field kernels and 64-byte atomic requests of the
+    table-gradient kernels, means per launch; durations from the kernel trace of the same script."""
+    dur = {r["Name"]: float(r["AverageNs"]) for r in csv.DictReader(open(kernel_stats_csv))}
+    want = ("k_mlp_fwd", "k_mlp_bwd", "k_density_uniform_v2", "k_density_from_features", "k_encode_sliced", "k_hashgrid_bwd")
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    for path in (mfma_csv, atomics_csv):
+        for r in csv.DictReader(open(path)):
+            if any(k in r["Kernel_Name"] for k in want):
+                per[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out = {"csrc_digest_all": nvsf_build.csrc_digest_all(),
+           "note": "tools/bench_train.py (config 4 step, 4096 + 4096 rays x 768), two separate --pmc passes: SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES "
+                   "SQ_INSTS_VALU_MFMA_MOPS_F16 and TCC_EA0_ATOMIC_sum TCC_EA0_WRREQ_sum; means per launch; mfma_pipe_util = MFMA busy cycles / "
+                   "(kernel-trace duration x 2.4 GHz x 1024 SIMDs); atomic_TBps = atomic requests x 64 B / duration", "kernels": {}}
+    for name, cs in per.items():
+        e = {k: sum(v) / len(v) for k, v in cs.items()}
+        e["launches"] = max(len(v) for v in cs.values())
+        d = next((v for k, v in dur.items() if k[:60] == name[:60]), None)
+        if d:
+            e["avg_duration_ns"] = d
+            if "SQ_INSTS_VALU_MFMA_MOPS_F16" in e and e["SQ_INSTS_VALU_MFMA_MOPS_F16"] > 0:
+                e["tflops"] = e["SQ_INSTS_VALU_MFMA_MOPS_F16"] * 512.0 / d / 1e3
+                e["mfma_pipe_util"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (d * 2.4 * 1024)
+            if "TCC_EA0_ATOMIC_sum" in e:
+                e["atomic_TBps"] = e["TCC_EA0_ATOMIC_sum"] * 64.0 / d / 1e3
+        out["kernels"][name[:100]] = e
+    json.dump(out, open(out_path, "w"), indent=1)
+    for k, e in out["kernels"].items():
+        print(k[:70], {x: round(e[x], 4) for x in ("tflops", "mfma_pipe_util", "TCC_EA0_ATOMIC_sum", "atomic_TBps") if x in e})
+
+
 args = sys.argv[1:]
 if args and args[0] == "--mfma":
     mfma_summary(*args[1:4])
+    sys.exit(0)
+if args and args[0] == "--train":
+    train_summary(*args[1:5])
     sys.exit(0)
 alternating = ["k_weights_fwd"]
 if "--alternating" in args:

@@ -20,6 +20,9 @@ timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pw -- $B --step
 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU_MFMA_MOPS_F16 --output-format csv -d $O/pm -- python3 $R/bench.py --cpu-rays 0 --no-extra-legs --train-steps 0 --steps 5 --warmup 1 > $O/pm.log 2>&1
 # 6. kernel traces of the secondary legs
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_train -- python3 $R/tools/bench_train.py > $O/kt_train.log 2>&1
+# 6b. counters of the training step's kernels: MFMA pipe (SQ) and 64-byte atomic requests (TCC), separate passes
+timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F16 --output-format csv -d $O/pm_train -- python3 $R/tools/bench_train.py > $O/pm_train.log 2>&1
+timeout 900 rocprofv3 --pmc TCC_EA0_ATOMIC_sum TCC_EA0_WRREQ_sum --output-format csv -d $O/pa_train -- python3 $R/tools/bench_train.py > $O/pa_train.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_occ -- python3 $R/tools/bench_occupancy.py > $O/kt_occ.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_dyn -- python3 $R/tools/bench_dynamic.py > $O/kt_dyn.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt_dyn_train -- python3 $R/tools/bench_train_dynamic.py > $O/kt_dyn_train.log 2>&1
