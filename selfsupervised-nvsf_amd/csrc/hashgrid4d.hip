@@ -456,23 +456,44 @@ __global__ __launch_bounds__(kBlock) void k_hash_dynamic_bwd_scalar(const float*
 }
 
 // The same sums through LDS (the form nvsf_hashgrid4d_dynamic_bwd_scalar launches).  A time-sliced 2-D grid has 2^13 - 2^15
-// rows per level (hash_size_dynamic = [15, 13, 13], hash_field.py:96): ONE level of ONE pair is a 32 - 128 KB table of scalar
-// sums -- it fits the 160 KB of LDS of a CU.  So a workgroup owns (pair, level, slice of the samples), accumulates its slice
-// into an LDS copy of that level with LDS atomics (no memory-side atomic per sample and corner: those cost one 64-byte
-// segment each, 2.96 ms per 1.6 M samples in the run-merging kernel above) and adds the copy to the global sums once, with
-// contiguous atomics (the full-rate shape).  Same products w_corner * g as k_hash_dynamic_bwd_scalar, summed in another order.
+// rows per level (hash_size_dynamic = [15, 13, 13], hash_field.py:96): ONE level of ONE pair is a small table of scalar sums that
+// fits the 160 KB of LDS of a CU.  So a workgroup owns (pair, level, row range, slice of the samples), accumulates its slice into an
+// LDS image of its rows (no memory-side atomic per sample and corner: those cost one 64-byte segment each, 2.96 ms per 1.6 M
+// samples in the run-merging kernel above) and adds the image to the global sums once, with contiguous atomics (the full-rate
+// shape).  The image is 64-bit FIXED POINT: LDS float atomics run at a quarter of the rate of the integer ones on gfx950
+// (hashgrid.hip, k_hashgrid_bwd_reduce).  Scale = 2^(36 - e), e the exponent of the largest |g| of the workgroup's own slice
+// and level (a first pass over the column; every workgroup converts back to fp32 before it adds to the global sums, so the scale
+// is private to it): the product is exact, one truncation per addend.  2^15-row levels take two workgroups per slice, one per
+// half of the rows (128 KB each); both walk the slice, each keeps the addends of its rows.
+template <int SPLIT>
 __global__ void k_hash_dynamic_bwd_lds(const float* __restrict__ x, uint32_t x_stride, uint32_t M, const float* __restrict__ grad_out,
                                        PlaneSums pg, uint32_t pl0, uint32_t chunk_len) {
-    extern __shared__ float s_tab[];
-    const uint32_t pl = pl0 + blockIdx.y / kPlaneLevels, l = blockIdx.y % kPlaneLevels;
+    extern __shared__ unsigned long long s_fx[];
+    __shared__ float s_red[16];
+    const uint32_t part = blockIdx.y % SPLIT, yl = blockIdx.y / SPLIT;
+    const uint32_t pl = pl0 + yl / kPlaneLevels, l = yl % kPlaneLevels;
     const GridMeta& g = pg.meta[pl];
     const float scale = g.scale[l];
     const uint32_t res = g.res[l], row0 = g.offset[l], hsize = g.offset[l + 1] - row0;
-    for (uint32_t i = threadIdx.x; i < hsize; i += blockDim.x) s_tab[i] = 0.0f;
-    __syncthreads();
+    const uint32_t rows_wg = (hsize + SPLIT - 1) / SPLIT, row_lo = part * rows_wg;
+    const uint32_t n_rows = row_lo < hsize ? (hsize - row_lo < rows_wg ? hsize - row_lo : rows_wg) : 0u;
     const uint32_t ca = pl == 2 ? 1u : 0u, cb = pl == 0 ? 1u : 2u;
     const unsigned long long first = (unsigned long long)blockIdx.x * chunk_len;
     const uint32_t m0 = (uint32_t)(first < M ? first : M), m1 = (uint32_t)(first + chunk_len < M ? first + chunk_len : M);
+    const size_t gcol = (size_t)pl * kPlaneLevels + l;
+    // largest |g| of this slice and level
+    float mx = 0.0f;
+    for (uint32_t m = m0 + threadIdx.x; m < m1; m += blockDim.x) mx = fmaxf(mx, fabsf(grad_out[(size_t)m * (3 * kPlaneLevels) + gcol]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63u) == 0u) s_red[threadIdx.x >> 6] = mx;
+    for (uint32_t i = threadIdx.x; i < n_rows; i += blockDim.x) s_fx[i] = 0ull;
+    __syncthreads();
+    mx = 0.0f;
+    for (uint32_t wv = 0; wv < (blockDim.x >> 6); ++wv) mx = fmaxf(mx, s_red[wv]);
+    if (!(mx > 0.0f) || n_rows == 0u) return;  // uniform
+    const int e = (int)((__float_as_uint(mx) >> 23) & 0xFFu) - 127;
+    const float to_fixed = __builtin_ldexpf(1.0f, 36 - e);
     // four samples per thread and round: their (strided, line-per-sample) loads are in flight together
     constexpr int U = 4;
     for (uint32_t mb = m0 + threadIdx.x; mb < m1; mb += U * blockDim.x) {
@@ -482,7 +503,7 @@ __global__ void k_hash_dynamic_bwd_lds(const float* __restrict__ x, uint32_t x_s
             const uint32_t m = mb + (uint32_t)u * blockDim.x;
             const bool ok = m < m1;
             const size_t mm = ok ? m : m0;
-            go[u] = ok ? grad_out[mm * (3 * kPlaneLevels) + pl * kPlaneLevels + l] : 0.0f;
+            go[u] = ok ? grad_out[mm * (3 * kPlaneLevels) + gcol] : 0.0f;
             xa[u] = x[mm * x_stride + ca];
             xb[u] = x[mm * x_stride + cb];
         }
@@ -497,15 +518,18 @@ __global__ void k_hash_dynamic_bwd_lds(const float* __restrict__ x, uint32_t x_s
             for (int c = 0; c < 4; ++c) {
                 const float w = ((c & 1) ? ra : (1.0f - ra)) * ((c & 2) ? rb : (1.0f - rb));
                 const uint32_t cc[2] = {ia + (uint32_t)(c & 1), ib + (uint32_t)((c >> 1) & 1)};
-                __hip_atomic_fetch_add(&s_tab[grid_row<2>(cc, res, hsize)], w * go[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t row = grid_row<2>(cc, res, hsize) - row_lo;
+                const long long fx = (long long)((w * go[u]) * to_fixed);
+                if (row < n_rows && fx != 0) atomicAdd(&s_fx[row], (unsigned long long)fx);
             }
         }
     }
     __syncthreads();
-    float* table = pg.g[pl] + row0;
-    for (uint32_t i = threadIdx.x; i < hsize; i += blockDim.x) {
-        const float v = s_tab[i];
-        if (v != 0.0f) atomicAdd(table + i, v);
+    const double from_fixed = (double)__builtin_ldexpf(1.0f, e - 36);
+    float* table = pg.g[pl] + row0 + row_lo;
+    for (uint32_t i = threadIdx.x; i < n_rows; i += blockDim.x) {
+        const long long v = (long long)s_fx[i];
+        if (v != 0) atomicAdd(table + i, (float)((double)v * from_fixed));
     }
 }
 
@@ -645,9 +669,9 @@ NVSF_API int nvsf_hashgrid4d_dynamic_bwd_scalar(const float* x, uint32_t x_strid
         const int st = fill_meta(pg.meta[p], kPlaneLevels, h_scales + p * kPlaneLevels, h_res + p * kPlaneLevels, h_offsets + p * (kPlaneLevels + 1));
         if (st != NVSF_OK) return st;
     }
-    // LDS form: one launch per group of pairs with the same level size (pair 0: 2^15 rows = 128 KB of LDS, 1024-thread workgroups;
-    // pairs 1, 2: 2^13 rows = 32 KB).  Variant 1 (tests) selects the run-merging global-atomic kernel (the reference form; also
-    // taken when a level does not fit LDS or the batch is too small to fill the chip with slices).
+    // LDS form: one launch per group of pairs with the same level size (pair 0: 2^15 rows = two row ranges of 128 KB of 64-bit sums,
+    // 1024-thread workgroups; pairs 1, 2: 2^13 rows = 64 KB, 512 threads).  Variant 1 (tests) selects the run-merging global-atomic
+    // kernel (the reference form; also taken when a level does not fit LDS or the batch is too small to fill the chip with slices).
     uint32_t max_rows[3];
     bool fits = true;
     for (int p = 0; p < 3; ++p) {
@@ -656,19 +680,23 @@ NVSF_API int nvsf_hashgrid4d_dynamic_bwd_scalar(const float* x, uint32_t x_strid
             const uint32_t rows = pg.meta[p].offset[l + 1] - pg.meta[p].offset[l];
             max_rows[p] = rows > max_rows[p] ? rows : max_rows[p];
         }
-        fits = fits && max_rows[p] * sizeof(float) <= 128u * 1024u;
+        fits = fits && max_rows[p] * sizeof(unsigned long long) <= 2u * 128u * 1024u;
     }
     if (fits && M >= (1u << 16) && nvsf_variant(kVarHash4dBwd) == 0) {
         int p = 0;
         while (p < 3) {
             int q = p + 1;
             while (q < 3 && max_rows[q] == max_rows[p]) ++q;  // consecutive pairs with equal level size share a launch
-            const uint32_t lds = max_rows[p] * (uint32_t)sizeof(float);
-            const uint32_t threads = lds > 64u * 1024u ? 1024u : 256u;
+            const uint32_t split = max_rows[p] * (uint32_t)sizeof(unsigned long long) > 128u * 1024u ? 2u : 1u;
+            const uint32_t lds = (max_rows[p] + split - 1) / split * (uint32_t)sizeof(unsigned long long);
+            const uint32_t threads = lds > 64u * 1024u ? 1024u : 512u;
             const uint32_t n_slices = lds > 64u * 1024u ? 32u : 64u;
             const uint32_t chunk_len = (M + n_slices - 1) / n_slices;
-            hipLaunchKernelGGL(k_hash_dynamic_bwd_lds, dim3(n_slices, (uint32_t)(q - p) * kPlaneLevels), dim3(threads), lds, stream, x, x_stride, M,
-                               grad_out, pg, (uint32_t)p, chunk_len);
+            const dim3 grid(n_slices, (uint32_t)(q - p) * kPlaneLevels * split);
+            if (split == 2)
+                hipLaunchKernelGGL(k_hash_dynamic_bwd_lds<2>, grid, dim3(threads), lds, stream, x, x_stride, M, grad_out, pg, (uint32_t)p, chunk_len);
+            else
+                hipLaunchKernelGGL(k_hash_dynamic_bwd_lds<1>, grid, dim3(threads), lds, stream, x, x_stride, M, grad_out, pg, (uint32_t)p, chunk_len);
             p = q;
         }
         return nvsf_launch_status();
