@@ -247,8 +247,10 @@ int nvsf_exp_col(const float* h, uint32_t row_stride, uint32_t col, uint32_t M, 
 /* ref: tcnn.Network("FullyFusedMLP") network_dynamic.py:125-135,138-161,180-189.
  * x [M, x_stride] fp32 (x_is_f16 == 0) or fp16; weights fp16 = W0 [hidden][in_cols] ++ (n_hidden-1) x
  * [hidden][hidden] ++ W_out [out_cols][hidden]; columns n_in..in_cols-1 of the input read as 1.0.
- * Supported: hidden = 64, out_cols = 16, n_hidden in 1..3, in_cols in {16,...,128}.
- * out fp32 [M, out_stride >= 16] (16-byte aligned rows): the output layer is NOT rounded to fp16. */
+ * Supported: hidden = 64, n_hidden in 1..3, in_cols in {16,...,128}; the output layer always has 16 rows in `weights`.
+ * out_cols = 16: out fp32 [M, out_stride >= 16] (16-byte aligned rows) receives all 16 outputs; out_cols in 1..4: only the
+ * leading out_cols outputs are stored, out fp32 [M, out_stride >= out_cols] (a head with one or three outputs writes 4 ... 16
+ * bytes per row instead of 64; two heads may interleave their columns in one buffer).  The output layer is NOT rounded to fp16. */
 int nvsf_mlp_fwd(const void* x, int x_is_f16, uint32_t M, uint32_t n_in, uint32_t x_stride, const void* weights_f16,
                  uint32_t in_cols, uint32_t hidden, uint32_t n_hidden, uint32_t out_cols, float* out_f32,
                  uint32_t out_stride, nvsf_stream_t stream);

@@ -13,7 +13,7 @@ constexpr int kBlock = 256;
 template <int IN_STEPS, int N_HIDDEN, bool X_F16, bool FAST>
 __global__ __launch_bounds__(kBlock) void k_mlp_fwd(const void* __restrict__ x, uint32_t M, uint32_t n_in, uint32_t x_stride,
                                                     const _Float16* __restrict__ weights, uint32_t in_cols,
-                                                    float* __restrict__ out, uint32_t out_stride, int vec_ok, XPrefix pre) {
+                                                    float* __restrict__ out, uint32_t out_stride, int vec_ok, XPrefix pre, uint32_t n_store) {
     const int lane = lane_id();
     const int g = lane >> 4, sl = lane & 15;
     // ---- weights -> registers
@@ -61,23 +61,30 @@ __global__ __launch_bounds__(kBlock) void k_mlp_fwd(const void* __restrict__ x, 
             pack_hidden(acc, h);
         }
         const float4_t o = wout.apply(h);
-        if (m < M) *reinterpret_cast<float4_t*>(out + (size_t)m * out_stride + 4 * g) = o;  // fp32 logits (not rounded to fp16)
+        if (n_store >= 16u) {  // uniform
+            if (m < M) *reinterpret_cast<float4_t*>(out + (size_t)m * out_stride + 4 * g) = o;  // fp32 logits (not rounded to fp16)
+        } else if (m < M && g == 0) {  // a head with 1 ... 4 outputs: only those columns leave (4 ... 16 B per sample instead of 64)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if ((uint32_t)r < n_store) out[(size_t)m * out_stride + r] = o[r];
+        }
     }
 }
 }  // namespace
 
 #define REQUIRE(cond) do { if (!(cond)) return NVSF_ERR_INVALID_ARG; } while (0)
 
-// weights: fp16 [64][in_cols] ++ (n_hidden-1) x [64][64] ++ [16][64]; out fp32 [M, out_stride>=16]
+// weights: fp16 [64][in_cols] ++ (n_hidden-1) x [64][64] ++ [16][64]; out fp32 [M, out_stride]: all 16 columns (out_cols = 16) or the leading 1 ... 4
 static int mlp_fwd_impl(const void* x, int x_is_f16, uint32_t M, uint32_t n_in, uint32_t x_stride, const void* weights_f16,
                         uint32_t in_cols, uint32_t hidden, uint32_t n_hidden, uint32_t out_cols, float* out_f32,
                         uint32_t out_stride, XPrefix pre, hipStream_t stream) {
     if (M == 0) return NVSF_OK;
     REQUIRE(x && weights_f16 && out_f32);
     REQUIRE(n_in >= 1 && n_in <= in_cols && in_cols % 16 == 0 && x_stride >= n_in - pre.split);
-    REQUIRE(out_stride >= 16 && out_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(out_f32) & 15u) == 0);
+    if (out_cols == 16) REQUIRE(out_stride >= 16 && out_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(out_f32) & 15u) == 0);
+    else REQUIRE(out_cols >= 1 && out_cols <= 4 && out_stride >= out_cols && (reinterpret_cast<uintptr_t>(out_f32) & 3u) == 0);
     REQUIRE((reinterpret_cast<uintptr_t>(weights_f16) & 15u) == 0);
-    if (hidden != (uint32_t)kHidden || out_cols != 16 || n_hidden < 1 || n_hidden > 3 || in_cols > 128) return NVSF_ERR_UNSUPPORTED;
+    if (hidden != (uint32_t)kHidden || n_hidden < 1 || n_hidden > 3 || in_cols > 128) return NVSF_ERR_UNSUPPORTED;
     const int in_steps = (int)((in_cols + 31) / 32);
     const size_t esz = x_is_f16 ? 2 : 4;
     const int vec_ok = ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) && ((x_stride * esz) % 16 == 0);
@@ -92,7 +99,7 @@ static int mlp_fwd_impl(const void* x, int x_is_f16, uint32_t M, uint32_t n_in, 
     }
 #define LAUNCH(S, H, XF, FA)                                                                                                   \
     hipLaunchKernelGGL((k_mlp_fwd<S, H, XF, FA>), dim3(blocks), dim3(kBlock), 0, stream, x, M, n_in, x_stride, w, in_cols, o, \
-                       out_stride, vec_ok, pre)
+                       out_stride, vec_ok, pre, out_cols)
 #define BY_F(S, H, XF) do { if (fast) LAUNCH(S, H, XF, true); else LAUNCH(S, H, XF, false); } while (0)
 #define BY_X(S, H) do { if (x_is_f16) BY_F(S, H, true); else BY_F(S, H, false); } while (0)
 #define BY_H(S)                                       \

@@ -203,22 +203,25 @@ def _rows(x):
     return x
 
 
-def mlp_forward(x, weights_f16, spec, out=None, prefix=None):
+def mlp_forward(x, weights_f16, spec, out=None, prefix=None, n_store=None):
     """x [M, n_in] (fp32 or fp16) -> fp32 [M, out_cols] (fp16 operands, fp32 accumulate, output not rounded).
     `out`: optional fp32 destination, 16-byte aligned rows of >= out_cols columns (e.g. a column block of a wider buffer).
+    `n_store` in 1..4 (with `out` [M, >= n_store], any 4-byte alignment, unit column stride): only the leading n_store outputs are
+    stored -- a head with one or three outputs writes 4 ... 16 bytes per row instead of 64.
     `prefix` = (rows fp16 [G, >= n_cols], rows_per_prefix, n_cols): the first n_cols input columns of row r are
     prefix_rows[r // rows_per_prefix] and x holds the remaining n_in - n_cols columns only (nvsf_mlp_fwd_prefix)."""
     x = _rows(x)
     M = x.shape[0]
     if out is None:
-        out = torch.empty(M, spec.out_cols, dtype=torch.float32, device=x.device)
+        out = torch.empty(M, spec.out_cols if n_store is None else n_store, dtype=torch.float32, device=x.device)
+    cols = spec.out_cols if n_store is None else int(n_store)
     if prefix is not None:
         rows, per, n_cols = prefix
         _hip.call("nvsf_mlp_fwd_prefix", _hip.ptr_rows(rows), rows.stride(0), int(per), int(n_cols), _hip.ptr_rows(x), M, spec.n_in, x.stride(0),
-                  _hip.ptr(weights_f16), spec.in_cols, spec.hidden, spec.n_hidden, spec.out_cols, _hip.ptr_rows(out), out.stride(0))
+                  _hip.ptr(weights_f16), spec.in_cols, spec.hidden, spec.n_hidden, cols, _hip.ptr_rows(out), out.stride(0))
         return out
     _hip.call("nvsf_mlp_fwd", _hip.ptr_rows(x), 1 if x.dtype == torch.float16 else 0, M, spec.n_in, x.stride(0), _hip.ptr(weights_f16),
-              spec.in_cols, spec.hidden, spec.n_hidden, spec.out_cols, _hip.ptr_rows(out), out.stride(0))
+              spec.in_cols, spec.hidden, spec.n_hidden, cols, _hip.ptr_rows(out), out.stride(0))
     return out
 
 
@@ -387,14 +390,7 @@ class HeadsFn(Function):
             prefix = (enc_ray, M // N, n_enc)
             ctx.save_for_backward(x16, w16_a, w16_b, enc_ray)
             ctx.spec, ctx.n_enc, ctx.n_geo, ctx.geo_dtype, ctx.prefix_rows = spec, n_enc, n_geo, geo.dtype, M // N
-            if w16_b is None:
-                return mlp_forward(x16, w16_a, spec, prefix=prefix)[:, :spec.n_out]
-            blocks = torch.empty(M, 2 * spec.out_cols, dtype=torch.float32, device=geo.device)
-            mlp_forward(x16, w16_a, spec, out=blocks[:, :spec.out_cols], prefix=prefix)
-            mlp_forward(x16, w16_b, spec, out=blocks[:, spec.out_cols:], prefix=prefix)
-            if spec.n_out == 1:
-                return blocks.view(M, 2, spec.out_cols)[:, :, 0]
-            return blocks.view(M, 2, spec.out_cols)[:, :, :spec.n_out].reshape(M, 2 * spec.n_out)
+            return HeadsFn._logits(x16, w16_a, w16_b, spec, prefix)
         assert n_enc + n_geo == spec.n_in and buf.shape[1] >= spec.n_in and buf.dtype == torch.float16
         ctx.prefix_rows = None
         if enc_ray is not None:  # per-ray encoding [N, >= n_enc] fp16: rows assembled whole (nvsf_heads_input_f16)
@@ -407,17 +403,22 @@ class HeadsFn(Function):
         u = buf[:, :spec.n_in]
         ctx.save_for_backward(buf, w16_a, w16_b)
         ctx.spec, ctx.n_enc, ctx.n_geo, ctx.geo_dtype = spec, n_enc, n_geo, geo.dtype
+        return HeadsFn._logits(u, w16_a, w16_b, spec, None)
+
+    @staticmethod
+    def _logits(u, w16_a, w16_b, spec, prefix):
+        """[M, n_out] (one head) or [M, 2 n_out] = [head a | head b]: each head stores only its n_out <= 4 logits, the two heads
+        interleaved in one buffer (no 16-column fp32 blocks of which one column is used, no torch.cat pass over the samples)."""
+        M, n = u.shape[0], spec.n_out
+        if n > 4:
+            raise _hip.NvsfHipError("per-sample heads with more than 4 outputs are not supported")
         if w16_b is None:
-            return mlp_forward(u, w16_a, spec)[:, :spec.n_out]
-        # both heads write their 16-column logit blocks side by side; [raydrop | intensity] is a strided view of the
-        # leading columns of the two blocks (no torch.cat pass over the samples)
-        M = buf.shape[0]
-        blocks = torch.empty(M, 2 * spec.out_cols, dtype=torch.float32, device=buf.device)
-        mlp_forward(u, w16_a, spec, out=blocks[:, :spec.out_cols])
-        mlp_forward(u, w16_b, spec, out=blocks[:, spec.out_cols:])
-        if spec.n_out == 1:
-            return blocks.view(M, 2, spec.out_cols)[:, :, 0]
-        return blocks.view(M, 2, spec.out_cols)[:, :, :spec.n_out].reshape(M, 2 * spec.n_out)
+            width = 4 if n == 3 else n  # colour: 16-byte rows, the view drops the padding column
+            return mlp_forward(u, w16_a, spec, out=torch.empty(M, width, dtype=torch.float32, device=u.device), prefix=prefix, n_store=n)[:, :n]
+        both = torch.empty(M, 2 * n, dtype=torch.float32, device=u.device)
+        mlp_forward(u, w16_a, spec, out=both[:, :n], prefix=prefix, n_store=n)
+        mlp_forward(u, w16_b, spec, out=both[:, n:], prefix=prefix, n_store=n)
+        return both
 
     @staticmethod
     def backward(ctx, grad_h):

@@ -222,6 +222,27 @@ def test_mlp_forward(ops, dev, case):
     assert (np.abs(got - ref) <= 2e-6 * scale).mean() > 0.97
 
 
+def test_mlp_forward_stores_only_the_leading_outputs(ops, dev):
+    """out_cols in 1..4 (mlp_forward(n_store=...)): the leading outputs of the same evaluation, bit for bit, into a narrow buffer --
+    one column of an interleaved [M, 2] buffer (two heads side by side) and an unaligned three-column view; the neighbouring
+    columns are not touched."""
+    spec = ops.MlpSpec(87, 1, 64, 2)
+    rng = np.random.default_rng(9)
+    M = 2049
+    x = _t(rng.standard_normal((M, 87)).astype(np.float16), dev)
+    w = _t(np.concatenate([(rng.uniform(-1, 1, a * b) * np.sqrt(6.0 / (a + b))).astype(np.float16) for a, b in spec.shapes]), dev)
+    full = ops.mlp_forward(x, w, spec)
+    both = torch.full((M, 2), 7.0, device=dev)
+    ops.mlp_forward(x, w, spec, out=both[:, 1:], n_store=1)
+    assert torch.equal(both[:, 1], full[:, 0]) and bool((both[:, 0] == 7.0).all())
+    for n in (2, 3, 4):
+        buf = torch.full((M, 5), 7.0, device=dev)
+        ops.mlp_forward(x, w, spec, out=buf[:, 1:], n_store=n)
+        assert torch.equal(buf[:, 1:1 + n], full[:, :n]) and bool((buf[:, 0] == 7.0).all()) and bool((buf[:, 1 + n:] == 7.0).all())
+    with pytest.raises(Exception):
+        ops.mlp_forward(x, w, spec, out=torch.empty(M, 8, device=dev), n_store=5)
+
+
 def test_mlp_operand_layout_with_integers(ops, dev):
     """Exact-integer check of the MFMA fragment maps (asymmetric weights: a transposed or permuted fragment
     cannot pass): one hidden layer, W0 = small integers, identity-like second layer."""
