@@ -84,6 +84,7 @@ def _bin_from(spec, M, rows_per_ray):
     return fine_levels_from(spec, rows_per_ray) if (rows_per_ray and M >= (1 << 18) and M % rows_per_ray == 0) else None
 
 
+_BIN_ROWS_MAX = 1 << 23
 _BIN_WS = {}  # (device, stream) -> scratch of the binned scatter; one per stream: side-stream scatters of two tables may overlap
 
 
@@ -113,8 +114,15 @@ def hashgrid_backward(x, cols, spec, grad_out, grad_table=None, fine_from=None):
     if grad_table is None:
         grad_table = torch.zeros(spec.n_params, dtype=torch.float32, device=x.device)
     M = x.shape[0]
+    need = 0
     if fine_from is not None and fine_from < spec.L:
+        if M > _BIN_ROWS_MAX:  # the fixed-point image of the bins takes 2^26 addends per row: longer batches go in pieces (sums accumulate)
+            for i in range(0, M, _BIN_ROWS_MAX):
+                hashgrid_backward(x[i:i + _BIN_ROWS_MAX], cols, spec, grad_out[i:i + _BIN_ROWS_MAX], grad_table, fine_from)
+            return grad_table
+        # 0: the grid has no binned form: every level through the atomics
         need = _hip.hashgrid_bwd_ws_bytes(M, spec.L - fine_from, spec.F, int(spec.offsets[-1] - spec.offsets[-2]))
+    if need:
         key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
         ws = _BIN_WS.get(key)
         if ws is None or ws.numel() < need:

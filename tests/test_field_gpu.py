@@ -154,6 +154,13 @@ def test_hashgrid_backward_binned_levels_agree_with_the_oracle(ops, dev, L, F, l
     acc = ops.hashgrid_backward(_t(x, dev), (0, 1, 2), spec, _t(go, dev), fine_from=fine_from)
     acc = ops.hashgrid_backward(_t(x, dev), (0, 1, 2), spec, _t(go, dev), grad_table=acc, fine_from=fine_from).cpu().numpy()
     np.testing.assert_allclose(acc, 2 * O.hashgrid_bwd(x, (0, 1, 2), spec, go), atol=1e-3, rtol=1e-4)
+    # a batch longer than the bins' fixed-point headroom allows goes in pieces
+    old_max, ops._BIN_ROWS_MAX = ops._BIN_ROWS_MAX, 1777
+    try:
+        got = ops.hashgrid_backward(_t(x, dev), (0, 1, 2), spec, _t(go, dev), fine_from=fine_from).cpu().numpy()
+    finally:
+        ops._BIN_ROWS_MAX = old_max
+    np.testing.assert_allclose(got, O.hashgrid_bwd(x, (0, 1, 2), spec, go), atol=5e-4, rtol=1e-4)
     # every sample in one cell: 8 rows per level receive everything, far beyond a bin's capacity
     M2 = 20001
     x2 = (np.array([[0.3141, 0.2718, 0.5772]]) + rng.random((M2, 3)) * 1e-6).astype(np.float32)
