@@ -332,7 +332,7 @@ __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_bin(const float* __rest
                                                              uint32_t c2, GridMeta meta, uint32_t l_first, uint32_t n_fine,
                                                              const void* __restrict__ grad_out, uint32_t go_stride, float* __restrict__ grad_table,
                                                              uint32_t* __restrict__ cursors, uint32_t* __restrict__ level_max,
-                                                             uint32_t* __restrict__ pair_row, float* __restrict__ pair_val, uint32_t cap,
+                                                             uint16_t* __restrict__ pair_row, float* __restrict__ pair_val, uint32_t cap,
                                                              uint32_t nbins) {
     using C = BinCfg<F>;
     constexpr int SPT = C::kTile / kBlock;
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_bin(const float* __rest
             const uint32_t q = s_gbase[b] + (p - s_pre[b]);
             if (q < cap) {
                 const size_t at = (size_t)(j * nbins + b) * cap + q;
-                pair_row[at] = row;
+                pair_row[at] = (uint16_t)(row & (uint32_t)(C::kBinRows - 1));  // the row inside its bin: 12 / 11 bits
                 if constexpr (F == 2) {
                     *reinterpret_cast<float2*>(pair_val + at * 2) = make_float2(s_val[p * 2], s_val[p * 2 + 1]);
                 } else {
@@ -459,7 +459,7 @@ constexpr int kReduceBlock = 512;
 constexpr int kFixedTop = 36;  // the level's largest |g| has its leading bit at 2^36 in the fixed-point image
 template <int F>
 __global__ __launch_bounds__(kReduceBlock) void k_hashgrid_bwd_reduce(const uint32_t* __restrict__ cursors, const uint32_t* __restrict__ level_max,
-                                                                      const uint32_t* __restrict__ pair_row, const float* __restrict__ pair_val,
+                                                                      const uint16_t* __restrict__ pair_row, const float* __restrict__ pair_val,
                                                                       uint32_t cap, uint32_t nbins, uint32_t split, GridMeta meta, uint32_t l_first,
                                                                       float* __restrict__ grad_table) {
     using C = BinCfg<F>;
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(kReduceBlock) void k_hashgrid_bwd_reduce(const uint
     const float to_fixed = __builtin_ldexpf(1.0f, kFixedTop - e);
     for (int i = (int)threadIdx.x; i < C::kBinRows * F; i += kReduceBlock) s_acc[i] = 0ull;
     __syncthreads();
-    const uint32_t* pr = pair_row + (size_t)bin_id * cap;
+    const uint16_t* pr = pair_row + (size_t)bin_id * cap;
     const float* pv = pair_val + (size_t)bin_id * cap * F;
     constexpr int U = 4;
     for (uint32_t q = q0 + threadIdx.x; q < q1; q += kReduceBlock * U) {
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(kReduceBlock) void k_hashgrid_bwd_reduce(const uint
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const uint32_t qq = q + (uint32_t)u * kReduceBlock;
-            row[u] = qq < q1 ? pr[qq] : 0xFFFFFFFFu;
+            row[u] = qq < q1 ? (uint32_t)pr[qq] : 0xFFFFFFFFu;
             if (qq < q1) {
                 if constexpr (F == 2) {
                     const float2 t = *reinterpret_cast<const float2*>(pv + (size_t)qq * 2);
@@ -586,7 +586,7 @@ struct BinPlan {
     uint32_t nbins, cap;
     size_t cursors_bytes, rows_bytes, vals_bytes;
 };
-// Workspace of the binned scatter: [cursors: n_fine x nbins u32, max |g| bits: 16 u32 | pair rows: n_fine x nbins x cap u32 | pair values: ... x F fp32]
+// Workspace of the binned scatter: [cursors: n_fine x nbins u32, max |g| bits: 16 u32 | pair rows: n_fine x nbins x cap u16 | pair values: ... x F fp32]
 bool bin_plan(uint32_t M, uint32_t n_fine, uint32_t F, uint32_t rows_per_level, BinPlan& bp) {
     if ((F != 2 && F != 4) || n_fine == 0 || n_fine > 16) return false;
     const uint32_t bin_rows = 8192u / F;
@@ -598,7 +598,7 @@ bool bin_plan(uint32_t M, uint32_t n_fine, uint32_t F, uint32_t rows_per_level, 
     if (cap * n_fine * bp.nbins >= (1ull << 32)) return false;
     bp.cap = (uint32_t)cap;
     bp.cursors_bytes = (((size_t)(n_fine * bp.nbins + 16u) * sizeof(uint32_t)) + 255u) & ~(size_t)255u;  // cursors + max |g| per level
-    bp.rows_bytes = (size_t)n_fine * bp.nbins * cap * sizeof(uint32_t);
+    bp.rows_bytes = (((size_t)n_fine * bp.nbins * cap * sizeof(uint16_t)) + 255u) & ~(size_t)255u;
     bp.vals_bytes = (size_t)n_fine * bp.nbins * cap * F * sizeof(float);
     return true;
 }
@@ -626,7 +626,7 @@ int hashgrid_bwd_launch(const float* x, uint32_t M, uint32_t x_stride, const uin
         REQUIRE(bin_plan(M, n_fine, F, rows, bp));
         REQUIRE(workspace_bytes >= bp.cursors_bytes + bp.rows_bytes + bp.vals_bytes);
         uint32_t* cursors = reinterpret_cast<uint32_t*>(workspace);
-        uint32_t* pair_row = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + bp.cursors_bytes);
+        uint16_t* pair_row = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) + bp.cursors_bytes);
         float* pair_val = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + bp.cursors_bytes + bp.rows_bytes);
         {
             const hipError_t e = hipMemsetAsync(cursors, 0, bp.cursors_bytes, stream);
