@@ -178,19 +178,24 @@ int nvsf_hashgrid_bwd(const float* x, uint32_t M, uint32_t x_stride, const uint3
                       const void* grad_out, int grad_is_f16, uint32_t go_stride, float* grad_table_f32,
                       nvsf_stream_t stream);
 
-/* The same gradient with the levels fine_from ... L-1 scattered through bins instead of one memory-side atomic per corner pair
- * (levels whose cells are shorter than a ray step: no two consecutive samples share a cell, nothing to merge).  Two streaming
- * passes: (sample, corner) contributions are appended to the bin (16384 / F consecutive rows of one level) their row falls into,
- * then one workgroup per bin sums its contributions in LDS and adds the 64-KB image to grad_table_f32.  Levels below fine_from
- * take the kernel of nvsf_hashgrid_bwd.  Requirements: D = 3, F in {2, 4}, the fine levels hashed and of ONE power-of-two size
- * (16384 / F ... 2^20 rows).  workspace: device memory, 256-byte aligned, at least nvsf_hashgrid_bwd_binned_ws_bytes(M, L -
- * fine_from, F, rows of a fine level) bytes (0 = shape not supported), contents irrelevant.  Same sums as nvsf_hashgrid_bwd up to
- * the order of the fp32 additions, for any input (contributions beyond a bin's capacity are added directly). */
-size_t nvsf_hashgrid_bwd_binned_ws_bytes(uint32_t M, uint32_t n_fine, uint32_t F, uint32_t rows_per_level);
+/* The same gradient with the levels merge_from ... L-1 scattered through bins instead of memory-side atomics.  Two streaming passes:
+ * contributions {row, F values} are appended to the bin (8192 / F consecutive rows of one level) their row falls into, then the
+ * workgroups of a bin sum its contributions in LDS (64-bit fixed point, order-independent) and add the image to grad_table_f32.
+ *   levels fine_from ... L-1  (cells shorter than a ray step: no two consecutive rows share a cell): one contribution per (row,
+ *                             vertex); these levels must be hashed;
+ *   levels merge_from ... fine_from-1: runs of up to 8 CONSECUTIVE ROWS that fall into one cell are summed in registers first and
+ *                             contribute once per vertex (rows are expected in ray order; any order is correct);
+ *   levels 0 ... merge_from-1: the kernel of nvsf_hashgrid_bwd.
+ * Requirements: D = 3, F in {2, 4}, binned levels of at most 2^20 rows and 256 bins, hashed ones of power-of-two size, M * 8 <= 2^26.
+ * workspace: device memory, 256-byte aligned, at least nvsf_hashgrid_bwd_binned_ws_bytes(...) bytes (0 = shape not supported),
+ * contents irrelevant.  Same sums as nvsf_hashgrid_bwd up to the order of the fp32 additions (2^-33 of a level's largest gradient per
+ * contribution), for any input: contributions beyond a bin's capacity are added directly. */
+size_t nvsf_hashgrid_bwd_binned_ws_bytes(uint32_t M, uint32_t L, uint32_t F, const uint32_t* h_res, const uint32_t* h_offsets,
+                                         uint32_t merge_from, uint32_t fine_from);
 int nvsf_hashgrid_bwd_binned(const float* x, uint32_t M, uint32_t x_stride, const uint32_t* cols, uint32_t D, uint32_t L,
                              uint32_t F, const float* h_scales, const uint32_t* h_res, const uint32_t* h_offsets,
                              const void* grad_out, int grad_is_f16, uint32_t go_stride, float* grad_table_f32,
-                             uint32_t fine_from, void* workspace, size_t workspace_bytes, nvsf_stream_t stream);
+                             uint32_t merge_from, uint32_t fine_from, void* workspace, size_t workspace_bytes, nvsf_stream_t stream);
 
 /* ref: tcnn.Encoding("Frequency") network_dynamic.py:108-114.  x fp32 [M,n_dims] ->
  * out fp16 [M, out_stride >= 2*n_dims*n_freq], out[i*2K+2k] = sin(2^k pi x_i), [..+1] = cos. */

@@ -312,11 +312,11 @@ __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_corners(const float* __
 //                          atomic per bin and copies the sorted pairs out as contiguous runs; it also records max |g| of the level;
 //   k_hashgrid_bwd_reduce  (bins): a workgroup adds the pairs of its bin into an LDS image of the bin and adds the image to the table
 //                          gradient with contiguous atomics (512 pieces per bin instead of one per pair).  The image is 64-bit FIXED
-//                          POINT (value x 2^(36 - exponent of the level's max |g|), ds_add_u64): LDS float atomics run at a quarter
+//                          POINT (value x 2^(33 - exponent of the level's max |g|), ds_add_u64): LDS float atomics run at a quarter
 //                          of the rate of the integer ones on gfx950 (measured: 1.6 ms against 0.38 ms for the five fine levels of a
-//                          camera batch), and integer sums do not depend on the order of the pairs.  |w g| < 2^(e+1) scales below 2^37,
-//                          a row can take 2^26 contributions before the sum leaves 63 bits (the host limits M x 8 to that); the
-//                          resolution 2^(e-36) is 2^-13 ulp of the largest gradient.
+//                          camera batch), and integer sums do not depend on the order of the pairs.  A contribution (a run of up to 8 rows,
+//                          |w g| < 2^(e+1) each) scales below 2^37, a row can take 2^26 of them before the sum leaves 63 bits (the host
+//                          limits M x 8 to that); the resolution 2^(e-33) is 2^-10 ulp of the largest gradient.
 // A bin holds `cap` pairs (1.25 x the mean of a uniform hash + slack); what does not fit is added to the table directly, so the result is
 // the same sum for any input (only slower when the hash is badly skewed).  Same addends as the other kernels, another order.
 template <int F> struct BinCfg {
@@ -327,13 +327,23 @@ template <int F> struct BinCfg {
     static constexpr int kMaxBins = 256;                  // rows per level <= 256 bins (checked on the host)
 };
 
+// The binned levels of one launch: level, bins, capacity of a bin, where its cursors / pairs / reduce workgroups start.  `merged`: the
+// level's contributions are run sums -- up to 8 consecutive rows that fall into one cell add their w_c g in registers first (a
+// segmented scan over the lanes of the wave, whose lanes are consecutive rows) and the LAST row of the run emits the eight sums.  On
+// the levels whose cells are several ray steps long this leaves a fraction of the contributions (and of the memory-side atomics the
+// corner-parallel kernel pays for them).
+struct BinLevels {
+    uint32_t n;
+    uint32_t level[16], nbins[16], bin0[16], cap[16], split[16], wg0[17], merged[16];
+    unsigned long long pair0[16];
+};
+
 template <int F, bool GRAD_F16>
 __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_bin(const float* __restrict__ x, uint32_t M, uint32_t x_stride, uint32_t c0, uint32_t c1,
-                                                             uint32_t c2, GridMeta meta, uint32_t l_first, uint32_t n_fine,
-                                                             const void* __restrict__ grad_out, uint32_t go_stride, float* __restrict__ grad_table,
-                                                             uint32_t* __restrict__ cursors, uint32_t* __restrict__ level_max,
-                                                             uint16_t* __restrict__ pair_row, float* __restrict__ pair_val, uint32_t cap,
-                                                             uint32_t nbins) {
+                                                             uint32_t c2, GridMeta meta, BinLevels bl, const void* __restrict__ grad_out,
+                                                             uint32_t go_stride, float* __restrict__ grad_table, uint32_t* __restrict__ cursors,
+                                                             uint32_t* __restrict__ level_max, uint16_t* __restrict__ pair_row,
+                                                             float* __restrict__ pair_val) {
     using C = BinCfg<F>;
     constexpr int SPT = C::kTile / kBlock;
     __shared__ uint32_t s_cnt[C::kMaxBins], s_pre[C::kMaxBins], s_gbase[C::kMaxBins], s_total, s_max;
@@ -344,47 +354,94 @@ __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_bin(const float* __rest
     uint32_t mrow[SPT];
 #pragma unroll
     for (int s = 0; s < SPT; ++s) {
-        mrow[s] = blockIdx.x * C::kTile + s * kBlock + tid;
+        mrow[s] = blockIdx.x * C::kTile + s * kBlock + tid;  // lanes of a wave = consecutive rows
         const uint32_t mm = mrow[s] < M ? mrow[s] : M - 1;
         const float* px = x + (size_t)mm * x_stride;
         xs[s][0] = px[c0];
         xs[s][1] = px[c1];
         xs[s][2] = px[c2];
     }
-    for (uint32_t j = 0; j < n_fine; ++j) {
-        const uint32_t l = l_first + j;
+    for (uint32_t j = 0; j < bl.n; ++j) {
+        const uint32_t l = bl.level[j], nbins = bl.nbins[j], cap = bl.cap[j], bin0 = bl.bin0[j];
+        const bool merged = bl.merged[j] != 0u;  // uniform
         const float scale = meta.scale[l];
         const uint32_t res = meta.res[l], row0 = meta.offset[l], hsize = meta.offset[l + 1] - row0;
         for (int b = tid; b < C::kMaxBins; b += kBlock) s_cnt[b] = 0u;
         if (tid == 0) s_max = 0u;
         __syncthreads();
-        float g[SPT][F], frac[SPT][3];
+        float val[SPT][8][F];   // contributions of this lane's row (or of the run that ends with it) to the eight vertices of its cell
         uint32_t pk[SPT][8];
         float gmax = 0.0f;
 #pragma unroll
         for (int s = 0; s < SPT; ++s) {
+            float g[F];
             bool any = false;
 #pragma unroll
             for (int f = 0; f < F; ++f) {
                 const size_t at = (size_t)(mrow[s] < M ? mrow[s] : 0u) * go_stride + l * F + f;
-                if constexpr (GRAD_F16) g[s][f] = (float)reinterpret_cast<const _Float16*>(grad_out)[at];
-                else g[s][f] = reinterpret_cast<const float*>(grad_out)[at];
-                if (mrow[s] >= M) g[s][f] = 0.0f;
-                any = any || g[s][f] != 0.0f;
-                gmax = fmaxf(gmax, fabsf(g[s][f]));
+                if constexpr (GRAD_F16) g[f] = (float)reinterpret_cast<const _Float16*>(grad_out)[at];
+                else g[f] = reinterpret_cast<const float*>(grad_out)[at];
+                if (mrow[s] >= M) g[f] = 0.0f;
+                any = any || g[f] != 0.0f;
+                gmax = fmaxf(gmax, fabsf(g[f]));
             }
             uint32_t cell[3];
+            float frac[3];
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
                 const float pos = fmaf(scale, xs[s][d], 0.5f);
                 const float fl = floorf(pos);
-                frac[s][d] = pos - fl;
+                frac[d] = pos - fl;
                 cell[d] = (uint32_t)(int32_t)fl;
             }
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
+                const float w = ((1.0f * ((c & 1) ? frac[0] : 1.0f - frac[0])) * ((c & 2) ? frac[1] : 1.0f - frac[1])) *
+                                ((c & 4) ? frac[2] : 1.0f - frac[2]);
+#pragma unroll
+                for (int f = 0; f < F; ++f) val[s][c][f] = w * g[f];
+            }
+            bool emit = any;
+            if (merged) {
+                // runs: consecutive lanes in one cell, cut every 8 lanes (a run never crosses a DPP row of 16, three scan steps reach
+                // its first lane).  head = first lane of a run, dist = lanes since the head, tail = last lane of a run.
+                bool head = (lane & 7) == 0;
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cell[d], 0x111 /* row_shr:1 */, 0xF, 0xF, false);
+                    head = head || prev != cell[d];
+                }
+                const unsigned long long hm = __ballot(head);
+                const unsigned long long below = hm & ((2ull << lane) - 1ull);
+                const int dist = lane - (63 - __builtin_clzll(below));
+                const bool tail = (lane & 7) == 7 || ((hm >> ((lane + 1) & 63)) & 1ull) != 0ull;
+                bool run_any = false;
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+#pragma unroll
+                    for (int f = 0; f < F; ++f) {
+                        float v = val[s][c][f];
+                        {
+                            const float t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xF, 0xF, false));
+                            if (dist >= 1) v += t;
+                        }
+                        {
+                            const float t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x112, 0xF, 0xF, false));
+                            if (dist >= 2) v += t;
+                        }
+                        {
+                            const float t = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x114, 0xF, 0xF, false));
+                            if (dist >= 4) v += t;
+                        }
+                        val[s][c][f] = v;
+                        run_any = run_any || v != 0.0f;
+                    }
+                emit = tail && run_any;
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
                 pk[s][c] = 0xFFFFFFFFu;
-                if (any) {
+                if (emit) {
                     const uint32_t cc[3] = {cell[0] + (c & 1u), cell[1] + ((c >> 1) & 1u), cell[2] + ((c >> 2) & 1u)};
                     const uint32_t row = grid_row<3>(cc, res, hsize);
                     const uint32_t rank = atomicAdd(&s_cnt[row >> C::kBinShift], 1u);
@@ -409,7 +466,7 @@ __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_bin(const float* __rest
                 }
                 if (b < nbins) {
                     s_pre[b] = run + incl - cnt;
-                    s_gbase[b] = cnt ? atomicAdd(&cursors[j * nbins + b], cnt) : 0u;
+                    s_gbase[b] = cnt ? atomicAdd(&cursors[bin0 + b], cnt) : 0u;
                 }
                 run += (uint32_t)__shfl((int)incl, kWave - 1);
             }
@@ -426,11 +483,9 @@ __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_bin(const float* __rest
                 if (pk[s][c] == 0xFFFFFFFFu) continue;
                 const uint32_t row = pk[s][c] & 0xFFFFFu, rank = pk[s][c] >> 20;
                 const uint32_t at = s_pre[row >> C::kBinShift] + rank;
-                const float w = ((1.0f * ((c & 1) ? frac[s][0] : 1.0f - frac[s][0])) * ((c & 2) ? frac[s][1] : 1.0f - frac[s][1])) *
-                                ((c & 4) ? frac[s][2] : 1.0f - frac[s][2]);
                 s_row[at] = row;
 #pragma unroll
-                for (int f = 0; f < F; ++f) s_val[at * F + f] = w * g[s][f];
+                for (int f = 0; f < F; ++f) s_val[at * F + f] = val[s][c][f];
             }
         __syncthreads();
         const uint32_t total = s_total;
@@ -438,7 +493,7 @@ __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_bin(const float* __rest
             const uint32_t row = s_row[p], b = row >> C::kBinShift;
             const uint32_t q = s_gbase[b] + (p - s_pre[b]);
             if (q < cap) {
-                const size_t at = (size_t)(j * nbins + b) * cap + q;
+                const size_t at = (size_t)bl.pair0[j] + (size_t)b * cap + q;
                 pair_row[at] = (uint16_t)(row & (uint32_t)(C::kBinRows - 1));  // the row inside its bin: 12 / 11 bits
                 if constexpr (F == 2) {
                     *reinterpret_cast<float2*>(pair_val + at * 2) = make_float2(s_val[p * 2], s_val[p * 2 + 1]);
@@ -456,17 +511,19 @@ __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_bin(const float* __rest
 }
 
 constexpr int kReduceBlock = 512;
-constexpr int kFixedTop = 36;  // the level's largest |g| has its leading bit at 2^36 in the fixed-point image
+constexpr int kFixedTop = 33;  // the level's largest |g| has its leading bit at 2^33 in the fixed-point image (a run sum reaches 2^37)
 template <int F>
 __global__ __launch_bounds__(kReduceBlock) void k_hashgrid_bwd_reduce(const uint32_t* __restrict__ cursors, const uint32_t* __restrict__ level_max,
                                                                       const uint16_t* __restrict__ pair_row, const float* __restrict__ pair_val,
-                                                                      uint32_t cap, uint32_t nbins, uint32_t split, GridMeta meta, uint32_t l_first,
-                                                                      float* __restrict__ grad_table) {
+                                                                      BinLevels bl, GridMeta meta, float* __restrict__ grad_table) {
     using C = BinCfg<F>;
     __shared__ unsigned long long s_acc[C::kBinRows * F];
-    const uint32_t bin_id = blockIdx.x / split, part = blockIdx.x - bin_id * split;
-    const uint32_t j = bin_id / nbins, b = bin_id - j * nbins;
-    uint32_t n = cursors[bin_id];
+    uint32_t j = 0;
+    while (j + 1 < bl.n && blockIdx.x >= bl.wg0[j + 1]) ++j;  // uniform
+    const uint32_t local = blockIdx.x - bl.wg0[j], split = bl.split[j], cap = bl.cap[j];
+    const uint32_t b = local / split, part = local - b * split;
+    const uint32_t l = bl.level[j], rows_l = meta.offset[l + 1] - meta.offset[l];
+    uint32_t n = cursors[bl.bin0[j] + b];
     n = n < cap ? n : cap;
     const uint32_t q0 = (uint32_t)((unsigned long long)n * part / split), q1 = (uint32_t)((unsigned long long)n * (part + 1) / split);
     if (q0 == q1) return;  // uniform
@@ -475,8 +532,9 @@ __global__ __launch_bounds__(kReduceBlock) void k_hashgrid_bwd_reduce(const uint
     const float to_fixed = __builtin_ldexpf(1.0f, kFixedTop - e);
     for (int i = (int)threadIdx.x; i < C::kBinRows * F; i += kReduceBlock) s_acc[i] = 0ull;
     __syncthreads();
-    const uint16_t* pr = pair_row + (size_t)bin_id * cap;
-    const float* pv = pair_val + (size_t)bin_id * cap * F;
+    const size_t base = (size_t)bl.pair0[j] + (size_t)b * cap;
+    const uint16_t* pr = pair_row + base;
+    const float* pv = pair_val + base * F;
     constexpr int U = 4;
     for (uint32_t q = q0 + threadIdx.x; q < q1; q += kReduceBlock * U) {
         uint32_t row[U];
@@ -508,8 +566,10 @@ __global__ __launch_bounds__(kReduceBlock) void k_hashgrid_bwd_reduce(const uint
     }
     __syncthreads();
     const double from_fixed = (double)__builtin_ldexpf(1.0f, e - kFixedTop);
-    float* dst = grad_table + ((size_t)meta.offset[l_first + j] + (size_t)b * C::kBinRows) * F;
-    for (int i = (int)threadIdx.x; i < C::kBinRows * F; i += kReduceBlock) {
+    const uint32_t first_row = b * (uint32_t)C::kBinRows;
+    const uint32_t n_rows = rows_l - first_row < (uint32_t)C::kBinRows ? rows_l - first_row : (uint32_t)C::kBinRows;  // the last bin of a dense level is short
+    float* dst = grad_table + ((size_t)meta.offset[l] + first_row) * F;
+    for (uint32_t i = threadIdx.x; i < n_rows * F; i += kReduceBlock) {
         const long long sum = (long long)s_acc[i];
         if (sum != 0) atomicAdd(dst + i, (float)((double)sum * from_fixed));
     }
@@ -583,47 +643,75 @@ NVSF_API int nvsf_hashgrid_fwd(const float* x, uint32_t M, uint32_t x_stride, co
 
 namespace {
 struct BinPlan {
-    uint32_t nbins, cap;
+    BinLevels bl;
+    uint32_t total_bins, total_wgs;
     size_t cursors_bytes, rows_bytes, vals_bytes;
 };
-// Workspace of the binned scatter: [cursors: n_fine x nbins u32, max |g| bits: 16 u32 | pair rows: n_fine x nbins x cap u16 | pair values: ... x F fp32]
-bool bin_plan(uint32_t M, uint32_t n_fine, uint32_t F, uint32_t rows_per_level, BinPlan& bp) {
-    if ((F != 2 && F != 4) || n_fine == 0 || n_fine > 16) return false;
+// Levels merge_from ... L-1 go through the bins: [merge_from, fine_from) as run sums, [fine_from, L) one contribution per (row, vertex).
+// Workspace: [cursors: one u32 per bin, max |g| bits: 16 u32 | rows of the contributions, u16 | their values, F fp32 each].
+bool bin_plan(uint32_t M, uint32_t L, uint32_t F, const uint32_t* h_res, const uint32_t* h_offsets, uint32_t merge_from, uint32_t fine_from,
+              BinPlan& bp) {
+    if ((F != 2 && F != 4) || merge_from > fine_from || fine_from > L || merge_from == L || L - merge_from > 16u) return false;
+    if ((unsigned long long)M * 8ull > (1ull << 26)) return false;  // 2^26 contributions per row at most (fixed-point headroom)
     const uint32_t bin_rows = 8192u / F;
-    if ((rows_per_level & (rows_per_level - 1u)) != 0u || rows_per_level < bin_rows || rows_per_level > (1u << 20)) return false;
-    bp.nbins = rows_per_level / bin_rows;
-    if (bp.nbins > 256u || (unsigned long long)M * 8ull > (1ull << 26)) return false;  // 2^26 contributions per row at most (fixed-point headroom)
-    const unsigned long long mean = ((unsigned long long)M * 8ull + bp.nbins - 1) / bp.nbins;
-    const unsigned long long cap = ((mean + mean / 4 + 2048ull) + 63ull) & ~63ull;
-    if (cap * n_fine * bp.nbins >= (1ull << 32)) return false;
-    bp.cap = (uint32_t)cap;
-    bp.cursors_bytes = (((size_t)(n_fine * bp.nbins + 16u) * sizeof(uint32_t)) + 255u) & ~(size_t)255u;  // cursors + max |g| per level
-    bp.rows_bytes = (((size_t)n_fine * bp.nbins * cap * sizeof(uint16_t)) + 255u) & ~(size_t)255u;
-    bp.vals_bytes = (size_t)n_fine * bp.nbins * cap * F * sizeof(float);
+    BinLevels& bl = bp.bl;
+    bl.n = L - merge_from;
+    unsigned long long pairs = 0;
+    uint32_t bins = 0, wgs = 0;
+    for (uint32_t j = 0; j < bl.n; ++j) {
+        const uint32_t l = merge_from + j, rows = h_offsets[l + 1] - h_offsets[l];
+        const bool hashed = (unsigned long long)h_res[l] * h_res[l] * h_res[l] > rows;
+        if (rows > (1u << 20) || (hashed && (rows & (rows - 1u)) != 0u)) return false;
+        const uint32_t nbins = (rows + bin_rows - 1) / bin_rows;
+        if (nbins > 256u) return false;
+        const unsigned long long all = (unsigned long long)M * 8ull, mean = (all + nbins - 1) / nbins;
+        unsigned long long cap;
+        if (l >= fine_from) cap = mean + mean / 4 + 2048ull;          // uniform hash, one contribution per (row, vertex)
+        else if (hashed) cap = mean + 4096ull;                        // run sums: never more than that
+        else cap = (mean < all / 2 ? mean : all / 2) + 4096ull;       // dense level: bins are slabs of space (skewed): the unmerged uniform share
+        cap = (cap + 63ull) & ~63ull;
+        bl.level[j] = l;
+        bl.nbins[j] = nbins;
+        bl.bin0[j] = bins;
+        bl.cap[j] = (uint32_t)cap;
+        bl.merged[j] = l < fine_from ? 1u : 0u;
+        bl.pair0[j] = pairs;
+        uint32_t split = (uint32_t)((cap + 98303ull) / 98304ull);
+        bl.split[j] = split < 1u ? 1u : (split > 128u ? 128u : split);
+        if (l >= fine_from && bl.split[j] < 4u) bl.split[j] = 4u;
+        bl.wg0[j] = wgs;
+        bins += nbins;
+        wgs += nbins * bl.split[j];
+        pairs += cap * nbins;
+        if (cap >= (1ull << 31) || pairs >= (1ull << 40)) return false;
+    }
+    bl.wg0[bl.n] = wgs;
+    bp.total_bins = bins;
+    bp.total_wgs = wgs;
+    bp.cursors_bytes = (((size_t)(bins + 16u) * sizeof(uint32_t)) + 255u) & ~(size_t)255u;  // cursors + max |g| per level
+    bp.rows_bytes = (((size_t)pairs * sizeof(uint16_t)) + 255u) & ~(size_t)255u;
+    bp.vals_bytes = (size_t)pairs * F * sizeof(float);
     return true;
 }
 
 int hashgrid_bwd_launch(const float* x, uint32_t M, uint32_t x_stride, const uint32_t* cols, uint32_t D, uint32_t L, uint32_t F,
                         const float* h_scales, const uint32_t* h_res, const uint32_t* h_offsets, const void* grad_out, int grad_is_f16,
-                        uint32_t go_stride, float* grad_table_f32, uint32_t fine_from, void* workspace, size_t workspace_bytes,
-                        hipStream_t stream) {
+                        uint32_t go_stride, float* grad_table_f32, uint32_t merge_from, uint32_t fine_from, void* workspace,
+                        size_t workspace_bytes, hipStream_t stream) {
     if (M == 0) return NVSF_OK;
-    REQUIRE(x && cols && grad_out && grad_table_f32 && (D == 2 || D == 3) && go_stride >= L * F && fine_from <= L);
+    REQUIRE(x && cols && grad_out && grad_table_f32 && (D == 2 || D == 3) && go_stride >= L * F && merge_from <= fine_from && fine_from <= L);
     for (uint32_t d = 0; d < D; ++d) REQUIRE(cols[d] < x_stride);
     GridMeta meta;
     const int st = fill_meta(meta, L, h_scales, h_res, h_offsets);
     if (st != NVSF_OK) return st;
     const uint32_t c0 = cols[0], c1 = cols[1], c2 = D == 3 ? cols[2] : 0;
-    if (nvsf_variant(kVarHashgridBwd) != 0) fine_from = L;  // tests: every level through the plain kernel
-    if (fine_from < L) {  // levels fine_from ... L-1 through the bins
+    if (nvsf_variant(kVarHashgridBwd) != 0) merge_from = fine_from = L;  // tests: every level through the plain kernel
+    if (merge_from < L) {  // levels merge_from ... L-1 through the bins
         REQUIRE(D == 3 && workspace && (reinterpret_cast<uintptr_t>(workspace) & 255u) == 0);
-        const uint32_t n_fine = L - fine_from, rows = h_offsets[fine_from + 1] - h_offsets[fine_from];
-        for (uint32_t l = fine_from; l < L; ++l) {
-            const unsigned long long cells = (unsigned long long)h_res[l] * h_res[l] * h_res[l];
-            REQUIRE(h_offsets[l + 1] - h_offsets[l] == rows && cells > rows);  // hashed levels of one (power-of-two) size
-        }
+        for (uint32_t l = fine_from; l < L; ++l)
+            REQUIRE((unsigned long long)h_res[l] * h_res[l] * h_res[l] > h_offsets[l + 1] - h_offsets[l]);  // per-row contributions: hashed levels
         BinPlan bp;
-        REQUIRE(bin_plan(M, n_fine, F, rows, bp));
+        REQUIRE(bin_plan(M, L, F, h_res, h_offsets, merge_from, fine_from, bp));
         REQUIRE(workspace_bytes >= bp.cursors_bytes + bp.rows_bytes + bp.vals_bytes);
         uint32_t* cursors = reinterpret_cast<uint32_t*>(workspace);
         uint16_t* pair_row = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) + bp.cursors_bytes);
@@ -632,43 +720,41 @@ int hashgrid_bwd_launch(const float* x, uint32_t M, uint32_t x_stride, const uin
             const hipError_t e = hipMemsetAsync(cursors, 0, bp.cursors_bytes, stream);
             if (e != hipSuccess) return (int)e;
         }
-        uint32_t* level_max = cursors + (size_t)n_fine * bp.nbins;
-        const uint32_t split = 4;  // workgroups per bin: 5 levels x 128 bins x 4 >> 256 CUs x 2 resident
+        uint32_t* level_max = cursors + bp.total_bins;
 #define CALLB(FF)                                                                                                                      \
     do {                                                                                                                               \
         const dim3 bgrid(cdiv(M, (uint32_t)BinCfg<FF>::kTile));                                                                        \
         if (grad_is_f16)                                                                                                               \
             hipLaunchKernelGGL((k_hashgrid_bwd_bin<FF, true>), bgrid, dim3(kBlock), 0, stream, x, M, x_stride, c0, c1, c2, meta,       \
-                               fine_from, n_fine, grad_out, go_stride, grad_table_f32, cursors, level_max, pair_row, pair_val, bp.cap, \
-                               bp.nbins);                                                                                              \
+                               bp.bl, grad_out, go_stride, grad_table_f32, cursors, level_max, pair_row, pair_val);                    \
         else                                                                                                                           \
             hipLaunchKernelGGL((k_hashgrid_bwd_bin<FF, false>), bgrid, dim3(kBlock), 0, stream, x, M, x_stride, c0, c1, c2, meta,      \
-                               fine_from, n_fine, grad_out, go_stride, grad_table_f32, cursors, level_max, pair_row, pair_val, bp.cap, \
-                               bp.nbins);                                                                                              \
-        hipLaunchKernelGGL((k_hashgrid_bwd_reduce<FF>), dim3(n_fine * bp.nbins * split), dim3(kReduceBlock), 0, stream, cursors,       \
-                           level_max, pair_row, pair_val, bp.cap, bp.nbins, split, meta, fine_from, grad_table_f32);                   \
+                               bp.bl, grad_out, go_stride, grad_table_f32, cursors, level_max, pair_row, pair_val);                    \
+        hipLaunchKernelGGL((k_hashgrid_bwd_reduce<FF>), dim3(bp.total_wgs), dim3(kReduceBlock), 0, stream, cursors, level_max,         \
+                           pair_row, pair_val, bp.bl, meta, grad_table_f32);                                                           \
     } while (0)
         if (F == 2) CALLB(2);
         else CALLB(4);
 #undef CALLB
-        if (fine_from == 0) return nvsf_launch_status();
+        if (merge_from == 0) return nvsf_launch_status();
     }
+    const uint32_t l_end = merge_from;  // the levels below go through the atomics
     // production form: corner-parallel run merging.  Variant 1 (tests) selects the plain one-thread-per-(row, level) kernel,
     // which is also the fallback for shapes whose 2^D x F lanes do not divide the levels evenly
     const uint32_t ipw = kWave / ((1u << D) * F);
-    if (nvsf_variant(kVarHashgridBwd) == 0 && (L % ipw == 0 || fine_from < L)) {
+    if (nvsf_variant(kVarHashgridBwd) == 0 && (L % ipw == 0 || l_end < L)) {
         const uint32_t run = M >= (1u << 20) ? 128u : 32u;  // rows per item: long runs once there is enough work to fill the chip
-        const uint32_t l_items = (fine_from + ipw - 1) / ipw * ipw;  // items of a wave = ipw consecutive levels of one chunk
+        const uint32_t l_items = (l_end + ipw - 1) / ipw * ipw;  // items of a wave = ipw consecutive levels of one chunk
         const unsigned long long waves = (unsigned long long)cdiv(M, run) * (l_items / ipw);
         const dim3 cgrid((uint32_t)((waves + kBlock / kWave - 1) / (kBlock / kWave)));
 #define CALLC(DD, FF)                                                                                                                \
     do {                                                                                                                             \
         if (grad_is_f16)                                                                                                             \
             hipLaunchKernelGGL((k_hashgrid_bwd_corners<DD, FF, true>), cgrid, dim3(kBlock), 0, stream, x, M, x_stride, c0, c1, c2, l_items, meta, \
-                               grad_out, go_stride, grad_table_f32, run, fine_from);                                                 \
+                               grad_out, go_stride, grad_table_f32, run, l_end);                                                     \
         else                                                                                                                         \
             hipLaunchKernelGGL((k_hashgrid_bwd_corners<DD, FF, false>), cgrid, dim3(kBlock), 0, stream, x, M, x_stride, c0, c1, c2, l_items, meta, \
-                               grad_out, go_stride, grad_table_f32, run, fine_from);                                                 \
+                               grad_out, go_stride, grad_table_f32, run, l_end);                                                     \
     } while (0)
         DISPATCH_DF(D, F, CALLC);
 #undef CALLC
@@ -693,19 +779,21 @@ int hashgrid_bwd_launch(const float* x, uint32_t M, uint32_t x_stride, const uin
 NVSF_API int nvsf_hashgrid_bwd(const float* x, uint32_t M, uint32_t x_stride, const uint32_t* cols, uint32_t D, uint32_t L, uint32_t F,
                                const float* h_scales, const uint32_t* h_res, const uint32_t* h_offsets, const void* grad_out,
                                int grad_is_f16, uint32_t go_stride, float* grad_table_f32, hipStream_t stream) {
-    return hashgrid_bwd_launch(x, M, x_stride, cols, D, L, F, h_scales, h_res, h_offsets, grad_out, grad_is_f16, go_stride, grad_table_f32, L,
+    return hashgrid_bwd_launch(x, M, x_stride, cols, D, L, F, h_scales, h_res, h_offsets, grad_out, grad_is_f16, go_stride, grad_table_f32, L, L,
                                nullptr, 0, stream);
 }
 
-NVSF_API size_t nvsf_hashgrid_bwd_binned_ws_bytes(uint32_t M, uint32_t n_fine, uint32_t F, uint32_t rows_per_level) {
+NVSF_API size_t nvsf_hashgrid_bwd_binned_ws_bytes(uint32_t M, uint32_t L, uint32_t F, const uint32_t* h_res, const uint32_t* h_offsets,
+                                                  uint32_t merge_from, uint32_t fine_from) {
     BinPlan bp;
-    return bin_plan(M, n_fine, F, rows_per_level, bp) ? bp.cursors_bytes + bp.rows_bytes + bp.vals_bytes : 0;
+    if (!h_res || !h_offsets || L == 0 || L > (uint32_t)kMaxLevels) return 0;
+    return bin_plan(M, L, F, h_res, h_offsets, merge_from, fine_from, bp) ? bp.cursors_bytes + bp.rows_bytes + bp.vals_bytes : 0;
 }
 
 NVSF_API int nvsf_hashgrid_bwd_binned(const float* x, uint32_t M, uint32_t x_stride, const uint32_t* cols, uint32_t D, uint32_t L, uint32_t F,
                                       const float* h_scales, const uint32_t* h_res, const uint32_t* h_offsets, const void* grad_out,
-                                      int grad_is_f16, uint32_t go_stride, float* grad_table_f32, uint32_t fine_from, void* workspace,
-                                      size_t workspace_bytes, hipStream_t stream) {
+                                      int grad_is_f16, uint32_t go_stride, float* grad_table_f32, uint32_t merge_from, uint32_t fine_from,
+                                      void* workspace, size_t workspace_bytes, hipStream_t stream) {
     return hashgrid_bwd_launch(x, M, x_stride, cols, D, L, F, h_scales, h_res, h_offsets, grad_out, grad_is_f16, go_stride, grad_table_f32,
-                               fine_from, workspace, workspace_bytes, stream);
+                               merge_from, fine_from, workspace, workspace_bytes, stream);
 }

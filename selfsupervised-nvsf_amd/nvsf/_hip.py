@@ -38,7 +38,7 @@ SIGNATURES = {
     # section 3: field operators
     "nvsf_hashgrid_fwd": [_P, _U, _U, _P, _U, _P, _U, _U, _P, _P, _P, _P, _U],
     "nvsf_hashgrid_bwd": [_P, _U, _U, _P, _U, _U, _U, _P, _P, _P, _P, _I, _U, _P],
-    "nvsf_hashgrid_bwd_binned": [_P, _U, _U, _P, _U, _U, _U, _P, _P, _P, _P, _I, _U, _P, _U, _P, ctypes.c_size_t],
+    "nvsf_hashgrid_bwd_binned": [_P, _U, _U, _P, _U, _U, _U, _P, _P, _P, _P, _I, _U, _P, _U, _U, _P, ctypes.c_size_t],
     "nvsf_freq_encode": [_P, _U, _U, _U, _P, _U],
     "nvsf_sh4_encode": [_P, _U, _P, _U],
     "nvsf_adam_prepare": [_P, _P, _F, _F],
@@ -110,7 +110,7 @@ def load():
     lib.nvsf_march_rays_train_ws_bytes.restype = ctypes.c_size_t
     lib.nvsf_march_rays_train_ws_bytes.argtypes = [_U]
     lib.nvsf_hashgrid_bwd_binned_ws_bytes.restype = ctypes.c_size_t
-    lib.nvsf_hashgrid_bwd_binned_ws_bytes.argtypes = [_U, _U, _U, _U]
+    lib.nvsf_hashgrid_bwd_binned_ws_bytes.argtypes = [_U, _U, _U, _P, _P, _U, _U]
     lib.nvsf_version.restype = ctypes.c_char_p
     lib.nvsf_version.argtypes = []
     lib.nvsf_test_variant.restype = ctypes.c_int
@@ -128,9 +128,9 @@ def march_ws_bytes(n_rays):
     return int(load().nvsf_march_rays_train_ws_bytes(int(n_rays)))
 
 
-def hashgrid_bwd_ws_bytes(n_rows, n_fine, n_features, rows_per_level):
-    """Scratch bytes nvsf_hashgrid_bwd_binned needs (0: the shape has no binned form)."""
-    return int(load().nvsf_hashgrid_bwd_binned_ws_bytes(int(n_rows), int(n_fine), int(n_features), int(rows_per_level)))
+def hashgrid_bwd_ws_bytes(n_rows, spec, merge_from, fine_from):
+    """Scratch bytes nvsf_hashgrid_bwd_binned needs for a grid (field_ops.GridSpec) (0: the shape has no binned form)."""
+    return int(load().nvsf_hashgrid_bwd_binned_ws_bytes(int(n_rows), spec.L, spec.F, spec.h_res, spec.h_offsets, int(merge_from), int(fine_from)))
 
 
 def ptr(t):

@@ -81,17 +81,35 @@ class ray_ordered_rows:
 
 
 def _bin_from(spec, M, rows_per_ray):
-    return fine_levels_from(spec, rows_per_ray) if (rows_per_ray and M >= (1 << 18) and M % rows_per_ray == 0) else None
+    """(merge_from, fine_from) for a batch of M ray-ordered rows, or None: the form of the table scatter (hashgrid_backward)."""
+    if not (rows_per_ray and M >= (1 << 18) and M % rows_per_ray == 0):
+        return None
+    fine = fine_levels_from(spec, rows_per_ray)
+    return None if fine >= spec.L else (merge_levels_from(spec, fine, rows_per_ray), fine)
 
 
 _BIN_ROWS_MAX = 1 << 23
 _BIN_WS = {}  # (device, stream) -> scratch of the binned scatter; one per stream: side-stream scatters of two tables may overlap
 
 
+def merge_levels_from(spec, fine_from, rows_per_ray):
+    """First level whose RUN SUMS go through the bins: the levels whose cells are 1.4 ... 4 ray steps long (res >= T / 4), down to a
+    whole group of the run-merging atomic kernel (64 / (8 F) levels per wave).  Measured on the config-2 batches (tools/
+    bench_hashgrid_bwd.py, MERGE=...): 8 is the minimum (1.80 ms against 1.88 with the atomics for levels 8-10, 1.94 with no atomics at
+    all -- the bin pass has a fixed cost per level and tile that the coarse levels' few contributions do not repay)."""
+    first = fine_from
+    for l in range(fine_from - 1, -1, -1):
+        if int(spec.res[l]) < 0.25 * rows_per_ray:
+            break
+        first = l
+    per_wave = max(1, 64 // (8 * spec.F))
+    return min(fine_from, (first + per_wave - 1) // per_wave * per_wave if first % per_wave else first)
+
+
 def fine_levels_from(spec, rows_per_ray):
     """First level of the trailing run of hashed, equally sized levels whose cells are shorter than ~1.4 steps of a ray that
-    crosses the unit cube in `rows_per_ray` samples (no two consecutive samples share a cell there, so run merging cannot help
-    and nvsf_hashgrid_bwd_binned pays off); spec.L when there is none or the grid has no binned form."""
+    crosses the unit cube in `rows_per_ray` samples (no two consecutive samples share a cell there: one contribution per row and
+    vertex); spec.L when there is none or the grid has no binned form."""
     if rows_per_ray is None or spec.D != 3 or spec.F not in (2, 4):
         return spec.L
     rows = [int(spec.offsets[l + 1] - spec.offsets[l]) for l in range(spec.L)]
@@ -101,27 +119,32 @@ def fine_levels_from(spec, rows_per_ray):
         if not (hashed and rows[l] == rows[-1] and int(spec.res[l]) >= 0.7 * rows_per_ray):
             break
         first = l
-    if first < spec.L and _hip.hashgrid_bwd_ws_bytes(1 << 20, spec.L - first, spec.F, rows[-1]) == 0:
+    if first < spec.L and _hip.hashgrid_bwd_ws_bytes(1 << 20, spec, first, first) == 0:
         return spec.L
     return first
 
 
-def hashgrid_backward(x, cols, spec, grad_out, grad_table=None, fine_from=None):
+def hashgrid_backward(x, cols, spec, grad_out, grad_table=None, fine_from=None, merge_from=None):
     """Scatter-adds d L / d table (fp32 [n_params]) from grad_out ([M, L*F], fp16 or fp32).  `fine_from` < L sends the levels from
-    there on through the binned scatter (see fine_levels_from)."""
+    there on through the binned scatter, one contribution per (row, vertex); `merge_from` <= fine_from the levels in between as sums
+    over runs of consecutive rows in one cell (nvsf_hashgrid_bwd_binned; fine_levels_from / merge_levels_from).  `fine_from` may be a
+    (merge_from, fine_from) pair."""
+    if isinstance(fine_from, tuple):
+        merge_from, fine_from = fine_from
     x = x.contiguous()
     grad_out = grad_out.contiguous()
     if grad_table is None:
         grad_table = torch.zeros(spec.n_params, dtype=torch.float32, device=x.device)
     M = x.shape[0]
     need = 0
-    if fine_from is not None and fine_from < spec.L:
+    if fine_from is not None and (fine_from < spec.L or (merge_from is not None and merge_from < spec.L)):
+        merge_from = fine_from if merge_from is None else min(merge_from, fine_from)
         if M > _BIN_ROWS_MAX:  # the fixed-point image of the bins takes 2^26 addends per row: longer batches go in pieces (sums accumulate)
             for i in range(0, M, _BIN_ROWS_MAX):
-                hashgrid_backward(x[i:i + _BIN_ROWS_MAX], cols, spec, grad_out[i:i + _BIN_ROWS_MAX], grad_table, fine_from)
+                hashgrid_backward(x[i:i + _BIN_ROWS_MAX], cols, spec, grad_out[i:i + _BIN_ROWS_MAX], grad_table, fine_from, merge_from)
             return grad_table
         # 0: the grid has no binned form: every level through the atomics
-        need = _hip.hashgrid_bwd_ws_bytes(M, spec.L - fine_from, spec.F, int(spec.offsets[-1] - spec.offsets[-2]))
+        need = _hip.hashgrid_bwd_ws_bytes(M, spec, merge_from, fine_from)
     if need:
         key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
         ws = _BIN_WS.get(key)
@@ -129,7 +152,7 @@ def hashgrid_backward(x, cols, spec, grad_out, grad_table=None, fine_from=None):
             ws = _BIN_WS[key] = torch.empty(need, dtype=torch.uint8, device=x.device)
         _hip.call("nvsf_hashgrid_bwd_binned", _hip.ptr(x), M, x.shape[1], _hip.host_u32(cols), spec.D, spec.L, spec.F, spec.h_scales,
                   spec.h_res, spec.h_offsets, _hip.ptr(grad_out), 1 if grad_out.dtype == torch.float16 else 0, grad_out.stride(0),
-                  _hip.ptr(grad_table), fine_from, _hip.ptr(ws), ws.numel())
+                  _hip.ptr(grad_table), merge_from, fine_from, _hip.ptr(ws), ws.numel())
         return grad_table
     _hip.call("nvsf_hashgrid_bwd", _hip.ptr(x), M, x.shape[1], _hip.host_u32(cols), spec.D, spec.L, spec.F, spec.h_scales,
               spec.h_res, spec.h_offsets, _hip.ptr(grad_out), 1 if grad_out.dtype == torch.float16 else 0, grad_out.stride(0),

@@ -128,15 +128,19 @@ def test_hashgrid_backward_kernels_agree_with_the_oracle(ops, dev, D, L, F, log2
         np.testing.assert_allclose(got, ref, atol=5e-4, rtol=1e-4)  # fp32 atomics: order-dependent rounding
 
 
-@pytest.mark.parametrize("L,F,log2_T,base,top,fine_from", [(16, 2, 14, 16, 512, 12), (16, 2, 14, 16, 512, 5), (8, 4, 12, 16, 256, 4), (8, 4, 13, 64, 1024, 0)])
-def test_hashgrid_backward_binned_levels_agree_with_the_oracle(ops, dev, L, F, log2_T, base, top, fine_from):
-    """nvsf_hashgrid_bwd_binned: the levels from `fine_from` on go through the bins (contributions appended per table chunk, summed in
-    LDS), the others through the run-merging kernel; ray-ordered rows with zero rows / zero features, fp32 and fp16 gradients, M not a
-    multiple of the tile; then a batch whose samples all sit in ONE cell, which overflows the bins (the direct-add path)."""
+@pytest.mark.parametrize("L,F,log2_T,base,top,fine_from,merge_from", [
+    (16, 2, 14, 16, 512, 12, 12), (16, 2, 14, 16, 512, 5, 5), (8, 4, 12, 16, 256, 4, 4), (8, 4, 13, 64, 1024, 0, 0),
+    (16, 2, 14, 16, 512, 12, 0), (16, 2, 14, 16, 512, 9, 3), (8, 4, 12, 16, 256, 6, 0), (16, 2, 14, 16, 512, 16, 0)])
+def test_hashgrid_backward_binned_levels_agree_with_the_oracle(ops, dev, L, F, log2_T, base, top, fine_from, merge_from):
+    """nvsf_hashgrid_bwd_binned: the levels from `fine_from` on go through the bins one contribution per (row, vertex), the levels
+    from `merge_from` on as sums over runs of consecutive rows in one cell (dense levels with a short last bin included), the others
+    through the run-merging atomics; ray-ordered rows with zero rows / zero features, fp32 and fp16 gradients, M not a multiple of the
+    tile; a batch in pieces; then a batch whose samples all sit in ONE cell, which overflows the bins (the direct-add path)."""
     spec = _spec(ops, 3, L, F, log2_T, base, top)
+    fine_from = (merge_from, fine_from)
     rows = np.diff(spec.offsets)
-    assert all(int(spec.res[l]) ** 3 > rows[l] and rows[l] == rows[-1] for l in range(fine_from, L))
-    rng = np.random.default_rng(L + F + fine_from)
+    assert all(int(spec.res[l]) ** 3 > rows[l] for l in range(fine_from[1], L))
+    rng = np.random.default_rng(L + F + sum(fine_from))
     n_rays, T = 41, 131
     o = rng.random((n_rays, 1, 3)) * 0.5 + 0.1
     d = rng.standard_normal((n_rays, 1, 3))

@@ -1,5 +1,6 @@
 """Table-gradient scatter of the config-2 grid (L16 F2 T2^19) and the reference-default static grid (L8 F4 T2^19) on the bench's
-LiDAR / camera sample batches: nvsf_hashgrid_bwd against nvsf_hashgrid_bwd_binned for every choice of the first binned level."""
+LiDAR / camera sample batches: nvsf_hashgrid_bwd against nvsf_hashgrid_bwd_binned for every choice of the first per-row level
+(FF=..) and, with MERGE=a,b,.., of the first run-merged level; BATCH= / GRID= restrict the sweep."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "selfsupervised-nvsf_amd"))
@@ -49,7 +50,9 @@ for tag, (o, d) in {"lidar": S.lidar_rays(N, rng), "camera": S.camera_rays(N, rn
                 break
             if ONLY_FF and ff != int(ONLY_FF):
                 continue
-            out = ops.hashgrid_backward(x, (0, 1, 2), spec, g, fine_from=ff)
-            err = float((out - ref).abs().max() / ref.abs().max())
-            ms = timed(lambda: ops.hashgrid_backward(x, (0, 1, 2), spec, g, grad_table=out, fine_from=ff))
-            print(f"    fine_from {ff:2d}: {ms:.3f} ms   rel err {err:.2e}", flush=True)
+            merges = [ff] if not os.environ.get("MERGE") else sorted({int(v) for v in os.environ["MERGE"].split(",") if int(v) <= ff})
+            for mf in merges:
+                out = ops.hashgrid_backward(x, (0, 1, 2), spec, g, fine_from=ff, merge_from=mf)
+                err = float((out - ref).abs().max() / ref.abs().max())
+                ms = timed(lambda: ops.hashgrid_backward(x, (0, 1, 2), spec, g, grad_table=out, fine_from=ff, merge_from=mf))
+                print(f"    fine_from {ff:2d} merge_from {mf:2d}: {ms:.3f} ms   rel err {err:.2e}", flush=True)
