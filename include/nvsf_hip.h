@@ -189,13 +189,17 @@ int nvsf_hashgrid_bwd(const float* x, uint32_t M, uint32_t x_stride, const uint3
  * Requirements: D = 3, F in {2, 4}, binned levels of at most 2^20 rows and 256 bins, hashed ones of power-of-two size, M * 8 <= 2^26.
  * workspace: device memory, 256-byte aligned, at least nvsf_hashgrid_bwd_binned_ws_bytes(...) bytes (0 = shape not supported),
  * contents irrelevant.  Same sums as nvsf_hashgrid_bwd up to the order of the fp32 additions (2^-33 of a level's largest gradient per
- * contribution), for any input: contributions beyond a bin's capacity are added directly. */
+ * contribution), for any input: contributions beyond a bin's capacity are added directly.
+ * grad_out: rows [M, go_stride >= L F] (go_level_stride = 0) or level-major [L][M][F] (go_level_stride = elements between two levels,
+ * go_stride = F: what nvsf_mlp_bwd writes in its column-block layout) -- every pass over a level then reads one contiguous column
+ * instead of 8 ... 16 bytes out of every 128-byte row. */
 size_t nvsf_hashgrid_bwd_binned_ws_bytes(uint32_t M, uint32_t L, uint32_t F, const uint32_t* h_res, const uint32_t* h_offsets,
                                          uint32_t merge_from, uint32_t fine_from);
 int nvsf_hashgrid_bwd_binned(const float* x, uint32_t M, uint32_t x_stride, const uint32_t* cols, uint32_t D, uint32_t L,
                              uint32_t F, const float* h_scales, const uint32_t* h_res, const uint32_t* h_offsets,
-                             const void* grad_out, int grad_is_f16, uint32_t go_stride, float* grad_table_f32,
-                             uint32_t merge_from, uint32_t fine_from, void* workspace, size_t workspace_bytes, nvsf_stream_t stream);
+                             const void* grad_out, int grad_is_f16, uint32_t go_stride, uint32_t go_level_stride,
+                             float* grad_table_f32, uint32_t merge_from, uint32_t fine_from, void* workspace,
+                             size_t workspace_bytes, nvsf_stream_t stream);
 
 /* ref: tcnn.Encoding("Frequency") network_dynamic.py:108-114.  x fp32 [M,n_dims] ->
  * out fp16 [M, out_stride >= 2*n_dims*n_freq], out[i*2K+2k] = sin(2^k pi x_i), [..+1] = cos. */
@@ -266,7 +270,10 @@ int nvsf_mlp_fwd(const void* x, int x_is_f16, uint32_t M, uint32_t n_in, uint32_
  * grad_x fp32 [M, gx_stride] or NULL: column j receives dL/dx of input column gx_col0 + j, j < n_in - gx_col0 (gx_col0 = 0:
  * the whole input gradient).  Input tiles left of gx_col0 are not computed -- a head whose leading columns are a
  * parameter-free direction encoding only needs the gradient of its trailing geometry features.  gx_accumulate != 0 adds
- * to grad_x instead of overwriting it (two heads sharing one input).
+ * to grad_x instead of overwriting it (two heads sharing one input).  Bits 8..15 of gx_accumulate = B in {2, 4} select a
+ * column-block layout of grad_x instead of rows: grad_x [n_in / B][M][B] (gx_col0 = 0, gx_stride ignored, n_in % 4 == 0,
+ * 16-byte aligned rows of x) -- the gradient of a hash grid's L x F features level by level, what nvsf_hashgrid_bwd_binned
+ * reads with go_level_stride = M * F.
  * grad_weights_f32: fp32 buffer in the layout of weights_f16; dL/dW is ADDED to it (zero it first).
  * Gradients travel in fp16 multiplied by grad_scale (tcnn's loss_scale, e.g. 128) and are unscaled on the way out.
  * Supported: hidden = 64, out_cols = 16, n_hidden in 1..2, in_cols <= 128. */

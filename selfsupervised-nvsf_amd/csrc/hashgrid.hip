@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 template <int D, int F, bool GRAD_F16>
 __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd(const float* __restrict__ x, uint32_t M, uint32_t x_stride, uint32_t c0,
                                                          uint32_t c1, uint32_t c2, uint32_t L, GridMeta meta,
-                                                         const void* __restrict__ grad_out, uint32_t go_stride,
+                                                         const void* __restrict__ grad_out, uint32_t go_stride, uint32_t go_level,
                                                          float* __restrict__ grad_table) {
     const uint32_t m = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t l = blockIdx.y;
@@ -148,8 +148,8 @@ __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd(const float* __restrict
     float g[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) {
-        if constexpr (GRAD_F16) g[f] = (float)reinterpret_cast<const _Float16*>(grad_out)[(size_t)m * go_stride + l * F + f];
-        else g[f] = reinterpret_cast<const float*>(grad_out)[(size_t)m * go_stride + l * F + f];
+        if constexpr (GRAD_F16) g[f] = (float)reinterpret_cast<const _Float16*>(grad_out)[(size_t)m * go_stride + (size_t)l * go_level + f];
+        else g[f] = reinterpret_cast<const float*>(grad_out)[(size_t)m * go_stride + (size_t)l * go_level + f];
     }
     bool any = false;
 #pragma unroll
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd(const float* __restrict
 template <int D, int F, bool GRAD_F16>
 __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_corners(const float* __restrict__ x, uint32_t M, uint32_t x_stride, uint32_t c0,
                                                                  uint32_t c1, uint32_t c2, uint32_t L, GridMeta meta,
-                                                                 const void* __restrict__ grad_out, uint32_t go_stride,
+                                                                 const void* __restrict__ grad_out, uint32_t go_stride, uint32_t go_level,
                                                                  float* __restrict__ grad_table, uint32_t run, uint32_t l_end) {
     auto flush = [&](float* dst, float acc) { atomicAdd(dst, acc); };
     constexpr int G = (1 << D) * F;  // lanes per item
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_corners(const float* __
     if (l - (uint32_t)sub >= l_end) return;  // uniform
     const float scale = meta.scale[l];
     const uint32_t res = meta.res[l], row0 = meta.offset[l], hsize = meta.offset[l + 1] - row0;
-    const uint32_t gcol = l * F + (uint32_t)f;
+    const size_t gcol = (size_t)l * go_level + (uint32_t)f;  // go_level = F: rows [M, L F]; = M F: level-major [L][M][F]
     float acc = 0.0f;
     uint32_t cur[D];
     bool have = false;
@@ -341,7 +341,7 @@ struct BinLevels {
 template <int F, bool GRAD_F16>
 __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_bin(const float* __restrict__ x, uint32_t M, uint32_t x_stride, uint32_t c0, uint32_t c1,
                                                              uint32_t c2, GridMeta meta, BinLevels bl, const void* __restrict__ grad_out,
-                                                             uint32_t go_stride, float* __restrict__ grad_table, uint32_t* __restrict__ cursors,
+                                                             uint32_t go_stride, uint32_t go_level, float* __restrict__ grad_table, uint32_t* __restrict__ cursors,
                                                              uint32_t* __restrict__ level_max, uint16_t* __restrict__ pair_row,
                                                              float* __restrict__ pair_val) {
     using C = BinCfg<F>;
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_bin(const float* __rest
             bool any = false;
 #pragma unroll
             for (int f = 0; f < F; ++f) {
-                const size_t at = (size_t)(mrow[s] < M ? mrow[s] : 0u) * go_stride + l * F + f;
+                const size_t at = (size_t)(mrow[s] < M ? mrow[s] : 0u) * go_stride + (size_t)l * go_level + f;
                 if constexpr (GRAD_F16) g[f] = (float)reinterpret_cast<const _Float16*>(grad_out)[at];
                 else g[f] = reinterpret_cast<const float*>(grad_out)[at];
                 if (mrow[s] >= M) g[f] = 0.0f;
@@ -696,10 +696,13 @@ bool bin_plan(uint32_t M, uint32_t L, uint32_t F, const uint32_t* h_res, const u
 
 int hashgrid_bwd_launch(const float* x, uint32_t M, uint32_t x_stride, const uint32_t* cols, uint32_t D, uint32_t L, uint32_t F,
                         const float* h_scales, const uint32_t* h_res, const uint32_t* h_offsets, const void* grad_out, int grad_is_f16,
-                        uint32_t go_stride, float* grad_table_f32, uint32_t merge_from, uint32_t fine_from, void* workspace,
-                        size_t workspace_bytes, hipStream_t stream) {
+                        uint32_t go_stride, uint32_t go_level_stride, float* grad_table_f32, uint32_t merge_from, uint32_t fine_from,
+                        void* workspace, size_t workspace_bytes, hipStream_t stream) {
     if (M == 0) return NVSF_OK;
-    REQUIRE(x && cols && grad_out && grad_table_f32 && (D == 2 || D == 3) && go_stride >= L * F && merge_from <= fine_from && fine_from <= L);
+    REQUIRE(x && cols && grad_out && grad_table_f32 && (D == 2 || D == 3) && merge_from <= fine_from && fine_from <= L);
+    // rows [M, go_stride >= L F] (go_level_stride = 0), or level-major [L][M][F]: go_level_stride elements between levels, go_stride = F
+    REQUIRE(go_level_stride ? (go_stride >= F && (unsigned long long)go_level_stride >= (unsigned long long)M * go_stride) : go_stride >= L * F);
+    const uint32_t go_level = go_level_stride ? go_level_stride : F;
     for (uint32_t d = 0; d < D; ++d) REQUIRE(cols[d] < x_stride);
     GridMeta meta;
     const int st = fill_meta(meta, L, h_scales, h_res, h_offsets);
@@ -726,10 +729,10 @@ int hashgrid_bwd_launch(const float* x, uint32_t M, uint32_t x_stride, const uin
         const dim3 bgrid(cdiv(M, (uint32_t)BinCfg<FF>::kTile));                                                                        \
         if (grad_is_f16)                                                                                                               \
             hipLaunchKernelGGL((k_hashgrid_bwd_bin<FF, true>), bgrid, dim3(kBlock), 0, stream, x, M, x_stride, c0, c1, c2, meta,       \
-                               bp.bl, grad_out, go_stride, grad_table_f32, cursors, level_max, pair_row, pair_val);                    \
+                               bp.bl, grad_out, go_stride, go_level, grad_table_f32, cursors, level_max, pair_row, pair_val);                    \
         else                                                                                                                           \
             hipLaunchKernelGGL((k_hashgrid_bwd_bin<FF, false>), bgrid, dim3(kBlock), 0, stream, x, M, x_stride, c0, c1, c2, meta,      \
-                               bp.bl, grad_out, go_stride, grad_table_f32, cursors, level_max, pair_row, pair_val);                    \
+                               bp.bl, grad_out, go_stride, go_level, grad_table_f32, cursors, level_max, pair_row, pair_val);                    \
         hipLaunchKernelGGL((k_hashgrid_bwd_reduce<FF>), dim3(bp.total_wgs), dim3(kReduceBlock), 0, stream, cursors, level_max,         \
                            pair_row, pair_val, bp.bl, meta, grad_table_f32);                                                           \
     } while (0)
@@ -751,10 +754,10 @@ int hashgrid_bwd_launch(const float* x, uint32_t M, uint32_t x_stride, const uin
     do {                                                                                                                             \
         if (grad_is_f16)                                                                                                             \
             hipLaunchKernelGGL((k_hashgrid_bwd_corners<DD, FF, true>), cgrid, dim3(kBlock), 0, stream, x, M, x_stride, c0, c1, c2, l_items, meta, \
-                               grad_out, go_stride, grad_table_f32, run, l_end);                                                     \
+                               grad_out, go_stride, go_level, grad_table_f32, run, l_end);                                                     \
         else                                                                                                                         \
             hipLaunchKernelGGL((k_hashgrid_bwd_corners<DD, FF, false>), cgrid, dim3(kBlock), 0, stream, x, M, x_stride, c0, c1, c2, l_items, meta, \
-                               grad_out, go_stride, grad_table_f32, run, l_end);                                                     \
+                               grad_out, go_stride, go_level, grad_table_f32, run, l_end);                                                     \
     } while (0)
         DISPATCH_DF(D, F, CALLC);
 #undef CALLC
@@ -765,10 +768,10 @@ int hashgrid_bwd_launch(const float* x, uint32_t M, uint32_t x_stride, const uin
     do {                                                                                                                         \
         if (grad_is_f16)                                                                                                         \
             hipLaunchKernelGGL((k_hashgrid_bwd<DD, FF, true>), grid, dim3(kBlock), 0, stream, x, M, x_stride, c0, c1, c2, L, meta, \
-                               grad_out, go_stride, grad_table_f32);                                                             \
+                               grad_out, go_stride, go_level, grad_table_f32);                                                   \
         else                                                                                                                     \
             hipLaunchKernelGGL((k_hashgrid_bwd<DD, FF, false>), grid, dim3(kBlock), 0, stream, x, M, x_stride, c0, c1, c2, L, meta, \
-                               grad_out, go_stride, grad_table_f32);                                                             \
+                               grad_out, go_stride, go_level, grad_table_f32);                                                   \
     } while (0)
     DISPATCH_DF(D, F, CALL);
 #undef CALL
@@ -779,7 +782,7 @@ int hashgrid_bwd_launch(const float* x, uint32_t M, uint32_t x_stride, const uin
 NVSF_API int nvsf_hashgrid_bwd(const float* x, uint32_t M, uint32_t x_stride, const uint32_t* cols, uint32_t D, uint32_t L, uint32_t F,
                                const float* h_scales, const uint32_t* h_res, const uint32_t* h_offsets, const void* grad_out,
                                int grad_is_f16, uint32_t go_stride, float* grad_table_f32, hipStream_t stream) {
-    return hashgrid_bwd_launch(x, M, x_stride, cols, D, L, F, h_scales, h_res, h_offsets, grad_out, grad_is_f16, go_stride, grad_table_f32, L, L,
+    return hashgrid_bwd_launch(x, M, x_stride, cols, D, L, F, h_scales, h_res, h_offsets, grad_out, grad_is_f16, go_stride, 0, grad_table_f32, L, L,
                                nullptr, 0, stream);
 }
 
@@ -792,8 +795,8 @@ NVSF_API size_t nvsf_hashgrid_bwd_binned_ws_bytes(uint32_t M, uint32_t L, uint32
 
 NVSF_API int nvsf_hashgrid_bwd_binned(const float* x, uint32_t M, uint32_t x_stride, const uint32_t* cols, uint32_t D, uint32_t L, uint32_t F,
                                       const float* h_scales, const uint32_t* h_res, const uint32_t* h_offsets, const void* grad_out,
-                                      int grad_is_f16, uint32_t go_stride, float* grad_table_f32, uint32_t merge_from, uint32_t fine_from,
-                                      void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    return hashgrid_bwd_launch(x, M, x_stride, cols, D, L, F, h_scales, h_res, h_offsets, grad_out, grad_is_f16, go_stride, grad_table_f32,
+                                      int grad_is_f16, uint32_t go_stride, uint32_t go_level_stride, float* grad_table_f32, uint32_t merge_from,
+                                      uint32_t fine_from, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    return hashgrid_bwd_launch(x, M, x_stride, cols, D, L, F, h_scales, h_res, h_offsets, grad_out, grad_is_f16, go_stride, go_level_stride, grad_table_f32,
                                merge_from, fine_from, workspace, workspace_bytes, stream);
 }

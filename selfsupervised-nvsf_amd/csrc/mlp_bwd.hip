@@ -233,11 +233,31 @@ __global__ __launch_bounds__(kBlock) void k_mlp_bwd(const void* __restrict__ x, 
                     float* row_x = grad_x + (size_t)m * gx_stride;
                     if constexpr (FAST) {  // 16-byte aligned window: this lane's four columns as one store (the last group may
                                            // reach into the row's alignment padding)
-                        if (valid && k0 >= gx_col0 && k0 < n_in) {
-                            float4_t* p = reinterpret_cast<float4_t*>(row_x + (k0 - gx_col0));
+                        const uint32_t blk = ((uint32_t)gx_accumulate >> 8) & 0xFFu;  // 0: rows; 2 / 4: column blocks (below)
+                        if (blk == 0u) {
+                            if (valid && k0 >= gx_col0 && k0 < n_in) {
+                                float4_t* p = reinterpret_cast<float4_t*>(row_x + (k0 - gx_col0));
+                                float4_t v = a * inv_scale;
+                                if (gx_accumulate & 1) v += *p;
+                                *p = v;
+                            }
+                        } else if (valid && k0 < n_in) {
+                            // block-major dX: [n_in / blk][M][blk] -- the gradient of a hash grid's features, level by level, so that the
+                            // table scatter reads a level's column as one stream (a row-major [M, 32] costs it a 128-byte line per 8 bytes
+                            // and level: hashgrid.hip).  16 consecutive samples of a level are 16 * blk * 4 contiguous bytes.
                             float4_t v = a * inv_scale;
-                            if (gx_accumulate) v += *p;
-                            *p = v;
+                            if (blk == 4u) {
+                                float4_t* p = reinterpret_cast<float4_t*>(grad_x + ((size_t)(k0 >> 2) * M + m) * 4);
+                                if (gx_accumulate & 1) v += *p;
+                                *p = v;
+                            } else {
+                                float2* p0 = reinterpret_cast<float2*>(grad_x + ((size_t)(k0 >> 1) * M + m) * 2);
+                                float2* p1 = reinterpret_cast<float2*>(grad_x + ((size_t)((k0 >> 1) + 1u) * M + m) * 2);
+                                float2 v0 = make_float2(v[0], v[1]), v1 = make_float2(v[2], v[3]);
+                                if (gx_accumulate & 1) { v0.x += p0->x; v0.y += p0->y; v1.x += p1->x; v1.y += p1->y; }
+                                *p0 = v0;
+                                *p1 = v1;
+                            }
                         }
                     } else if (valid) {
 #pragma unroll
@@ -245,7 +265,7 @@ __global__ __launch_bounds__(kBlock) void k_mlp_bwd(const void* __restrict__ x, 
                             const uint32_t k = k0 + r;
                             if (k < n_in && k >= gx_col0) {
                                 const float v = a[r] * inv_scale;
-                                row_x[k - gx_col0] = gx_accumulate ? row_x[k - gx_col0] + v : v;
+                                row_x[k - gx_col0] = (gx_accumulate & 1) ? row_x[k - gx_col0] + v : v;
                             }
                         }
                     }
@@ -335,7 +355,9 @@ static int mlp_bwd_impl(const void* x, int x_is_f16, uint32_t M, uint32_t n_in, 
     REQUIRE(x && weights_f16 && grad_out && grad_weights_f32);
     REQUIRE(n_in >= 1 && n_in <= in_cols && in_cols % 16 == 0 && x_stride >= n_in - pre.split);
     REQUIRE(n_out >= 1 && n_out <= 16 && go_stride >= n_out && grad_scale > 0.0f);
-    REQUIRE(!grad_x || (gx_col0 < n_in && gx_stride >= n_in - gx_col0));
+    const uint32_t gx_blk = ((uint32_t)gx_accumulate >> 8) & 0xFFu;
+    REQUIRE(!grad_x || gx_blk || (gx_col0 < n_in && gx_stride >= n_in - gx_col0));
+    REQUIRE(!gx_blk || (grad_x && (gx_blk == 2u || gx_blk == 4u) && gx_col0 == 0 && n_in % 4 == 0 && (reinterpret_cast<uintptr_t>(grad_x) & 15u) == 0));
     REQUIRE((reinterpret_cast<uintptr_t>(weights_f16) & 15u) == 0);
     if (hidden != (uint32_t)kHidden || out_cols != 16 || n_hidden < 1 || n_hidden > 2 || in_cols > 128) return NVSF_ERR_UNSUPPORTED;
     const int in_steps = (int)((in_cols + 31) / 32);
@@ -349,9 +371,10 @@ static int mlp_bwd_impl(const void* x, int x_is_f16, uint32_t M, uint32_t n_in, 
     const _Float16* w = reinterpret_cast<const _Float16*>(weights_f16);
     // FAST: 16-byte loads of x (mlp_device.h) and 16-byte stores of dX (window and rows aligned to four floats, rows wide
     // enough for the last group of four)
-    const bool gx_vec = !grad_x || (gx_col0 % 4 == 0 && gx_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(grad_x) & 15u) == 0 &&
-                                    (n_in - gx_col0 + 3u) / 4u * 4u <= gx_stride);
+    const bool gx_vec = !grad_x || gx_blk || (gx_col0 % 4 == 0 && gx_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(grad_x) & 15u) == 0 &&
+                                              (n_in - gx_col0 + 3u) / 4u * 4u <= gx_stride);
     const bool fast = x_rows_fast(n_in - pre.split, x_stride, vec_ok) && gx_vec;
+    REQUIRE(!gx_blk || fast);  // column blocks: the aligned-row form of the kernel only
     if (pre.a) {  // shared-prefix rows (mlp_device.h: XPrefix): aligned fp16 only, whole 8-column groups, a tile inside one group
         REQUIRE(x_is_f16 && fast && pre.split % 8 == 0 && pre.split < n_in && pre.a_stride >= pre.split && pre.a_stride % 8 == 0);
         REQUIRE(pre.rows_per_a >= 16 && pre.rows_per_a % 16 == 0 && (reinterpret_cast<uintptr_t>(pre.a) & 15u) == 0);

@@ -38,7 +38,7 @@ SIGNATURES = {
     # section 3: field operators
     "nvsf_hashgrid_fwd": [_P, _U, _U, _P, _U, _P, _U, _U, _P, _P, _P, _P, _U],
     "nvsf_hashgrid_bwd": [_P, _U, _U, _P, _U, _U, _U, _P, _P, _P, _P, _I, _U, _P],
-    "nvsf_hashgrid_bwd_binned": [_P, _U, _U, _P, _U, _U, _U, _P, _P, _P, _P, _I, _U, _P, _U, _U, _P, ctypes.c_size_t],
+    "nvsf_hashgrid_bwd_binned": [_P, _U, _U, _P, _U, _U, _U, _P, _P, _P, _P, _I, _U, _U, _P, _U, _U, _P, ctypes.c_size_t],
     "nvsf_freq_encode": [_P, _U, _U, _U, _P, _U],
     "nvsf_sh4_encode": [_P, _U, _P, _U],
     "nvsf_adam_prepare": [_P, _P, _F, _F],

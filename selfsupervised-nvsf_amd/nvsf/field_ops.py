@@ -89,6 +89,7 @@ def _bin_from(spec, M, rows_per_ray):
 
 
 _BIN_ROWS_MAX = 1 << 23
+LEVEL_MAJOR_GRADIENT = True  # the density MLP hands dL/d(features) to the binned scatter level by level ([L, M, F])
 _BIN_WS = {}  # (device, stream) -> scratch of the binned scatter; one per stream: side-stream scatters of two tables may overlap
 
 
@@ -133,14 +134,15 @@ def hashgrid_backward(x, cols, spec, grad_out, grad_table=None, fine_from=None, 
         merge_from, fine_from = fine_from
     x = x.contiguous()
     grad_out = grad_out.contiguous()
+    level_major = grad_out.dim() == 3  # [L, M, F] (mlp_backward(grad_x_blocks=F)): only the binned entry point reads it
     if grad_table is None:
         grad_table = torch.zeros(spec.n_params, dtype=torch.float32, device=x.device)
     M = x.shape[0]
     need = 0
     if fine_from is not None and (fine_from < spec.L or (merge_from is not None and merge_from < spec.L)):
         merge_from = fine_from if merge_from is None else min(merge_from, fine_from)
-        if M > _BIN_ROWS_MAX:  # the fixed-point image of the bins takes 2^26 addends per row: longer batches go in pieces (sums accumulate)
-            for i in range(0, M, _BIN_ROWS_MAX):
+        if M > _BIN_ROWS_MAX and not level_major:  # the fixed-point image of the bins takes 2^26 addends per row: longer batches go in
+            for i in range(0, M, _BIN_ROWS_MAX):    # pieces (sums accumulate)
                 hashgrid_backward(x[i:i + _BIN_ROWS_MAX], cols, spec, grad_out[i:i + _BIN_ROWS_MAX], grad_table, fine_from, merge_from)
             return grad_table
         # 0: the grid has no binned form: every level through the atomics
@@ -151,9 +153,12 @@ def hashgrid_backward(x, cols, spec, grad_out, grad_table=None, fine_from=None, 
         if ws is None or ws.numel() < need:
             ws = _BIN_WS[key] = torch.empty(need, dtype=torch.uint8, device=x.device)
         _hip.call("nvsf_hashgrid_bwd_binned", _hip.ptr(x), M, x.shape[1], _hip.host_u32(cols), spec.D, spec.L, spec.F, spec.h_scales,
-                  spec.h_res, spec.h_offsets, _hip.ptr(grad_out), 1 if grad_out.dtype == torch.float16 else 0, grad_out.stride(0),
+                  spec.h_res, spec.h_offsets, _hip.ptr(grad_out), 1 if grad_out.dtype == torch.float16 else 0,
+                  spec.F if level_major else grad_out.stride(0), M * spec.F if level_major else 0,
                   _hip.ptr(grad_table), merge_from, fine_from, _hip.ptr(ws), ws.numel())
         return grad_table
+    if level_major:
+        raise _hip.NvsfHipError("a level-major gradient needs the binned scatter (nvsf_hashgrid_bwd_binned)")
     _hip.call("nvsf_hashgrid_bwd", _hip.ptr(x), M, x.shape[1], _hip.host_u32(cols), spec.D, spec.L, spec.F, spec.h_scales,
               spec.h_res, spec.h_offsets, _hip.ptr(grad_out), 1 if grad_out.dtype == torch.float16 else 0, grad_out.stride(0),
               _hip.ptr(grad_table))
@@ -260,7 +265,7 @@ MLP_GRAD_SCALE = 128.0  # fp16 gradients inside nvsf_mlp_bwd are multiplied by t
 
 
 def mlp_backward(x, weights_f16, spec, grad_out, need_grad_x=True, grad_scale=MLP_GRAD_SCALE, grad_x=None, gx_col0=0,
-                 accumulate=False, prefix=None):
+                 accumulate=False, prefix=None, grad_x_blocks=0):
     """One fused kernel: (x, weights, dL/dout [M, n_out] fp32) -> dL/dx fp32 [M, n_in] (or None), dL/dW fp32 [n_params].
     With `grad_x` given (fp32, unit column stride) the input gradient of columns gx_col0.. is written (or added, with
     `accumulate`) there: grad_x[:, j] = dL/dx[:, gx_col0 + j]."""
@@ -270,6 +275,15 @@ def mlp_backward(x, weights_f16, spec, grad_out, need_grad_x=True, grad_scale=ML
         grad_out = grad_out.contiguous()
     M = x.shape[0]
     grad_w = torch.zeros(spec.n_params, dtype=torch.float32, device=x.device)
+    mode = (1 if accumulate else 0) | (int(grad_x_blocks) << 8)
+    if grad_x_blocks:  # dL/dx as column blocks [n_in / B, M, B] (the gradient of a hash grid's features, level by level)
+        assert need_grad_x and gx_col0 == 0 and spec.n_in % grad_x_blocks == 0 and prefix is None
+        if grad_x is None:
+            grad_x = torch.empty(spec.n_in // grad_x_blocks, M, grad_x_blocks, dtype=torch.float32, device=x.device)
+        _hip.call("nvsf_mlp_bwd", _hip.ptr_rows(x), 1 if x.dtype == torch.float16 else 0, M, spec.n_in, x.stride(0), _hip.ptr(weights_f16),
+                  spec.in_cols, spec.hidden, spec.n_hidden, spec.out_cols, _hip.ptr_rows(grad_out), grad_out.shape[1], grad_out.stride(0),
+                  float(grad_scale), _hip.ptr(grad_x), grad_x_blocks, _hip.ptr(grad_w), 0, mode)
+        return grad_x, grad_w
     if grad_x is None and need_grad_x:
         n_gx = spec.n_in - gx_col0  # rows padded to four floats: the kernel then stores 16 bytes per lane
         grad_x = torch.empty(M, (n_gx + 3) // 4 * 4, dtype=torch.float32, device=x.device)[:, :n_gx]
@@ -624,10 +638,14 @@ def _density_backward(ctx, g_sigma, g_geo):
               None if g_geo is None else _hip.ptr_rows(g_geo), 0 if g_geo is None else g_geo.stride(0), spec.n_out - 1, M,
               _hip.ptr(grad_h), 16, ctx.clamp[0], ctx.clamp[1])
     need_table, need_w = ctx.need_table, ctx.need_w
-    grad_feat, grad_w = mlp_backward(feat, mlp_w16, spec, grad_h[:, :spec.n_out], need_grad_x=need_table)
+    # levels whose cells are shorter than a few ray steps go through the binned scatter (rows are ray-ordered with a known ray length);
+    # the MLP then hands its input gradient over level by level ([L, M, F]): every pass of the scatter reads one contiguous column
+    fine = _bin_from(ctx.grid_spec, M, getattr(ctx, "rows_per_ray", None)) if need_table else None
+    blocks = ctx.grid_spec.F if (LEVEL_MAJOR_GRADIENT and fine is not None and M <= _BIN_ROWS_MAX and spec.n_in == ctx.grid_spec.L * ctx.grid_spec.F
+                                 and feat.dtype == torch.float16 and feat.stride(0) % 8 == 0
+                                 and _hip.hashgrid_bwd_ws_bytes(M, ctx.grid_spec, fine[0], fine[1]) > 0) else 0
+    grad_feat, grad_w = mlp_backward(feat, mlp_w16, spec, grad_h[:, :spec.n_out], need_grad_x=need_table, grad_x_blocks=blocks)
     grad_table = None
-    # levels whose cells are shorter than a ray step go through the binned scatter (rows are ray-ordered with a known ray length)
-    fine = _bin_from(ctx.grid_spec, M, getattr(ctx, "rows_per_ray", None))
     if need_table:
         last = _scatter_done(ctx.table_param)
         sink = GRAD_SINK

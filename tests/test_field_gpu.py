@@ -158,6 +158,10 @@ def test_hashgrid_backward_binned_levels_agree_with_the_oracle(ops, dev, L, F, l
     acc = ops.hashgrid_backward(_t(x, dev), (0, 1, 2), spec, _t(go, dev), fine_from=fine_from)
     acc = ops.hashgrid_backward(_t(x, dev), (0, 1, 2), spec, _t(go, dev), grad_table=acc, fine_from=fine_from).cpu().numpy()
     np.testing.assert_allclose(acc, 2 * O.hashgrid_bwd(x, (0, 1, 2), spec, go), atol=1e-3, rtol=1e-4)
+    # the same gradient handed over level by level ([L, M, F], what mlp_backward(grad_x_blocks=F) writes)
+    go_lm = _t(np.ascontiguousarray(go.reshape(M, L, F).transpose(1, 0, 2)), dev)
+    got = ops.hashgrid_backward(_t(x, dev), (0, 1, 2), spec, go_lm, fine_from=fine_from).cpu().numpy()
+    np.testing.assert_allclose(got, O.hashgrid_bwd(x, (0, 1, 2), spec, go), atol=5e-4, rtol=1e-4)
     # a batch longer than the bins' fixed-point headroom allows goes in pieces
     old_max, ops._BIN_ROWS_MAX = ops._BIN_ROWS_MAX, 1777
     try:

@@ -233,3 +233,23 @@ def test_glue_kernels_against_torch(dev):
             if use_gg:
                 ref[:, 1:] = gg[:, :15]
             assert torch.equal(out, ref), (stride, use_gs, use_gg)
+
+
+def test_input_gradient_in_column_blocks(dev):
+    """nvsf_mlp_bwd's column-block layout of dL/dx ([n_in / B][M][B], bits 8..15 of gx_accumulate): the same numbers as the row layout,
+    transposed, for B = 2 and 4, written and accumulated; M not a multiple of the tile."""
+    from nvsf import field_ops as ops
+    spec = ops.MlpSpec(32, 16, 64, 1)
+    g = torch.Generator().manual_seed(5)
+    M = 3003
+    x = torch.randn(M, 32, generator=g).to(dev).half()
+    w = (torch.randn(spec.n_params, generator=g) * 0.2).to(dev).half()
+    go = torch.randn(M, 16, generator=g).to(dev)
+    ref, gw_ref = ops.mlp_backward(x, w, spec, go)
+    for B in (2, 4):
+        got, gw = ops.mlp_backward(x, w, spec, go, grad_x_blocks=B)
+        assert tuple(got.shape) == (32 // B, M, B)
+        assert torch.equal(got.permute(1, 0, 2).reshape(M, 32), ref)
+        torch.testing.assert_close(gw, gw_ref, rtol=1e-4, atol=1e-5)
+        twice, _ = ops.mlp_backward(x, w, spec, go, grad_x=got.clone(), grad_x_blocks=B, accumulate=True)
+        torch.testing.assert_close(twice.permute(1, 0, 2).reshape(M, 32), 2 * ref, rtol=1e-6, atol=0)

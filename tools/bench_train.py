@@ -19,6 +19,9 @@ batch = {"rays_o_lidar": torch.from_numpy(lo).to(dev)[None], "rays_d_lidar": tor
          "gt_intensity": torch.rand(1, N, generator=g).to(dev), "gt_rgb": torch.rand(1, N, 3, generator=g).to(dev)}
 step = RenderTrainStep(m, num_steps=T, scale=S.SCALE, ray_chunks=int(os.environ.get('CHUNKS', 1)), split_backward=os.environ.get('SPLIT', '1') == '1')
 step.scatter_overlap = os.environ.get('OVERLAP', '1') == '1'
+if os.environ.get('LM') == '0':
+    from nvsf import field_ops as _ops
+    _ops.LEVEL_MAJOR_GRADIENT = False
 for _ in range(2): step.step(batch)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 K = int(os.environ.get("K", 5))
