@@ -51,8 +51,9 @@ for tag, (o, d) in {"lidar": S.lidar_rays(N, rng), "camera": S.camera_rays(N, rn
             if ONLY_FF and ff != int(ONLY_FF):
                 continue
             merges = [ff] if not os.environ.get("MERGE") else sorted({int(v) for v in os.environ["MERGE"].split(",") if int(v) <= ff})
+            g_in = g.view(-1, spec.L, spec.F).permute(1, 0, 2).contiguous() if os.environ.get("LM", "1") == "1" else g  # level-major, as the MLP backward hands it over
             for mf in merges:
-                out = ops.hashgrid_backward(x, (0, 1, 2), spec, g, fine_from=ff, merge_from=mf)
+                out = ops.hashgrid_backward(x, (0, 1, 2), spec, g_in, fine_from=ff, merge_from=mf)
                 err = float((out - ref).abs().max() / ref.abs().max())
-                ms = timed(lambda: ops.hashgrid_backward(x, (0, 1, 2), spec, g, grad_table=out, fine_from=ff, merge_from=mf))
+                ms = timed(lambda: ops.hashgrid_backward(x, (0, 1, 2), spec, g_in, grad_table=out, fine_from=ff, merge_from=mf))
                 print(f"    fine_from {ff:2d} merge_from {mf:2d}: {ms:.3f} ms   rel err {err:.2e}", flush=True)
