@@ -19,9 +19,13 @@ batch = {"rays_o_lidar": torch.from_numpy(lo).to(dev)[None], "rays_d_lidar": tor
          "gt_intensity": torch.rand(1, N, generator=g).to(dev), "gt_rgb": torch.rand(1, N, 3, generator=g).to(dev)}
 step = RenderTrainStep(m, num_steps=T, scale=S.SCALE, ray_chunks=int(os.environ.get('CHUNKS', 1)), split_backward=os.environ.get('SPLIT', '1') == '1')
 step.scatter_overlap = os.environ.get('OVERLAP', '1') == '1'
+from nvsf import field_ops as _ops
 if os.environ.get('LM') == '0':
-    from nvsf import field_ops as _ops
     _ops.LEVEL_MAJOR_GRADIENT = False
+if os.environ.get('MERGE') == '0':  # run sums off: atomics for every level below the per-row ones
+    _ops.merge_levels_from = lambda spec, fine, rows: fine
+if os.environ.get('BINS') == '0':   # no bins at all
+    _ops._bin_from = lambda spec, M, rows: None
 for _ in range(2): step.step(batch)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 K = int(os.environ.get("K", 5))
