@@ -712,6 +712,38 @@ def main():
         elapsed = float(t.item())
     finite = bool(torch.isfinite(out[0]["image_lidar"]).all() and torch.isfinite(out[1]["image"]).all())
 
+    # Second figure (not `value`): a FRESH ray batch every step with the sampler's jitter on (perturb = True), as an epoch of the
+    # reference's loader delivers them -- the timed loop above re-renders one batch, which is cache-warm in the coarse levels.
+    fresh = None
+    if not args.no_extra_legs or os.environ.get("NVSF_BENCH_FRESH") == "1":
+        n_b = 8
+        batches = []
+        for b in range(n_b):
+            rng_b = np.random.default_rng(5000 + 97 * rank + b)
+            lo_b, ld_b = S.lidar_rays(args.num_rays_lidar, rng_b)
+            co_b, cd_b = S.camera_rays(args.num_rays, rng_b)
+            batches.append(tuple(torch.from_numpy(a).to(dev)[None] for a in (lo_b, ld_b, co_b, cd_b)))
+
+        def fresh_step(i):
+            lo_t, ld_t, co_t, cd_t = batches[i % n_b]
+            with torch.no_grad():
+                a = model.render(lo_t, ld_t, tm, cal_lidar_color=True, num_steps=T, perturb=True)
+                b = model.render(co_t, cd_t, tm, cal_lidar_color=False, num_steps=T, perturb=True)
+            return a, b
+        keep = None
+        for i in range(2 * n_b):
+            keep = fresh_step(i)
+        torch.cuda.synchronize()
+        tf0 = time.perf_counter()
+        for i in range(args.steps):
+            keep = fresh_step(i)
+        torch.cuda.synchronize()
+        tf = time.perf_counter() - tf0
+        fresh = {"ms_per_step": tf / args.steps * 1e3, "value": (args.num_rays + args.num_rays_lidar) * args.steps / tf, "unit": "rays/s (this rank)",
+                 "batches": n_b, "perturb": True,
+                 "note": "a different pre-generated ray batch (another camera pose / LiDAR origin) per step, sampler jitter on: what an epoch delivers"}
+        del keep, batches
+
     if rank == 0:
         rays_per_step = (args.num_rays + args.num_rays_lidar) * world
         ms_per_step = elapsed / args.steps * 1e3
@@ -727,6 +759,8 @@ def main():
             "per_rank_ms_per_step": per_rank_ms, "ranks_seen": build_info["ranks_seen"],
             "build": {k: build_info[k] for k in ("version", "csrc_digest", "lib_sha1", "ranks_agree")},
         }
+        if fresh is not None:
+            line["fresh_batches"] = fresh
         if same_device:
             line["invalid"] = "NVSF_BENCH_SAME_DEVICE=1: all ranks shared cuda:0 (control-flow check only)"
         if not args.no_kernel_breakdown:
