@@ -466,7 +466,7 @@ __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_bin(const float* __rest
                 }
                 if (b < nbins) {
                     s_pre[b] = run + incl - cnt;
-                    s_gbase[b] = cnt ? atomicAdd(&cursors[bin0 + b], cnt) : 0u;
+                    s_gbase[b] = (cnt ? atomicAdd(&cursors[bin0 + b], cnt) : 0u) - (run + incl - cnt);  // global slot of staged pair p: p + s_gbase[bin] (mod 2^32)
                 }
                 run += (uint32_t)__shfl((int)incl, kWave - 1);
             }
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_bin(const float* __rest
         const uint32_t total = s_total;
         for (uint32_t p = (uint32_t)tid; p < total; p += kBlock) {
             const uint32_t row = s_row[p], b = row >> C::kBinShift;
-            const uint32_t q = s_gbase[b] + (p - s_pre[b]);
+            const uint32_t q = p + s_gbase[b];
             if (q < cap) {
                 const size_t at = (size_t)bl.pair0[j] + (size_t)b * cap + q;
                 pair_row[at] = (uint16_t)(row & (uint32_t)(C::kBinRows - 1));  // the row inside its bin: 12 / 11 bits
