@@ -366,6 +366,7 @@ __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_bin(const float* __rest
         const bool merged = bl.merged[j] != 0u;  // uniform
         const float scale = meta.scale[l];
         const uint32_t res = meta.res[l], row0 = meta.offset[l], hsize = meta.offset[l + 1] - row0;
+        const bool lvl_hashed = (unsigned long long)res * res * res > hsize;  // uniform
         for (int b = tid; b < C::kMaxBins; b += kBlock) s_cnt[b] = 0u;
         if (tid == 0) s_max = 0u;
         __syncthreads();
@@ -438,12 +439,33 @@ __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_bin(const float* __rest
                     }
                 emit = tail && run_any;
             }
+            // rows of the eight vertices (grid_row<3> of hashgrid_device.h with the level's kind decided once: per-axis terms of the
+            // cell and of its upper neighbour, combined by xor + mask on a hashed level, by sums + one wrap on a dense one)
+            uint32_t tx[2], ty[2], tz[2];
+            tx[0] = cell[0];
+            tx[1] = cell[0] + 1u;
+            if (lvl_hashed) {
+                ty[0] = cell[1] * 2654435761u;
+                ty[1] = ty[0] + 2654435761u;
+                tz[0] = cell[2] * 805459861u;
+                tz[1] = tz[0] + 805459861u;
+            } else {
+                ty[0] = cell[1] * res;
+                ty[1] = ty[0] + res;
+                tz[0] = cell[2] * res * res;
+                tz[1] = tz[0] + res * res;
+            }
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 pk[s][c] = 0xFFFFFFFFu;
                 if (emit) {
-                    const uint32_t cc[3] = {cell[0] + (c & 1u), cell[1] + ((c >> 1) & 1u), cell[2] + ((c >> 2) & 1u)};
-                    const uint32_t row = grid_row<3>(cc, res, hsize);
+                    uint32_t row;
+                    if (lvl_hashed) {
+                        row = (tx[c & 1] ^ ty[(c >> 1) & 1] ^ tz[c >> 2]) & (hsize - 1u);  // hashed levels are powers of two (host)
+                    } else {
+                        row = tx[c & 1] + ty[(c >> 1) & 1] + tz[c >> 2];  // < 2 hsize
+                        row = row >= hsize ? row - hsize : row;
+                    }
                     const uint32_t rank = atomicAdd(&s_cnt[row >> C::kBinShift], 1u);
                     pk[s][c] = row | (rank << 20);
                 }
