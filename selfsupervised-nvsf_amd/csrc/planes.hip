@@ -351,7 +351,9 @@ __global__ __launch_bounds__(kBlock) void k_planes_bwd_runs(const float* __restr
     // broadcasts (the tap arithmetic was 3/4 of this kernel's instructions).
     __shared__ uint32_t s_taps[kBlock / 32][32][3][8];
     const int lane = lane_id();
-    const int half = lane >> 5, k32 = lane & 31, tex = (lane >> 3) & 3, ch = lane & 7;
+    // lane of an item = (texel of the quad, channel): texel = bits 2-3, channel = bits 0-1 and bit 4 -- the four texel lanes of a channel
+    // are then 4 apart inside one DPP row of 16 and their sum is two rotate-and-add instructions (no LDS round trip)
+    const int half = lane >> 5, k32 = lane & 31, tex = (lane >> 2) & 3, ch = (lane & 3) | ((lane >> 2) & 4);
     const uint32_t n_grp = (want & 1 ? 1u : 0u) + (want & 2 ? 1u : 0u);
     const unsigned long long item = ((unsigned long long)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) * 2ull + (unsigned)half;
     const uint32_t per_chunk = meta.n_scales * n_grp;
@@ -402,9 +404,9 @@ __global__ __launch_bounds__(kBlock) void k_planes_bwd_runs(const float* __restr
                 idx[j] = taps[k][j][4 + tex];
                 quad[j] = taps[k][j][4];
                 float part = planes[meta.off[ss][pairs[j]] + (size_t)idx[j] * kC + ch] * w[j];
-                part += __shfl_xor(part, 8);
-                part += __shfl_xor(part, 16);
-                v[j] = part;  // interpolated value of plane j, channel ch (in all four texel lanes)
+                part += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part), 0x124 /* row_ror:4 */, 0xF, 0xF, false));
+                part += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part), 0x128 /* row_ror:8 */, 0xF, 0xF, false));
+                v[j] = part;  // interpolated value of plane j, channel ch (in all four texel lanes, up to the order of the additions)
             }
             if (!row_ok) continue;
 #pragma unroll
