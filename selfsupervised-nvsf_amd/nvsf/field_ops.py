@@ -145,8 +145,12 @@ def hashgrid_backward(x, cols, spec, grad_out, grad_table=None, fine_from=None, 
             for i in range(0, M, _BIN_ROWS_MAX):    # pieces (sums accumulate)
                 hashgrid_backward(x[i:i + _BIN_ROWS_MAX], cols, spec, grad_out[i:i + _BIN_ROWS_MAX], grad_table, fine_from, merge_from)
             return grad_table
-        # 0: the grid has no binned form: every level through the atomics
+        # 0: the grid has no binned form: every level through the atomics (first without the run-sum levels: a level of more than
+        # 2^20 rows cannot be binned)
         need = _hip.hashgrid_bwd_ws_bytes(M, spec, merge_from, fine_from)
+        if need == 0 and merge_from < fine_from < spec.L:
+            merge_from = fine_from
+            need = _hip.hashgrid_bwd_ws_bytes(M, spec, merge_from, fine_from)
     if need:
         key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
         ws = _BIN_WS.get(key)
