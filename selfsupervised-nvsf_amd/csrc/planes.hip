@@ -293,24 +293,32 @@ __global__ __launch_bounds__(kBlock) void k_planes_bwd(const float* __restrict__
             const float* gout = (grp == 0 ? g_static : g_dynamic) + (size_t)m * stride + s * kC;
             const int pairs[3] = {grp == 0 ? 0 : 2, grp == 0 ? 1 : 4, grp == 0 ? 3 : 5};
             Tap t[3];
-            float v[3][kC];
+            float v[3][kC], dvx[3][kC], dvy[3][kC];  // interpolated values and their derivatives along the two image axes
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int a = kPa[pairs[j]], b = kPb[pairs[j]];
                 t[j] = make_tap(p[a], p[b], meta.res[s][a], meta.res[s][b]);
-                interp(planes + meta.off[s][pairs[j]], t[j], v[j]);
-            }
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int q = pairs[j], a = kPa[q], b = kPb[q];
-                const float* plane = planes + meta.off[s][q];
-                float* gpl = g_planes ? g_planes + meta.off[s][q] : nullptr;
+                // the four texels are gathered ONCE: value and both derivatives come from the same registers (the first form
+                // interpolated in a helper and loaded the texels a second time for the derivatives: twice the gathers of a
+                // gather-bound kernel)
+                const float* plane = planes + meta.off[s][pairs[j]];
                 float tex00[kC], tex01[kC], tex10[kC], tex11[kC];
                 load_texel(plane, t[j].i00, tex00);
                 load_texel(plane, t[j].i01, tex01);
                 load_texel(plane, t[j].i10, tex10);
                 load_texel(plane, t[j].i11, tex11);
                 const float wx1 = t[j].ix_f - t[j].x0, wx0 = 1.0f - wx1, wy1 = t[j].iy_f - t[j].y0, wy0 = 1.0f - wy1;
+#pragma unroll
+                for (int k = 0; k < kC; ++k) {
+                    v[j][k] = ((tex00[k] * t[j].nw + tex01[k] * t[j].ne) + tex10[k] * t[j].sw) + tex11[k] * t[j].se;  // = interp()
+                    dvx[j][k] = (tex01[k] - tex00[k]) * wy0 + (tex11[k] - tex10[k]) * wy1;
+                    dvy[j][k] = (tex10[k] - tex00[k]) * wx0 + (tex11[k] - tex01[k]) * wx1;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int q = pairs[j], a = kPa[q], b = kPb[q];
+                float* gpl = g_planes ? g_planes + meta.off[s][q] : nullptr;
                 float dix = 0.0f, diy = 0.0f;
 #pragma unroll
                 for (int k = 0; k < kC; ++k) {
@@ -322,8 +330,8 @@ __global__ __launch_bounds__(kBlock) void k_planes_bwd(const float* __restrict__
                         atomicAdd(gpl + (size_t)t[j].i10 * kC + k, gv * t[j].sw);
                         atomicAdd(gpl + (size_t)t[j].i11 * kC + k, gv * t[j].se);
                     }
-                    dix += gv * ((tex01[k] - tex00[k]) * wy0 + (tex11[k] - tex10[k]) * wy1);
-                    diy += gv * ((tex10[k] - tex00[k]) * wx0 + (tex11[k] - tex01[k]) * wx1);
+                    dix += gv * dvx[j][k];
+                    diy += gv * dvy[j][k];
                 }
                 gp[a] += dix * t[j].gx;
                 gp[b] += diy * t[j].gy;
