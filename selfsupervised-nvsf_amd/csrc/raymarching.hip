@@ -678,13 +678,14 @@ __global__ __launch_bounds__(kBlock) void k_march_rays8(uint32_t n_alive, const 
                                                         float* __restrict__ xyzs, float* __restrict__ dirs,
                                                         float* __restrict__ deltas, const float* __restrict__ noises) {
     const uint32_t n = blockIdx.x * kBlock + threadIdx.x;
-    if (n >= n_alive) return;
-    const int index = rays_alive[n];
+    if (n - (uint32_t)lane_id() >= n_alive) return;  // whole wave past the end
+    const bool valid = n < n_alive;                    // lanes past the end of the last wave march nothing but help to store
+    const int index = rays_alive[valid ? n : n_alive - 1u];
     Marcher m;
     m.init(rays_o + 3 * (size_t)index, rays_d + 3 * (size_t)index, grid, bound, dt_gamma, max_steps, C, H);
-    const float far = fars[index];
+    const float far = valid ? fars[index] : -1.0f;
     float t = rays_t[index];
-    t += m.step_len(t) * noises[n];
+    t += m.step_len(t) * noises[valid ? n : n_alive - 1u];
     float last_t = t;
     float rec[8][5];  // x, y, z, dt, t_new - last_t; unfilled slots stay zero (they signal termination to composite_rays)
 #pragma unroll
@@ -704,23 +705,43 @@ __global__ __launch_bounds__(kBlock) void k_march_rays8(uint32_t n_alive, const 
             ++step;
         }
     }
-    float4* px = reinterpret_cast<float4*>(xyzs + 24 * (size_t)n);
-    float4* pd = reinterpret_cast<float4*>(dirs + 24 * (size_t)n);
-    float4* pl = reinterpret_cast<float4*>(deltas + 16 * (size_t)n);
-    float fx[24], fd[24];
+    // The records of a wave's 64 rays are contiguous in memory (64 x 96 B, 64 x 96 B, 64 x 64 B): staged through LDS, every store
+    // instruction writes 1 KB of consecutive bytes (whole 128-byte lines) instead of 64 pieces of 16 bytes 96 bytes apart.
+    __shared__ float s_rec[kBlock / kWave][kWave * 24 + 8];
+    float* stage = s_rec[threadIdx.x >> 6];
+    const int lane = lane_id();
+    const uint32_t wave_first = n - (uint32_t)lane;                       // first ray of this wave
+    const uint32_t wave_rays = n_alive - wave_first < (uint32_t)kWave ? n_alive - wave_first : (uint32_t)kWave;
+    auto flush = [&](float* __restrict__ dst, uint32_t per_ray) {         // stage holds wave_rays x per_ray floats, ray-major
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t n4 = wave_rays * per_ray / 4u;
+        float4* out = reinterpret_cast<float4*>(dst + (size_t)per_ray * wave_first);
+        for (uint32_t e = (uint32_t)lane; e < n4; e += (uint32_t)kWave) out[e] = *reinterpret_cast<const float4*>(stage + 4u * e);
+        __builtin_amdgcn_wave_barrier();
+    };
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        fx[3 * k] = rec[k][0]; fx[3 * k + 1] = rec[k][1]; fx[3 * k + 2] = rec[k][2];
+        stage[24 * lane + 3 * k] = rec[k][0];
+        stage[24 * lane + 3 * k + 1] = rec[k][1];
+        stage[24 * lane + 3 * k + 2] = rec[k][2];
+    }
+    flush(xyzs, 24u);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
         const bool filled = (uint32_t)k < step;
-        fd[3 * k] = filled ? m.dx : 0.0f; fd[3 * k + 1] = filled ? m.dy : 0.0f; fd[3 * k + 2] = filled ? m.dz : 0.0f;
+        stage[24 * lane + 3 * k] = filled ? m.dx : 0.0f;
+        stage[24 * lane + 3 * k + 1] = filled ? m.dy : 0.0f;
+        stage[24 * lane + 3 * k + 2] = filled ? m.dz : 0.0f;
     }
+    flush(dirs, 24u);
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        px[q] = make_float4(fx[4 * q], fx[4 * q + 1], fx[4 * q + 2], fx[4 * q + 3]);
-        pd[q] = make_float4(fd[4 * q], fd[4 * q + 1], fd[4 * q + 2], fd[4 * q + 3]);
+    for (int k = 0; k < 8; ++k) {
+        stage[16 * lane + 2 * k] = rec[k][3];
+        stage[16 * lane + 2 * k + 1] = rec[k][4];
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) pl[q] = make_float4(rec[2 * q][3], rec[2 * q][4], rec[2 * q + 1][3], rec[2 * q + 1][4]);
+    flush(deltas, 16u);
 }
 
 // ------------------------------------------------------------------------------------------------
