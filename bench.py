@@ -311,6 +311,100 @@ def outputs_match_oracle(out, oracle_outputs, tol=1e-4):
     return res
 
 
+def train_kernel_rows(step, batch, M, n_steps=3):
+    """Per-kernel rows of the training step as it runs (side-stream scatters beside the MLP backward included): kernel trace of
+    `n_steps` steps through torch.profiler (kineto / roctracer), average duration per launch, launches per step, and for the kernels
+    whose algorithmic work is known a roofline fraction -- the fused MLP kernels against the dense fp16 MFMA peak (FLOP counted from
+    the template arguments <IN_STEPS, N_HIDDEN>: in_cols = 32 IN_STEPS, 64-wide hidden layers, 16 outputs; backward = 3 x forward:
+    recomputed forward + data + weight gradients), the streaming kernels against HBM.  Not run under rocprofv3 (two tracers in one
+    process): the committed profiles/r04_*_train_kernel_stats.csv + *_pmc_train.json are that view, with counters."""
+    import re
+    if any(k.startswith("ROCPROF") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return {"skipped": "running under rocprofv3"}
+    try:
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for _ in range(n_steps):
+                step.step(batch)
+            torch.cuda.synchronize()
+        per = {}
+        for ev in prof.events():
+            if ev.device_type is not None and "cuda" in str(ev.device_type).lower() and ev.device_time > 0:
+                d = per.setdefault(ev.name, [0, 0.0])
+                d[0] += 1
+                d[1] += ev.device_time  # us
+    except Exception as e:  # noqa: BLE001 -- a secondary figure: never fail the bench line for it
+        return {"skipped": f"{type(e).__name__}: {e}"}
+    if not per:
+        return {"skipped": "the profiler returned no device events"}
+
+    def mlp_flops(name):
+        m = re.search(r"k_mlp_(fwd|bwd)(?:<|ILi)(\d+)(?:, |ELi)(\d+)", name)
+        if not m:
+            return None
+        in_cols, n_hidden = 32 * int(m.group(2)), int(m.group(3))
+        f = 2 * (64 * in_cols + 64 * 64 * (n_hidden - 1) + 16 * 64)
+        return f * (3 if m.group(1) == "bwd" else 1)
+
+    streams = {"k_density_uniform_v2": (588 + 140, "588 + 140 B/sample (gathers, features, training outputs)"),
+               "k_encode_sliced_pairs": (580, "580 B/sample"), "k_density_from_features": (76 + 140, "216 B/sample"),
+               "k_sigma_geo_bwd": (132, "132 B/sample"), "k_weights_fwd": (12, "12 B/sample"), "k_weights_bwd": (24, "24 B/sample"),
+               "k_image_fwd": (16, "16 B/sample"), "k_image_bwd": (28, "28 B/sample"), "k_masked_sigmoid": (16, "16 B/sample"), "k_sigmoid_bwd": (24, "24 B/sample")}
+    total_us = sum(v[1] for v in per.values())
+    ours, glue_launches, glue_us = [], 0, 0.0
+    for name, (calls, us) in sorted(per.items(), key=lambda kv: -kv[1][1]):
+        short = re.sub(r"^void |\(anonymous namespace\)::|_ZN12_GLOBAL__N_1\d+", "", name).split("(")[0][:72]
+        if "k_" not in name.split("(")[0]:
+            glue_launches += calls
+            glue_us += us
+            continue
+        ms = us / calls / 1e3
+        row = {"kernel": short, "launches_per_step": calls / n_steps, "ms": ms, "share_of_kernel_time": us / total_us}
+        fl = mlp_flops(name)
+        if fl is not None:
+            tf = fl * M / (ms * 1e-3) / 1e12
+            row.update({"bound": "mfma", "unit": "TFLOP/s", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "frac": tf / MFMA_PEAK_TFLOPS, "per_unit": f"{fl} FLOP/sample"})
+        else:
+            for key, (b, note) in streams.items():
+                if key in name:
+                    gbs = b * M / (ms * 1e-3) / 1e9
+                    row.update({"bound": "hbm", "unit": "GB/s", "achieved": gbs, "peak": HBM_PEAK_GBS, "frac": gbs / HBM_PEAK_GBS, "per_unit": note})
+                    break
+        ours.append(row)
+    return {"steps_traced": n_steps, "kernel_ms_per_step": total_us / n_steps / 1e3, "launches_per_step": sum(v[0] for v in per.values()) / n_steps,
+            "glue": {"what": "torch / rocclr launches (fills, copies, elementwise, random numbers)", "launches_per_step": glue_launches / n_steps,
+                     "ms_per_step": glue_us / n_steps / 1e3},
+            "rows": ours[:24], "units": M,
+            "note": "durations are device times inside the step (the table scatters run on a side stream beside the MLP backward, so the sum "
+                    "exceeds ms_per_step); MFMA fractions from algorithmic FLOP / duration -- the counter view is profiles/*_pmc_train.json"}
+
+
+def train_grads_match(model, batch, T, scale):
+    """The check of tests/test_config4_full_size_gpu.py on the bench's own batch: one forward + backward of the production plan
+    (binned scatter, level-major gradient, side stream) against the atomic variant (every level through nvsf_hashgrid_bwd), same
+    jitter; max |difference| per parameter relative to that parameter's largest gradient entry."""
+    from nvsf import testing
+    from nvsf.nerf.train_step import RenderTrainStep
+    step = RenderTrainStep(model, num_steps=T, scale=scale)
+    step.scaler = torch.amp.GradScaler("cuda", init_scale=128.0)
+    out = {}
+    for variant in ("binned", "atomic"):
+        torch.manual_seed(17)
+        with testing.variant(table_scatter=variant):
+            step.forward_backward(batch)
+        torch.cuda.synchronize()
+        out[variant] = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    model.zero_grad(set_to_none=True)
+    errs = {}
+    for n, a in out["atomic"].items():
+        b = out["binned"].get(n)
+        scale_n = float(a.abs().max())
+        errs[n] = float("inf") if (b is None or scale_n == 0.0 or not bool(torch.isfinite(b).all())) else float((a - b).abs().max()) / scale_n
+    tol = 5e-5
+    return {"ok": bool(errs) and all(v <= tol for v in errs.values()), "tolerance": tol, "max_rel_err": errs,
+            "what": "production table scatter (bins + level-major hand-over) against the atomic variant, every parameter, one full-size step"}
+
+
 def train_leg(model, tl, tc, tm, T, steps, dev, dist):
     """Secondary figure (not `value`): full multimodal training steps (BASELINE config 4 shape) -- both renders with
     gradient, losses, backward through the HIP operators, one bucketed RCCL gradient all-reduce when N > 1, Adam."""
@@ -354,8 +448,11 @@ def train_leg(model, tl, tc, tm, T, steps, dev, dist):
                          "per_bucket": [{"bucket": b, "MB": mb, "ms": ms} for b, mb, ms in rows], "sum_ms": sum(r[2] for r in rows),
                          "ring_estimate_ms": 2.0 * (world - 1) / world * step.buckets.payload_bytes / 153e9 * 1e3,
                          "ring_estimate": "2 (W - 1) / W x payload / 153 GB/s (one xGMI link per ring direction; DESIGN.md section 7)"}
+    kernels = train_kernel_rows(step, batch, n_l * T) if (dist is None or dist.get_rank() == 0) else None
+    grads_match = train_grads_match(model, batch, T, S_SCALE) if world == 1 else None
     model.eval()
     return {"metric": "trained rays/sec (LiDAR+cam, fwd+bwd+Adam)", "value": (n_l + n_c) * world * steps / dt, "ms_per_step": dt / steps * 1e3,
+            "kernels": kernels, "grads_match": grads_match,
             "steps": steps, "untimed_steps": n_spin, "allreduce_collectives_per_step": n_coll, "per_rank_ms_per_step": per_rank_ms, "allreduce": allreduce,
             "losses": "the reference's Trainer.train_step defaults: per-ray L1 range + MSE ray-drop + MSE intensity summed over rays, chamfer distance of the predicted point cloud, summed MSE RGB",
             "path": "operator path (autograd) under GradScaler (dense fp16 feature gradients): HIP forward kernels; HIP backward for hash grid "
@@ -500,9 +597,9 @@ def dynamic_fixture_check(m, dev, n_rays, T):
                     rng = np.random.default_rng(99)
                     o, d = (S.lidar_rays if lidar else S.camera_rays)(n_rays - GD.RD_N, rng)
                     o, d = np.concatenate([o24, o]), np.concatenate([d24, d])
-                    with torch.no_grad():
+                    with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16):  # the Trainer's autocast region (trainer.py:1332)
                         r = m.render(torch.from_numpy(o).to(dev)[None], torch.from_numpy(d).to(dev)[None],
-                                     torch.tensor([[tv]], dtype=torch.float32, device=dev), cal_lidar_color=lidar, num_steps=T, fp16=True)
+                                     torch.tensor([[tv]], dtype=torch.float32, device=dev), cal_lidar_color=lidar, num_steps=T)
                     sfx, key = ("_lidar" if lidar else ""), f"{flow}/{tag}/{'lidar' if lidar else 'cam'}"
                     for k in ("image", "depth", "weights_sum"):
                         ref = g[f"{key}/{k}"]
@@ -518,8 +615,9 @@ def dynamic_fixture_check(m, dev, n_rays, T):
 def dynamic_leg(dev, n_rays, T, steps):
     """Secondary figure (BASELINE config 5: "dynamic 4D field, fp16 MFMA path"): the reference-default space-time field
     (K-planes + static / dynamic hash grids + flow field, 93.6 M parameters, time_resolution 8), forward render of n_rays
-    LiDAR + n_rays camera rays, rendered as the reference's shipped configuration does: `fp16=True` reaches render (the flow MLP then
-    runs on the fused fp16 MFMA kernel = nn.Linear under autocast; the fp32 form is reported beside it).  `outputs_match_fixture`:
+    LiDAR + n_rays camera rays, rendered as the reference's shipped configuration (`fp16 = True`) does: inside an autocast region
+    (trainer.py:1332-1334, 1487: `torch.cuda.amp.autocast(enabled=self.fp16)`), where the flow MLP's nn.Linear layers compute in fp16
+    -- here the fused fp16 MFMA kernel; the fp32 form (no autocast) is reported beside it.  `outputs_match_fixture`:
     the same model with the fixture's parameters renders batches of the same size whose first 24 rays are the rays of
     tests/golden/network_dynamic_rd.npz -- renders of the REFERENCE's NeRFNetwork at this size -- still and moving scene."""
     from nvsf import synthetic as S
@@ -535,13 +633,13 @@ def dynamic_leg(dev, n_rays, T, steps):
     tm = torch.tensor([[0.5]], device=dev)
 
     def step(fp16):
-        with torch.no_grad():
-            m.render(tl[0], tl[1], tm, cal_lidar_color=True, num_steps=T, fp16=fp16)
-            m.render(tc[0], tc[1], tm, cal_lidar_color=False, num_steps=T, fp16=fp16)
+        with torch.no_grad(), torch.autocast("cuda", dtype=torch.float16, enabled=fp16):
+            m.render(tl[0], tl[1], tm, cal_lidar_color=True, num_steps=T)
+            m.render(tc[0], tc[1], tm, cal_lidar_color=False, num_steps=T)
 
     def timed(fp16):
-        """fp16 = the reference's `--fp16` option as it reaches render through **vars(opt) (trainer.py:200; set by the shipped config,
-        configs/kitti360_1908.txt): the flow MLP on the fused fp16 MFMA kernel.  False: its Linear layers in fp32 (rocBLAS)."""
+        """fp16 = the reference's `--fp16` option (set by the shipped config, configs/kitti360_1908.txt), i.e. the Trainer's autocast
+        region around render: the flow MLP on the fused fp16 MFMA kernel.  False: its Linear layers in fp32 (rocBLAS)."""
         for _ in range(2):
             step(fp16)
         torch.cuda.synchronize()

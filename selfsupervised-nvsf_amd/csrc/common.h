@@ -33,6 +33,7 @@ enum NvsfVariantKey : int {
     kVarHash4dBwd,      // 0 LDS accumulation, 1 run-merging global atomics
     kVarSlicePlan,      // 0 balanced slices, 1 every group its own slice
     kVarRenderTail,     // 0 two tiles per iteration, 1 one tile
+    kVarMarchSkew,      // one-launch marcher: 0 off, q + 1 = the workgroups of ticket queue q start late (the other queues steal from it)
     kVarCount
 };
 int nvsf_variant(int key);

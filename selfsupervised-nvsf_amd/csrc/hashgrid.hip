@@ -373,6 +373,7 @@ __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_bin(const float* __rest
         float val[SPT][8][F];   // contributions of this lane's row (or of the run that ends with it) to the eight vertices of its cell
         uint32_t pk[SPT][8];
         float gmax = 0.0f;
+        bool bad = false;
 #pragma unroll
         for (int s = 0; s < SPT; ++s) {
             float g[F];
@@ -383,6 +384,11 @@ __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_bin(const float* __rest
                 if constexpr (GRAD_F16) g[f] = (float)reinterpret_cast<const _Float16*>(grad_out)[at];
                 else g[f] = reinterpret_cast<const float*>(grad_out)[at];
                 if (mrow[s] >= M) g[f] = 0.0f;
+                // an inf / NaN gradient (an fp16 overflow under GradScaler) must REACH the table -- the memory-atomic path adds it
+                // there and the scaler's found_inf check skips the step -- but it must not enter the fixed-point image: fmaxf drops
+                // a NaN, an inf would set the level's exponent to 128 and truncate every finite addend to zero.  The
+                // value is taken out of the sums here and the level's first table entry is made NaN below.
+                if (!(fabsf(g[f]) <= 3.402823466e38f)) { bad = true; g[f] = 0.0f; }
                 any = any || g[f] != 0.0f;
                 gmax = fmaxf(gmax, fabsf(g[f]));
             }
@@ -474,6 +480,7 @@ __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_bin(const float* __rest
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, o));
         if (lane == 0 && gmax > 0.0f) atomicMax(&s_max, __float_as_uint(gmax));  // non-negative floats order like their bit patterns
+        if (__ballot(bad) != 0ull && lane == 0) atomicAdd(grad_table + (size_t)row0 * F, __builtin_nanf(""));
         __syncthreads();
         if (tid < kWave) {  // exclusive scan of the bin counts, one reservation per bin
             uint32_t run = 0;

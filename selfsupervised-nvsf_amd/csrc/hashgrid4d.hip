@@ -482,8 +482,18 @@ __global__ void k_hash_dynamic_bwd_lds(const float* __restrict__ x, uint32_t x_s
     const uint32_t m0 = (uint32_t)(first < M ? first : M), m1 = (uint32_t)(first + chunk_len < M ? first + chunk_len : M);
     const size_t gcol = (size_t)pl * kPlaneLevels + l;
     // largest |g| of this slice and level
+    // A non-finite gradient (fp16 overflow under GradScaler) has to reach the table, as it does through the memory atomics, so that
+    // the scaler's found_inf check skips the step; it must not enter the fixed-point image (fmaxf drops a NaN, an inf would put the
+    // exponent at 128 and truncate every finite addend): such values are left out of the sums and the level's first entry of this
+    // workgroup's slice is made NaN.
     float mx = 0.0f;
-    for (uint32_t m = m0 + threadIdx.x; m < m1; m += blockDim.x) mx = fmaxf(mx, fabsf(grad_out[(size_t)m * (3 * kPlaneLevels) + gcol]));
+    bool bad = false;
+    for (uint32_t m = m0 + threadIdx.x; m < m1; m += blockDim.x) {
+        const float a = fabsf(grad_out[(size_t)m * (3 * kPlaneLevels) + gcol]);
+        if (a <= 3.402823466e38f) mx = fmaxf(mx, a);
+        else bad = true;
+    }
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63u) == 0u && n_rows != 0u) atomicAdd(pg.g[pl] + row0 + row_lo, __builtin_nanf(""));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     if ((threadIdx.x & 63u) == 0u) s_red[threadIdx.x >> 6] = mx;
@@ -504,6 +514,7 @@ __global__ void k_hash_dynamic_bwd_lds(const float* __restrict__ x, uint32_t x_s
             const bool ok = m < m1;
             const size_t mm = ok ? m : m0;
             go[u] = ok ? grad_out[mm * (3 * kPlaneLevels) + gcol] : 0.0f;
+            if (!(fabsf(go[u]) <= 3.402823466e38f)) go[u] = 0.0f;  // reported above
             xa[u] = x[mm * x_stride + ca];
             xb[u] = x[mm * x_stride + cb];
         }

@@ -432,21 +432,43 @@ __device__ __forceinline__ void march_scanner(const unsigned long long* sums, un
 // address is served at ~90 per microsecond chip-wide (MI355X_MICROARCH.md, price list: dequeue), which 8192 tickets drawn by ~1500
 // workgroups run into (each draw sits in front of the workgroup's barrier).  Queue q hands out tickets q, q + Q, q + 2Q, ...; a
 // workgroup starts at queue blockIdx % Q -- with the round-robin placement of workgroups that is one queue per XCD and an equal
-// number of workgroups per queue -- and moves on to the next queue when its own is exhausted, so every ticket is drawn exactly
-// once, by a running workgroup (the scanner's frontier is the slowest queue's; the queues advance at the same rate).
+// number of workgroups per queue -- and moves on to another queue when its own is exhausted, so every ticket is drawn exactly
+// once, by a running workgroup.
 // Measured (32 768 rays x 1024 steps, one box): one counter 0.203 / 0.216 ms (dense / 10 % grid), 8 queues 0.191 / 0.205, 16 queues
 // 0.185 / 0.210, 32 queues 0.197 / 0.223 (fewer workgroups per queue: the queues drift apart); with 128-step rays -- two batches
 // per ray, nothing but the scaffolding -- 0.129 -> 0.082 ms.
+//
+// Progress invariant (the queues need NOT advance in step).  A worker waits for the exclusive prefix of its previous ticket p
+// while it may already HOLD the next, still uncounted ticket t, drawn early so that the draw's round trip hides behind the count
+// phase.  The scanner hands out prefixes in ticket order, so prefix(p) needs sum(t) whenever t < p -- which this very worker would
+// publish only after the wait.  Therefore a ticket is drawn EARLY only from the queue the pending ticket came from (tickets of one
+// queue grow: t > p); whenever the next ticket has to come from another queue -- the own one is exhausted, or the current ticket
+// was itself taken from another queue than the pending one -- it is drawn LATE, after the pending ticket's wait and stores, when
+// the worker holds nothing uncounted.  Then: the worker holding the smallest unpublished ticket never waits for a larger one, and
+// every queue that still has tickets keeps the workgroups that started on it (blockIdx % Q; for fewer than Q workers each queue
+// holds at most one ticket and the first, unconditional late draw hands all of them out), whose waits are for smaller tickets
+// of that queue -- by induction on the smallest unpublished ticket some worker always advances.  A queue slowed down by a
+// concurrent kernel on its XCD delays the launch; it cannot stall it until the spin limit.
 constexpr uint32_t kMarchQueues = 8;
 constexpr uint32_t kMarchHeadWords = 16 * kMarchQueues;   // 8-byte words in front of the flags: one 128-byte line per queue
-__device__ __forceinline__ uint32_t march_draw_ticket(unsigned int* heads, uint32_t n_tickets) {
-    const uint32_t q0 = blockIdx.x % kMarchQueues;
+constexpr uint32_t kTicketNone = 0xFFFFFFFFu;   // every queue is exhausted
+constexpr uint32_t kTicketLate = 0xFFFFFFFEu;   // to be drawn after the pending ticket has been stored
+__device__ __forceinline__ uint32_t march_draw_own(unsigned int* heads, uint32_t n_tickets, uint32_t q) {
+    const unsigned long long b = (unsigned long long)atomicAdd(&heads[32u * q], 1u) * kMarchQueues + q;
+    return b < n_tickets ? (uint32_t)b : kTicketLate;
+}
+__device__ __forceinline__ uint32_t march_draw_any(unsigned int* heads, uint32_t n_tickets, uint32_t q0) {
+    uint32_t head[kMarchQueues];  // looked at together (one memory latency): only queues that show tickets are drawn from
+#pragma unroll
+    for (uint32_t k = 0; k < kMarchQueues; ++k) head[k] = __hip_atomic_load(&heads[32u * ((q0 + k) % kMarchQueues)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
     for (uint32_t k = 0; k < kMarchQueues; ++k) {
         const uint32_t q = (q0 + k) % kMarchQueues;
+        if ((unsigned long long)head[k] * kMarchQueues + q >= n_tickets) continue;
         const unsigned long long b = (unsigned long long)atomicAdd(&heads[32u * q], 1u) * kMarchQueues + q;
         if (b < n_tickets) return (uint32_t)b;
     }
-    return 0xFFFFFFFFu;  // every queue is exhausted
+    return kTicketNone;
 }
 
 // PLAIN: dt_gamma == 0 and the batch-parallel walk -- the reference's defaults -- are compile-time facts of the instance: the
@@ -456,7 +478,7 @@ __device__ __forceinline__ void march_train_onepass_body(
     const float* __restrict__ rays_o, const float* __restrict__ rays_d, const uint8_t* __restrict__ grid, float bound, float dt_gamma_arg,
     uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* __restrict__ nears, const float* __restrict__ fars,
     const float* __restrict__ noises, int* __restrict__ rays, int* __restrict__ counter, unsigned long long* __restrict__ ws,
-    float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas, int serial_arg, uint32_t spin_limit) {
+    float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas, int serial_arg, uint32_t spin_limit, uint32_t skew) {
     const float dt_gamma = PLAIN ? 0.0f : dt_gamma_arg;
     const int serial = PLAIN ? 0 : serial_arg;
     const int lane = lane_id(), wid = (int)(threadIdx.x >> 6);
@@ -470,10 +492,13 @@ __device__ __forceinline__ void march_train_onepass_body(
     }
     extern __shared__ uint32_t s_lut[];  // H entries
     __shared__ MarchRayLds<BT> s_ray[kMarchRays][2];
+    __shared__ uint32_t s_late;
     __shared__ uint32_t s_cnt[2][kMarchRays], s_next[2], s_arrived[2];  // by parity of the iteration: written before its barrier, read right after it
     fill_spread_lut(s_lut, H);
     if (threadIdx.x < 2) s_arrived[threadIdx.x] = 0u;
-    if (threadIdx.x == 0) s_next[1] = march_draw_ticket(heads, n_tickets);  // ticket = position in the scan
+    if (skew && blockIdx.x % kMarchQueues == skew - 1u && threadIdx.x == 0)
+        for (int i = 0; i < 300; ++i) __builtin_amdgcn_s_sleep(64);  // tests: this queue's workgroups start ~0.5 ms late
+    if (threadIdx.x == 0) s_next[1] = march_draw_any(heads, n_tickets, blockIdx.x % kMarchQueues);  // ticket = position in the scan
     __syncthreads();
     uint32_t b = s_next[1];
     int cur = 0;
@@ -491,7 +516,9 @@ __device__ __forceinline__ void march_train_onepass_body(
             // everybody's ranges back (drawn before the count: 0.274 ms instead of 0.25) -- by the wave that finishes its ray FIRST, so
             // that the draw's round trip runs while the other rays of the ticket are still being counted
             if (lane == 0 && atomicAdd(&s_arrived[cur], 1u) == 0u) {
-                s_next[cur] = march_draw_ticket(heads, n_tickets);
+                // early only from the queue of the ticket this iteration is going to wait for (progress invariant above)
+                const uint32_t q = b % kMarchQueues;
+                s_next[cur] = (!pending || pend_ticket % kMarchQueues == q) ? march_draw_own(heads, n_tickets, q) : kTicketLate;
                 s_arrived[cur ^ 1] = 0u;  // the other parity's counter: last used before the previous barrier, next used after this one
             }
             __syncthreads();  // one barrier per ticket: the four counts -> the ticket's sum and every wave's place inside the ticket
@@ -530,7 +557,13 @@ __device__ __forceinline__ void march_train_onepass_body(
         pend_before = before;
         pend_count = count;
         pend_nrec = nrec;
-        b = s_next[cur];
+        uint32_t next = s_next[cur];
+        if (next == kTicketLate) {  // (the same value in every wave) nothing uncounted is held now: any queue may be drawn from
+            if (threadIdx.x == 0) s_late = march_draw_any(heads, n_tickets, b % kMarchQueues);
+            __syncthreads();  // s_late's previous readers are at least one count-phase barrier behind
+            next = s_late;
+        }
+        b = next;
         cur ^= 1;
     }
 }
@@ -542,9 +575,9 @@ __device__ __forceinline__ void march_train_onepass_body(
         uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* __restrict__ nears,                                \
         const float* __restrict__ fars, const float* __restrict__ noises, int* __restrict__ rays, int* __restrict__ counter,                \
         unsigned long long* __restrict__ ws, float* __restrict__ xyzs, float* __restrict__ dirs, float* __restrict__ deltas, int serial,    \
-        uint32_t spin_limit) {                                                                                                              \
+        uint32_t spin_limit, uint32_t skew) {                                                                                               \
         march_train_onepass_body<OFF32, PLAIN, BT>(rays_o,       rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, noises, rays,     \
-                                               counter, ws, xyzs, dirs, deltas, serial, spin_limit);                                        \
+                                               counter, ws, xyzs, dirs, deltas, serial, spin_limit, skew);                                  \
     }
 // Six waves per SIMD: 80 registers hold the marcher's state without spills (at eight waves = 64 registers, 12-14 of them went to
 // scratch, whose loads and stores queue behind the sample stores on the wave's memory counter), and six workgroups per compute
@@ -1031,7 +1064,7 @@ NVSF_API int nvsf_march_rays_train_ws(const float* rays_o, const float* rays_d, 
     const uint32_t wanted = 1u + cdiv(N, (uint32_t)kMarchRays), resident = kMarchWgPerCu * (uint32_t)march_cu_count();
     hipLaunchKernelGGL(kernel, dim3(wanted < resident ? wanted : resident), dim3(kBlock), H * sizeof(uint32_t), stream, rays_o, rays_d, grid, bound, dt_gamma,
                        max_steps, N, C, H, M, nears, fars, noises, rays, counter, reinterpret_cast<unsigned long long*>(workspace), xyzs, dirs,
-                       deltas, serial, spin_limit ? spin_limit : kMarchSpinLimit);
+                       deltas, serial, spin_limit ? spin_limit : kMarchSpinLimit, (uint32_t)nvsf_variant(kVarMarchSkew));
     return nvsf_launch_status();
 }
 

@@ -82,7 +82,7 @@ class ray_ordered_rows:
 
 def _bin_from(spec, M, rows_per_ray):
     """(merge_from, fine_from) for a batch of M ray-ordered rows, or None: the form of the table scatter (hashgrid_backward)."""
-    if not (rows_per_ray and M >= (1 << 18) and M % rows_per_ray == 0):
+    if not (rows_per_ray and M >= (1 << 18) and M % rows_per_ray == 0) or _testing.get("table_scatter") == "atomic":
         return None
     fine = fine_levels_from(spec, rows_per_ray)
     return None if fine >= spec.L else (merge_levels_from(spec, fine, rows_per_ray), fine)
@@ -681,6 +681,26 @@ def _density_backward(ctx, g_sigma, g_geo):
     return grad_table, None, None, (grad_w if need_w else None), None, None, None, None
 
 
+def density_uniform_train_forward(rays_o, rays_d, nears, fars, T, aabb_host, bound, noise, table_f16, grid_spec, mlp_w16, sliced):
+    """nvsf_field_density_uniform_train_fwd: rays -> z_vals [N, T], sigma [N T], geo16 [N T, 16] fp16 and what the backward reads:
+    normalised positions x01 [N T, 3], feature rows [N T, 32] fp16, MLP outputs h32 [N T, 16] fp32.  `sliced`: the level-sliced
+    (XCD-aware) encode pass + streaming MLP pass instead of the one-launch gather form; same values bit for bit."""
+    N, dev = rays_o.shape[0], rays_o.device
+    M = N * T
+    z_vals = torch.empty(N, T, dtype=torch.float32, device=dev)
+    sigma = torch.empty(M, dtype=torch.float32, device=dev)
+    geo16 = torch.empty(M, 16, dtype=torch.float16, device=dev)
+    x01 = torch.empty(M, 3, dtype=torch.float32, device=dev)
+    feat = torch.empty(M, 32, dtype=torch.float16, device=dev)
+    h32 = torch.empty(M, 16, dtype=torch.float32, device=dev)
+    planes = torch.empty(grid_spec.L, M, dtype=torch.int32, device=dev) if sliced else None
+    _hip.call("nvsf_field_density_uniform_train_fwd", _hip.ptr(rays_o), _hip.ptr(rays_d), _hip.ptr(nears), _hip.ptr(fars),
+              _hip.ptr(linspace01(T, dev)), _hip.ptr(noise), _hip.host_f32(aabb_host), float(bound), N, T, _hip.ptr(table_f16),
+              grid_spec.L, grid_spec.F, grid_spec.h_scales, grid_spec.h_res, grid_spec.h_offsets, _hip.ptr(mlp_w16), _hip.ptr(z_vals),
+              _hip.ptr(sigma), _hip.ptr(geo16), _hip.ptr(x01), _hip.ptr(feat), _hip.ptr(h32), _hip.ptr(planes))
+    return z_vals, sigma, geo16, x01, feat, h32
+
+
 class DensityRaysFn(Function):
     """The training forward of a static hash field from the RAYS: z_vals [N, T], sigma [N T], geo_feat [N T, 15] (fp32) and --
     not differentiable -- geo16 [N T, 16] fp16 = (fp16(geo_feat), 1.0), the per-sample input rows of the heads.
@@ -694,19 +714,8 @@ class DensityRaysFn(Function):
     @staticmethod
     def forward(ctx, rays_o, rays_d, nears, fars, T, aabb_host, bound, noise, table_params, table_f16, grid_spec, mlp_params, mlp_w16,
                 mlp_spec, sigma_lo, sigma_hi, sliced):
-        N, dev = rays_o.shape[0], rays_o.device
-        M = N * T
-        z_vals = torch.empty(N, T, dtype=torch.float32, device=dev)
-        sigma = torch.empty(M, dtype=torch.float32, device=dev)
-        geo16 = torch.empty(M, 16, dtype=torch.float16, device=dev)
-        x01 = torch.empty(M, 3, dtype=torch.float32, device=dev)
-        feat = torch.empty(M, 32, dtype=torch.float16, device=dev)
-        h32 = torch.empty(M, 16, dtype=torch.float32, device=dev)
-        planes = torch.empty(grid_spec.L, M, dtype=torch.int32, device=dev) if sliced else None
-        _hip.call("nvsf_field_density_uniform_train_fwd", _hip.ptr(rays_o), _hip.ptr(rays_d), _hip.ptr(nears), _hip.ptr(fars),
-                  _hip.ptr(linspace01(T, dev)), _hip.ptr(noise), _hip.host_f32(aabb_host), float(bound), N, T, _hip.ptr(table_f16),
-                  grid_spec.L, grid_spec.F, grid_spec.h_scales, grid_spec.h_res, grid_spec.h_offsets, _hip.ptr(mlp_w16), _hip.ptr(z_vals),
-                  _hip.ptr(sigma), _hip.ptr(geo16), _hip.ptr(x01), _hip.ptr(feat), _hip.ptr(h32), _hip.ptr(planes))
+        z_vals, sigma, geo16, x01, feat, h32 = density_uniform_train_forward(rays_o, rays_d, nears, fars, T, aabb_host, bound, noise, table_f16,
+                                                                             grid_spec, mlp_w16, sliced)
         ctx.save_for_backward(x01, feat, sigma, mlp_w16)
         ctx.grid_spec, ctx.mlp_spec, ctx.clamp = grid_spec, mlp_spec, (float(sigma_lo), float(sigma_hi))
         ctx.table_param = table_params

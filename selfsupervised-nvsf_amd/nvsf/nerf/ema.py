@@ -77,6 +77,15 @@ class ExponentialMovingAverage:
             p.copy_(c)
         self.collected_params = None
 
+    @torch.no_grad()
+    def reset_to_parameters(self):
+        """Starts the average again from the current weights (a checkpoint whose `ema` entry could not be restored)."""
+        for s, p in zip(self.shadow_params, self._params):
+            s.copy_(p.detach())
+        if self.num_updates is not None:
+            self.num_updates = 0
+        self.collected_params = None
+
     def state_dict(self):
         return {"decay": self.decay, "num_updates": self.num_updates, "shadow_params": self.shadow_params,
                 "collected_params": self.collected_params}

@@ -116,12 +116,20 @@ class FlowField(nn.Module):
     grid_train_mode = "fused"  # "fused": FlowGridFn; "chain" (tests): encoder + lagrange_reduce under plain autograd
 
     def mlp_mode(self, fp16=None):
-        """"torch" (fp32 Linear layers) or "fused" (fp16 MFMA kernels = the reference's Linear layers under autocast)."""
+        """"torch" (fp32 Linear layers) or "fused" (fp16 MFMA kernels = the reference's Linear layers under autocast).
+        In the reference precision is decided by the Trainer's CUDA autocast region alone (trainer.py:1332, 1487); `fp16` reaches
+        `render` through **vars(opt) and is ignored there.  Here: "auto" follows the CUDA autocast state (not the CPU one), which is
+        the reference's behaviour; an explicit `fp16=` argument of render / forward is an EXTENSION of this package that pins the
+        regime without an autocast region (tests, tools); the fixture-pinned default outside autocast is the fp32 form."""
         if fp16 is not None:
             return "fused" if fp16 else "torch"
         if self.flow_mlp_mode != "auto":
             return self.flow_mlp_mode
-        return "fused" if torch.is_autocast_enabled() else "torch"
+        try:
+            on = torch.is_autocast_enabled("cuda")
+        except TypeError:  # older torch: one device-agnostic flag
+            on = torch.is_autocast_enabled()
+        return "fused" if on else "torch"
 
     def _fused_mlp_ok(self):
         lin = [m for m in self.mlp if isinstance(m, nn.Linear)]

@@ -22,8 +22,8 @@ class Planes4D(nn.Module):
     24 permuted planes), the backward kernel's gradient buffer IS its gradient (no per-plane permute + accumulate launches), and
     the optimiser / EMA / gradient all-reduce see one tensor instead of 24 (the training step of the space-time model made ~200
     launches per step around the per-plane parameters).  state_dict()/load_state_dict() speak the reference's schema: the
-    `planes.<scale>.<pair>` keys with [1, C, H, W] tensors (hooks below), so reference checkpoints load unchanged and ours load
-    there; `plane(scale, pair)` / `plane_grad(scale, pair)` give [1, C, H, W] views for inspection."""
+    `planes.<scale>.<pair>` keys with [1, C, H, W] tensors (hooks below), so the `model` entry of a reference checkpoint loads
+    unchanged and ours loads there; the position-ordered `optimizer` / `ema` entries are translated by nvsf/nerf/checkpoint_compat.py; `plane(scale, pair)` / `plane_grad(scale, pair)` give [1, C, H, W] views for inspection."""
 
     def __init__(self, grid_dimensions=2, input_dim=4, output_dim=8, resolution=[32, 32, 32, 8], multiscale_res=[1, 2, 4, 8],
                  concat_ms_feat=True, decompose=True, reduction="prod"):

@@ -118,32 +118,68 @@ packbits = _packbits.apply
 # sample arrays are then incomplete.  Calls that read the counter back anyway check the flag in that same read; calls that do not
 # (mean_count > 0: no device->host read, as in the reference) leave an asynchronous copy of the flag here, which the next
 # march_rays_train call -- or check_march_status() -- looks at once its copy event has completed.
-_pending_status = []  # [(pinned int32 [1], event)]
+class _StatusRing:
+    """Per device: a few pinned int32 slots with their copy events, allocated once and handed out round-robin (a pinned allocation
+    and an event per march_rays_train call were on the hot path).  A slot is reused only after its copy has landed and been looked
+    at; when every slot is still in flight the oldest one is waited for."""
+    SLOTS = 8
+
+    def __init__(self):
+        self.host = torch.empty(self.SLOTS, dtype=torch.int32).pin_memory()
+        self.events = [torch.cuda.Event() for _ in range(self.SLOTS)]
+        self.busy = [False] * self.SLOTS
+        self.next = 0
+        self.failed = False
+
+    def note(self, flag):
+        i = self.next
+        if self.busy[i]:
+            self.events[i].synchronize()
+            self._look(i)
+        self.host[i:i + 1].copy_(flag, non_blocking=True)
+        self.events[i].record()
+        self.busy[i] = True
+        self.next = (i + 1) % self.SLOTS
+
+    def _look(self, i):
+        self.failed = self.failed or int(self.host[i]) < 0
+        self.busy[i] = False
+
+    def poll(self, wait):
+        for i in range(self.SLOTS):
+            if self.busy[i]:
+                if wait:
+                    self.events[i].synchronize()
+                if self.events[i].query():
+                    self._look(i)
+        failed, self.failed = self.failed, False
+        return failed
+
+
+_status_rings = {}  # device index -> _StatusRing
 
 
 def _note_status(step_counter):
-    host = torch.empty(1, dtype=torch.int32).pin_memory()
-    host.copy_(step_counter[1:2], non_blocking=True)
-    ev = torch.cuda.Event()
-    ev.record()
-    _pending_status.append((host, ev))
+    ring = _status_rings.get(step_counter.device.index)
+    if ring is None:
+        ring = _status_rings[step_counter.device.index] = _StatusRing()
+    ring.note(step_counter[1:2])
 
 
 def check_march_status(wait=False):
     """Raises NvsfHipError if a march_rays_train launch whose counter was not read back reported an expired wait.
-    wait=True synchronises with the outstanding launches first."""
-    keep, failed = [], False
-    for host, ev in _pending_status:
-        if wait:
-            ev.synchronize()
-        if ev.query():
-            failed = failed or int(host[0]) < 0
-        else:
-            keep.append((host, ev))
-    _pending_status[:] = keep
+    wait=True synchronises with the outstanding launches first (RenderTrainStep.step does, once per step, BEFORE the optimiser:
+    an expired launch hands empty ranges to the compositor, and its step must not be applied)."""
+    failed = False
+    for ring in _status_rings.values():
+        failed = ring.poll(wait) or failed
     if failed:
         raise _hip.NvsfHipError("nvsf_march_rays_train_ws: a bounded inter-workgroup wait expired (counter[1] < 0); "
                                 "the samples of that call are invalid")
+
+
+def march_status_pending():
+    return any(any(r.busy) for r in _status_rings.values())
 
 
 class _march_rays_train(Function):

@@ -269,14 +269,29 @@ class RenderTrainStep:
         return overlap
 
     def step(self, batch):
+        out = self.forward_backward(batch)
+        if getattr(self.model, "cuda_ray", False):
+            from nvsf.nerf.raymarching import raymarching
+            if raymarching.march_status_pending():  # occupancy-grid training without a counter read-back: the marcher's failure flag
+                raymarching.check_march_status(wait=True)  # is looked at before the optimiser, not one call later
+        self.scaler.step(self.opt)
+        self.scaler.update()
+        self.sched.step()
+        self.global_step += 1
+        return out
+
+    def forward_backward(self, batch):
+        """Everything of a step up to (not including) the optimiser: both renders, the losses, backward through the HIP operators,
+        the gradient all-reduce when there is more than one rank; on return every parameter's `.grad` (still multiplied by the
+        GradScaler's scale) is final on the current stream.  -> (loss, parts, number of collectives).  `step` = this + Adam."""
         from nvsf import field_ops
         field_ops.begin_scatter_count()  # a table is final after the LAST scatter it receives in this step (ray_chunks > 1: several)
         try:
-            return self._step(batch)
+            return self._forward_backward(batch)
         finally:
             field_ops.end_scatter_count()
 
-    def _step(self, batch):
+    def _forward_backward(self, batch):
         self.model.train()
         if self.buckets is not None:
             self.buckets.begin_step()
@@ -311,10 +326,6 @@ class RenderTrainStep:
             if overlap:
                 from nvsf import field_ops
                 field_ops.sync_side_streams()
-        self.scaler.step(self.opt)
-        self.scaler.update()
-        self.sched.step()
-        self.global_step += 1
         return loss.detach(), {k: v.detach() for k, v in parts.items()}, n_coll
 
     def end_epoch(self):
@@ -322,12 +333,20 @@ class RenderTrainStep:
         if self.ema is not None:
             self.ema.update()
 
-    def checkpoint_state(self, epoch=0, stats=None, full=True):
+    def checkpoint_state(self, epoch=0, stats=None, full=True, reference_layout=False):
         """The dict Trainer.save_checkpoint writes with torch.save (nvsf/nerf/utils.py:622-648): epoch, global_step, stats,
-        model and -- for a `full` checkpoint -- optimizer, lr_scheduler, scaler, ema."""
+        model and -- for a `full` checkpoint -- optimizer, lr_scheduler, scaler, ema.  `model` always speaks the reference's
+        schema (names and shapes).  `optimizer` and `ema` are lists by parameter position: written in this package's layout (one
+        entry per `planes_cl`) unless `reference_layout`, which expands the optimiser entry to one state per plane so that a
+        reference Trainer resumes from it (checkpoint_compat); the `ema` entry cannot be written for the reference -- torch_ema
+        wants shadows for the three unused modules this model does not have -- and the reference then starts a fresh average,
+        as it does for any checkpoint whose ema fails to load (utils.py:728-747).  load_checkpoint reads both layouts."""
         state = {"epoch": epoch, "global_step": self.global_step, "stats": stats if stats is not None else {}}
         if full:
             state["optimizer"] = self.opt.state_dict()
+            if reference_layout:
+                from nvsf.nerf import checkpoint_compat as compat
+                state["optimizer"] = compat.optimizer_state_in_reference_layout(state["optimizer"], self.model, self.opt)
             state["lr_scheduler"] = self.sched.state_dict()
             state["scaler"] = self.scaler.state_dict()
             if self.ema is not None:
@@ -335,8 +354,8 @@ class RenderTrainStep:
         state["model"] = self.model.state_dict()
         return state
 
-    def save_checkpoint(self, path, epoch=0, stats=None, full=True):
-        torch.save(self.checkpoint_state(epoch, stats, full), path)
+    def save_checkpoint(self, path, epoch=0, stats=None, full=True, reference_layout=False):
+        torch.save(self.checkpoint_state(epoch, stats, full, reference_layout), path)
 
     def load_checkpoint(self, checkpoint, model_only=False):
         """Trainer.load_checkpoint (nvsf/nerf/utils.py:682-747): a bare state_dict loads strictly; a checkpoint dict loads its
@@ -352,14 +371,31 @@ class RenderTrainStep:
         missing, unexpected = self.model.load_state_dict(checkpoint["model"], strict=False)
         self.failed_to_load = []
 
+        from nvsf.nerf import checkpoint_compat as compat
+
+        def translate(key, state):
+            """`ema` / `optimizer` entries are ordered by parameter POSITION: a reference checkpoint counts three unused modules and
+            24 tensors per Planes4D where this model has one (checkpoint_compat)."""
+            if key == "ema":
+                state = dict(state, shadow_params=compat.shadows_for_model(state["shadow_params"], self.model))
+                if state.get("collected_params") is not None:
+                    state["collected_params"] = compat.shadows_for_model(state["collected_params"], self.model)
+            elif key == "optimizer":
+                state = compat.optimizer_state_for_model(state, self.model, self.opt)
+            return state
+
         def restore(key, obj):
             if key in checkpoint and obj is not None:
                 try:
-                    obj.load_state_dict(checkpoint[key])
+                    obj.load_state_dict(translate(key, checkpoint[key]))
                 except Exception as e:  # noqa: BLE001 -- reference behaviour: warn and continue
                     self.failed_to_load.append(key)
                     warnings.warn(f"[WARN] Failed to load {key} state from the checkpoint ({type(e).__name__}: {e}); "
                                   f"continuing with a fresh {key}")
+                    if key == "ema":
+                        # "fresh" = the average starts again FROM THE WEIGHTS JUST LOADED: the shadows still hold the clones taken
+                        # at construction (random init), which evaluate_frames(ema=...) would otherwise copy over the checkpoint
+                        obj.reset_to_parameters()
         restore("ema", self.ema)  # before the model_only return, as the reference does (utils.py:715-719): evaluation runs under the EMA weights
         if model_only:
             return list(missing), list(unexpected), checkpoint.get("epoch")

@@ -22,6 +22,7 @@ _NATIVE = {
     "hash4d_bwd": {"lds": 0, "runs": 1},
     "slice_plan": {"balanced": 0, "home": 1},
     "render_tail": {"two": 0, "one": 1},
+    "march_skew": {"off": 0, **{f"queue{q}": q + 1 for q in range(8)}},
 }
 # operator-side choices (Python): name -> allowed values, the first one is the production form
 _PYTHON = {
@@ -31,6 +32,7 @@ _PYTHON = {
     "dynamic_fused": (True, False),             # network_dynamic no-grad feature path: fused launches / operator calls
     "density_tail_train": ("fused", "chain"),   # network_dynamic.density with autograd: DensityTailFn / torch blend + cat + MLP
     "density_fn": ("fused", "chain"),           # network_static.density: DensityFn / encoder -> MLP -> trunc_exp modules
+    "table_scatter": ("binned", "atomic"),      # field_ops._bin_from: binned fine levels where they pay / every level through nvsf_hashgrid_bwd
 }
 _state = {}
 

@@ -155,6 +155,17 @@ def hashgrid_bwd(x, cols, spec, grad_out):
     return gt
 
 
+def hashgrid_bwd_f64(x, cols, spec, grad_out):
+    """The table gradient accumulated in fp64 (order-independent to ~1e-16): the bar for full-size batches."""
+    xx, go = _f32(x), _f32(grad_out)
+    M, xs = xx.shape
+    gt = np.zeros(spec.offsets[-1] * spec.F, np.float64)
+    _lib("field").oracle_hashgrid_bwd_f64(_p(xx), U(M), U(xs), _p(np.asarray(cols, np.uint32)), U(spec.D), U(spec.L), U(spec.F),
+                                          _p(_f32(spec.scales)), _p(np.asarray(spec.res, np.uint32)), _p(np.asarray(spec.offsets, np.uint32)),
+                                          _p(go), U(go.shape[1]), _p(gt))
+    return gt
+
+
 def freq_encode(x, n_freq=12):
     xx = _f32(x)
     M, nd = xx.shape

@@ -584,3 +584,29 @@ def test_dynamic_hash_gradient_through_lds_equals_the_run_merging_kernel(dev, va
         scale = float((b - 0.5).abs().max())
         assert scale > 0 and float((a - b).abs().max()) <= 2e-5 * scale
         assert torch.equal(a == 0.5, b == 0.5)  # the same rows are touched
+
+
+@pytest.mark.parametrize("poison", [float("inf"), float("-inf"), float("nan")])
+def test_dynamic_hash_gradient_through_lds_keeps_non_finite_gradients(dev, poison):
+    """An inf / NaN gradient row (an fp16 overflow under GradScaler) must leave the level's sums non-finite, as the memory-atomic
+    kernels do, so that the scaler's found_inf check skips the step -- the fixed-point LDS image must not launder it into finite
+    garbage or zeros; the levels without a poisoned entry stay finite."""
+    import ctypes
+    from nvsf import _hip
+    from nvsf.nerf.models.hash_field import HashGrid4D
+    enc = HashGrid4D(time_resolution=4).to(dev)
+    specs = [pl.hash_t[0].spec for pl in enc.hash_dynamic]
+    M = 1 << 16
+    x = torch.rand(M, 3, device=dev)
+    g = torch.randn(M, 24, device=dev)
+    g[12345, 8 + 3] = poison   # pair 1, level 3
+    g[:, 16 + 5] = poison      # pair 2, level 5: a whole column (its largest finite |g| is 0)
+    h_scales = _hip.host_f32([v for s in specs for v in s.scales])
+    h_res = _hip.host_u32([v for s in specs for v in s.res])
+    h_off = _hip.host_u32([v for s in specs for v in s.offsets])
+    sums = [torch.zeros(s.n_rows, dtype=torch.float32, device=dev) for s in specs]
+    _hip.call("nvsf_hashgrid4d_dynamic_bwd_scalar", _hip.ptr(x), 3, M, h_scales, h_res, h_off, _hip.ptr(g),
+              (ctypes.c_void_p * 3)(*[t.data_ptr() for t in sums]))
+    lvl = lambda p, l: sums[p][specs[p].offsets[l]:specs[p].offsets[l + 1]]
+    assert not torch.isfinite(lvl(1, 3)).all() and not torch.isfinite(lvl(2, 5)).all()
+    assert torch.isfinite(sums[0]).all() and torch.isfinite(lvl(1, 2)).all() and torch.isfinite(lvl(2, 4)).all()

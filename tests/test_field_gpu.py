@@ -380,3 +380,34 @@ def test_hashgrid_backward_accumulates_and_ignores_zero_gradients(ops, dev):
     assert float(a.abs().max()) > 0 and torch.allclose(acc, a + 3.0, rtol=0, atol=1e-4) and torch.equal(acc[a == 0], base[a == 0])
     z = ops.hashgrid_backward(x, (0, 1, 2), spec, torch.zeros_like(go), grad_table=base.clone())
     assert torch.equal(z, base)
+
+
+@pytest.mark.parametrize("L,F,log2_T,base,top,plan", [(16, 2, 14, 16, 512, (9, 12)), (8, 4, 12, 16, 256, (0, 4))])
+@pytest.mark.parametrize("poison", [float("inf"), float("nan")])
+@pytest.mark.parametrize("half", [False, True])
+def test_hashgrid_backward_binned_keeps_non_finite_gradients(ops, dev, L, F, log2_T, base, top, plan, poison, half):
+    """An inf / NaN entry of dL/d(features) -- an fp16 overflow under GradScaler -- reaches the table gradient through the binned
+    scatter as it does through nvsf_hashgrid_bwd's memory atomics (GradScaler's found_inf check then skips the step): the bins'
+    fixed-point image must not turn it into zeros or finite garbage.  Row-major and level-major gradients; a run-sum
+    level, a per-row level and an atomic level are poisoned in turn; the other levels stay finite."""
+    spec = _spec(ops, 3, L, F, log2_T, base, top)
+    rng = np.random.default_rng(3)
+    n_rays, T = 32, 128
+    o = rng.random((n_rays, 1, 3)) * 0.5 + 0.1
+    d = rng.standard_normal((n_rays, 1, 3))
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    x = np.clip(o + d * np.linspace(0.0, 0.35, T).reshape(1, T, 1), 0.0, 1.0).reshape(-1, 3).astype(np.float32)
+    M = x.shape[0]
+    go = rng.standard_normal((M, L * F)).astype(np.float32)
+    for level in sorted({0, plan[0], L - 1}):
+        g = go.copy()
+        g[1777, level * F + F - 1] = poison
+        for level_major in (False, True):
+            if level_major and half:
+                continue
+            gin = np.ascontiguousarray(g.reshape(M, L, F).transpose(1, 0, 2)) if level_major else g
+            gin = _t(gin.astype(np.float16) if half else gin, dev)
+            got = ops.hashgrid_backward(_t(x, dev), (0, 1, 2), spec, gin, fine_from=plan).cpu().numpy()
+            for l in range(L):
+                a, b = spec.offsets[l] * F, spec.offsets[l + 1] * F
+                assert np.isfinite(got[a:b]).all() == (l != level), (level, l, level_major)

@@ -153,6 +153,36 @@ def test_march_rays_train_ws_matches_oracle(rm, dev, scene, n, max_steps, dt_gam
     assert not xyzs[m:].any()
 
 
+@pytest.mark.parametrize("n", [8192, 32768, 20])
+@pytest.mark.parametrize("queue", ["queue0", "queue3", "queue7"])
+def test_march_rays_train_ws_with_skewed_ticket_queues(rm, dev, scene, variants, n, queue):
+    """The eight ticket queues do NOT advance in step here: the workgroups of one queue start ~0.5 ms late (test variant
+    `march_skew`), so the others exhaust their own queues and take tickets of the lagging one that lie BELOW tickets they still
+    have pending -- the case in which an unguarded steal makes a worker wait for a prefix that needs the very ticket it holds
+    (the launch then only ends at the spin limit, with counter[1] < 0).  The early-own / late-any draw (raymarching.hip,
+    march_draw_own / march_draw_any) must finish normally, in order, with the three-launch form's outputs bit for bit; n = 20 (five tickets, five workers on queues 1-5) leaves
+    queue 0 -- ticket 0 -- without a workgroup of its own."""
+    from nvsf import _hip
+    max_steps = 256
+    o, d = _rays(n, 21, "cam")
+    aabb = np.array([-2, -2, -2, 2, 2, 2], np.float32)
+    nears, fars = O.near_far_from_aabb(o, d, aabb, 0.02)
+    T = lambda a: _t(a, dev)
+    to, td, tb, tn, tf, tz = T(o), T(d), T(scene["bits"]), T(nears), T(fars), torch.zeros(n, device=dev)
+    M = n * max_steps
+    xyzs = torch.zeros(M, 3, device=dev); dirs = torch.zeros(M, 3, device=dev); deltas = torch.zeros(M, 2, device=dev)
+    rays = torch.empty(n, 3, dtype=torch.int32, device=dev); counter = torch.zeros(2, dtype=torch.int32, device=dev)
+    _hip.call("nvsf_march_rays_train", _hip.ptr(to), _hip.ptr(td), _hip.ptr(tb), 2.0, 0.0, max_steps, n, 2, 128, M,
+              _hip.ptr(tn), _hip.ptr(tf), _hip.ptr(xyzs), _hip.ptr(dirs), _hip.ptr(deltas), _hip.ptr(rays), _hip.ptr(counter), _hip.ptr(tz))
+    variants.set(march_skew=queue)
+    # a spin limit far below the default (2^22 polls = seconds): a stalled launch fails this test quickly instead of hanging it
+    c2, r2, x2, d2, l2 = _march_ws(dev, to, td, tb, tn, tf, tz, n, max_steps, 0.0, M, spin_limit=1 << 17)
+    variants.clear("march_skew")
+    assert int(c2[1]) == n, "a bounded wait expired: the ticket order stalled"
+    assert torch.equal(c2, counter.cpu()) and torch.equal(r2, rays.cpu())
+    assert torch.equal(x2, xyzs.cpu()) and torch.equal(d2, dirs.cpu()) and torch.equal(l2, deltas.cpu())
+
+
 @pytest.mark.parametrize("kind", ["random10", "random50", "dense", "empty", "scene", "stripes"])
 @pytest.mark.parametrize("dt_gamma,max_steps", [(0.0, 1024), (0.0, 300), (1.0 / 256, 512), (0.0, 4096)])
 def test_march_rays_train_ws_equals_three_launch_form(rm, dev, scene, kind, dt_gamma, max_steps):

@@ -65,6 +65,25 @@ def _mlp(kernel, ms, flop_per_sample, bytes_per_sample, M, per_unit):
     return row
 
 
+def _bin_contributions(x01, spec, plan, T):
+    """Number of (row, values) records the binned scatter writes for ray-ordered rows x01 [M, 3]: 8 per row on the levels from
+    fine_from on; on the run-sum levels 8 per RUN = up to 8 consecutive rows of a wave (64 consecutive rows) that share a cell."""
+    merge_from, fine_from = plan
+    M = x01.shape[0]
+    total = 8 * M * (spec.L - fine_from)
+    idx = torch.arange(M, device=x01.device)
+    for l in range(merge_from, fine_from):
+        cell = torch.floor(x01 * spec.scales[l] + 0.5).to(torch.int64)
+        key = (cell[:, 0] * 4096 + cell[:, 1]) * 4096 + cell[:, 2]
+        new = torch.ones(M, dtype=torch.bool, device=x01.device)
+        new[1:] = key[1:] != key[:-1]
+        new |= (idx % 64) == 0
+        starts = torch.nonzero(new).squeeze(1)
+        lengths = torch.diff(starts, append=torch.tensor([M], device=x01.device))
+        total += 8 * int(((lengths + 7) // 8).sum())
+    return int(total)
+
+
 def field_op_rooflines(dev, n_rays=4096, T=768, seed=0):
     import tinycudann as tcnn
     from nvsf import field_ops as ops, synthetic as S
@@ -107,9 +126,30 @@ def field_op_rooflines(dev, n_rays=4096, T=768, seed=0):
             rows.append(_hbm(f"hashgrid_fwd[{name}, {tag}]", ms, 512 + 12 + 64, M, "588 B/sample (8 corners x 32 features x 2 B gathered + 12 + 64)"))
             g = torch.randn(M, enc.n_output_dims, device=dev).half()
             gt = torch.zeros(enc.spec.n_params, dtype=torch.float32, device=dev)
+            # (1) what a training step LAUNCHES at this size: the plan of field_ops._bin_from (run sums + per-row bins for the fine levels,
+            # run-merging atomics below) fed with the density MLP's level-major fp32 gradient [L, M, F] (mlp_backward(grad_x_blocks=F))
+            plan = ops._bin_from(enc.spec, M, T)
+            g_lm = g.float().view(M, enc.spec.L, enc.spec.F).permute(1, 0, 2).contiguous()
+            if plan is not None:
+                ms = _time_ms(lambda: ops.hashgrid_backward(x, (0, 1, 2), enc.spec, g_lm, grad_table=gt, fine_from=plan), 5)
+                row = _hbm(f"hashgrid_bwd[{name}, {tag}]", ms, 8 * 32 * 4 + 12 + 128, M,
+                           "production plan (merge_from, fine_from) = %s, level-major fp32 gradient; 1164 B/sample (8 corners x 32 features x 4 B added "
+                           "+ 12 + 128 read)" % (plan,))
+                contrib = _bin_contributions(x, enc.spec, plan, T)
+                rec = 2 + 4 * enc.spec.F
+                row.update({"plan": list(plan), "bin_contributions": contrib, "contribution_bytes": 2 * rec * contrib,
+                            "contribution_GBs": 2 * rec * contrib / (ms * 1e-3) / 1e9,
+                            "contribution_note": "%d-byte (row, values) records of the binned levels, written once and read once; the time also covers "
+                                                 "the atomics of the levels below merge_from" % rec})
+                rows.append(row)
+                ms = _time_ms(lambda: ops.hashgrid_backward(x, (0, 1, 2), enc.spec, g, grad_table=gt, fine_from=plan), 5)
+                rows.append(_hbm(f"hashgrid_bwd[{name}, {tag}, row-major fp16 gradient]", ms, 8 * 32 * 4 + 12 + 64, M,
+                                 "same plan fed with [M, L F] fp16 rows (HashGridFn outside DensityFn)"))
+            # (2) the fallback every level takes below 2^18 rows / without ray order: run-merging fp32 atomics
             ms = _time_ms(lambda: ops.hashgrid_backward(x, (0, 1, 2), enc.spec, g, grad_table=gt), 5)
-            rows.append(_hbm(f"hashgrid_bwd[{name}, {tag}]", ms, 8 * 32 * 4 + 12 + 64, M,
-                             "1100 B/sample (8 corners x 32 features x 4 B of fp32 atomics + 12 + 64 read); ceiling = atomic rate ~1.3 TB/s"))
+            rows.append(_hbm(f"hashgrid_bwd[{name}, {tag}, atomics only]", ms, 8 * 32 * 4 + 12 + 64, M,
+                             "NOT what a full-size step launches: every level through nvsf_hashgrid_bwd (the form small batches take); 1100 B/sample "
+                             "(8 corners x 32 features x 4 B of fp32 atomics + 12 + 64 read); ceiling = atomic rate ~1.3 TB/s"))
         del enc, table
 
     # ---- a16: fused MLPs at the shapes of the model, aligned fp16 rows
