@@ -74,6 +74,18 @@ def render_sharded(model, rays_o, rays_d, time, cal_lidar_color=False, max_ray_b
     return {k: gather_ray_outputs(part[k][0], N).unsqueeze(0) for k in keys}
 
 
+def allreduce_sums(values, device=None):
+    """Sums a short list of host scalars over the ranks with ONE all-reduce -- the statistics collective of the reference's
+    evaluation loop (`dist.all_reduce(loss, op=SUM); loss /= world_size`, trainer.py:1506-1509; SURVEY 8e: the only collective
+    besides the gradients worth keeping).  fp64 on the wire; returns floats; the identity with one rank."""
+    rank, ws = world()
+    if ws == 1:
+        return [float(v) for v in values]
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t.tolist()]
+
+
 def allreduce_gradients(params, bucket_bytes=64 << 20):
     """Averages the gradients of `params` over all ranks AFTER backward has finished, in as few, as large all-reduces as
     `bucket_bytes` allows (one-shot form; `GradBuckets` is the overlapped form the training step uses).  A parameter without a
@@ -135,6 +147,7 @@ class GradBuckets:
             self.flat.append(flat)
         self._index = {p: i for i, p in enumerate(self.params)}
         self._flags = torch.zeros(len(self.params), dtype=torch.float32, device=self.params[0].device)
+        self._flags_host = None
         self._pending, self._next, self._handles, self._fired = [], 0, [], set()
         self._events = [[] for _ in self.buckets]
         self._hold, self._held = False, []
@@ -248,9 +261,15 @@ class GradBuckets:
             field_ops.GRAD_SINK = None
             field_ops.sync_side_streams()
         self._launch_ready(force=True)
-        self._flags.zero_()
-        if self._fired:
-            self._flags[[self._index[p] for p in self._fired]] = 1.0
+        # "somebody produced a gradient" flags: written on the host (pinned) and copied without blocking
+        if self._flags_host is None:
+            self._flags_host = torch.zeros(len(self.params), dtype=torch.float32)
+            if self._cuda:
+                self._flags_host = self._flags_host.pin_memory()
+        self._flags_host.zero_()
+        for p in self._fired:
+            self._flags_host[self._index[p]] = 1.0
+        self._flags.copy_(self._flags_host, non_blocking=True)
         if self.ws > 1:
             self._handles.append(dist.all_reduce(self._flags, op=dist.ReduceOp.MAX, async_op=True))
             self.n_collectives += 1
@@ -258,7 +277,12 @@ class GradBuckets:
                 h.wait()
             for flat in self.flat:
                 flat.div_(self.ws)
-        touched = self._flags.tolist() if self.ws > 1 else [1.0 if p in self._fired else 0.0 for p in self.params]
+        # A parameter is touched if ANY rank produced a gradient for it.  Every parameter this rank fired is touched, whatever the
+        # others did: only when some parameter did NOT fire here does the answer depend on the reduced flags -- and only then are they
+        # read back (one device->host sync; a step that uses every parameter on every rank, the usual case, has none).  The MAX
+        # all-reduce above is issued regardless: collectives are matched across ranks by sequence, and another rank may need it.
+        local = [1.0 if p in self._fired else 0.0 for p in self.params]
+        touched = self._flags.tolist() if (self.ws > 1 and not all(local)) else local
         for p, t in zip(self.params, touched):
             if t == 0.0:
                 p.grad = None

@@ -485,7 +485,8 @@ class PointsMeter:
         return f"Points_error(CD, F-score) = {[round(float(cd), 3), round(float(f), 3)]}"
 
 
-def eval_step(model, data, num_steps, alpha_d=1.0, alpha_r=0.01, alpha_i=0.1, alpha_rgb=1.0, raydrop_thres=0.5, max_ray_batch=4096, **render_kwargs):
+def eval_step(model, data, num_steps, alpha_d=1.0, alpha_r=0.01, alpha_i=0.1, alpha_rgb=1.0, raydrop_thres=0.5, max_ray_batch=4096,
+              split_rays=True, **render_kwargs):
     """Whole-frame evaluation of one frame, the reference's Trainer.eval_step (nvsf/nerf/trainer.py:658-815) without its optional
     U-Net ray-drop refinement: `data` = FrameSet(..., training=False).collate([i]) -- every pixel of the range image and of the camera
     image.  Both modalities go through the staged render, a frame's rays split over the ranks (frame_shard.render_sharded); the
@@ -493,6 +494,10 @@ def eval_step(model, data, num_steps, alpha_d=1.0, alpha_r=0.01, alpha_i=0.1, al
     its own mask (:695-696); loss = the reference's mean-reduced L1 range + MSE ray-drop + MSE intensity + MSE RGB (:733-737, :795-796;
     criteria as main_nvsf.py:205-221).  Returns a dict of [B, H, W(, C)] predictions / ground truths and `loss`."""
     from nvsf import frame_shard
+    if split_rays:
+        render = lambda *a, **k: frame_shard.render_sharded(model, *a, **k)
+    else:  # this rank renders the whole frame by itself (evaluate_frames(shard="frames"))
+        render = lambda o, d, t, **k: model.render(o, d, t, staged=True, **k)
     out = {}
     loss = torch.zeros((), device=data["rays_o_lidar"].device)
     with torch.no_grad():
@@ -500,8 +505,8 @@ def eval_step(model, data, num_steps, alpha_d=1.0, alpha_r=0.01, alpha_i=0.1, al
         B, Hl, Wl, _ = gl.shape
         gt_raydrop = gl[..., 0]
         gt_intensity, gt_depth = gl[..., 1] * gt_raydrop, gl[..., 2] * gt_raydrop
-        o = frame_shard.render_sharded(model, data["rays_o_lidar"], data["rays_d_lidar"], data["time"], cal_lidar_color=True, num_steps=num_steps,
-                                       max_ray_batch=max_ray_batch, **render_kwargs)
+        o = render(data["rays_o_lidar"], data["rays_d_lidar"], data["time"], cal_lidar_color=True, num_steps=num_steps,
+                   max_ray_batch=max_ray_batch, **render_kwargs)
         img = o["image_lidar"].reshape(B, Hl, Wl, 2)
         pred_raydrop, pred_intensity, pred_depth = img[..., 0], img[..., 1], o["depth_lidar"].reshape(B, Hl, Wl)
         mask = (pred_raydrop > raydrop_thres).to(pred_depth.dtype)
@@ -513,23 +518,32 @@ def eval_step(model, data, num_steps, alpha_d=1.0, alpha_r=0.01, alpha_i=0.1, al
         gi = data["images"]  # [B, H, W, 3 or 4]
         _, H, W, C = gi.shape
         gt_rgb = gi[..., :3] * gi[..., 3:] + (1 - gi[..., 3:]) if C == 4 else gi  # fixed white background (:774-781)
-        c = frame_shard.render_sharded(model, data["rays_o"], data["rays_d"], data["time"], num_steps=num_steps, max_ray_batch=max_ray_batch,
-                                       bg_color=1, **render_kwargs)
+        c = render(data["rays_o"], data["rays_d"], data["time"], num_steps=num_steps, max_ray_batch=max_ray_batch, bg_color=1, **render_kwargs)
         pred_rgb = c["image"].reshape(B, H, W, 3)
         loss = loss + alpha_rgb * ((pred_rgb - gt_rgb) ** 2).mean()
         out.update(pred_rgb=pred_rgb, pred_rgb_depth=c["depth"].reshape(B, H, W), gt_rgb=gt_rgb, loss=loss)
     return out
 
 
-def evaluate_frames(model, frames, num_steps, indices=None, ema=None, **eval_kwargs):
+def evaluate_frames(model, frames, num_steps, indices=None, ema=None, shard="rays", **eval_kwargs):
     """The metric half of the reference's evaluate_one_epoch (trainer.py:1458-1560) over a FrameSet opened with training=False:
     per frame eval_step, then the two quality metrics of the headline benchmark -- PSNR of the image (error_matrices.py:48-57), range
     RMSE in metres (:263-285) -- and chamfer distance / F-score of the range image's point cloud (PointsMeter, :299-356, on
     csrc/chamfer.hip); means over the frames.  `ema`: the step's ExponentialMovingAverage (RenderTrainStep.ema) -- the reference
     evaluates under `ema.store(); ema.copy_to()` and `restore()`s afterwards (trainer.py:1475-1477, 1843-1844), so metrics are
-    those of the averaged weights once EMA is on (its default).  Every rank returns the same numbers (the renders are
-    all-gathered).  The reference's other meters (ray-drop accuracy / F1, intensity MAE, SSIM, LPIPS: SURVEY 2 #18) are outside
-    this package's scope; nvsf/nerf/meters_extra.py restates two of them for users who want them beside these."""
+    those of the averaged weights once EMA is on (its default).
+    Across ranks, `shard`:
+      "rays"   every frame's rays are split over the ranks and the renders all-gathered (frame_shard.render_sharded): every rank
+               computes the same statistics from the same full frames, no statistics collective is needed;
+      "frames" the reference's scheme (trainer.py:1495-1524): rank r evaluates frames r, r + W, ... on its own and the per-rank SUMS
+               of loss and metrics go through ONE all-reduce (frame_shard.allreduce_sums = the `dist.all_reduce(loss)` of
+               trainer.py:1508, widened to the metrics); no per-pixel data crosses xGMI.
+    Every rank returns the same numbers.  The reference's other meters (ray-drop accuracy / F1, intensity MAE, SSIM, LPIPS: SURVEY 2
+    #18) are outside this package's scope; nvsf/nerf/meters_extra.py restates two of them for users who want them beside these."""
+    from nvsf import frame_shard
+    if shard not in ("rays", "frames"):
+        raise ValueError("shard: 'rays' or 'frames'")
+    rank, ws = frame_shard.world()
     was_training = model.training
     model.eval()
     if ema is not None:
@@ -538,8 +552,11 @@ def evaluate_frames(model, frames, num_steps, indices=None, ema=None, **eval_kwa
     try:
         points = PointsMeter(frames.scale, frames.intrinsics_lidar, frames.intrinsics_hoz_lidar)
         ps, rm, ls = [], [], []
-        for i in (range(len(frames)) if indices is None else indices):
-            e = eval_step(model, frames.collate([int(i)]), num_steps, **eval_kwargs)
+        todo = list(range(len(frames)) if indices is None else indices)
+        if shard == "frames" and ws > 1:
+            todo = todo[rank::ws]
+        for i in todo:
+            e = eval_step(model, frames.collate([int(i)]), num_steps, split_rays=(shard == "rays"), **eval_kwargs)
             ps.append(psnr(e["pred_rgb"], e["gt_rgb"]))
             rm.append(depth_rmse(e["pred_depth"], e["gt_depth"], frames.scale))
             points.update(e["pred_depth"], e["gt_depth"])
@@ -548,6 +565,10 @@ def evaluate_frames(model, frames, num_steps, indices=None, ema=None, **eval_kwa
         if ema is not None:
             ema.restore()
         model.train(was_training)
-    cd, fs = points.measure()
-    return {"loss": float(np.mean(ls)), "psnr": float(np.mean(ps)), "depth_rmse_m": float(np.mean(rm)), "chamfer_distance": float(cd),
-            "f_score": float(fs), "frames": len(ps)}
+    cdf = np.array(points.V, dtype=np.float64).reshape(-1, 2).sum(0)
+    sums = [float(np.sum(ls)), float(np.sum(ps)), float(np.sum(rm)), float(cdf[0]), float(cdf[1]), float(len(ps))]
+    if shard == "frames":
+        sums = frame_shard.allreduce_sums(sums, device=next(model.parameters()).device)
+    n = max(sums[5], 1.0)
+    return {"loss": sums[0] / n, "psnr": sums[1] / n, "depth_rmse_m": sums[2] / n, "chamfer_distance": sums[3] / n, "f_score": sums[4] / n,
+            "frames": int(sums[5])}

@@ -145,6 +145,17 @@ def hashgrid_fwd(x, cols, table_f16, spec):
     return out
 
 
+def hashgrid_fwd_tcnn(x, cols, table_f16, spec):
+    """tiny-cuda-nn's published accumulation (fp16 weight, one fp16-rounded fma per corner) instead of the specification's."""
+    xx = _f32(x)
+    M, xs = xx.shape
+    out = np.empty((M, spec.L * spec.F), np.float16)
+    _lib("field").oracle_hashgrid_fwd_tcnn(_p(xx), U(M), U(xs), _p(np.asarray(cols, np.uint32)), U(spec.D), _p(np.ascontiguousarray(table_f16)),
+                                           U(spec.L), U(spec.F), _p(_f32(spec.scales)), _p(np.asarray(spec.res, np.uint32)),
+                                           _p(np.asarray(spec.offsets, np.uint32)), _p(out), U(out.shape[1]))
+    return out
+
+
 def hashgrid_bwd(x, cols, spec, grad_out):
     xx, go = _f32(x), _f32(grad_out)
     M, xs = xx.shape
@@ -300,14 +311,24 @@ def sigmoid_f32(h):
 
 
 def render_static(rays_o, rays_d, nears, fars, lin, noise, bound, table_f16, spec, w_sigma, lidar, w_head_a, w_head_b, bg,
-                  k_scale=1.0, w_thresh=1e-4):
-    """Returns dict(z_vals, sigmas, geo (fp16 [N,T,15]), weights, weights_sum, depth, image)."""
+                  k_scale=1.0, w_thresh=1e-4, tcnn_arith=False):
+    """Returns dict(z_vals, sigmas, geo (fp16 [N,T,15]), weights, weights_sum, depth, image).
+    tcnn_arith: the two places where the specification departs from tiny-cuda-nn's published arithmetic are
+    switched to tiny-cuda-nn's: hash-grid corners accumulated in fp16 (hashgrid_fwd_tcnn) and every network output rounded to fp16
+    (FullyFusedMLP returns __half) before trunc_exp / sigmoid / the heads read it -- with what follows in the reference's own graph:
+    trunc_exp casts the half logit to fp32 (activation.py:9, under the Trainer's autocast), torch.sigmoid returns a half
+    (network_dynamic.py:323-326).  NOT restated: FullyFusedMLP's half-precision WMMA accumulator fragments (hardware-defined)."""
     aabb = np.array([-bound] * 3 + [bound] * 3, np.float32)
     z, xyz = uniform_samples(rays_o, rays_d, nears, fars, lin, noise, aabb)
     N, T = z.shape
     x01 = ((xyz.reshape(-1, 3) + np.float32(bound)) * np.float32(1.0 / (2.0 * bound))).astype(np.float32)
-    feat = hashgrid_fwd(x01, (0, 1, 2), table_f16, spec)
+    feat = (hashgrid_fwd_tcnn if tcnn_arith else hashgrid_fwd)(x01, (0, 1, 2), table_f16, spec)
     h = mlp_fwd(feat, w_sigma, 32, 32, 1)
+    if tcnn_arith:
+        _net_out = lambda a: a.astype(np.float16).astype(np.float32)
+        h = _net_out(h)
+    else:
+        _net_out = lambda a: a
     sigmas = np.exp(h[:, 0]).astype(np.float32).reshape(N, T)
     geo = h[:, 1:16].astype(np.float16)  # geometry features enter the heads as fp16 operands
     w, ws, dp = composite_uniform_weights(sigmas, z, nears, fars, k_scale)
@@ -325,7 +346,8 @@ def render_static(rays_o, rays_d, nears, fars, lin, noise, bound, table_f16, spe
             hh = np.concatenate([ra, it], axis=1)
         else:
             hh = mlp_fwd(logits, w_head_a, 31, 32, 2)[:, :3]
-        rgbs[mask] = sigmoid_f32(hh)
+        # the reference applies torch.sigmoid to the network's __half output (network_dynamic.py:323-326): a half result
+        rgbs[mask] = _net_out(sigmoid_f32(_net_out(hh)))
     img = composite_uniform_image(w, rgbs.reshape(N, T, C), ws, None if lidar else bg)
     return dict(z_vals=z, sigmas=sigmas, geo=geo.reshape(N, T, 15), weights=w, weights_sum=ws, depth=dp, image=img,
                 rgbs=rgbs.reshape(N, T, C))

@@ -84,6 +84,8 @@ def test_eval_step_and_evaluate_frames(tmp_path):
     for k in ("pred_rgb", "pred_depth", "pred_raydrop", "pred_intensity"):
         assert torch.equal(e[k], whole[k]), k
     res = evaluate_frames(m, fe, 48, raydrop_thres=thres)
+    res_frames = evaluate_frames(m, fe, 48, raydrop_thres=thres, shard="frames")  # the reference's per-rank-frames + all-reduced sums scheme
+    assert res_frames.keys() == res.keys() and all(res_frames[k] == pytest.approx(res[k], rel=1e-6, nan_ok=True) for k in res)
     assert res["frames"] == 2 and all(np.isfinite(v) for v in res.values())
     assert set(res) == {"loss", "psnr", "depth_rmse_m", "chamfer_distance", "f_score", "frames"}
     pm = PointsMeter(scale, fe.intrinsics_lidar, fe.intrinsics_hoz_lidar)

@@ -84,6 +84,9 @@ def _worker(rank, world_size, port, q):
         out = FS.render_sharded(Stub(), o, d, torch.tensor([[0.5]]), cal_lidar_color=True)
         ok_rays = ok_rays and Stub.calls == [e - b] and torch.equal(out["depth_lidar"], o[..., 0] + d[..., 1]) \
             and torch.equal(out["image_lidar"], torch.stack([o[..., 0], d[..., 2]], -1) * 0.5)
+        # --- evaluation statistics: per-rank sums through ONE all-reduce (the reference's dist.all_reduce(loss), trainer.py:1508)
+        sums = FS.allreduce_sums([1.5 * (rank + 1), 10.0 + rank, 3.0])
+        ok_rays = ok_rays and sums == [4.5, 21.0, 6.0]
         # --- frames
         mine = FS.frames_for_rank(61, epoch=3, rank=rank, world_size=world_size, seed=5)
         objs = [None] * world_size
@@ -128,3 +131,4 @@ def test_single_process_paths_are_no_ops():
     assert FS.frames_for_rank(9, 1, 0, 2, drop_last=True) + FS.frames_for_rank(9, 1, 1, 2, drop_last=True) != []
     x = torch.randn(5, 2)
     assert FS.gather_ray_outputs(x, 5) is x
+    assert FS.allreduce_sums([1.25, 2]) == [1.25, 2.0]
