@@ -34,9 +34,11 @@ enum NvsfVariantKey : int {
     kVarSlicePlan,      // 0 balanced slices, 1 every group its own slice
     kVarRenderTail,     // 0 two tiles per iteration, 1 one tile
     kVarMarchSkew,      // one-launch marcher: 0 off, q + 1 = the workgroups of ticket queue q start late (the other queues steal from it)
+    kVarMlpBwd,         // nvsf_mlp_bwd: 0 by shape (wave-independent kernel, transposes on the matrix core; LDS-staged kernel for 32-64-16), 1 staged, 2 wave
     kVarCount
 };
 int nvsf_variant(int key);
+int nvsf_cu_count();  // compute units of the current device (256 on MI355X)
 
 // ---- wave-level primitives (64 lanes) -------------------------------------------------
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }

@@ -343,6 +343,314 @@ __global__ __launch_bounds__(kBlock) void k_mlp_bwd(const void* __restrict__ x, 
 #pragma unroll
     for (int r = 0; r < 4; ++r) atomicAdd(gwo + (size_t)(4 * g + r) * kHidden + 16 * w + c, dwo[r] * inv_scale);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Wave-independent form (production): no LDS staging, no barrier inside the loop.
+//
+// The staged form above transposes every dW operand through LDS with 2-byte scatter writes and pays six barriers per 64 samples;
+// its counters show neither the MFMA pipe (11-15 %) nor HBM as the bound, but LDS (weight fragments re-read per 16-sample tile,
+// the transposing writes).  Here a WAVE owns two 16-sample tiles per iteration and everything it needs:
+//   * transposition on the matrix core: the data path keeps "sample on the lane, units in registers" (mlp_device.h); the weight
+//     gradient dW[o][k] = sum_s dP[s][o] A[s][k] has the SAMPLE as the MFMA K dimension and needs "unit on the lane, samples in
+//     registers".  Swapping the A and B operands of an MFMA transposes its result, so a 16 x 16 block of any fp16 fragment V is
+//     transposed by ONE mfma(A = V, B = selection matrix of 0 / 1): exact (products by 1, sums with 0), 16 cycles, no LDS.  The two
+//     tiles give the two halves of a K = 32 operand: k-block g, element j <-> sample 4g + (j & 3) of tile (j >> 2); both operands
+//     of a dW product use that same mapping, so the sum over k is the sum over the 32 samples.
+//   * every weight fragment read from LDS feeds two tiles (as k_render_tail2 does): half the LDS reads per sample of the staged form.
+//   * the whole dW of the network is accumulated by each wave (all output-tile rows: up to 52 accumulator tiles = 208 registers),
+//     in ACCUMULATION registers (AGPRs, inline-asm MFMA: the library is built with -amdgpu-mfma-vgpr-form, which would put them in
+//     the 256 architected registers), one wave per SIMD (amdgpu_waves_per_eu 1): 512 registers per lane.
+//   * after the loop the four waves' accumulators are summed in LDS and leave with ONE float atomic per weight and workgroup
+//     (256 workgroups: 2.9 M atomics for the LiDAR head, as contiguous 1-KB instructions).
+// MFMA count per 16-sample tile of the 87-64-64-1 head: 20 recompute + 16 data path + 23 transposes + 22 dW = 81 (58 staged).
+__device__ __forceinline__ void mfma16_agpr(float4_t& acc, half8_t a, half8_t b) {
+    // s_nop 1: a VALU write of an MFMA source operand needs two wait states before the MFMA reads it (gfx90a+: the compiler inserts
+    // them for its own MFMAs -- GCNHazardRecognizer, "legacy VALU writes VGPR" -- and cannot see into this statement; without them the
+    // v_cvt_pk that packs a transposed operand right in front of the MFMA is read half-written: measured, wrong sums)
+    asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+
+template <int IN_STEPS, int N_HIDDEN, bool X_F16, bool FAST>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_mlp_bwd_wave(
+    const void* __restrict__ x, uint32_t M, uint32_t n_in, uint32_t x_stride, const _Float16* __restrict__ weights, uint32_t in_cols,
+    const float* __restrict__ grad_out, uint32_t n_out, uint32_t go_stride, float grad_scale, float* __restrict__ grad_x, uint32_t gx_stride,
+    float* __restrict__ grad_w, int vec_ok, uint32_t gx_col0, int gx_accumulate, int go_vec, XPrefix pre) {
+    using FR = BwdFrags<IN_STEPS, N_HIDDEN>;
+    constexpr int IN_TILES = FR::IN_TILES;
+    constexpr int kDwMax = kHidden * 32 * IN_STEPS + (N_HIDDEN == 2 ? kHidden * kHidden : 0) + 16 * kHidden;
+    __shared__ half8_t s_frag[FR::kCount * kWave];
+    __shared__ float s_dw[kDwMax];
+    const int lane = lane_id(), g = lane >> 4, c = lane & 15, w = (int)(threadIdx.x >> 6);
+    for (int f = w; f < FR::kCount; f += kWavesPerBlock) s_frag[f * kWave + lane] = bwd_fragment<IN_STEPS, N_HIDDEN>(f, lane, weights, (int)in_cols);
+    __syncthreads();
+    const half8_t* frag = s_frag + lane;
+    const float inv_scale = 1.0f / grad_scale;
+
+    // selection matrices (B operands): P[h] picks accumulator tile 2s + h out of a kappa-ordered k-step, Q[h] the 16 columns 16h .. 16h + 15
+    // out of a naturally ordered one
+    half8_t P[2], Q[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            P[h][j] = ((j >> 2) == h && c == 4 * g + (j & 3)) ? (_Float16)1.0f : (_Float16)0.0f;
+            Q[h][j] = ((g >> 1) == h && c == 8 * (g & 1) + j) ? (_Float16)1.0f : (_Float16)0.0f;
+        }
+    // 16 x 16 block of fragment v, transposed: lane (unit c, g) gets the samples 4g .. 4g + 3
+    auto tr = [&](half8_t v, half8_t sel) { return mfma16(v, sel, float4_t{0, 0, 0, 0}); };
+
+    float4_t dw0[kHidTiles][IN_TILES], dw1[kHidTiles][kHidTiles], dwo[kHidTiles];
+#pragma unroll
+    for (int to = 0; to < kHidTiles; ++to) {
+#pragma unroll
+        for (int i = 0; i < IN_TILES; ++i) dw0[to][i] = float4_t{0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < kHidTiles; ++i) dw1[to][i] = float4_t{0, 0, 0, 0};
+        dwo[to] = float4_t{0, 0, 0, 0};
+    }
+
+    const uint32_t n_tiles = (M + 15) / 16;
+    const uint32_t n_pairs = (n_tiles + 1) / 2;
+    const uint32_t pairs_per_iter = gridDim.x * kWavesPerBlock;
+    const uint32_t n_iters = (n_pairs + pairs_per_iter - 1) / pairs_per_iter;
+
+    XTail tail;
+    if constexpr (FAST) tail.init(32 * (IN_STEPS - 1) + 8 * g, (int)n_in, (int)in_cols);
+    struct Operands {
+        half8_t xf[IN_STEPS];
+        float go[8];
+        uint32_t m;
+        bool valid;
+    };
+    auto fetch = [&](uint32_t it, int u, Operands& op) {
+        const uint32_t tile = 2u * ((it * gridDim.x + blockIdx.x) * kWavesPerBlock + (uint32_t)w) + (uint32_t)u;
+        op.m = tile * 16 + (uint32_t)c;
+        op.valid = tile < n_tiles && op.m < M;
+        const size_t row = op.valid ? op.m : (M - 1);
+        const uint32_t tile_u = __builtin_amdgcn_readfirstlane(tile);
+        const _Float16* prow = pre.a ? pre.row_of((tile_u < n_tiles && tile_u * 16u < M) ? tile_u * 16u : M - 1u) : nullptr;
+        issue_x_row<IN_STEPS, X_F16, FAST>(op.xf, x, row, x_stride, g, (int)n_in, (int)in_cols, vec_ok != 0, tail, prow, pre.split);
+        const float* go_row = grad_out + row * go_stride;
+        if (go_vec) {
+            const float4* p = reinterpret_cast<const float4*>(go_row) + 2 * (g & 1);
+            const float4 a = p[0], b = p[1];
+            op.go[0] = a.x; op.go[1] = a.y; op.go[2] = a.z; op.go[3] = a.w;
+            op.go[4] = b.x; op.go[5] = b.y; op.go[6] = b.z; op.go[7] = b.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t o = 8 * (g & 1) + j;
+                op.go[j] = go_row[o < n_out ? o : n_out - 1];
+            }
+        }
+    };
+    constexpr bool kPrefetch = FAST && X_F16;  // the next pair's operands are requested before this pair is worked on
+    Operands next[2];
+    if (kPrefetch && n_iters) { fetch(0, 0, next[0]); fetch(0, 1, next[1]); }
+
+    for (uint32_t it = 0; it < n_iters; ++it) {
+        if (!kPrefetch) { fetch(it, 0, next[0]); fetch(it, 1, next[1]); }
+        half8_t xf[2][IN_STEPS];
+        float gor[2][8];
+        uint32_t m[2];
+        bool valid[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int s = 0; s < IN_STEPS; ++s) xf[u][s] = next[u].xf[s];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gor[u][j] = next[u].go[j];
+            m[u] = next[u].m;
+            valid[u] = next[u].valid;
+            if constexpr (FAST) xf[u][IN_STEPS - 1] = tail.apply(xf[u][IN_STEPS - 1]);
+        }
+        if (kPrefetch && it + 1 < n_iters) { fetch(it + 1, 0, next[0]); fetch(it + 1, 1, next[1]); }
+        // ---- forward recompute (sample on the lane)
+        half8_t h0[2][kHidSteps], h1[2][kHidSteps];
+        {
+            float4_t acc[2][kHidTiles];
+#pragma unroll
+            for (int t = 0; t < kHidTiles; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    float4_t a = {0, 0, 0, 0};
+#pragma unroll
+                    for (int s = 0; s < IN_STEPS; ++s) a = mfma16(frag[(FR::kF0 + t * IN_STEPS + s) * kWave], xf[u][s], a);
+                    acc[u][t] = a;
+                }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) pack_hidden(acc[u], h0[u]);
+            if constexpr (N_HIDDEN == 2) {
+#pragma unroll
+                for (int t = 0; t < kHidTiles; ++t)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        float4_t a = {0, 0, 0, 0};
+#pragma unroll
+                        for (int s = 0; s < kHidSteps; ++s) a = mfma16(frag[(FR::kF1 + 2 * t + s) * kWave], h0[u][s], a);
+                        acc[u][t] = a;
+                    }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) pack_hidden(acc[u], h1[u]);
+            }
+        }
+        const half8_t(&h_last)[2][kHidSteps] = N_HIDDEN == 2 ? h1 : h0;
+        // ---- output gradient -> B fragment (natural order of the 16 outputs, zero beyond n_out, scaled)
+        half8_t go[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) go[u][j] = (valid[u] && g < 2 && 8u * g + j < n_out) ? (_Float16)(gor[u][j] * grad_scale) : (_Float16)0.0f;
+        // ---- output layer: data path, then its weight gradient  dW_out[o][k] = sum_s dOut[s][o] h_last[s][k]
+        half8_t gp_last[2][kHidSteps], gp0[2][kHidSteps];
+        {
+            float4_t gacc[2][kHidTiles];
+#pragma unroll
+            for (int t = 0; t < kHidTiles; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) gacc[u][t] = mfma16(frag[(FR::kBO + t) * kWave], go[u], float4_t{0, 0, 0, 0});
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                relu_mask(gacc[u], h_last[u]);
+#pragma unroll
+                for (int s = 0; s < kHidSteps; ++s) gp_last[u][s] = plain_pack(gacc[u][2 * s], gacc[u][2 * s + 1]);
+            }
+        }
+        {
+            const half8_t go_n = plain_pack(tr(go[0], Q[0]), tr(go[1], Q[0]));
+#pragma unroll
+            for (int tk = 0; tk < kHidTiles; ++tk)
+                mfma16_agpr(dwo[tk], go_n, plain_pack(tr(h_last[0][tk >> 1], P[tk & 1]), tr(h_last[1][tk >> 1], P[tk & 1])));
+        }
+        // ---- hidden layer: dP0 and  dW1[o][k] = sum_s dP1[s][o] h0[s][k]
+        if constexpr (N_HIDDEN == 2) {
+            float4_t gacc[2][kHidTiles];
+#pragma unroll
+            for (int t = 0; t < kHidTiles; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    float4_t a = {0, 0, 0, 0};
+#pragma unroll
+                    for (int s = 0; s < kHidSteps; ++s) a = mfma16(frag[(FR::kB1 + 2 * t + s) * kWave], gp_last[u][s], a);
+                    gacc[u][t] = a;
+                }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                relu_mask(gacc[u], h0[u]);
+#pragma unroll
+                for (int s = 0; s < kHidSteps; ++s) gp0[u][s] = plain_pack(gacc[u][2 * s], gacc[u][2 * s + 1]);
+            }
+            half8_t h0n[kHidTiles];
+#pragma unroll
+            for (int tk = 0; tk < kHidTiles; ++tk) h0n[tk] = plain_pack(tr(h0[0][tk >> 1], P[tk & 1]), tr(h0[1][tk >> 1], P[tk & 1]));
+#pragma unroll
+            for (int to = 0; to < kHidTiles; ++to) {
+                const half8_t gn = plain_pack(tr(gp_last[0][to >> 1], P[to & 1]), tr(gp_last[1][to >> 1], P[to & 1]));
+#pragma unroll
+                for (int tk = 0; tk < kHidTiles; ++tk) mfma16_agpr(dw1[to][tk], gn, h0n[tk]);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int s = 0; s < kHidSteps; ++s) gp0[u][s] = gp_last[u][s];
+        }
+        // ---- input gradient
+        if (grad_x) {
+#pragma unroll
+            for (int ti = 0; ti < IN_TILES; ++ti) {
+                if (16u * ti < n_in && 16u * ti + 16u > gx_col0) {  // input tiles without a requested column are skipped
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        float4_t a = {0, 0, 0, 0};
+#pragma unroll
+                        for (int s = 0; s < kHidSteps; ++s) a = mfma16(frag[(FR::kB0 + 2 * ti + s) * kWave], gp0[u][s], a);
+                        const uint32_t k0 = 16 * ti + 4 * g;
+                        float* row_x = grad_x + (size_t)m[u] * gx_stride;
+                        if constexpr (FAST) {
+                            const uint32_t blk = ((uint32_t)gx_accumulate >> 8) & 0xFFu;  // 0: rows; 2 / 4: column blocks
+                            if (blk == 0u) {
+                                if (valid[u] && k0 >= gx_col0 && k0 < n_in) {
+                                    float4_t* p = reinterpret_cast<float4_t*>(row_x + (k0 - gx_col0));
+                                    float4_t v = a * inv_scale;
+                                    if (gx_accumulate & 1) v += *p;
+                                    *p = v;
+                                }
+                            } else if (valid[u] && k0 < n_in) {
+                                float4_t v = a * inv_scale;
+                                if (blk == 4u) {
+                                    float4_t* p = reinterpret_cast<float4_t*>(grad_x + ((size_t)(k0 >> 2) * M + m[u]) * 4);
+                                    if (gx_accumulate & 1) v += *p;
+                                    *p = v;
+                                } else {
+                                    float2* p0 = reinterpret_cast<float2*>(grad_x + ((size_t)(k0 >> 1) * M + m[u]) * 2);
+                                    float2* p1 = reinterpret_cast<float2*>(grad_x + ((size_t)((k0 >> 1) + 1u) * M + m[u]) * 2);
+                                    float2 v0 = make_float2(v[0], v[1]), v1 = make_float2(v[2], v[3]);
+                                    if (gx_accumulate & 1) { v0.x += p0->x; v0.y += p0->y; v1.x += p1->x; v1.y += p1->y; }
+                                    *p0 = v0;
+                                    *p1 = v1;
+                                }
+                            }
+                        } else if (valid[u]) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const uint32_t k = k0 + r;
+                                if (k < n_in && k >= gx_col0) {
+                                    const float v = a[r] * inv_scale;
+                                    row_x[k - gx_col0] = (gx_accumulate & 1) ? row_x[k - gx_col0] + v : v;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // ---- first layer:  dW0[o][k] = sum_s dP0[s][o] x[s][k]
+        {
+            half8_t gn[kHidTiles];
+#pragma unroll
+            for (int to = 0; to < kHidTiles; ++to) gn[to] = plain_pack(tr(gp0[0][to >> 1], P[to & 1]), tr(gp0[1][to >> 1], P[to & 1]));
+#pragma unroll
+            for (int ti = 0; ti < IN_TILES; ++ti) {
+                const half8_t xn = plain_pack(tr(xf[0][ti >> 1], Q[ti & 1]), tr(xf[1][ti >> 1], Q[ti & 1]));
+#pragma unroll
+                for (int to = 0; to < kHidTiles; ++to) mfma16_agpr(dw0[to][ti], gn[to], xn);
+            }
+        }
+    }
+    // ---- flush: the four waves' sums are added up in LDS, then one atomic per weight and workgroup.
+    // accumulator element (row 4g + r, column c) of tile (to, tk)
+    const uint32_t off1 = (uint32_t)kHidden * in_cols, offo = off1 + (N_HIDDEN == 2 ? kHidden * kHidden : 0), n_w = offo + 16 * kHidden;
+    for (int ww = 0; ww < kWavesPerBlock; ++ww) {
+        if (w == ww) {
+            auto put = [&](uint32_t idx, float v) { s_dw[idx] = ww == 0 ? v : s_dw[idx] + v; };
+#pragma unroll
+            for (int to = 0; to < kHidTiles; ++to) {
+#pragma unroll
+                for (int ti = 0; ti < IN_TILES; ++ti) {
+                    const uint32_t k = 16 * ti + c;
+                    if (k < in_cols) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) put((uint32_t)(16 * to + 4 * g + r) * in_cols + k, dw0[to][ti][r]);
+                    }
+                }
+                if constexpr (N_HIDDEN == 2) {
+#pragma unroll
+                    for (int tk = 0; tk < kHidTiles; ++tk)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) put(off1 + (uint32_t)(16 * to + 4 * g + r) * kHidden + 16 * tk + c, dw1[to][tk][r]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) put(offo + (uint32_t)(4 * g + r) * kHidden + 16 * to + c, dwo[to][r]);
+            }
+        }
+        __syncthreads();
+    }
+    for (uint32_t i = threadIdx.x; i < n_w; i += kBlock) {
+        const float v = s_dw[i] * inv_scale;
+        if (v != 0.0f) atomicAdd(grad_w + i, v);
+    }
+}
 }  // namespace
 
 #define REQUIRE(cond) do { if (!(cond)) return NVSF_ERR_INVALID_ARG; } while (0)
@@ -379,9 +687,28 @@ static int mlp_bwd_impl(const void* x, int x_is_f16, uint32_t M, uint32_t n_in, 
         REQUIRE(x_is_f16 && fast && pre.split % 8 == 0 && pre.split < n_in && pre.a_stride >= pre.split && pre.a_stride % 8 == 0);
         REQUIRE(pre.rows_per_a >= 16 && pre.rows_per_a % 16 == 0 && (reinterpret_cast<uintptr_t>(pre.a) & 15u) == 0);
     }
-#define LAUNCH(S, H, XF, FA)                                                                                                          \
-    hipLaunchKernelGGL((k_mlp_bwd<S, H, XF, FA>), dim3(blocks), dim3(kBlock), 0, stream, x, M, n_in, x_stride, w, in_cols, grad_out, \
-                       n_out, go_stride, grad_scale, grad_x, gx_stride, grad_weights_f32, vec_ok, gx_col0, gx_accumulate, go_vec, pre)
+    // production: the wave-independent kernel, one workgroup per compute unit; nvsf_test_variant("mlp_bwd", 1): the LDS-staged kernel
+    // The 32-wide one-hidden-layer network (the density MLP: 256 B of rows per sample for 18 432 FLOP = 72 FLOP/B, far below the ridge of
+    // 312) is bound by its row traffic, which one wave per SIMD cannot keep in flight (measured 0.30 ms against 0.19 ms at 3.1 M rows):
+    // that shape stays on the staged kernel (three workgroups per CU).  nvsf_test_variant("mlp_bwd", 1 / 2) forces staged / wave.
+    const int forced = nvsf_variant(kVarMlpBwd);
+    const bool staged = forced == 1 || (forced == 0 && in_steps == 1 && n_hidden == 1);
+    if (!staged) {
+        const uint32_t n_pairs = (n_tiles + 1) / 2, cus = (uint32_t)nvsf_cu_count();
+        blocks = (n_pairs + kWavesPerBlock - 1) / kWavesPerBlock;
+        if (blocks > cus) blocks = cus;
+    }
+#define LAUNCH(S, H, XF, FA)                                                                                                               \
+    do {                                                                                                                                   \
+        if (staged)                                                                                                                        \
+            hipLaunchKernelGGL((k_mlp_bwd<S, H, XF, FA>), dim3(blocks), dim3(kBlock), 0, stream, x, M, n_in, x_stride, w, in_cols,        \
+                               grad_out, n_out, go_stride, grad_scale, grad_x, gx_stride, grad_weights_f32, vec_ok, gx_col0,              \
+                               gx_accumulate, go_vec, pre);                                                                                \
+        else                                                                                                                               \
+            hipLaunchKernelGGL((k_mlp_bwd_wave<S, H, XF, FA>), dim3(blocks), dim3(kBlock), 0, stream, x, M, n_in, x_stride, w, in_cols,   \
+                               grad_out, n_out, go_stride, grad_scale, grad_x, gx_stride, grad_weights_f32, vec_ok, gx_col0,              \
+                               gx_accumulate, go_vec, pre);                                                                                \
+    } while (0)
 #define BY_F(S, H, XF) do { if (fast) LAUNCH(S, H, XF, true); else LAUNCH(S, H, XF, false); } while (0)
 #define BY_X(S, H) do { if (x_is_f16) BY_F(S, H, true); else BY_F(S, H, false); } while (0)
 #define BY_H(S) do { if (n_hidden == 1) BY_X(S, 1); else BY_X(S, 2); } while (0)

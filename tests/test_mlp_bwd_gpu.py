@@ -38,9 +38,14 @@ def _numpy_backward(x, mats, g_out, n_in):
     return g[:, :n_in], np.concatenate([w.reshape(-1) for w in reversed(grads)]), peak
 
 
-@pytest.mark.parametrize("n_in,n_out,n_hidden,M", [(32, 16, 1, 64), (31, 3, 2, 100), (87, 1, 2, 257), (120, 16, 1, 130), (16, 2, 2, 16)])
-def test_mlp_bwd_exact_integers(dev, n_in, n_out, n_hidden, M):
+@pytest.mark.parametrize("kernel", ["wave", "staged"])
+@pytest.mark.parametrize("n_in,n_out,n_hidden,M", [(32, 16, 1, 64), (31, 3, 2, 100), (87, 1, 2, 257), (120, 16, 1, 130), (16, 2, 2, 16), (87, 1, 2, 40001),
+                                                   (64, 16, 2, 33), (128, 4, 2, 1000)])
+def test_mlp_bwd_exact_integers(dev, n_in, n_out, n_hidden, M, kernel, variants):
+    """kernel: "wave" = the production form (a wave owns two 16-sample tiles, dW operands transposed on the matrix core, all of dW
+    in accumulation registers), "staged" = the LDS-staged kernel it replaced (kept as the test reference)."""
     from nvsf import field_ops as ops
+    variants.set(mlp_bwd=kernel)
     spec = ops.MlpSpec(n_in, n_out, 64, n_hidden)
     rng = np.random.default_rng(n_in + M)
     # sparse small integers keep every intermediate exactly representable in fp16 operands / fp32 accumulators
@@ -51,6 +56,8 @@ def test_mlp_bwd_exact_integers(dev, n_in, n_out, n_hidden, M):
         mats.append(W)
     x = rng.integers(-2, 3, size=(M, n_in)).astype(np.float32)
     g_out = rng.integers(-2, 3, size=(M, n_out)).astype(np.float32)
+    if M > 10000:  # several iterations per wave: keep the sums over the samples exactly representable
+        g_out[rng.random(M) < 0.97] = 0
     w16 = np.concatenate([m.reshape(-1) for m in mats]).astype(np.float16)
     gx_ref, gw_ref, peak = _numpy_backward(x.astype(np.float64), mats, g_out.astype(np.float64), n_in)
     assert peak <= 2048 and np.abs(gw_ref).max() < 2 ** 24 and np.abs(gx_ref).max() < 2 ** 24  # fp16 operands / fp32 sums stay exact
@@ -107,11 +114,13 @@ def test_mlp_bwd_accumulates_and_rejects(dev):
                   _hip.ptr(buf), 0, 0)
 
 
+@pytest.mark.parametrize("kernel", ["wave", "staged"])
 @pytest.mark.parametrize("n_enc,n_geo,n_out,M", [(72, 15, 1, 300), (16, 15, 3, 257)])
-def test_mlp_bwd_column_window_accumulate_and_aligned_rows(dev, n_enc, n_geo, n_out, M):
+def test_mlp_bwd_column_window_accumulate_and_aligned_rows(dev, n_enc, n_geo, n_out, M, kernel, variants):
     """The heads' form of the call: x = the first n_in columns of a wider 16-byte aligned fp16 buffer, only the gradient of
     the trailing n_geo columns requested, a second head accumulating into the same buffer.  Exact small-integer case."""
     from nvsf import field_ops as ops
+    variants.set(mlp_bwd=kernel)
     n_in = n_enc + n_geo
     spec = ops.MlpSpec(n_in, n_out, 64, 2)
     rng = np.random.default_rng(n_in)

@@ -26,6 +26,9 @@ if os.environ.get('MERGE') == '0':  # run sums off: atomics for every level belo
     _ops.merge_levels_from = lambda spec, fine, rows: fine
 if os.environ.get('BINS') == '0':   # no bins at all
     _ops._bin_from = lambda spec, M, rows: None
+if os.environ.get('MLP_BWD'):  # staged / wave: force one kernel of nvsf_mlp_bwd
+    from nvsf import testing as _testing
+    _cm = _testing.variant(mlp_bwd=os.environ['MLP_BWD']); _cm.__enter__()
 for _ in range(2): step.step(batch)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 K = int(os.environ.get("K", 5))
