@@ -85,7 +85,12 @@ def _bin_from(spec, M, rows_per_ray):
     if not (rows_per_ray and M >= (1 << 18) and M % rows_per_ray == 0) or _testing.get("table_scatter") == "atomic":
         return None
     fine = fine_levels_from(spec, rows_per_ray)
-    return None if fine >= spec.L else (merge_levels_from(spec, fine, rows_per_ray), fine)
+    # Every binned level goes in as RUN SUMS (fine_from = L): measured on the config-2 batches (4096 rays x 768, jittered) the plan
+    # (8, 16) takes 1.33 / 1.54 ms (LiDAR / camera) against 1.65 / 1.63 ms for per-row contributions from level 11 on, and on the
+    # reference-default grid (0, 8) takes 2.03 / 2.26 ms against 2.62 / 2.52 ms -- a LiDAR step is 0.57 of a finest cell, so even the
+    # finest level merges rows there, and where no two rows share a cell the run form costs no more than the per-row form.
+    # `fine_levels_from` still decides WHETHER the grid has levels worth binning (hashed, equally sized, cells of a few steps at most).
+    return None if fine >= spec.L else (merge_levels_from(spec, fine, rows_per_ray), spec.L)
 
 
 _BIN_ROWS_MAX = 1 << 23
