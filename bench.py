@@ -339,7 +339,7 @@ def train_kernel_rows(step, batch, M, n_steps=3):
         return {"skipped": "the profiler returned no device events"}
 
     def mlp_flops(name):
-        m = re.search(r"k_mlp_(fwd|bwd)(?:<|ILi)(\d+)(?:, |ELi)(\d+)", name)
+        m = re.search(r"k_mlp_(fwd|bwd)(?:_wave)?(?:<|ILi)(\d+)(?:, |ELi)(\d+)", name)
         if not m:
             return None
         in_cols, n_hidden = 32 * int(m.group(2)), int(m.group(3))
@@ -354,7 +354,7 @@ def train_kernel_rows(step, batch, M, n_steps=3):
     ours, glue_launches, glue_us = [], 0, 0.0
     for name, (calls, us) in sorted(per.items(), key=lambda kv: -kv[1][1]):
         short = re.sub(r"^void |\(anonymous namespace\)::|_ZN12_GLOBAL__N_1\d+", "", name).split("(")[0][:72]
-        if "k_" not in name.split("(")[0]:
+        if not re.search(r"(?<![A-Za-z])\d*k_[a-z]", name) or name.startswith("void at::"):
             glue_launches += calls
             glue_us += us
             continue
@@ -385,8 +385,10 @@ def train_grads_match(model, batch, T, scale):
     jitter; max |difference| per parameter relative to that parameter's largest gradient entry."""
     from nvsf import testing
     from nvsf.nerf.train_step import RenderTrainStep
+    from nvsf.nerf.loss_scaler import LossScaler
+    from nvsf.nerf.loss_scaler import LossScaler
     step = RenderTrainStep(model, num_steps=T, scale=scale)
-    step.scaler = torch.amp.GradScaler("cuda", init_scale=128.0)
+    step.scaler = LossScaler(init_scale=128.0)
     out = {}
     for variant in ("binned", "atomic"):
         torch.manual_seed(17)

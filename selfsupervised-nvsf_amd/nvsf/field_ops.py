@@ -554,13 +554,21 @@ class LocalGradSink:
     add or read on the main stream while the side stream still writes (a table that receives more than one DensityFn.backward
     per pass -- RenderTrainStep(ray_chunks > 1) -- would otherwise be summed by the engine without any wait on the side stream)."""
 
+    def __init__(self):
+        self.side_scatters = []  # (parameter, event recorded on the side stream behind its LAST scatter of the step), in issue order
+
     def view_for(self, p):
         if p.grad is None:
             p.grad = torch.zeros_like(p, dtype=torch.float32)
         return p.grad
 
     def mark_ready(self, p):
-        pass
+        """Called on the stream that ran the last scatter of table `p` in this step, right behind it."""
+        stream = torch.cuda.current_stream(p.device)
+        if p.is_cuda and stream != torch.cuda.default_stream(p.device):
+            ev = torch.cuda.Event()
+            ev.record(stream)
+            self.side_scatters.append((p, ev))
 
 
 # Scatters a table still has to receive in the running step (counted at DensityFn.forward while counting is on): a sink may only

@@ -78,13 +78,17 @@ class FusedAdam(torch.optim.Optimizer):
         raise _hip.NvsfHipError("FusedAdam: more than 64 distinct update histories among the parameters")
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, params=None):
+        """`params`: restrict the update to these parameters (a set / list); the others are left for a later call of the same
+        step -- RenderTrainStep updates everything whose gradient is final, then, on the stream of the last table scatter, the table
+        that scatter writes.  The two calls of one step see the same `grad_scale` / `found_inf`; step counts stay per parameter."""
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
         grad_scale, found_inf = getattr(self, "grad_scale", None), getattr(self, "found_inf", None)
-        active = [p for g in self.param_groups for p in g["params"] if p.grad is not None]
+        only = None if params is None else set(params)
+        active = [p for g in self.param_groups for p in g["params"] if p.grad is not None and (only is None or p in only)]
         if not active:
             return loss
         first = active[0]
@@ -102,7 +106,7 @@ class FusedAdam(torch.optim.Optimizer):
             if group.get("weight_decay", 0) or group.get("amsgrad", False) or group.get("maximize", False):
                 raise _hip.NvsfHipError("FusedAdam: plain Adam only (no weight decay / amsgrad / maximize)")
             for p in group["params"]:
-                if p.grad is None:
+                if p.grad is None or (only is not None and p not in only):
                     continue
                 if p.dtype != torch.float32 or p.grad.dtype != torch.float32 or not p.is_contiguous():
                     raise _hip.NvsfHipError("FusedAdam: fp32 contiguous parameters and gradients")

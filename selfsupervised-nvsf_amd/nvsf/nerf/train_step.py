@@ -123,7 +123,10 @@ class RenderTrainStep:
         # loss scaling of the reference's mixed-precision run (trainer.py:119, 1332-1334: GradScaler(enabled=fp16) -> scale(loss)
         # .backward() -> step -> update; `-L` / `--fp16` in main_nvsf.py:17,43,159).  The encoders hand fp16 features to the
         # MLPs, so the gradients that travel back between them are fp16 tensors.
-        self.scaler = torch.amp.GradScaler("cuda", enabled=bool(fp16) and torch.cuda.is_available())
+        # LossScaler = GradScaler's rule, state_dict and kernels; it lets the step decide about an overflow before the last table
+        # scatter has finished (nvsf/nerf/loss_scaler.py)
+        from nvsf.nerf.loss_scaler import LossScaler
+        self.scaler = LossScaler(enabled=bool(fp16) and torch.cuda.is_available())
         if fp16 and hasattr(model, "flow_net"):
             model.flow_net.flow_mlp_mode = "fused"  # the flow MLP as autocast runs it: fp16 MFMA kernels (flow_field.FlowMlpFn)
         # Adam as one HIP pass per parameter tensor with the scaler's overflow flag consumed on the device (nvsf/nerf/adam.py).
@@ -154,6 +157,15 @@ class RenderTrainStep:
         self.buckets = None
         if frame_shard.world()[1] > 1:
             self.buckets = frame_shard.GradBuckets([p for g in self.opt.param_groups for p in g["params"]], bucket_bytes)
+        # One process: the optimiser pass of the table whose scatter ran LAST is issued on that scatter's stream, behind it, and the
+        # main stream goes on with the next step (whose first pass -- the camera's -- does not read that table): `defer_last_table`.
+        self.defer_last_table = on_gpu and self.buckets is None
+        self._sink = None
+        self._pending = None  # (event behind the deferred optimiser pass, its parameters)
+        self._cache_of = {}   # parameter -> the fp16 cache of the module that owns it (tinycudann.Encoding / Network)
+        for mod in model.modules():
+            if hasattr(mod, "_cache") and isinstance(getattr(mod, "params", None), torch.nn.Parameter):
+                self._cache_of[mod.params] = mod._cache
 
     def _render(self, rays_o, rays_d, time, **kw):
         """model.render on `ray_chunks` slices of the batch, results concatenated.  Each slice is its own autograd sub-graph, and
@@ -258,7 +270,9 @@ class RenderTrainStep:
             from nvsf import field_ops
             field_ops.SCATTER_OVERLAP = True
             if field_ops.GRAD_SINK is None:  # one process: the side-stream scatters accumulate straight into p.grad
-                field_ops.GRAD_SINK, local_sink = field_ops.LocalGradSink(), True
+                if self._sink is None:
+                    self._sink = field_ops.LocalGradSink()
+                field_ops.GRAD_SINK, local_sink = self._sink, True
         try:
             self.scaler.scale(loss).backward()
         finally:
@@ -268,30 +282,86 @@ class RenderTrainStep:
                     field_ops.GRAD_SINK = None
         return overlap
 
+    def sync(self):
+        """The calling stream waits for the optimiser pass `step` left on the scatter stream (the last table's).  Readers inside this
+        package that go through the encoders' fp16 copies wait by themselves (tinycudann._HalfCache.pending); call this before
+        touching the fp32 parameters or the optimiser state directly (end_epoch / checkpoint_state / load_checkpoint do)."""
+        if self._pending is not None:
+            ev, params = self._pending
+            torch.cuda.current_stream().wait_event(ev)
+            for p in params:
+                cache = self._cache_of.get(p)
+                if cache is not None and cache.pending is ev:
+                    cache.pending = None
+            self._pending = None
+
     def step(self, batch):
-        out = self.forward_backward(batch)
+        defer = self.defer_last_table and self.scatter_overlap
+        loss, parts, n_coll, late = self._run(batch, defer)
         if getattr(self.model, "cuda_ray", False):
             from nvsf.nerf.raymarching import raymarching
             if raymarching.march_status_pending():  # occupancy-grid training without a counter read-back: the marcher's failure flag
                 raymarching.check_march_status(wait=True)  # is looked at before the optimiser, not one call later
-        self.scaler.step(self.opt)
-        self.scaler.update()
+        if not late:
+            found = self.scaler.step(self.opt)
+        else:
+            # every gradient but the late tables' is final on this stream: overflow decision from those (sufficient: loss_scaler.py),
+            # their update here, the late tables' update behind their scatter on the side stream
+            from nvsf import field_ops
+            late_set = {p for p, _ in late}
+            early = [p for g in self.opt.param_groups for p in g["params"] if p.grad is not None and p not in late_set]
+            if self.scaler.is_enabled():
+                found = self.scaler.found_inf([p.grad for p in early])
+                scale = self.scaler.scale_tensor()
+                self.opt.grad_scale, self.opt.found_inf = scale, found
+            else:
+                found = None
+            try:
+                self.opt.step(params=early)
+                main = torch.cuda.current_stream()
+                side = field_ops.side_stream(late[0][0].device)
+                side.wait_stream(main)  # found / scale exist; (the scatters themselves are already in front of us on `side`)
+                with torch.cuda.stream(side):
+                    for p in late_set:
+                        p.grad.record_stream(side)  # zero_grad of the next step drops the tensor while this pass may still read it
+                    if found is not None:
+                        found.record_stream(side)
+                        scale.record_stream(side)
+                    self.opt.step(params=list(late_set))
+                    ev = torch.cuda.Event()
+                    ev.record(side)
+            finally:
+                if found is not None:
+                    del self.opt.grad_scale, self.opt.found_inf
+            self._pending = (ev, list(late_set))
+            for p in late_set:
+                cache = self._cache_of.get(p)
+                if cache is not None:
+                    cache.pending = ev
+        if found is not None:
+            self.scaler.update(found)
         self.sched.step()
         self.global_step += 1
-        return out
+        return loss, parts, n_coll
 
     def forward_backward(self, batch):
         """Everything of a step up to (not including) the optimiser: both renders, the losses, backward through the HIP operators,
         the gradient all-reduce when there is more than one rank; on return every parameter's `.grad` (still multiplied by the
-        GradScaler's scale) is final on the current stream.  -> (loss, parts, number of collectives).  `step` = this + Adam."""
+        loss scale) is final on the current stream.  -> (loss, parts, number of collectives).  `step` = this + Adam (with the
+        wait for the last table scatter moved behind the optimiser pass of everything else)."""
+        return self._run(batch, False)[:3]
+
+    def _run(self, batch, defer):
         from nvsf import field_ops
         field_ops.begin_scatter_count()  # a table is final after the LAST scatter it receives in this step (ray_chunks > 1: several)
+        self._sink = None
         try:
-            return self._forward_backward(batch)
+            return self._forward_backward(batch, defer)
         finally:
             field_ops.end_scatter_count()
+            self._sink = None
 
-    def _forward_backward(self, batch):
+    def _forward_backward(self, batch, defer=False):
         self.model.train()
         if self.buckets is not None:
             self.buckets.begin_step()
@@ -308,7 +378,9 @@ class RenderTrainStep:
                 if self.buckets is not None:  # parameters both passes reach (the sigma MLP) are final only after the second
                     self.buckets.hold(first)
                 part_loss, part = self.losses(sub)
+                n_before = len(self._sink.side_scatters) if self._sink is not None else 0
                 overlap = self._backward(part_loss) or overlap
+                self._last_pass_tables = {p for p, _ in self._sink.side_scatters[n_before:]} if self._sink is not None else set()
                 loss = part_loss.detach() if loss is None else loss + part_loss.detach()
                 parts.update(part)
             if self.buckets is not None:
@@ -316,20 +388,34 @@ class RenderTrainStep:
         else:
             loss, parts = self.losses(batch)
             overlap = self._backward(loss)
+            self._last_pass_tables = set()  # one joint backward: nothing is left to overlap a deferred pass with -- all tables early
         # the all-reduce is linear: it runs on the scaled gradients (an inf / nan on one rank reaches every rank, so all of
         # them skip the step together); scaler.step unscales, checks and steps.  Buckets go out during backward (hooks); finish()
         # closes the rest, waits and averages.  The table scatters run on a side stream: their consumers wait here.
+        late = []
         if self.buckets is not None:
             n_coll = self.buckets.finish()
         else:
             n_coll = 0
             if overlap:
                 from nvsf import field_ops
-                field_ops.sync_side_streams()
-        return loss.detach(), {k: v.detach() for k, v in parts.items()}, n_coll
+                scatters = self._sink.side_scatters if self._sink is not None else []
+                if defer and scatters:
+                    # wait only for the tables scattered BEFORE the last backward pass (long finished); the last pass' tables stay late
+                    last_pass = self._last_pass_tables
+                    main = torch.cuda.current_stream()
+                    for p, ev in scatters:
+                        if p in last_pass:
+                            late.append((p, ev))
+                        else:
+                            main.wait_event(ev)
+                else:
+                    field_ops.sync_side_streams()
+        return loss.detach(), {k: v.detach() for k, v in parts.items()}, n_coll, late
 
     def end_epoch(self):
         """What the reference does after the step loop of an epoch (trainer.py:1420-1421): one EMA update."""
+        self.sync()
         if self.ema is not None:
             self.ema.update()
 
@@ -341,6 +427,7 @@ class RenderTrainStep:
         reference Trainer resumes from it (checkpoint_compat); the `ema` entry cannot be written for the reference -- torch_ema
         wants shadows for the three unused modules this model does not have -- and the reference then starts a fresh average,
         as it does for any checkpoint whose ema fails to load (utils.py:728-747).  load_checkpoint reads both layouts."""
+        self.sync()
         state = {"epoch": epoch, "global_step": self.global_step, "stats": stats if stats is not None else {}}
         if full:
             state["optimizer"] = self.opt.state_dict()
@@ -363,6 +450,7 @@ class RenderTrainStep:
         lr_scheduler / scaler / ema where present.  checkpoint: path or the loaded dict.  Returns (missing_keys, unexpected_keys,
         epoch); `self.failed_to_load` lists the components whose state could not be restored (each also raises a warning, as
         the reference logs "[WARN] Failed to load ..." and trains on, utils.py:728-747)."""
+        self.sync()
         if not isinstance(checkpoint, dict):
             checkpoint = torch.load(checkpoint, map_location=next(self.model.parameters()).device)
         if "model" not in checkpoint:

@@ -27,8 +27,12 @@ class _HalfCache:
 
     def __init__(self):
         self._key, self._half = None, None
+        self.pending = None  # event behind an optimiser update of the parameter that was issued on another stream (RenderTrainStep)
 
     def get(self, p):
+        if self.pending is not None:  # the reader's stream waits for that update before it looks at the parameter
+            torch.cuda.current_stream(p.device).wait_event(self.pending)
+            self.pending = None
         key = (p.data_ptr(), p._version, p.device)
         if key != self._key:
             self._half = p.detach().to(torch.float16).contiguous()

@@ -20,6 +20,11 @@ import oracle_lib as O
 
 pytestmark = pytest.mark.gpu
 
+
+def _LossScaler():
+    from nvsf.nerf.loss_scaler import LossScaler  # the step's loss scaler (GradScaler's rule and state_dict; nvsf/nerf/loss_scaler.py)
+    return LossScaler
+
 N_RAYS, T = 4096, 768
 
 
@@ -51,7 +56,7 @@ def _new_step(S, m):
     step = RenderTrainStep(m, num_steps=T, scale=S.SCALE)
     # GradScaler starts at 2^16 and halves on every overflowing step until the fp16 gradients fit; the comparison wants ONE step with
     # finite gradients, so it starts where the benchmark's scaler settles (2^7 = tcnn's default loss scale)
-    step.scaler = torch.amp.GradScaler("cuda", init_scale=128.0)
+    step.scaler = _LossScaler()(init_scale=128.0)
     return step
 
 

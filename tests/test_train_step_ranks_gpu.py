@@ -11,6 +11,11 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+
+def _LossScaler():
+    from nvsf.nerf.loss_scaler import LossScaler  # the step's loss scaler (GradScaler's rule and state_dict; nvsf/nerf/loss_scaler.py)
+    return LossScaler
+
 KW = dict(log2_hashmap_size=15)
 
 
@@ -42,7 +47,7 @@ def _grads_of_one_step(student, batch, S, T=64, **step_kw):
     from nvsf.nerf.train_step import RenderTrainStep
     m = student()
     step = RenderTrainStep(m, num_steps=T, scale=S.SCALE, ema_decay=None, **step_kw)
-    step.scaler = torch.amp.GradScaler("cuda", init_scale=64.0, growth_interval=10 ** 6)
+    step.scaler = _LossScaler()(init_scale=64.0, growth_interval=10 ** 6)
     torch.manual_seed(10)  # the jitter of perturb=True: drawn per render call, [N, T] at a time ...
     # ... so that slices of a batch see the jitter of the whole batch, the draws are replayed from one [N, T] table
     N = batch["rays_o"].shape[1]
