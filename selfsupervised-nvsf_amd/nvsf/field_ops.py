@@ -60,24 +60,34 @@ def hashgrid_forward(x, cols, table_f16, spec, out=None):
     return out
 
 
-RAY_ROWS = None  # samples per ray of the rows being encoded, while a renderer evaluates a field on ray-ordered rows (else None)
+class RowHint:
+    """`T`: samples per ray of the rows a renderer is handing to its field right now ([M, ...] rows = T consecutive samples per ray),
+    None otherwise.  One object per MODEL (NeRFRenderer creates it and gives the same object to every sub-module, renderer_dynamic.py):
+    the autograd nodes of the hash grids read it in `forward`, on the caller's thread, and choose the form of their table scatter by
+    it (_bin_from); values and gradients do not depend on it.  Not process-wide: two models in one process do not see each other's."""
+
+    def __init__(self):
+        self.T = None
+
+    def rows(self, T):
+        return _RowScope(self, T)
 
 
-class ray_ordered_rows:
-    """`with ray_ordered_rows(T):` -- the [M, ...] rows handed to the encoders inside are T consecutive samples per ray.  The
-    autograd nodes of the hash grids record it and choose the form of their table scatter with it (fine_levels_from); values and
-    gradients do not depend on it."""
-
-    def __init__(self, T):
-        self.T = int(T)
+class _RowScope:
+    def __init__(self, hint, T):
+        self.hint, self.T = hint, int(T)
 
     def __enter__(self):
-        global RAY_ROWS
-        self.prev, RAY_ROWS = RAY_ROWS, self.T
+        self.prev, self.hint.T = self.hint.T, self.T
 
     def __exit__(self, *exc):
-        global RAY_ROWS
-        RAY_ROWS = self.prev
+        self.hint.T = self.prev
+
+
+def rows_hint(module):
+    """The samples-per-ray hint of the model `module` belongs to (None outside a renderer's field evaluation)."""
+    hint = module.__dict__.get("_row_hint") if module is not None else None
+    return None if hint is None else hint.T
 
 
 def _bin_from(spec, M, rows_per_ray):
@@ -95,7 +105,6 @@ def _bin_from(spec, M, rows_per_ray):
 
 _BIN_ROWS_MAX = 1 << 23
 LEVEL_MAJOR_GRADIENT = True  # the density MLP hands dL/d(features) to the binned scatter level by level ([L, M, F])
-_BIN_WS = {}  # (device, stream) -> scratch of the binned scatter; one per stream: side-stream scatters of two tables may overlap
 
 
 def merge_levels_from(spec, fine_from, rows_per_ray):
@@ -130,7 +139,7 @@ def fine_levels_from(spec, rows_per_ray):
     return first
 
 
-def hashgrid_backward(x, cols, spec, grad_out, grad_table=None, fine_from=None, merge_from=None):
+def hashgrid_backward(x, cols, spec, grad_out, grad_table=None, fine_from=None, merge_from=None, ws_pool=None):
     """Scatter-adds d L / d table (fp32 [n_params]) from grad_out ([M, L*F], fp16 or fp32).  `fine_from` < L sends the levels from
     there on through the binned scatter, one contribution per (row, vertex); `merge_from` <= fine_from the levels in between as sums
     over runs of consecutive rows in one cell (nvsf_hashgrid_bwd_binned; fine_levels_from / merge_levels_from).  `fine_from` may be a
@@ -148,7 +157,7 @@ def hashgrid_backward(x, cols, spec, grad_out, grad_table=None, fine_from=None, 
         merge_from = fine_from if merge_from is None else min(merge_from, fine_from)
         if M > _BIN_ROWS_MAX and not level_major:  # the fixed-point image of the bins takes 2^26 addends per row: longer batches go in
             for i in range(0, M, _BIN_ROWS_MAX):    # pieces (sums accumulate)
-                hashgrid_backward(x[i:i + _BIN_ROWS_MAX], cols, spec, grad_out[i:i + _BIN_ROWS_MAX], grad_table, fine_from, merge_from)
+                hashgrid_backward(x[i:i + _BIN_ROWS_MAX], cols, spec, grad_out[i:i + _BIN_ROWS_MAX], grad_table, fine_from, merge_from, ws_pool)
             return grad_table
         # 0: the grid has no binned form: every level through the atomics (first without the run-sum levels: a level of more than
         # 2^20 rows cannot be binned)
@@ -157,10 +166,13 @@ def hashgrid_backward(x, cols, spec, grad_out, grad_table=None, fine_from=None, 
             merge_from = fine_from
             need = _hip.hashgrid_bwd_ws_bytes(M, spec, merge_from, fine_from)
     if need:
+        # scratch of the binned scatter, one per stream (scatters issued from two streams may overlap): the caller's pool (a training
+        # step shares one between its tables: TrainContext.ws_pool), else kept on the grid's spec (= per encoder)
+        pool = ws_pool if ws_pool is not None else spec.__dict__.setdefault("_bin_ws", {})
         key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
-        ws = _BIN_WS.get(key)
+        ws = pool.get(key)
         if ws is None or ws.numel() < need:
-            ws = _BIN_WS[key] = torch.empty(need, dtype=torch.uint8, device=x.device)
+            ws = pool[key] = torch.empty(need, dtype=torch.uint8, device=x.device)
         _hip.call("nvsf_hashgrid_bwd_binned", _hip.ptr(x), M, x.shape[1], _hip.host_u32(cols), spec.D, spec.L, spec.F, spec.h_scales,
                   spec.h_res, spec.h_offsets, _hip.ptr(grad_out), 1 if grad_out.dtype == torch.float16 else 0,
                   spec.F if level_major else grad_out.stride(0), M * spec.F if level_major else 0,
@@ -178,11 +190,11 @@ class HashGridFn(Function):
     """fp16 features = encode(x; table).  Gradient flows to the (fp32 master) table only."""
 
     @staticmethod
-    def forward(ctx, x, params, table_f16, spec, cols):
+    def forward(ctx, x, params, table_f16, spec, cols, rows_per_ray=None):
         x = x.float().contiguous()
         out = hashgrid_forward(x, cols, table_f16, spec)
         ctx.save_for_backward(x)
-        ctx.spec, ctx.cols, ctx.rows_per_ray = spec, cols, RAY_ROWS
+        ctx.spec, ctx.cols, ctx.rows_per_ray = spec, cols, rows_per_ray
         return out
 
     @staticmethod
@@ -190,7 +202,7 @@ class HashGridFn(Function):
         (x,) = ctx.saved_tensors
         fine = _bin_from(ctx.spec, x.shape[0], ctx.rows_per_ray)
         grad_params = hashgrid_backward(x, ctx.cols, ctx.spec, grad_out, fine_from=fine) if ctx.needs_input_grad[1] else None
-        return None, grad_params, None, None, None
+        return None, grad_params, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -540,11 +552,9 @@ def cast_cols_f16(src, dst):
 # with the vector and matrix pipes idle; the MLP backward kernels of the OTHER modality's branch are MFMA / LDS work.  DensityFn
 # therefore issues the scatter on a side stream: the main stream goes on with the next branch of backward and only the consumers
 # of the table gradient (gradient all-reduce, overflow check, optimiser) wait for it (`sync_side_streams`).
-# Only a caller that synchronises afterwards turns this on (`SCATTER_OVERLAP = True` around backward, then `sync_side_streams()`:
+# Only a caller that synchronises afterwards turns this on (`TrainContext.overlap` around backward, then `sync_side_streams()`:
 # nvsf.nerf.train_step.RenderTrainStep.step); everywhere else the scatter stays on the calling stream.
-_SIDE_STREAMS = {}
-SCATTER_OVERLAP = False
-GRAD_SINK = None  # where table gradients are scattered: frame_shard.GradBuckets of the running step (multi-rank) or a LocalGradSink
+_SIDE_STREAMS = {}  # (device) -> the stream table scatters are issued on beside backward (a device resource, shared by design)
 
 
 class LocalGradSink:
@@ -571,32 +581,41 @@ class LocalGradSink:
             self.side_scatters.append((p, ev))
 
 
-# Scatters a table still has to receive in the running step (counted at DensityFn.forward while counting is on): a sink may only
-# be told that a table's gradient is final -- and send its bucket to the all-reduce -- after the LAST of them.
-_SCATTERS_LEFT = None
+class TrainContext:
+    """What the table-scatter nodes (DensityFn / DensityRaysFn) need to know about the training step they run in -- owned by the step
+    object (RenderTrainStep.train_ctx), attached to its model (`model._train_ctx`), read by the nodes at `forward` and carried to
+    `backward` on the autograd ctx.  Nothing here is process-wide: two steps / two models in one process keep separate state.
+      sink     where table gradients are scattered: frame_shard.GradBuckets (multi-rank) or a LocalGradSink; None: the node returns
+               the gradient tensor to autograd
+      overlap  issue the scatters on the side stream beside the rest of backward; only a caller that waits for them afterwards
+               turns this on (RenderTrainStep, around backward)
+      left     scatters a table still has to receive in the running step (counted at forward): a sink may only be told that a
+               table's gradient is final -- and send its bucket to the all-reduce -- after the LAST of them."""
+
+    def __init__(self):
+        self.sink, self.overlap, self.left = None, False, None
+        self.ws_pool = {}  # (device, stream) -> scratch of the binned table scatters of this step's tables
+
+    def begin_step(self):
+        self.left = {}
+
+    def end_step(self):
+        self.left = None
+
+    def expect(self, p):
+        if self.left is not None and p is not None:
+            self.left[p] = self.left.get(p, 0) + 1
+
+    def done(self, p):
+        """True when this was the last outstanding scatter of table `p` in the step (always, outside a counted step)."""
+        if self.left is None or p not in self.left:
+            return True
+        self.left[p] -= 1
+        return self.left[p] <= 0
 
 
-def begin_scatter_count():
-    global _SCATTERS_LEFT
-    _SCATTERS_LEFT = {}
-
-
-def end_scatter_count():
-    global _SCATTERS_LEFT
-    _SCATTERS_LEFT = None
-
-
-def _scatter_expected(p):
-    if _SCATTERS_LEFT is not None and p is not None:
-        _SCATTERS_LEFT[p] = _SCATTERS_LEFT.get(p, 0) + 1
-
-
-def _scatter_done(p):
-    """True when this was the last outstanding scatter of table `p` in the step (always, outside a counted step)."""
-    if _SCATTERS_LEFT is None or p not in _SCATTERS_LEFT:
-        return True
-    _SCATTERS_LEFT[p] -= 1
-    return _SCATTERS_LEFT[p] <= 0
+def train_context(module):
+    return module.__dict__.get("_train_ctx") if module is not None else None
 
 
 def side_stream(device):
@@ -622,7 +641,7 @@ class DensityFn(Function):
     leaves nvsf_mlp_bwd (the operator chain rounds it to fp16 in between, a pass over [M, 32])."""
 
     @staticmethod
-    def forward(ctx, x01, table_params, table_f16, grid_spec, mlp_params, mlp_w16, mlp_spec, sigma_lo, sigma_hi):
+    def forward(ctx, x01, table_params, table_f16, grid_spec, mlp_params, mlp_w16, mlp_spec, sigma_lo, sigma_hi, rows_per_ray=None, train_ctx=None):
         x01 = x01.float().contiguous()
         feat = hashgrid_forward(x01, (0, 1, 2), table_f16, grid_spec)
         h = mlp_forward(feat, mlp_w16, mlp_spec)
@@ -631,15 +650,15 @@ class DensityFn(Function):
         ctx.save_for_backward(x01, feat, sigma, mlp_w16)
         ctx.grid_spec, ctx.mlp_spec, ctx.clamp = grid_spec, mlp_spec, (float(sigma_lo), float(sigma_hi))
         ctx.table_param = table_params
-        ctx.rows_per_ray = RAY_ROWS
+        ctx.rows_per_ray, ctx.train_ctx = rows_per_ray, train_ctx
         ctx.need_table, ctx.need_w = ctx.needs_input_grad[1], ctx.needs_input_grad[4]
-        if table_params is not None and table_params.requires_grad and torch.is_grad_enabled():
-            _scatter_expected(table_params)
+        if train_ctx is not None and table_params is not None and table_params.requires_grad and torch.is_grad_enabled():
+            train_ctx.expect(table_params)
         return sigma, h[:, 1:mlp_spec.n_out]
 
     @staticmethod
     def backward(ctx, g_sigma, g_geo):
-        return (None,) + _density_backward(ctx, g_sigma, g_geo)
+        return (None,) + _density_backward(ctx, g_sigma, g_geo) + (None, None)
 
 
 def _density_backward(ctx, g_sigma, g_geo):
@@ -664,22 +683,24 @@ def _density_backward(ctx, g_sigma, g_geo):
     grad_feat, grad_w = mlp_backward(feat, mlp_w16, spec, grad_h[:, :spec.n_out], need_grad_x=need_table, grad_x_blocks=blocks)
     grad_table = None
     if need_table:
-        last = _scatter_done(ctx.table_param)
-        sink = GRAD_SINK
-        if not (SCATTER_OVERLAP and x01.is_cuda):
+        tctx = getattr(ctx, "train_ctx", None)
+        last = tctx.done(ctx.table_param) if tctx is not None else True
+        sink = tctx.sink if tctx is not None else None
+        pool = tctx.ws_pool if tctx is not None else None
+        if not (tctx is not None and tctx.overlap and x01.is_cuda):
             view = sink.view_for(ctx.table_param) if sink is not None else None
             if view is not None:
-                hashgrid_backward(x01, (0, 1, 2), ctx.grid_spec, grad_feat, grad_table=view.view(-1), fine_from=fine)
+                hashgrid_backward(x01, (0, 1, 2), ctx.grid_spec, grad_feat, grad_table=view.view(-1), fine_from=fine, ws_pool=pool)
                 if last:
                     sink.mark_ready(ctx.table_param)
             else:
-                grad_table = hashgrid_backward(x01, (0, 1, 2), ctx.grid_spec, grad_feat, fine_from=fine)
+                grad_table = hashgrid_backward(x01, (0, 1, 2), ctx.grid_spec, grad_feat, fine_from=fine, ws_pool=pool)
         else:
             # Side stream.  The destination is ONE buffer per table and step, obtained (and, the first time, zero-filled) on the
             # main stream BEFORE the side stream is made to wait for it: a bucket view (multi-rank) or the parameter's .grad
             # (LocalGradSink).  The node returns no tensor for the table, so the autograd engine never touches the buffer.
             if sink is None:
-                raise _hip.NvsfHipError("SCATTER_OVERLAP needs a gradient sink (RenderTrainStep sets field_ops.GRAD_SINK)")
+                raise _hip.NvsfHipError("TrainContext.overlap needs a gradient sink (RenderTrainStep sets TrainContext.sink)")
             view = sink.view_for(ctx.table_param)
             if view is None:
                 raise _hip.NvsfHipError("the gradient sink has no buffer for this table")
@@ -688,7 +709,7 @@ def _density_backward(ctx, g_sigma, g_geo):
             with torch.cuda.stream(side):
                 x01.record_stream(side)
                 grad_feat.record_stream(side)
-                hashgrid_backward(x01, (0, 1, 2), ctx.grid_spec, grad_feat, grad_table=view.view(-1), fine_from=fine)
+                hashgrid_backward(x01, (0, 1, 2), ctx.grid_spec, grad_feat, grad_table=view.view(-1), fine_from=fine, ws_pool=pool)
                 if last:  # the table's gradient is final: its bucket may go out (event recorded on the side stream)
                     sink.mark_ready(ctx.table_param)
     return grad_table, None, None, (grad_w if need_w else None), None, None, None, None
@@ -726,23 +747,23 @@ class DensityRaysFn(Function):
 
     @staticmethod
     def forward(ctx, rays_o, rays_d, nears, fars, T, aabb_host, bound, noise, table_params, table_f16, grid_spec, mlp_params, mlp_w16,
-                mlp_spec, sigma_lo, sigma_hi, sliced):
+                mlp_spec, sigma_lo, sigma_hi, sliced, train_ctx=None):
         z_vals, sigma, geo16, x01, feat, h32 = density_uniform_train_forward(rays_o, rays_d, nears, fars, T, aabb_host, bound, noise, table_f16,
                                                                              grid_spec, mlp_w16, sliced)
         ctx.save_for_backward(x01, feat, sigma, mlp_w16)
         ctx.grid_spec, ctx.mlp_spec, ctx.clamp = grid_spec, mlp_spec, (float(sigma_lo), float(sigma_hi))
         ctx.table_param = table_params
         ctx.need_table, ctx.need_w = ctx.needs_input_grad[8], ctx.needs_input_grad[11]
-        ctx.rows_per_ray = T
-        if table_params is not None and table_params.requires_grad and torch.is_grad_enabled():
-            _scatter_expected(table_params)
+        ctx.rows_per_ray, ctx.train_ctx = T, train_ctx
+        if train_ctx is not None and table_params is not None and table_params.requires_grad and torch.is_grad_enabled():
+            train_ctx.expect(table_params)
         ctx.mark_non_differentiable(z_vals, geo16)
         return z_vals, sigma, h32[:, 1:mlp_spec.n_out], geo16
 
     @staticmethod
     def backward(ctx, _g_z, g_sigma, g_geo, _g_geo16):
         g = _density_backward(ctx, g_sigma, g_geo)  # (grad_table, None, None, grad_w, ...)
-        return (None,) * 8 + (g[0], None, None, g[3], None, None, None, None, None)
+        return (None,) * 8 + (g[0], None, None, g[3], None, None, None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -120,7 +120,8 @@ class GradBuckets:
       produced a gradient" flags, waits, averages, and sets `p.grad = None` for parameters no rank touched -- Adam then skips
       them, exactly as in a single process (a zero gradient would still move them by their momentum)."""
 
-    def __init__(self, params, bucket_bytes=64 << 20, hooks=True):
+    def __init__(self, params, bucket_bytes=64 << 20, hooks=True, train_ctx=None):
+        self.train_ctx = train_ctx  # field_ops.TrainContext of the step that owns these buckets (None: no kernel scatters into them)
         self.params = [p for p in params if p.requires_grad]
         self.ws = world()[1]
         order = list(reversed(self.params))
@@ -174,9 +175,8 @@ class GradBuckets:
             flat.zero_()
         for p in self.params:
             p.grad = self.views[p]
-        if self._cuda:  # kernels that scatter a gradient straight into its bucket view ask for it here (field_ops.DensityFn)
-            from nvsf import field_ops
-            field_ops.GRAD_SINK = self
+        if self._cuda and self.train_ctx is not None:  # kernels that scatter a gradient straight into its bucket view ask for it here
+            self.train_ctx.sink = self                  # (field_ops.DensityFn, through the step's TrainContext)
 
     def view_for(self, p):
         return self.views.get(p)
@@ -258,7 +258,8 @@ class GradBuckets:
     def finish(self):
         if self._cuda:
             from nvsf import field_ops
-            field_ops.GRAD_SINK = None
+            if self.train_ctx is not None:
+                self.train_ctx.sink = None
             field_ops.sync_side_streams()
         self._launch_ready(force=True)
         # "somebody produced a gradient" flags: written on the host (pinned) and copied without blocking

@@ -187,7 +187,7 @@ class FlowGridFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, field, xt, t_host, params):
         ctx.save_for_backward(xt)
-        ctx.field, ctx.t_host, ctx.rows_per_ray = field, t_host, ops.RAY_ROWS
+        ctx.field, ctx.t_host, ctx.rows_per_ray = field, t_host, ops.rows_hint(field)
         return field._grid_lagrange(xt, t_host)
 
     @staticmethod

@@ -61,7 +61,7 @@ class NeRFNetworkStatic(NeRFRenderer):
                 and net.spec.out_cols == 16 and testing.get("density_fn") == "fused"):
             # one autograd node for encode -> MLP -> trunc_exp / slice (ops.DensityFn): same forward kernels, leaner backward
             sigma, geo = ops.DensityFn.apply(x, enc.params, enc.table_f16(), enc.spec, net.params, net.weights_f16(), net.spec,
-                                             activation._LO, activation._HI)
+                                             activation._LO, activation._HI, ops.rows_hint(self), ops.train_context(self))
             return {"sigma": sigma, "geo_feat": geo}
         h = net(enc(x))
         return {"sigma": trunc_exp(h[..., 0]), "geo_feat": h[..., 1:]}
@@ -80,7 +80,7 @@ class NeRFNetworkStatic(NeRFRenderer):
         sliced = ops.prefer_sliced(enc.spec, rays_o.shape[0], T, ray_length, float(self.bound))
         z_vals, sigma, geo, geo16 = ops.DensityRaysFn.apply(rays_o, rays_d, nears, fars, int(T), self._aabb_host, float(self.bound), noise,
                                                             enc.params, enc.table_f16(), enc.spec, net.params, net.weights_f16(), net.spec,
-                                                            activation._LO, activation._HI, bool(sliced))
+                                                            activation._LO, activation._HI, bool(sliced), ops.train_context(self))
         return {"z_vals": z_vals, "sigma": sigma, "geo_feat": geo, "geo16": geo16}
 
     fused_train_forward = True  # False (tests): NeRFRenderer.run takes the operator chain (uniform_samples -> density)

@@ -184,6 +184,16 @@ class NeRFRenderer(nn.Module):
         suffix = "_lidar" if cal_lidar_color else ""
         return {"depth" + suffix: depth.view(*prefix), "image" + suffix: image.view(*prefix, out_dim), "weights_sum" + suffix: weights_sum}
 
+    def _rows_hint(self):
+        """The model's RowHint (field_ops), shared with every sub-module the first time it is asked for: the hash-grid autograd nodes
+        of the encoders read it at forward time (samples per ray of the rows they are given)."""
+        hint = self.__dict__.get("_row_hint")
+        if hint is None:
+            hint = ops.RowHint()
+            for m in self.modules():
+                m.__dict__["_row_hint"] = hint
+        return hint
+
     # -- to be provided by the field network -----------------------------------------------------
     def forward(self, x, d):
         raise NotImplementedError()
@@ -254,7 +264,7 @@ class NeRFRenderer(nn.Module):
                 xyz_arg = dirs_arg = None
             else:
                 z_vals, xyzs = ops.uniform_samples(rays_o, rays_d, nears, fars, T, aabb, noise)
-                with ops.ray_ordered_rows(T):  # rows are T consecutive samples per ray: lets the table scatters pick their form
+                with self._rows_hint().rows(T):  # rows are T consecutive samples per ray: lets the table scatters pick their form
                     density_outputs = self.density(xyzs.view(-1, 3), time, cal_lidar_color, **kwargs)
                 xyz_arg, dirs_arg = xyzs.view(-1, 3), rays_d.view(-1, 1, 3).expand(N, T, 3).reshape(-1, 3)
             sigma = density_outputs["sigma"].view(N, T)

@@ -154,9 +154,15 @@ class RenderTrainStep:
         self.split_backward = bool(split_backward)
         self.ray_chunks = max(1, int(ray_chunks))
         # more than one rank: gradients live in flat buckets that are all-reduced while backward still runs (frame_shard.GradBuckets)
+        # what the table-scatter nodes of the model need to know about this step (gradient sink, side-stream overlap, scatters still
+        # expected): an object of the step, attached to the model -- not process-wide state
+        from nvsf import field_ops
+        self.train_ctx = field_ops.TrainContext()
+        for mod in model.modules():
+            mod.__dict__["_train_ctx"] = self.train_ctx
         self.buckets = None
         if frame_shard.world()[1] > 1:
-            self.buckets = frame_shard.GradBuckets([p for g in self.opt.param_groups for p in g["params"]], bucket_bytes)
+            self.buckets = frame_shard.GradBuckets([p for g in self.opt.param_groups for p in g["params"]], bucket_bytes, train_ctx=self.train_ctx)
         # One process: the optimiser pass of the table whose scatter ran LAST is issued on that scatter's stream, behind it, and the
         # main stream goes on with the next step (whose first pass -- the camera's -- does not read that table): `defer_last_table`.
         self.defer_last_table = on_gpu and self.buckets is None
@@ -266,20 +272,21 @@ class RenderTrainStep:
     def _backward(self, loss):
         overlap = loss.is_cuda and self.scatter_overlap
         local_sink = False
+        tctx = self.train_ctx
         if overlap:
             from nvsf import field_ops
-            field_ops.SCATTER_OVERLAP = True
-            if field_ops.GRAD_SINK is None:  # one process: the side-stream scatters accumulate straight into p.grad
+            tctx.overlap = True
+            if tctx.sink is None:  # one process: the side-stream scatters accumulate straight into p.grad
                 if self._sink is None:
                     self._sink = field_ops.LocalGradSink()
-                field_ops.GRAD_SINK, local_sink = self._sink, True
+                tctx.sink, local_sink = self._sink, True
         try:
             self.scaler.scale(loss).backward()
         finally:
             if overlap:
-                field_ops.SCATTER_OVERLAP = False
+                tctx.overlap = False
                 if local_sink:
-                    field_ops.GRAD_SINK = None
+                    tctx.sink = None
         return overlap
 
     def sync(self):
@@ -352,13 +359,15 @@ class RenderTrainStep:
         return self._run(batch, False)[:3]
 
     def _run(self, batch, defer):
-        from nvsf import field_ops
-        field_ops.begin_scatter_count()  # a table is final after the LAST scatter it receives in this step (ray_chunks > 1: several)
+        if self.model.__dict__.get("_train_ctx") is not self.train_ctx:  # another step object was built on this model since
+            for mod in self.model.modules():
+                mod.__dict__["_train_ctx"] = self.train_ctx
+        self.train_ctx.begin_step()  # a table is final after the LAST scatter it receives in this step (ray_chunks > 1: several)
         self._sink = None
         try:
             return self._forward_backward(batch, defer)
         finally:
-            field_ops.end_scatter_count()
+            self.train_ctx.end_step()
             self._sink = None
 
     def _forward_backward(self, batch, defer=False):
