@@ -190,19 +190,26 @@ class HashGridFn(Function):
     """fp16 features = encode(x; table).  Gradient flows to the (fp32 master) table only."""
 
     @staticmethod
-    def forward(ctx, x, params, table_f16, spec, cols, rows_per_ray=None):
+    def forward(ctx, x, params, table_f16, spec, cols, rows_per_ray=None, train_ctx=None):
         x = x.float().contiguous()
         out = hashgrid_forward(x, cols, table_f16, spec)
         ctx.save_for_backward(x)
         ctx.spec, ctx.cols, ctx.rows_per_ray = spec, cols, rows_per_ray
+        ctx.train_ctx, ctx.table_param = train_ctx, params
+        if train_ctx is not None and isinstance(params, torch.nn.Parameter) and params.requires_grad and torch.is_grad_enabled():
+            train_ctx.expect(params)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         (x,) = ctx.saved_tensors
+        if not ctx.needs_input_grad[1]:
+            return None, None, None, None, None, None, None
         fine = _bin_from(ctx.spec, x.shape[0], ctx.rows_per_ray)
-        grad_params = hashgrid_backward(x, ctx.cols, ctx.spec, grad_out, fine_from=fine) if ctx.needs_input_grad[1] else None
-        return None, grad_params, None, None, None, None
+        done = scatter_beside_backward(ctx.train_ctx, ctx.table_param, (x, grad_out), lambda view, pool: hashgrid_backward(
+            x, ctx.cols, ctx.spec, grad_out, grad_table=view.view(-1), fine_from=fine, ws_pool=pool))
+        grad_params = None if done else hashgrid_backward(x, ctx.cols, ctx.spec, grad_out, fine_from=fine)
+        return None, grad_params, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------
@@ -616,6 +623,30 @@ class TrainContext:
 
 def train_context(module):
     return module.__dict__.get("_train_ctx") if module is not None else None
+
+
+def scatter_beside_backward(tctx, param, tensors, scatter):
+    """Runs `scatter(view, scratch pool)` -- which ADDS a table gradient into `view` -- on the side stream of the training step `tctx`
+    belongs to, into the step's gradient sink (the parameter's .grad or its bucket view); the autograd node then returns no tensor
+    for the table.  Returns False (nothing done) outside such a step: the caller scatters on its own stream and returns the
+    gradient to autograd.  `tensors`: what the scatter reads (kept alive for the side stream)."""
+    if tctx is None or not tctx.overlap or tctx.sink is None or not isinstance(param, torch.nn.Parameter) or not param.is_cuda:
+        if tctx is not None and isinstance(param, torch.nn.Parameter):
+            tctx.done(param)
+        return False
+    last = tctx.done(param)
+    view = tctx.sink.view_for(param)  # obtained (and, the first time, zero-filled) on the main stream
+    if view is None:
+        raise _hip.NvsfHipError("the gradient sink has no buffer for this table")
+    main, side = torch.cuda.current_stream(param.device), side_stream(param.device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        for t in tensors:
+            t.record_stream(side)
+        scatter(view, tctx.ws_pool)
+        if last:
+            tctx.sink.mark_ready(param)
+    return True
 
 
 def side_stream(device):

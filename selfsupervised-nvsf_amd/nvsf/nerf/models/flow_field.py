@@ -188,6 +188,9 @@ class FlowGridFn(torch.autograd.Function):
     def forward(ctx, field, xt, t_host, params):
         ctx.save_for_backward(xt)
         ctx.field, ctx.t_host, ctx.rows_per_ray = field, t_host, ops.rows_hint(field)
+        ctx.train_ctx, ctx.table_param = ops.train_context(field), params
+        if ctx.train_ctx is not None and params.requires_grad and torch.is_grad_enabled():
+            ctx.train_ctx.expect(params)
         return field._grid_lagrange(xt, t_host)
 
     @staticmethod
@@ -200,9 +203,20 @@ class FlowGridFn(torch.autograd.Function):
         # feature 2i+e of a level receives w_i * dL/d(reduced column e): the four chunks of an entry get the same scattered sum
         # up to the scalar w_i.  Scatter G[row][e] = sum g_e w_corner ONCE on a 2-feature view of the grid (a quarter of the
         # atomics, which bound this pass) and expand to the 8 features afterwards.
-        import copy
-        spec2 = copy.copy(spec)
-        spec2.F, spec2.n_params, spec2.n_output_dims = 2, spec.n_rows * 2, spec.L * 2
-        G = ops.hashgrid_backward(xt, (0, 1, 2), spec2, grad_red.float().contiguous(), fine_from=ops._bin_from(spec2, xt.shape[0], ctx.rows_per_ray))
+        spec2 = field.__dict__.get("_spec2")
+        if spec2 is None or spec2.n_rows != spec.n_rows:
+            import copy
+            spec2 = copy.copy(spec)
+            spec2.F, spec2.n_params, spec2.n_output_dims = 2, spec.n_rows * 2, spec.L * 2
+            field.__dict__["_spec2"] = spec2
+        g = grad_red.float().contiguous()
+        fine = ops._bin_from(spec2, xt.shape[0], ctx.rows_per_ray)
+
+        def scatter(view, pool):  # on the step's side stream: scatter the 2-feature sums, expand them into the table's gradient
+            G = ops.hashgrid_backward(xt, (0, 1, 2), spec2, g, fine_from=fine, ws_pool=pool)
+            view.view(-1, 4, 2).addcmul_(G.view(-1, 1, 2), w.view(1, 4, 1))
+        if ops.scatter_beside_backward(ctx.train_ctx, ctx.table_param, (xt, g, w), scatter):
+            return None, None, None, None
+        G = ops.hashgrid_backward(xt, (0, 1, 2), spec2, g, fine_from=fine)
         grad_table = (G.view(-1, 1, 2) * w.view(1, 4, 1)).reshape(-1)
         return None, None, None, grad_table

@@ -78,7 +78,7 @@ class Encoding(nn.Module):
     def forward(self, x):
         x = x.reshape(-1, self.n_input_dims) if x.dim() != 2 else x
         if self.otype in ("HashGrid", "Grid"):
-            return _ops.HashGridFn.apply(x, self.params, self.table_f16(), self.spec, self._cols, _ops.rows_hint(self))
+            return _ops.HashGridFn.apply(x, self.params, self.table_f16(), self.spec, self._cols, _ops.rows_hint(self), _ops.train_context(self))
         if self.otype == "Frequency":
             return _ops.freq_encode(x, self.n_frequencies)
         return _ops.sh4_encode(x)
@@ -87,7 +87,7 @@ class Encoding(nn.Module):
         """HashGrid only: encode the columns `cols` of a wider coordinate matrix in place (no gather copy) --
         e.g. the (x, z) pair of an [N, 3] position tensor for a 2-D time-slice grid."""
         assert self.otype in ("HashGrid", "Grid") and len(cols) == self.n_input_dims
-        return _ops.HashGridFn.apply(x, self.params, self.table_f16(), self.spec, tuple(cols), _ops.rows_hint(self))
+        return _ops.HashGridFn.apply(x, self.params, self.table_f16(), self.spec, tuple(cols), _ops.rows_hint(self), _ops.train_context(self))
 
     def extra_repr(self):
         return f"n_input_dims={self.n_input_dims}, n_output_dims={self.n_output_dims}, {self.encoding_config}"
