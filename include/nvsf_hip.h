@@ -496,8 +496,9 @@ int nvsf_field_heads_uniform_fwd(const float* weights, const void* geo_f16, cons
 int nvsf_chamfer_forward(const float* xyz1, const float* xyz2, uint32_t B, uint32_t n, uint32_t m, float* dist1,
                          float* dist2, int32_t* idx1, int32_t* idx2, void* workspace_u64, nvsf_stream_t stream);
 
-/* ref: chamfer_3D.backward, chamfer3D.cu:167-234.  grad_xyz1 [B,n,3], grad_xyz2 [B,m,3] zero-initialised by the
- * caller (dist_chamfer_3D.py:79-80). */
+/* ref: chamfer_3D.backward, chamfer3D.cu:167-234.  grad_xyz1 [B,n,3] is written whole (no zero fill needed: its rows are stored by
+ * the first direction before the second adds); grad_xyz2 [B,m,3] zero-initialised by the caller (dist_chamfer_3D.py:79-80).  Either
+ * may be NULL (that cloud needs no gradient -- e.g. the measured cloud of the training loss), not both. */
 int nvsf_chamfer_backward(const float* xyz1, const float* xyz2, uint32_t B, uint32_t n, uint32_t m,
                           const float* grad_dist1, const float* grad_dist2, const int32_t* idx1, const int32_t* idx2,
                           float* grad_xyz1, float* grad_xyz2, nvsf_stream_t stream);
@@ -524,9 +525,11 @@ int nvsf_adam_prepare(float* state4, const float* found_inf, float beta1, float 
  * Nothing is written when state4[3] != 0 (overflow: the step is skipped).
  * ema_shadow (fp32 [n], may be NULL): shadow -= ema_one_minus_decay * (shadow - param) with the UPDATED parameter, in the same
  * pass (an every-step exponential moving average of the weights; the reference's per-epoch one is nvsf_ema_update). */
+/* param_f16 (fp16 [n], may be NULL): the updated parameter rounded to fp16, written in the same pass -- the copy the forward kernels
+ * read (hash tables, MLP weights), which otherwise costs a cast pass per parameter and step. */
 int nvsf_adam_update(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr, float beta1,
                      float beta2, float eps, const float* state4, const float* grad_scale, float* ema_shadow,
-                     float ema_one_minus_decay, nvsf_stream_t stream);
+                     float ema_one_minus_decay, void* param_f16, nvsf_stream_t stream);
 
 /* ref: the LiDAR terms of Trainer.train_step, nvsf/nerf/trainer.py:187-219 (criteria with reduction = "none", main_nvsf.py:205-221;
  * summed at trainer.py:540-543) and the point clouds of its chamfer term (trainer.py:229-233), all [N] fp32 unless noted:

@@ -39,7 +39,7 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 __global__ __launch_bounds__(kBlock) void k_adam_update(float* __restrict__ param, const float* __restrict__ grad, float* __restrict__ exp_avg,
                                                         float* __restrict__ exp_avg_sq, unsigned long long n, float lr, float beta1, float beta2,
                                                         float eps, const float* __restrict__ state, const float* __restrict__ grad_scale,
-                                                        float* __restrict__ ema, float ema_omd, int vec) {
+                                                        float* __restrict__ ema, float ema_omd, _Float16* __restrict__ half_copy, int vec) {
     if (state[3] != 0.0f) return;  // overflow in this step's gradients: the step is skipped (GradScaler semantics)
     const float scale = grad_scale ? grad_scale[0] : 1.0f;
     const float step_size = lr / state[1], bc2_sqrt = state[2];
@@ -57,6 +57,10 @@ __global__ __launch_bounds__(kBlock) void k_adam_update(float* __restrict__ para
                 p[k] = pk; m[k] = mk; v[k] = vk;
             }
             reinterpret_cast<float4_t*>(param)[i] = p;
+            if (half_copy) {  // the fp16 copy the forward kernels read (tables, MLP weights): written here instead of by a cast pass per step
+                typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+                reinterpret_cast<half4v*>(half_copy)[i] = __builtin_convertvector(p, half4v);
+            }
             if (ema) {
                 float4_t e = reinterpret_cast<float4_t*>(ema)[i];
 #pragma unroll
@@ -70,6 +74,7 @@ __global__ __launch_bounds__(kBlock) void k_adam_update(float* __restrict__ para
     }
     for (; i < n; i += stride) {
         adam_one(param[i], grad[i], exp_avg[i], exp_avg_sq[i], scale, step_size, beta1, beta2, eps, bc2_sqrt);
+        if (half_copy) half_copy[i] = (_Float16)param[i];
         if (ema) ema[i] = ema[i] - (ema[i] - param[i]) * ema_omd;
     }
 }
@@ -103,17 +108,17 @@ NVSF_API int nvsf_adam_prepare(float* state4, const float* found_inf, float beta
 
 NVSF_API int nvsf_adam_update(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, uint64_t n, float lr, float beta1,
                               float beta2, float eps, const float* state4, const float* grad_scale, float* ema_shadow, float ema_one_minus_decay,
-                              hipStream_t stream) {
+                              void* param_f16, hipStream_t stream) {
     if (n == 0) return NVSF_OK;
     REQUIRE(param && grad && exp_avg && exp_avg_sq && state4);
     const uintptr_t all = reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
                           reinterpret_cast<uintptr_t>(exp_avg_sq) | reinterpret_cast<uintptr_t>(ema_shadow);
-    const int vec = (all & 15u) == 0;
+    const int vec = (all & 15u) == 0 && (reinterpret_cast<uintptr_t>(param_f16) & 7u) == 0;
     const unsigned long long work = vec ? (n + 3) / 4 : n;
     unsigned long long blocks = (work + kBlock - 1) / kBlock;
     if (blocks > 256ull * 16) blocks = 256ull * 16;  // grid-stride beyond 16 workgroups per CU
     hipLaunchKernelGGL(k_adam_update, dim3((unsigned)blocks), dim3(kBlock), 0, stream, param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps,
-                       state4, grad_scale, ema_shadow, ema_one_minus_decay, vec);
+                       state4, grad_scale, ema_shadow, ema_one_minus_decay, reinterpret_cast<_Float16*>(param_f16), vec);
     return nvsf_launch_status();
 }
 

@@ -54,7 +54,10 @@ __global__ __launch_bounds__(kBlock) void k_chamfer_unpack(const unsigned long l
     idx[i] = (int)(uint32_t)w;
 }
 
-// grad_a[j] += 2 g (a_j - b_nn(j)),  grad_b[nn(j)] -= the same  (chamfer3D.cu:167-195)
+// grad_a[j] += 2 g (a_j - b_nn(j)),  grad_b[nn(j)] -= the same  (chamfer3D.cu:167-195).  grad_a / grad_b may be NULL (that cloud needs
+// no gradient); STORE_A: grad_a[j] is WRITTEN -- point j of the query cloud is this thread's alone -- so a caller that runs this
+// direction first needs no zero fill of grad_a.
+template <bool STORE_A>
 __global__ __launch_bounds__(kBlock) void k_chamfer_grad(const float* __restrict__ a, uint32_t n, const float* __restrict__ bpts, uint32_t m,
                                                          const float* __restrict__ grad_dist, const int* __restrict__ idx,
                                                          float* __restrict__ grad_a, float* __restrict__ grad_b, uint32_t B) {
@@ -68,8 +71,11 @@ __global__ __launch_bounds__(kBlock) void k_chamfer_grad(const float* __restrict
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float v = g * (p[c] - r[c]);
-        atomicAdd(grad_a + i * 3 + c, v);
-        atomicAdd(grad_b + ((size_t)bb * m + j2) * 3 + c, -v);
+        if (grad_a) {
+            if constexpr (STORE_A) grad_a[i * 3 + c] = v;
+            else atomicAdd(grad_a + i * 3 + c, v);
+        }
+        if (grad_b) atomicAdd(grad_b + ((size_t)bb * m + j2) * 3 + c, -v);
     }
 }
 }  // namespace
@@ -102,15 +108,17 @@ NVSF_API int nvsf_chamfer_forward(const float* xyz1, const float* xyz2, uint32_t
     return scan_one_direction(xyz2, m, xyz1, n, B, ws, dist2, idx2, stream);
 }
 
-// grad_xyz1 / grad_xyz2 must be zero-initialised by the caller (dist_chamfer_3D.py:79-80)
+// grad_xyz2 must be zero-initialised by the caller (dist_chamfer_3D.py:79-80) unless it is NULL (the second cloud needs no gradient:
+// the measured point cloud of the training loss); grad_xyz1 may hold anything: the first direction writes every row of it before the
+// second one adds.  grad_xyz1 NULL: only the second cloud's gradient is formed (then grad_xyz2 is written first / added second).
 NVSF_API int nvsf_chamfer_backward(const float* xyz1, const float* xyz2, uint32_t B, uint32_t n, uint32_t m, const float* grad_dist1,
                                    const float* grad_dist2, const int32_t* idx1, const int32_t* idx2, float* grad_xyz1, float* grad_xyz2,
                                    hipStream_t stream) {
     if (B == 0 || n == 0 || m == 0) return NVSF_OK;
-    REQUIRE(xyz1 && xyz2 && grad_dist1 && grad_dist2 && idx1 && idx2 && grad_xyz1 && grad_xyz2);
-    hipLaunchKernelGGL(k_chamfer_grad, dim3(cdiv((unsigned long long)B * n, kBlock)), dim3(kBlock), 0, stream, xyz1, n, xyz2, m, grad_dist1, idx1,
+    REQUIRE(xyz1 && xyz2 && grad_dist1 && grad_dist2 && idx1 && idx2 && (grad_xyz1 || grad_xyz2));
+    hipLaunchKernelGGL(k_chamfer_grad<true>, dim3(cdiv((unsigned long long)B * n, kBlock)), dim3(kBlock), 0, stream, xyz1, n, xyz2, m, grad_dist1, idx1,
                        grad_xyz1, grad_xyz2, B);
-    hipLaunchKernelGGL(k_chamfer_grad, dim3(cdiv((unsigned long long)B * m, kBlock)), dim3(kBlock), 0, stream, xyz2, m, xyz1, n, grad_dist2, idx2,
+    hipLaunchKernelGGL(k_chamfer_grad<false>, dim3(cdiv((unsigned long long)B * m, kBlock)), dim3(kBlock), 0, stream, xyz2, m, xyz1, n, grad_dist2, idx2,
                        grad_xyz2, grad_xyz1, B);
     return nvsf_launch_status();
 }

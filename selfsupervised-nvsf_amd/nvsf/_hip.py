@@ -42,7 +42,7 @@ SIGNATURES = {
     "nvsf_freq_encode": [_P, _U, _U, _U, _P, _U],
     "nvsf_sh4_encode": [_P, _U, _P, _U],
     "nvsf_adam_prepare": [_P, _P, _F, _F],
-    "nvsf_adam_update": [_P, _P, _P, _P, _U64, _F, _F, _F, _F, _P, _P, _P, _F],
+    "nvsf_adam_update": [_P, _P, _P, _P, _U64, _F, _F, _F, _F, _P, _P, _P, _F, _P],
     "nvsf_ema_update": [_P, _P, _U64, _F],
     "nvsf_sigma_geo_bwd": [_P, _P, _P, _U, _U, _U, _P, _U, _F, _F],
     "nvsf_cast_cols_f16": [_P, _I, _U, _U, _U, _P, _U],

@@ -35,6 +35,8 @@ class FusedAdam(torch.optim.Optimizer):
         self._row_of = {}      # parameter -> row index
         self._n_rows = 0
         self.ema = None        # optional (shadow tensors by parameter, one_minus_decay): EMA folded into the update pass
+        self.half_caches = {}  # parameter -> the fp16 cache of the module that owns it (tinycudann._HalfCache): the update pass writes
+                               # the fp16 copy the forward kernels read and marks the cache fresh (no cast pass per parameter and step)
 
     _MAX_ROWS = 64
 
@@ -116,12 +118,16 @@ class FusedAdam(torch.optim.Optimizer):
                     state["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                 grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 shadow = shadows.get(p)
+                cache = self.half_caches.get(p)
+                half = cache.writable(p) if cache is not None else None
                 _hip.call("nvsf_adam_update", p.data_ptr(), grad.data_ptr(), state["exp_avg"].data_ptr(), state["exp_avg_sq"].data_ptr(),
                           p.numel(), lr, float(beta1), float(beta2), eps, rows[self._row_of[p]].data_ptr(), scale_ptr,
-                          None if shadow is None else shadow.data_ptr(), float(omd))
+                          None if shadow is None else shadow.data_ptr(), float(omd), None if half is None else half.data_ptr())
                 # the kernel wrote through the raw pointer: tell autograd (and every cache keyed on `_version`, e.g. the fp16
                 # copies of tables and weights the forward kernels read) that the parameter changed
                 torch.autograd.graph.increment_version(p)
+                if half is not None:
+                    cache.mark_fresh(p)  # ... except the cache this very pass has just brought up to date
         return loss
 
     # ---- torch.optim.Adam-compatible state dicts ---------------------------------------------------------------------------

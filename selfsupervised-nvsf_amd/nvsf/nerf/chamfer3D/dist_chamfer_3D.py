@@ -35,7 +35,13 @@ class chamfer_3DFunction(Function):
         B, n, _ = xyz1.shape
         m = xyz2.shape[1]
         g1, g2 = graddist1.float().contiguous(), graddist2.float().contiguous()
-        gradxyz1, gradxyz2 = torch.zeros_like(xyz1), torch.zeros_like(xyz2)
+        # the first cloud's gradient is WRITTEN by the first direction's kernel (no zero fill); the second cloud's is formed only when
+        # it is asked for (the training loss compares against the measured cloud, which has no gradient)
+        need1, need2 = ctx.needs_input_grad
+        if not (need1 or need2):
+            return None, None
+        gradxyz1 = torch.empty_like(xyz1) if need1 else None
+        gradxyz2 = torch.zeros_like(xyz2) if need2 else None
         _hip.call("nvsf_chamfer_backward", _hip.ptr(xyz1), _hip.ptr(xyz2), B, n, m, _hip.ptr(g1), _hip.ptr(g2), _hip.ptr(idx1), _hip.ptr(idx2),
                   _hip.ptr(gradxyz1), _hip.ptr(gradxyz2))
         return gradxyz1, gradxyz2

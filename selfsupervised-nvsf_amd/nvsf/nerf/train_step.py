@@ -172,6 +172,8 @@ class RenderTrainStep:
         for mod in model.modules():
             if hasattr(mod, "_cache") and isinstance(getattr(mod, "params", None), torch.nn.Parameter):
                 self._cache_of[mod.params] = mod._cache
+        if on_gpu:  # the optimiser pass writes the fp16 copies the forward kernels read (no cast pass per parameter and step)
+            self.opt.half_caches = {p: c for p, c in self._cache_of.items() if p.numel() > 0}
 
     def _render(self, rays_o, rays_d, time, **kw):
         """model.render on `ray_chunks` slices of the batch, results concatenated.  Each slice is its own autograd sub-graph, and

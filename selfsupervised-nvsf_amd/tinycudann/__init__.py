@@ -39,6 +39,16 @@ class _HalfCache:
             self._key = key
         return self._half
 
+    def writable(self, p):
+        """The fp16 buffer for a kernel that is about to update `p` and write the copy itself (nvsf_adam_update): allocated (and
+        filled) if it does not exist or `p` moved; the caller calls `mark_fresh(p)` after bumping the parameter's version."""
+        if self._half is None or self._half.numel() != p.numel() or self._half.device != p.device or self._key is None or self._key[0] != p.data_ptr():
+            self.get(p)
+        return self._half
+
+    def mark_fresh(self, p):
+        self._key = (p.data_ptr(), p._version, p.device)
+
 
 class Encoding(nn.Module):
     def __init__(self, n_input_dims, encoding_config, seed=1337, dtype=None):

@@ -48,6 +48,19 @@ def test_chamfer_forward_backward(dev, B, n, m):
     # terms, so the last bits depend on the run (observed: 1.3e-5 relative on an entry of magnitude 129)
     np.testing.assert_allclose(ta.grad.cpu().numpy(), ga, atol=2e-5, rtol=5e-5)
     np.testing.assert_allclose(tb.grad.cpu().numpy(), gb, atol=2e-5, rtol=5e-5)
+    # one cloud without a gradient (the training loss: predicted cloud against the measured one, and the other way round): the other
+    # cloud's gradient is the same, formed without the zero fill / the atomics of the cloud that needs none
+    for first in (True, False):
+        ta2 = torch.from_numpy(a).to(dev).requires_grad_(first)
+        tb2 = torch.from_numpy(b).to(dev).requires_grad_(not first)
+        e1, e2, _, _ = chamfer_3DDist()(ta2, tb2)
+        ((e1 * torch.from_numpy(g1).to(dev)).sum() + (e2 * torch.from_numpy(g2).to(dev)).sum()).backward()
+        if first:
+            assert tb2.grad is None
+            np.testing.assert_allclose(ta2.grad.cpu().numpy(), ga, atol=2e-5, rtol=5e-5)
+        else:
+            assert ta2.grad is None
+            np.testing.assert_allclose(tb2.grad.cpu().numpy(), gb, atol=2e-5, rtol=5e-5)
 
 
 def test_points_meter_cd_and_fscore(dev):

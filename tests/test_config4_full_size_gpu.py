@@ -74,11 +74,11 @@ def test_full_size_step_runs_the_production_plan_and_matches_the_oracle_scatter(
     seen = []
     real = ops.hashgrid_backward
 
-    def recording(x, cols, spec, grad_out, grad_table=None, fine_from=None, merge_from=None):
+    def recording(x, cols, spec, grad_out, grad_table=None, fine_from=None, merge_from=None, **kw):
         # runs on the stream the scatter is issued on (the side stream): copies are ordered before it
         seen.append({"x": x.detach().clone(), "g": grad_out.detach().clone(), "fine_from": fine_from, "table": grad_table,
                      "stream": torch.cuda.current_stream().cuda_stream})
-        return real(x, cols, spec, grad_out, grad_table=grad_table, fine_from=fine_from, merge_from=merge_from)
+        return real(x, cols, spec, grad_out, grad_table=grad_table, fine_from=fine_from, merge_from=merge_from, **kw)
 
     monkeypatch.setattr(ops, "hashgrid_backward", recording)
     loss, grads = _grads(step, m, batch)

@@ -20,6 +20,8 @@ batch = {"rays_o_lidar": torch.from_numpy(lo).to(dev)[None], "rays_d_lidar": tor
 step = RenderTrainStep(m, num_steps=T, scale=S.SCALE, ray_chunks=int(os.environ.get('CHUNKS', 1)), split_backward=os.environ.get('SPLIT', '1') == '1')
 step.scatter_overlap = os.environ.get('OVERLAP', '1') == '1'
 from nvsf import field_ops as _ops
+if os.environ.get('HALF') == '0':  # the fp16 copies of tables / weights by a cast pass per step instead of by the optimiser pass
+    step.opt.half_caches = {}
 if os.environ.get('LM') == '0':
     _ops.LEVEL_MAJOR_GRADIENT = False
 if os.environ.get('MERGE') == '0':  # run sums off: atomics for every level below the per-row ones

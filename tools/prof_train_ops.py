@@ -12,4 +12,4 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     for _ in range(3):
         step.step(batch)
     torch.cuda.synchronize()
-print(prof.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=45, max_name_column_width=50, max_shapes_column_width=70))
+print(prof.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=int(os.environ.get("ROWS", 45)), max_name_column_width=50, max_shapes_column_width=70))
