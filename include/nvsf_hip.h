@@ -426,6 +426,22 @@ int nvsf_render_uniform_fwd(const float* rays_o, const float* rays_d, const floa
                             float w_thresh, const float* h_bg_color, const void* feat_scratch, float* z_vals,
                             float* weights, float* weights_sum, float* depth, float* image, nvsf_stream_t stream);
 
+/* The TRAINING forward of the same render (renderer_dynamic.py:155-237 under autograd; field_ops.RenderRaysFn): the launch(es) of
+ * nvsf_render_uniform_fwd -- with feat_scratch the level-sliced encode pass runs first, inside this call -- which additionally keep
+ * what the backward of the whole render reads: x01 [M,3] unit-cube positions, feat_rows_f16 [M,32] encoded features (column 2 l + f),
+ * geo_f16 [M,16] = (h1 .. h15, 1.0), sigmas [M] = exp(h0), rgbs [M,C] = [weight > w_thresh] sigmoid(logits); M = N T.  Same z_vals /
+ * weights / weights_sum / depth / image as nvsf_render_uniform_fwd bit for bit.  Replaces, in the training graph, the chain
+ * nvsf_field_density_uniform_train_fwd -> nvsf_composite_uniform_weights_fwd -> nvsf_mlp_fwd_prefix (x 1-2) -> nvsf_masked_sigmoid ->
+ * nvsf_composite_uniform_image_fwd and their intermediate [M,16] fp32 outputs, logits and mask. */
+int nvsf_render_uniform_train_fwd(const float* rays_o, const float* rays_d, const float* nears, const float* fars,
+                                  const float* lin, const float* noise, const float* h_aabb, float bound, uint32_t N,
+                                  uint32_t T, const void* table_f16, uint32_t L, uint32_t F, const float* h_scales,
+                                  const uint32_t* h_res, const uint32_t* h_offsets, const void* sigma_weights_f16, int lidar,
+                                  const void* head_a_weights_f16, const void* head_b_weights_f16, float k_scale,
+                                  float w_thresh, const float* h_bg_color, void* feat_scratch, float* z_vals, float* weights,
+                                  float* weights_sum, float* depth, float* image, float* x01, void* feat_rows_f16,
+                                  void* geo_f16, float* sigmas, float* rgbs, nvsf_stream_t stream);
+
 /* ref: the evaluation-mode protocol of the raymarching extension, raymarching.py:389-409 (march_rays) + 480-493
  * (composite_rays) around the field, for a static hash field (L*F = 32, F = 2): ONE launch instead of the host
  * loop over surviving rays.  Per ray: march through the occupancy bit field `grid` (layout of nvsf_march_rays),

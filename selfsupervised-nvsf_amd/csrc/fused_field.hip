@@ -290,6 +290,19 @@ __device__ __forceinline__ void store_feat_row(_Float16* __restrict__ feat, unsi
     if (ok) *reinterpret_cast<uint4*>(feat + s * 32 + 8 * g) = mine;
 }
 
+// The same 4 x 4 transpose over the lane groups without LDS: gfx950's row / half-wave swaps.  v_permlane16_swap exchanges the odd
+// rows (of 16 lanes) of its first operand with the even rows of its second, v_permlane32_swap the upper half-wave of the first
+// with the lower half-wave of the second.  With (x, y) = levels (g, 4 + g) the row swap leaves the level PAIRS (0,1) (4,5) (2,3)
+// (6,7) in lane groups 0..3 -- likewise (8,9) (12,13) (10,11) (14,15) from (z, w) -- and the half-wave swap of the two pairs hands
+// lane group g the dwords 4g .. 4g + 3 of its sample's row: four cross-lane instructions, one 16-byte store.
+__device__ __forceinline__ void store_feat_row_swap(_Float16* __restrict__ feat, unsigned long long s, int g, const uint4& p, bool ok) {
+    const auto a = __builtin_amdgcn_permlane16_swap(p.x, p.y, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap(p.z, p.w, false, false);
+    const auto lo = __builtin_amdgcn_permlane32_swap(a[0], b[0], false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap(a[1], b[1], false, false);
+    if (ok) *reinterpret_cast<uint4*>(feat + s * 32 + 8 * g) = make_uint4(lo[0], hi[0], lo[1], hi[1]);
+}
+
 // density_eval + store of sigma / geo / z.
 template <int F, int QG, bool TRAIN = false>
 __device__ __forceinline__ void density_tile(const DensityCtx<F>& cx, const float (&x)[3], float z, unsigned long long s, bool in_range,
@@ -1268,12 +1281,25 @@ __device__ __forceinline__ float row16_scan_mul(float v) {  // inclusive product
     return v;
 }
 
-template <bool LIDAR, bool FROM_FEATURES>
+// What the TRAINING form of the render kernels keeps beside z_vals / weights (ops.RenderRaysFn): everything the backward of the
+// whole render reads -- unit-cube positions (table scatter), the 32 encoded features as fp16 rows in level order (the density MLP's
+// backward recomputes its hidden layer from them), sigma (compositor backward), the geometry rows (h1 .. h15, 1.0) the heads'
+// backward reads as their per-sample input, and the masked per-sample colours sigmoid(logits) [weight > w_thresh] (image / sigmoid
+// backward).  The per-sample logits, the [M, 16] fp32 network outputs and the mask never reach memory.
+struct RenderTrainOut {
+    float* x01;      // [M, 3]   (written by the kernel that forms the positions: k_render_uniform<*, false> / k_encode_sliced_pairs)
+    _Float16* feat;  // [M, 32], column 2 l + f
+    _Float16* geo;   // [M, 16]
+    float* sigma;    // [M]
+    float* rgb;      // [M, C]
+};
+
+template <bool LIDAR, bool FROM_FEATURES, bool TRAIN = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_render_uniform(
     RayBatch rb, const _Float16* __restrict__ table, uint32_t table_bytes, GridMeta meta, uint32_t first_hashed,
     const uint2* __restrict__ feat, const _Float16* __restrict__ w_sigma, const _Float16* __restrict__ w_a, const _Float16* __restrict__ w_b,
     float k_scale, float w_thresh, float bg0, float bg1, float bg2, int use_bg, float* __restrict__ z_vals, float* __restrict__ weights,
-    float* __restrict__ weights_sum, float* __restrict__ depth, float* __restrict__ image) {
+    float* __restrict__ weights_sum, float* __restrict__ depth, float* __restrict__ image, RenderTrainOut rt = RenderTrainOut()) {
     using FR = OccFrags<LIDAR>;
     constexpr int F = 2;
     constexpr int IN_STEPS = FR::IN_STEPS;
@@ -1388,7 +1414,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             x[1] = (fminf(fmaxf(oy + rd1 * z, rb.lo[1]), rb.hi[1]) + rb.bound) * rb.inv_extent;
             x[2] = (fminf(fmaxf(oz + rd2 * z, rb.lo[2]), rb.hi[2]) + rb.bound) * rb.inv_extent;
             feat8 = density_encode<F, 4, true>(cx, x);
+            if constexpr (TRAIN) {
+                if (g == 0 && valid) { rt.x01[3 * s] = x[0]; rt.x01[3 * s + 1] = x[1]; rt.x01[3 * s + 2] = x[2]; }
+            }
         }
+        if constexpr (TRAIN) store_feat_row_swap(rt.feat, s, g, __builtin_bit_cast(uint4, feat8), valid);
         // ---- sigma MLP
         float4_t o;
         {
@@ -1414,12 +1444,19 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         if (g == 3 && valid) {
             weights[s] = w;
             if constexpr (!FROM_FEATURES) z_vals[s] = z;
+            if constexpr (TRAIN) rt.sigma[s] = expf(o[3]);
         }
         ws += w;
         dp += w * z;
         // ---- heads on the samples that carry weight
         const float w0 = __shfl(w, 48 + c, 64);  // weight of sample c, for the lanes that hold its colour (g == 0); needed after the heads
         const bool on = w0 > w_thresh;
+        float cr[C];  // TRAIN: masked colour of sample c (lanes g == 0)
+#pragma unroll
+        for (int k = 0; k < C; ++k) cr[k] = 0.0f;
+        if constexpr (TRAIN) {  // geometry row (h1 .. h15, 1.0) of sample c: lane group g holds its columns 4g .. 4g + 3
+            if (valid) *reinterpret_cast<uint2*>(rt.geo + s * 16 + 4 * g) = make_uint2(pack_h2(o[0], o[1]), pack_h2(o[2], g == 3 ? 1.0f : o[3]));
+        }
         if (__ballot(w > w_thresh)) {  // w is zero outside lane group 3: the same set of samples
             const uint32_t p0 = pack_h2(o[0], o[1]), p1 = pack_h2(o[2], g == 3 ? 1.0f : o[3]);
             typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
@@ -1433,14 +1470,25 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             if constexpr (LIDAR) {
                 const float4_t ob = head(1, x_last);
                 if (g == 0 && on) {
-                    img[0] += w0 * sigmoid_f32(oa[0]);
-                    img[1] += w0 * sigmoid_f32(ob[0]);
+                    cr[0] = sigmoid_f32(oa[0]);
+                    cr[1] = sigmoid_f32(ob[0]);
+                    img[0] += w0 * cr[0];
+                    img[1] += w0 * cr[1];
                 }
             } else {
                 if (g == 0 && on) {
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) img[k] += w0 * sigmoid_f32(oa[k]);
+                    for (int k = 0; k < 3; ++k) {
+                        cr[k] = sigmoid_f32(oa[k]);
+                        img[k] += w0 * cr[k];
+                    }
                 }
+            }
+        }
+        if constexpr (TRAIN) {
+            if (g == 0 && valid) {
+#pragma unroll
+                for (int k = 0; k < C; ++k) rt.rgb[s * C + k] = cr[k];
             }
         }
     }
@@ -1468,12 +1516,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 // fragment is read ONCE and feeds two MFMAs (half the LDS traffic), and the two tiles are independent chains up to the
 // transmittance carry, which enters only at the scan (tile 2j+1 scans with tile 2j's carry).  Arithmetic per tile is that
 // of k_render_uniform (same scans over 16 lanes, same MFMA chains): bit-identical outputs.
-template <bool LIDAR>
+template <bool LIDAR, bool TRAIN = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_render_tail2(
     RayBatch rb, const uint2* __restrict__ feat, const _Float16* __restrict__ w_sigma, const _Float16* __restrict__ w_a,
     const _Float16* __restrict__ w_b, float k_scale, float w_thresh, float bg0, float bg1, float bg2, int use_bg,
     const float* __restrict__ z_vals, float* __restrict__ weights, float* __restrict__ weights_sum, float* __restrict__ depth,
-    float* __restrict__ image) {
+    float* __restrict__ image, RenderTrainOut rt = RenderTrainOut()) {
     using FR = OccFrags<LIDAR>;
     constexpr int IN_STEPS = FR::IN_STEPS;
     constexpr int C = LIDAR ? 2 : 3;
@@ -1599,6 +1647,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             z[u] = cur[u].z;
             const u4_t packed = {cur[u].p0.x, cur[u].p1.x, cur[u].p1.y, cur[u].p0.y};
             feat8[u] = __builtin_bit_cast(half8_t, packed);
+            if constexpr (TRAIN)  // feature rows in level order (fragment pieces = levels g, g + 4, g + 8, g + 12)
+                store_feat_row_swap(rt.feat, row0 + idx[u], g, make_uint4(packed.x, packed.y, packed.z, packed.w), valid[u]);
         }
         // depth of the following sample: lane c + 1 of the tile, lane 0 of the next tile for c == 15 (the same fp32 words the
         // one-tile kernel loads as z_vals[s + 1]); only read where i + 1 < T
@@ -1647,7 +1697,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             const float carry1 = carry * readlane_f32(incl, 63);  // transmittance in front of tile 2j + 1
             w = alpha * ((hi ? carry : carry1) * excl);  // zero outside lane groups 2, 3
             carry = carry1 * readlane_f32(incl, 47);
-            if (live) weights[row0 + i] = w;
+            if (live) {
+                weights[row0 + i] = w;
+                if constexpr (TRAIN) rt.sigma[row0 + i] = expf(lg);
+            }
             w0[0] = __shfl(w, 48 + c, 64);  // weights of sample c of either tile, for the lanes that hold its colour (g == 0)
             w0[1] = __shfl(w, 32 + c, 64);
             on[0] = w0[0] > w_thresh;
@@ -1658,6 +1711,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             dp += a0 * z[0];
             ws += a1;
             dp += a1 * z[1];
+        }
+        float cr[2][C];  // TRAIN: masked colours of sample c of either tile (lanes g == 0)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int k = 0; k < C; ++k) cr[u][k] = 0.0f;
+        if constexpr (TRAIN) {
+            // geometry rows (h1 .. h15, 1.0): tile 2j has columns 4g .. 4g + 3 in lane group g; tile 2j + 1 ran its output layer with the
+            // rows rotated by 5, so lane group g holds columns 4 (g + 1 mod 4) .. of its sample and the logit sits in lane group 2
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const uint32_t q0 = pack_h2(o[u][0], o[u][1]), q1 = pack_h2(o[u][2], g == 3 - u ? 1.0f : o[u][3]);
+                const int col = u ? 4 * ((g + 1) & 3) : 4 * g;
+                if (valid[u]) *reinterpret_cast<uint2*>(rt.geo + (row0 + idx[u]) * 16 + col) = make_uint2(q0, q1);
+            }
         }
         // ---- heads on the samples that carry weight (the test reads the weights where they are: zero outside lane groups 2, 3)
         if (__ballot(w > w_thresh)) {
@@ -1680,17 +1748,30 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
                     if (g == 0 && on[u]) {
-                        img[0] += w0[u] * sigmoid_f32(oa[u][0]);
-                        img[1] += w0[u] * sigmoid_f32(ob[u][0]);
+                        cr[u][0] = sigmoid_f32(oa[u][0]);
+                        cr[u][1] = sigmoid_f32(ob[u][0]);
+                        img[0] += w0[u] * cr[u][0];
+                        img[1] += w0[u] * cr[u][1];
                     }
             } else {
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
                     if (g == 0 && on[u]) {
 #pragma unroll
-                        for (int k = 0; k < 3; ++k) img[k] += w0[u] * sigmoid_f32(oa[u][k]);
+                        for (int k = 0; k < 3; ++k) {
+                            cr[u][k] = sigmoid_f32(oa[u][k]);
+                            img[k] += w0[u] * cr[u][k];
+                        }
                     }
             }
+        }
+        if constexpr (TRAIN) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (g == 0 && valid[u]) {
+#pragma unroll
+                    for (int k = 0; k < C; ++k) rt.rgb[(row0 + idx[u]) * C + k] = cr[u][k];
+                }
         }
         cur[0] = nxt[0];
         cur[1] = nxt[1];
@@ -1928,13 +2009,13 @@ NVSF_API int nvsf_render_occupancy_fwd(const float* rays_o, const float* rays_d,
     return nvsf_launch_status();
 }
 
-NVSF_API int nvsf_render_uniform_fwd(const float* rays_o, const float* rays_d, const float* nears, const float* fars, const float* lin,
-                                     const float* noise, const float* h_aabb, float bound, uint32_t N, uint32_t T, const void* table_f16,
-                                     uint32_t L, uint32_t F, const float* h_scales, const uint32_t* h_res, const uint32_t* h_offsets,
-                                     const void* sigma_weights_f16, int lidar, const void* head_a_weights_f16,
-                                     const void* head_b_weights_f16, float k_scale, float w_thresh, const float* h_bg_color,
-                                     const void* feat_scratch, float* z_vals, float* weights, float* weights_sum, float* depth, float* image,
-                                     hipStream_t stream) {
+static int render_uniform_impl(const float* rays_o, const float* rays_d, const float* nears, const float* fars, const float* lin,
+                               const float* noise, const float* h_aabb, float bound, uint32_t N, uint32_t T, const void* table_f16,
+                               uint32_t L, uint32_t F, const float* h_scales, const uint32_t* h_res, const uint32_t* h_offsets,
+                               const void* sigma_weights_f16, int lidar, const void* head_a_weights_f16,
+                               const void* head_b_weights_f16, float k_scale, float w_thresh, const float* h_bg_color,
+                               const void* feat_scratch, float* z_vals, float* weights, float* weights_sum, float* depth, float* image,
+                               hipStream_t stream, const RenderTrainOut* train) {
     if (N == 0 || T == 0) return NVSF_OK;
     REQUIRE(rays_o && rays_d && nears && fars && h_aabb && table_f16 && sigma_weights_f16 && head_a_weights_f16);
     REQUIRE(z_vals && weights && weights_sum && depth && image && (feat_scratch || lin));
@@ -1973,15 +2054,70 @@ NVSF_API int nvsf_render_uniform_fwd(const float* rays_o, const float* rays_d, c
     const int use_bg = (h_bg_color && !lidar) ? 1 : 0;
     const dim3 grid_dim(cdiv(N, kWavesPerBlock)), block(kBlock);
 #define LAUNCH_RU(LD, FF)                                                                                                             \
-    hipLaunchKernelGGL((k_render_uniform<LD, FF>), grid_dim, block, 0, stream, rb, tb, (uint32_t)table_bytes, meta, first_hashed, fp, ws, wa, \
-                       wb, k_scale, w_thresh, b0, b1, b2, use_bg, z_vals, weights, weights_sum, depth, image)
+    do {                                                                                                                              \
+        if (train)                                                                                                                    \
+            hipLaunchKernelGGL((k_render_uniform<LD, FF, true>), grid_dim, block, 0, stream, rb, tb, (uint32_t)table_bytes, meta,     \
+                               first_hashed, fp, ws, wa, wb, k_scale, w_thresh, b0, b1, b2, use_bg, z_vals, weights, weights_sum,     \
+                               depth, image, *train);                                                                                \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((k_render_uniform<LD, FF, false>), grid_dim, block, 0, stream, rb, tb, (uint32_t)table_bytes, meta,    \
+                               first_hashed, fp, ws, wa, wb, k_scale, w_thresh, b0, b1, b2, use_bg, z_vals, weights, weights_sum,     \
+                               depth, image, RenderTrainOut());                                                                      \
+    } while (0)
 #define LAUNCH_TAIL(LD)                                                                                                               \
-    hipLaunchKernelGGL((k_render_tail2<LD>), grid_dim, block, 0, stream, rb, fp, ws, wa, wb, k_scale, w_thresh, b0, b1, b2, use_bg, z_vals, \
-                       weights, weights_sum, depth, image)
+    do {                                                                                                                              \
+        if (train)                                                                                                                    \
+            hipLaunchKernelGGL((k_render_tail2<LD, true>), grid_dim, block, 0, stream, rb, fp, ws, wa, wb, k_scale, w_thresh, b0, b1, \
+                               b2, use_bg, z_vals, weights, weights_sum, depth, image, *train);                                      \
+        else                                                                                                                          \
+            hipLaunchKernelGGL((k_render_tail2<LD, false>), grid_dim, block, 0, stream, rb, fp, ws, wa, wb, k_scale, w_thresh, b0,    \
+                               b1, b2, use_bg, z_vals, weights, weights_sum, depth, image, RenderTrainOut());                        \
+    } while (0)
     const bool tail2 = nvsf_variant(kVarRenderTail) == 0;  // 1 (tests): one tile per iteration (k_render_uniform<*, true>)
     if (lidar) { if (fp) { if (tail2) LAUNCH_TAIL(true); else LAUNCH_RU(true, true); } else LAUNCH_RU(true, false); }
     else { if (fp) { if (tail2) LAUNCH_TAIL(false); else LAUNCH_RU(false, true); } else LAUNCH_RU(false, false); }
 #undef LAUNCH_TAIL
 #undef LAUNCH_RU
     return nvsf_launch_status();
+}
+
+NVSF_API int nvsf_render_uniform_fwd(const float* rays_o, const float* rays_d, const float* nears, const float* fars, const float* lin,
+                                     const float* noise, const float* h_aabb, float bound, uint32_t N, uint32_t T, const void* table_f16,
+                                     uint32_t L, uint32_t F, const float* h_scales, const uint32_t* h_res, const uint32_t* h_offsets,
+                                     const void* sigma_weights_f16, int lidar, const void* head_a_weights_f16,
+                                     const void* head_b_weights_f16, float k_scale, float w_thresh, const float* h_bg_color,
+                                     const void* feat_scratch, float* z_vals, float* weights, float* weights_sum, float* depth, float* image,
+                                     hipStream_t stream) {
+    return render_uniform_impl(rays_o, rays_d, nears, fars, lin, noise, h_aabb, bound, N, T, table_f16, L, F, h_scales, h_res, h_offsets,
+                               sigma_weights_f16, lidar, head_a_weights_f16, head_b_weights_f16, k_scale, w_thresh, h_bg_color, feat_scratch,
+                               z_vals, weights, weights_sum, depth, image, stream, nullptr);
+}
+
+// The TRAINING forward of a whole uniform render (ops.RenderRaysFn): nvsf_render_uniform_fwd's launch(es) -- with feat_scratch the
+// level-sliced encode pass runs first, here, and writes the positions -- that also keep what the backward of the render reads
+// (RenderTrainOut).  Same image / depth / weights as nvsf_render_uniform_fwd bit for bit.
+NVSF_API int nvsf_render_uniform_train_fwd(const float* rays_o, const float* rays_d, const float* nears, const float* fars, const float* lin,
+                                           const float* noise, const float* h_aabb, float bound, uint32_t N, uint32_t T,
+                                           const void* table_f16, uint32_t L, uint32_t F, const float* h_scales, const uint32_t* h_res,
+                                           const uint32_t* h_offsets, const void* sigma_weights_f16, int lidar,
+                                           const void* head_a_weights_f16, const void* head_b_weights_f16, float k_scale, float w_thresh,
+                                           const float* h_bg_color, void* feat_scratch, float* z_vals, float* weights, float* weights_sum,
+                                           float* depth, float* image, float* x01, void* feat_rows_f16, void* geo_f16, float* sigmas,
+                                           float* rgbs, hipStream_t stream) {
+    if (N == 0 || T == 0) return NVSF_OK;
+    REQUIRE(x01 && feat_rows_f16 && geo_f16 && sigmas && rgbs && lin);
+    REQUIRE((reinterpret_cast<uintptr_t>(feat_rows_f16) & 15u) == 0 && (reinterpret_cast<uintptr_t>(geo_f16) & 15u) == 0);
+    RenderTrainOut rt;
+    rt.x01 = x01; rt.feat = reinterpret_cast<_Float16*>(feat_rows_f16); rt.geo = reinterpret_cast<_Float16*>(geo_f16);
+    rt.sigma = sigmas; rt.rgb = rgbs;
+    if (feat_scratch) {  // level-sliced form: encode pass (positions, feature planes, z_vals), then the streaming tail
+        TrainOut tr;
+        tr.x01 = x01; tr.feat = rt.feat; tr.h32 = nullptr; tr.tile = nullptr;
+        const int st = density_uniform_impl(rays_o, rays_d, nears, fars, lin, noise, h_aabb, bound, N, T, table_f16, L, F, h_scales, h_res, h_offsets,
+                                            sigma_weights_f16, z_vals, sigmas, geo_f16, feat_scratch, 1u, stream, &tr);
+        if (st != NVSF_OK) return st;
+    }
+    return render_uniform_impl(rays_o, rays_d, nears, fars, lin, noise, h_aabb, bound, N, T, table_f16, L, F, h_scales, h_res, h_offsets,
+                               sigma_weights_f16, lidar, head_a_weights_f16, head_b_weights_f16, k_scale, w_thresh, h_bg_color, feat_scratch,
+                               z_vals, weights, weights_sum, depth, image, stream, &rt);
 }

@@ -82,6 +82,8 @@ SIGNATURES = {
     "nvsf_field_density_uniform_sliced_fwd": [_P, _P, _P, _P, _P, _P, _P, _F, _U, _U, _P, _U, _U, _P, _P, _P, _P, _P, _P, _P, _P, _U],
     "nvsf_render_uniform_fwd": [_P, _P, _P, _P, _P, _P, _P, _F, _U, _U, _P, _U, _U, _P, _P, _P, _P, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P,
                                 _P, _P],
+    "nvsf_render_uniform_train_fwd": [_P, _P, _P, _P, _P, _P, _P, _F, _U, _U, _P, _U, _U, _P, _P, _P, _P, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P,
+                                      _P, _P, _P, _P, _P, _P, _P],
     "nvsf_render_occupancy_fwd": [_P, _P, _P, _P, _P, _F, _F, _U, _U, _U, _U, _P, _U, _U, _P, _P, _P, _P, _I, _P, _P, _F, _F, _P, _P, _P, _P],
     "nvsf_field_heads_uniform_fwd": [_P, _P, _P, _P, _I, _P, _P, _U, _U, _F, _P, _P],
 }

@@ -797,6 +797,116 @@ class DensityRaysFn(Function):
         return (None,) * 8 + (g[0], None, None, g[3], None, None, None, None, None, None)
 
 
+def render_uniform_train_forward(rays_o, rays_d, nears, fars, T, aabb_host, bound, noise, table_f16, grid_spec, sigma_w16, lidar, head_a_w16,
+                                 head_b_w16, k_scale, bg_host, w_thresh, sliced):
+    """nvsf_render_uniform_train_fwd: rays -> z_vals, weights [N, T], weights_sum, depth [N], image [N, C] and what the backward of the
+    render reads: x01 [M, 3], feature rows [M, 32] fp16, geo16 [M, 16] fp16, sigma [M], masked per-sample colours [M, C].  `sliced`: the
+    level-sliced encode pass + streaming tail instead of the one-launch gather form; same values bit for bit."""
+    N, dev = rays_o.shape[0], rays_o.device
+    M, C = N * T, (2 if lidar else 3)
+    f32 = dict(dtype=torch.float32, device=dev)
+    z_vals, weights = torch.empty(N, T, **f32), torch.empty(N, T, **f32)
+    ws, depth, image = torch.empty(N, **f32), torch.empty(N, **f32), torch.empty(N, C, **f32)
+    x01, sigma, rgbs = torch.empty(M, 3, **f32), torch.empty(M, **f32), torch.empty(M, C, **f32)
+    feat = torch.empty(M, 32, dtype=torch.float16, device=dev)
+    geo16 = torch.empty(M, 16, dtype=torch.float16, device=dev)
+    planes = torch.empty(grid_spec.L, M, dtype=torch.int32, device=dev) if sliced else None
+    _hip.call("nvsf_render_uniform_train_fwd", _hip.ptr(rays_o), _hip.ptr(rays_d), _hip.ptr(nears), _hip.ptr(fars), _hip.ptr(linspace01(T, dev)),
+              _hip.ptr(noise), _hip.host_f32(aabb_host), float(bound), N, T, _hip.ptr(table_f16), grid_spec.L, grid_spec.F, grid_spec.h_scales,
+              grid_spec.h_res, grid_spec.h_offsets, _hip.ptr(sigma_w16), 1 if lidar else 0, _hip.ptr(head_a_w16), _hip.ptr(head_b_w16),
+              float(k_scale), float(w_thresh), _hip.host_f32(bg_host) if bg_host is not None else None, _hip.ptr(planes), _hip.ptr(z_vals),
+              _hip.ptr(weights), _hip.ptr(ws), _hip.ptr(depth), _hip.ptr(image), _hip.ptr(x01), _hip.ptr(feat), _hip.ptr(geo16), _hip.ptr(sigma),
+              _hip.ptr(rgbs))
+    return z_vals, weights, ws, depth, image, x01, feat, geo16, sigma, rgbs
+
+
+class RenderRaysFn(Function):
+    """The TRAINING forward of a whole uniform render of a static hash field from the rays, as ONE autograd node:
+    (rays, tables, MLP weights) -> z_vals [N, T], weights [N, T], weights_sum [N], depth [N], image [N, C]
+    (renderer_dynamic.py:155-237 with network_dynamic.py:213-330 inside).
+
+    Forward = the evaluation render's kernel(s) in their TRAIN form (nvsf_render_uniform_train_fwd: one launch, a wave per ray;
+    level-sliced encode pass + streaming tail for camera batches), which also keep what the backward reads: positions, feature
+    rows, sigma, geometry rows, masked per-sample colours -- 128 B per sample.  The operator chain it replaces (DensityRaysFn ->
+    CompositeWeightsFn -> mask / count -> HeadsFn x 1-2 -> MaskedSigmoidFn -> CompositeImageFn) runs the same arithmetic as seven
+    to nine launches that write and re-read the [M, 16] network outputs, the per-sample logits and the mask: 1.0 against 0.4 ms of
+    device time for a LiDAR batch of 4096 x 768.  Backward = the chain's backward kernels in the chain's order: image -> sigmoid ->
+    heads (fused data + weight gradients on shared-prefix rows) -> compositor -> density MLP -> table scatter (_density_backward:
+    side stream, gradient sink, level-major hand-over -- unchanged)."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, nears, fars, T, aabb_host, bound, noise, table_params, table_f16, grid_spec, sigma_params, sigma_w16,
+                sigma_spec, head_a_params, head_a_w16, head_b_params, head_b_w16, head_spec, enc_ray, n_enc, lidar, k_scale, bg_host, w_thresh,
+                sigma_lo, sigma_hi, sliced, train_ctx):
+        N, C = rays_o.shape[0], (2 if lidar else 3)
+        z_vals, weights, ws, depth, image, x01, feat, geo16, sigma, rgbs = render_uniform_train_forward(
+            rays_o, rays_d, nears, fars, T, aabb_host, bound, noise, table_f16, grid_spec, sigma_w16, lidar, head_a_w16, head_b_w16, k_scale, bg_host,
+            w_thresh, sliced)
+        ctx.save_for_backward(x01, feat, sigma, sigma_w16, geo16, rgbs, weights, z_vals, nears, fars, head_a_w16, head_b_w16, enc_ray)
+        ctx.dims = (N, T, C, int(n_enc), bool(lidar), float(k_scale), None if bg_host is None or lidar else tuple(float(v) for v in bg_host))
+        ctx.grid_spec, ctx.mlp_spec, ctx.head_spec, ctx.clamp = grid_spec, sigma_spec, head_spec, (float(sigma_lo), float(sigma_hi))
+        ctx.table_param, ctx.rows_per_ray, ctx.train_ctx = table_params, T, train_ctx
+        ctx.need_table, ctx.need_w = ctx.needs_input_grad[8], ctx.needs_input_grad[11]
+        ctx.need_heads = (ctx.needs_input_grad[14], ctx.needs_input_grad[16])
+        if train_ctx is not None and table_params is not None and table_params.requires_grad and torch.is_grad_enabled():
+            train_ctx.expect(table_params)
+        ctx.mark_non_differentiable(z_vals)
+        return z_vals, weights, ws, depth, image
+
+    @staticmethod
+    def backward(ctx, _g_z, g_weights, g_ws, g_depth, g_image):
+        import types
+        x01, feat, sigma, sigma_w16, geo16, rgbs, weights, z_vals, nears, fars, w16_a, w16_b, enc_ray = ctx.saved_tensors
+        N, T, C, n_enc, lidar, k_scale, bg = ctx.dims
+        M, dev = N * T, x01.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        c = lambda t: None if t is None else t.float().contiguous()
+        g_weights, g_ws, g_depth, g_image = c(g_weights), c(g_ws), c(g_depth), c(g_image)
+        # ---- image = sum_i w rgb (+ (1 - ws) bg)
+        g_w = g_ws_img = None
+        g_rgb = torch.zeros(M, C, **f32) if g_image is None else torch.empty(M, C, **f32)
+        if g_image is not None:
+            g_w = torch.empty(N, T, **f32)
+            g_ws_img = torch.empty(N, **f32) if bg is not None else None
+            _hip.call("nvsf_composite_uniform_image_bwd", _hip.ptr(weights), _hip.ptr(rgbs), _hip.ptr(g_image), N, T, C,
+                      _hip.ptr(device_constant(bg, dev)) if bg is not None else None, _hip.ptr(g_w), _hip.ptr(g_rgb), _hip.ptr(g_ws_img))
+        # ---- rgb = [w > thresh] sigmoid(logits): g rgb (1 - rgb) vanishes on the masked samples by itself
+        g_logits = torch.empty(M, C, **f32)
+        _hip.call("nvsf_sigmoid_bwd", _hip.ptr(g_rgb), _hip.ptr(rgbs), M * C, _hip.ptr(g_logits))
+        # ---- heads on shared-prefix rows (the encoded direction once per ray): data + weight gradients in one launch per head
+        hs = ctx.head_spec
+        n_geo = hs.n_in - n_enc
+        grad_geo = torch.empty(M, (n_geo + 3) // 4 * 4, **f32)[:, :n_geo]
+        prefix = (enc_ray, T, n_enc)
+        _, gw_a = mlp_backward(geo16, w16_a, hs, g_logits[:, :hs.n_out], need_grad_x=True, grad_x=grad_geo, gx_col0=n_enc, prefix=prefix)
+        gw_b = None
+        if lidar:
+            _, gw_b = mlp_backward(geo16, w16_b, hs, g_logits[:, hs.n_out:2 * hs.n_out], need_grad_x=True, grad_x=grad_geo, gx_col0=n_enc,
+                                   accumulate=True, prefix=prefix)
+        # ---- weights / weights_sum / depth from sigma
+        if g_w is not None and g_weights is not None:
+            g_w = g_w + g_weights
+        elif g_w is None:
+            g_w = g_weights
+        if g_ws_img is not None:
+            g_ws = g_ws_img if g_ws is None else g_ws + g_ws_img
+        g_sigma = torch.empty(N, T, **f32)
+        _hip.call("nvsf_composite_uniform_weights_bwd", _hip.ptr(sigma), _hip.ptr(z_vals), _hip.ptr(nears), _hip.ptr(fars), _hip.ptr(g_w), _hip.ptr(g_ws),
+                  _hip.ptr(g_depth), N, T, k_scale, _hip.ptr(g_sigma))
+        # ---- density MLP + table scatter: DensityFn's backward on what this node saved
+        dctx = types.SimpleNamespace(saved_tensors=(x01, feat, sigma, sigma_w16), mlp_spec=ctx.mlp_spec, clamp=ctx.clamp, grid_spec=ctx.grid_spec,
+                                     table_param=ctx.table_param, rows_per_ray=ctx.rows_per_ray, train_ctx=ctx.train_ctx, need_table=ctx.need_table,
+                                     need_w=ctx.need_w)
+        d = _density_backward(dctx, g_sigma.view(-1), grad_geo)  # (grad_table, None, None, grad_w_sigma, ...)
+        out = [None] * 29
+        out[8], out[11] = d[0], d[3]
+        if ctx.need_heads[0]:
+            out[14] = gw_a
+        if lidar and ctx.need_heads[1]:
+            out[16] = gw_b
+        return tuple(out)
+
+
 # ------------------------------------------------------------------------------------------------
 # K-planes (planes_field.py)
 # ------------------------------------------------------------------------------------------------

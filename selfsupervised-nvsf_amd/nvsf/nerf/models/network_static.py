@@ -84,6 +84,35 @@ class NeRFNetworkStatic(NeRFRenderer):
         return {"z_vals": z_vals, "sigma": sigma, "geo_feat": geo, "geo16": geo16}
 
     fused_train_forward = True  # False (tests): NeRFRenderer.run takes the operator chain (uniform_samples -> density)
+    fused_train_render = True   # False (tests): training forward as DensityRaysFn + compositor + heads nodes instead of ONE node
+
+    def render_from_rays_train(self, rays_o, rays_d, nears, fars, T, noise, cal_lidar_color, bg_host, **kwargs):
+        """The whole training forward of a ray batch as ONE autograd node (ops.RenderRaysFn: the evaluation render's kernels in their
+        TRAIN form; the chain's backward kernels).  Returns (z_vals, weights, weights_sum, depth, image) or None where the fused
+        kernels are not built (NeRFRenderer.run then composes DensityRaysFn / the operator chain)."""
+        enc = self.hash_encoder_lidar if cal_lidar_color else self.hash_encoder_camera
+        net = self.sigma_net
+        if cal_lidar_color:
+            head_a, head_b, venc = self.raydrop_net, self.intensity_net, self.view_encoder_lidar
+        else:
+            head_a, head_b, venc = self.color_net, None, self.view_encoder_camera
+        hs = head_a.spec
+        n_enc = venc.n_output_dims
+        if not (self.fused_train_forward and self.fused_train_render and rays_o.is_cuda and ops.render_uniform_eligible(enc.spec)
+                and net.spec.n_hidden == 1 and net.spec.hidden == 64 and net.spec.in_cols == 32 and net.spec.out_cols == 16
+                and hs.n_hidden == 2 and hs.n_in == n_enc + 15 and n_enc % 8 == 0 and T % 16 == 0
+                and (head_b is None or (head_b.spec.n_in == hs.n_in and head_b.spec.n_out == hs.n_out and head_b.spec.n_hidden == 2))):
+            return None
+        ray_length = float(self.lidar_max_depth - self.min_near_lidar) if cal_lidar_color else 2.0 * float(self.bound)
+        sliced = ops.prefer_sliced(enc.spec, rays_o.shape[0], T, ray_length, float(self.bound)) and T % 32 == 0
+        with torch.no_grad():  # per-ray direction encoding: the prefix rows the heads' backward reads
+            d01 = (rays_d + 1) / 2
+            enc_ray = ops.freq_encode(d01, venc.n_frequencies) if venc.otype == "Frequency" else ops.sh4_encode(d01)
+        return ops.RenderRaysFn.apply(rays_o, rays_d, nears, fars, int(T), self._aabb_host, float(self.bound), noise, enc.params, enc.table_f16(),
+                                      enc.spec, net.params, net.weights_f16(), net.spec, head_a.params, head_a.weights_f16(),
+                                      None if head_b is None else head_b.params, None if head_b is None else head_b.weights_f16(), hs, enc_ray,
+                                      n_enc, bool(cal_lidar_color), self._k_scale(), None if cal_lidar_color else bg_host, ops.W_THRESH,
+                                      activation._LO, activation._HI, bool(sliced), ops.train_context(self))
 
     def color(self, x, d, cal_lidar_color=False, mask=None, geo_feat=None, **kwargs):
         ray_dirs = kwargs.get("ray_dirs")  # [N, 3] from NeRFRenderer.run: d is these rows, each repeated for its ray's samples

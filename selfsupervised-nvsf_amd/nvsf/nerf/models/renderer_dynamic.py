@@ -251,10 +251,17 @@ class NeRFRenderer(nn.Module):
                 bg_host = [float(bg_color)] * self.out_dim
 
         fused = getattr(self, "fused_uniform_render", None)
+        rendered = None
         if fused is not None and not torch.is_grad_enabled():
             z_vals, weights, weights_sum, depth, image = fused(rays_o, rays_d, nears, fars, T, aabb, noise, cal_lidar_color,
                                                                bg_host, time=time, **kwargs)
         else:
+            whole = getattr(self, "render_from_rays_train", None)
+            rendered = whole(rays_o, rays_d, nears, fars, T, noise, cal_lidar_color, bg_host, **kwargs) if whole is not None else None
+        if rendered is not None:
+            # training forward of a field that renders a ray batch as ONE autograd node (network_static: ops.RenderRaysFn)
+            z_vals, weights, weights_sum, depth, image = rendered
+        elif fused is None or torch.is_grad_enabled():
             density_rays = getattr(self, "density_from_rays", None)
             density_outputs = density_rays(rays_o, rays_d, nears, fars, T, noise, cal_lidar_color, **kwargs) if density_rays is not None else None
             if density_outputs is not None:

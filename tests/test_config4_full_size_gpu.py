@@ -150,3 +150,38 @@ def test_full_size_sliced_training_forward_is_bit_identical(dev, setup):
         ia = a.view(torch.int16 if a.dtype == torch.float16 else torch.int32)
         ib = b.view(torch.int16 if b.dtype == torch.float16 else torch.int32)
         assert torch.equal(ia, ib), name
+
+
+@pytest.mark.parametrize("lidar", [False, True])
+def test_full_size_training_render_sliced_equals_one_launch_and_the_evaluation_render(dev, setup, lidar):
+    """ops.RenderRaysFn's forward (nvsf_render_uniform_train_fwd: what the default RenderTrainStep launches) at full size: the
+    level-sliced form (camera batches) == the one-launch form bit for bit on every output and on everything kept for the backward,
+    and image / depth / weights == the evaluation render's (nvsf_render_uniform_fwd), which is pinned to the oracle."""
+    from nvsf import field_ops as ops
+    from nvsf.nerf.raymarching import raymarching
+    S, m, batch = setup
+    enc, net = (m.hash_encoder_lidar, m.sigma_net) if lidar else (m.hash_encoder_camera, m.sigma_net)
+    sfx = "_lidar" if lidar else ""
+    rays_o, rays_d = batch["rays_o" + sfx][0].contiguous(), batch["rays_d" + sfx][0].contiguous()
+    if lidar:
+        nears = torch.full((N_RAYS,), float(m.min_near_lidar), device=dev)
+        fars = torch.full((N_RAYS,), float(m.lidar_max_depth), device=dev)
+        head_a, head_b, bg = m.raydrop_net.weights_f16(), m.intensity_net.weights_f16(), None
+    else:
+        nears, fars = raymarching.near_far_from_aabb(rays_o, rays_d, m.aabb_train, m.min_near)
+        head_a, head_b, bg = m.color_net.weights_f16(), None, [1.0, 1.0, 1.0]
+    g = torch.Generator(device=dev).manual_seed(4)
+    noise = torch.rand(N_RAYS, T, device=dev, generator=g)
+    outs = [ops.render_uniform_train_forward(rays_o, rays_d, nears, fars, T, m._aabb_host, float(S.BOUND), noise, enc.table_f16(), enc.spec,
+                                             net.weights_f16(), lidar, head_a, head_b, m._k_scale(), bg, ops.W_THRESH, sliced) for sliced in (False, True)]
+    torch.cuda.synchronize()
+    names = ("z_vals", "weights", "weights_sum", "depth", "image", "x01", "feat", "geo16", "sigma", "rgbs")
+    for name, a, b in zip(names, *outs):
+        assert a.dtype == b.dtype and a.shape == b.shape
+        bits = torch.int16 if a.dtype == torch.float16 else torch.int32
+        assert torch.equal(a.view(bits), b.view(bits)), name
+    ev = ops.render_uniform(rays_o, rays_d, nears, fars, T, m._aabb_host, float(S.BOUND), enc.table_f16(), enc.spec, net.weights_f16(), lidar, head_a,
+                            head_b, m._k_scale(), bg, noise, sliced=not lidar)
+    for name, a, b in zip(names[:5], outs[0][:5], ev):
+        assert torch.equal(a, b), name
+    assert float(outs[0][2].mean()) > 0.05 and bool((outs[0][9] > 0).any())  # not an empty render: some samples carry colour

@@ -539,13 +539,16 @@ def test_fused_training_forward_equals_operator_chain(dev):
     batch = _batch(S, teacher, dev, n=700, T=64, seed=2)
     noise = {True: torch.rand(700, 64, device=dev), False: torch.rand(700, 64, device=dev)}
     res = {}
-    for fused in (False, True):
+    # False: operator chain; True: DensityRaysFn + compositor / heads nodes; "render": the whole forward as ONE node (ops.RenderRaysFn:
+    # the evaluation render's kernels in their TRAIN form, the chain's backward kernels) -- what RenderTrainStep runs by default
+    for fused in (False, True, "render"):
         torch.manual_seed(9)
         m = NeRFNetworkStatic(**kw).to(dev)
         with torch.no_grad():
             for enc in (m.hash_encoder_lidar, m.hash_encoder_camera):
                 enc.params.normal_(0.0, 0.3)
-        m.fused_train_forward = fused
+        m.fused_train_forward = bool(fused)
+        m.fused_train_render = fused == "render"
         step = RenderTrainStep(m, num_steps=64, scale=S.SCALE, ema_decay=None)
         step.scaler = _LossScaler()(init_scale=64.0, growth_interval=10 ** 6)
         real_render, real_rand = m.render, torch.rand
@@ -563,19 +566,25 @@ def test_fused_training_forward_equals_operator_chain(dev):
         loss, parts, _ = step.step(batch)
         torch.cuda.synchronize()
         res[fused] = (float(loss), outs, {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.numel() and p.grad is not None})
-    assert abs(res[True][0] - res[False][0]) <= 1e-6 * abs(res[False][0])
-    for lidar in (True, False):
-        for k, v in res[False][1][lidar].items():
-            w = res[True][1][lidar][k]
-            assert v.shape == w.shape, k
-            if k == "z_vals":
-                assert torch.equal(v, w)
-            else:
-                assert float((v - w).abs().max()) <= 5e-6 * max(1.0, float(v.abs().max())), (lidar, k)
-    assert set(res[True][2]) == set(res[False][2]) and len(res[True][2]) == 6
-    for n, a in res[False][2].items():
-        b = res[True][2][n]
-        assert float(a.abs().max()) > 0 and float((a - b).abs().max()) <= 2e-5 * float(a.abs().max()), n
+    # the one-node render scans the transmittance 16 samples at a time and adds the direction-only part of the heads' first layer as
+    # the MFMA's C operand (the evaluation kernels' arithmetic, pinned to the oracle at 1e-4): outputs agree with the chain to fp32
+    # rounding, gradients to the rounding of the fp16 activations they pass through
+    for mode, out_tol, grad_tol in ((True, 5e-6, 2e-5), ("render", 2e-5, 1e-4)):
+        assert abs(res[mode][0] - res[False][0]) <= max(1e-6, out_tol) * abs(res[False][0]), mode
+        for lidar in (True, False):
+            for k, v in res[False][1][lidar].items():
+                w = res[mode][1][lidar][k]
+                assert v.shape == w.shape, k
+                if k == "z_vals":
+                    assert torch.equal(v, w)
+                else:
+                    assert float((v - w).abs().max()) <= out_tol * max(1.0, float(v.abs().max())), (mode, lidar, k)
+        assert set(res[mode][2]) == set(res[False][2]) and len(res[mode][2]) == 6
+        for n, a in res[False][2].items():
+            b = res[mode][2][n]
+            err = float((a - b).abs().max()) / float(a.abs().max())
+            assert float(a.abs().max()) > 0 and err <= grad_tol, (mode, n, err)
+            print(f"training forward {mode!r} vs chain: {n} max rel grad err {err:.2e}")
     # the level-sliced form of the training forward (what a camera batch of the full-size field takes): every output bit for bit
     # the one-launch form's
     torch.manual_seed(1)
