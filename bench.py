@@ -346,7 +346,9 @@ def train_kernel_rows(step, batch, M, n_steps=3):
         f = 2 * (64 * in_cols + 64 * 64 * (n_hidden - 1) + 16 * 64)
         return f * (3 if m.group(1) == "bwd" else 1)
 
-    streams = {"k_density_uniform_v2": (588 + 140, "588 + 140 B/sample (gathers, features, training outputs)"),
+    streams = {"k_render_uniform": (520 + 128, "520 + 128 B/sample (gathers, z, weights; positions, feature rows, geometry rows, sigma, colours kept for the "
+                                               "backward); sigma MLP + compositing + both heads in the same launch (51 200 FLOP/sample)"),
+               "k_density_uniform_v2": (588 + 140, "588 + 140 B/sample (gathers, features, training outputs)"),
                "k_encode_sliced_pairs": (580, "580 B/sample"), "k_density_from_features": (76 + 140, "216 B/sample"),
                "k_sigma_geo_bwd": (132, "132 B/sample"), "k_weights_fwd": (12, "12 B/sample"), "k_weights_bwd": (24, "24 B/sample"),
                "k_image_fwd": (16, "16 B/sample"), "k_image_bwd": (28, "28 B/sample"), "k_masked_sigmoid": (16, "16 B/sample"), "k_sigmoid_bwd": (24, "24 B/sample")}
@@ -361,6 +363,8 @@ def train_kernel_rows(step, batch, M, n_steps=3):
         ms = us / calls / 1e3
         row = {"kernel": short, "launches_per_step": calls / n_steps, "ms": ms, "share_of_kernel_time": us / total_us}
         fl = mlp_flops(name)
+        if fl is None and "k_render_tail2" in name:  # camera batch: sigma MLP + colour head on the feature planes of the encode pass
+            fl = 6144 + 14336
         if fl is not None:
             tf = fl * M / (ms * 1e-3) / 1e12
             row.update({"bound": "mfma", "unit": "TFLOP/s", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "frac": tf / MFMA_PEAK_TFLOPS, "per_unit": f"{fl} FLOP/sample"})
@@ -457,8 +461,11 @@ def train_leg(model, tl, tc, tm, T, steps, dev, dist):
             "kernels": kernels, "grads_match": grads_match,
             "steps": steps, "untimed_steps": n_spin, "allreduce_collectives_per_step": n_coll, "per_rank_ms_per_step": per_rank_ms, "allreduce": allreduce,
             "losses": "the reference's Trainer.train_step defaults: per-ray L1 range + MSE ray-drop + MSE intensity summed over rays, chamfer distance of the predicted point cloud, summed MSE RGB",
-            "path": "operator path (autograd) under GradScaler (dense fp16 feature gradients): HIP forward kernels; HIP backward for hash grid "
-                    "(fine levels: binned contributions summed in LDS; other levels: corner-parallel run-merging atomics), MLPs (fused data + weight gradients, shared aligned head input) and compositors"}
+            "path": "training forward of a ray batch as ONE autograd node (the evaluation render's kernels in TRAIN form: one launch for LiDAR, "
+                    "level-sliced encode + streaming tail for camera); backward: image / sigmoid / heads (wave-independent fused MLP backward) / "
+                    "compositor / density MLP kernels, table scatter on a side stream (levels 8-15: run sums through bins summed in LDS; levels 0-7: "
+                    "corner-parallel run-merging atomics); loss scaling with the overflow decision taken before the last scatter has finished, that "
+                    "table's Adam pass behind its scatter (nvsf/nerf/loss_scaler.py)"}
 
 
 def eval_leg(model, dev, T, frames, dist):
