@@ -556,6 +556,55 @@ def occupancy_leg(model_cls, dev, n_rays, steps):
     return out
 
 
+def reference_default_grid_leg(model_cls, dev, n_rays, T, steps):
+    """Secondary figure: the static field with the reference's DEFAULT hash grid (8 levels x 4 features, 512 -> 32768, T = 2^19,
+    main_nvsf.py:45-52) through the same fused render (level-sliced encode pass, one level per XCD, + streaming tail) and the same
+    training step as the headline's L16 F2 field.  Never `value`."""
+    from nvsf import synthetic as S
+    from nvsf.nerf.train_step import RenderTrainStep
+    torch.manual_seed(0)
+    m = model_cls(bound=S.BOUND, min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH, num_frames=S.NUM_FRAMES,
+                  n_levels_hash=8, n_features_per_level_hash=4, base_resolution=512, max_resolution=32768, log2_hashmap_size=19).to(dev).eval()
+    rng = np.random.default_rng(0)
+    lo, ld = S.lidar_rays(n_rays, rng)
+    co, cd = S.camera_rays(n_rays, rng)
+    tl = [torch.from_numpy(a).to(dev)[None] for a in (lo, ld)]
+    tc = [torch.from_numpy(a).to(dev)[None] for a in (co, cd)]
+    tm = torch.tensor([[0.5]], device=dev)
+
+    def render():
+        with torch.no_grad():
+            m.render(tl[0], tl[1], tm, cal_lidar_color=True, num_steps=T)
+            m.render(tc[0], tc[1], tm, cal_lidar_color=False, num_steps=T)
+    for _ in range(3):
+        render()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        render()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out = {"metric": "rendered rays/sec (LiDAR+cam), static field with the reference-default grid L8 F4", "value": 2 * n_rays / dt,
+           "ms_per_step": dt * 1e3, "path": "k_encode_sliced_f4 + k_render_tail2 per ray batch"}
+    g = torch.Generator(device="cpu").manual_seed(3)
+    batch = {"rays_o_lidar": tl[0], "rays_d_lidar": tl[1], "rays_o": tc[0], "rays_d": tc[1], "time": tm,
+             "gt_depth": torch.rand(1, n_rays, generator=g).to(dev) * 0.5, "gt_raydrop": (torch.rand(1, n_rays, generator=g) > 0.3).float().to(dev),
+             "gt_intensity": torch.rand(1, n_rays, generator=g).to(dev), "gt_rgb": torch.rand(1, n_rays, 3, generator=g).to(dev)}
+    m.train()
+    step = RenderTrainStep(m, num_steps=T, scale=S.SCALE)
+    for _ in range(3):
+        step.step(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step.step(batch)
+    step.sync()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out["train"] = {"value": 2 * n_rays / dt, "ms_per_step": dt * 1e3, "path": "RenderRaysFn (one node per ray batch) + binned table scatter + FusedAdam"}
+    return out
+
+
 def raymarching_leg(dev):
     """Secondary figure: every kernel of the raymarching extension against the HBM roofline at a
     size where the launch is not latency-bound (tools/bench_raymarching.py; at 4096 rays each of them moves < 1 MB).
@@ -896,6 +945,7 @@ def main():
         if not args.no_extra_legs and world == 1:  # secondary figures for BASELINE configs 3 and 5 (never `value`)
             line["occupancy"] = occupancy_leg(NeRFNetworkStatic, dev, args.num_rays, 10)
             line["dynamic"] = dynamic_leg(dev, args.num_rays, T, 3)
+            line["reference_default_grid"] = reference_default_grid_leg(NeRFNetworkStatic, dev, args.num_rays, T, 10)
             line["raymarching"] = raymarching_leg(dev)
             line["field_ops"] = field_ops_leg(dev, args.num_rays, T)
     if not args.no_extra_legs:

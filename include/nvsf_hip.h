@@ -413,7 +413,8 @@ int nvsf_field_density_uniform_fwd(const float* rays_o, const float* rays_d, con
  * compositing, masked colour, image), evaluation only: the whole render of a ray in one wave, ONE launch per batch.
  * Same arithmetic as nvsf_field_density_uniform_fwd -> nvsf_composite_uniform_weights_fwd ->
  * nvsf_field_heads_uniform_fwd, but sigma and the geometry features stay in registers (the three-kernel form writes
- * and re-reads 48 B per sample) and the transmittance product is scanned per 16 samples.  Requires L == 16, F == 2.
+ * and re-reads 48 B per sample) and the transmittance product is scanned per 16 samples.  Requires L == 16, F == 2, or
+ * L == 8, F == 4 (the reference's default grid, main_nvsf.py:45-52) with feat_scratch given (NVSF_ERR_UNSUPPORTED otherwise).
  * feat_scratch: NULL (the kernel gathers from the table itself) or the feature planes filled by
  * nvsf_field_density_uniform_sliced_fwd(passes = 1), which must also have written z_vals.
  * Outputs: z_vals, weights [N,T]; weights_sum, depth [N]; image [N,3] (+ (1 - weights_sum) * h_bg_color when
@@ -482,7 +483,9 @@ int nvsf_field_density_uniform_train_fwd(const float* rays_o, const float* rays_
  * feat_scratch: device buffer of 4 * L * N * T bytes (encoded features, written and read once).
  * passes: 3 = both launches; 1 = encode only (fills feat_scratch and z_vals), 2 = MLP only (reads feat_scratch) --
  * the split exists so that each launch can be timed on its own.
- * Requires L == 16, F == 2, N*T < 2^32; NVSF_ERR_UNSUPPORTED otherwise. */
+ * Requires L == 16, F == 2, N*T < 2^32 -- or L == 8, F == 4, N*T < 2^28: one level per XCD, the same planes by column pair
+ * (plane 2g = columns {2g, 2g+1, 2g+24, 2g+25}, plane 2g+1 = columns {2g+8, 2g+9, 2g+16, 2g+17} of the [32] feature row);
+ * NVSF_ERR_UNSUPPORTED otherwise. */
 int nvsf_field_density_uniform_sliced_fwd(const float* rays_o, const float* rays_d, const float* nears,
                                           const float* fars, const float* lin, const float* noise,
                                           const float* h_aabb, float bound, uint32_t N, uint32_t T,

@@ -688,6 +688,165 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Encode pass for the OTHER 32-feature shape: L = 8 levels of F = 4 features (the reference's default grid, main_nvsf.py:45-52:
+// 512 -> 32768, T = 2^19).  One LEVEL per workgroup group (= per XCD): with 4 MB per hashed level an XCD keeps gathering from the
+// table that fits its L2 -- the scheme of k_hashgrid_fwd_levels8, here from the RAYS (positions formed in registers, z_vals /
+// positions written by the group of level 0) and for dense or hashed levels.  Two lanes per sample (lane = 2 * sample + x-bit): a lane
+// gathers the four 8-byte entries with its x-bit; the even lane blends features 0, 1 and the odd lane features 2, 3, each over
+// all eight corners in the specification's order (the partner's half of every entry arrives by a quad swap): bit-identical to
+// encode_level<3, 4>.
+//
+// Where the features go: the row of a sample is 32 fp16 = 16 column PAIRS; for F = 2 pair v is level v, for F = 4 pair v is
+// features 2 (v & 1), 2 (v & 1) + 1 of level v >> 1.  The planes are laid out by pair exactly as k_encode_sliced_pairs lays them
+// out by level (plane 2g = pairs {g, g + 12}, plane 2g + 1 = pairs {g + 4, g + 8}), so every consumer of the planes -- the
+// streaming tails k_render_tail2 / k_render_uniform<*, true> / k_density_from_features, their permuted W0 fragments and the
+// TRAIN forms' feature rows -- is the same code for both shapes.  A lane stores its own pair (4 bytes) into its plane.
+__device__ __forceinline__ uint32_t pair_plane_dword(uint32_t v, uint32_t M, uint32_t s) {  // dword index of column pair v of sample s
+    const uint32_t vg = v & 3u, vq = v >> 2;
+    const uint32_t plane = 2u * vg + ((vq == 1u || vq == 2u) ? 1u : 0u), slot = vq >> 1;
+    return (plane * M + s) * 2u + slot;  // < 2^32: M < 2^28 is required by the launcher
+}
+
+template <bool UNIFORM_RAY>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_encode_sliced_f4(
+    RayBatch rb, const _Float16* __restrict__ table, uint32_t table_bytes, GridMeta meta, uint32_t first_hashed, uint32_t M,
+    float* __restrict__ z_vals, uint32_t* __restrict__ feat_dw, SlicePlan plan, float* __restrict__ x01 = nullptr) {
+    const uint32_t group = blockIdx.x & 7u, sb = blockIdx.x >> 3, n_sb = gridDim.x >> 3;
+    for (uint32_t item = 0; item < plan.n[group]; ++item) {
+    const uint32_t level = plan.slice[group][item], unit_begin = plan.begin[group][item], unit_end = plan.end[group][item];
+    SliceLevel<4> lv;
+    lv.scale = meta.scale[level];
+    lv.res = meta.res[level];
+    lv.res2 = meta.res[level] * meta.res[level];
+    lv.boff = meta.offset[level] * 8u;
+    lv.rows = meta.offset[level + 1] - meta.offset[level];
+    lv.hashed = level >= first_hashed;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(table), 0, (int)table_bytes, 0x00020000);
+    const int lane = lane_id();
+    const uint32_t xb = (uint32_t)(lane & 1), half_lane = (uint32_t)(lane >> 1);
+    const uint32_t pair = 2u * level + xb;  // this lane's column pair
+    const uint32_t n_units = unit_end;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(unit_begin + sb * kWavesPerBlock + (threadIdx.x >> 6)), wave_count = n_sb * kWavesPerBlock;
+    if (wave >= n_units) continue;
+    const uint32_t T = rb.T;
+    struct Unit {
+        uint32_t s, n;
+        bool in_range;
+        float near, far, lin, noise, o[3], d[3];
+    };
+    uint32_t ray = 0, first = 0, d_ray = 0, d_first = 0;
+    if constexpr (UNIFORM_RAY) {  // T % 32 == 0: a unit lies inside one ray; the cursor advances without a division
+        ray = (wave * 32u) / T;
+        first = wave * 32u - ray * T;
+        d_ray = (wave_count * 32u) / T;
+        d_first = wave_count * 32u - d_ray * T;
+    }
+    auto fetch = [&](uint32_t unit, uint32_t n_u, uint32_t i_u) {
+        Unit u;
+        const uint32_t s_raw = unit * 32u + half_lane;
+        uint32_t i;
+        if constexpr (UNIFORM_RAY) {
+            u.in_range = true;
+            u.s = s_raw;
+            u.n = n_u;
+            i = i_u + half_lane;
+        } else {
+            u.in_range = s_raw < M;
+            u.s = u.in_range ? s_raw : M - 1u;
+            u.n = u.s / T;
+            i = u.s - u.n * T;
+        }
+        u.near = rb.nears[u.n];
+        u.far = rb.fars[u.n];
+        u.lin = rb.lin[i];
+        u.noise = rb.noise ? rb.noise[u.s] : 0.5f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            u.o[k] = rb.rays_o[3 * (size_t)u.n + k];
+            u.d[k] = rb.rays_d[3 * (size_t)u.n + k];
+        }
+        return u;
+    };
+    Unit cur = fetch(wave, ray, first);
+    for (uint32_t unit = wave; unit < n_units; unit += wave_count) {
+        const bool more = unit + wave_count < n_units;
+        uint32_t ray_n = ray, first_n = first;
+        if constexpr (UNIFORM_RAY) {
+            if (more) {
+                ray_n = ray + d_ray;
+                first_n = first + d_first;
+                if (first_n >= T) {
+                    first_n -= T;
+                    ray_n += 1u;
+                }
+            }
+        }
+        const Unit nxt = fetch(more ? unit + wave_count : unit, ray_n, first_n);
+        ray = ray_n;
+        first = first_n;
+        const float range = cur.far - cur.near;
+        float z = cur.near + range * cur.lin;
+        if (rb.noise) z = z + (cur.noise - 0.5f) * (range / (float)T);
+        float x[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float p = cur.o[k] + cur.d[k] * z;
+            p = fminf(fmaxf(p, rb.lo[k]), rb.hi[k]);
+            x[k] = (p + rb.bound) * rb.inv_extent;
+        }
+        float frac[3];
+        uint32_t c[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float pos = fmaf(lv.scale, x[d], 0.5f);
+            const float fl = floorf(pos);
+            frac[d] = pos - fl;
+            c[d] = (uint32_t)(int32_t)fl;
+        }
+        uint32_t idx[4];
+        if (!lv.hashed) {  // block-uniform
+            const uint32_t b00 = c[0] + c[1] * lv.res + c[2] * lv.res2;
+            const uint32_t base[4] = {b00, b00 + lv.res, b00 + lv.res2, b00 + lv.res + lv.res2};
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const uint32_t v = base[p] + xb;
+                idx[p] = v >= lv.rows ? v - lv.rows : v;
+            }
+        } else {
+            const uint32_t hy0 = c[1] * 2654435761u, hy1 = hy0 + 2654435761u;
+            const uint32_t hz0 = c[2] * 805459861u, hz1 = hz0 + 805459861u;
+            const uint32_t yz[4] = {hy0 ^ hz0, hy1 ^ hz0, hy0 ^ hz1, hy1 ^ hz1};
+            const uint32_t mask = lv.rows - 1u;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) idx[p] = ((c[0] + xb) ^ yz[p]) & mask;
+        }
+        typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+        u2v raw[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) raw[p] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, lv.boff + (idx[p] << 3), 0, 0);
+        // this lane's feature pair of all eight corners: its own entries' dword, and the partner's (the corners with the other x-bit)
+        uint32_t mine[8];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const uint32_t own = xb ? raw[p][1] : raw[p][0], send = xb ? raw[p][0] : raw[p][1];
+            const uint32_t recv = quad_swap(send);
+            mine[2 * p] = xb ? recv : own;
+            mine[2 * p + 1] = xb ? own : recv;
+        }
+        const uint32_t packed = slice_blend(frac, mine);
+        if (cur.in_range) {
+            feat_dw[pair_plane_dword(pair, M, cur.s)] = packed;
+            if (level == 0u && xb == 0u) {
+                z_vals[cur.s] = z;
+                if (x01) { x01[3 * (size_t)cur.s] = x[0]; x01[3 * (size_t)cur.s + 1] = x[1]; x01[3 * (size_t)cur.s + 2] = x[2]; }
+            }
+        }
+        cur = nxt;
+    }
+    }
+}
+
 // Static balance of the encode pass (host).  Cost of a slice relative to the VALU work of streaming every sample through one XCD
 // (= 1; 0.16 ms for 3.1 M samples).  With c = res_l / T = the number of cells a step crosses at level l on a ray that spans the
 // box, the finer level of the slice costs fill(c) = 1 + 0.72 clamp((c - 0.3) / 0.72, 0, 1) + 0.25 max(0, c - 1): from c ~ 1 on
@@ -1845,11 +2004,24 @@ static int density_uniform_impl(const float* rays_o, const float* rays_d, const 
     const unsigned long long table_bytes = (unsigned long long)h_offsets[L] * F * sizeof(_Float16);
     if (sliced_passes) {
         const unsigned long long total = (unsigned long long)N * T;
-        if (!(F == 2 && L == 16 && monotone && table_bytes < (1ull << 31) && total < (1ull << 32))) return NVSF_ERR_UNSUPPORTED;
+        const bool f4 = F == 4 && L == 8;  // the reference-default shape: one level per XCD group (k_encode_sliced_f4), same planes
+        if (!(((F == 2 && L == 16) || f4) && monotone && table_bytes < (1ull << 31) && total < (f4 ? (1ull << 28) : (1ull << 32)))) return NVSF_ERR_UNSUPPORTED;
         REQUIRE(feat_scratch && (reinterpret_cast<uintptr_t>(feat_scratch) & 15u) == 0);
         const uint32_t M = (uint32_t)total;
         uint2* fp = reinterpret_cast<uint2*>(feat_scratch);
-        if (sliced_passes & 1u) {
+        if ((sliced_passes & 1u) && f4) {
+            const uint32_t units32 = (M + 31u) / 32u;
+            uint32_t ps = (units32 + kWavesPerBlock - 1) / kWavesPerBlock;
+            if (ps > 512u) ps = 512u;
+            const SlicePlan plan = slice_plan(units32, T, h_res, first_hashed, false);  // every group its own level
+            float* x01 = train ? train->x01 : nullptr;
+            if (T % 32u == 0u)
+                hipLaunchKernelGGL((k_encode_sliced_f4<true>), dim3(8u * ps), dim3(kBlock), 0, stream, rb, tb, (uint32_t)table_bytes, meta,
+                                   first_hashed, M, z_vals, reinterpret_cast<uint32_t*>(fp), plan, x01);
+            else
+                hipLaunchKernelGGL((k_encode_sliced_f4<false>), dim3(8u * ps), dim3(kBlock), 0, stream, rb, tb, (uint32_t)table_bytes, meta,
+                                   first_hashed, M, z_vals, reinterpret_cast<uint32_t*>(fp), plan, x01);
+        } else if (sliced_passes & 1u) {
             const uint32_t units32 = (M + 31u) / 32u;
             uint32_t ps = (units32 + kWavesPerBlock - 1) / kWavesPerBlock;
             if (ps > 512u) ps = 512u;  // 32 CUs per XCD x 8 resident workgroups x 2 (measured: 256 -> 512 gains 1.5 %)
@@ -1921,7 +2093,7 @@ NVSF_API int nvsf_field_density_uniform_train_fwd(const float* rays_o, const flo
                                                   void* feat_scratch, hipStream_t stream) {
     if (N == 0 || T == 0) return NVSF_OK;
     REQUIRE(x01 && feat_rows_f16 && h32 && (reinterpret_cast<uintptr_t>(feat_rows_f16) & 3u) == 0);
-    if (!(L == 16 && F == 2)) return NVSF_ERR_UNSUPPORTED;
+    if (!((L == 16 && F == 2) || (L == 8 && F == 4 && feat_scratch))) return NVSF_ERR_UNSUPPORTED;  // L8 F4: level-sliced form only
     TrainOut tr;
     tr.x01 = x01; tr.feat = reinterpret_cast<_Float16*>(feat_rows_f16); tr.h32 = h32;
     return density_uniform_impl(rays_o, rays_d, nears, fars, lin, noise, h_aabb, bound, N, T, table_f16, L, F, h_scales, h_res, h_offsets,
@@ -2024,7 +2196,9 @@ static int render_uniform_impl(const float* rays_o, const float* rays_d, const f
     REQUIRE((reinterpret_cast<uintptr_t>(table_f16) & 15u) == 0 && (reinterpret_cast<uintptr_t>(sigma_weights_f16) & 15u) == 0 &&
             (reinterpret_cast<uintptr_t>(head_a_weights_f16) & 15u) == 0 && (reinterpret_cast<uintptr_t>(head_b_weights_f16) & 15u) == 0 &&
             (reinterpret_cast<uintptr_t>(feat_scratch) & 15u) == 0);
-    if (F != 2 || L != 16) return NVSF_ERR_UNSUPPORTED;
+    // L16 F2 (BASELINE config 2): gathers in the render kernel or feature planes; L8 F4 (the reference-default grid): feature planes
+    // only -- the streaming tails read column pairs and do not know which shape produced them (k_encode_sliced_f4)
+    if (!((F == 2 && L == 16) || (F == 4 && L == 8 && feat_scratch))) return NVSF_ERR_UNSUPPORTED;
     GridMeta meta;
     const int st = fill_meta(meta, L, h_scales, h_res, h_offsets);
     if (st != NVSF_OK) return st;

@@ -758,7 +758,7 @@ def density_uniform_train_forward(rays_o, rays_d, nears, fars, T, aabb_host, bou
     x01 = torch.empty(M, 3, dtype=torch.float32, device=dev)
     feat = torch.empty(M, 32, dtype=torch.float16, device=dev)
     h32 = torch.empty(M, 16, dtype=torch.float32, device=dev)
-    planes = torch.empty(grid_spec.L, M, dtype=torch.int32, device=dev) if sliced else None
+    planes = torch.empty(16, M, dtype=torch.int32, device=dev) if sliced else None  # 8 planes of 8 bytes per sample
     _hip.call("nvsf_field_density_uniform_train_fwd", _hip.ptr(rays_o), _hip.ptr(rays_d), _hip.ptr(nears), _hip.ptr(fars),
               _hip.ptr(linspace01(T, dev)), _hip.ptr(noise), _hip.host_f32(aabb_host), float(bound), N, T, _hip.ptr(table_f16),
               grid_spec.L, grid_spec.F, grid_spec.h_scales, grid_spec.h_res, grid_spec.h_offsets, _hip.ptr(mlp_w16), _hip.ptr(z_vals),
@@ -810,7 +810,7 @@ def render_uniform_train_forward(rays_o, rays_d, nears, fars, T, aabb_host, boun
     x01, sigma, rgbs = torch.empty(M, 3, **f32), torch.empty(M, **f32), torch.empty(M, C, **f32)
     feat = torch.empty(M, 32, dtype=torch.float16, device=dev)
     geo16 = torch.empty(M, 16, dtype=torch.float16, device=dev)
-    planes = torch.empty(grid_spec.L, M, dtype=torch.int32, device=dev) if sliced else None
+    planes = torch.empty(16, M, dtype=torch.int32, device=dev) if sliced else None  # 8 planes of 8 bytes per sample
     _hip.call("nvsf_render_uniform_train_fwd", _hip.ptr(rays_o), _hip.ptr(rays_d), _hip.ptr(nears), _hip.ptr(fars), _hip.ptr(linspace01(T, dev)),
               _hip.ptr(noise), _hip.host_f32(aabb_host), float(bound), N, T, _hip.ptr(table_f16), grid_spec.L, grid_spec.F, grid_spec.h_scales,
               grid_spec.h_res, grid_spec.h_offsets, _hip.ptr(sigma_w16), 1 if lidar else 0, _hip.ptr(head_a_w16), _hip.ptr(head_b_w16),
@@ -1061,6 +1061,8 @@ def prefer_sliced(spec, N, T, ray_length, bound, coherent=False):
     host-side estimate of far - near.  `coherent`: the batch is a run of consecutive pixels of a frame (staged evaluation) --
     neighbouring rays then ask for neighbouring cells and the one-launch gather form finds them in L1 / L2 (measured on whole
     frames: 51.5 against 62.8 ms per frame, 19.4 against 15.9 frames/s).  Tests force either form (testing.variant(density_sliced=...))."""
+    if sliced_only(spec):  # L8 F4: the fused kernels exist in the level-sliced form only (one level per XCD)
+        return N * T < 2 ** 28
     if not (spec.L == 16 and spec.F == 2 and spec.D == 3 and N * T < 2 ** 32):
         return False
     forced = _testing.get("density_sliced")
@@ -1085,7 +1087,7 @@ def density_uniform(rays_o, rays_d, nears, fars, T, aabb_host, bound, table_f16,
         z_vals = torch.empty(N, T, dtype=torch.float32, device=dev)
         sigmas = torch.empty(N, T, dtype=torch.float32, device=dev)
         geo = torch.empty(N, T, 16, dtype=torch.float16, device=dev)
-        feat = torch.empty(spec.L, N * T, dtype=torch.int32, device=dev) if sliced else None
+        feat = torch.empty(16, N * T, dtype=torch.int32, device=dev) if sliced else None  # 8 planes of 8 bytes per sample
     args = (_hip.ptr(rays_o), _hip.ptr(rays_d), _hip.ptr(nears), _hip.ptr(fars),
             _hip.ptr(linspace01(T, dev)), _hip.ptr(noise), _hip.host_f32(aabb_host), float(bound), N, T, _hip.ptr(table_f16),
             spec.L, spec.F, spec.h_scales, spec.h_res, spec.h_offsets, _hip.ptr(sigma_weights_f16), _hip.ptr(z_vals),
@@ -1127,7 +1129,7 @@ def render_uniform(rays_o, rays_d, nears, fars, T, aabb_host, bound, table_f16, 
         ws = torch.empty(N, dtype=torch.float32, device=dev)
         depth = torch.empty(N, dtype=torch.float32, device=dev)
         image = torch.empty(N, 2 if lidar else 3, dtype=torch.float32, device=dev)
-        feat = torch.empty(spec.L, N * T, dtype=torch.int32, device=dev) if sliced else None
+        feat = torch.empty(16, N * T, dtype=torch.int32, device=dev) if sliced else None  # 8 planes of 8 bytes per sample
     if sliced and _stage != "tail":
         _hip.call("nvsf_field_density_uniform_sliced_fwd", _hip.ptr(rays_o), _hip.ptr(rays_d), _hip.ptr(nears), _hip.ptr(fars), _hip.ptr(lin),
                   _hip.ptr(noise), _hip.host_f32(aabb_host), float(bound), N, T, _hip.ptr(table_f16), spec.L, spec.F, spec.h_scales,
@@ -1145,8 +1147,15 @@ def render_uniform(rays_o, rays_d, nears, fars, T, aabb_host, bound, table_f16, 
     return z_vals, weights, ws, depth, image
 
 
-def render_uniform_eligible(spec):
-    return spec.D == 3 and spec.F == 2 and spec.L == 16
+def sliced_only(spec):
+    """The reference-default grid shape (8 levels x 4 features, main_nvsf.py:45-52): its encode pass (k_encode_sliced_f4) writes the
+    same feature planes as the L16 F2 pass, so the streaming render / density tails serve both; there is no one-launch gather form."""
+    return spec.D == 3 and spec.F == 4 and spec.L == 8
+
+
+def render_uniform_eligible(spec, n_samples=0):
+    """Grid shapes the fused render / training-forward kernels are built for (32 encoded features either way)."""
+    return spec.D == 3 and ((spec.F == 2 and spec.L == 16) or (sliced_only(spec) and n_samples < 2 ** 28))
 
 
 def occupancy_fused_eligible(spec):

@@ -73,7 +73,7 @@ class NeRFNetworkStatic(NeRFRenderer):
         then runs the operator chain through `density`)."""
         enc = self.hash_encoder_lidar if cal_lidar_color else self.hash_encoder_camera
         net = self.sigma_net
-        if not (self.fused_train_forward and rays_o.is_cuda and ops.render_uniform_eligible(enc.spec) and net.spec.n_hidden == 1
+        if not (self.fused_train_forward and rays_o.is_cuda and ops.render_uniform_eligible(enc.spec, rays_o.shape[0] * T) and net.spec.n_hidden == 1
                 and net.spec.hidden == 64 and net.spec.in_cols == 32 and net.spec.out_cols == 16):
             return None
         ray_length = float(self.lidar_max_depth - self.min_near_lidar) if cal_lidar_color else 2.0 * float(self.bound)
@@ -98,8 +98,8 @@ class NeRFNetworkStatic(NeRFRenderer):
             head_a, head_b, venc = self.color_net, None, self.view_encoder_camera
         hs = head_a.spec
         n_enc = venc.n_output_dims
-        if not (self.fused_train_forward and self.fused_train_render and rays_o.is_cuda and ops.render_uniform_eligible(enc.spec)
-                and net.spec.n_hidden == 1 and net.spec.hidden == 64 and net.spec.in_cols == 32 and net.spec.out_cols == 16
+        if not (self.fused_train_forward and self.fused_train_render and rays_o.is_cuda and ops.render_uniform_eligible(enc.spec, rays_o.shape[0] * T)
+                and (T % 32 == 0 or not ops.sliced_only(enc.spec)) and net.spec.n_hidden == 1 and net.spec.hidden == 64 and net.spec.in_cols == 32 and net.spec.out_cols == 16
                 and hs.n_hidden == 2 and hs.n_in == n_enc + 15 and n_enc % 8 == 0 and T % 16 == 0
                 and (head_b is None or (head_b.spec.n_in == hs.n_in and head_b.spec.n_out == hs.n_out and head_b.spec.n_hidden == 2))):
             return None
@@ -164,7 +164,7 @@ class NeRFNetworkStatic(NeRFRenderer):
         # host-side estimate of far - near: exact for LiDAR (constant range), the box side for camera rays (AABB exit)
         ray_length = float(self.lidar_max_depth - self.min_near_lidar) if cal_lidar_color else 2.0 * float(self.bound)
         sliced = ops.prefer_sliced(enc.spec, rays_o.shape[0], T, ray_length, float(self.bound), coherent=bool(kwargs.get("rays_in_image_order", False)))
-        if ops.render_uniform_eligible(enc.spec):
+        if ops.render_uniform_eligible(enc.spec, rays_o.shape[0] * T):
             # one launch per batch (plus the encode pass of the level-sliced path): sigma / geo never reach HBM
             if cal_lidar_color:
                 head_a, head_b = self.raydrop_net.weights_f16(), self.intensity_net.weights_f16()

@@ -111,7 +111,9 @@ def test_prefer_sliced_choice_and_rejections(dev):
     assert ops.prefer_sliced(spec, 4096, 768, 2.0 * S.BOUND, S.BOUND) is True       # camera batch of config 2
     assert ops.prefer_sliced(spec, 4096, 768, lidar_len, S.BOUND) is False           # LiDAR batch: < 1 finest cell per step
     assert ops.prefer_sliced(spec, 64, 64, 2.0 * S.BOUND, S.BOUND) is False          # too small to pay for two launches
-    small = ops.GridSpec(3, 8, 4, 19, 16, 1.5)
+    f4 = ops.GridSpec(3, 8, 4, 19, 16, 1.5)
+    assert ops.prefer_sliced(f4, 64, 64, lidar_len, S.BOUND) is True                 # L8 F4: fused kernels in the sliced form only (tests/test_l8f4_fused_gpu.py)
+    small = ops.GridSpec(3, 4, 8, 19, 16, 1.5)
     assert ops.prefer_sliced(small, 4096, 768, 2.0 * S.BOUND, S.BOUND) is False      # shape the sliced kernels are not built for
     # the C entry point rejects such a shape instead of silently running something else
     o, d, nears, fars = _batch(m, dev, False, 8, np.random.default_rng(1))

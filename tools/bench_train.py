@@ -8,7 +8,14 @@ from nvsf.nerf.models.network_static import NeRFNetworkStatic
 from nvsf.nerf.train_step import RenderTrainStep
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-m = NeRFNetworkStatic(bound=S.BOUND, min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH, num_frames=S.NUM_FRAMES).to(dev)
+GRID = {}
+if os.environ.get('GRID') == 'L8F4':  # the reference-default hash grid (main_nvsf.py:45-52) on the static field
+    GRID = dict(n_levels_hash=8, n_features_per_level_hash=4, base_resolution=512, max_resolution=32768, log2_hashmap_size=19)
+m = NeRFNetworkStatic(bound=S.BOUND, min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH, num_frames=S.NUM_FRAMES, **GRID).to(dev)
+if os.environ.get('NODE') == '0':     # training forward as DensityRaysFn + compositor + heads nodes instead of ONE node
+    m.fused_train_render = False
+if os.environ.get('FUSED') == '0':    # the operator chain
+    m.fused_train_forward = m.fused_train_render = False
 rng = np.random.default_rng(0)
 N, T = int(os.environ.get("N", 4096)), int(os.environ.get("T", 768))
 lo, ld = S.lidar_rays(N, rng); co, cd = S.camera_rays(N, rng)
