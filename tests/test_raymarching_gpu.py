@@ -432,8 +432,9 @@ def test_empty_inputs(rm, dev):
 def test_march_rays_train_expired_wait_is_reported(rm, dev, scene):
     """nvsf_march_rays_train_ws with a spin limit of one poll (test-only argument): the scanner finds no published sum at its first
     look, gives up, and every worker gives up on its prefix -- the launch terminates and marks counter[1] negative (include/nvsf_hip.h).
-    The operator must turn that into an exception: at once when it reads the counter back (force_all_rays / no mean_count), at the
-    next call or check_march_status() when it does not (mean_count > 0), and the un-read path must not hand garbage ranges to the
+    The operator must not hand such a call's samples on: when it reads the counter back (force_all_rays / no mean_count) it repeats the
+    call through the three-launch entry point (an exception if the flag was already set by the caller's counter); when it does not
+    (mean_count > 0) the next call or check_march_status() raises, and the un-read path must not hand garbage ranges to the
     compositor (`rays` rows stay (0, 0, 0))."""
     from nvsf import _hip
     n, max_steps = 4096, 256
@@ -448,9 +449,14 @@ def test_march_rays_train_expired_wait_is_reported(rm, dev, scene):
     ctr = torch.tensor([0, -2 ** 31], dtype=torch.int32, device=dev)
     with pytest.raises(_hip.NvsfHipError, match="expired"):
         rm.march_rays_train(to, td, 2.0, tb, 2, 128, tn, tf, ctr, -1, False, 128, True, 0, max_steps)
-    # read-back path
-    with pytest.raises(_hip.NvsfHipError, match="expired"):
-        rm.march_rays_train(to, td, 2.0, tb, 2, 128, tn, tf, None, -1, False, 128, True, 0, max_steps, "ws", 1)
+    # read-back path: the call is repeated through the reference-shaped three-launch entry point (no inter-workgroup waits) with a
+    # warning, and returns what that entry point returns
+    with pytest.warns(UserWarning, match="expired"):
+        got = rm.march_rays_train(to, td, 2.0, tb, 2, 128, tn, tf, None, -1, False, 128, True, 0, max_steps, "ws", 1)
+    want = rm.march_rays_train(to, td, 2.0, tb, 2, 128, tn, tf, None, -1, False, 128, True, 0, max_steps, "ref")
+    assert want[0].shape[0] > 0
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
     # no read-back (mean_count > 0): reported by the deferred check; the ranges handed on are empty, not garbage
     xyzs, dirs, deltas, rays = rm.march_rays_train(to, td, 2.0, tb, 2, 128, tn, tf, None, 4096, False, 128, False, 0, max_steps, "ws", 1)
     assert not rays.any()
