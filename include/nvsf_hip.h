@@ -171,6 +171,14 @@ int nvsf_hashgrid_fwd(const float* x, uint32_t M, uint32_t x_stride, const uint3
                       const void* table_f16, uint32_t L, uint32_t F, const float* h_scales, const uint32_t* h_res,
                       const uint32_t* h_offsets, void* out_f16, uint32_t out_stride, nvsf_stream_t stream);
 
+/* ref: the static hash encoder of the space-time field, hash_field.py:109-119 (tcnn HashGrid, D = 3, L = 8, F = 4, every level
+ * hashed), evaluated for the density tail of network_dynamic.py:273-287.  Same features as nvsf_hashgrid_fwd, stored LEVEL-MAJOR:
+ * out fp16 [L][M][F] (what nvsf_density_dynamic_lm_fwd reads).  x fp32 [M, x_stride >= 3], columns 0..2.  Other grid shapes:
+ * NVSF_ERR_UNSUPPORTED (use nvsf_hashgrid_fwd). */
+int nvsf_hashgrid_fwd_level_major(const float* x, uint32_t M, uint32_t x_stride, const void* table_f16, uint32_t L, uint32_t F,
+                                  const float* h_scales, const uint32_t* h_res, const uint32_t* h_offsets, void* out_f16,
+                                  nvsf_stream_t stream);
+
 /* gradient wrt the table: grad_table_f32[row*F+f] += w_corner * grad_out[m, l*F+f] (fp32 atomics; the
  * caller zero-initialises).  grad_out [M, go_stride] is fp16 (grad_is_f16 != 0) or fp32. */
 int nvsf_hashgrid_bwd(const float* x, uint32_t M, uint32_t x_stride, const uint32_t* cols, uint32_t D, uint32_t L,
@@ -393,6 +401,13 @@ int nvsf_density_dynamic_f16planes_fwd(const void* plane_s_f16, const void* plan
                                        const float* hash_d, const void* hash_1, int hash_1_is_f16, const void* hash_2,
                                        int hash_2_is_f16, uint32_t M, const void* sigma_weights_f16, float* out_h,
                                        float* sigmas, void* geo_f16, void* x_f16_out, nvsf_stream_t stream);
+
+/* ... and with the static hash features level-major, fp16 [8][M][4], as nvsf_hashgrid_fwd_level_major writes them (the row
+ * form costs its producer eight partial writes per 64-byte row).  Bit-identical outputs (network_dynamic.py:273-287). */
+int nvsf_density_dynamic_lm_fwd(const void* plane_s_f16, const void* plane_d_blended_f16, const void* hash_s_level_major_f16,
+                                const float* hash_d, const void* hash_1, int hash_1_is_f16, const void* hash_2,
+                                int hash_2_is_f16, uint32_t M, const void* sigma_weights_f16, float* out_h,
+                                float* sigmas, void* geo_f16, void* x_f16_out, nvsf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Section 4: fused kernels of the uniform-sampling render (BASELINE config 2 hot path).

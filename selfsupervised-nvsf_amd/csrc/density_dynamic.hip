@@ -23,6 +23,7 @@ struct DynFeat {
     const void* hash_2;
     int h1_f16, h2_f16;
     int planes_f16;  // plane_s / plane_d are fp16 [M,32] rows and plane_d is already the blend (nvsf_planes_multi_fwd, blend = 2)
+    int hash_s_lm;   // hash_s is level-major [8][M][4] (nvsf_hashgrid_fwd_level_major) instead of rows [M,32]
 };
 
 __device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
@@ -72,7 +73,14 @@ __global__ __launch_bounds__(kBlock) void k_density_dynamic(DynFeat f, uint32_t 
 #pragma unroll
             for (int j = 0; j < 8; ++j) xf[1][j] = (_Float16)(0.5f * a[j] + 0.25f * (b[j] + c[j]));
         }
-        xf[2] = *reinterpret_cast<const half8_t*>(f.hash_s + m * 32 + 8 * g);
+        if (f.hash_s_lm) {  // features 8g .. 8g + 7 = levels 2g, 2g + 1
+            typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+            const uint2 lo = reinterpret_cast<const uint2*>(f.hash_s)[(size_t)(2 * g) * M + m], hi = reinterpret_cast<const uint2*>(f.hash_s)[(size_t)(2 * g + 1) * M + m];
+            const u4v v = {lo.x, lo.y, hi.x, hi.y};
+            xf[2] = __builtin_bit_cast(half8_t, v);
+        } else {
+            xf[2] = *reinterpret_cast<const half8_t*>(f.hash_s + m * 32 + 8 * g);
+        }
         if (g < 3) {
             load8(f.hash_d + m * 24 + 8 * g, a);
             if (f.h1_f16) load8h(reinterpret_cast<const _Float16*>(f.hash_1) + m * 24 + 8 * g, b);
@@ -125,7 +133,7 @@ __global__ __launch_bounds__(kBlock) void k_density_dynamic(DynFeat f, uint32_t 
 #define REQUIRE(cond) do { if (!(cond)) return NVSF_ERR_INVALID_ARG; } while (0)
 
 static int density_dynamic_impl(const float* plane_s, const float* plane_d, const float* plane_1, const float* plane_2, int planes_f16,
-                                      const void* hash_s_f16, const float* hash_d, const void* hash_1, int hash_1_is_f16, const void* hash_2,
+                                      int hash_s_lm, const void* hash_s_f16, const float* hash_d, const void* hash_1, int hash_1_is_f16, const void* hash_2,
                                       int hash_2_is_f16, uint32_t M, const void* sigma_weights_f16, float* out_h, float* sigmas,
                                       void* geo_f16, void* x_f16_out, hipStream_t stream) {
     if (M == 0) return NVSF_OK;
@@ -139,6 +147,7 @@ static int density_dynamic_impl(const float* plane_s, const float* plane_d, cons
     f.hash_d = hash_d; f.hash_1 = hash_1; f.hash_2 = hash_2;
     f.h1_f16 = hash_1_is_f16; f.h2_f16 = hash_2_is_f16;
     f.planes_f16 = planes_f16;
+    f.hash_s_lm = hash_s_lm;
     const uint32_t n_tiles = (M + 15) / 16;
     const uint32_t blocks = n_tiles / kWavesPerBlock + 1 < 2048u ? n_tiles / kWavesPerBlock + 1 : 2048u;
     const _Float16* w = reinterpret_cast<const _Float16*>(sigma_weights_f16);
@@ -156,7 +165,7 @@ NVSF_API int nvsf_density_dynamic_fwd(const float* plane_s, const float* plane_d
                                       const void* hash_s_f16, const float* hash_d, const void* hash_1, int hash_1_is_f16, const void* hash_2,
                                       int hash_2_is_f16, uint32_t M, const void* sigma_weights_f16, float* out_h, float* sigmas,
                                       void* geo_f16, void* x_f16_out, hipStream_t stream) {
-    return density_dynamic_impl(plane_s, plane_d, plane_1, plane_2, 0, hash_s_f16, hash_d, hash_1, hash_1_is_f16, hash_2, hash_2_is_f16, M,
+    return density_dynamic_impl(plane_s, plane_d, plane_1, plane_2, 0, 0, hash_s_f16, hash_d, hash_1, hash_1_is_f16, hash_2, hash_2_is_f16, M,
                                 sigma_weights_f16, out_h, sigmas, geo_f16, x_f16_out, stream);
 }
 
@@ -168,6 +177,17 @@ NVSF_API int nvsf_density_dynamic_f16planes_fwd(const void* plane_s_f16, const v
                                                 void* geo_f16, void* x_f16_out, hipStream_t stream) {
     const float* ps = reinterpret_cast<const float*>(plane_s_f16);
     const float* pd = reinterpret_cast<const float*>(plane_d_blended_f16);
-    return density_dynamic_impl(ps, pd, pd, pd, 1, hash_s_f16, hash_d, hash_1, hash_1_is_f16, hash_2, hash_2_is_f16, M, sigma_weights_f16, out_h,
+    return density_dynamic_impl(ps, pd, pd, pd, 1, 0, hash_s_f16, hash_d, hash_1, hash_1_is_f16, hash_2, hash_2_is_f16, M, sigma_weights_f16, out_h,
                                 sigmas, geo_f16, x_f16_out, stream);
+}
+
+// ... and with the static hash features level-major, fp16 [8][M][4], as nvsf_hashgrid_fwd_level_major writes them.  Bit-identical outputs.
+NVSF_API int nvsf_density_dynamic_lm_fwd(const void* plane_s_f16, const void* plane_d_blended_f16, const void* hash_s_level_major_f16,
+                                         const float* hash_d, const void* hash_1, int hash_1_is_f16, const void* hash_2,
+                                         int hash_2_is_f16, uint32_t M, const void* sigma_weights_f16, float* out_h, float* sigmas,
+                                         void* geo_f16, void* x_f16_out, hipStream_t stream) {
+    const float* ps = reinterpret_cast<const float*>(plane_s_f16);
+    const float* pd = reinterpret_cast<const float*>(plane_d_blended_f16);
+    return density_dynamic_impl(ps, pd, pd, pd, 1, 1, hash_s_level_major_f16, hash_d, hash_1, hash_1_is_f16, hash_2, hash_2_is_f16, M,
+                                sigma_weights_f16, out_h, sigmas, geo_f16, x_f16_out, stream);
 }

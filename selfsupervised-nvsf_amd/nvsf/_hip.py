@@ -37,6 +37,7 @@ SIGNATURES = {
     "nvsf_composite_uniform_image_bwd": [_P, _P, _P, _U, _U, _U, _P, _P, _P, _P],
     # section 3: field operators
     "nvsf_hashgrid_fwd": [_P, _U, _U, _P, _U, _P, _U, _U, _P, _P, _P, _P, _U],
+    "nvsf_hashgrid_fwd_level_major": [_P, _U, _U, _P, _U, _U, _P, _P, _P, _P],
     "nvsf_hashgrid_bwd": [_P, _U, _U, _P, _U, _U, _U, _P, _P, _P, _P, _I, _U, _P],
     "nvsf_hashgrid_bwd_binned": [_P, _U, _U, _P, _U, _U, _U, _P, _P, _P, _P, _I, _U, _U, _P, _U, _U, _P, ctypes.c_size_t],
     "nvsf_freq_encode": [_P, _U, _U, _U, _P, _U],
@@ -70,6 +71,7 @@ SIGNATURES = {
     "nvsf_mse_sum_fwd": [_P, _P, _U, _F, _P],
     "nvsf_mse_sum_bwd": [_P, _P, _U, _F, _P, _P],
     "nvsf_density_dynamic_f16planes_fwd": [_P, _P, _P, _P, _P, _I, _P, _I, _U, _P, _P, _P, _P, _P],
+    "nvsf_density_dynamic_lm_fwd": [_P, _P, _P, _P, _P, _I, _P, _I, _U, _P, _P, _P, _P, _P],
     # section 5: ray generation
     "nvsf_lidar_rays": [_P, _P, _U, _U, _U, _F, _F, _F, _P, _P],
     "nvsf_camera_rays": [_P, _P, _U, _U, _F, _F, _F, _F, _P, _P],

@@ -49,6 +49,25 @@ class GridSpec:
         self.h_scales, self.h_res, self.h_offsets = _hip.host_f32(scales), _hip.host_u32(res), _hip.host_u32(offsets)
 
 
+def level_major_eligible(spec):
+    """Grids nvsf_hashgrid_fwd_level_major is built for: the static hash of the space-time field (3-D, 8 levels x 4 features, every
+    level hashed into a power-of-two table)."""
+    return (spec.D == 3 and spec.L == 8 and spec.F == 4 and spec.n_params * 2 < 2 ** 31
+            and all(int(r) ** 3 > (int(b) - int(a)) and ((int(b) - int(a)) & (int(b) - int(a) - 1)) == 0
+                    for r, a, b in zip(spec.res, spec.offsets[:-1], spec.offsets[1:])))
+
+
+def hashgrid_forward_level_major(x, table_f16, spec):
+    """x fp32 [M, >= 3] (columns 0..2) -> fp16 [L, M, F]: the features of hashgrid_forward stored level by level (the one-level-per-XCD
+    kernel then writes whole lines; density tail: nvsf_density_dynamic_lm_fwd).  No autograd."""
+    x = x.contiguous()
+    M = x.shape[0]
+    out = torch.empty(spec.L, M, spec.F, dtype=torch.float16, device=x.device)
+    _hip.call("nvsf_hashgrid_fwd_level_major", _hip.ptr(x), M, x.shape[1], _hip.ptr(table_f16), spec.L, spec.F, spec.h_scales, spec.h_res,
+              spec.h_offsets, _hip.ptr(out))
+    return out
+
+
 def hashgrid_forward(x, cols, table_f16, spec, out=None):
     """x fp32 [M, x_stride]; cols = the D columns of x to encode; table fp16 [n_params] -> fp16 [M, L*F]."""
     x = x.contiguous()

@@ -155,7 +155,13 @@ class HashGrid4D(nn.Module):
         total = (xy + xz) + yz
         return total / 3 if self.reduction == "mean" else total
 
-    def forward_static(self, x):
+    def forward_static(self, x, level_major=False):
+        """Static features [N, 32]; level_major=True (no autograd): fp16 [8, N, 4] where the encoder offers it -- the layout its
+        one-level-per-XCD kernel writes as whole lines and the fused density tail reads (network_dynamic._density_tail_fused)."""
+        if level_major:
+            out = self.hash_static.forward_level_major(x)
+            if out is not None:
+                return out
         return self.hash_static(x)
 
     def forward_dynamic(self, x, t, t_host=None, offset=None, offset_col=0):

@@ -134,7 +134,7 @@ class NeRFNetwork(NeRFRenderer):
         F = self.num_frames
         xt = torch.cat([x, t.float().expand(x.shape[0], 1)], dim=-1)
         flow = self.flow_net(xt, t_host, fp16=fp16)
-        hash_s = hash_enc.forward_static(x)
+        hash_s = hash_enc.forward_static(x, level_major=True)  # [8, M, 4] where available: _density_tail_fused reads either layout
         nb = []
         for col, frame in ((0, frame_idx + 1), (3, frame_idx - 1)):
             # 0-dim CPU tensor as in the reference (:244, :260): the fp16 regime of HashGridT
@@ -202,6 +202,10 @@ class NeRFNetwork(NeRFRenderer):
             if plane_d.dtype != torch.float16 or plane_1 is not plane_d or plane_2 is not plane_d:
                 raise ValueError("fp16 plane rows come blended (plane_1 = plane_2 = plane_d)")
             entry, planes = "nvsf_density_dynamic_f16planes_fwd", planes[:2]
+        if hash_s.dim() == 3:  # level-major static hash features (hash_field.forward_static(level_major=True))
+            if entry != "nvsf_density_dynamic_f16planes_fwd" or tuple(hash_s.shape) != (8, M, 4) or hash_s.dtype != torch.float16:
+                raise ValueError("level-major static hash features come as fp16 [8, M, 4] together with fp16 plane rows")
+            entry = "nvsf_density_dynamic_lm_fwd"
         args = planes + [_hip.ptr(c(hash_s)), _hip.ptr(c(hash_d)),
                          _hip.ptr(c(hash_1)), 1 if hash_1.dtype == torch.float16 else 0, _hip.ptr(c(hash_2)), 1 if hash_2.dtype == torch.float16 else 0,
                          M, _hip.ptr(self.sigma_net.weights_f16())]

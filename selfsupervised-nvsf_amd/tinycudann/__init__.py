@@ -93,6 +93,14 @@ class Encoding(nn.Module):
             return _ops.freq_encode(x, self.n_frequencies)
         return _ops.sh4_encode(x)
 
+    def forward_level_major(self, x):
+        """HashGrid, no autograd: the features of forward(x) stored level by level, fp16 [n_levels, M, n_features_per_level], or None
+        where that form is not built (ops.level_major_eligible).  Not part of tiny-cuda-nn's interface: the fused density tail of the
+        space-time field reads it (network_dynamic._density_tail_fused)."""
+        if self.otype not in ("HashGrid", "Grid") or torch.is_grad_enabled() or not x.is_cuda or x.dim() != 2 or not _ops.level_major_eligible(self.spec):
+            return None
+        return _ops.hashgrid_forward_level_major(x, self.table_f16(), self.spec)
+
     def encode_columns(self, x, cols):
         """HashGrid only: encode the columns `cols` of a wider coordinate matrix in place (no gather copy) --
         e.g. the (x, z) pair of an [N, 3] position tensor for a 2-D time-slice grid."""

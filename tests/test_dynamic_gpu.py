@@ -231,6 +231,11 @@ def test_fused_dynamic_features_equal_the_separate_launches(dev, flow_scale, t_v
         with torch.no_grad():
             feats = m._dynamic_features(m._unit_cube(x), t, True)
             dens = m.density(x, t, cal_lidar_color=True)
+        # the fused form takes the static hash features level-major, fp16 [8, M, 4] (nvsf_hashgrid_fwd_level_major): rows for the comparison
+        feats = [v.permute(1, 0, 2).reshape(v.shape[1], -1) if v.dim() == 3 else v for v in feats]
+        if mode == "1":
+            with torch.no_grad():
+                assert m.hash_encoder_lidar.forward_static(m._unit_cube(x), level_major=True).shape == (8, x.shape[0], 4)
         f = [v.float() for v in feats]
         # the fused form blends the K-planes neighbours inside its kernel (plane_d == plane_1 == plane_2 == the blend) and hands the
         # plane features over as fp16 rows: compare the blend network_dynamic.py:273 forms, rounded to fp16 as the density MLP

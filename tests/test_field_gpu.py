@@ -78,6 +78,30 @@ def test_hashgrid_forward_one_level_per_xcd_is_bit_identical(ops, dev, variants)
     assert np.array_equal(got.cpu().numpy()[rows].view(np.uint16), exp.view(np.uint16))
 
 
+@pytest.mark.parametrize("M", [(1 << 16) + 4099, 77, 1])
+def test_hashgrid_forward_level_major_holds_the_rows(ops, dev, M):
+    """nvsf_hashgrid_fwd_level_major: fp16 [L, M, F] with out[l, m, f] == rows[m, l F + f] bit for bit (any batch size, strided
+    input, boundary samples); grids it is not built for are refused (the caller keeps the row form)."""
+    from nvsf import _hip
+    spec = _spec(ops, 3, 8, 4, 19, 512, 32768)
+    rng = np.random.default_rng(9)
+    x = rng.random((M, 4)).astype(np.float32)
+    x[:min(M, 4), :3] = np.array([[0, 0, 0], [1, 1, 1], [1e-7, 1 - 1e-7, 0.25], [0.999999, 0.000001, 0.5]], np.float32)[:min(M, 4)]
+    table = (rng.standard_normal(spec.n_params) * 0.5).astype(np.float16)
+    xd, td = _t(x, dev), _t(table, dev)
+    assert ops.level_major_eligible(spec)
+    lm = ops.hashgrid_forward_level_major(xd, td, spec)
+    assert lm.shape == (8, M, 4) and lm.dtype == torch.float16
+    rows = ops.hashgrid_forward(xd, (0, 1, 2), td, spec)
+    assert torch.equal(lm.permute(1, 0, 2).reshape(M, 32).view(torch.int16), rows.view(torch.int16))
+    exp = O.hashgrid_fwd(x[:64], (0, 1, 2), table, spec)
+    assert np.array_equal(rows.cpu().numpy()[:64].view(np.uint16), exp.view(np.uint16))
+    for other in (_spec(ops, 3, 16, 2, 19, 16, 2048), _spec(ops, 3, 8, 4, 19, 16, 2048)):  # another shape; dense coarse levels
+        assert not ops.level_major_eligible(other)
+        with pytest.raises(_hip.NvsfHipError):
+            ops.hashgrid_forward_level_major(xd, torch.zeros(other.n_params, dtype=torch.float16, device=dev), other)
+
+
 def test_hashgrid_level_table_matches_published_rules(ops):
     spec = _spec(ops, 3, 16, 2, 19, 16, 2048)
     assert spec.res[0] == 16 and spec.res[-1] == 2048
