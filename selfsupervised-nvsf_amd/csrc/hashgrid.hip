@@ -474,8 +474,11 @@ __global__ __launch_bounds__(kBlock) void k_hashgrid_bwd_bin(const float* __rest
                     if (lvl_hashed) {
                         row = (tx[c & 1] ^ ty[(c >> 1) & 1] ^ tz[c >> 2]) & (hsize - 1u);  // hashed levels are powers of two (host)
                     } else {
-                        row = tx[c & 1] + ty[(c >> 1) & 1] + tz[c >> 2];  // < 2 hsize
-                        row = row >= hsize ? row - hsize : row;
+                        row = tx[c & 1] + ty[(c >> 1) & 1] + tz[c >> 2];  // < 2 hsize for a position inside the unit cube
+                        if (row >= hsize) {
+                            row -= hsize;
+                            if (row >= hsize) row %= hsize;  // a position outside [0, 1]^3 (any cell index): grid_row's general modulo
+                        }
                     }
                     const uint32_t rank = atomicAdd(&s_cnt[row >> C::kBinShift], 1u);
                     pk[s][c] = row | (rank << 20);

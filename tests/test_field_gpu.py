@@ -152,6 +152,32 @@ def test_hashgrid_backward_kernels_agree_with_the_oracle(ops, dev, D, L, F, log2
         np.testing.assert_allclose(got, ref, atol=5e-4, rtol=1e-4)  # fp32 atomics: order-dependent rounding
 
 
+@pytest.mark.parametrize("form", ["atomic", "corners", "binned"])
+def test_hashgrid_backward_positions_outside_the_unit_cube(ops, dev, form, variants):
+    """tiny-cuda-nn wraps ANY cell index into the level's table (index modulo size), so a position outside [0, 1]^3 -- a flow-warped
+    neighbour position, a caller that does not normalise -- scatters to some in-range row instead of faulting.  Every form of the table
+    gradient does the same as the oracle for positions in [-0.4, 1.5]^3, dense levels (whose one-subtraction wrap only covers the unit
+    cube) included."""
+    spec = _spec(ops, 3, 16, 2, 14, 16, 512)
+    rng = np.random.default_rng(77)
+    n_rays, T = 33, 96
+    o = rng.random((n_rays, 1, 3)) * 1.9 - 0.4
+    d = rng.standard_normal((n_rays, 1, 3))
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    x = (o + d * np.linspace(0.0, 0.3, T).reshape(1, T, 1)).reshape(-1, 3).astype(np.float32)
+    assert (x < 0).any() and (x > 1).any()
+    go = rng.standard_normal((x.shape[0], spec.L * spec.F)).astype(np.float32)
+    ref = O.hashgrid_bwd(x, (0, 1, 2), spec, go)
+    if form == "binned":
+        got = ops.hashgrid_backward(_t(x, dev), (0, 1, 2), spec, _t(go, dev), fine_from=(0, 16))
+    else:
+        variants.set(hashgrid_bwd=form)
+        got = ops.hashgrid_backward(_t(x, dev), (0, 1, 2), spec, _t(go, dev))
+    np.testing.assert_allclose(got.cpu().numpy(), ref, atol=5e-4, rtol=1e-4)
+    fwd = ops.hashgrid_forward(_t(x, dev), (0, 1, 2), _t((rng.standard_normal(spec.n_params) * 0.5).astype(np.float16), dev), spec)
+    assert bool(torch.isfinite(fwd.float()).all())
+
+
 @pytest.mark.parametrize("L,F,log2_T,base,top,fine_from,merge_from", [
     (16, 2, 14, 16, 512, 12, 12), (16, 2, 14, 16, 512, 5, 5), (8, 4, 12, 16, 256, 4, 4), (8, 4, 13, 64, 1024, 0, 0),
     (16, 2, 14, 16, 512, 12, 0), (16, 2, 14, 16, 512, 9, 3), (8, 4, 12, 16, 256, 6, 0), (16, 2, 14, 16, 512, 16, 0)])
