@@ -20,7 +20,7 @@ __global__ __launch_bounds__(kBlock) void k_hashgrid_fwd(const float* __restrict
     // staging tile [64 samples][L*F/2 + 1] dwords (half2 granularity; the odd row stride keeps the
     // per-lane b32 writes and the row-major b32 read-back free of bank conflicts)
     extern __shared__ uint32_t stage[];
-    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform by construction: level tables, pointers and loop control in SGPRs
     const uint32_t m = blockIdx.x * kSamplesPerBlock + lane;
     const uint32_t row_dw = L * F / 2, row_pitch = row_dw + 1;
     float xs[D];

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(kBlock) void k_hash_dynamic(const float* __restrict
                                                          uint32_t off_stride, uint32_t off_col, uint32_t M, PlaneSet ps,
                                                          void* __restrict__ out) {
     __shared__ float stage[kSamplesPerBlock][3 * kPlaneLevels + 1];
-    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform by construction: level tables, pointers and loop control in SGPRs
     const uint32_t m = blockIdx.x * kSamplesPerBlock + lane;
     const uint32_t mm = m < M ? m : M - 1;
     float p[3];
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kBlock) void k_hash_dynamic3(const float* __restric
                                                           uint32_t off_stride, uint32_t M, PlaneSet3 ps, float* __restrict__ out0,
                                                           _Float16* __restrict__ out1, _Float16* __restrict__ out2) {
     __shared__ float stage[3][kSamplesPerBlock][3 * kPlaneLevels + 1];
-    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform by construction: level tables, pointers and loop control in SGPRs
     const uint32_t xb = (uint32_t)(lane & 1);
     float p[2][3][3];  // [pass][evaluation][axis]
 #pragma unroll
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(kBlock) void k_hash3d_lagrange(const float* __restr
                                                             const _Float16* __restrict__ table, uint32_t L, GridMeta meta, float w0, float w1,
                                                             float w2, float w3, float* __restrict__ out) {
     extern __shared__ float stage_dyn[];  // [64][2L + 1]
-    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6);
+    const int lane = lane_id(), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform by construction: level tables, pointers and loop control in SGPRs
     const uint32_t m = blockIdx.x * kSamplesPerBlock + lane;
     const uint32_t mm = m < M ? m : M - 1;
     const uint32_t pitch = 2 * L + 1;
