@@ -459,7 +459,7 @@ int nvsf_render_uniform_train_fwd(const float* rays_o, const float* rays_d, cons
                                   void* geo_f16, float* sigmas, float* rgbs, nvsf_stream_t stream);
 
 /* ref: the evaluation-mode protocol of the raymarching extension, raymarching.py:389-409 (march_rays) + 480-493
- * (composite_rays) around the field, for a static hash field (L*F = 32, F = 2): ONE launch instead of the host
+ * (composite_rays) around the field, for a static hash field (L*F = 32 with F = 2 or F = 4): ONE launch instead of the host
  * loop over surviving rays.  Per ray: march through the occupancy bit field `grid` (layout of nvsf_march_rays),
  * field on every sample (sigma = exp(h0) * density_scale; colour = sigmoid(heads), LiDAR: raydrop, intensity),
  * alpha compositing in sample order, stop at the first sample whose incoming transmittance < T_thresh, at `far`,

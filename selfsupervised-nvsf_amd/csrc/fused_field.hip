@@ -140,6 +140,15 @@ template <>
 __device__ __forceinline__ uint32_t gather_raw<2>(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
     return __builtin_amdgcn_raw_buffer_load_b32(rsrc, byte_off, 0, 0);
 }
+// F = 4: a table entry is 8 bytes (two dwords of two fp16 features), one 8-byte gather
+typedef uint32_t entry4_t __attribute__((ext_vector_type(2)));
+template <int F> struct EntryOf { typedef uint32_t type; };
+template <> struct EntryOf<4> { typedef entry4_t type; };
+template <>
+__device__ __forceinline__ uint32_t gather_raw<4>(__amdgpu_buffer_rsrc_t, uint32_t) = delete;
+__device__ __forceinline__ entry4_t gather_raw4(__amdgpu_buffer_rsrc_t rsrc, uint32_t byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b64(rsrc, byte_off, 0, 0);
+}
 
 // Per-wave constants of the v2 kernel: level table slice, permuted W0 fragment, rotated output fragment.
 template <int F>
@@ -182,7 +191,7 @@ __device__ __forceinline__ half8_t density_encode(const DensityCtx<F>& cx, const
 #pragma unroll
     for (int q0 = 0; q0 < Q; q0 += QG) {
     float frac[Q][3];
-    uint32_t raw[Q][8];
+    typename EntryOf<F>::type raw[Q][8];
 #pragma unroll
     for (int q = q0; q < q0 + QG; ++q) {
         uint32_t c[3];
@@ -219,21 +228,38 @@ __device__ __forceinline__ half8_t density_encode(const DensityCtx<F>& cx, const
             }
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) raw[q][k] = gather_raw<F>(cx.rsrc, lv.boff[q] + idx[k] * (uint32_t)(F * sizeof(_Float16)));
+        for (int k = 0; k < 8; ++k) {
+            if constexpr (F == 2) raw[q][k] = gather_raw<2>(cx.rsrc, lv.boff[q] + idx[k] * (uint32_t)(F * sizeof(_Float16)));
+            else raw[q][k] = gather_raw4(cx.rsrc, lv.boff[q] + idx[k] * (uint32_t)(F * sizeof(_Float16)));
+        }
     }
     // phase 2: trilinear blend (corner order and fma chain of the specification)
 #pragma unroll
     for (int q = q0; q < q0 + QG; ++q) {
         const float fx = frac[q][0], fy = frac[q][1], fz = frac[q][2];
         const float wx[2] = {1.0f - fx, fx}, wy[2] = {1.0f - fy, fy}, wz[2] = {1.0f - fz, fz};
-        float a0 = 0.0f, a1 = 0.0f;
+        if constexpr (F == 2) {
+            float a0 = 0.0f, a1 = 0.0f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float w = (wx[k & 1] * wy[(k >> 1) & 1]) * wz[k >> 2];
-            fma_entry(w, raw[q][k], a0, a1);
+            for (int k = 0; k < 8; ++k) {
+                const float w = (wx[k & 1] * wy[(k >> 1) & 1]) * wz[k >> 2];
+                fma_entry(w, raw[q][k], a0, a1);
+            }
+            xf[q * F] = (_Float16)a0;
+            xf[q * F + 1] = (_Float16)a1;
+        } else {
+            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float w = (wx[k & 1] * wy[(k >> 1) & 1]) * wz[k >> 2];
+                fma_entry(w, raw[q][k][0], a0, a1);
+                fma_entry(w, raw[q][k][1], a2, a3);
+            }
+            xf[q * F] = (_Float16)a0;
+            xf[q * F + 1] = (_Float16)a1;
+            xf[q * F + 2] = (_Float16)a2;
+            xf[q * F + 3] = (_Float16)a3;
         }
-        xf[q * F] = (_Float16)a0;
-        xf[q * F + 1] = (_Float16)a1;
     }
     }
     return xf;
@@ -1155,7 +1181,9 @@ struct OccFrags {
     static constexpr int kPre = kHeads * 16;                   // float4 per wave: the per-ray part of the first layer (ray_head_constants)
 };
 
-template <bool LIDAR>
+// F: features per level of the grid whose encode fills the sigma net's B fragment IN THIS KERNEL (density_encode<F>: fragment
+// element q F + f of lane group g = feature (4 q + g) F + f); the kernels that read feature planes use F = 2 (column pairs).
+template <bool LIDAR, int F = 2>
 __device__ __forceinline__ half8_t occ_fragment(int f, int lane, const _Float16* __restrict__ w_sigma, const _Float16* __restrict__ w_a,
                                                 const _Float16* __restrict__ w_b) {
     using FR = OccFrags<LIDAR>;
@@ -1164,10 +1192,17 @@ __device__ __forceinline__ half8_t occ_fragment(int f, int lane, const _Float16*
     if (f < 4) {
         const _Float16* row = w_sigma + (size_t)(16 * f + sl) * 32;
         half8_t v;
+        if constexpr (F == 2) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            v[2 * q] = row[(4 * q + g) * 2];
-            v[2 * q + 1] = row[(4 * q + g) * 2 + 1];
+            for (int q = 0; q < 4; ++q) {
+                v[2 * q] = row[(4 * q + g) * 2];
+                v[2 * q + 1] = row[(4 * q + g) * 2 + 1];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8 / F; ++q)
+#pragma unroll
+                for (int e = 0; e < F; ++e) v[q * F + e] = row[(4 * q + g) * F + e];
         }
         return v;
     }
@@ -1206,7 +1241,7 @@ __device__ __forceinline__ void ray_head_constants(const half8_t* xf, const _Flo
     }
 }
 
-template <bool LIDAR>
+template <bool LIDAR, int F = 2>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_render_occupancy_lds(OccRays rr, const _Float16* __restrict__ table, uint32_t table_bytes,
                                                                  GridMeta meta, uint32_t first_hashed, const _Float16* __restrict__ w_sigma,
                                                                  const _Float16* __restrict__ w_a, const _Float16* __restrict__ w_b,
@@ -1214,7 +1249,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 4))) 
                                                                  float* __restrict__ weights_sum, float* __restrict__ depth,
                                                                  float* __restrict__ image) {
     using FR = OccFrags<LIDAR>;
-    constexpr int F = 2;
     constexpr int IN_STEPS = FR::IN_STEPS;
     __shared__ uint4 s_lv[kMaxLevels];
     __shared__ half8_t s_frag[FR::kCount * kWave];
@@ -1228,7 +1262,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 4))) 
     }
     if (threadIdx.x < kLutH) s_lut[threadIdx.x] = spread3(threadIdx.x);
     const int lane = lane_id(), g = lane >> 4, sl = lane & 15;
-    for (int f = (int)(threadIdx.x >> 6); f < FR::kCount; f += kWavesPerBlock) s_frag[f * kWave + lane] = occ_fragment<LIDAR>(f, lane, w_sigma, w_a, w_b);
+    for (int f = (int)(threadIdx.x >> 6); f < FR::kCount; f += kWavesPerBlock) s_frag[f * kWave + lane] = occ_fragment<LIDAR, F>(f, lane, w_sigma, w_a, w_b);
     __syncthreads();
     const uint32_t n = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
     if (n >= rr.N) return;
@@ -1339,7 +1373,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 4))) 
         const uint32_t cnt = __builtin_amdgcn_readfirstlane(count);
         if (cnt == 0u) break;
         const float x01[3] = {(sx + rr.bound) / extent, (sy + rr.bound) / extent, (sz + rr.bound) / extent};
-        const half8_t feat = density_encode<F, 4, true>(cx, x01);
+        const half8_t feat = density_encode<F, 8 / F, true>(cx, x01);
         float4_t o;
         {
             float4_t acc1[kHidTiles];
@@ -2148,7 +2182,7 @@ NVSF_API int nvsf_render_occupancy_fwd(const float* rays_o, const float* rays_d,
     REQUIRE(bound > 0.0f && C >= 1 && C <= 8 && H >= 2 && H <= 1024 && max_steps >= 1);
     REQUIRE((reinterpret_cast<uintptr_t>(table_f16) & 15u) == 0 && (reinterpret_cast<uintptr_t>(sigma_weights_f16) & 15u) == 0 &&
             (reinterpret_cast<uintptr_t>(head_a_weights_f16) & 15u) == 0 && (reinterpret_cast<uintptr_t>(head_b_weights_f16) & 15u) == 0);
-    if (F != 2 || L * F != 32) return NVSF_ERR_UNSUPPORTED;
+    if ((F != 2 && F != 4) || L * F != 32) return NVSF_ERR_UNSUPPORTED;  // 16 levels x 2 (BASELINE config 2) or 8 x 4 (the reference default)
     GridMeta meta;
     const int st = fill_meta(meta, L, h_scales, h_res, h_offsets);
     if (st != NVSF_OK) return st;
@@ -2172,12 +2206,12 @@ NVSF_API int nvsf_render_occupancy_fwd(const float* rays_o, const float* rays_d,
     const _Float16* wb = reinterpret_cast<const _Float16*>(head_b_weights_f16);
     const float b0 = h_bg_color ? h_bg_color[0] : 0.0f, b1 = h_bg_color ? h_bg_color[1] : 0.0f, b2 = h_bg_color ? h_bg_color[2] : 0.0f;
     const dim3 grid_dim(cdiv(N, kWavesPerBlock)), block(kBlock);
-    if (lidar)
-        hipLaunchKernelGGL(k_render_occupancy_lds<true>, grid_dim, block, 0, stream, rr, tb, (uint32_t)table_bytes, meta, first_hashed, ws,
-                           wa, wb, density_scale, T_thresh, b0, b1, b2, weights_sum, depth, image);
-    else
-        hipLaunchKernelGGL(k_render_occupancy_lds<false>, grid_dim, block, 0, stream, rr, tb, (uint32_t)table_bytes, meta, first_hashed, ws,
-                           wa, wb, density_scale, T_thresh, b0, b1, b2, weights_sum, depth, image);
+#define LAUNCH_OCC(LD, FF)                                                                                                                \
+    hipLaunchKernelGGL((k_render_occupancy_lds<LD, FF>), grid_dim, block, 0, stream, rr, tb, (uint32_t)table_bytes, meta, first_hashed, ws, \
+                       wa, wb, density_scale, T_thresh, b0, b1, b2, weights_sum, depth, image)
+    if (lidar) { if (F == 2) LAUNCH_OCC(true, 2); else LAUNCH_OCC(true, 4); }
+    else { if (F == 2) LAUNCH_OCC(false, 2); else LAUNCH_OCC(false, 4); }
+#undef LAUNCH_OCC
     return nvsf_launch_status();
 }
 

@@ -1178,8 +1178,9 @@ def render_uniform_eligible(spec, n_samples=0):
 
 
 def occupancy_fused_eligible(spec):
-    """Static hash fields nvsf_render_occupancy_fwd is built for."""
-    return spec.D == 3 and spec.F == 2 and spec.L * spec.F == 32
+    """Static hash fields nvsf_render_occupancy_fwd is built for: 32 encoded features as 16 levels x 2 (BASELINE config 2) or
+    8 levels x 4 (the reference-default grid shape)."""
+    return spec.D == 3 and spec.F in (2, 4) and spec.L * spec.F == 32
 
 
 def render_occupancy(rays_o, rays_d, nears, fars, bitfield, bound, dt_gamma, max_steps, C, H, table_f16, spec, sigma_weights_f16, lidar,

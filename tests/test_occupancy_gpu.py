@@ -14,12 +14,18 @@ def _t(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
 
-@pytest.fixture(scope="module")
-def setup(dev):
-    from nvsf import synthetic as S
+# the grid of BASELINE config 2 (16 levels x 2 features) and the reference-default shape (8 levels x 4; here with dense coarse levels)
+GRIDS = {"L16F2": {}, "L8F4": dict(n_levels_hash=8, n_features_per_level_hash=4, base_resolution=16, max_resolution=1024)}
+
+
+@pytest.fixture(scope="module", params=list(GRIDS))
+def setup(dev, request):
+    from nvsf import synthetic as S, field_ops as ops
     from nvsf.nerf.models.network_static import NeRFNetworkStatic
     torch.manual_seed(0)
-    m = NeRFNetworkStatic(bound=S.BOUND, min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH, log2_hashmap_size=15)
+    m = NeRFNetworkStatic(bound=S.BOUND, min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH, log2_hashmap_size=15,
+                          **GRIDS[request.param])
+    assert ops.occupancy_fused_eligible(m.hash_encoder_camera.spec)
     g = torch.Generator().manual_seed(1)
     with torch.no_grad():
         for enc in (m.hash_encoder_lidar, m.hash_encoder_camera):
@@ -120,9 +126,16 @@ def test_fused_occupancy_equals_host_loop(dev, setup, lidar):
     o, d = (S.lidar_rays if lidar else S.camera_rays)(N, rng)
     args = (_t(o, dev)[None], _t(d, dev)[None], torch.tensor([[0.5]], device=dev))
     bg = None if lidar else torch.tensor([0.1, 0.5, 0.9], device=dev)
-    with torch.no_grad():
-        a = m.render(*args, cal_lidar_color=lidar, max_steps=max_steps, bg_color=bg, fused=True)
-        b = m.render(*args, cal_lidar_color=lidar, max_steps=max_steps, bg_color=bg, fused=False)
+    from nvsf import field_ops as ops
+    launches, real = [], ops.render_occupancy
+    ops.render_occupancy = lambda *a_, **k_: (launches.append(1), real(*a_, **k_))[1]
+    try:
+        with torch.no_grad():
+            a = m.render(*args, cal_lidar_color=lidar, max_steps=max_steps, bg_color=bg, fused=True)
+            b = m.render(*args, cal_lidar_color=lidar, max_steps=max_steps, bg_color=bg, fused=False)
+    finally:
+        ops.render_occupancy = real
+    assert len(launches) == 1  # the one-launch kernel ran for `fused=True` (either grid shape), the survivor loop for the other
     sfx = "_lidar" if lidar else ""
     assert float(b["weights_sum" + sfx].max()) > 0.05  # the batch does hit occupied space
     for k in ("weights_sum" + sfx, "depth" + sfx, "image" + sfx):

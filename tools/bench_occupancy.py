@@ -13,7 +13,10 @@ from nvsf.nerf.models.network_static import NeRFNetworkStatic
 
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-m = NeRFNetworkStatic(bound=S.BOUND, min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH, num_frames=S.NUM_FRAMES)
+GRID = {}
+if os.environ.get("GRID") == "L8F4":  # the reference-default hash grid (main_nvsf.py:45-52)
+    GRID = dict(n_levels_hash=8, n_features_per_level_hash=4, base_resolution=512, max_resolution=32768, log2_hashmap_size=19)
+m = NeRFNetworkStatic(bound=S.BOUND, min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH, num_frames=S.NUM_FRAMES, **GRID)
 m = m.to(dev).enable_occupancy_grid().to(dev)
 rng = np.random.default_rng(0)
 grid = S.boxes_density_grid(rng, cascades=m.cascade, H=m.grid_size, n_boxes=int(os.environ.get("BOXES", 64)))
