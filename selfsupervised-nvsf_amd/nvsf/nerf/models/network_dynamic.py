@@ -304,7 +304,27 @@ class DensityTailFn(torch.autograd.Function):
         grad_h = grad_h[:, :spec.n_out]
         grad_x, gw = ops.mlp_backward(x16[:, :spec.n_in], w16, spec, grad_h, need_grad_x=need_x)
         out = [None] * 10
-        if need_x:
+        if need_x and grad_x.is_cuda and grad_x.stride(1) == 1 and grad_x.stride(0) % 4 == 0 and grad_x.shape[1] >= 120:
+            # the blend factors and the dtype of hash_s applied in ONE pass over the rows (nvsf_density_tail_grad_split)
+            dev = grad_x.device
+            f32 = dict(dtype=torch.float32, device=dev)
+            g_half = torch.empty(M, 32, **f32) if need[2] else None
+            g_quarter = torch.empty(M, 32, **f32) if (need[3] or need[4]) else None
+            g_hs = torch.empty(M, 32, dtype=ctx.hash_s_dtype, device=dev) if (need[5] and ctx.hash_s_dtype in (torch.float16, torch.float32)) else None
+            g_hd = torch.empty(M, 24, **f32) if need[6] else None
+            if g_half is not None or g_quarter is not None or g_hs is not None or g_hd is not None:
+                _hip.call("nvsf_density_tail_grad_split", _hip.ptr(grad_x), grad_x.stride(0), M, _hip.ptr(g_half), _hip.ptr(g_quarter), _hip.ptr(g_hs),
+                          1 if ctx.hash_s_dtype == torch.float16 else 0, _hip.ptr(g_hd))
+            if need[1]:
+                out[1] = grad_x[:, 0:32]
+            out[2], out[6] = g_half, g_hd
+            if need[3]:
+                out[3] = g_quarter
+            if need[4]:
+                out[4] = g_quarter
+            if need[5]:
+                out[5] = g_hs if g_hs is not None else grad_x[:, 64:96].to(ctx.hash_s_dtype)
+        elif need_x:
             g_pd = grad_x[:, 32:64]
             quarter = 0.25 * g_pd if (need[3] or need[4]) else None
             if need[1]:
