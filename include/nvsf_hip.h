@@ -412,9 +412,9 @@ int nvsf_density_dynamic_lm_fwd(const void* plane_s_f16, const void* plane_d_ble
 /* ref: the backward of network_dynamic.py:273-287 (autograd of the blends 0.5 d + 0.25 (d1 + d2) and of torch.cat): the density MLP's
  * input gradient grad_x fp32 [M, gx_stride >= 120] handed back per input in one pass -- g_plane_half = 0.5 grad_x[:, 32:64],
  * g_plane_quarter = 0.25 grad_x[:, 32:64], g_hash_s = grad_x[:, 64:96] (fp16 or fp32 rows of 32), g_hash_d_half = 0.5 grad_x[:, 96:120]
- * ([M,24]); NULL outputs are skipped.  The same values as the four elementwise operations. */
+ * ([M,24]), g_plane_s = grad_x[:, 0:32] as rows of its own; NULL outputs are skipped.  The same values as the elementwise operations. */
 int nvsf_density_tail_grad_split(const float* grad_x, uint32_t gx_stride, uint32_t M, float* g_plane_half, float* g_plane_quarter,
-                                 void* g_hash_s, int hash_s_is_f16, float* g_hash_d_half, nvsf_stream_t stream);
+                                 void* g_hash_s, int hash_s_is_f16, float* g_hash_d_half, float* g_plane_s, nvsf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Section 4: fused kernels of the uniform-sampling render (BASELINE config 2 hot path).

@@ -164,12 +164,13 @@ __global__ __launch_bounds__(kBlock) void k_exp_col(const float* __restrict__ h,
 // torch's sum over a bool tensor reduces int64 element by element: 0.21 ms for the 3.1 M samples of a batch, twice per training step.
 // Input gradient of the space-time density tail, handed back per input with the blend factors of network_dynamic.py:273-287
 // (DensityTailFn.backward): from dL/dx [M, 120] of the density MLP
-//   0.5 g[:, 32:64] (plane_d), 0.25 g[:, 32:64] (plane_1 = plane_2), g[:, 64:96] in the dtype of hash_s, 0.5 g[:, 96:120] (hash_d)
-// in ONE pass over the rows (four elementwise launches re-read the row once each).  Item = (row, piece of four columns).
+//   g[:, 0:32] (plane_s, as rows of its own), 0.5 g[:, 32:64] (plane_d), 0.25 g[:, 32:64] (plane_1 = plane_2), g[:, 64:96] in the
+//   dtype of hash_s, 0.5 g[:, 96:120] (hash_d)
+// in ONE pass over the rows (five elementwise / strided-copy launches re-read the row once each).  Item = (row, piece of four columns).
 __global__ __launch_bounds__(kBlock) void k_density_tail_grad_split(const float* __restrict__ gx, uint32_t gx_stride, uint32_t M, float* __restrict__ g_half,
                                                                     float* __restrict__ g_quarter, void* __restrict__ g_hash_s, int hash_s_f16,
-                                                                    float* __restrict__ g_hash_d) {
-    constexpr uint32_t kPieces = 8 + 8 + 6;
+                                                                    float* __restrict__ g_hash_d, float* __restrict__ g_plane_s) {
+    constexpr uint32_t kPieces = 8 + 8 + 6 + 8;
     const unsigned long long n = (unsigned long long)M * kPieces;
     for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * kBlock) {
         const uint32_t m = (uint32_t)(i / kPieces), p = (uint32_t)(i - (unsigned long long)m * kPieces);
@@ -189,11 +190,15 @@ __global__ __launch_bounds__(kBlock) void k_density_tail_grad_split(const float*
             } else {
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(g_hash_s) + (size_t)m * 32 + 4 * q) = v;
             }
-        } else {
+        } else if (p < 22u) {
             if (!g_hash_d) continue;
             const uint32_t q = p - 16u;
             const float4 v = *reinterpret_cast<const float4*>(row + 96 + 4 * q);
             *reinterpret_cast<float4*>(g_hash_d + (size_t)m * 24 + 4 * q) = make_float4(0.5f * v.x, 0.5f * v.y, 0.5f * v.z, 0.5f * v.w);
+        } else {
+            if (!g_plane_s) continue;
+            const uint32_t q = p - 22u;
+            *reinterpret_cast<float4*>(g_plane_s + (size_t)m * 32 + 4 * q) = *reinterpret_cast<const float4*>(row + 4 * q);
         }
     }
 }
@@ -331,15 +336,15 @@ NVSF_API int nvsf_exp_col(const float* h, uint32_t row_stride, uint32_t col, uin
 }
 
 NVSF_API int nvsf_density_tail_grad_split(const float* grad_x, uint32_t gx_stride, uint32_t M, float* g_plane_half, float* g_plane_quarter,
-                                          void* g_hash_s, int hash_s_is_f16, float* g_hash_d_half, hipStream_t stream) {
+                                          void* g_hash_s, int hash_s_is_f16, float* g_hash_d_half, float* g_plane_s, hipStream_t stream) {
     if (M == 0) return NVSF_OK;
-    REQUIRE(grad_x && gx_stride >= 120 && gx_stride % 4 == 0 && (g_plane_half || g_plane_quarter || g_hash_s || g_hash_d_half));
-    const void* ptrs[] = {grad_x, g_plane_half, g_plane_quarter, g_hash_d_half};
+    REQUIRE(grad_x && gx_stride >= 120 && gx_stride % 4 == 0 && (g_plane_half || g_plane_quarter || g_hash_s || g_hash_d_half || g_plane_s));
+    const void* ptrs[] = {grad_x, g_plane_half, g_plane_quarter, g_hash_d_half, g_plane_s};
     for (const void* q : ptrs) REQUIRE((reinterpret_cast<uintptr_t>(q) & 15u) == 0);
     REQUIRE((reinterpret_cast<uintptr_t>(g_hash_s) & (hash_s_is_f16 ? 7u : 15u)) == 0);
-    const unsigned long long items = (unsigned long long)M * 22ull;
+    const unsigned long long items = (unsigned long long)M * 30ull;
     const unsigned long long want = (items + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(k_density_tail_grad_split, dim3((uint32_t)(want < 8192ull ? want : 8192ull)), dim3(kBlock), 0, stream, grad_x, gx_stride, M,
-                       g_plane_half, g_plane_quarter, g_hash_s, hash_s_is_f16, g_hash_d_half);
+                       g_plane_half, g_plane_quarter, g_hash_s, hash_s_is_f16, g_hash_d_half, g_plane_s);
     return nvsf_launch_status();
 }

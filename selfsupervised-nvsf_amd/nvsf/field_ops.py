@@ -937,7 +937,7 @@ class PlanesFn(Function):
     [M, S*8] features.  The gradient of `planes_cl` is the buffer the backward kernel scatters into, as it is."""
 
     @staticmethod
-    def forward(ctx, xt, planes_cl, res_host, want):
+    def forward(ctx, xt, planes_cl, res_host, want, train_ctx=None):
         xt = xt.float().contiguous()
         M, S = xt.shape[0], len(res_host) // 4
         dev = xt.device
@@ -950,6 +950,9 @@ class PlanesFn(Function):
                   _hip.ptr(out_d))
         ctx.save_for_backward(xt, cl)
         ctx.res_host, ctx.want = res_host, want
+        ctx.train_ctx, ctx.planes_param = train_ctx, planes_cl
+        if train_ctx is not None and isinstance(planes_cl, torch.nn.Parameter) and planes_cl.requires_grad and torch.is_grad_enabled():
+            train_ctx.expect(planes_cl)
         outs = tuple(o for o in (out_s, out_d) if o is not None)
         return outs if len(outs) > 1 else outs[0]
 
@@ -961,12 +964,24 @@ class PlanesFn(Function):
         g_s = next(gi).float().contiguous() if want & 1 else None
         g_d = next(gi).float().contiguous() if want & 2 else None
         need_x, need_p = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        g_planes = torch.zeros_like(planes_cl) if need_p else None
+        # Inside a training step the texel gradients are ADDED straight into the step's gradient sink (the parameter's .grad or its
+        # bucket view), as the table scatters are: a space-time model evaluates its planes three times per ray batch, and autograd
+        # would zero-fill a 67 MB buffer per evaluation and add the three up again.
+        tctx, param = ctx.train_ctx, ctx.planes_param
+        view = None
+        if need_p and tctx is not None and tctx.sink is not None and isinstance(param, torch.nn.Parameter) and param.is_cuda and param.dtype == torch.float32:
+            last = tctx.done(param)
+            view = tctx.sink.view_for(param)
+        g_planes = view if view is not None else (torch.zeros_like(planes_cl) if need_p else None)
         g_xt = torch.empty_like(xt) if need_x else None
         if need_p or need_x:
             _hip.call("nvsf_planes_bwd", _hip.ptr(xt), xt.shape[0], _hip.ptr(planes_cl), S, 8, _hip.host_u32(ctx.res_host), int(want),
                       _hip.ptr(g_s), _hip.ptr(g_d), _hip.ptr(g_planes), _hip.ptr(g_xt))
-        return g_xt, g_planes, None, None
+        if view is not None:
+            if last:
+                tctx.sink.mark_ready(param)
+            return g_xt, None, None, None, None
+        return g_xt, g_planes, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------

@@ -100,7 +100,7 @@ class Planes4D(nn.Module):
 
     def _encode(self, xt, want):
         xt = xt.reshape(-1, 4)
-        return ops.PlanesFn.apply(xt, self.planes_cl, self._res_host, want)
+        return ops.PlanesFn.apply(xt, self.planes_cl, self._res_host, want, ops.train_context(self))
 
     @torch.no_grad()
     def forward_multi(self, x, evals, blend=False, out_f16=False):
