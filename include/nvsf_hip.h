@@ -355,6 +355,13 @@ int nvsf_hashgrid4d_dynamic_bwd_scalar(const float* x, uint32_t x_stride, uint32
                                        const uint32_t* h_offsets, const float* grad_out, void* const* h_sums_f32,
                                        nvsf_stream_t stream);
 
+/* The same (ref: the autograd of hash_field.py:60-74, 150-156) with the gradient COLUMN-major, fp32 [24][M], as
+ * nvsf_density_tail_grad_split writes it: every workgroup of the LDS kernel reads one contiguous column instead of 4 bytes of every
+ * 96-byte row.  NVSF_ERR_UNSUPPORTED where the launch would not take the LDS kernel (M < 2^16, a level beyond LDS). */
+int nvsf_hashgrid4d_dynamic_bwd_scalar_t(const float* x, uint32_t x_stride, uint32_t M, const float* h_scales, const uint32_t* h_res,
+                                         const uint32_t* h_offsets, const float* grad_out_t, void* const* h_sums_f32,
+                                         nvsf_stream_t stream);
+
 /* The three space-time evaluations of one density query in one launch (ref: network_dynamic.py:220-271: hash_encoder(x, t)
  * in the fp32 regime and hash_encoder.forward_dynamic(x + flow, t_neighbour) twice in the fp16 regime).  h_tables_f16: 18
  * device pointers = for evaluation e = 0, 1, 2 the lo slice of pair 0,1,2 then the hi slice of pair 0,1,2; h_time: 18 floats
@@ -412,9 +419,11 @@ int nvsf_density_dynamic_lm_fwd(const void* plane_s_f16, const void* plane_d_ble
 /* ref: the backward of network_dynamic.py:273-287 (autograd of the blends 0.5 d + 0.25 (d1 + d2) and of torch.cat): the density MLP's
  * input gradient grad_x fp32 [M, gx_stride >= 120] handed back per input in one pass -- g_plane_half = 0.5 grad_x[:, 32:64],
  * g_plane_quarter = 0.25 grad_x[:, 32:64], g_hash_s = grad_x[:, 64:96] (fp16 or fp32 rows of 32), g_hash_d_half = 0.5 grad_x[:, 96:120]
- * ([M,24]), g_plane_s = grad_x[:, 0:32] as rows of its own; NULL outputs are skipped.  The same values as the elementwise operations. */
+ * ([M,24], or [24][M] with hash_d_col_major != 0: the layout nvsf_hashgrid4d_dynamic_bwd_scalar_t reads), g_plane_s = grad_x[:, 0:32] as
+ * rows of its own; NULL outputs are skipped.  The same values as the elementwise operations. */
 int nvsf_density_tail_grad_split(const float* grad_x, uint32_t gx_stride, uint32_t M, float* g_plane_half, float* g_plane_quarter,
-                                 void* g_hash_s, int hash_s_is_f16, float* g_hash_d_half, float* g_plane_s, nvsf_stream_t stream);
+                                 void* g_hash_s, int hash_s_is_f16, float* g_hash_d_half, int hash_d_col_major, float* g_plane_s,
+                                 nvsf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Section 4: fused kernels of the uniform-sampling render (BASELINE config 2 hot path).

@@ -169,7 +169,23 @@ __global__ __launch_bounds__(kBlock) void k_exp_col(const float* __restrict__ h,
 // in ONE pass over the rows (five elementwise / strided-copy launches re-read the row once each).  Item = (row, piece of four columns).
 __global__ __launch_bounds__(kBlock) void k_density_tail_grad_split(const float* __restrict__ gx, uint32_t gx_stride, uint32_t M, float* __restrict__ g_half,
                                                                     float* __restrict__ g_quarter, void* __restrict__ g_hash_s, int hash_s_f16,
-                                                                    float* __restrict__ g_hash_d, float* __restrict__ g_plane_s) {
+                                                                    float* __restrict__ g_hash_d, float* __restrict__ g_plane_s, int hash_d_col_major) {
+    // hash_d gradient column-major, [24][M] (its consumer k_hash_dynamic_bwd_lds reads one column per workgroup): lane = row, so that a
+    // wave instruction writes 256 contiguous bytes of a column
+    if (g_hash_d && hash_d_col_major) {
+        for (unsigned long long m = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; m < M; m += (unsigned long long)gridDim.x * kBlock) {
+            const float* row = gx + (size_t)m * gx_stride + 96;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(row + 4 * q);
+                g_hash_d[(size_t)(4 * q) * M + m] = 0.5f * v.x;
+                g_hash_d[(size_t)(4 * q + 1) * M + m] = 0.5f * v.y;
+                g_hash_d[(size_t)(4 * q + 2) * M + m] = 0.5f * v.z;
+                g_hash_d[(size_t)(4 * q + 3) * M + m] = 0.5f * v.w;
+            }
+        }
+        g_hash_d = nullptr;
+    }
     constexpr uint32_t kPieces = 8 + 8 + 6 + 8;
     const unsigned long long n = (unsigned long long)M * kPieces;
     for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * kBlock) {
@@ -336,7 +352,8 @@ NVSF_API int nvsf_exp_col(const float* h, uint32_t row_stride, uint32_t col, uin
 }
 
 NVSF_API int nvsf_density_tail_grad_split(const float* grad_x, uint32_t gx_stride, uint32_t M, float* g_plane_half, float* g_plane_quarter,
-                                          void* g_hash_s, int hash_s_is_f16, float* g_hash_d_half, float* g_plane_s, hipStream_t stream) {
+                                          void* g_hash_s, int hash_s_is_f16, float* g_hash_d_half, int hash_d_col_major, float* g_plane_s,
+                                          hipStream_t stream) {
     if (M == 0) return NVSF_OK;
     REQUIRE(grad_x && gx_stride >= 120 && gx_stride % 4 == 0 && (g_plane_half || g_plane_quarter || g_hash_s || g_hash_d_half || g_plane_s));
     const void* ptrs[] = {grad_x, g_plane_half, g_plane_quarter, g_hash_d_half, g_plane_s};
@@ -345,6 +362,6 @@ NVSF_API int nvsf_density_tail_grad_split(const float* grad_x, uint32_t gx_strid
     const unsigned long long items = (unsigned long long)M * 30ull;
     const unsigned long long want = (items + kBlock - 1) / kBlock;
     hipLaunchKernelGGL(k_density_tail_grad_split, dim3((uint32_t)(want < 8192ull ? want : 8192ull)), dim3(kBlock), 0, stream, grad_x, gx_stride, M,
-                       g_plane_half, g_plane_quarter, g_hash_s, hash_s_is_f16, g_hash_d_half, g_plane_s);
+                       g_plane_half, g_plane_quarter, g_hash_s, hash_s_is_f16, g_hash_d_half, g_plane_s, hash_d_col_major);
     return nvsf_launch_status();
 }

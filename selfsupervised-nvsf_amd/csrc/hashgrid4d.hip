@@ -467,7 +467,10 @@ __global__ __launch_bounds__(kBlock) void k_hash_dynamic_bwd_scalar(const float*
 // half of the rows (128 KB each); both walk the slice, each keeps the addends of its rows.
 template <int SPLIT>
 __global__ void k_hash_dynamic_bwd_lds(const float* __restrict__ x, uint32_t x_stride, uint32_t M, const float* __restrict__ grad_out,
-                                       PlaneSums pg, uint32_t pl0, uint32_t chunk_len) {
+                                       PlaneSums pg, uint32_t pl0, uint32_t chunk_len, uint32_t go_row, uint32_t go_col) {
+    // grad_out[m * go_row + column * go_col]: rows [M, 24] (24, 1) or COLUMN-major (1, M) -- a workgroup reads ONE column of all its
+    // samples: 4 bytes of every 96-byte row in the row form (every line of the matrix fetched by each of the 24 columns' workgroups:
+    // 2.4 GB of line traffic per 1.57 M samples), contiguous in the column form
     extern __shared__ unsigned long long s_fx[];
     __shared__ float s_red[16];
     const uint32_t part = blockIdx.y % SPLIT, yl = blockIdx.y / SPLIT;
@@ -480,7 +483,7 @@ __global__ void k_hash_dynamic_bwd_lds(const float* __restrict__ x, uint32_t x_s
     const uint32_t ca = pl == 2 ? 1u : 0u, cb = pl == 0 ? 1u : 2u;
     const unsigned long long first = (unsigned long long)blockIdx.x * chunk_len;
     const uint32_t m0 = (uint32_t)(first < M ? first : M), m1 = (uint32_t)(first + chunk_len < M ? first + chunk_len : M);
-    const size_t gcol = (size_t)pl * kPlaneLevels + l;
+    const size_t gcol = ((size_t)pl * kPlaneLevels + l) * go_col;
     // largest |g| of this slice and level
     // A non-finite gradient (fp16 overflow under GradScaler) has to reach the table, as it does through the memory atomics, so that
     // the scaler's found_inf check skips the step; it must not enter the fixed-point image (fmaxf drops a NaN, an inf would put the
@@ -489,7 +492,7 @@ __global__ void k_hash_dynamic_bwd_lds(const float* __restrict__ x, uint32_t x_s
     float mx = 0.0f;
     bool bad = false;
     for (uint32_t m = m0 + threadIdx.x; m < m1; m += blockDim.x) {
-        const float a = fabsf(grad_out[(size_t)m * (3 * kPlaneLevels) + gcol]);
+        const float a = fabsf(grad_out[(size_t)m * go_row + gcol]);
         if (a <= 3.402823466e38f) mx = fmaxf(mx, a);
         else bad = true;
     }
@@ -513,7 +516,7 @@ __global__ void k_hash_dynamic_bwd_lds(const float* __restrict__ x, uint32_t x_s
             const uint32_t m = mb + (uint32_t)u * blockDim.x;
             const bool ok = m < m1;
             const size_t mm = ok ? m : m0;
-            go[u] = ok ? grad_out[mm * (3 * kPlaneLevels) + gcol] : 0.0f;
+            go[u] = ok ? grad_out[mm * go_row + gcol] : 0.0f;
             if (!(fabsf(go[u]) <= 3.402823466e38f)) go[u] = 0.0f;  // reported above
             xa[u] = x[mm * x_stride + ca];
             xb[u] = x[mm * x_stride + cb];
@@ -669,8 +672,8 @@ NVSF_API int nvsf_hashgrid4d_dynamic3_fwd(const float* x, uint32_t x_stride, con
 
 // Scalar table-gradient sums of the space-time encoder: h_sums_f32 = 3 device pointers (one per pair) to fp32 [rows] buffers; the sum
 // G[row] = sum over samples of grad_out[pair][level] * w_corner is ADDED to them.  dL/dtable[slice][row][i] = lag_i * blend_slice * G[row].
-NVSF_API int nvsf_hashgrid4d_dynamic_bwd_scalar(const float* x, uint32_t x_stride, uint32_t M, const float* h_scales, const uint32_t* h_res,
-                                                const uint32_t* h_offsets, const float* grad_out, void* const* h_sums_f32, hipStream_t stream) {
+static int hash4d_bwd_scalar_impl(const float* x, uint32_t x_stride, uint32_t M, const float* h_scales, const uint32_t* h_res,
+                                  const uint32_t* h_offsets, const float* grad_out, int grad_col_major, void* const* h_sums_f32, hipStream_t stream) {
     if (M == 0) return NVSF_OK;
     REQUIRE(x && grad_out && h_sums_f32 && x_stride >= 3);
     PlaneSums pg;
@@ -693,6 +696,8 @@ NVSF_API int nvsf_hashgrid4d_dynamic_bwd_scalar(const float* x, uint32_t x_strid
         }
         fits = fits && max_rows[p] * sizeof(unsigned long long) <= 2u * 128u * 1024u;
     }
+    const uint32_t go_row = grad_col_major ? 1u : (uint32_t)(3 * kPlaneLevels), go_col = grad_col_major ? M : 1u;
+    if (!(fits && M >= (1u << 16) && nvsf_variant(kVarHash4dBwd) == 0) && grad_col_major) return NVSF_ERR_UNSUPPORTED;  // rows for the other kernel
     if (fits && M >= (1u << 16) && nvsf_variant(kVarHash4dBwd) == 0) {
         int p = 0;
         while (p < 3) {
@@ -705,9 +710,9 @@ NVSF_API int nvsf_hashgrid4d_dynamic_bwd_scalar(const float* x, uint32_t x_strid
             const uint32_t chunk_len = (M + n_slices - 1) / n_slices;
             const dim3 grid(n_slices, (uint32_t)(q - p) * kPlaneLevels * split);
             if (split == 2)
-                hipLaunchKernelGGL(k_hash_dynamic_bwd_lds<2>, grid, dim3(threads), lds, stream, x, x_stride, M, grad_out, pg, (uint32_t)p, chunk_len);
+                hipLaunchKernelGGL(k_hash_dynamic_bwd_lds<2>, grid, dim3(threads), lds, stream, x, x_stride, M, grad_out, pg, (uint32_t)p, chunk_len, go_row, go_col);
             else
-                hipLaunchKernelGGL(k_hash_dynamic_bwd_lds<1>, grid, dim3(threads), lds, stream, x, x_stride, M, grad_out, pg, (uint32_t)p, chunk_len);
+                hipLaunchKernelGGL(k_hash_dynamic_bwd_lds<1>, grid, dim3(threads), lds, stream, x, x_stride, M, grad_out, pg, (uint32_t)p, chunk_len, go_row, go_col);
             p = q;
         }
         return nvsf_launch_status();
@@ -718,4 +723,17 @@ NVSF_API int nvsf_hashgrid4d_dynamic_bwd_scalar(const float* x, uint32_t x_strid
     hipLaunchKernelGGL(k_hash_dynamic_bwd_scalar, dim3((uint32_t)((waves + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, stream, x, x_stride,
                        M, grad_out, pg, run);
     return nvsf_launch_status();
+}
+
+NVSF_API int nvsf_hashgrid4d_dynamic_bwd_scalar(const float* x, uint32_t x_stride, uint32_t M, const float* h_scales, const uint32_t* h_res,
+                                                const uint32_t* h_offsets, const float* grad_out, void* const* h_sums_f32, hipStream_t stream) {
+    return hash4d_bwd_scalar_impl(x, x_stride, M, h_scales, h_res, h_offsets, grad_out, 0, h_sums_f32, stream);
+}
+
+// The same with the gradient COLUMN-major, fp32 [24][M] (what nvsf_density_tail_grad_split writes): the LDS kernel's workgroups read one
+// column each.  NVSF_ERR_UNSUPPORTED where the launch would take the run-merging kernel (small batches, levels beyond LDS, test variant):
+// the caller then passes rows.
+NVSF_API int nvsf_hashgrid4d_dynamic_bwd_scalar_t(const float* x, uint32_t x_stride, uint32_t M, const float* h_scales, const uint32_t* h_res,
+                                                  const uint32_t* h_offsets, const float* grad_out_t, void* const* h_sums_f32, hipStream_t stream) {
+    return hash4d_bwd_scalar_impl(x, x_stride, M, h_scales, h_res, h_offsets, grad_out_t, 1, h_sums_f32, stream);
 }

@@ -318,13 +318,23 @@ class HashDynFn(torch.autograd.Function):
         # The two slices of a pair see the same cells and corner weights; their gradients differ by the scalar blend factors
         # only (dL/dtable_lo = blend_lo G, dL/dtable_hi = blend_hi G with G = sum g lag_i w_c).  G is scattered ONCE -- half the
         # atomics, which are what bounds this pass -- and scaled into the two gradients afterwards (tables of ~1 M floats).
-        g_out = grad_out.float().contiguous()
+        # a column-major gradient ([M, 24] with strides (1, M): DensityTailFn.backward hands it over that way) goes to the kernel as it is
+        M = x.shape[0]
+        col_major = (grad_out.dtype == torch.float32 and grad_out.dim() == 2 and grad_out.shape[1] == 24 and grad_out.stride() == (1, M)
+                     and M >= (1 << 16) and testing.get("hash4d_train") == "fused")
+        g_out = grad_out if col_major else grad_out.float().contiguous()
         lag_t = _ops.device_constant(lag, x.device)
         # ... and the four features of an entry are the four Lagrange chunks: dL/dtable[row][i] = lag_i * blend * G[row] with ONE
         # scalar sum per entry (nvsf_hashgrid4d_dynamic_bwd_scalar), expanded here
         sums = [torch.zeros(s.n_rows, dtype=torch.float32, device=x.device) for s in specs]
-        _hip.call("nvsf_hashgrid4d_dynamic_bwd_scalar", _hip.ptr(x), x.shape[1], x.shape[0], h_scales, h_res, h_off, _hip.ptr(g_out),
-                  (ctypes.c_void_p * 3)(*[g.data_ptr() for g in sums]))
+        sum_ptrs = (ctypes.c_void_p * 3)(*[g.data_ptr() for g in sums])
+        if col_major:
+            try:
+                _hip.call("nvsf_hashgrid4d_dynamic_bwd_scalar_t", _hip.ptr(x), x.shape[1], M, h_scales, h_res, h_off, g_out.data_ptr(), sum_ptrs)
+            except _hip.NvsfHipError:  # the launch would not take the LDS kernel: rows for the run-merging one
+                col_major, g_out = False, grad_out.contiguous()
+        if not col_major:
+            _hip.call("nvsf_hashgrid4d_dynamic_bwd_scalar", _hip.ptr(x), x.shape[1], M, h_scales, h_res, h_off, _hip.ptr(g_out), sum_ptrs)
         acc = [(g.view(-1, 1) * lag_t.view(1, 4)).reshape(-1) for g in sums]
         if same:  # the same parameter tensors were passed twice: the whole gradient goes to the first occurrence
             grads = acc + [None, None, None]

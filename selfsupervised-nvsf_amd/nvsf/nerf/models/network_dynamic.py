@@ -311,11 +311,13 @@ class DensityTailFn(torch.autograd.Function):
             g_half = torch.empty(M, 32, **f32) if need[2] else None
             g_quarter = torch.empty(M, 32, **f32) if (need[3] or need[4]) else None
             g_hs = torch.empty(M, 32, dtype=ctx.hash_s_dtype, device=dev) if (need[5] and ctx.hash_s_dtype in (torch.float16, torch.float32)) else None
-            g_hd = torch.empty(M, 24, **f32) if need[6] else None
+            # hash_d's gradient column-major ([M, 24] with strides (1, M)): the table-gradient kernel of the space-time grids has every
+            # workgroup read ONE column of it (hash_field.HashDynFn._backward passes such a tensor on as it is)
+            g_hd = torch.empty(24, M, **f32).t() if need[6] else None
             g_ps = torch.empty(M, 32, **f32) if need[1] else None  # rows of its own: the planes' backward reads contiguous rows
             if g_half is not None or g_quarter is not None or g_hs is not None or g_hd is not None or g_ps is not None:
                 _hip.call("nvsf_density_tail_grad_split", _hip.ptr(grad_x), grad_x.stride(0), M, _hip.ptr(g_half), _hip.ptr(g_quarter), _hip.ptr(g_hs),
-                          1 if ctx.hash_s_dtype == torch.float16 else 0, _hip.ptr(g_hd), _hip.ptr(g_ps))
+                          1 if ctx.hash_s_dtype == torch.float16 else 0, None if g_hd is None else g_hd.data_ptr(), 1, _hip.ptr(g_ps))
             out[1], out[2], out[6] = g_ps, g_half, g_hd
             if need[3]:
                 out[3] = g_quarter
