@@ -170,51 +170,56 @@ __global__ __launch_bounds__(kBlock) void k_exp_col(const float* __restrict__ h,
 __global__ __launch_bounds__(kBlock) void k_density_tail_grad_split(const float* __restrict__ gx, uint32_t gx_stride, uint32_t M, float* __restrict__ g_half,
                                                                     float* __restrict__ g_quarter, void* __restrict__ g_hash_s, int hash_s_f16,
                                                                     float* __restrict__ g_hash_d, float* __restrict__ g_plane_s, int hash_d_col_major) {
-    // hash_d gradient column-major, [24][M] (its consumer k_hash_dynamic_bwd_lds reads one column per workgroup): lane = row, so that a
-    // wave instruction writes 256 contiguous bytes of a column
-    if (g_hash_d && hash_d_col_major) {
-        for (unsigned long long m = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; m < M; m += (unsigned long long)gridDim.x * kBlock) {
-            const float* row = gx + (size_t)m * gx_stride + 96;
-#pragma unroll
-            for (int q = 0; q < 6; ++q) {
-                const float4 v = *reinterpret_cast<const float4*>(row + 4 * q);
-                g_hash_d[(size_t)(4 * q) * M + m] = 0.5f * v.x;
-                g_hash_d[(size_t)(4 * q + 1) * M + m] = 0.5f * v.y;
-                g_hash_d[(size_t)(4 * q + 2) * M + m] = 0.5f * v.z;
-                g_hash_d[(size_t)(4 * q + 3) * M + m] = 0.5f * v.w;
+    // A workgroup stages 64 rows (columns 0 .. 119) in LDS with whole-line reads and writes every output from there in the order that
+    // output wants: rows as 16-byte pieces, the column-major hash_d gradient ([24][M]: its consumer k_hash_dynamic_bwd_lds reads one
+    // column per workgroup) as 64 consecutive floats per column.
+    constexpr int kRows = 64, kPitch = 121;  // odd pitch: a column of the tile is conflict-free
+    __shared__ float s_t[kRows * kPitch];
+    const uint32_t n_tiles = (M + kRows - 1) / kRows;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const uint32_t m0 = tile * kRows, rows = min((uint32_t)kRows, M - m0);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < rows * 30u; i += kBlock) {
+            const uint32_t r = i / 30u, q = i - r * 30u;
+            const float4 v = *reinterpret_cast<const float4*>(gx + (size_t)(m0 + r) * gx_stride + 4u * q);
+            float* d = s_t + r * kPitch + 4u * q;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < rows * 8u; i += kBlock) {  // 32-column outputs, 16 bytes per item
+            const uint32_t r = i >> 3, q = i & 7u;
+            const size_t at = (size_t)(m0 + r) * 32 + 4u * q;
+            if (g_plane_s) {
+                const float* a = s_t + r * kPitch + 4u * q;
+                *reinterpret_cast<float4*>(g_plane_s + at) = make_float4(a[0], a[1], a[2], a[3]);
+            }
+            const float* b = s_t + r * kPitch + 32 + 4u * q;
+            if (g_half) *reinterpret_cast<float4*>(g_half + at) = make_float4(0.5f * b[0], 0.5f * b[1], 0.5f * b[2], 0.5f * b[3]);
+            if (g_quarter) *reinterpret_cast<float4*>(g_quarter + at) = make_float4(0.25f * b[0], 0.25f * b[1], 0.25f * b[2], 0.25f * b[3]);
+            if (g_hash_s) {
+                const float* c = s_t + r * kPitch + 64 + 4u * q;
+                if (hash_s_f16) {
+                    typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+                    const h4v h = {(_Float16)c[0], (_Float16)c[1], (_Float16)c[2], (_Float16)c[3]};
+                    *reinterpret_cast<h4v*>(reinterpret_cast<_Float16*>(g_hash_s) + at) = h;
+                } else {
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(g_hash_s) + at) = make_float4(c[0], c[1], c[2], c[3]);
+                }
             }
         }
-        g_hash_d = nullptr;
-    }
-    constexpr uint32_t kPieces = 8 + 8 + 6 + 8;
-    const unsigned long long n = (unsigned long long)M * kPieces;
-    for (unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * kBlock) {
-        const uint32_t m = (uint32_t)(i / kPieces), p = (uint32_t)(i - (unsigned long long)m * kPieces);
-        const float* row = gx + (size_t)m * gx_stride;
-        if (p < 8u) {
-            const float4 v = *reinterpret_cast<const float4*>(row + 32 + 4 * p);
-            if (g_half) *reinterpret_cast<float4*>(g_half + (size_t)m * 32 + 4 * p) = make_float4(0.5f * v.x, 0.5f * v.y, 0.5f * v.z, 0.5f * v.w);
-            if (g_quarter) *reinterpret_cast<float4*>(g_quarter + (size_t)m * 32 + 4 * p) = make_float4(0.25f * v.x, 0.25f * v.y, 0.25f * v.z, 0.25f * v.w);
-        } else if (p < 16u) {
-            if (!g_hash_s) continue;
-            const uint32_t q = p - 8u;
-            const float4 v = *reinterpret_cast<const float4*>(row + 64 + 4 * q);
-            if (hash_s_f16) {
-                typedef _Float16 h4v __attribute__((ext_vector_type(4)));
-                const h4v h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
-                *reinterpret_cast<h4v*>(reinterpret_cast<_Float16*>(g_hash_s) + (size_t)m * 32 + 4 * q) = h;
+        if (g_hash_d) {
+            if (hash_d_col_major) {
+                for (uint32_t i = threadIdx.x; i < 24u * kRows; i += kBlock) {
+                    const uint32_t c = i >> 6, r = i & 63u;
+                    if (r < rows) g_hash_d[(size_t)c * M + m0 + r] = 0.5f * s_t[r * kPitch + 96 + c];
+                }
             } else {
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(g_hash_s) + (size_t)m * 32 + 4 * q) = v;
+                for (uint32_t i = threadIdx.x; i < rows * 6u; i += kBlock) {
+                    const uint32_t r = i / 6u, q = i - r * 6u;
+                    const float* d = s_t + r * kPitch + 96 + 4u * q;
+                    *reinterpret_cast<float4*>(g_hash_d + (size_t)(m0 + r) * 24 + 4u * q) = make_float4(0.5f * d[0], 0.5f * d[1], 0.5f * d[2], 0.5f * d[3]);
+                }
             }
-        } else if (p < 22u) {
-            if (!g_hash_d) continue;
-            const uint32_t q = p - 16u;
-            const float4 v = *reinterpret_cast<const float4*>(row + 96 + 4 * q);
-            *reinterpret_cast<float4*>(g_hash_d + (size_t)m * 24 + 4 * q) = make_float4(0.5f * v.x, 0.5f * v.y, 0.5f * v.z, 0.5f * v.w);
-        } else {
-            if (!g_plane_s) continue;
-            const uint32_t q = p - 22u;
-            *reinterpret_cast<float4*>(g_plane_s + (size_t)m * 32 + 4 * q) = *reinterpret_cast<const float4*>(row + 4 * q);
         }
     }
 }
@@ -359,9 +364,8 @@ NVSF_API int nvsf_density_tail_grad_split(const float* grad_x, uint32_t gx_strid
     const void* ptrs[] = {grad_x, g_plane_half, g_plane_quarter, g_hash_d_half, g_plane_s};
     for (const void* q : ptrs) REQUIRE((reinterpret_cast<uintptr_t>(q) & 15u) == 0);
     REQUIRE((reinterpret_cast<uintptr_t>(g_hash_s) & (hash_s_is_f16 ? 7u : 15u)) == 0);
-    const unsigned long long items = (unsigned long long)M * 30ull;
-    const unsigned long long want = (items + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(k_density_tail_grad_split, dim3((uint32_t)(want < 8192ull ? want : 8192ull)), dim3(kBlock), 0, stream, grad_x, gx_stride, M,
+    const uint32_t want = (M + 63u) / 64u;
+    hipLaunchKernelGGL(k_density_tail_grad_split, dim3(want < 4096u ? want : 4096u), dim3(kBlock), 0, stream, grad_x, gx_stride, M,
                        g_plane_half, g_plane_quarter, g_hash_s, hash_s_is_f16, g_hash_d_half, g_plane_s, hash_d_col_major);
     return nvsf_launch_status();
 }
