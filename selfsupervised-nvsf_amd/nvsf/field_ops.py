@@ -4,7 +4,6 @@ Thin, allocation-only wrappers over the C ABI (include/nvsf_hip.h sections 2-4) 
 the trainer needs.  No arithmetic of the hot path happens in Python: every function here ends in a HIP
 kernel launch on the current stream, forward and backward.
 """
-import math
 
 import numpy as np
 import torch
