@@ -416,14 +416,22 @@ int nvsf_density_dynamic_lm_fwd(const void* plane_s_f16, const void* plane_d_ble
                                 int hash_2_is_f16, uint32_t M, const void* sigma_weights_f16, float* out_h,
                                 float* sigmas, void* geo_f16, void* x_f16_out, nvsf_stream_t stream);
 
+/* ... the four-buffer form of nvsf_density_dynamic_fwd (fp32 plane rows, blend formed in the kernel: the training forward,
+ * network_dynamic.py:273-287) with the static hash features level-major, fp16 [8][M][4]. */
+int nvsf_density_dynamic_lm32_fwd(const float* plane_s, const float* plane_d, const float* plane_1, const float* plane_2,
+                                  const void* hash_s_level_major_f16, const float* hash_d, const void* hash_1, int hash_1_is_f16,
+                                  const void* hash_2, int hash_2_is_f16, uint32_t M, const void* sigma_weights_f16,
+                                  float* out_h, float* sigmas, void* geo_f16, void* x_f16_out, nvsf_stream_t stream);
+
 /* ref: the backward of network_dynamic.py:273-287 (autograd of the blends 0.5 d + 0.25 (d1 + d2) and of torch.cat): the density MLP's
  * input gradient grad_x fp32 [M, gx_stride >= 120] handed back per input in one pass -- g_plane_half = 0.5 grad_x[:, 32:64],
  * g_plane_quarter = 0.25 grad_x[:, 32:64], g_hash_s = grad_x[:, 64:96] (fp16 or fp32 rows of 32), g_hash_d_half = 0.5 grad_x[:, 96:120]
  * ([M,24], or [24][M] with hash_d_col_major != 0: the layout nvsf_hashgrid4d_dynamic_bwd_scalar_t reads), g_plane_s = grad_x[:, 0:32] as
- * rows of its own; NULL outputs are skipped.  The same values as the elementwise operations. */
+ * rows of its own; hash_s_level_major != 0: g_hash_s as [8][M][4] (the layout of nvsf_hashgrid_fwd_level_major's output).  NULL outputs are
+ * skipped.  The same values as the elementwise operations. */
 int nvsf_density_tail_grad_split(const float* grad_x, uint32_t gx_stride, uint32_t M, float* g_plane_half, float* g_plane_quarter,
-                                 void* g_hash_s, int hash_s_is_f16, float* g_hash_d_half, int hash_d_col_major, float* g_plane_s,
-                                 nvsf_stream_t stream);
+                                 void* g_hash_s, int hash_s_is_f16, int hash_s_level_major, float* g_hash_d_half, int hash_d_col_major,
+                                 float* g_plane_s, nvsf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Section 4: fused kernels of the uniform-sampling render (BASELINE config 2 hot path).

@@ -191,3 +191,12 @@ NVSF_API int nvsf_density_dynamic_lm_fwd(const void* plane_s_f16, const void* pl
     return density_dynamic_impl(ps, pd, pd, pd, 1, 1, hash_s_level_major_f16, hash_d, hash_1, hash_1_is_f16, hash_2, hash_2_is_f16, M,
                                 sigma_weights_f16, out_h, sigmas, geo_f16, x_f16_out, stream);
 }
+
+// The four-buffer plane form (training forward: fp32 plane rows, the blend formed here) with the static hash features level-major.
+NVSF_API int nvsf_density_dynamic_lm32_fwd(const float* plane_s, const float* plane_d, const float* plane_1, const float* plane_2,
+                                           const void* hash_s_level_major_f16, const float* hash_d, const void* hash_1, int hash_1_is_f16,
+                                           const void* hash_2, int hash_2_is_f16, uint32_t M, const void* sigma_weights_f16, float* out_h,
+                                           float* sigmas, void* geo_f16, void* x_f16_out, hipStream_t stream) {
+    return density_dynamic_impl(plane_s, plane_d, plane_1, plane_2, 0, 1, hash_s_level_major_f16, hash_d, hash_1, hash_1_is_f16, hash_2, hash_2_is_f16, M,
+                                sigma_weights_f16, out_h, sigmas, geo_f16, x_f16_out, stream);
+}

@@ -169,7 +169,8 @@ __global__ __launch_bounds__(kBlock) void k_exp_col(const float* __restrict__ h,
 // in ONE pass over the rows (five elementwise / strided-copy launches re-read the row once each).  Item = (row, piece of four columns).
 __global__ __launch_bounds__(kBlock) void k_density_tail_grad_split(const float* __restrict__ gx, uint32_t gx_stride, uint32_t M, float* __restrict__ g_half,
                                                                     float* __restrict__ g_quarter, void* __restrict__ g_hash_s, int hash_s_f16,
-                                                                    float* __restrict__ g_hash_d, float* __restrict__ g_plane_s, int hash_d_col_major) {
+                                                                    float* __restrict__ g_hash_d, float* __restrict__ g_plane_s, int hash_d_col_major,
+                                                                    int hash_s_lm) {
     // A workgroup stages 64 rows (columns 0 .. 119) in LDS with whole-line reads and writes every output from there in the order that
     // output wants: rows as 16-byte pieces, the column-major hash_d gradient ([24][M]: its consumer k_hash_dynamic_bwd_lds reads one
     // column per workgroup) as 64 consecutive floats per column.
@@ -198,6 +199,7 @@ __global__ __launch_bounds__(kBlock) void k_density_tail_grad_split(const float*
             if (g_quarter) *reinterpret_cast<float4*>(g_quarter + at) = make_float4(0.25f * b[0], 0.25f * b[1], 0.25f * b[2], 0.25f * b[3]);
             if (g_hash_s) {
                 const float* c = s_t + r * kPitch + 64 + 4u * q;
+                const size_t at = hash_s_lm ? ((size_t)q * M + m0 + r) * 4 : (size_t)(m0 + r) * 32 + 4u * q;  // [8][M][4]: piece q = level q
                 if (hash_s_f16) {
                     typedef _Float16 h4v __attribute__((ext_vector_type(4)));
                     const h4v h = {(_Float16)c[0], (_Float16)c[1], (_Float16)c[2], (_Float16)c[3]};
@@ -357,8 +359,8 @@ NVSF_API int nvsf_exp_col(const float* h, uint32_t row_stride, uint32_t col, uin
 }
 
 NVSF_API int nvsf_density_tail_grad_split(const float* grad_x, uint32_t gx_stride, uint32_t M, float* g_plane_half, float* g_plane_quarter,
-                                          void* g_hash_s, int hash_s_is_f16, float* g_hash_d_half, int hash_d_col_major, float* g_plane_s,
-                                          hipStream_t stream) {
+                                          void* g_hash_s, int hash_s_is_f16, int hash_s_level_major, float* g_hash_d_half, int hash_d_col_major,
+                                          float* g_plane_s, hipStream_t stream) {
     if (M == 0) return NVSF_OK;
     REQUIRE(grad_x && gx_stride >= 120 && gx_stride % 4 == 0 && (g_plane_half || g_plane_quarter || g_hash_s || g_hash_d_half || g_plane_s));
     const void* ptrs[] = {grad_x, g_plane_half, g_plane_quarter, g_hash_d_half, g_plane_s};
@@ -366,6 +368,6 @@ NVSF_API int nvsf_density_tail_grad_split(const float* grad_x, uint32_t gx_strid
     REQUIRE((reinterpret_cast<uintptr_t>(g_hash_s) & (hash_s_is_f16 ? 7u : 15u)) == 0);
     const uint32_t want = (M + 63u) / 64u;
     hipLaunchKernelGGL(k_density_tail_grad_split, dim3(want < 4096u ? want : 4096u), dim3(kBlock), 0, stream, grad_x, gx_stride, M,
-                       g_plane_half, g_plane_quarter, g_hash_s, hash_s_is_f16, g_hash_d_half, g_plane_s, hash_d_col_major);
+                       g_plane_half, g_plane_quarter, g_hash_s, hash_s_is_f16, g_hash_d_half, g_plane_s, hash_d_col_major, hash_s_level_major);
     return nvsf_launch_status();
 }

@@ -46,7 +46,7 @@ SIGNATURES = {
     "nvsf_adam_update": [_P, _P, _P, _P, _U64, _F, _F, _F, _F, _P, _P, _P, _F, _P],
     "nvsf_ema_update": [_P, _P, _U64, _F],
     "nvsf_sigma_geo_bwd": [_P, _P, _P, _U, _U, _U, _P, _U, _F, _F],
-    "nvsf_density_tail_grad_split": [_P, _U, _U, _P, _P, _P, _I, _P, _I, _P],
+    "nvsf_density_tail_grad_split": [_P, _U, _U, _P, _P, _P, _I, _I, _P, _I, _P],
     "nvsf_cast_cols_f16": [_P, _I, _U, _U, _U, _P, _U],
     "nvsf_masked_sigmoid": [_P, _U, _U, _P, _U, _U, _P],
     "nvsf_sigmoid_bwd": [_P, _P, _U, _P],
@@ -74,6 +74,7 @@ SIGNATURES = {
     "nvsf_mse_sum_bwd": [_P, _P, _U, _F, _P, _P],
     "nvsf_density_dynamic_f16planes_fwd": [_P, _P, _P, _P, _P, _I, _P, _I, _U, _P, _P, _P, _P, _P],
     "nvsf_density_dynamic_lm_fwd": [_P, _P, _P, _P, _P, _I, _P, _I, _U, _P, _P, _P, _P, _P],
+    "nvsf_density_dynamic_lm32_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _U, _P, _P, _P, _P, _P],
     # section 5: ray generation
     "nvsf_lidar_rays": [_P, _P, _U, _U, _U, _F, _F, _F, _P, _P],
     "nvsf_camera_rays": [_P, _P, _U, _U, _F, _F, _F, _F, _P, _P],

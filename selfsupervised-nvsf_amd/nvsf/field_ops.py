@@ -208,9 +208,11 @@ class HashGridFn(Function):
     """fp16 features = encode(x; table).  Gradient flows to the (fp32 master) table only."""
 
     @staticmethod
-    def forward(ctx, x, params, table_f16, spec, cols, rows_per_ray=None, train_ctx=None):
+    def forward(ctx, x, params, table_f16, spec, cols, rows_per_ray=None, train_ctx=None, level_major=False):
         x = x.float().contiguous()
-        out = hashgrid_forward(x, cols, table_f16, spec)
+        # level_major: fp16 [L, M, F] instead of rows [M, L F] (hashgrid_forward_level_major; the caller has checked level_major_eligible):
+        # the gradient then comes back in the same layout, which is the one the binned scatter reads level by level
+        out = hashgrid_forward_level_major(x, table_f16, spec) if level_major else hashgrid_forward(x, cols, table_f16, spec)
         ctx.save_for_backward(x)
         ctx.spec, ctx.cols, ctx.rows_per_ray = spec, cols, rows_per_ray
         ctx.train_ctx, ctx.table_param = train_ctx, params
@@ -222,12 +224,14 @@ class HashGridFn(Function):
     def backward(ctx, grad_out):
         (x,) = ctx.saved_tensors
         if not ctx.needs_input_grad[1]:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         fine = _bin_from(ctx.spec, x.shape[0], ctx.rows_per_ray)
+        if grad_out.dim() == 3 and (fine is None or _hip.hashgrid_bwd_ws_bytes(x.shape[0], ctx.spec, fine[0], fine[1]) <= 0 or x.shape[0] > _BIN_ROWS_MAX):
+            grad_out = grad_out.permute(1, 0, 2).reshape(x.shape[0], -1)  # only the binned entry point reads level-major gradients
         done = scatter_beside_backward(ctx.train_ctx, ctx.table_param, (x, grad_out), lambda view, pool: hashgrid_backward(
             x, ctx.cols, ctx.spec, grad_out, grad_table=view.view(-1), fine_from=fine, ws_pool=pool))
         grad_params = None if done else hashgrid_backward(x, ctx.cols, ctx.spec, grad_out, fine_from=fine)
-        return None, grad_params, None, None, None, None, None
+        return None, grad_params, None, None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------

@@ -159,6 +159,8 @@ class HashGrid4D(nn.Module):
         """Static features [N, 32]; level_major=True (no autograd): fp16 [8, N, 4] where the encoder offers it -- the layout its
         one-level-per-XCD kernel writes as whole lines and the fused density tail reads (network_dynamic._density_tail_fused)."""
         if level_major:
+            if torch.is_grad_enabled():
+                return self.hash_static(x, level_major=True)  # rows where the level-major form is not built
             out = self.hash_static.forward_level_major(x)
             if out is not None:
                 return out

@@ -97,7 +97,8 @@ class NeRFNetwork(NeRFRenderer):
         flow = self.flow_net(xt, t_host, fp16=fp16)
         fused3 = hash_enc.training_fused3(x, t, t_host, flow, frame_idx, self.num_frames)
         if fused3 is not None:
-            hash_s = hash_enc.forward_static(x)
+            # level-major [8, M, 4] where the fused density tail (DensityTailFn) will take it: `density` turns it back into rows otherwise
+            hash_s = hash_enc.forward_static(x, level_major=torch.is_grad_enabled() and self._tail_fused_in_training())
             hash_d, hash_1f, hash_2f = fused3
         else:
             hash_s, hash_d = hash_enc(x, t, t_host)
@@ -155,15 +156,20 @@ class NeRFNetwork(NeRFRenderer):
         plane_1 = plane_2 = plane_d
         return (plane_s, plane_d, plane_1, plane_2, hash_s, hash_d, hash_d if hash_1 is None else hash_1, hash_d if hash_2 is None else hash_2)
 
+    def _tail_fused_in_training(self):
+        return testing.get("density_tail_train") == "fused" and self.sigma_net.spec.in_cols == 128 and self.sigma_net.spec.n_hidden == 1
+
     def density(self, x, t=None, cal_lidar_color=False, **kwargs):
         plane_s, plane_d, plane_1, plane_2, hash_s, hash_d, hash_1, hash_2 = self._dynamic_features(self._unit_cube(x), t, cal_lidar_color,
                                                                                                      fp16=kwargs.get("fp16"))
+        tail_train = (torch.is_grad_enabled() and self._tail_fused_in_training() and hash_s.dtype == torch.float16 and plane_s.dtype == torch.float32
+                      and hash_d.dtype == torch.float32 and not hash_1.requires_grad and not hash_2.requires_grad)
+        if torch.is_grad_enabled() and hash_s.dim() == 3 and not tail_train:  # level-major features without the node that reads them: rows
+            hash_s = hash_s.permute(1, 0, 2).reshape(hash_s.shape[1], -1)
         if not torch.is_grad_enabled():
             # fused tail (csrc/density_dynamic.hip): neighbour blend + concatenation + density MLP in one kernel
             h = self._density_tail_fused(plane_s, plane_d, plane_1, plane_2, hash_s, hash_d, hash_1, hash_2)
-        elif (testing.get("density_tail_train") == "fused" and self.sigma_net.spec.in_cols == 128
-              and self.sigma_net.spec.n_hidden == 1 and hash_s.dtype == torch.float16 and plane_s.dtype == torch.float32
-              and hash_d.dtype == torch.float32 and not hash_1.requires_grad and not hash_2.requires_grad):
+        elif tail_train:
             # neighbour blend + concatenation + density MLP as ONE forward launch that also leaves the rounded network input
             # for the fused MLP backward; no [M,120] fp32 concatenation, no blend temporaries, in either direction
             sigma, geo = DensityTailFn.apply(self, plane_s, plane_d, plane_1, plane_2, hash_s, hash_d, hash_1, hash_2, self.sigma_net.params)
@@ -203,9 +209,9 @@ class NeRFNetwork(NeRFRenderer):
                 raise ValueError("fp16 plane rows come blended (plane_1 = plane_2 = plane_d)")
             entry, planes = "nvsf_density_dynamic_f16planes_fwd", planes[:2]
         if hash_s.dim() == 3:  # level-major static hash features (hash_field.forward_static(level_major=True))
-            if entry != "nvsf_density_dynamic_f16planes_fwd" or tuple(hash_s.shape) != (8, M, 4) or hash_s.dtype != torch.float16:
-                raise ValueError("level-major static hash features come as fp16 [8, M, 4] together with fp16 plane rows")
-            entry = "nvsf_density_dynamic_lm_fwd"
+            if tuple(hash_s.shape) != (8, M, 4) or hash_s.dtype != torch.float16:
+                raise ValueError("level-major static hash features come as fp16 [8, M, 4]")
+            entry = "nvsf_density_dynamic_lm_fwd" if entry == "nvsf_density_dynamic_f16planes_fwd" else "nvsf_density_dynamic_lm32_fwd"
         args = planes + [_hip.ptr(c(hash_s)), _hip.ptr(c(hash_d)),
                          _hip.ptr(c(hash_1)), 1 if hash_1.dtype == torch.float16 else 0, _hip.ptr(c(hash_2)), 1 if hash_2.dtype == torch.float16 else 0,
                          M, _hip.ptr(self.sigma_net.weights_f16())]
@@ -281,7 +287,13 @@ class DensityTailFn(torch.autograd.Function):
         ctx.save_for_backward(x16, net.sigma_net.weights_f16(), sigma)
         ctx.spec = net.sigma_net.spec
         ctx.hash_s_dtype = hash_s.dtype
+        ctx.hash_s_lm = hash_s.dim() == 3
         return sigma, h[:, 1:net.sigma_net.spec.n_out]
+
+    @staticmethod
+    def _hash_s_grad(ctx, grad_x):
+        g = grad_x[:, 64:96].to(ctx.hash_s_dtype)
+        return g.reshape(-1, 8, 4).permute(1, 0, 2).contiguous() if ctx.hash_s_lm else g
 
     @staticmethod
     def backward(ctx, g_sigma, g_geo):
@@ -310,21 +322,24 @@ class DensityTailFn(torch.autograd.Function):
             f32 = dict(dtype=torch.float32, device=dev)
             g_half = torch.empty(M, 32, **f32) if need[2] else None
             g_quarter = torch.empty(M, 32, **f32) if (need[3] or need[4]) else None
-            g_hs = torch.empty(M, 32, dtype=ctx.hash_s_dtype, device=dev) if (need[5] and ctx.hash_s_dtype in (torch.float16, torch.float32)) else None
+            g_hs = None
+            if need[5] and ctx.hash_s_dtype in (torch.float16, torch.float32):  # in hash_s's own layout: rows [M, 32] or level-major [8, M, 4]
+                g_hs = torch.empty((8, M, 4) if ctx.hash_s_lm else (M, 32), dtype=ctx.hash_s_dtype, device=dev)
             # hash_d's gradient column-major ([M, 24] with strides (1, M)): the table-gradient kernel of the space-time grids has every
             # workgroup read ONE column of it (hash_field.HashDynFn._backward passes such a tensor on as it is)
             g_hd = torch.empty(24, M, **f32).t() if need[6] else None
             g_ps = torch.empty(M, 32, **f32) if need[1] else None  # rows of its own: the planes' backward reads contiguous rows
             if g_half is not None or g_quarter is not None or g_hs is not None or g_hd is not None or g_ps is not None:
                 _hip.call("nvsf_density_tail_grad_split", _hip.ptr(grad_x), grad_x.stride(0), M, _hip.ptr(g_half), _hip.ptr(g_quarter), _hip.ptr(g_hs),
-                          1 if ctx.hash_s_dtype == torch.float16 else 0, None if g_hd is None else g_hd.data_ptr(), 1, _hip.ptr(g_ps))
+                          1 if ctx.hash_s_dtype == torch.float16 else 0, 1 if ctx.hash_s_lm else 0, None if g_hd is None else g_hd.data_ptr(), 1,
+                          _hip.ptr(g_ps))
             out[1], out[2], out[6] = g_ps, g_half, g_hd
             if need[3]:
                 out[3] = g_quarter
             if need[4]:
                 out[4] = g_quarter
             if need[5]:
-                out[5] = g_hs if g_hs is not None else grad_x[:, 64:96].to(ctx.hash_s_dtype)
+                out[5] = g_hs if g_hs is not None else DensityTailFn._hash_s_grad(ctx, grad_x)
         elif need_x:
             g_pd = grad_x[:, 32:64]
             quarter = 0.25 * g_pd if (need[3] or need[4]) else None
@@ -337,7 +352,7 @@ class DensityTailFn(torch.autograd.Function):
             if need[4]:
                 out[4] = quarter
             if need[5]:
-                out[5] = grad_x[:, 64:96].to(ctx.hash_s_dtype)
+                out[5] = DensityTailFn._hash_s_grad(ctx, grad_x)
             if need[6]:
                 out[6] = 0.5 * grad_x[:, 96:120]
         if need[9]:

@@ -85,10 +85,13 @@ class Encoding(nn.Module):
     def table_f16(self):
         return self._cache.get(self.params)
 
-    def forward(self, x):
+    def forward(self, x, level_major=False):
+        """level_major (not part of tiny-cuda-nn's interface): fp16 [n_levels, M, n_features_per_level] where ops.level_major_eligible,
+        with autograd -- the static hash of the space-time field hands its features to the fused density tail that way."""
         x = x.reshape(-1, self.n_input_dims) if x.dim() != 2 else x
         if self.otype in ("HashGrid", "Grid"):
-            return _ops.HashGridFn.apply(x, self.params, self.table_f16(), self.spec, self._cols, _ops.rows_hint(self), _ops.train_context(self))
+            lm = bool(level_major) and x.is_cuda and self._cols == (0, 1, 2) and _ops.level_major_eligible(self.spec)
+            return _ops.HashGridFn.apply(x, self.params, self.table_f16(), self.spec, self._cols, _ops.rows_hint(self), _ops.train_context(self), lm)
         if self.otype == "Frequency":
             return _ops.freq_encode(x, self.n_frequencies)
         return _ops.sh4_encode(x)
@@ -105,7 +108,7 @@ class Encoding(nn.Module):
         """HashGrid only: encode the columns `cols` of a wider coordinate matrix in place (no gather copy) --
         e.g. the (x, z) pair of an [N, 3] position tensor for a 2-D time-slice grid."""
         assert self.otype in ("HashGrid", "Grid") and len(cols) == self.n_input_dims
-        return _ops.HashGridFn.apply(x, self.params, self.table_f16(), self.spec, tuple(cols), _ops.rows_hint(self), _ops.train_context(self))
+        return _ops.HashGridFn.apply(x, self.params, self.table_f16(), self.spec, tuple(cols), _ops.rows_hint(self), _ops.train_context(self), False)
 
     def extra_repr(self):
         return f"n_input_dims={self.n_input_dims}, n_output_dims={self.n_output_dims}, {self.encoding_config}"
