@@ -971,19 +971,35 @@ class PlanesFn(Function):
         # bucket view), as the table scatters are: a space-time model evaluates its planes three times per ray batch, and autograd
         # would zero-fill a 67 MB buffer per evaluation and add the three up again.
         tctx, param = ctx.train_ctx, ctx.planes_param
-        view = None
-        if need_p and tctx is not None and tctx.sink is not None and isinstance(param, torch.nn.Parameter) and param.is_cuda and param.dtype == torch.float32:
+        res = _hip.host_u32(ctx.res_host)
+
+        def launch(g_planes, g_xt):  # the coordinate gradients and the texel scatter are separate kernels: either pointer may be NULL
+            _hip.call("nvsf_planes_bwd", _hip.ptr(xt), xt.shape[0], _hip.ptr(planes_cl), S, 8, res, int(want), _hip.ptr(g_s), _hip.ptr(g_d),
+                      _hip.ptr(g_planes), _hip.ptr(g_xt))
+        g_xt = torch.empty_like(xt) if need_x else None
+        sink_ok = (need_p and tctx is not None and tctx.sink is not None and isinstance(param, torch.nn.Parameter) and param.is_cuda
+                   and param.dtype == torch.float32)
+        if sink_ok and tctx.overlap:
+            # the coordinate gradients (what the flow field's backward waits for) on this stream, the texel scatter -- the longest
+            # kernel of a space-time step -- on the step's side stream beside the rest of backward, as the table scatters
+            if need_x:
+                launch(None, g_xt)
+            tensors = tuple(t for t in (xt, planes_cl, g_s, g_d) if t is not None)
+            if scatter_beside_backward(tctx, param, tensors, lambda view, pool: launch(view, None)):
+                return g_xt, None, None, None, None
+            raise _hip.NvsfHipError("PlanesFn: the step's gradient sink refused the planes parameter")
+        if sink_ok:
             last = tctx.done(param)
             view = tctx.sink.view_for(param)
-        g_planes = view if view is not None else (torch.zeros_like(planes_cl) if need_p else None)
-        g_xt = torch.empty_like(xt) if need_x else None
-        if need_p or need_x:
-            _hip.call("nvsf_planes_bwd", _hip.ptr(xt), xt.shape[0], _hip.ptr(planes_cl), S, 8, _hip.host_u32(ctx.res_host), int(want),
-                      _hip.ptr(g_s), _hip.ptr(g_d), _hip.ptr(g_planes), _hip.ptr(g_xt))
-        if view is not None:
+            launch(view, g_xt)
             if last:
                 tctx.sink.mark_ready(param)
             return g_xt, None, None, None, None
+        if tctx is not None and isinstance(param, torch.nn.Parameter):
+            tctx.done(param)
+        g_planes = torch.zeros_like(planes_cl) if need_p else None
+        if need_p or need_x:
+            launch(g_planes, g_xt)
         return g_xt, g_planes, None, None, None
 
 

@@ -93,13 +93,24 @@ class Planes4D(nn.Module):
                 missing_keys.append(k)
         state[prefix + "planes_cl"] = flat
 
+    def wait_pending_update(self):
+        """A training step may leave the optimiser pass of this parameter on its table-scatter stream (RenderTrainStep: the planes
+        scattered in the last backward pass are updated behind their scatter, like the hash tables).  The first reader of the
+        parameter makes ITS stream wait for that pass here (the hash tables do the same through their fp16 cache)."""
+        ev = self.__dict__.get("_pending_update")
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self.__dict__["_pending_update"] = None
+
     def _channel_last(self):
         """The buffer the kernels read: the parameter itself."""
+        self.wait_pending_update()
         p = self.planes_cl
         return p if (p.dtype == torch.float32 and p.is_contiguous()) else p.detach().float().contiguous()
 
     def _encode(self, xt, want):
         xt = xt.reshape(-1, 4)
+        self.wait_pending_update()
         return ops.PlanesFn.apply(xt, self.planes_cl, self._res_host, want, ops.train_context(self))
 
     @torch.no_grad()

@@ -168,6 +168,8 @@ class RenderTrainStep:
         self.defer_last_table = on_gpu and self.buckets is None
         self._sink = None
         self._pending = None  # (event behind the deferred optimiser pass, its parameters)
+        # parameter -> the Planes4D module that owns it (its kernels read the fp32 parameter: planes_field.Planes4D.wait_pending_update)
+        self._plane_owner = {mod.planes_cl: mod for mod in model.modules() if isinstance(getattr(mod, "planes_cl", None), torch.nn.Parameter)}
         self._cache_of = {}   # parameter -> the fp16 cache of the module that owns it (tinycudann.Encoding / Network)
         for mod in model.modules():
             if hasattr(mod, "_cache") and isinstance(getattr(mod, "params", None), torch.nn.Parameter):
@@ -302,6 +304,9 @@ class RenderTrainStep:
                 cache = self._cache_of.get(p)
                 if cache is not None and cache.pending is ev:
                     cache.pending = None
+                owner = self._plane_owner.get(p)
+                if owner is not None and owner.__dict__.get("_pending_update") is ev:
+                    owner.__dict__["_pending_update"] = None
             self._pending = None
 
     def step(self, batch):
@@ -347,6 +352,9 @@ class RenderTrainStep:
                 cache = self._cache_of.get(p)
                 if cache is not None:
                     cache.pending = ev
+                owner = self._plane_owner.get(p)
+                if owner is not None:  # K-planes: read as fp32 by their kernels, the module makes its first reader wait
+                    owner.__dict__["_pending_update"] = ev
         if found is not None:
             self.scaler.update(found)
         self.sched.step()
