@@ -403,6 +403,60 @@ def test_network_trains_end_to_end(dev, net):
     assert not torch.equal(before, m.sigma_net.params.detach())
 
 
+def test_training_step_scatters_beside_backward_and_defers_the_last_pass(dev, net):
+    """RenderTrainStep on the space-time model: the texel scatter of the K-planes and the table scatters run on the step's side stream
+    into the gradient sink, the parameters scattered in the LAST backward pass (the LiDAR encoders) are updated behind their scatter
+    and their first reader waits for that (Planes4D.wait_pending_update / the encoders' fp16 caches).  Same gradients as with every
+    kernel on one stream (atomic order only), and steps that follow each other stay finite and keep decreasing the loss."""
+    import copy
+    from nvsf import synthetic as S
+    from nvsf.nerf.train_step import RenderTrainStep
+    from nvsf.nerf.loss_scaler import LossScaler
+    rng = np.random.default_rng(5)
+    N = 256
+    lo, ld = S.lidar_rays(N, rng)
+    co, cd = S.camera_rays(N, rng)
+    g = torch.Generator().manual_seed(3)
+    batch = {"rays_o_lidar": _t(lo, dev)[None], "rays_d_lidar": _t(ld, dev)[None], "rays_o": _t(co, dev)[None], "rays_d": _t(cd, dev)[None],
+             "time": torch.tensor([[0.4]], device=dev), "gt_depth": (torch.rand(1, N, generator=g) * 0.5).to(dev),
+             "gt_raydrop": (torch.rand(1, N, generator=g) > 0.3).float().to(dev), "gt_intensity": torch.rand(1, N, generator=g).to(dev),
+             "gt_rgb": torch.rand(1, N, 3, generator=g).to(dev)}
+    grads, losses = {}, {}
+    for overlap in (False, True):
+        m = copy.deepcopy(net).train()
+        step = RenderTrainStep(m, num_steps=64, scale=S.SCALE, ema_decay=None)
+        step.scatter_overlap = overlap
+        step.scaler = LossScaler(init_scale=64.0, growth_interval=10 ** 6)
+        torch.manual_seed(10)
+        loss0, _, _ = step.step(batch)
+        grads[overlap] = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.numel() and p.grad is not None}
+        planes = m.planes_encoder_lidar
+        if overlap:
+            assert step._pending is not None and any(p is planes.planes_cl for p in step._pending[1])   # updated behind its scatter ...
+            assert planes.__dict__.get("_pending_update") is step._pending[0]                             # ... its first reader will wait
+            with torch.no_grad():
+                m.eval()
+                m.render(batch["rays_o_lidar"], batch["rays_d_lidar"], batch["time"], cal_lidar_color=True, num_steps=32)
+                m.train()
+            assert planes.__dict__.get("_pending_update") is None
+        cur = [float(loss0)]
+        for _ in range(4):
+            torch.manual_seed(10)
+            cur.append(float(step.step(batch)[0]))
+        step.sync()
+        torch.cuda.synchronize()
+        assert all(bool(torch.isfinite(p).all()) for p in m.parameters())
+        losses[overlap] = cur
+        assert cur[-1] < cur[0]
+    assert set(grads[False]) == set(grads[True])
+    for n, a in grads[False].items():
+        b = grads[True][n]
+        scale = float(a.abs().max())
+        if scale > 0:
+            assert float((a - b).abs().max()) <= 2e-5 * scale, n
+    assert abs(losses[True][-1] - losses[False][-1]) <= 2e-2 * abs(losses[False][-1])
+
+
 def test_host_time_cache_follows_the_tensor_object(dev):
     from nvsf.nerf.models.hash_field import _host_time
     t = torch.tensor([[0.25]], device=dev)
