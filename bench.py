@@ -16,7 +16,9 @@ skipped), synthetic rays resident in HBM.  A step renders both ray batches (forw
 fp32 compositing).  Frames are independent: with N GPUs each rank renders its own frame, no data-path
 collective (weak scaling); value = total rays / max-over-ranks time.
 
-One JSON line on stdout (rank 0): metric / value / ... plus
+stdout of rank 0 is ONE compact JSON line (<= FINAL_LINE_MAX_BYTES; `compact_line`): the contract keys, `roofline`, `cpu_baseline`
+and one-number summaries of the legs.  Everything else the legs measured -- per-kernel rows, per-parameter errors, notes -- goes to
+gpurun_out/bench_detail.json (`write_detail`), never to stdout (round 4's 30 KB line was not parsed by the driver).  Keys of the detail:
   roofline      the dominant launch of the step (the hash-grid encode pass of the camera batch), timed live with HIP
                 events on the launch stream; achieved = algorithmic B/sample (512 gathered + what the
                 launch writes) x samples / duration; traffic = 2*FETCH_SIZE + WRITE_SIZE of the committed PMC passes
@@ -38,8 +40,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "selfsupervised-nvsf_amd"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+os.environ.setdefault("TORCH_CPP_LOG_LEVEL", "ERROR")  # the train leg's kernel trace (torch.profiler) is chatty on stderr
+import warnings
+
 import numpy as np
 import torch
+
+warnings.filterwarnings("ignore", message=".*Profiler clears events.*")
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA peak
@@ -174,6 +181,16 @@ def kernel_breakdown(model, batches, T, iters):
     return rows
 
 
+def _running_render_digest(nvsf_build):
+    """Digest of the render kernels' sources the MAPPED library was built from (nvsf_build_digest(1)); without a HIP device
+    (the CPU contract test) nothing is mapped for compute and the digest of the sources on disk stands in."""
+    try:
+        from nvsf import _hip
+        return _hip.build_digest(render_only=True)
+    except Exception:
+        return nvsf_build.csrc_digest()
+
+
 def pmc_traffic(kernel_label):
     """HBM-side bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes
     (profiles/*_pmc_traffic.json, produced by tools/pmc_summary.py from separate --pmc FETCH_SIZE / WRITE_SIZE runs of
@@ -187,10 +204,11 @@ def pmc_traffic(kernel_label):
     if not files:
         return {"traffic": None}
     prof = json.load(open(files[-1]))
-    if prof.get("csrc_digest") != nvsf_build.csrc_digest():
+    running = _running_render_digest(nvsf_build)
+    if prof.get("csrc_digest") != running:
         # counters of another build of the kernels say nothing about this one: no figure rather than a stale one
         return {"traffic": None, "traffic_stale": f"{os.path.relpath(files[-1], ROOT)} was taken on kernel sources {prof.get('csrc_digest', '(unrecorded)')}, "
-                                                  f"this build is {nvsf_build.csrc_digest()}"}
+                                                  f"this build is {running}"}
     ks = prof["kernels"]
     which = "camera" if "camera" in kernel_label else "lidar"
     src = os.path.relpath(files[-1], ROOT) + " (2*FETCH_SIZE + WRITE_SIZE, bytes per launch)"
@@ -746,13 +764,144 @@ def dynamic_leg(dev, n_rays, T, steps):
     return out
 
 
+FINAL_LINE_MAX_BYTES = 6144  # the 29.7 KB line of round 4 was not parsed by the driver (18.2 KB in round 3 was)
+
+
+def _r(v, digits=5):
+    """Floats of the final line to `digits` significant digits (enough for every figure quoted; keeps the line short)."""
+    if isinstance(v, float):
+        return float(f"{v:.{digits}g}")
+    if isinstance(v, dict):
+        return {k: _r(x, digits) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_r(x, digits) for x in v]
+    return v
+
+
+def _extremes(rows, bound):
+    """Worst and best row of a leg against one roofline: {"n", "worst": [kernel, frac], "best": [kernel, frac]}."""
+    rows = [r for r in rows if r.get("bound") == bound and r.get("frac")]
+    if not rows:
+        return None
+    lo, hi = min(rows, key=lambda r: r["frac"]), max(rows, key=lambda r: r["frac"])
+    return {"n": len(rows), "worst": [lo["kernel"][:48], lo["frac"]], "best": [hi["kernel"][:48], hi["frac"]]}
+
+
+def write_detail(line):
+    """Everything the legs measured (per-kernel rows, per-parameter errors, notes) goes to gpurun_out/bench_detail.json -- next to
+    the driver's n1.out, merged back by gpurun -- NOT to stdout: the stdout of this program is the one compact line."""
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        path = os.path.join(out_dir, "bench_detail.json")
+        with open(path, "w") as f:
+            json.dump(line, f, indent=1)
+        return os.path.relpath(path, ROOT)
+    except OSError as e:  # a read-only checkout: the figures of the final line do not depend on the file
+        print(f"bench.py: detail not written ({e})", file=sys.stderr)
+        return None
+
+
+def compact_line(line, detail_path=None):
+    """The ONE stdout line: the contract keys in full, `roofline` and `cpu_baseline` in full (long sample descriptions shortened),
+    and one-number summaries of the secondary legs.  The per-kernel rows, per-parameter gradient errors and notes are in the
+    detail file.  Size is asserted (FINAL_LINE_MAX_BYTES)."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config", "outputs_finite", "spinup_ms", "per_rank_ms_per_step", "ranks_seen", "build", "invalid", "kernel_ms_sum")
+    out = {k: line[k] for k in keep if k in line}
+    out["config"] = {k: v for k, v in line["config"].items() if k != "pass"}
+    if "roofline" in line:
+        out["roofline"] = dict(line["roofline"])
+    if "kernels" in line:
+        out["kernels"] = [[r["kernel"], r["ms"], r["bound"], r["frac"]] for r in line["kernels"]]
+    if "cpu_baseline" in line:
+        c = line["cpu_baseline"]
+        cb = {k: c[k] for k in ("value", "unit", "cores", "kind") if k in c}
+        cb["sample"] = c["sample"][:200]
+        if "one_core" in c:
+            cb["one_core"] = c["one_core"]["value"]
+        if "torch_cpu" in c:
+            cb["torch_cpu"] = {"value": c["torch_cpu"]["value"], "cores": c["torch_cpu"].get("cores"),
+                               "one_core": c["torch_cpu"].get("one_core", {}).get("value")}
+        out["cpu_baseline"] = cb
+    if "outputs_match_oracle" in line:
+        o = line["outputs_match_oracle"]
+        errs = [v for k, v in o.items() if k.startswith("max_abs_err")]
+        out["outputs_match_oracle"] = {"ok": o["ok"], "tolerance": o["tolerance"], "max_abs_err": max(errs) if errs else None,
+                                       "checked_rays": [o.get("checked_rays_lidar"), o.get("checked_rays")]}
+    if "fresh_batches" in line:
+        out["fresh_batches"] = {k: line["fresh_batches"][k] for k in ("ms_per_step", "value")}
+    if "occupancy" in line:
+        o = line["occupancy"]
+        out["occupancy"] = {"value": o["eval"]["value"], "ms_per_step": o["eval"]["ms_per_step"],
+                            "train_forward_ms": o["train_forward"]["ms_per_step"], "occupied_fraction": o["occupied_fraction"]}
+    if "dynamic" in line:
+        d = line["dynamic"]
+        out["dynamic"] = {"value": d["value"], "ms_per_step": d["ms_per_step"], "fp32_flow_mlp_ms": d["fp32_flow_mlp"]["ms_per_step"],
+                          "moving_scene_ms": d["moving_scene"]["ms_per_step"],
+                          "outputs_match_fixture": {k: d["outputs_match_fixture"][k] for k in ("ok", "tolerance", "max_abs_err")},
+                          "train": {k: d["train"][k] for k in ("value", "ms_per_step") if k in d["train"]}}
+        if "grads_match" in d["train"]:
+            g = d["train"]["grads_match"]
+            out["dynamic"]["train"]["grads_match"] = {"ok": g["ok"], "tolerance": g["tolerance"], "max_rel_err": max(g["max_rel_err"].values())}
+    if "reference_default_grid" in line:
+        r = line["reference_default_grid"]
+        out["reference_default_grid"] = {"value": r["value"], "ms_per_step": r["ms_per_step"], "train_ms_per_step": r["train"]["ms_per_step"]}
+        if "grads_match" in r["train"]:
+            g = r["train"]["grads_match"]
+            out["reference_default_grid"]["train_grads_match"] = {"ok": g["ok"], "max_rel_err": max(g["max_rel_err"].values())}
+    if "eval" in line:
+        out["eval"] = {k: line["eval"][k] for k in ("value", "rays_per_s", "ms_per_frame", "scaling", "ranks") if k in line["eval"]}
+        out["eval"]["unit"] = "frames/s"
+    if "train" in line:
+        t = line["train"]
+        tr = {"value": t["value"], "ms_per_step": t["ms_per_step"], "steps": t["steps"], "per_rank_ms_per_step": t.get("per_rank_ms_per_step")}
+        if t.get("grads_match"):
+            tr["grads_match"] = {"ok": t["grads_match"]["ok"], "tolerance": t["grads_match"]["tolerance"],
+                                 "max_rel_err": max(t["grads_match"]["max_rel_err"].values())}
+        if t.get("kernels"):
+            k = t["kernels"]
+            tr["launches_per_step"] = k["launches_per_step"]
+            tr["glue_launches_per_step"] = k["glue"]["launches_per_step"]
+            tr["kernel_ms_per_step"] = k["kernel_ms_per_step"]
+            mf = [r for r in k["rows"] if r.get("bound") == "mfma"]
+            tr["mlp_kernels_mfma_frac_algorithmic"] = [[r["kernel"].split("(")[0][:28], r["ms"], r["frac"]] for r in mf[:6]]
+        if t.get("allreduce"):
+            a = t["allreduce"]
+            tr["allreduce"] = {k: a[k] for k in ("payload_MB", "buckets", "sum_ms", "ring_estimate_ms") if k in a}
+            tr["allreduce_collectives_per_step"] = t.get("allreduce_collectives_per_step")
+        out["train"] = tr
+    for leg in ("raymarching", "field_ops"):
+        if leg in line:
+            rows = line[leg]["kernels"]
+            out[leg] = {"hbm": _extremes(rows, "hbm")}
+            if _extremes(rows, "mfma"):
+                out[leg]["mfma"] = _extremes(rows, "mfma")
+            if leg == "field_ops":  # the stand-alone MLP rows carry both columns (VERDICT r4 item 7)
+                pipes = [[r["kernel"][:40], r["mfma_frac"]] for r in rows if r.get("mfma_frac")][:10]
+                if pipes:
+                    out[leg]["mlp_rows_mfma_frac"] = pipes
+    if detail_path:
+        out["detail"] = detail_path
+    out = _r(out)
+    n = len(json.dumps(out))
+    if n > FINAL_LINE_MAX_BYTES:  # never print a line the driver may not parse: shed the optional summaries, keep the contract
+        for k in ("field_ops", "raymarching", "kernels", "reference_default_grid", "occupancy", "eval", "fresh_batches"):
+            out.pop(k, None)
+            if len(json.dumps(out)) <= FINAL_LINE_MAX_BYTES:
+                break
+        out["shed"] = f"summaries dropped to stay under {FINAL_LINE_MAX_BYTES} bytes (line was {n})"
+    return out
+
+
 def rank_agreement(dist, nvsf_build):
     """After rank 0's build + barrier: every rank loads libnvsf_hip.so and reports (nvsf_version(), digest of ALL kernel sources,
     sha1 of the shared object it mapped); a rank that disagrees with rank 0 ends the run.  Also what each rank believes the world
     to be (`ranks_seen`: MIN / MAX of get_world_size() and the number of ranks that answered)."""
     import hashlib
     from nvsf import _hip
-    mine = {"version": _hip.version(), "csrc_digest": nvsf_build.csrc_digest_all(),
+    # csrc_digest: of the sources the mapped library was BUILT from (embedded by build.py), not of the sources on disk
+    mine = {"version": _hip.version(), "csrc_digest": _hip.build_digest(), "sources_on_disk": nvsf_build.csrc_digest_all(),
             "lib_sha1": hashlib.sha1(open(_hip.LIB_PATH, "rb").read()).hexdigest()[:16]}
     if dist is None:
         return dict(mine, ranks_agree=True, ranks_seen={"min": 1, "max": 1, "answered": 1})
@@ -797,6 +946,9 @@ def main():
     if dist is not None:
         dist.barrier()
     build_info = rank_agreement(dist, nvsf_build)  # every rank loads the library rank 0 built: same version, same sources
+    if build_info["csrc_digest"] != build_info["sources_on_disk"]:
+        raise SystemExit(f"bench.py: the mapped library was built from sources {build_info['csrc_digest']}, the sources on disk are "
+                         f"{build_info['sources_on_disk']} (build.build() should have relinked it)")
     from nvsf import synthetic as S
     from nvsf.nerf.models.network_static import NeRFNetworkStatic
 
@@ -913,7 +1065,7 @@ def main():
                        "pass": "forward render (no_grad): one wave-per-ray launch per batch (+ the XCD-sliced encode pass for the camera batch)", "parallelism": f"frame-sharded x{world}, no collective"},
             "outputs_finite": finite, "spinup_ms": args.spinup_ms,
             "per_rank_ms_per_step": per_rank_ms, "ranks_seen": build_info["ranks_seen"],
-            "build": {k: build_info[k] for k in ("version", "csrc_digest", "lib_sha1", "ranks_agree")},
+            "build": {k: build_info[k] for k in ("version", "csrc_digest", "sources_on_disk", "lib_sha1", "ranks_agree")},
         }
         if fresh is not None:
             line["fresh_batches"] = fresh
@@ -957,7 +1109,8 @@ def main():
         if rank == 0:
             line["train"] = tr
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        detail_path = write_detail(line)
+        print(json.dumps(compact_line(line, detail_path)), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -33,6 +33,12 @@ typedef struct ihipStream_t* nvsf_stream_t; /* == hipStream_t */
 /* library / build identification: returns a static string "nvsf_hip <version> gfx950" */
 const char* nvsf_version(void);
 
+/* identity of the SOURCES the mapped library was built from: which = 0: sha1[:16] over every translation unit, every csrc header and
+ * the compile flags (build.csrc_digest_all()); which = 1: the same over the render kernels' translation unit + headers + flags
+ * (build.csrc_digest(), what PMC profiles are tagged with).  A static 16-character string; "unknown_________" for a build made
+ * without build.py.  bench.py reports THIS digest (not that of the sources on disk) and build.py relinks when it differs. */
+const char* nvsf_build_digest(int which);
+
 /* TEST-ONLY: selects a second formulation of an operator -- the one the tests pin the production form against -- for every later
  * call of this process: name in {"march", "planes_fwd", "planes_bwd", "hashgrid_fwd", "hashgrid_bwd", "hash4d_bwd", "slice_plan",
  * "render_tail"}, value 0 = the production form (the default), 1 (march: 1, 2) = the reference form.  Returns the previous value,

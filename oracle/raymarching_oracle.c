@@ -34,6 +34,18 @@
 
 #define ORACLE_API __attribute__((visibility("default")))
 
+/* MADD(a, b, c) = a * b + c.  Default build: two individually rounded operations (the contract above).  Built a second time with
+ * -DORACLE_FMAD (liboracle_raymarching_fmad.so) the same sites are single-rounding fmaf -- the contraction nvcc applies by default
+ * (--fmad=true) to a product feeding an add in the marcher of raymarching.cu:375-438 (`ox + t * dx`, `x * mip_rbound + 1`, the
+ * cell-exit expressions, the jitter of t0).  That variant exists ONLY to price the deviation of this oracle (and of the HIP build,
+ * which follows it bit for bit) from a contracted build of the reference: tests/test_oracle_cpu.py marches the same rays both ways
+ * and records how often a discrete decision -- a ray's sample count -- differs. */
+#ifdef ORACLE_FMAD
+#define MADD(a, b, c) fmaf((a), (b), (c))
+#else
+#define MADD(a, b, c) ((a) * (b) + (c))
+#endif
+
 /* ---- helpers: raymarching.cu:25-95 ------------------------------------------------ */
 static const float kSqrt3 = 1.7320508075688772f; /* :25 */
 static const float kRPi = 0.3183098861837907f;   /* :28 */
@@ -165,9 +177,9 @@ static void ctx_init(march_ctx *c, const float *o, const float *d, const uint8_t
 /* Evaluates the sample at parameter t.  Returns 1 if the cell is occupied (sample is emitted,
  * xyz/dt filled) else 0 and *t_skip = the t reached after leaving the empty cell (:414-438). */
 static int march_probe(const march_ctx *c, float t, float xyz[3], float *dt_out, float *t_skip) {
-    const float x = clampf(c->ox + t * c->dx, -c->bound, c->bound); /* :386-388 */
-    const float y = clampf(c->oy + t * c->dy, -c->bound, c->bound);
-    const float z = clampf(c->oz + t * c->dz, -c->bound, c->bound);
+    const float x = clampf(MADD(t, c->dx, c->ox), -c->bound, c->bound); /* :386-388 */
+    const float y = clampf(MADD(t, c->dy, c->oy), -c->bound, c->bound);
+    const float z = clampf(MADD(t, c->dz, c->oz), -c->bound, c->bound);
     const float dt = clampf(t * c->dt_gamma, c->dt_min, c->dt_max); /* :390 */
     const int lp = mip_from_pos(x, y, z, (float)c->C), ld = mip_from_dt(dt, (float)c->H, (float)c->C);
     const int level = lp > ld ? lp : ld;                            /* :393-394 */
@@ -175,9 +187,9 @@ static int march_probe(const march_ctx *c, float t, float xyz[3], float *dt_out,
     const float mip_rbound = 1.0f / mip_bound;
     const float Hf = (float)c->H, Hm1 = (float)(c->H - 1);
     /* :400-405 -- the reference evaluates 0.5*(..)*H in double; both factors are exact there */
-    const int nx = (int)clampf((float)(0.5 * (double)(x * mip_rbound + 1.0f) * (double)c->H), 0.0f, Hm1);
-    const int ny = (int)clampf((float)(0.5 * (double)(y * mip_rbound + 1.0f) * (double)c->H), 0.0f, Hm1);
-    const int nz = (int)clampf((float)(0.5 * (double)(z * mip_rbound + 1.0f) * (double)c->H), 0.0f, Hm1);
+    const int nx = (int)clampf((float)(0.5 * (double)MADD(x, mip_rbound, 1.0f) * (double)c->H), 0.0f, Hm1);
+    const int ny = (int)clampf((float)(0.5 * (double)MADD(y, mip_rbound, 1.0f) * (double)c->H), 0.0f, Hm1);
+    const int nz = (int)clampf((float)(0.5 * (double)MADD(z, mip_rbound, 1.0f) * (double)c->H), 0.0f, Hm1);
     (void)Hf;
     const uint32_t index = (uint32_t)((float)level * c->H3 + (float)morton3((uint32_t)nx, (uint32_t)ny, (uint32_t)nz)); /* :407 */
     const int occ = (c->grid[index / 8] & (1u << (index % 8))) != 0;                                                   /* :408 */
@@ -185,9 +197,10 @@ static int march_probe(const march_ctx *c, float t, float xyz[3], float *dt_out,
     *dt_out = dt;
     if (occ) return 1;
     /* distance to the exit face of the empty cell, :420-433 */
-    const float tx = ((((float)nx + 0.5f + 0.5f * sgn1(c->dx)) * c->rH * 2.0f - 1.0f) * mip_bound - x) * c->rdx;
-    const float ty = ((((float)ny + 0.5f + 0.5f * sgn1(c->dy)) * c->rH * 2.0f - 1.0f) * mip_bound - y) * c->rdy;
-    const float tz = ((((float)nz + 0.5f + 0.5f * sgn1(c->dz)) * c->rH * 2.0f - 1.0f) * mip_bound - z) * c->rdz;
+    /* (n + 0.5f + 0.5f * sign) and (.. * rH) * 2 - 1 are exact either way (halves of small integers, a doubling) */
+    const float tx = MADD(MADD(MADD(0.5f, sgn1(c->dx), (float)nx + 0.5f) * c->rH, 2.0f, -1.0f), mip_bound, -x) * c->rdx;
+    const float ty = MADD(MADD(MADD(0.5f, sgn1(c->dy), (float)ny + 0.5f) * c->rH, 2.0f, -1.0f), mip_bound, -y) * c->rdy;
+    const float tz = MADD(MADD(MADD(0.5f, sgn1(c->dz), (float)nz + 0.5f) * c->rH, 2.0f, -1.0f), mip_bound, -z) * c->rdz;
     const float tt = t + fmaxf(0.0f, fminf(tx, fminf(ty, tz)));
     do { /* :435-437; the reference spins forever once the step drops below 1 ulp of t -- the restatement
           * (and the HIP path) leave the ray instead, which only differs where the reference never returns */
@@ -210,7 +223,7 @@ ORACLE_API void oracle_march_rays_train(const float *rays_o, const float *rays_d
         ctx_init(&c, rays_o + 3 * (size_t)n, rays_d + 3 * (size_t)n, grid, bound, dt_gamma, max_steps, C, H);
         const float far = fars[n];
         float t0 = nears[n];
-        t0 += clampf(t0 * dt_gamma, c.dt_min, c.dt_max) * noises[n]; /* :375 */
+        t0 = MADD(clampf(t0 * dt_gamma, c.dt_min, c.dt_max), noises[n], t0); /* :375 */
 
         /* pass 1 (:378-439): count */
         float t = t0, xyz[3], dt, tskip;
@@ -328,7 +341,7 @@ ORACLE_API void oracle_march_rays(uint32_t n_alive, uint32_t n_step, const int32
         float t = rays_t[index];
         const float far = fars[index];
         (void)nears;
-        t += clampf(t * dt_gamma, c.dt_min, c.dt_max) * noises[n]; /* :856 */
+        t = MADD(clampf(t * dt_gamma, c.dt_min, c.dt_max), noises[n], t); /* :856 */
         float last_t = t, xyz[3], dt, tskip;
         uint32_t step = 0;
         while (t < far && step < n_step) {

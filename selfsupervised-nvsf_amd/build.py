@@ -56,43 +56,86 @@ def sources():
 
 
 OBJDIR = os.path.join(LIBDIR, "obj")
-
-
-def _headers():
-    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.abspath(__file__)]
+DIGEST_MARK = b"NVSF_CSRC_DIGEST_ALL="  # followed by the 16 hex digits of csrc_digest_all() inside the shared object (csrc/version.hip)
 
 
 def _obj(src):
     return os.path.join(OBJDIR, os.path.basename(src)[:-4] + ".o")
 
 
+def _unit_digest(src, extra=""):
+    """What an object file was compiled from: flags, its translation unit, every header (+ for version.hip the digests it embeds)."""
+    import hashlib
+    h = hashlib.sha1((" ".join(FLAGS) + extra).encode())
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith(".h"):
+            h.update(f.encode())
+            h.update(open(os.path.join(CSRC, f), "rb").read())
+    h.update(open(src, "rb").read())
+    return h.hexdigest()
+
+
+def embedded_digest(path=LIB):
+    """The csrc_digest_all() of the sources a built libnvsf_hip.so was compiled from, read from the file's bytes (no dlopen); None
+    when the file is missing or predates the marker.  `nvsf_build_digest()` returns the same string from the mapped library."""
+    try:
+        blob = open(path, "rb").read()
+    except OSError:
+        return None
+    i = blob.find(DIGEST_MARK)
+    if i < 0:
+        return None
+    d = blob[i + len(DIGEST_MARK): i + len(DIGEST_MARK) + 16]
+    return d.decode() if re.fullmatch(rb"[0-9a-f]{16}", d) else None
+
+
 def _compile(args):
-    hipcc, src, report = args
-    cmd = [hipcc] + [f for f in FLAGS if f != "-shared"] + ["-c", src, "-o", _obj(src)]
+    hipcc, src, report, defines, digest = args
+    cmd = [hipcc] + [f for f in FLAGS if f != "-shared"] + defines + ["-c", src, "-o", _obj(src)]
     if report:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
     proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode == 0:
+        with open(_obj(src) + ".sha1", "w") as f:
+            f.write(digest)
     return src, proc.returncode, proc.stderr
 
 
 def build(force=False, report=False, verbose=True):
-    """One translation unit per .hip file, compiled in parallel into lib/obj/*.o (only the ones older than their source or any
-    csrc header), then linked into libnvsf_hip.so.  Kernels live in anonymous namespaces: no cross-file device linking."""
+    """One translation unit per .hip file, compiled in parallel into lib/obj/*.o, then linked into libnvsf_hip.so.  Staleness is
+    decided by CONTENT, not by mtime (a prebuilt library pushed to another box is newer than its sources whatever
+    they say): an object is rebuilt when the sha1 of (flags, its source, every header) differs from the one stored beside it, and
+    the library is relinked when the digest embedded in it (version.hip is compiled with -DNVSF_CSRC_DIGEST_ALL=csrc_digest_all())
+    is not the digest of the sources on disk.  Kernels live in anonymous namespaces: no cross-file device linking."""
     from concurrent.futures import ThreadPoolExecutor
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    newest_header = max(os.path.getmtime(h) for h in _headers())
     srcs = sources()
-    todo = [s for s in srcs if force or report or not os.path.exists(_obj(s))
-            or os.path.getmtime(_obj(s)) < max(os.path.getmtime(s), newest_header)]
-    stale_objs = [o for o in os.listdir(OBJDIR) if o.endswith(".o") and os.path.join(OBJDIR, o) not in {_obj(s) for s in srcs}]
+    want_all, want_render = csrc_digest_all(), csrc_digest()
+    defines = {s: [] for s in srcs}
+    digests = {}
+    for s in srcs:
+        extra = ""
+        if os.path.basename(s) == "version.hip":
+            defines[s] = [f'-DNVSF_CSRC_DIGEST_ALL="{want_all}"', f'-DNVSF_CSRC_DIGEST_RENDER="{want_render}"']
+            extra = want_all + want_render
+        digests[s] = _unit_digest(s, extra)
+
+    def stored(s):
+        try:
+            return open(_obj(s) + ".sha1").read().strip()
+        except OSError:
+            return None
+    todo = [s for s in srcs if force or report or not os.path.exists(_obj(s)) or stored(s) != digests[s]]
+    keep = {_obj(s) for s in srcs} | {_obj(s) + ".sha1" for s in srcs}
+    stale_objs = [o for o in os.listdir(OBJDIR) if os.path.join(OBJDIR, o) not in keep]
     for o in stale_objs:
         os.remove(os.path.join(OBJDIR, o))
-    if not todo and not stale_objs and os.path.exists(LIB) and os.path.getmtime(LIB) >= max(os.path.getmtime(_obj(s)) for s in srcs):
+    if not todo and not stale_objs and embedded_digest() == want_all:
         return LIB
     errors, logs = [], []
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
-        for src, rc, err in pool.map(_compile, [(hipcc, s, report) for s in todo]):
+        for src, rc, err in pool.map(_compile, [(hipcc, s, report, defines[s], digests[s]) for s in todo]):
             logs.append(err)
             if rc != 0:
                 errors.append((src, err))
@@ -105,6 +148,8 @@ def build(force=False, report=False, verbose=True):
     if link.returncode != 0:
         sys.stderr.write(link.stderr[-8000:])
         raise RuntimeError(f"hipcc failed ({link.returncode}) linking {LIB}")
+    if embedded_digest(LIB + ".tmp") != want_all:
+        raise RuntimeError("the linked library does not carry the digest of the sources it was built from")
     os.replace(LIB + ".tmp", LIB)
     text = "\n".join(logs)
     warn = [l for l in text.splitlines() if "warning:" in l]

@@ -3,6 +3,22 @@
 #include <string.h>
 NVSF_API const char* nvsf_version(void) { return "nvsf_hip 0.1.0 gfx950"; }
 
+// Identity of the sources this object was built from (build.py passes both digests on the command line of THIS translation unit
+// only; build.embedded_digest() finds the marker in the file's bytes, nvsf_build_digest() returns it from the mapped library).
+#ifndef NVSF_CSRC_DIGEST_ALL
+#define NVSF_CSRC_DIGEST_ALL "unknown_________"
+#endif
+#ifndef NVSF_CSRC_DIGEST_RENDER
+#define NVSF_CSRC_DIGEST_RENDER "unknown_________"
+#endif
+#define NVSF_MARK_ALL "NVSF_CSRC_DIGEST_ALL="
+#define NVSF_MARK_RENDER "NVSF_CSRC_DIGEST_RENDER="
+static const char g_digest_all[] = NVSF_MARK_ALL NVSF_CSRC_DIGEST_ALL;
+static const char g_digest_render[] = NVSF_MARK_RENDER NVSF_CSRC_DIGEST_RENDER;
+NVSF_API const char* nvsf_build_digest(int which) {
+    return which == 1 ? g_digest_render + sizeof(NVSF_MARK_RENDER) - 1 : g_digest_all + sizeof(NVSF_MARK_ALL) - 1;
+}
+
 static int g_variant[kVarCount] = {};
 __attribute__((visibility("hidden"))) int nvsf_variant(int key) { return key >= 0 && key < kVarCount ? g_variant[key] : 0; }
 

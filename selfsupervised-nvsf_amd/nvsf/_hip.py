@@ -120,6 +120,8 @@ def load():
     lib.nvsf_hashgrid_bwd_binned_ws_bytes.argtypes = [_U, _U, _U, _P, _P, _U, _U]
     lib.nvsf_version.restype = ctypes.c_char_p
     lib.nvsf_version.argtypes = []
+    lib.nvsf_build_digest.restype = ctypes.c_char_p
+    lib.nvsf_build_digest.argtypes = [ctypes.c_int]
     lib.nvsf_test_variant.restype = ctypes.c_int
     lib.nvsf_test_variant.argtypes = [ctypes.c_char_p, ctypes.c_int]
     _lib = lib
@@ -128,6 +130,11 @@ def load():
 
 def version():
     return load().nvsf_version().decode()
+
+
+def build_digest(render_only=False):
+    """Digest of the sources the MAPPED library was compiled from (csrc/version.hip), not of the sources on disk."""
+    return load().nvsf_build_digest(1 if render_only else 0).decode()
 
 
 def march_ws_bytes(n_rays):

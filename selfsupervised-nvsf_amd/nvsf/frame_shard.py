@@ -149,6 +149,7 @@ class GradBuckets:
         self._index = {p: i for i, p in enumerate(self.params)}
         self._flags = torch.zeros(len(self.params), dtype=torch.float32, device=self.params[0].device)
         self._flags_host = None
+        self._flags_copied = None  # event behind the last asynchronous copy out of the pinned flag buffer
         self._pending, self._next, self._handles, self._fired = [], 0, [], set()
         self._events = [[] for _ in self.buckets]
         self._hold, self._held = False, []
@@ -263,14 +264,23 @@ class GradBuckets:
             field_ops.sync_side_streams()
         self._launch_ready(force=True)
         # "somebody produced a gradient" flags: written on the host (pinned) and copied without blocking
+        #  the copy is asynchronous and, when every parameter fired, nothing below waits for it: the pinned buffer may be
+        # rewritten only after the PREVIOUS step's copy has left it -- an event behind the copy, waited for (on the host, normally long
+        # past) before the buffer is touched again
         if self._flags_host is None:
             self._flags_host = torch.zeros(len(self.params), dtype=torch.float32)
             if self._cuda:
                 self._flags_host = self._flags_host.pin_memory()
+            self._flags_copied = None
+        if self._flags_copied is not None:
+            self._flags_copied.synchronize()
         self._flags_host.zero_()
         for p in self._fired:
             self._flags_host[self._index[p]] = 1.0
         self._flags.copy_(self._flags_host, non_blocking=True)
+        if self._cuda:
+            self._flags_copied = torch.cuda.Event()
+            self._flags_copied.record()
         if self.ws > 1:
             self._handles.append(dist.all_reduce(self._flags, op=dist.ReduceOp.MAX, async_op=True))
             self.n_collectives += 1

@@ -29,6 +29,13 @@ class ExponentialMovingAverage:
         self.shadow_params = [p.detach().clone() for p in self._params]
         self.collected_params = None
         self._optimizer = None
+        # called before anything here reads or writes the parameters / shadows: RenderTrainStep leaves the optimiser pass of the last
+        # table on a side stream (with the shadow update folded in) and sets this to its sync()
+        self.before_access = None
+
+    def _settle(self):
+        if self.before_access is not None:
+            self.before_access()
 
     def _decay_now(self):
         """torch_ema: the count is incremented first, then decay = min(decay, (1 + n) / (10 + n))."""
@@ -39,6 +46,7 @@ class ExponentialMovingAverage:
 
     @torch.no_grad()
     def update(self):
+        self._settle()
         one_minus_decay = 1.0 - self._decay_now()
         for s, p in zip(self.shadow_params, self._params):
             if not p.requires_grad or p.numel() == 0:
@@ -62,17 +70,20 @@ class ExponentialMovingAverage:
     # ---- evaluation under the averaged weights (trainer.py:1475-1477, 1843-1844) --------------------------------------------
     @torch.no_grad()
     def copy_to(self):
+        self._settle()
         for s, p in zip(self.shadow_params, self._params):
             p.copy_(s)  # in-place: bumps the version the fp16 weight / table caches are keyed on
 
     @torch.no_grad()
     def store(self):
+        self._settle()
         self.collected_params = [p.detach().clone() for p in self._params]
 
     @torch.no_grad()
     def restore(self):
         if self.collected_params is None:
             raise RuntimeError("This ExponentialMovingAverage has no `store()`ed weights to `restore()`")
+        self._settle()
         for c, p in zip(self.collected_params, self._params):
             p.copy_(c)
         self.collected_params = None
@@ -80,6 +91,7 @@ class ExponentialMovingAverage:
     @torch.no_grad()
     def reset_to_parameters(self):
         """Starts the average again from the current weights (a checkpoint whose `ema` entry could not be restored)."""
+        self._settle()
         for s, p in zip(self.shadow_params, self._params):
             s.copy_(p.detach())
         if self.num_updates is not None:
@@ -87,10 +99,12 @@ class ExponentialMovingAverage:
         self.collected_params = None
 
     def state_dict(self):
+        self._settle()
         return {"decay": self.decay, "num_updates": self.num_updates, "shadow_params": self.shadow_params,
                 "collected_params": self.collected_params}
 
     def load_state_dict(self, state):
+        self._settle()
         self.decay = float(state["decay"])
         self.num_updates = state["num_updates"]
         if len(state["shadow_params"]) != len(self._params):

@@ -147,6 +147,7 @@ class RenderTrainStep:
         if ema_decay is not None and on_gpu:
             from nvsf.nerf.ema import ExponentialMovingAverage
             self.ema = ExponentialMovingAverage(model.parameters(), decay=ema_decay)
+            self.ema.before_access = self.sync  # evaluate_frames(ema=step.ema) right after step(): store / copy_to / restore wait
         self._cham = None
         self.global_step = 0
         self.failed_to_load = []  # components of the last load_checkpoint whose state could not be restored
@@ -168,6 +169,15 @@ class RenderTrainStep:
         self.defer_last_table = on_gpu and self.buckets is None
         self._sink = None
         self._pending = None  # (event behind the deferred optimiser pass, its parameters)
+        self._late_carry = None  # overflow found ONLY in a deferred table's gradient: reaches the scaler one step later (step())
+        if self.defer_last_table:
+            # a direct model.state_dict() / optimiser state_dict right after step() must see the deferred pass finished as well
+            # (the fp16-cache and K-planes readers wait by themselves; fp32 readers outside this package go through these hooks)
+            import weakref
+            me = weakref.ref(self)
+            settle = lambda *a, **k: (me() is not None and me().sync()) and None
+            model.register_state_dict_pre_hook(settle)
+            self.opt.register_state_dict_pre_hook(lambda *a, **k: settle())
         # parameter -> the Planes4D module that owns it (its kernels read the fp32 parameter: planes_field.Planes4D.wait_pending_update)
         self._plane_owner = {mod.planes_cl: mod for mod in model.modules() if isinstance(getattr(mod, "planes_cl", None), torch.nn.Parameter)}
         self._cache_of = {}   # parameter -> the fp16 cache of the module that owns it (tinycudann.Encoding / Network)
@@ -319,8 +329,14 @@ class RenderTrainStep:
         if not late:
             found = self.scaler.step(self.opt)
         else:
-            # every gradient but the late tables' is final on this stream: overflow decision from those (sufficient: loss_scaler.py),
-            # their update here, the late tables' update behind their scatter on the side stream
+            # every gradient but the late tables' is final on this stream: the step's overflow decision is taken from those (for a
+            # table fed by an fp32 input gradient that is sufficient: loss_scaler.py), their update here, the late tables' update
+            # behind their scatter on the side stream.  A table fed through an fp16 hand-over (the static hash of the space-time
+            # field: the density tail's gradient-split kernel casts a finite fp32 dX > 65504 to inf) is NOT covered by that argument,
+            # so the late gradients are inspected as well -- on the side stream, behind their scatter: `found_late` = early OR late
+            # is what the late tables' Adam pass skips on (no inf / nan can reach a table, its EMA shadow or its fp16 copy), and an
+            # overflow seen ONLY there reaches the scaler's update one step later (`_late_carry`: the scale is halved after the next
+            # step instead of this one; waiting for it here would put the scatter back on the critical path).
             from nvsf import field_ops
             late_set = {p for p, _ in late}
             early = [p for g in self.opt.param_groups for p in g["params"] if p.grad is not None and p not in late_set]
@@ -330,6 +346,7 @@ class RenderTrainStep:
                 self.opt.grad_scale, self.opt.found_inf = scale, found
             else:
                 found = None
+            carry = None
             try:
                 self.opt.step(params=early)
                 main = torch.cuda.current_stream()
@@ -341,6 +358,9 @@ class RenderTrainStep:
                     if found is not None:
                         found.record_stream(side)
                         scale.record_stream(side)
+                        late_only = self.scaler.found_inf([p.grad for p in late_set])
+                        self.opt.found_inf = torch.maximum(found, late_only)
+                        carry = torch.clamp_(late_only - found, min=0.0)  # 1 only when the early gradients were clean
                     self.opt.step(params=list(late_set))
                     ev = torch.cuda.Event()
                     ev.record(side)
@@ -356,6 +376,10 @@ class RenderTrainStep:
                 if owner is not None:  # K-planes: read as fp32 by their kernels, the module makes its first reader wait
                     owner.__dict__["_pending_update"] = ev
         if found is not None:
+            prev, self._late_carry = self._late_carry, (None if not late or carry is None else (ev, carry))
+            if prev is not None:  # a late-only overflow of the PREVIOUS step (its event is long past: this step's passes read that table)
+                torch.cuda.current_stream().wait_event(prev[0])
+                found = torch.maximum(found, prev[1])
             self.scaler.update(found)
         self.sched.step()
         self.global_step += 1

@@ -42,7 +42,9 @@ class _HalfCache:
     def writable(self, p):
         """The fp16 buffer for a kernel that is about to update `p` and write the copy itself (nvsf_adam_update): allocated (and
         filled) if it does not exist or `p` moved; the caller calls `mark_fresh(p)` after bumping the parameter's version."""
-        if self._half is None or self._half.numel() != p.numel() or self._half.device != p.device or self._key is None or self._key[0] != p.data_ptr():
+        # ... or is STALE (`p` changed since the copy was made -- load_state_dict, ema.restore -- with no forward read since): the
+        # update pass leaves the copy alone when the step is skipped on an overflow, and mark_fresh() would then bless old values
+        if self._half is None or self._half.numel() != p.numel() or self._key != (p.data_ptr(), p._version, p.device):
             self.get(p)
         return self._half
 

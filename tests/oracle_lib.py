@@ -21,7 +21,7 @@ def build():
 def _lib(name):
     if name not in _libs:
         path = os.path.join(ORACLE_DIR, f"liboracle_{name}.so")
-        src = os.path.join(ORACLE_DIR, f"{name}_oracle.c")
+        src = os.path.join(ORACLE_DIR, f"{name.replace('_fmad', '')}_oracle.c")
         if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
             build()
         _libs[name] = ctypes.CDLL(path)
@@ -82,14 +82,15 @@ def packbits(grid, thresh):
     return out
 
 
-def march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, C, H, M, nears, fars, noises, counter=None):
+def march_rays_train(rays_o, rays_d, grid, bound, dt_gamma, max_steps, C, H, M, nears, fars, noises, counter=None, fmad=False):
+    """fmad: the build of the same restatement whose multiply-adds are single-rounding fmaf (nvcc's default contraction)."""
     o, d = _f32(rays_o).reshape(-1, 3), _f32(rays_d).reshape(-1, 3)
     N = o.shape[0]
     xyzs, dirs, deltas = np.zeros((M, 3), np.float32), np.zeros((M, 3), np.float32), np.zeros((M, 2), np.float32)
     rays = np.zeros((N, 3), np.int32)
     counter = np.zeros(2, np.int32) if counter is None else counter
     g = np.ascontiguousarray(grid, dtype=np.uint8)
-    _lib("raymarching").oracle_march_rays_train(_p(o), _p(d), _p(g), F(bound), F(dt_gamma), U(max_steps), U(N), U(C), U(H), U(M),
+    _lib("raymarching_fmad" if fmad else "raymarching").oracle_march_rays_train(_p(o), _p(d), _p(g), F(bound), F(dt_gamma), U(max_steps), U(N), U(C), U(H), U(M),
                                                 _p(_f32(nears)), _p(_f32(fars)), _p(xyzs), _p(dirs), _p(deltas), _p(rays),
                                                 _p(counter), _p(_f32(noises)))
     return xyzs, dirs, deltas, rays, counter

@@ -77,27 +77,55 @@ def test_gpus_flag_starts_that_many_ranks(monkeypatch):
 def test_committed_bench_line_follows_the_contract():
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_line.json")))
     assert files
-    d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
+    text = open(files[-1]).read().strip().splitlines()[-1]
+    # the ONE stdout line must stay small enough for the driver to parse (BENCH_r04.parsed was null at 29.7 KB)
+    b = _bench()
+    assert len(text) <= b.FINAL_LINE_MAX_BYTES <= 8192, len(text)
+    d = json.loads(text)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["unit"] == "rays/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     rays = (d["config"]["num_rays"] + d["config"]["num_rays_lidar"]) * d["n_gpus"]
-    assert abs(d["value"] - rays / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6  # value = whole-job rays / time
+    assert abs(d["value"] - rays / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3  # value = whole-job rays / time (5 significant digits)
     r = d["roofline"]
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4
     assert r["traffic"] is None or r["traffic"] > 0
     # achieved = algorithmic bytes per launch / live launch duration
     if r["bound"] == "hbm":
         per_unit = float(r["algorithmic"].split()[0])
-        assert abs(r["achieved"] - per_unit * r["units_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-6
+        assert abs(r["achieved"] - per_unit * r["units_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-3
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "rays/s" and c["sample"]
-    for leg in ("occupancy", "dynamic", "train", "raymarching", "field_ops"):
+    # one-number summaries of the legs; the rows they summarise are in the detail file committed beside the line
+    for leg in ("occupancy", "dynamic", "train", "raymarching", "field_ops", "eval", "reference_default_grid", "outputs_match_oracle"):
         assert leg in d, leg
-    for row in d["raymarching"]["kernels"] + d["field_ops"]["kernels"] + d["kernels"]:
+    assert d["outputs_match_oracle"]["ok"] is True and d["train"]["grads_match"]["ok"] is True
+    assert d["dynamic"]["outputs_match_fixture"]["ok"] is True
+    det = json.load(open(files[-1].replace("_bench_line.json", "_bench_detail.json")))
+    assert abs(det["value"] - d["value"]) / d["value"] < 1e-3
+    for row in det["raymarching"]["kernels"] + det["field_ops"]["kernels"] + det["kernels"]:
         assert row["ms"] > 0 and row["frac"] > 0 and row["bound"] in ("hbm", "mfma", "l1")  # l1: L2-resident gathers (secondary rows only)
+    for row in det["field_ops"]["kernels"]:  # stand-alone MLP rows keep BOTH columns
+        if row["kernel"].startswith("mlp_"):
+            assert row["bound"] == "hbm" and 0 < row["mfma_frac"] < 1
+
+
+def test_compact_line_stays_small_whatever_the_legs_return():
+    """compact_line() on the last committed detail reproduces a line under the limit, and sheds summaries rather than the contract
+    keys when a leg grows."""
+    b = _bench()
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_detail.json")))
+    assert files
+    det = json.load(open(files[-1]))
+    line = b.compact_line(det, "gpurun_out/bench_detail.json")
+    assert len(json.dumps(line)) <= b.FINAL_LINE_MAX_BYTES and "shed" not in line
+    det["train"]["kernels"]["rows"] = [dict(r, kernel="k" * 28 + str(i)) for i, r in enumerate(det["train"]["kernels"]["rows"] * 40) if r.get("bound") == "mfma"]
+    line = b.compact_line(det, None)
+    assert len(json.dumps(line)) <= b.FINAL_LINE_MAX_BYTES
+    for k in ("metric", "value", "roofline", "cpu_baseline", "config"):
+        assert k in line
 
 
 def test_two_rank_line_carries_what_a_scaling_run_is_checked_by():

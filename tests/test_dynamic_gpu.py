@@ -457,6 +457,111 @@ def test_training_step_scatters_beside_backward_and_defers_the_last_pass(dev, ne
     assert abs(losses[True][-1] - losses[False][-1]) <= 2e-2 * abs(losses[False][-1])
 
 
+def test_overflow_only_in_a_deferred_table_gradient_never_reaches_the_table(dev, net):
+    """with the last pass' parameters deferred, the step's overflow decision is taken from the EARLY gradients.  For the
+    space-time model that is not sufficient by itself: the static hash of the field receives its feature gradient through an fp16
+    hand-over (nvsf_density_tail_grad_split), where a finite fp32 value above 65504 becomes inf while the density MLP's own weight
+    gradient stays finite.  Emulated here by writing an inf into the deferred table's gradient behind its scatter (on the scatter's
+    stream, every early gradient clean): the deferred Adam pass must skip (table, fp16 copy and EMA shadow untouched, no nan
+    anywhere), everything early may move (its gradients were clean), and the scaler halves its scale one step later."""
+    import copy
+    from nvsf import field_ops
+    from nvsf import synthetic as S
+    from nvsf.nerf.train_step import RenderTrainStep
+    from nvsf.nerf.loss_scaler import LossScaler
+    rng = np.random.default_rng(7)
+    N = 128
+    lo, ld = S.lidar_rays(N, rng)
+    co, cd = S.camera_rays(N, rng)
+    g = torch.Generator().manual_seed(4)
+    batch = {"rays_o_lidar": _t(lo, dev)[None], "rays_d_lidar": _t(ld, dev)[None], "rays_o": _t(co, dev)[None], "rays_d": _t(cd, dev)[None],
+             "time": torch.tensor([[0.4]], device=dev), "gt_depth": (torch.rand(1, N, generator=g) * 0.5).to(dev),
+             "gt_raydrop": (torch.rand(1, N, generator=g) > 0.3).float().to(dev), "gt_intensity": torch.rand(1, N, generator=g).to(dev),
+             "gt_rgb": torch.rand(1, N, 3, generator=g).to(dev)}
+    m = copy.deepcopy(net).train()
+    step = RenderTrainStep(m, num_steps=32, scale=S.SCALE, ema_decay=0.95)
+    step.scaler = LossScaler(init_scale=1.0, growth_interval=10 ** 6)  # small: no genuine fp16 overflow in these steps
+    step.ema.attach(step.opt)  # the every-step form: the shadow update rides in the (deferred) Adam pass
+    table = m.hash_encoder_lidar.hash_static.params
+    real_run, poisoned = step._run, []
+
+    def run_and_poison(b, defer):
+        out = real_run(b, defer)
+        late = out[3]
+        assert any(p is table for p, _ in late)  # the static hash of the LiDAR field is scattered in the last pass
+        if not poisoned:
+            with torch.cuda.stream(field_ops.side_stream(table.device)):
+                table.grad.view(-1)[12345] = float("inf")
+            poisoned.append(True)
+        return out
+    step._run = run_and_poison
+    torch.manual_seed(1)
+    step.ema.before_step()
+    step.step(batch)  # the poison is in this first step
+    step.sync()
+    torch.cuda.synchronize()
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    names = dict(m.named_parameters())
+    # first step: poisoned -> every deferred parameter skipped, nothing non-finite anywhere
+    ref = {n: p.detach() for n, p in net.named_parameters()}  # the untrained weights the step started from
+    t0 = ref["hash_encoder_lidar.hash_static.params"]
+    assert torch.equal(table.detach(), t0)
+    assert torch.equal(m.hash_encoder_lidar.hash_static._cache.get(table), t0.half())
+    shadow = dict(zip([id(p) for p in step.ema._params], step.ema.shadow_params))[id(table)]
+    assert torch.equal(shadow, t0)
+    assert not torch.equal(m.sigma_net.params.detach(), ref["sigma_net.params"])  # early parameters were clean and moved
+    for n, p in names.items():
+        assert bool(torch.isfinite(p).all()), n
+    assert step.scaler.get_scale() == 1.0       # the early decision was "clean" ...
+    torch.manual_seed(2)
+    step.ema.before_step()
+    step.step(batch)
+    step.sync()
+    torch.cuda.synchronize()
+    assert all(bool(torch.isfinite(p.grad).all()) for p in m.parameters() if p.grad is not None)  # this step itself was clean
+    assert step.scaler.get_scale() == 0.5        # ... and the late-only overflow reached the scaler one step later
+    assert not torch.equal(table.detach(), before["hash_encoder_lidar.hash_static.params"])  # a clean step updates the table again
+    for n, p in names.items():
+        assert bool(torch.isfinite(p).all()), n
+    torch.manual_seed(3)
+    step.ema.before_step()
+    step.step(batch)
+    step.sync()
+    assert step.scaler.get_scale() == 0.5        # carried once, not twice
+
+
+def test_fp32_readers_wait_for_the_deferred_update(dev, net):
+    """evaluate_frames(ema=step.ema) / model.state_dict() / optimiser.state_dict() right after step() -- the deferred
+    optimiser pass may still be writing the last table, its EMA shadow and Adam state on the side stream.  EMA store / copy_to /
+    restore / state_dict and the two state_dict() entry points call RenderTrainStep.sync() themselves."""
+    import copy
+    from nvsf import synthetic as S
+    from nvsf.nerf.train_step import RenderTrainStep
+    from nvsf.nerf.loss_scaler import LossScaler
+    rng = np.random.default_rng(9)
+    N = 128
+    lo, ld = S.lidar_rays(N, rng)
+    g = torch.Generator().manual_seed(4)
+    batch = {"rays_o_lidar": _t(lo, dev)[None], "rays_d_lidar": _t(ld, dev)[None],
+             "time": torch.tensor([[0.4]], device=dev), "gt_depth": (torch.rand(1, N, generator=g) * 0.5).to(dev),
+             "gt_raydrop": (torch.rand(1, N, generator=g) > 0.3).float().to(dev), "gt_intensity": torch.rand(1, N, generator=g).to(dev)}
+    co, cd = S.camera_rays(N, rng)
+    batch.update({"rays_o": _t(co, dev)[None], "rays_d": _t(cd, dev)[None], "gt_rgb": torch.rand(1, N, 3, generator=g).to(dev)})
+    m = copy.deepcopy(net).train()
+    step = RenderTrainStep(m, num_steps=32, scale=S.SCALE, ema_decay=0.95)
+    step.scaler = LossScaler(init_scale=64.0, growth_interval=10 ** 6)
+    readers = {"ema.store": step.ema.store, "ema.copy_to": step.ema.copy_to, "ema.restore": step.ema.restore, "ema.state_dict": step.ema.state_dict,
+               "ema.update": step.ema.update, "model.state_dict": m.state_dict, "optimizer.state_dict": step.opt.state_dict}
+    for name, reader in readers.items():
+        if name == "ema.restore":
+            step.ema.store()
+        step.step(batch)
+        assert step._pending is not None, name
+        reader()
+        assert step._pending is None, name  # the reader's stream has been made to wait for the deferred pass
+    torch.cuda.synchronize()
+
+
 def test_host_time_cache_follows_the_tensor_object(dev):
     from nvsf.nerf.models.hash_field import _host_time
     t = torch.tensor([[0.25]], device=dev)
