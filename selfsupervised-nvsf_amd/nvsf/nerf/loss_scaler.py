@@ -8,8 +8,9 @@ modality that went last, 1.3 ms on a side stream with nothing left to overlap it
 This class keeps GradScaler's rule (scale x 2 after `growth_interval` clean steps, x 0.5 and the step skipped on an overflow), its
 constructor arguments and its `state_dict` keys (scale, growth_factor, backoff_factor, growth_interval, _growth_tracker: reference
 checkpoints load, ours load there), and the same ATen kernels (`_amp_foreach_non_finite_check_and_unscale_`, `_amp_update_scale_`).
-What changes is WHICH gradients are inspected: `found_inf(grads)` takes the list the caller passes.  RenderTrainStep passes every
-gradient except the hash tables still being scattered, which is sufficient, not an approximation:
+What changes is WHICH gradients are inspected: `found_inf(grads)` takes the list the caller passes.  RenderTrainStep takes the step's
+decision from every gradient except the parameters still being scattered.  For a table fed by an fp32 input gradient (the static
+field: DensityFn / RenderRaysFn) that is sufficient, not an approximation:
 
     a table gradient is  sum_s w_c(s) g[s]  with interpolation weights in [0, 1] and g = dL/d(features) = the input gradient of the
     density MLP, dX[s][k] = sum_o W0[o][k] dP0[s][o];  it is non-finite only if some dP0[s][o] is (finite fp16 operands cannot
@@ -17,6 +18,11 @@ gradient except the hash tables still being scattered, which is sufficient, not 
     sum_s dP0[s][o] x[s][k] for every k, and inf x anything is inf or nan -- so the density MLP's weight gradient, which IS
     inspected, is non-finite whenever a table gradient is (tests/test_train_step_gpu.py: an injected overflow skips every
     parameter, tables included).
+
+A table that receives its feature gradient through an fp16 hand-over (the static hash of the space-time field: a finite fp32 dX above
+65504 becomes inf in the cast) is not covered by that argument, so RenderTrainStep.step also inspects the deferred gradients -- on
+the side stream behind their scatter: the deferred Adam pass skips on (early OR late), and an overflow found only there reaches
+`update` one step later (tests/test_dynamic_gpu.py::test_overflow_only_in_a_deferred_table_gradient_never_reaches_the_table).
 """
 import torch
 
@@ -28,7 +34,7 @@ class LossScaler:
         self._init_scale, self._growth_factor = float(init_scale), float(growth_factor)
         self._backoff_factor, self._growth_interval = float(backoff_factor), int(growth_interval)
         self._init_growth_tracker = 0
-        self._scale = self._growth_tracker = None
+        self._scale = self._growth_tracker = self._one = None
 
     def is_enabled(self):
         return self._enabled
@@ -62,7 +68,9 @@ class LossScaler:
         found = torch.zeros(1, dtype=torch.float32, device=self._device)
         grads = [g for g in grads if g is not None and g.numel()]
         if grads:
-            torch._amp_foreach_non_finite_check_and_unscale_(grads, found, torch.ones((), dtype=torch.float32, device=self._device))
+            if self._one is None:
+                self._one = torch.ones((), dtype=torch.float32, device=self._device)
+            torch._amp_foreach_non_finite_check_and_unscale_(grads, found, self._one)
         return found
 
     def step(self, optimizer, found_inf=None, params=None):

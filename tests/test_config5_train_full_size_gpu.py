@@ -1,0 +1,262 @@
+"""GPU: the TRAINING half of BASELINE config 5 (and of the static field with the reference-default grid) at the size it is timed.
+
+`bench.py`'s `dynamic.train` / `reference_default_grid.train` legs run one `RenderTrainStep` step of the reference-default models at
+4096 LiDAR + 4096 camera rays x 768 samples.  Only at that size (M = 3.1 M ray-ordered rows >= 2^18, field_ops._bin_from) does the
+production plan of these models switch on:
+
+  * static hash of the space-time field, L8 F4 T2^19: EVERY level through the bins as run sums -- plan (0, 8) -- fed by the fp16
+    LEVEL-MAJOR gradient `[8, M, 4]` the density tail hands over (nvsf_density_tail_grad_split);
+  * flow grid, L16 F8 T2^18, scattered as its 2-feature view (flow_field.FlowGridFn) with the plan `_bin_from` gives that view;
+  * the three space-time grids through the LDS kernel fed by the COLUMN-MAJOR `[24][M]` gradient (nvsf_hashgrid4d_dynamic_bwd_scalar_t);
+  * K-planes texel scatter and the table scatters on the step's side stream, straight into `.grad`.
+
+Every `-m gpu` training test of the space-time model elsewhere stays below the switch ("What's weak" 2).  Here, as
+tests/test_config4_full_size_gpu.py does for config 4 (reference: nvsf/nerf/models/network_dynamic.py:213-287, trainer.py:153-219, 491-503):
+
+  (a) each binned table gradient == the CPU oracle's scatter summed in fp64 (oracle_hashgrid_bwd_f64) of exactly the positions and
+      feature gradients the step handed to its scatter, <= 2e-5 of each level's largest entry;
+  (b) production plan == the reference formulations (`table_scatter="atomic"`, `hash4d_bwd="runs"`, `planes_bwd="atomic"`) on EVERY
+      parameter, `planes_cl` included;
+  (c) scatters beside backward (side stream) == everything on one stream, at this size.
+The same (a) + (b) for the static model with the L8 F4 grid (RenderRaysFn, level-major fp32 hand-over, plan (0, 8)).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_lib as O
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+import golden_dynamic as GD  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+N_RAYS, T = 4096, 768
+M = N_RAYS * T
+
+
+def _batch(S, dev):
+    rng = np.random.default_rng(0)
+    lo, ld = S.lidar_rays(N_RAYS, rng)
+    co, cd = S.camera_rays(N_RAYS, rng)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    t = lambda a: torch.from_numpy(a).to(dev)[None]
+    return {"rays_o_lidar": t(lo), "rays_d_lidar": t(ld), "rays_o": t(co), "rays_d": t(cd), "time": torch.tensor([[0.5]], device=dev),
+            "gt_depth": torch.rand(1, N_RAYS, generator=g).to(dev) * 0.5, "gt_raydrop": (torch.rand(1, N_RAYS, generator=g) > 0.3).float().to(dev),
+            "gt_intensity": torch.rand(1, N_RAYS, generator=g).to(dev), "gt_rgb": torch.rand(1, N_RAYS, 3, generator=g).to(dev)}
+
+
+@pytest.fixture(scope="module")
+def dynamic(dev):
+    """The reference's NeRFNetwork with its defaults (93.6 M parameters), parameters from name-derived seeds as in tests/test_config5_gpu.py
+    (tables N(0, 0.1)-sized: densities, weights and therefore gradients are not uniformly tiny), a flow of |flow| ~ 8e-4."""
+    from nvsf import synthetic as S
+    from nvsf.nerf.models.network_dynamic import NeRFNetwork
+    m = NeRFNetwork(min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH, **GD.RD)
+    GD.init_by_name(m)
+    assert 93e6 < sum(p.numel() for p in m.parameters()) < 94e6
+    return S, m.to(dev), _batch(S, dev)
+
+
+@pytest.fixture(scope="module")
+def static_rd(dev):
+    """The static field with the reference-default grid (main_nvsf.py:45-52: 8 levels x 4 features, 512 -> 32768, T 2^19)."""
+    from nvsf import synthetic as S
+    from nvsf.nerf.models.network_static import NeRFNetworkStatic
+    torch.manual_seed(0)
+    m = NeRFNetworkStatic(bound=S.BOUND, min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH, num_frames=S.NUM_FRAMES,
+                          num_levels=8, level_dim=4, base_resolution=512, desired_resolution=32768)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(5)
+        for enc in (m.hash_encoder_lidar, m.hash_encoder_camera):
+            enc.params.copy_(torch.randn(enc.params.shape, generator=g) * 0.1)
+    return S, m.to(dev), _batch(S, dev)
+
+
+def _new_step(S, m):
+    from nvsf.nerf.train_step import RenderTrainStep
+    from nvsf.nerf.loss_scaler import LossScaler
+    step = RenderTrainStep(m, num_steps=T, scale=S.SCALE, ema_decay=None)
+    step.scaler = LossScaler(init_scale=128.0)  # where the benchmark's scaler settles: ONE step with finite fp16 gradients
+    return step
+
+
+def _grads(step, m, batch, seed=11):
+    torch.manual_seed(seed)  # sampler jitter (perturb=True) from torch.rand: same seed, same samples
+    loss, parts, _ = step.forward_backward(batch)
+    torch.cuda.synchronize()
+    return float(loss), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+
+def _recording(monkeypatch):
+    """Records every call of field_ops.hashgrid_backward (inputs cloned on the stream the scatter is issued on) and what it returned."""
+    from nvsf import field_ops as ops
+    seen, real = [], ops.hashgrid_backward
+
+    def recording(x, cols, spec, grad_out, grad_table=None, fine_from=None, merge_from=None, **kw):
+        rec = {"x": x.detach().clone(), "g": grad_out.detach().clone(), "plan": fine_from, "spec": spec, "cols": tuple(cols),
+               "given_table": grad_table, "stream": torch.cuda.current_stream().cuda_stream}
+        out = real(x, cols, spec, grad_out, grad_table=grad_table, fine_from=fine_from, merge_from=merge_from, **kw)
+        rec["out"] = out.detach().clone()
+        seen.append(rec)
+        return out
+    monkeypatch.setattr(ops, "hashgrid_backward", recording)
+    return seen
+
+
+def _check_against_f64(rec, got, what):
+    spec = rec["spec"]
+    g = rec["g"]
+    if g.dim() == 3:  # level-major [L, M, F] -> rows
+        g = g.permute(1, 0, 2).reshape(g.shape[1], spec.L * spec.F)
+    ref = O.hashgrid_bwd_f64(rec["x"].cpu().numpy(), rec["cols"], spec, g.float().contiguous().cpu().numpy())
+    got = got.double().cpu().numpy().reshape(-1)
+    assert got.shape == ref.shape and np.isfinite(got).all(), what
+    worst = 0.0
+    for l in range(spec.L):
+        a, b = spec.offsets[l] * spec.F, spec.offsets[l + 1] * spec.F
+        scale = float(np.abs(ref[a:b]).max())
+        assert scale > 0.0, (what, l)
+        err = float(np.abs(got[a:b] - ref[a:b]).max()) / scale
+        worst = max(worst, err)
+        # the bins' fixed-point image truncates at 2^-40 of a level's largest addend, fp32 atomics round per addend: both far below
+        assert err <= 2e-5, (what, l, err)
+    print(f"{what}: worst level error {worst:.2e} of the level's largest entry (plan {rec['plan']}, gradient {tuple(rec['g'].shape)} {rec['g'].dtype})")
+
+
+def test_space_time_step_runs_the_production_plans_and_matches_the_oracle_scatter(dev, dynamic, monkeypatch):
+    from nvsf import field_ops as ops
+    S, m, batch = dynamic
+    step = _new_step(S, m)
+    seen = _recording(monkeypatch)
+    loss, grads = _grads(step, m, batch)
+    assert np.isfinite(loss)
+    main = torch.cuda.current_stream().cuda_stream
+    names = {id(p): n for n, p in m.named_parameters()}
+    static_calls = [r for r in seen if r["spec"].F == 4 and r["spec"].L == 8]
+    flow_calls = [r for r in seen if r["spec"].F == 2 and r["spec"].L == 16]
+    assert len(static_calls) == 2 and len(flow_calls) == 2 and len(seen) == 4  # camera pass, then LiDAR pass (split_backward)
+    for rec, enc in zip(static_calls, (m.hash_encoder_camera.hash_static, m.hash_encoder_lidar.hash_static)):
+        spec = enc.spec
+        # what the benchmark times: fp16 level-major hand-over, every level as run sums through the bins, on the side stream, into .grad
+        assert tuple(rec["g"].shape) == (8, M, 4) and rec["g"].dtype == torch.float16
+        assert rec["plan"] == (0, 8) == ops._bin_from(spec, M, T)
+        assert rec["stream"] != main
+        assert rec["given_table"].data_ptr() == enc.params.grad.data_ptr()
+        _check_against_f64(rec, grads[names[id(enc.params)]], f"static hash ({names[id(enc.params)]})")
+    # flow grid: both passes scatter G[row][e] on the 2-feature view of the L16 F8 T2^18 grid and expand it by the Lagrange weights
+    spec8 = m.flow_net.grid_enc.spec
+    assert (spec8.L, spec8.F, spec8.log2_hashmap_size) == (16, 8, 18)
+    total = torch.zeros(spec8.n_rows, 4, 2, dtype=torch.float64, device=dev)
+    from nvsf.nerf.models.hash_field import lagrange_weights_host
+    w = torch.tensor(np.asarray(lagrange_weights_host(0.5, 4, True), np.float64), device=dev)
+    for i, rec in enumerate(flow_calls):
+        assert tuple(rec["g"].shape) == (M, 32) and rec["g"].dtype == torch.float32
+        assert rec["plan"] == ops._bin_from(rec["spec"], M, T) and rec["plan"] is not None  # binned at this size
+        assert rec["stream"] != main
+        _check_against_f64(rec, rec["out"], f"flow grid, pass {i} (2-feature view)")
+        total += rec["out"].double().view(-1, 1, 2) * w.view(1, 4, 1)
+    got = grads["flow_net.grid_enc.params"].double().view(-1, 4, 2)
+    scale = float(total.abs().max())
+    assert scale > 0 and float((got - total).abs().max()) <= 1e-5 * scale  # the expansion + the sum of the two passes
+
+
+def test_space_time_production_plan_equals_the_reference_formulations_on_every_parameter(dev, dynamic, variants):
+    S, m, batch = dynamic
+    step = _new_step(S, m)
+    loss_p, prod = _grads(step, m, batch)
+    variants.set(table_scatter="atomic")    # static hash + flow grid: every level through nvsf_hashgrid_bwd (fp32 atomics)
+    variants.set(hash4d_bwd="runs")         # space-time grids: run-merging atomics instead of the LDS image
+    variants.set(planes_bwd="atomic")       # K-planes: per-sample atomics instead of run sums
+    loss_r, ref = _grads(step, m, batch)
+    for k in ("table_scatter", "hash4d_bwd", "planes_bwd"):
+        variants.clear(k)
+    assert loss_p == loss_r  # same forward, bit for bit
+    with_grad = {n for n, p in m.named_parameters() if p.numel() > 0 and p.requires_grad}
+    assert set(prod) == set(ref) == with_grad
+    assert any("planes_cl" in n for n in prod) and any("hash_dynamic" in n for n in prod) and "flow_net.grid_enc.params" in prod
+    worst = {}
+    for name in sorted(prod):
+        a, b = ref[name].double(), prod[name].double()
+        assert torch.isfinite(b).all(), name
+        scale = float(a.abs().max())
+        assert scale > 0.0, name
+        err = float((a - b).abs().max()) / scale
+        worst[name] = err
+        # same operands everywhere; fp32 atomics in another order / fixed-point bins / LDS integer sums against fp32 atomics
+        assert err <= 5e-5, (name, err)
+    top = sorted(worst.items(), key=lambda kv: -kv[1])[:3]
+    print("production plan vs reference formulations, largest relative differences:", ", ".join(f"{n} {e:.1e}" for n, e in top))
+
+
+def test_space_time_scatters_beside_backward_equal_one_stream(dev, dynamic):
+    S, m, batch = dynamic
+    step = _new_step(S, m)
+    _, side = _grads(step, m, batch)
+    step.scatter_overlap = False
+    _, one = _grads(step, m, batch)
+    step.scatter_overlap = True
+    assert set(side) == set(one)
+    for name in sorted(side):
+        a, b = one[name].double(), side[name].double()
+        scale = float(a.abs().max())
+        assert scale > 0.0 and float((a - b).abs().max()) <= 2e-5 * scale, name  # same kernels and operands: fp32 atomic order only
+
+
+def test_space_time_full_step_updates_every_parameter_and_stays_finite(dev, dynamic):
+    """Whole steps (forward, backward, loss scaling, Adam with the last pass' parameters updated behind their scatter) at the timed size."""
+    import copy
+    S, m0, batch = dynamic
+    m = copy.deepcopy(m0)
+    step = _new_step(S, m)
+    before = {n: p.detach().clone() for n, p in m.named_parameters() if p.numel()}
+    losses = []
+    for i in range(3):
+        torch.manual_seed(20 + i)
+        losses.append(float(step.step(batch)[0]))
+    step.sync()
+    torch.cuda.synchronize()
+    assert all(np.isfinite(losses))
+    for n, p in m.named_parameters():
+        if p.numel() and p.requires_grad:
+            assert bool(torch.isfinite(p).all()), n
+            assert not torch.equal(p.detach(), before[n]), n
+    del m, step
+    torch.cuda.empty_cache()
+
+
+def test_static_rd_step_runs_the_production_plan_and_matches_the_oracle_scatter(dev, static_rd, monkeypatch):
+    from nvsf import field_ops as ops
+    S, m, batch = static_rd
+    step = _new_step(S, m)
+    seen = _recording(monkeypatch)
+    loss, grads = _grads(step, m, batch)
+    assert np.isfinite(loss) and len(seen) == 2
+    main = torch.cuda.current_stream().cuda_stream
+    names = {id(p): n for n, p in m.named_parameters()}
+    for rec, enc in zip(seen, (m.hash_encoder_camera, m.hash_encoder_lidar)):
+        spec = enc.spec
+        assert (spec.L, spec.F) == (8, 4)
+        assert tuple(rec["g"].shape) == (8, M, 4) and rec["g"].dtype == torch.float32  # level-major fp32 from the density MLP's backward
+        assert rec["plan"] == (0, 8) == ops._bin_from(spec, M, T)
+        assert rec["stream"] != main and rec["given_table"].data_ptr() == enc.params.grad.data_ptr()
+        _check_against_f64(rec, grads[names[id(enc.params)]], f"static L8 F4 ({names[id(enc.params)]})")
+
+
+def test_static_rd_binned_plan_equals_the_atomic_variant_on_every_parameter(dev, static_rd, variants):
+    S, m, batch = static_rd
+    step = _new_step(S, m)
+    loss_b, binned = _grads(step, m, batch)
+    variants.set(table_scatter="atomic")
+    loss_a, atomic = _grads(step, m, batch)
+    variants.clear("table_scatter")
+    assert loss_a == loss_b
+    assert set(binned) == set(atomic) == {n for n, p in m.named_parameters() if p.numel() > 0}
+    for name in binned:
+        a, b = atomic[name].double(), binned[name].double()
+        assert torch.isfinite(b).all(), name
+        scale = float(a.abs().max())
+        assert scale > 0.0, name
+        assert float((a - b).abs().max()) / scale <= 5e-5, name
