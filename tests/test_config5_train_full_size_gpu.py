@@ -48,16 +48,21 @@ def _batch(S, dev):
             "gt_intensity": torch.rand(1, N_RAYS, generator=g).to(dev), "gt_rgb": torch.rand(1, N_RAYS, 3, generator=g).to(dev)}
 
 
-@pytest.fixture(scope="module")
-def dynamic(dev):
-    """The reference's NeRFNetwork with its defaults (93.6 M parameters), parameters from name-derived seeds as in tests/test_config5_gpu.py
-    (tables N(0, 0.1)-sized: densities, weights and therefore gradients are not uniformly tiny), a flow of |flow| ~ 8e-4."""
+def _make_dynamic(dev):
     from nvsf import synthetic as S
     from nvsf.nerf.models.network_dynamic import NeRFNetwork
     m = NeRFNetwork(min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH, **GD.RD)
     GD.init_by_name(m)
     assert 93e6 < sum(p.numel() for p in m.parameters()) < 94e6
-    return S, m.to(dev), _batch(S, dev)
+    return m.to(dev)
+
+
+@pytest.fixture(scope="module")
+def dynamic(dev):
+    """The reference's NeRFNetwork with its defaults (93.6 M parameters), parameters from name-derived seeds as in tests/test_config5_gpu.py
+    (tables N(0, 0.1)-sized: densities, weights and therefore gradients are not uniformly tiny)."""
+    from nvsf import synthetic as S
+    return S, _make_dynamic(dev), _batch(S, dev)
 
 
 @pytest.fixture(scope="module")
@@ -67,7 +72,7 @@ def static_rd(dev):
     from nvsf.nerf.models.network_static import NeRFNetworkStatic
     torch.manual_seed(0)
     m = NeRFNetworkStatic(bound=S.BOUND, min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH, num_frames=S.NUM_FRAMES,
-                          num_levels=8, level_dim=4, base_resolution=512, desired_resolution=32768)
+                          n_levels_hash=8, n_features_per_level_hash=4, base_resolution=512, max_resolution=32768, log2_hashmap_size=19)
     with torch.no_grad():
         g = torch.Generator().manual_seed(5)
         for enc in (m.hash_encoder_lidar, m.hash_encoder_camera):
@@ -174,8 +179,9 @@ def test_space_time_production_plan_equals_the_reference_formulations_on_every_p
     for k in ("table_scatter", "hash4d_bwd", "planes_bwd"):
         variants.clear(k)
     assert loss_p == loss_r  # same forward, bit for bit
-    with_grad = {n for n, p in m.named_parameters() if p.numel() > 0 and p.requires_grad}
-    assert set(prod) == set(ref) == with_grad
+    # (time slices of the space-time grids other than the two around t = 0.5 receive no gradient: same set both ways)
+    untouched = {n for n, p in m.named_parameters() if p.numel() > 0 and p.requires_grad} - set(prod)
+    assert set(prod) == set(ref) and all(".hash_t." in n for n in untouched) and len(untouched) == 2 * 3 * 6
     assert any("planes_cl" in n for n in prod) and any("hash_dynamic" in n for n in prod) and "flow_net.grid_enc.params" in prod
     worst = {}
     for name in sorted(prod):
@@ -185,10 +191,93 @@ def test_space_time_production_plan_equals_the_reference_formulations_on_every_p
         assert scale > 0.0, name
         err = float((a - b).abs().max()) / scale
         worst[name] = err
-        # same operands everywhere; fp32 atomics in another order / fixed-point bins / LDS integer sums against fp32 atomics
-        assert err <= 5e-5, (name, err)
+        # same operands everywhere; fp32 atomics in another order / fixed-point bins / LDS integer sums against fp32 atomics.
+        # planes_cl: the REFERENCE formulation (one fp32 atomic per sample, texel and channel) is the inaccurate side at this size --
+        # a texel of a time plane receives ~10^5..10^6 same-sign addends one by one -- so it only bounds the production kernel
+        # loosely here; test_planes_texel_gradient_at_full_size_against_fp64 below holds both against a deterministic fp64 sum
+        assert err <= (1e-2 if name.endswith("planes_cl") else 5e-5), (name, err)
     top = sorted(worst.items(), key=lambda kv: -kv[1])[:3]
     print("production plan vs reference formulations, largest relative differences:", ", ".join(f"{n} {e:.1e}" for n, e in top))
+
+
+def _fp64_plane_grad(enc, xt, g_out, si, pi, pairs):
+    """dL/d(plane si, pi) of Planes4D in fp64 WITHOUT atomics (the reference's formulas, planes_field.py:54-141: bilinear,
+    align_corners, border clamp, product over the three planes of a group): per-sample corner contributions sorted by texel,
+    segment sums as differences of a cumulative sum."""
+    pts = xt.double()
+    comb = pairs[pi]
+    group = [pj for pj, c in enumerate(pairs) if (3 in c) == (3 in comb)]
+    vals = {}
+    for pj in group:
+        _, _, off, C, H, W = enc._layout[si * 6 + pj]
+        plane = enc.planes_cl.detach()[off:off + C * H * W].double().view(H, W, C)
+        u, v = pts[:, pairs[pj][0]].clamp(0, 1) * (W - 1), pts[:, pairs[pj][1]].clamp(0, 1) * (H - 1)
+        u0, v0 = u.floor().clamp(max=max(W - 2, 0)), v.floor().clamp(max=max(H - 2, 0))
+        fu, fv = u - u0, v - v0
+        u0, v0 = u0.long(), v0.long()
+        val = (plane[v0, u0] * ((1 - fu) * (1 - fv))[:, None] + plane[v0, u0 + 1] * (fu * (1 - fv))[:, None]
+               + plane[v0 + 1, u0] * ((1 - fu) * fv)[:, None] + plane[v0 + 1, u0 + 1] * (fu * fv)[:, None])
+        vals[pj] = (val, u0, v0, fu, fv, H, W, C)
+    others = [pj for pj in group if pj != pi]
+    gval = g_out.double()[:, 8 * si: 8 * si + 8] * vals[others[0]][0] * vals[others[1]][0]
+    _, u0, v0, fu, fv, H, W, C = vals[pi]
+    keys = torch.cat([v0 * W + u0, v0 * W + u0 + 1, (v0 + 1) * W + u0, (v0 + 1) * W + u0 + 1])
+    wts = torch.cat([(1 - fu) * (1 - fv), fu * (1 - fv), (1 - fu) * fv, fu * fv])
+    contrib = gval.repeat(4, 1) * wts[:, None]
+    order = torch.argsort(keys)
+    keys, contrib = keys[order], contrib[order]
+    cs = torch.cumsum(contrib, 0)
+    last = torch.ones_like(keys, dtype=torch.bool)
+    last[:-1] = keys[1:] != keys[:-1]
+    ends = cs[last]
+    seg = ends.clone()
+    seg[1:] -= ends[:-1]
+    out = torch.zeros(H * W, C, dtype=torch.float64, device=xt.device)
+    out[keys[last]] = seg
+    return out.view(-1)
+
+
+def test_planes_texel_gradient_at_full_size_against_fp64(dev, dynamic, variants):
+    """The K-planes texel scatter of the step (k_planes_bwd_runs: run sums, one atomic per texel-quad change) at the timed size, on
+    the LiDAR batch's own sample positions and a SMOOTH, same-sign feature gradient (what a loss gradient looks like: the worst
+    case for one-by-one fp32 accumulation), against the deterministic fp64 sum.  Both formulations are reported; the production
+    kernel is held to 2e-5 of each plane's largest entry."""
+    import itertools
+    S, m, batch = dynamic
+    enc = m.planes_encoder_lidar
+    pairs = list(itertools.combinations(range(4), 2))
+    z = torch.linspace(float(S.MIN_NEAR), float(S.LIDAR_MAX_DEPTH), T, device=dev)
+    x = batch["rays_o_lidar"][0][:, None, :] + batch["rays_d_lidar"][0][:, None, :] * z[None, :, None]
+    x = ((x + S.BOUND) / (2 * S.BOUND)).clamp(0, 1).reshape(-1, 3)
+    xt0 = torch.cat([x, torch.full((x.shape[0], 1), 0.5, device=dev)], -1).contiguous()
+    gen = torch.Generator().manual_seed(1)
+    base = (0.5 + x[:, :1]) * 1e-3                                                        # smooth in space, one sign
+    ws = (base * (1.0 + 0.05 * torch.randn(x.shape[0], 32, generator=gen).to(dev))).contiguous()
+    wd = (base * (1.0 + 0.05 * torch.randn(x.shape[0], 32, generator=gen).to(dev))).contiguous()
+    got = {}
+    for variant in ("runs", "atomic"):
+        variants.set(planes_bwd=variant)
+        enc.planes_cl.grad = None
+        xt = xt0.clone().requires_grad_()
+        s_, d_ = enc(xt)
+        ((s_ * ws).sum() + (d_ * wd).sum()).backward()
+        torch.cuda.synchronize()
+        got[variant] = enc.planes_cl.grad.detach().clone()
+    variants.clear("planes_bwd")
+    enc.planes_cl.grad = None
+    worst = {"runs": 0.0, "atomic": 0.0}
+    for si in range(len(enc.multiscale_res)):
+        for pi in range(6):
+            _, _, off, C, H, W = enc._layout[si * 6 + pi]
+            ref = _fp64_plane_grad(enc, xt0, wd if 3 in pairs[pi] else ws, si, pi, pairs)
+            scale = float(ref.abs().max())
+            assert scale > 0
+            for variant in worst:
+                worst[variant] = max(worst[variant], float((got[variant][off:off + C * H * W].double() - ref).abs().max()) / scale)
+    print(f"K-planes texel gradient vs deterministic fp64 at M = {xt0.shape[0]}: run sums {worst['runs']:.2e}, per-sample atomics {worst['atomic']:.2e} "
+          "of a plane's largest entry")
+    assert worst["runs"] <= 2e-5
+    assert worst["atomic"] <= 2e-2  # the reference formulation's own accuracy at this size (informational bound)
 
 
 def test_space_time_scatters_beside_backward_equal_one_stream(dev, dynamic):
@@ -202,14 +291,15 @@ def test_space_time_scatters_beside_backward_equal_one_stream(dev, dynamic):
     for name in sorted(side):
         a, b = one[name].double(), side[name].double()
         scale = float(a.abs().max())
-        assert scale > 0.0 and float((a - b).abs().max()) <= 2e-5 * scale, name  # same kernels and operands: fp32 atomic order only
+        # same kernels and operands: only the order of the fp32 atomics changes (the three evaluations of a plane set land in the
+        # sink in another order: measured 4.2e-5 on planes_cl, whose largest entries are sums of ~10^5 addends)
+        assert scale > 0.0 and float((a - b).abs().max()) <= (1e-4 if name.endswith("planes_cl") else 2e-5) * scale, name
 
 
 def test_space_time_full_step_updates_every_parameter_and_stays_finite(dev, dynamic):
     """Whole steps (forward, backward, loss scaling, Adam with the last pass' parameters updated behind their scatter) at the timed size."""
-    import copy
-    S, m0, batch = dynamic
-    m = copy.deepcopy(m0)
+    S, _, batch = dynamic
+    m = _make_dynamic(dev)  # a model of its own: the steps below move the parameters
     step = _new_step(S, m)
     before = {n: p.detach().clone() for n, p in m.named_parameters() if p.numel()}
     losses = []
@@ -219,10 +309,16 @@ def test_space_time_full_step_updates_every_parameter_and_stays_finite(dev, dyna
     step.sync()
     torch.cuda.synchronize()
     assert all(np.isfinite(losses))
+    moved = 0
     for n, p in m.named_parameters():
         if p.numel() and p.requires_grad:
             assert bool(torch.isfinite(p).all()), n
-            assert not torch.equal(p.detach(), before[n]), n
+            if p.grad is None:  # the time slices of the space-time grids away from t = 0.5 are not touched by this batch
+                assert ".hash_t." in n and torch.equal(p.detach(), before[n]), n
+            else:
+                assert not torch.equal(p.detach(), before[n]), n
+                moved += 1
+    assert moved >= 20
     del m, step
     torch.cuda.empty_cache()
 
