@@ -401,32 +401,35 @@ def train_kernel_rows(step, batch, M, n_steps=3):
                     "exceeds ms_per_step); MFMA fractions from algorithmic FLOP / duration -- the counter view is profiles/*_pmc_train.json"}
 
 
-def train_grads_match(model, batch, T, scale):
-    """The check of tests/test_config4_full_size_gpu.py on the bench's own batch: one forward + backward of the production plan
-    (binned scatter, level-major gradient, side stream) against the atomic variant (every level through nvsf_hashgrid_bwd), same
-    jitter; max |difference| per parameter relative to that parameter's largest gradient entry."""
+def train_grads_match(model, batch, T, scale, reference=None, what=None):
+    """The check of tests/test_config4_full_size_gpu.py / test_config5_train_full_size_gpu.py on the bench's own batch: one forward +
+    backward of the production plan (binned scatter, level-major gradient, side stream) against the reference formulations
+    (`reference`: nvsf.testing variants; default: every level of every table through nvsf_hashgrid_bwd), same jitter; max |difference|
+    per parameter relative to that parameter's largest gradient entry."""
     from nvsf import testing
     from nvsf.nerf.train_step import RenderTrainStep
     from nvsf.nerf.loss_scaler import LossScaler
-    from nvsf.nerf.loss_scaler import LossScaler
-    step = RenderTrainStep(model, num_steps=T, scale=scale)
+    reference = reference or {"table_scatter": "atomic"}
+    step = RenderTrainStep(model, num_steps=T, scale=scale, ema_decay=None)
     step.scaler = LossScaler(init_scale=128.0)
     out = {}
-    for variant in ("binned", "atomic"):
+    for name, variants in (("production", {}), ("reference", reference)):
         torch.manual_seed(17)
-        with testing.variant(table_scatter=variant):
+        with testing.variant(**variants):
             step.forward_backward(batch)
         torch.cuda.synchronize()
-        out[variant] = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        out[name] = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
     model.zero_grad(set_to_none=True)
     errs = {}
-    for n, a in out["atomic"].items():
-        b = out["binned"].get(n)
+    for n, a in out["reference"].items():
+        b = out["production"].get(n)
         scale_n = float(a.abs().max())
         errs[n] = float("inf") if (b is None or scale_n == 0.0 or not bool(torch.isfinite(b).all())) else float((a - b).abs().max()) / scale_n
     tol = 5e-5
-    return {"ok": bool(errs) and all(v <= tol for v in errs.values()), "tolerance": tol, "max_rel_err": errs,
-            "what": "production table scatter (bins + level-major hand-over) against the atomic variant, every parameter, one full-size step"}
+    del step, out
+    return {"ok": bool(errs) and all(v <= tol for v in errs.values()), "tolerance": tol, "max_rel_err": errs, "parameters": len(errs),
+            "reference": reference,
+            "what": what or "production table scatter (bins + level-major hand-over) against the atomic variant, every parameter, one full-size step"}
 
 
 def train_leg(model, tl, tc, tm, T, steps, dev, dist):
@@ -609,6 +612,8 @@ def reference_default_grid_leg(model_cls, dev, n_rays, T, steps):
              "gt_depth": torch.rand(1, n_rays, generator=g).to(dev) * 0.5, "gt_raydrop": (torch.rand(1, n_rays, generator=g) > 0.3).float().to(dev),
              "gt_intensity": torch.rand(1, n_rays, generator=g).to(dev), "gt_rgb": torch.rand(1, n_rays, 3, generator=g).to(dev)}
     m.train()
+    grads_match = train_grads_match(m, batch, T, S.SCALE, what="binned plan (0, 8) of the L8 F4 grid (fp32 level-major gradient) against fp32 "
+                                                                "atomics for every level, every parameter, one full-size step")
     step = RenderTrainStep(m, num_steps=T, scale=S.SCALE)
     for _ in range(3):
         step.step(batch)
@@ -619,7 +624,8 @@ def reference_default_grid_leg(model_cls, dev, n_rays, T, steps):
     step.sync()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    out["train"] = {"value": 2 * n_rays / dt, "ms_per_step": dt * 1e3, "path": "RenderRaysFn (one node per ray batch) + binned table scatter + FusedAdam"}
+    out["train"] = {"value": 2 * n_rays / dt, "ms_per_step": dt * 1e3, "path": "RenderRaysFn (one node per ray batch) + binned table scatter + FusedAdam",
+                    "grads_match": grads_match}
     return out
 
 
@@ -748,6 +754,11 @@ def dynamic_leg(dev, n_rays, T, steps):
     batch = {"rays_o_lidar": tl[0], "rays_d_lidar": tl[1], "rays_o": tc[0], "rays_d": tc[1], "time": tm,
              "gt_depth": torch.rand(1, n_rays, generator=g).to(dev) * 0.5, "gt_raydrop": (torch.rand(1, n_rays, generator=g) > 0.3).float().to(dev),
              "gt_intensity": torch.rand(1, n_rays, generator=g).to(dev), "gt_rgb": torch.rand(1, n_rays, 3, generator=g).to(dev)}
+    m.train()
+    grads_match = train_grads_match(m, batch, T, S.SCALE, reference={"table_scatter": "atomic", "hash4d_bwd": "runs"},
+                                    what="production plan of the space-time model (static hash: fp16 level-major gradient through the bins, plan "
+                                         "(0, 8); flow grid: 2-feature view through the bins; space-time grids: LDS image fed column-major) against "
+                                         "fp32 atomics for every table, every parameter, one full-size step (K-planes: same kernel both ways)")
     trainer = RenderTrainStep(m, num_steps=T, scale=S.SCALE)
     for _ in range(4):  # loss scale settled, optimiser state and allocator pools in place
         trainer.step(batch)
@@ -757,7 +768,8 @@ def dynamic_leg(dev, n_rays, T, steps):
         trainer.step(batch)
     torch.cuda.synchronize()
     dtt = (time.perf_counter() - t0) / max(2, steps)
-    out["train"] = {"metric": "trained rays/sec (LiDAR+cam, fwd+bwd+Adam), dynamic 4-D field", "value": 2 * n_rays / dtt, "ms_per_step": dtt * 1e3}
+    out["train"] = {"metric": "trained rays/sec (LiDAR+cam, fwd+bwd+Adam), dynamic 4-D field", "value": 2 * n_rays / dtt, "ms_per_step": dtt * 1e3,
+                    "grads_match": grads_match}
     out["peak_mem_GiB"] = torch.cuda.max_memory_allocated() / 2 ** 30
     del trainer, m
     torch.cuda.empty_cache()

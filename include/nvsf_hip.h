@@ -614,6 +614,42 @@ int nvsf_lidar_losses_bwd(const float* image_lidar, const float* depth_lidar, co
                           const float* grad_loss_intensity, const float* grad_pred_depth, const float* grad_pred_points,
                           float* grad_image_lidar, float* grad_depth_lidar, nvsf_stream_t stream);
 
+/* ref: the structural regularisation of Trainer.train_step on LiDAR patches, its `grad_loss` branch: nvsf/nerf/trainer.py:296-470
+ * (switched on by configs/kitti360_1908.txt:13; patches of change_patch_size_lidar = [2, 8] every second epoch, trainer.py:1035-1062).
+ * The batch is N / (patch_h patch_w) patches in row-major patch order; pred_depth / gt_depth [N]: the MASKED range in scene units
+ * (pred_depth of nvsf_lidar_losses_fwd, gt_range * gt_raydrop); pano_inds int64 [N]: pixel indices h W + w in the frame's range
+ * image; pano_range: the range channel of that frame ([H, W], element stride pano_stride floats: 3 for the [H, W, 3] ground truth).
+ * First differences with the last column / row repeated, in metres (/ scale); masks = gt_raydrop x (|second difference of the TRUE
+ * frame at the pixel| < 0.05); loss = alpha sum crit(grad_x(pred) m_x, grad_x(gt) m_x) + the same in y; criterion 0 L1, 1 MSE,
+ * 2 Huber(delta = criterion_param), 3 SmoothL1(beta = criterion_param) (main_nvsf.py:204-221, `--depth_grad_loss`; the cosine form and
+ * the Sobel / smoothness / TV options of the same block are not built).  One launch, deterministic sum. */
+int nvsf_lidar_grad_loss_fwd(const float* pred_depth, const float* gt_depth, const float* gt_raydrop, const int64_t* pano_inds,
+                             const float* pano_range, uint32_t pano_stride, uint32_t N, uint32_t patch_h, uint32_t patch_w, uint32_t H,
+                             uint32_t W, float scale, int criterion, float criterion_param, float alpha, float* loss, nvsf_stream_t stream);
+/* gradient of the above with respect to pred_depth [N], given the gradient of the loss (a device float) */
+int nvsf_lidar_grad_loss_bwd(const float* pred_depth, const float* gt_depth, const float* gt_raydrop, const int64_t* pano_inds,
+                             const float* pano_range, uint32_t pano_stride, uint32_t N, uint32_t patch_h, uint32_t patch_w, uint32_t H,
+                             uint32_t W, float scale, int criterion, float criterion_param, float alpha, const float* grad_loss,
+                             float* grad_pred_depth, nvsf_stream_t stream);
+
+/* ref: the error map behind the pixel sampler, nvsf/nerf/trainer.py:552-630 (`--use_error_map`, configs/kitti360_1908.txt:14).
+ * nvsf_lidar_ray_losses: the per-ray LiDAR loss `lidar_loss` of trainer.py:213-216 (the three terms of nvsf_lidar_losses_fwd, not
+ * summed); nvsf_mse_rows: row_loss[n] = sum_c alpha (a[n, c] - b[n, c])^2 (the camera's `rgb_loss.sum(dim=2)`, trainer.py:598).
+ * min_max_bits (uint32 [2], may be NULL): running (min, max) of the written values as unsigned bit patterns -- the caller sets it
+ * to (0x7f800000, 0) first. */
+int nvsf_lidar_ray_losses(const float* image_lidar, const float* depth_lidar, const float* gt_raydrop, const float* gt_intensity,
+                          const float* gt_range, uint32_t N, float alpha_d, float alpha_r, float alpha_i, float smooth_factor,
+                          float* ray_loss, uint32_t* min_max_bits, nvsf_stream_t stream);
+int nvsf_mse_rows(const float* a, const float* b, uint32_t N, uint32_t C, float alpha, float* row_loss, uint32_t* min_max_bits,
+                  nvsf_stream_t stream);
+/* error = (ray_loss - min) / (max - min + eps) * 999 + 1;  cell = (floor(h scale_h), floor(w scale_w)) with (h, w) = divmod(pixel_inds, W)
+ * and scale_h = map_h / H, scale_w = map_w / W evaluated by the caller as the reference does (Python floats);
+ * error_map[cell] = 0.1 error_map[cell] + 0.9 error (trainer.py:566-583).  Where several rays fall into one cell the reference's indexed
+ * assignment keeps an unspecified one; here the ray with the largest index.  owner: uint32 [map_h map_w] scratch, zero on entry, zero
+ * again on return.  Two launches. */
+int nvsf_error_map_update(const float* ray_loss, const int64_t* pixel_inds, uint32_t N, uint32_t W, float* error_map, uint32_t map_h,
+                          uint32_t map_w, float scale_h, float scale_w, const uint32_t* min_max_bits, uint32_t* owner, nvsf_stream_t stream);
+
 /* ref: the camera term, trainer.py:491-503: loss = sum alpha (a - b)^2 over n floats (one launch); grad_a = grad_loss 2 alpha (a - b). */
 int nvsf_mse_sum_fwd(const float* a, const float* b, uint32_t n, float alpha, float* loss, nvsf_stream_t stream);
 int nvsf_mse_sum_bwd(const float* a, const float* b, uint32_t n, float alpha, const float* grad_loss, float* grad_a,

@@ -115,6 +115,174 @@ __global__ __launch_bounds__(256) void k_mse_sum_bwd(const float* __restrict__ a
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < n) grad_a[i] = *g * alpha * 2.0f * (a[i] - b[i]);
 }
+
+// ---- structural regularisation on LiDAR patches: the `grad_loss` branch of Trainer.train_step (trainer.py:296-470) ----------------
+// The batch is num_patch patches of pH x pW range-image pixels in row-major patch order (dataset_utils.py:407-503 draws them so):
+// pixel j = (p pH + r) pW + c, inds[j] = h W + w.  With q = depth / scale (metres):
+//   grad_x(j) = q(j) - q(j + 1)          for c < pW - 1,   grad_x(r, pW - 1) = grad_x(r, pW - 2)      (trainer.py:340-343, 381-384)
+//   grad_y(j) = q(j) - q(j + pW)         for r < pH - 1,   grad_y(pH - 1, c) = grad_y(pH - 2, c)
+// for the rendered and the true range alike.  The terms are masked by the true ray-drop channel and by the flatness of the TRUE
+// range image around the pixel (trainer.py:386-431): first differences of the whole frame (same padding rule), their absolute second
+// differences, mask = |second difference at (h, w)| < 0.05.  loss = alpha sum_j crit(grad_x m_x, gt_grad_x m_x) + the same in y
+// (trainer.py:449-458: criterion with reduction "none", summed), crit in {L1, MSE, Huber(delta), SmoothL1(beta)} (main_nvsf.py:204-221).
+struct PatchGeom {
+    uint32_t pH, pW, H, W;
+    float scale;
+};
+
+__device__ __forceinline__ float sr_crit(float e, int kind, float param) {
+    const float a = fabsf(e);
+    if (kind == 0) return a;                                                       // L1
+    if (kind == 1) return e * e;                                                   // MSE
+    if (kind == 2) return a <= param ? 0.5f * e * e : param * (a - 0.5f * param);  // Huber(delta)
+    return a < param ? 0.5f * e * e / param : a - 0.5f * param;                    // SmoothL1(beta)
+}
+__device__ __forceinline__ float sr_crit_grad(float e, int kind, float param) {
+    const float sgn = e > 0.0f ? 1.0f : (e < 0.0f ? -1.0f : 0.0f);
+    const float a = fabsf(e);
+    if (kind == 0) return sgn;
+    if (kind == 1) return 2.0f * e;
+    if (kind == 2) return a <= param ? e : param * sgn;
+    return a < param ? e / param : sgn;
+}
+// first difference of the frame's range channel along x at (h, w), in metres, with the reference's padding of the last column
+__device__ __forceinline__ float pano_dx(const float* __restrict__ pano, uint32_t stride, uint32_t h, uint32_t w, const PatchGeom& g) {
+    const uint32_t ww = w < g.W - 1 ? w : g.W - 2;
+    const float* row = pano + (size_t)h * g.W * stride;
+    return (row[(size_t)ww * stride] - row[(size_t)(ww + 1) * stride]) / g.scale;
+}
+__device__ __forceinline__ float pano_dy(const float* __restrict__ pano, uint32_t stride, uint32_t h, uint32_t w, const PatchGeom& g) {
+    const uint32_t hh = h < g.H - 1 ? h : g.H - 2;
+    return (pano[((size_t)hh * g.W + w) * stride] - pano[((size_t)(hh + 1) * g.W + w) * stride]) / g.scale;
+}
+// e = m (grad(pred) - grad(gt)) of pixel j in direction `dir` (0: x, 1: y); also the index pair (a, b) with grad = q(a) - q(b) and m
+__device__ __forceinline__ float sr_error(const float* __restrict__ pred, const float* __restrict__ gt, const float* __restrict__ gt_rd,
+                                          const long long* __restrict__ inds, const float* __restrict__ pano, uint32_t pano_stride, uint32_t j,
+                                          int dir, const PatchGeom& g, uint32_t& a, uint32_t& b, float& m) {
+    const uint32_t c = j % g.pW, r = (j / g.pW) % g.pH;
+    if (dir == 0) { a = c < g.pW - 1 ? j : j - 1; b = a + 1; }
+    else { a = r < g.pH - 1 ? j : j - g.pW; b = a + g.pW; }
+    const float gp = pred[a] / g.scale - pred[b] / g.scale, gg = gt[a] / g.scale - gt[b] / g.scale;
+    const uint32_t h = (uint32_t)(inds[j] / (long long)g.W), w = (uint32_t)(inds[j] % (long long)g.W);
+    float second;
+    if (dir == 0) {
+        const uint32_t ww = w < g.W - 1 ? w : g.W - 2;  // padding of the second difference's last column
+        second = fabsf(pano_dx(pano, pano_stride, h, ww, g)) - fabsf(pano_dx(pano, pano_stride, h, ww + 1, g));
+    } else {
+        const uint32_t hh = h < g.H - 1 ? h : g.H - 2;
+        second = fabsf(pano_dy(pano, pano_stride, hh, w, g)) - fabsf(pano_dy(pano, pano_stride, hh + 1, w, g));
+    }
+    m = gt_rd[j] * (fabsf(second) < 0.05f ? 1.0f : 0.0f);
+    return gp * m - gg * m;
+}
+
+__global__ __launch_bounds__(kBlock) void k_lidar_grad_loss_fwd(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                                const float* __restrict__ gt_rd, const long long* __restrict__ inds,
+                                                                const float* __restrict__ pano, uint32_t pano_stride, uint32_t N, PatchGeom g,
+                                                                int kind, float param, float alpha, float* __restrict__ loss) {
+    float acc[1] = {0.0f};
+    for (uint32_t j = threadIdx.x; j < N; j += kBlock) {
+        uint32_t a, b;
+        float m;
+        const float ex = sr_error(pred, gt, gt_rd, inds, pano, pano_stride, j, 0, g, a, b, m);
+        const float ey = sr_error(pred, gt, gt_rd, inds, pano, pano_stride, j, 1, g, a, b, m);
+        acc[0] += alpha * (sr_crit(ex, kind, param) + sr_crit(ey, kind, param));
+    }
+    float* o[1] = {loss};
+    block_sums<1>(acc, o);
+}
+
+// d loss / d pred(k): pixel k enters grad(j) = q(a_j) - q(b_j) of itself, of its left / upper neighbour (as b) and -- in the second-to-last
+// column / row -- of the padded last one (as a)
+__global__ __launch_bounds__(256) void k_lidar_grad_loss_bwd(const float* __restrict__ pred, const float* __restrict__ gt,
+                                                             const float* __restrict__ gt_rd, const long long* __restrict__ inds,
+                                                             const float* __restrict__ pano, uint32_t pano_stride, uint32_t N, PatchGeom g,
+                                                             int kind, float param, float alpha, const float* __restrict__ g_loss,
+                                                             float* __restrict__ grad_pred) {
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= N) return;
+    const uint32_t c = k % g.pW, r = (k / g.pW) % g.pH;
+    float sum = 0.0f;
+#pragma unroll
+    for (int dir = 0; dir < 2; ++dir) {
+        const uint32_t step = dir == 0 ? 1u : g.pW, pos = dir == 0 ? c : r, len = dir == 0 ? g.pW : g.pH;
+        const uint32_t cand[3] = {k, k - step, k + step};
+        const bool ok[3] = {true, pos >= 1, pos + 1 < len};
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            if (!ok[t]) continue;
+            uint32_t a, b;
+            float m;
+            const float e = sr_error(pred, gt, gt_rd, inds, pano, pano_stride, cand[t], dir, g, a, b, m);
+            const float d = sr_crit_grad(e, kind, param) * m;
+            if (a == k) sum += d;
+            if (b == k) sum -= d;
+        }
+    }
+    grad_pred[k] = *g_loss * alpha * sum / g.scale;
+}
+
+// ---- error map of the pixel sampler (trainer.py:552-630) -----------------------------------------------------------------------
+// per-ray LiDAR loss = alpha_d |.| + alpha_r (.)^2 + alpha_i (.)^2 (trainer.py:213-216, reduction "none") / per-ray camera loss =
+// sum over channels of alpha_rgb (.)^2 (trainer.py:598); stats[0 .. 1] = (min, max) over the rays as ordered unsigned bit patterns
+// (the losses are >= 0), to be initialised to (0x7f800000, 0) by the caller
+__global__ __launch_bounds__(256) void k_lidar_ray_losses(const float* __restrict__ image, const float* __restrict__ depth, const float* __restrict__ gt_rd,
+                                                          const float* __restrict__ gt_i, const float* __restrict__ gt_d, uint32_t N, float alpha_d,
+                                                          float alpha_r, float alpha_i, float smooth, float* __restrict__ out, uint32_t* __restrict__ stats) {
+    const uint32_t n = blockIdx.x * 256u + threadIdx.x;
+    if (n >= N) return;
+    const float m = gt_rd[n];
+    const float gd = gt_d[n] * m, gi = gt_i[n] * m;
+    const float pd = depth[n] * m, pr = image[2 * (size_t)n], pi = image[2 * (size_t)n + 1] * m;
+    const float tr = fminf(fmaxf(m, smooth), 1.0f - smooth);
+    const float er = pr - tr, ei = pi - gi;
+    const float v = alpha_d * fabsf(pd - gd) + alpha_r * (er * er) + alpha_i * (ei * ei);
+    out[n] = v;
+    if (stats && v >= 0.0f) { atomicMin(stats, __float_as_uint(v)); atomicMax(stats + 1, __float_as_uint(v)); }
+}
+__global__ __launch_bounds__(256) void k_mse_rows(const float* __restrict__ a, const float* __restrict__ b, uint32_t N, uint32_t C, float alpha,
+                                                  float* __restrict__ out, uint32_t* __restrict__ stats) {
+    const uint32_t n = blockIdx.x * 256u + threadIdx.x;
+    if (n >= N) return;
+    float v = 0.0f;
+    for (uint32_t k = 0; k < C; ++k) {
+        const float e = a[(size_t)n * C + k] - b[(size_t)n * C + k];
+        v += alpha * (e * e);
+    }
+    out[n] = v;
+    if (stats && v >= 0.0f) { atomicMin(stats, __float_as_uint(v)); atomicMax(stats + 1, __float_as_uint(v)); }
+}
+// error = (loss - min) / (max - min + eps) * 999 + 1; cell = (floor(h eH / H), floor(w eW / W)); map[cell] = 0.1 map[cell] + 0.9 error.
+// Several rays of a batch may fall into one cell: the reference's indexed assignment keeps an unspecified one of them (each computed
+// from the OLD map value); here the ray with the LARGEST index wins (what a sequential execution of the assignment gives): pass 1
+// leaves max(ray index + 1) per touched cell in `owner` (zero on entry), pass 2 lets that ray write and clears the slot again.
+__global__ __launch_bounds__(256) void k_error_map_claim(const long long* __restrict__ inds, uint32_t N, uint32_t W, uint32_t eH, uint32_t eW,
+                                                         float sh, float sw, uint32_t* __restrict__ owner) {
+    const uint32_t n = blockIdx.x * 256u + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t h = (uint32_t)(inds[n] / (long long)W), w = (uint32_t)(inds[n] % (long long)W);
+    uint32_t ch = (uint32_t)((float)h * sh), cw = (uint32_t)((float)w * sw);
+    ch = ch < eH ? ch : eH - 1;  // (a caller-side scale that rounds up: stay inside the map)
+    cw = cw < eW ? cw : eW - 1;
+    atomicMax(owner + (size_t)ch * eW + cw, n + 1u);
+}
+__global__ __launch_bounds__(256) void k_error_map_write(const float* __restrict__ loss, const long long* __restrict__ inds, uint32_t N,
+                                                         uint32_t W, uint32_t eH, uint32_t eW, float sh, float sw, const uint32_t* __restrict__ stats,
+                                                         uint32_t* __restrict__ owner, float* __restrict__ map) {
+    const uint32_t n = blockIdx.x * 256u + threadIdx.x;
+    if (n >= N) return;
+    const uint32_t h = (uint32_t)(inds[n] / (long long)W), w = (uint32_t)(inds[n] % (long long)W);
+    uint32_t ch = (uint32_t)((float)h * sh), cw = (uint32_t)((float)w * sw);
+    ch = ch < eH ? ch : eH - 1;
+    cw = cw < eW ? cw : eW - 1;
+    const size_t cell = (size_t)ch * eW + cw;
+    if (owner[cell] != n + 1u) return;
+    const float lo = __uint_as_float(stats[0]), hi = __uint_as_float(stats[1]);
+    float e = (loss[n] - lo) / (hi - lo + 1.1920928955078125e-07f);  // torch.finfo().eps
+    e = e * (1000.0f - 1.0f) + 1.0f;
+    map[cell] = 0.1f * map[cell] + 0.9f * e;
+    owner[cell] = 0u;
+}
 }  // namespace
 
 #define REQUIRE(cond) do { if (!(cond)) return NVSF_ERR_INVALID_ARG; } while (0)
@@ -163,5 +331,63 @@ NVSF_API int nvsf_mse_sum_bwd(const float* a, const float* b, uint32_t n, float 
     if (n == 0) return NVSF_OK;
     REQUIRE(a && b && grad_loss && grad_a);
     hipLaunchKernelGGL(k_mse_sum_bwd, dim3(cdiv(n, 256)), dim3(256), 0, stream, a, b, n, alpha, grad_loss, grad_a);
+    return nvsf_launch_status();
+}
+
+NVSF_API int nvsf_lidar_grad_loss_fwd(const float* pred_depth, const float* gt_depth, const float* gt_raydrop, const int64_t* pano_inds,
+                                      const float* pano_range, uint32_t pano_stride, uint32_t N, uint32_t patch_h, uint32_t patch_w, uint32_t H,
+                                      uint32_t W, float scale, int criterion, float criterion_param, float alpha, float* loss, hipStream_t stream) {
+    REQUIRE(loss);
+    if (N == 0) return hipMemsetAsync(loss, 0, 4, stream) == hipSuccess ? NVSF_OK : (int)hipGetLastError();
+    REQUIRE(pred_depth && gt_depth && gt_raydrop && pano_inds && pano_range && pano_stride >= 1);
+    REQUIRE(patch_h >= 2 && patch_w >= 2 && N % (patch_h * patch_w) == 0 && H >= 2 && W >= 2 && scale != 0.0f);
+    REQUIRE(criterion >= 0 && criterion <= 3 && (criterion < 2 || criterion_param > 0.0f));
+    const PatchGeom g = {patch_h, patch_w, H, W, scale};
+    hipLaunchKernelGGL(k_lidar_grad_loss_fwd, dim3(1), dim3(kBlock), 0, stream, pred_depth, gt_depth, gt_raydrop,
+                       reinterpret_cast<const long long*>(pano_inds), pano_range, pano_stride, N, g, criterion, criterion_param, alpha, loss);
+    return nvsf_launch_status();
+}
+
+NVSF_API int nvsf_lidar_grad_loss_bwd(const float* pred_depth, const float* gt_depth, const float* gt_raydrop, const int64_t* pano_inds,
+                                      const float* pano_range, uint32_t pano_stride, uint32_t N, uint32_t patch_h, uint32_t patch_w, uint32_t H,
+                                      uint32_t W, float scale, int criterion, float criterion_param, float alpha, const float* grad_loss,
+                                      float* grad_pred_depth, hipStream_t stream) {
+    if (N == 0) return NVSF_OK;
+    REQUIRE(pred_depth && gt_depth && gt_raydrop && pano_inds && pano_range && pano_stride >= 1 && grad_loss && grad_pred_depth);
+    REQUIRE(patch_h >= 2 && patch_w >= 2 && N % (patch_h * patch_w) == 0 && H >= 2 && W >= 2 && scale != 0.0f);
+    REQUIRE(criterion >= 0 && criterion <= 3 && (criterion < 2 || criterion_param > 0.0f));
+    const PatchGeom g = {patch_h, patch_w, H, W, scale};
+    hipLaunchKernelGGL(k_lidar_grad_loss_bwd, dim3(cdiv(N, 256)), dim3(256), 0, stream, pred_depth, gt_depth, gt_raydrop,
+                       reinterpret_cast<const long long*>(pano_inds), pano_range, pano_stride, N, g, criterion, criterion_param, alpha, grad_loss,
+                       grad_pred_depth);
+    return nvsf_launch_status();
+}
+
+NVSF_API int nvsf_lidar_ray_losses(const float* image_lidar, const float* depth_lidar, const float* gt_raydrop, const float* gt_intensity,
+                                   const float* gt_range, uint32_t N, float alpha_d, float alpha_r, float alpha_i, float smooth_factor,
+                                   float* ray_loss, uint32_t* min_max_bits, hipStream_t stream) {
+    if (N == 0) return NVSF_OK;
+    REQUIRE(image_lidar && depth_lidar && gt_raydrop && gt_intensity && gt_range && ray_loss);
+    hipLaunchKernelGGL(k_lidar_ray_losses, dim3(cdiv(N, 256)), dim3(256), 0, stream, image_lidar, depth_lidar, gt_raydrop, gt_intensity, gt_range, N,
+                       alpha_d, alpha_r, alpha_i, smooth_factor, ray_loss, min_max_bits);
+    return nvsf_launch_status();
+}
+
+NVSF_API int nvsf_mse_rows(const float* a, const float* b, uint32_t N, uint32_t C, float alpha, float* row_loss, uint32_t* min_max_bits,
+                           hipStream_t stream) {
+    if (N == 0) return NVSF_OK;
+    REQUIRE(a && b && row_loss && C >= 1);
+    hipLaunchKernelGGL(k_mse_rows, dim3(cdiv(N, 256)), dim3(256), 0, stream, a, b, N, C, alpha, row_loss, min_max_bits);
+    return nvsf_launch_status();
+}
+
+NVSF_API int nvsf_error_map_update(const float* ray_loss, const int64_t* pixel_inds, uint32_t N, uint32_t W, float* error_map, uint32_t map_h,
+                                   uint32_t map_w, float scale_h, float scale_w, const uint32_t* min_max_bits, uint32_t* owner, hipStream_t stream) {
+    if (N == 0) return NVSF_OK;
+    REQUIRE(ray_loss && pixel_inds && error_map && min_max_bits && owner && W >= 1 && map_h >= 1 && map_w >= 1 && scale_h > 0.0f && scale_w > 0.0f);
+    hipLaunchKernelGGL(k_error_map_claim, dim3(cdiv(N, 256)), dim3(256), 0, stream, reinterpret_cast<const long long*>(pixel_inds), N, W, map_h,
+                       map_w, scale_h, scale_w, owner);
+    hipLaunchKernelGGL(k_error_map_write, dim3(cdiv(N, 256)), dim3(256), 0, stream, ray_loss, reinterpret_cast<const long long*>(pixel_inds), N, W,
+                       map_h, map_w, scale_h, scale_w, min_max_bits, owner, error_map);
     return nvsf_launch_status();
 }

@@ -130,12 +130,37 @@ class FrameSet:
         self.times = torch.from_numpy(t["times"].astype(np.float32)).view(-1, 1).to(dev)
         self.frame_ids = torch.from_numpy(t["frame_ids"]).view(-1, 1)
         self.error_map = self.error_map_rgb = None
+        self.use_error_map = False  # set per epoch by RenderTrainStep.set_epoch (trainer.py:1056-1059)
+        self._em_stats, self._em_owner = {}, {}
+
+    def enable_error_maps(self):
+        """The sampler's per-frame error maps as base_dataset.py:243-246 creates them: ones, [F, H_lidar / 2, W_lidar / 2] for the range
+        image and [F, H / 4, W / 4] for the camera image (updated by RenderTrainStep.update_error_maps, trainer.py:552-630)."""
+        n = len(self)
+        self.error_map = torch.ones(n, int(self.H_lidar / 2), int(self.W_lidar / 2), dtype=torch.float32, device=self.device)
+        self.error_map_rgb = torch.ones(n, int(self.H / 4), int(self.W / 4), dtype=torch.float32, device=self.device)
+        return self
+
+    def error_map_stats(self, device):
+        """uint32 [2] = bit patterns of (+inf, 0): the running (min, max) the per-ray loss kernels reduce into."""
+        fresh = self._em_stats.get("fresh")
+        if fresh is None or fresh.device != device:
+            fresh = self._em_stats["fresh"] = torch.tensor([0x7f800000, 0], dtype=torch.int64).to(torch.int32).to(device)
+        return fresh.clone()
+
+    def error_map_owner(self, device, n_cells):
+        """uint32 [n_cells] scratch of nvsf_error_map_update (zero between calls: the kernel clears what it used)."""
+        buf = self._em_owner.get(n_cells)
+        if buf is None or buf.device != device:
+            buf = self._em_owner[n_cells] = torch.zeros(n_cells, dtype=torch.int32, device=device)
+        return buf
 
     def __len__(self):
         return self.poses_lidar.shape[0]
 
-    def collate(self, index, use_error_map=False):
+    def collate(self, index, use_error_map=None):
         """index: list with one frame index (batch_size 1, base_dataset.py:415-421).  Keys as in base_dataset.py:303-407."""
+        use_error_map = self.use_error_map if use_error_map is None else use_error_map
         idx = torch.as_tensor(index, dtype=torch.long, device=self.device)
         B = idx.shape[0]
         res = {"index": index, "time": self.times[idx], "frame_id": self.frame_ids[idx.cpu()]}
@@ -154,6 +179,7 @@ class FrameSet:
             images = gather_pixels(images, rays["inds"])
             images_lidar = gather_pixels(images_lidar, rl["inds"])
         res["images"], res["images_lidar"] = images, images_lidar
+        res["pano_frame"] = self.images_lidar[idx]  # the whole ground-truth frame (base_dataset.py:403): the structural regulariser's masks
         return res
 
     def train_batch(self, index):
@@ -161,4 +187,6 @@ class FrameSet:
         c = self.collate(index)
         gl = c["images_lidar"]  # [B, N, 3] = raydrop, intensity, range
         return {"rays_o_lidar": c["rays_o_lidar"], "rays_d_lidar": c["rays_d_lidar"], "rays_o": c["rays_o"], "rays_d": c["rays_d"],
-                "time": c["time"], "gt_raydrop": gl[..., 0], "gt_intensity": gl[..., 1], "gt_depth": gl[..., 2], "gt_rgb": c["images"][..., :3]}
+                "time": c["time"], "gt_raydrop": gl[..., 0], "gt_intensity": gl[..., 1], "gt_depth": gl[..., 2], "gt_rgb": c["images"][..., :3],
+                # what the structural regulariser and the error-map update read (trainer.py:386-391, 552-556, 588-590)
+                "index": c["index"], "rays_pano_inds": c["rays_pano_inds"], "rays_rgb_inds": c["rays_rgb_inds"], "pano_frame": c["pano_frame"]}

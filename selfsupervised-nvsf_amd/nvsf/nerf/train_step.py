@@ -16,8 +16,12 @@ Only what sits directly around the hot path, restated from the reference's `Trai
   * EMA of the weights, decay 0.95, updated once per epoch (trainer.py:112-114, 1420-1421; nvsf/nerf/ema.py);
   * PSNR (nvsf/lib/error_matrices.py:48-57) and depth RMSE in metres (error_matrices.py:263-285).
 Across GPUs the step is frame-sharded: every rank renders its own frame, then ONE bucketed gradient all-reduce
-(nvsf/frame_shard.py).  Checkpoints use the reference's dict (utils.py:622-747).  Logging, UNet refinement, error maps and the
-structural-regularisation losses on LiDAR patches (patch_size_lidar > 1) of the reference's Trainer are out of scope.
+(nvsf/frame_shard.py).  Checkpoints use the reference's dict (utils.py:622-747).
+Shipped-config extras (configs/kitti360_1908.txt:13-15 `grad_loss`, `use_error_map`): the structural regularisation on LiDAR patches
+in its `grad_loss` form (trainer.py:296-470: first differences of the rendered / true range inside pH x pW patches, masked by the true
+ray-drop channel and the flatness of the true frame; `LidarGradLossFn`, csrc/losses.hip), the alternation between random pixels and
+patches (trainer.py:1035-1062: `set_epoch`) and the error maps the patch sampler draws from (trainer.py:552-630: `update_error_maps`).
+Logging, UNet refinement and the Sobel / smoothness / TV / cosine options of the regulariser are out of scope.
 """
 import math
 import warnings
@@ -107,10 +111,50 @@ class MseSumFn(torch.autograd.Function):
         return grad.view(ctx.shape), None, None
 
 
+class LidarGradLossFn(torch.autograd.Function):
+    """Structural regularisation of trainer.py:296-470 in its `grad_loss` form as one launch each way (nvsf_lidar_grad_loss_fwd / _bwd):
+    pred_depth, gt_depth [1, N] the masked ranges (scene units), gt_raydrop [1, N], pano_inds int64 [1, N] pixel indices of the batch
+    (N / (pH pW) patches in patch order), pano_frame [H, W, 3] (or [1, H, W, 3]) the frame's ground truth (channel 2 = range x scale)."""
+    CRITERIA = {"l1": 0, "mse": 1, "huber": 2, "smoothl1": 3}
+
+    @staticmethod
+    def forward(ctx, pred_depth, gt_depth, gt_raydrop, pano_inds, pano_frame, patch, scale, criterion, alpha):
+        from nvsf import _hip
+        if criterion not in LidarGradLossFn.CRITERIA:
+            raise NotImplementedError(f"depth_grad_loss={criterion!r}: l1 / mse / huber / smoothl1 are built (the cosine form is not)")
+        c = lambda t: t.detach().float().contiguous()
+        pd, gd, rd = c(pred_depth), c(gt_depth), c(gt_raydrop)
+        inds = pano_inds.detach().long().contiguous()
+        frame = pano_frame.detach().float()
+        frame = frame[0] if frame.dim() == 4 else frame
+        frame = frame.contiguous()
+        H, W, C = frame.shape
+        pH, pW = int(patch[0]), int(patch[1])
+        N = pd.numel()
+        kind = LidarGradLossFn.CRITERIA[criterion]
+        param = 0.2 * float(scale) if criterion == "huber" else (0.1 if criterion == "smoothl1" else 0.0)  # main_nvsf.py:207-208
+        out = torch.empty((), dtype=torch.float32, device=pd.device)
+        args = (_hip.ptr(pd), _hip.ptr(gd), _hip.ptr(rd), _hip.ptr(inds), frame.data_ptr() + 4 * (C - 1 if C >= 3 else 0), C, N, pH, pW, H, W,
+                float(scale), kind, float(param), float(alpha))
+        _hip.call("nvsf_lidar_grad_loss_fwd", *args, _hip.ptr(out))
+        ctx.save_for_backward(pd, gd, rd, inds, frame)
+        ctx.args, ctx.shape = args, pred_depth.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from nvsf import _hip
+        pd = ctx.saved_tensors[0]
+        grad = torch.empty_like(pd)
+        _hip.call("nvsf_lidar_grad_loss_bwd", *ctx.args, _hip.ptr(g.float().contiguous()), _hip.ptr(grad))
+        return (grad.view(ctx.shape),) + (None,) * 8
+
+
 class RenderTrainStep:
     def __init__(self, model, lr=1e-2, iters=30000, num_steps=768, alpha_d=1.0, alpha_r=0.01, alpha_i=0.1, alpha_rgb=1.0,
                  smooth_factor=0.0, use_urf_loss=False, bucket_bytes=64 << 20, fp16=True, scale=1.0, chamfer_loss=True,
-                 flow_loss=False, pc_list=None, ema_decay=0.95, split_backward=True, ray_chunks=1):
+                 flow_loss=False, pc_list=None, ema_decay=0.95, split_backward=True, ray_chunks=1, grad_loss=False, depth_grad_loss="l1",
+                 alpha_grad=0.1, patch_size_lidar=1, change_patch_size_lidar=(2, 8), change_patch_size_epoch=2, use_error_map=False):
         """Defaults = the reference's CLI defaults (main_nvsf.py:60-97).  `scale`: the scene scale the chamfer loss divides by
         (opt.scale); `pc_list`: {frame index: [P, 3] tensor} world-frame point clouds for the scene-flow loss
         (Trainer.process_pointcloud, trainer.py:1848-1912, builds them from the range images); `ema_decay=None` disables EMA.
@@ -143,6 +187,14 @@ class RenderTrainStep:
         self.alpha_d, self.alpha_r, self.alpha_i, self.alpha_rgb = alpha_d, alpha_r, alpha_i, alpha_rgb
         self.smooth, self.use_urf, self.bucket_bytes = smooth_factor, use_urf_loss, bucket_bytes
         self.scale, self.use_chamfer, self.use_flow, self.pc_list = float(scale), bool(chamfer_loss), bool(flow_loss), pc_list or {}
+        # structural regularisation on LiDAR patches + the error maps of the patch sampler (main_nvsf.py:79-111 defaults; the shipped
+        # config switches grad_loss and use_error_map on, configs/kitti360_1908.txt:13-14)
+        self.grad_loss, self.depth_grad_loss, self.alpha_grad = bool(grad_loss), str(depth_grad_loss), float(alpha_grad)
+        self.patch_size_lidar = patch_size_lidar
+        self.change_patch_size_lidar, self.change_patch_size_epoch = tuple(change_patch_size_lidar), int(change_patch_size_epoch)
+        self.use_error_map, self.pixel_sampler = bool(use_error_map), "random"
+        self.error_maps = None   # the FrameSet whose error_map / error_map_rgb the step keeps up to date (attach_error_maps)
+        self._for_error_map = {}
         self.ema = None
         if ema_decay is not None and on_gpu:
             from nvsf.nerf.ema import ExponentialMovingAverage
@@ -254,6 +306,14 @@ class RenderTrainStep:
                 if self.use_chamfer:
                     d1, d2, _, _ = self._chamfer(pred_pts, gt_pts)
                     out["chamfer"] = (d1 + d2).mean() * 0.5
+                pH, pW = self._patch_dims()
+                if pH > 1 and self.grad_loss:
+                    if "rays_pano_inds" not in batch or "pano_frame" not in batch:
+                        raise ValueError("grad_loss on LiDAR patches needs batch['rays_pano_inds'] and batch['pano_frame'] (FrameSet.train_batch)")
+                    out["sr"] = LidarGradLossFn.apply(pred_depth, gt_d * gt_rd, gt_rd, batch["rays_pano_inds"], batch["pano_frame"], (pH, pW),
+                                                      self.scale, self.depth_grad_loss, self.alpha_grad)
+                if self.error_maps is not None:
+                    self._for_error_map["lidar"] = (r["image_lidar"].detach(), r["depth_lidar"].detach(), gt_rd, gt_i, gt_d)
             else:  # host-side logic tests: the same terms as torch expressions
                 gt_int, gt_depth = gt_i * gt_rd, gt_d * gt_rd  # trainer.py:187-189
                 pred_rd = r["image_lidar"][:, :, 0]
@@ -277,11 +337,69 @@ class RenderTrainStep:
             gt_rgb = batch["gt_rgb"] if "gt_rgb" in batch else batch["images"][..., :3]
             r = self._render(batch["rays_o"], batch["rays_d"], batch["time"], perturb=True, num_steps=self.num_steps, bg_color=1)
             out["rgb"] = MseSumFn.apply(r["image"], gt_rgb, self.alpha_rgb) if r["image"].is_cuda else (self.alpha_rgb * (r["image"] - gt_rgb) ** 2).sum()
+            if self.error_maps is not None and r["image"].is_cuda:
+                self._for_error_map["camera"] = (r["image"].detach(), gt_rgb)
         total = sum(out.values())
         total = torch.nan_to_num(total, nan=0.0, posinf=1e5, neginf=1e5)  # trainer.py:545-546 (|inf| -> 1e5)
         return total, out
 
-    CAMERA_KEYS = ("rays_o", "rays_d", "gt_rgb", "images")
+    def _patch_dims(self):
+        p = self.patch_size_lidar
+        if isinstance(p, int):
+            return p, p
+        return (p[0], p[0]) if len(p) == 1 else (p[0], p[1])
+
+    def set_epoch(self, epoch, frames=None):
+        """The per-epoch switch of trainer.py:1035-1062: with change_patch_size_lidar[0] > 1, every change_patch_size_epoch-th epoch
+        samples LiDAR PATCHES (and regularises on them; the sampler draws from the error map when use_error_map), the others random
+        pixels.  `frames`: the FrameSet whose sampler follows (default: the one given to attach_error_maps)."""
+        frames = frames if frames is not None else self.error_maps
+        if self.change_patch_size_lidar[0] > 1:
+            patch = epoch % self.change_patch_size_epoch == 0
+            self.pixel_sampler = "patch" if patch else "random"
+            self.patch_size_lidar = tuple(self.change_patch_size_lidar) if patch else 1
+            if frames is not None:
+                frames.patch_size_lidar = self.patch_size_lidar
+        if frames is not None:
+            frames.use_error_map = self.use_error_map and self.pixel_sampler != "random"
+        return self.pixel_sampler
+
+    def attach_error_maps(self, frames):
+        """`frames`: a FrameSet with enable_error_maps() called -- after every step the per-ray losses of the batch are written into
+        its error_map / error_map_rgb (update_error_maps), as Trainer.train_step does whatever the sampler (trainer.py:552-630)."""
+        if getattr(frames, "error_map", None) is None:
+            frames.enable_error_maps()
+        self.error_maps = frames
+
+    def update_error_maps(self, batch):
+        """trainer.py:552-630 on the device: per-ray loss -> min / max -> normalised to [1, 1000] -> EMA into the frame's coarse map
+        at the rays' pixels (five small launches per modality, no host read)."""
+        from nvsf import _hip
+        frames, stash = self.error_maps, self._for_error_map
+        self._for_error_map = {}
+        if frames is None or "index" not in batch:
+            return
+        idx = int(batch["index"][0])
+        for key, inds_key, emap, H, W in (("lidar", "rays_pano_inds", frames.error_map, frames.H_lidar, frames.W_lidar),
+                                          ("camera", "rays_rgb_inds", frames.error_map_rgb, frames.H, frames.W)):
+            if key not in stash or inds_key not in batch or emap is None:
+                continue
+            inds = batch[inds_key].detach().long().contiguous().view(-1)
+            N, dev = inds.numel(), inds.device
+            ray_loss = torch.empty(N, dtype=torch.float32, device=dev)
+            stats = frames.error_map_stats(dev)
+            if key == "lidar":
+                img, dep, rd, gi, gd = (t.float().contiguous() for t in stash[key])
+                _hip.call("nvsf_lidar_ray_losses", _hip.ptr(img), _hip.ptr(dep), _hip.ptr(rd), _hip.ptr(gi), _hip.ptr(gd), N, self.alpha_d, self.alpha_r,
+                          self.alpha_i, self.smooth, _hip.ptr(ray_loss), _hip.ptr(stats))
+            else:
+                img, gt = (t.float().contiguous() for t in stash[key])
+                _hip.call("nvsf_mse_rows", _hip.ptr(img), _hip.ptr(gt), N, img.shape[-1], self.alpha_rgb, _hip.ptr(ray_loss), _hip.ptr(stats))
+            eH, eW = emap.shape[-2:]
+            _hip.call("nvsf_error_map_update", _hip.ptr(ray_loss), _hip.ptr(inds), N, int(W), emap[idx].data_ptr(), int(eH), int(eW), float(eH / H),
+                      float(eW / W), _hip.ptr(stats), _hip.ptr(frames.error_map_owner(dev, eH * eW)))
+
+    CAMERA_KEYS = ("rays_o", "rays_d", "gt_rgb", "images", "rays_rgb_inds", "H", "W")
 
     def _backward(self, loss):
         overlap = loss.is_cuda and self.scatter_overlap
@@ -381,6 +499,8 @@ class RenderTrainStep:
                 torch.cuda.current_stream().wait_event(prev[0])
                 found = torch.maximum(found, prev[1])
             self.scaler.update(found)
+        if self.error_maps is not None:
+            self.update_error_maps(batch)
         self.sched.step()
         self.global_step += 1
         return loss, parts, n_coll
