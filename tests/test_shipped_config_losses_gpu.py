@@ -122,7 +122,7 @@ def test_patch_epochs_regularise_and_feed_the_error_map(dev, tmp_path):
     from nvsf.nerf.models.network_static import NeRFNetworkStatic
     from nvsf.nerf.train_step import RenderTrainStep
     seq, frames, images, pcs, K = make_dataset(str(tmp_path), n_frames=2, H=24, W=32, Hl=16, Wl=64)
-    fs = F.FrameSet(str(tmp_path), seq, "train", 0.0108, num_rays=128, num_rays_lidar=96, device=dev)
+    fs = F.FrameSet(str(tmp_path), seq, "train", 0.0108, num_rays=40, num_rays_lidar=96, device=dev)  # 40 <= the 6 x 8 cells of the camera map (dataset_utils.py:613)
     m = NeRFNetworkStatic(bound=2.0, min_near=0.01, min_near_lidar=0.01, lidar_max_depth=0.9).to(dev)
     step = RenderTrainStep(m, num_steps=32, scale=0.0108, grad_loss=True, use_error_map=True)
     step.attach_error_maps(fs)
@@ -134,7 +134,7 @@ def test_patch_epochs_regularise_and_feed_the_error_map(dev, tmp_path):
     assert "sr" not in parts and bool(torch.isfinite(loss))
     em, em_rgb = fs.error_map.clone(), fs.error_map_rgb.clone()
     assert bool((em[1] == 1).all()) and bool((em_rgb[1] == 1).all())                      # only the trained frame's maps move
-    assert 10 < int((em[0] != 1).sum()) <= 96 and 10 < int((em_rgb[0] != 1).sum()) <= 128
+    assert 10 < int((em[0] != 1).sum()) <= 96 and 5 < int((em_rgb[0] != 1).sum()) <= 40
     assert float(em[0].max()) <= 0.1 + 0.9 * 1000.0 + 1e-3 and float(em[0].min()) >= 1.0 - 1e-6
     # the cells that moved are the cells of the sampled pixels
     h, w = batch["rays_pano_inds"][0] // 64, batch["rays_pano_inds"][0] % 64
