@@ -137,6 +137,12 @@ def test_two_rank_line_carries_what_a_scaling_run_is_checked_by():
     assert files, "no round-3 two-rank line committed"
     d = json.loads(open(files[-1]).read().strip().splitlines()[-1])
     assert d["n_gpus"] == 2 and "invalid" in d
+    if "detail" in d:  # round 5 on: the stdout line is the compact one, the per-bucket rows are in the detail file committed beside it
+        assert len(open(files[-1]).read().strip()) <= _bench().FINAL_LINE_MAX_BYTES
+        assert d["train"]["allreduce"]["buckets"] >= 2 and d["train"]["allreduce_collectives_per_step"] >= 2
+        det = json.load(open(files[-1].replace("_line.json", "_detail.json")))
+        assert det["n_gpus"] == 2 and abs(det["value"] - d["value"]) / d["value"] < 1e-3
+        d = det
     assert d["ranks_seen"] == {"min": 2, "max": 2, "answered": 2}
     assert d["build"]["ranks_agree"] is True and len(d["build"]["csrc_digest"]) == 16 and d["build"]["version"].startswith("nvsf_hip")
     assert len(d["per_rank_ms_per_step"]) == 2 and max(d["per_rank_ms_per_step"]) == pytest_approx(d["ms_per_step"])

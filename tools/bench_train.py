@@ -38,6 +38,28 @@ if os.environ.get('BINS') == '0':   # no bins at all
 if os.environ.get('MLP_BWD'):  # staged / wave: force one kernel of nvsf_mlp_bwd
     from nvsf import testing as _testing
     _cm = _testing.variant(mlp_bwd=os.environ['MLP_BWD']); _cm.__enter__()
+if os.environ.get('SIDE_PRIO'):  # experiment: the scatter stream at another queue priority (lower number = higher priority)
+    lo_p, hi_p = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, 'priority_range') else (None, None)
+    print('priority range', lo_p, hi_p)
+    _ops._SIDE_STREAMS[(dev.type, dev.index)] = torch.cuda.Stream(device=dev, priority=int(os.environ['SIDE_PRIO']))
+if os.environ.get('SIDE_CUS'):  # experiment: the scatter stream restricted to a fraction of the CUs (hipExtStreamCreateWithCUMask)
+    import ctypes
+    hip = ctypes.CDLL('libamdhip64.so')
+    frac = float(os.environ['SIDE_CUS'])
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    words = (n_cu + 31) // 32
+    bits = [0] * words
+    pattern = os.environ.get('SIDE_PATTERN', 'stride')
+    chosen = 0
+    for i in range(n_cu):
+        take = (i % 100) < frac * 100 if pattern == 'stride' else i < frac * n_cu
+        if take:
+            bits[i // 32] |= 1 << (i % 32); chosen += 1
+    arr = (ctypes.c_uint32 * words)(*bits)
+    stream = ctypes.c_void_p()
+    rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(stream), ctypes.c_uint32(words), arr)
+    print('cu mask stream rc', rc, 'CUs', chosen, 'of', n_cu)
+    _ops._SIDE_STREAMS[(dev.type, dev.index)] = torch.cuda.ExternalStream(stream.value, device=dev)
 for _ in range(2): step.step(batch)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 K = int(os.environ.get("K", 5))

@@ -36,9 +36,12 @@ trim(one("pw/**/*counter_collection.csv"), f"{dst}/{tag}_pmc_write_size.csv")
 trim(one("pm/**/*counter_collection.csv"), f"{dst}/{tag}_pmc_mfma.csv")
 shutil.copy(f"{src}/raymarching.json", f"{dst}/{tag}_raymarching_rooflines.json")
 shutil.copy(f"{src}/field_ops.json", f"{dst}/{tag}_field_ops_rooflines.json")
-for log, name in (("bench1.log", "bench_line"), ("bench2.log", "bench2_same_device_line")):
+# the stdout of bench.py is ONE compact line; the per-kernel rows of the legs are in the detail file written beside it
+for log, name, detail in (("bench1.log", "bench_line", "bench1_detail.json"), ("bench2.log", "bench2_same_device_line", "bench2_detail.json")):
     line = [x for x in open(f"{src}/{log}") if x.startswith("{")][-1]
     open(f"{dst}/{tag}_{name}.json", "w").write(json.dumps(json.loads(line)) + "\n")
+    if os.path.exists(f"{src}/{detail}"):
+        shutil.copy(f"{src}/{detail}", f"{dst}/{tag}_{name.replace('_line', '_detail')}.json")
 py = sys.executable
 subprocess.check_call([py, os.path.join(ROOT, "tools", "pmc_summary.py"), f"{dst}/{tag}_pmc_fetch_size.csv", f"{dst}/{tag}_pmc_write_size.csv",
                        f"{dst}/{tag}_pmc_traffic.json"])
@@ -50,5 +53,5 @@ if glob.glob(os.path.join(src, "pm_train/**/*counter_collection.csv"), recursive
 d = json.loads(open(f"{dst}/{tag}_bench_line.json").read())
 print(tag, d["value"], d["ms_per_step"], "roofline", d["roofline"]["frac"], "traffic", d["roofline"].get("traffic"))
 print({k: {a: b for a, b in v.items() if a in ("value", "ms_per_step")} for k, v in d.items() if isinstance(v, dict) and k in ("train", "dynamic", "eval")},
-      "dynamic train", d["dynamic"]["train"]["ms_per_step"], "moving", d["dynamic"]["moving_scene"]["ms_per_step"], "occupancy", d["occupancy"]["eval"]["value"])
-print([(k["kernel"], round(k["ms"], 4), round(k["frac"], 3)) for k in d["kernels"]], d.get("outputs_match_oracle", {}).get("ok"))
+      "dynamic train", d["dynamic"]["train"]["ms_per_step"], "moving", d["dynamic"]["moving_scene_ms"], "occupancy", d["occupancy"]["value"])
+print(d["kernels"], d.get("outputs_match_oracle", {}).get("ok"))
