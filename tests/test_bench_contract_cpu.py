@@ -128,6 +128,23 @@ def test_compact_line_stays_small_whatever_the_legs_return():
         assert k in line
 
 
+def test_compact_line_survives_skipped_legs():
+    """N > 1 ranks, --no-extra-legs or a run under rocprofv3 leave legs out or reduce them to {"skipped": ...}: the summary must not
+    raise between the timed loop and the line (the first r05 two-rank run died there with a KeyError)."""
+    b = _bench()
+    det = json.load(open(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_detail.json")))[-1]))
+    thin = {k: det[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                                "data", "config")}
+    thin["train"] = {"value": 1.0, "ms_per_step": 2.0, "steps": 3, "kernels": {"skipped": "running under rocprofv3"}, "grads_match": None,
+                     "allreduce": {"payload_MB": 1.0, "buckets": 2, "per_bucket": []}, "allreduce_collectives_per_step": 3}
+    thin["dynamic"] = {"value": 1.0}
+    thin["occupancy"] = {}
+    thin["raymarching"] = {"error": "x"}
+    line = b.compact_line(thin, None)
+    assert line["train"]["ms_per_step"] == 2.0 and "launches_per_step" not in line["train"] and line["train"]["allreduce"]["buckets"] == 2
+    assert line["dynamic"]["train"] == {"value": None, "ms_per_step": None} and len(json.dumps(line)) <= b.FINAL_LINE_MAX_BYTES
+
+
 def test_two_rank_line_carries_what_a_scaling_run_is_checked_by():
     """The N > 1 control flow of bench.py as it ran on a 1-GPU box (two ranks sharing cuda:0 over gloo, NVSF_BENCH_SAME_DEVICE=1, line
     tagged `invalid`): the fields the first real 8-GPU run will be checked by must be there -- every rank loaded the same library
