@@ -335,7 +335,7 @@ def train_kernel_rows(step, batch, M, n_steps=3):
     whose algorithmic work is known a roofline fraction -- the fused MLP kernels against the dense fp16 MFMA peak (FLOP counted from
     the template arguments <IN_STEPS, N_HIDDEN>: in_cols = 32 IN_STEPS, 64-wide hidden layers, 16 outputs; backward = 3 x forward:
     recomputed forward + data + weight gradients), the streaming kernels against HBM.  Not run under rocprofv3 (two tracers in one
-    process): the committed profiles/r04_*_train_kernel_stats.csv + *_pmc_train.json are that view, with counters."""
+    process): the committed profiles/*_train_kernel_stats.csv + *_pmc_train.json are that view, with counters."""
     import re
     if any(k.startswith("ROCPROF") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return {"skipped": "running under rocprofv3"}

@@ -40,6 +40,11 @@ for name, n_in, n_out, n_pre in (("lidar head 87-64-64-1", 87, 1, 72), ("colour 
         with testing.variant(mlp_bwd=kernel):
             ms = timed(lambda: ops.mlp_backward(x16, w, spec, go, grad_x=gx, gx_col0=n_pre, prefix=(enc, T, n_pre)), reps=10)
         print(f"bwd {name} [{kernel}]: {ms:.4f} ms  {flop / ms / 1e9:.0f} TFLOP/s = {flop / ms / 1e9 / 2500:.3f} of the dense fp16 MFMA peak (3 x forward FLOP)", flush=True)
+        if kernel == "wave" and n_out == 1:  # the second LiDAR head of the step ADDS its geometry gradient to the first one's
+            gx.zero_()
+            with testing.variant(mlp_bwd=kernel):
+                ms = timed(lambda: ops.mlp_backward(x16, w, spec, go, grad_x=gx, gx_col0=n_pre, prefix=(enc, T, n_pre), accumulate=True), reps=10)
+            print(f"bwd {name} [{kernel}, accumulating dL/dx]: {ms:.4f} ms", flush=True)
 spec = ops.MlpSpec(32, 16, 64, 1)
 w = (torch.randn(spec.n_params, generator=g) * 0.1).to(dev).half()
 feat = torch.randn(M, 32, generator=g).to(dev).half()
