@@ -112,6 +112,8 @@ def build(force=False, report=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     srcs = sources()
     want_all, want_render = csrc_digest_all(), csrc_digest()
+    if not force and not report and embedded_digest() == want_all:
+        return LIB  # the library on disk was built from exactly these sources and flags (whether or not its objects came along)
     defines = {s: [] for s in srcs}
     digests = {}
     for s in srcs:

@@ -129,3 +129,20 @@ def test_integration_index_lists_every_entry_point():
     assert {re.match(r"\| `(nvsf_\w+)`", l).group(1) for l in rows} == set(_declared())
     for l in rows:
         assert l in doc, l
+
+
+def test_library_carries_the_digest_of_its_sources(hip_lib):
+    """VERDICT r4 "weak" 4: staleness by content, identity from the mapped library.  The shared object embeds the sha1 over every
+    translation unit, every header and the flags it was built from (csrc/version.hip, compiled with the digests on its command line);
+    build.embedded_digest() reads it from the file, nvsf_build_digest() from the mapped library; both equal the digest of the sources
+    on disk after build(), a marker-less file reads as None, and an mtime change alone does not make the library stale."""
+    import build as nvsf_build
+    from nvsf import _hip
+    lib = os.path.join(PKG, "lib", "libnvsf_hip.so")
+    assert nvsf_build.embedded_digest(lib) == nvsf_build.csrc_digest_all() == _hip.build_digest()
+    assert _hip.build_digest(render_only=True) == nvsf_build.csrc_digest() and len(_hip.build_digest()) == 16
+    assert nvsf_build.embedded_digest(__file__) is None and nvsf_build.embedded_digest(lib + ".missing") is None
+    before = os.path.getmtime(lib)
+    os.utime(os.path.join(PKG, "csrc", "common.h"))   # newer header, same content
+    nvsf_build.build(verbose=False)
+    assert os.path.getmtime(lib) == before            # not relinked
