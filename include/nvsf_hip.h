@@ -296,6 +296,18 @@ int nvsf_mlp_bwd(const void* x, int x_is_f16, uint32_t M, uint32_t n_in, uint32_
                  uint32_t n_out, uint32_t go_stride, float grad_scale, float* grad_x, uint32_t gx_stride,
                  float* grad_weights_f32, uint32_t gx_col0, int gx_accumulate, nvsf_stream_t stream);
 
+/* nvsf_mlp_bwd for a DENSITY network (network_dynamic.py:281-287: sigma = trunc_exp(h[:, 0]), geo_feat = h[:, 1:]) whose logit gradient is
+ * formed from its parts while the operands are fetched, instead of read from an [M, 16] matrix that nvsf_sigma_geo_bwd wrote:
+ *   grad_out[m][0] = grad_sigma[m] * clamp(sigma[m], sigma_lo, sigma_hi)   (trunc_exp's backward, activation.py:16-20; grad_sigma NULL: 0)
+ *   grad_out[m][1 + j] = grad_geo_a[m][j] (+ grad_geo_b[m][j] when given: two heads sharing the features),  j < n_geo <= 15
+ * grad_geo rows: fp32, geo_stride >= 16 floats (a multiple of 4), 16-byte aligned.  Everything else as nvsf_mlp_bwd with n_out = 1 + n_geo.
+ * One launch and 128 B / sample of matrix traffic less than nvsf_sigma_geo_bwd + nvsf_mlp_bwd; the second head needs no read-modify-write. */
+int nvsf_mlp_bwd_density(const void* x, int x_is_f16, uint32_t M, uint32_t n_in, uint32_t x_stride, const void* weights_f16,
+                         uint32_t in_cols, uint32_t hidden, uint32_t n_hidden, uint32_t out_cols, const float* grad_sigma,
+                         const float* sigma, const float* grad_geo_a, const float* grad_geo_b, uint32_t geo_stride, uint32_t n_geo,
+                         float sigma_lo, float sigma_hi, float grad_scale, float* grad_x, uint32_t gx_stride, float* grad_weights_f32,
+                         uint32_t gx_col0, int gx_accumulate, nvsf_stream_t stream);
+
 /* nvsf_mlp_fwd / nvsf_mlp_bwd on rows with a shared prefix: logical input row r =
  *   [ prefix[r / rows_per_prefix][0 : prefix_cols] | x[r][0 : n_in - prefix_cols] ]
  * -- the per-sample heads, whose first 72 (LiDAR) / 16 (camera) inputs are the encoded direction of the sample's RAY

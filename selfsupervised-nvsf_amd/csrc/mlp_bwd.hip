@@ -28,6 +28,37 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 __device__ __forceinline__ int kappa(int s, int g, int j) { return 16 * (2 * s + (j >> 2)) + 4 * g + (j & 3); }
 
+// dL/d(outputs) of a DENSITY network formed while the operands are fetched (nvsf_mlp_bwd_density) instead of read from a [M, 16] matrix
+// a kernel of its own wrote (nvsf_sigma_geo_bwd):  column 0 = grad_sigma * clamp(sigma, lo, hi) (trunc_exp's backward, activation.py:
+// 16-20), column 1 + j = geo_a[m][j] (+ geo_b[m][j]: the geometry gradients of two heads that share the features, summed here instead
+// of by a read-modify-write in the second head's launch).  geo rows: 16 floats, 16-byte aligned, column 15 unused.
+struct GoCompose {
+    const float* sigma;  // nullptr: grad_out is read as it is
+    const float* grad_sigma;
+    const float* geo_a;
+    const float* geo_b;
+    uint32_t stride;
+    float lo, hi;
+    // the eight values of lane group g of sample row `row`: outputs 8 (g & 1) .. + 7
+    __device__ __forceinline__ void load(size_t row, int g, float (&go)[8]) const {
+        const uint32_t h = (uint32_t)g & 1u;
+        const float* ra = geo_a + row * stride;
+        const float4* pa = reinterpret_cast<const float4*>(ra) + 2 * h;
+        float4 a = pa[0], b = pa[1];
+        float prev = h ? ra[7] : 0.0f;
+        if (geo_b) {
+            const float* rb = geo_b + row * stride;
+            const float4* pb = reinterpret_cast<const float4*>(rb) + 2 * h;
+            const float4 a2 = pb[0], b2 = pb[1];
+            a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
+            b.x += b2.x; b.y += b2.y; b.z += b2.z;
+            if (h) prev += rb[7];
+        }
+        if (!h) prev = grad_sigma ? grad_sigma[row] * fminf(fmaxf(sigma[row], lo), hi) : 0.0f;
+        go[0] = prev; go[1] = a.x; go[2] = a.y; go[3] = a.z; go[4] = a.w; go[5] = b.x; go[6] = b.y; go[7] = b.z;
+    }
+};
+
 // fp32 accumulator tiles (2s, 2s+1) -> B fragment of k-step s, no activation (cf. relu_pack)
 __device__ __forceinline__ half8_t plain_pack(float4_t a, float4_t b) {
     const float8_t v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
@@ -95,7 +126,7 @@ __global__ __launch_bounds__(kBlock) void k_mlp_bwd(const void* __restrict__ x, 
                                                     const _Float16* __restrict__ weights, uint32_t in_cols,
                                                     const float* __restrict__ grad_out, uint32_t n_out, uint32_t go_stride, float grad_scale,
                                                     float* __restrict__ grad_x, uint32_t gx_stride, float* __restrict__ grad_w, int vec_ok,
-                                                    uint32_t gx_col0, int gx_accumulate, int go_vec, XPrefix pre) {
+                                                    uint32_t gx_col0, int gx_accumulate, int go_vec, XPrefix pre, GoCompose gc) {
     using FR = BwdFrags<IN_STEPS, N_HIDDEN>;
     constexpr int IN_TILES = FR::IN_TILES;
     __shared__ half8_t s_frag[FR::kCount * kWave];
@@ -145,7 +176,9 @@ __global__ __launch_bounds__(kBlock) void k_mlp_bwd(const void* __restrict__ x, 
         const _Float16* prow = pre.a ? pre.row_of((tile_u < n_tiles && tile_u * 16u < M) ? tile_u * 16u : M - 1u) : nullptr;
         issue_x_row<IN_STEPS, X_F16, FAST>(op.xf, x, row, x_stride, g, (int)n_in, (int)in_cols, vec_ok != 0, tail, prow, pre.split);
         const float* go_row = grad_out + row * go_stride;
-        if (go_vec) {  // 16 outputs, 16-byte aligned rows: two 16-byte loads for the lanes that hold outputs (g < 2)
+        if (gc.sigma) {  // density network: the logit gradient composed from (grad_sigma, sigma, geometry gradient rows)
+            gc.load(row, g, op.go);
+        } else if (go_vec) {  // 16 outputs, 16-byte aligned rows: two 16-byte loads for the lanes that hold outputs (g < 2)
             const float4* p = reinterpret_cast<const float4*>(go_row) + 2 * (g & 1);
             const float4 a = p[0], b = p[1];
             op.go[0] = a.x; op.go[1] = a.y; op.go[2] = a.z; op.go[3] = a.w;
@@ -374,7 +407,7 @@ template <int IN_STEPS, int N_HIDDEN, bool X_F16, bool FAST>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_mlp_bwd_wave(
     const void* __restrict__ x, uint32_t M, uint32_t n_in, uint32_t x_stride, const _Float16* __restrict__ weights, uint32_t in_cols,
     const float* __restrict__ grad_out, uint32_t n_out, uint32_t go_stride, float grad_scale, float* __restrict__ grad_x, uint32_t gx_stride,
-    float* __restrict__ grad_w, int vec_ok, uint32_t gx_col0, int gx_accumulate, int go_vec, XPrefix pre) {
+    float* __restrict__ grad_w, int vec_ok, uint32_t gx_col0, int gx_accumulate, int go_vec, XPrefix pre, GoCompose gc) {
     using FR = BwdFrags<IN_STEPS, N_HIDDEN>;
     constexpr int IN_TILES = FR::IN_TILES;
     constexpr int kDwMax = kHidden * 32 * IN_STEPS + (N_HIDDEN == 2 ? kHidden * kHidden : 0) + 16 * kHidden;
@@ -431,7 +464,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         const _Float16* prow = pre.a ? pre.row_of((tile_u < n_tiles && tile_u * 16u < M) ? tile_u * 16u : M - 1u) : nullptr;
         issue_x_row<IN_STEPS, X_F16, FAST>(op.xf, x, row, x_stride, g, (int)n_in, (int)in_cols, vec_ok != 0, tail, prow, pre.split);
         const float* go_row = grad_out + row * go_stride;
-        if (go_vec) {
+        if (gc.sigma) {
+            gc.load(row, g, op.go);
+        } else if (go_vec) {
             const float4* p = reinterpret_cast<const float4*>(go_row) + 2 * (g & 1);
             const float4 a = p[0], b = p[1];
             op.go[0] = a.x; op.go[1] = a.y; op.go[2] = a.z; op.go[3] = a.w;
@@ -658,9 +693,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 static int mlp_bwd_impl(const void* x, int x_is_f16, uint32_t M, uint32_t n_in, uint32_t x_stride, const void* weights_f16,
                         uint32_t in_cols, uint32_t hidden, uint32_t n_hidden, uint32_t out_cols, const float* grad_out, uint32_t n_out,
                         uint32_t go_stride, float grad_scale, float* grad_x, uint32_t gx_stride, float* grad_weights_f32,
-                        uint32_t gx_col0, int gx_accumulate, XPrefix pre, hipStream_t stream) {
+                        uint32_t gx_col0, int gx_accumulate, XPrefix pre, GoCompose gc, hipStream_t stream) {
     if (M == 0) return NVSF_OK;
-    REQUIRE(x && weights_f16 && grad_out && grad_weights_f32);
+    REQUIRE(x && weights_f16 && (grad_out || gc.sigma) && grad_weights_f32);
     REQUIRE(n_in >= 1 && n_in <= in_cols && in_cols % 16 == 0 && x_stride >= n_in - pre.split);
     REQUIRE(n_out >= 1 && n_out <= 16 && go_stride >= n_out && grad_scale > 0.0f);
     const uint32_t gx_blk = ((uint32_t)gx_accumulate >> 8) & 0xFFu;
@@ -703,11 +738,11 @@ static int mlp_bwd_impl(const void* x, int x_is_f16, uint32_t M, uint32_t n_in, 
         if (staged)                                                                                                                        \
             hipLaunchKernelGGL((k_mlp_bwd<S, H, XF, FA>), dim3(blocks), dim3(kBlock), 0, stream, x, M, n_in, x_stride, w, in_cols,        \
                                grad_out, n_out, go_stride, grad_scale, grad_x, gx_stride, grad_weights_f32, vec_ok, gx_col0,              \
-                               gx_accumulate, go_vec, pre);                                                                                \
+                               gx_accumulate, go_vec, pre, gc);                                                                                \
         else                                                                                                                               \
             hipLaunchKernelGGL((k_mlp_bwd_wave<S, H, XF, FA>), dim3(blocks), dim3(kBlock), 0, stream, x, M, n_in, x_stride, w, in_cols,   \
                                grad_out, n_out, go_stride, grad_scale, grad_x, gx_stride, grad_weights_f32, vec_ok, gx_col0,              \
-                               gx_accumulate, go_vec, pre);                                                                                \
+                               gx_accumulate, go_vec, pre, gc);                                                                                \
     } while (0)
 #define BY_F(S, H, XF) do { if (fast) LAUNCH(S, H, XF, true); else LAUNCH(S, H, XF, false); } while (0)
 #define BY_X(S, H) do { if (x_is_f16) BY_F(S, H, true); else BY_F(S, H, false); } while (0)
@@ -727,8 +762,25 @@ NVSF_API int nvsf_mlp_bwd(const void* x, int x_is_f16, uint32_t M, uint32_t n_in
                           uint32_t go_stride, float grad_scale, float* grad_x, uint32_t gx_stride, float* grad_weights_f32,
                           uint32_t gx_col0, int gx_accumulate, hipStream_t stream) {
     const XPrefix none = {nullptr, 0, 1, 0};
+    const GoCompose as_is = {nullptr, nullptr, nullptr, nullptr, 0, 0.0f, 0.0f};
     return mlp_bwd_impl(x, x_is_f16, M, n_in, x_stride, weights_f16, in_cols, hidden, n_hidden, out_cols, grad_out, n_out, go_stride, grad_scale,
-                        grad_x, gx_stride, grad_weights_f32, gx_col0, gx_accumulate, none, stream);
+                        grad_x, gx_stride, grad_weights_f32, gx_col0, gx_accumulate, none, as_is, stream);
+}
+
+// nvsf_mlp_bwd for a density network whose logit gradient is formed from its parts while the operands are fetched (GoCompose above):
+// replaces nvsf_sigma_geo_bwd + nvsf_mlp_bwd (one launch and 128 B / sample of matrix traffic less) and sums two heads' geometry gradients.
+NVSF_API int nvsf_mlp_bwd_density(const void* x, int x_is_f16, uint32_t M, uint32_t n_in, uint32_t x_stride, const void* weights_f16,
+                                  uint32_t in_cols, uint32_t hidden, uint32_t n_hidden, uint32_t out_cols, const float* grad_sigma,
+                                  const float* sigma, const float* grad_geo_a, const float* grad_geo_b, uint32_t geo_stride, uint32_t n_geo,
+                                  float sigma_lo, float sigma_hi, float grad_scale, float* grad_x, uint32_t gx_stride, float* grad_weights_f32,
+                                  uint32_t gx_col0, int gx_accumulate, hipStream_t stream) {
+    if (M == 0) return NVSF_OK;
+    REQUIRE(sigma && grad_geo_a && n_geo >= 1 && n_geo <= 15 && geo_stride >= 16 && geo_stride % 4 == 0);
+    REQUIRE(((reinterpret_cast<uintptr_t>(grad_geo_a) | reinterpret_cast<uintptr_t>(grad_geo_b)) & 15u) == 0);
+    const XPrefix none = {nullptr, 0, 1, 0};
+    const GoCompose gc = {sigma, grad_sigma, grad_geo_a, grad_geo_b, geo_stride, sigma_lo, sigma_hi};
+    return mlp_bwd_impl(x, x_is_f16, M, n_in, x_stride, weights_f16, in_cols, hidden, n_hidden, out_cols, nullptr, 1 + n_geo, 16, grad_scale,
+                        grad_x, gx_stride, grad_weights_f32, gx_col0, gx_accumulate, none, gc, stream);
 }
 
 // nvsf_mlp_bwd on rows with a shared prefix (see nvsf_mlp_fwd_prefix); the columns of dL/dx are those of the logical row.
@@ -739,6 +791,7 @@ NVSF_API int nvsf_mlp_bwd_prefix(const void* prefix_f16, uint32_t prefix_stride,
                                  float* grad_weights_f32, uint32_t gx_col0, int gx_accumulate, hipStream_t stream) {
     REQUIRE(prefix_f16 && prefix_cols > 0);
     const XPrefix pre = {reinterpret_cast<const _Float16*>(prefix_f16), prefix_stride, rows_per_prefix, prefix_cols};
+    const GoCompose as_is = {nullptr, nullptr, nullptr, nullptr, 0, 0.0f, 0.0f};
     return mlp_bwd_impl(x_f16, 1, M, n_in, x_stride, weights_f16, in_cols, hidden, n_hidden, out_cols, grad_out, n_out, go_stride, grad_scale,
-                        grad_x, gx_stride, grad_weights_f32, gx_col0, gx_accumulate, pre, stream);
+                        grad_x, gx_stride, grad_weights_f32, gx_col0, gx_accumulate, pre, as_is, stream);
 }

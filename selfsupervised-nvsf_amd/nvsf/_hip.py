@@ -57,6 +57,7 @@ SIGNATURES = {
     "nvsf_mlp_fwd": [_P, _I, _U, _U, _U, _P, _U, _U, _U, _U, _P, _U],
     "nvsf_mlp_bwd": [_P, _I, _U, _U, _U, _P, _U, _U, _U, _U, _P, _U, _U, _F, _P, _U, _P, _U, _I],
     "nvsf_mlp_fwd_prefix": [_P, _U, _U, _U, _P, _U, _U, _U, _P, _U, _U, _U, _U, _P, _U],
+    "nvsf_mlp_bwd_density": [_P, _I, _U, _U, _U, _P, _U, _U, _U, _U, _P, _P, _P, _P, _U, _U, _F, _F, _F, _P, _U, _P, _U, _I],
     "nvsf_mlp_bwd_prefix": [_P, _U, _U, _U, _P, _U, _U, _U, _P, _U, _U, _U, _U, _P, _U, _U, _F, _P, _U, _P, _U, _I],
     "nvsf_planes_fwd": [_P, _U, _P, _U, _U, _P, _I, _P, _P],
     "nvsf_planes_multi_fwd": [_P, _U, _U, _P, _U, _U, _P, _U, _P, _P, _P, _P, _P, _P, _I],

@@ -314,18 +314,53 @@ def mlp_forward(x, weights_f16, spec, out=None, prefix=None, n_store=None):
 MLP_GRAD_SCALE = 128.0  # fp16 gradients inside nvsf_mlp_bwd are multiplied by this (tcnn's default loss_scale)
 
 
+def density_logit_gradient_parts(g_sigma, sigma, g_geo, g_geo_b, n_geo, clamp):
+    """(grad_sigma, sigma, geo_a, geo_b, n_geo, lo, hi) for mlp_backward(density_grad=...) when the pieces have the layout
+    nvsf_mlp_bwd_density reads (fp32, geometry-gradient rows of >= 16 floats, 16-byte aligned), else None."""
+    def rows_ok(t):
+        return (t is not None and t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= 16
+                and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 and t.shape[1] >= n_geo)
+    if not (1 <= n_geo <= 15 and rows_ok(g_geo) and (g_geo_b is None or (rows_ok(g_geo_b) and g_geo_b.stride(0) == g_geo.stride(0)))):
+        return None
+    if sigma is None or sigma.dtype != torch.float32 or not sigma.is_contiguous():
+        return None
+    if g_sigma is not None and (g_sigma.dtype != torch.float32 or not g_sigma.is_contiguous()):
+        return None
+    return (g_sigma, sigma, g_geo, g_geo_b, int(n_geo), float(clamp[0]), float(clamp[1]))
+
+
 def mlp_backward(x, weights_f16, spec, grad_out, need_grad_x=True, grad_scale=MLP_GRAD_SCALE, grad_x=None, gx_col0=0,
-                 accumulate=False, prefix=None, grad_x_blocks=0):
+                 accumulate=False, prefix=None, grad_x_blocks=0, density_grad=None):
     """One fused kernel: (x, weights, dL/dout [M, n_out] fp32) -> dL/dx fp32 [M, n_in] (or None), dL/dW fp32 [n_params].
     With `grad_x` given (fp32, unit column stride) the input gradient of columns gx_col0.. is written (or added, with
-    `accumulate`) there: grad_x[:, j] = dL/dx[:, gx_col0 + j]."""
+    `accumulate`) there: grad_x[:, j] = dL/dx[:, gx_col0 + j].
+    `density_grad` (density_logit_gradient_parts; `grad_out` is then None): dL/dout is formed inside the kernel from
+    (grad_sigma, sigma, geometry-gradient rows of one or two heads) -- nvsf_mlp_bwd_density."""
     x = _rows(x)
-    grad_out = grad_out.float()
-    if grad_out.dim() != 2 or (grad_out.shape[1] > 1 and grad_out.stride(1) != 1):
-        grad_out = grad_out.contiguous()
     M = x.shape[0]
     grad_w = torch.zeros(spec.n_params, dtype=torch.float32, device=x.device)
     mode = (1 if accumulate else 0) | (int(grad_x_blocks) << 8)
+    if density_grad is not None:
+        g_sigma, sigma, geo_a, geo_b, n_geo, lo, hi = density_grad
+        assert prefix is None and spec.n_out == 1 + n_geo
+        if grad_x_blocks:
+            assert need_grad_x and gx_col0 == 0 and spec.n_in % grad_x_blocks == 0
+            if grad_x is None:
+                grad_x = torch.empty(spec.n_in // grad_x_blocks, M, grad_x_blocks, dtype=torch.float32, device=x.device)
+            gx_ptr, gx_stride = _hip.ptr(grad_x), grad_x_blocks
+        else:
+            if grad_x is None and need_grad_x:
+                n_gx = spec.n_in - gx_col0
+                grad_x = torch.empty(M, (n_gx + 3) // 4 * 4, dtype=torch.float32, device=x.device)[:, :n_gx]
+            gx_ptr, gx_stride = (None, 0) if grad_x is None else (_hip.ptr_rows(grad_x), grad_x.stride(0))
+        _hip.call("nvsf_mlp_bwd_density", _hip.ptr_rows(x), 1 if x.dtype == torch.float16 else 0, M, spec.n_in, x.stride(0), _hip.ptr(weights_f16),
+                  spec.in_cols, spec.hidden, spec.n_hidden, spec.out_cols, None if g_sigma is None else _hip.ptr(g_sigma), _hip.ptr(sigma),
+                  _hip.ptr_rows(geo_a), None if geo_b is None else _hip.ptr_rows(geo_b), geo_a.stride(0), n_geo, lo, hi, float(grad_scale),
+                  gx_ptr, gx_stride, _hip.ptr(grad_w), int(gx_col0), mode)
+        return grad_x, grad_w
+    grad_out = grad_out.float()
+    if grad_out.dim() != 2 or (grad_out.shape[1] > 1 and grad_out.stride(1) != 1):
+        grad_out = grad_out.contiguous()
     if grad_x_blocks:  # dL/dx as column blocks [n_in / B, M, B] (the gradient of a hash grid's features, level by level)
         assert need_grad_x and gx_col0 == 0 and spec.n_in % grad_x_blocks == 0 and prefix is None
         if grad_x is None:
@@ -722,10 +757,20 @@ def _density_backward(ctx, g_sigma, g_geo):
         g_sigma = g_sigma.float().contiguous()
     if g_geo is not None and (g_geo.dtype != torch.float32 or g_geo.stride(1) != 1):
         g_geo = g_geo.float().contiguous()
-    grad_h = torch.empty(M, 16, dtype=torch.float32, device=x01.device)
-    _hip.call("nvsf_sigma_geo_bwd", None if g_sigma is None else _hip.ptr(g_sigma), _hip.ptr(sigma),
-              None if g_geo is None else _hip.ptr_rows(g_geo), 0 if g_geo is None else g_geo.stride(0), spec.n_out - 1, M,
-              _hip.ptr(grad_h), 16, ctx.clamp[0], ctx.clamp[1])
+    # the logit gradient [g_sigma clamp(sigma) | g_geo (+ g_geo_b)] is formed inside the MLP backward where the pieces have the layout it
+    # reads (nvsf_mlp_bwd_density); otherwise (and as the test reference, testing.variant(density_grad="matrix")) by a pass of its own
+    g_geo_b = getattr(ctx, "g_geo_b", None)
+    parts = None
+    if _testing.get("density_grad") == "composed" and x01.is_cuda:
+        parts = density_logit_gradient_parts(g_sigma, sigma.view(-1), g_geo, g_geo_b, spec.n_out - 1, ctx.clamp)
+    grad_h = None
+    if parts is None:
+        if g_geo_b is not None:
+            g_geo = g_geo + g_geo_b
+        grad_h = torch.empty(M, 16, dtype=torch.float32, device=x01.device)
+        _hip.call("nvsf_sigma_geo_bwd", None if g_sigma is None else _hip.ptr(g_sigma), _hip.ptr(sigma),
+                  None if g_geo is None else _hip.ptr_rows(g_geo), 0 if g_geo is None else g_geo.stride(0), spec.n_out - 1, M,
+                  _hip.ptr(grad_h), 16, ctx.clamp[0], ctx.clamp[1])
     need_table, need_w = ctx.need_table, ctx.need_w
     # levels whose cells are shorter than a few ray steps go through the binned scatter (rows are ray-ordered with a known ray length);
     # the MLP then hands its input gradient over level by level ([L, M, F]): every pass of the scatter reads one contiguous column
@@ -733,7 +778,8 @@ def _density_backward(ctx, g_sigma, g_geo):
     blocks = ctx.grid_spec.F if (LEVEL_MAJOR_GRADIENT and fine is not None and M <= _BIN_ROWS_MAX and spec.n_in == ctx.grid_spec.L * ctx.grid_spec.F
                                  and feat.dtype == torch.float16 and feat.stride(0) % 8 == 0
                                  and _hip.hashgrid_bwd_ws_bytes(M, ctx.grid_spec, fine[0], fine[1]) > 0) else 0
-    grad_feat, grad_w = mlp_backward(feat, mlp_w16, spec, grad_h[:, :spec.n_out], need_grad_x=need_table, grad_x_blocks=blocks)
+    grad_feat, grad_w = mlp_backward(feat, mlp_w16, spec, None if grad_h is None else grad_h[:, :spec.n_out], need_grad_x=need_table,
+                                     grad_x_blocks=blocks, density_grad=parts)
     grad_table = None
     if need_table:
         tctx = getattr(ctx, "train_ctx", None)
@@ -901,10 +947,16 @@ class RenderRaysFn(Function):
         grad_geo = torch.empty(M, (n_geo + 3) // 4 * 4, **f32)[:, :n_geo]
         prefix = (enc_ray, T, n_enc)
         _, gw_a = mlp_backward(geo16, w16_a, hs, g_logits[:, :hs.n_out], need_grad_x=True, grad_x=grad_geo, gx_col0=n_enc, prefix=prefix)
-        gw_b = None
+        gw_b = grad_geo_b = None
         if lidar:
-            _, gw_b = mlp_backward(geo16, w16_b, hs, g_logits[:, hs.n_out:2 * hs.n_out], need_grad_x=True, grad_x=grad_geo, gx_col0=n_enc,
-                                   accumulate=True, prefix=prefix)
+            # the second head's geometry gradient goes to rows of its own and the density MLP's backward sums the two while it fetches
+            # its operands (nvsf_mlp_bwd_density): adding into the first head's rows is a read-modify-write whose load the head
+            # kernel -- one wave per SIMD -- cannot hide (0.45 against 0.35 ms alone)
+            composed = _testing.get("density_grad") == "composed" and n_geo == ctx.mlp_spec.n_out - 1
+            if composed:
+                grad_geo_b = torch.empty(M, (n_geo + 3) // 4 * 4, **f32)[:, :n_geo]
+            _, gw_b = mlp_backward(geo16, w16_b, hs, g_logits[:, hs.n_out:2 * hs.n_out], need_grad_x=True,
+                                   grad_x=grad_geo_b if composed else grad_geo, gx_col0=n_enc, accumulate=not composed, prefix=prefix)
         # ---- weights / weights_sum / depth from sigma
         if g_w is not None and g_weights is not None:
             g_w = g_w + g_weights
@@ -918,7 +970,7 @@ class RenderRaysFn(Function):
         # ---- density MLP + table scatter: DensityFn's backward on what this node saved
         dctx = types.SimpleNamespace(saved_tensors=(x01, feat, sigma, sigma_w16), mlp_spec=ctx.mlp_spec, clamp=ctx.clamp, grid_spec=ctx.grid_spec,
                                      table_param=ctx.table_param, rows_per_ray=ctx.rows_per_ray, train_ctx=ctx.train_ctx, need_table=ctx.need_table,
-                                     need_w=ctx.need_w)
+                                     need_w=ctx.need_w, g_geo_b=grad_geo_b)
         d = _density_backward(dctx, g_sigma.view(-1), grad_geo)  # (grad_table, None, None, grad_w_sigma, ...)
         out = [None] * 29
         out[8], out[11] = d[0], d[3]

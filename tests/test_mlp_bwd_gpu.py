@@ -262,3 +262,43 @@ def test_input_gradient_in_column_blocks(dev):
         torch.testing.assert_close(gw, gw_ref, rtol=1e-4, atol=1e-5)
         twice, _ = ops.mlp_backward(x, w, spec, go, grad_x=got.clone(), grad_x_blocks=B, accumulate=True)
         torch.testing.assert_close(twice.permute(1, 0, 2).reshape(M, 32), 2 * ref, rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("n_in,two_heads,blocks", [(32, False, 0), (32, True, 2), (120, True, 0), (32, True, 0), (32, False, 4)])
+def test_density_logit_gradient_composed_in_the_kernel(dev, n_in, two_heads, blocks, variants):
+    """nvsf_mlp_bwd_density (round 5): the density network's logit gradient [g_sigma clamp(sigma) | g_geo_a (+ g_geo_b)] formed while the
+    operands are fetched == nvsf_sigma_geo_bwd (+ the sum of the two heads' rows) followed by nvsf_mlp_bwd: same dL/dx bit for bit (the
+    same fp32 values enter the same kernel), dL/dW up to the order of its per-workgroup float atomics.  32-64-16 = the LDS-staged kernel
+    (rows and level-major column blocks), 120-64-16 = the wave-independent kernel."""
+    from nvsf import field_ops as ops, _hip
+    from nvsf.nerf import activation
+    M = 5000 + 37
+    spec = ops.MlpSpec(n_in, 16, 64, 1)
+    g = torch.Generator().manual_seed(n_in + int(two_heads))
+    x = (torch.randn(M, n_in, generator=g)).to(dev).half()
+    w = (torch.randn(spec.n_params, generator=g) * 0.1).to(dev).half()
+    g_sigma = (torch.randn(M, generator=g) * 0.01).to(dev)
+    sigma = torch.exp(torch.randn(M, generator=g) * 2).to(dev)
+    sigma[:10], sigma[10:20] = 1e-9, 1e8                                   # beyond trunc_exp's clamp on either side
+    g_sigma[10:20] = 1e-9                                                  # (the clamped product stays inside fp16 after the loss scale)
+    geo_a = torch.full((M, 16), 123.0, device=dev)                         # column 15 is alignment padding: garbage on purpose
+    geo_a[:, :15] = (torch.randn(M, 15, generator=g) * 0.01).to(dev)
+    geo_b = None
+    if two_heads:
+        geo_b = torch.full((M, 16), -77.0, device=dev)
+        geo_b[:, :15] = (torch.randn(M, 15, generator=g) * 0.01).to(dev)
+    lo, hi = activation._LO, activation._HI
+    # reference: the matrix form
+    summed = geo_a[:, :15] if geo_b is None else (geo_a + geo_b)[:, :15]
+    grad_h = torch.empty(M, 16, device=dev)
+    _hip.call("nvsf_sigma_geo_bwd", _hip.ptr(g_sigma), _hip.ptr(sigma), _hip.ptr_rows(summed), summed.stride(0), 15, M, _hip.ptr(grad_h), 16, lo, hi)
+    gx_ref, gw_ref = ops.mlp_backward(x, w, spec, grad_h, grad_x_blocks=blocks)
+    parts = ops.density_logit_gradient_parts(g_sigma, sigma, geo_a[:, :15], None if geo_b is None else geo_b[:, :15], 15, (lo, hi))
+    assert parts is not None
+    gx, gw = ops.mlp_backward(x, w, spec, None, grad_x_blocks=blocks, density_grad=parts)
+    assert torch.equal(gx, gx_ref)
+    scale = float(gw_ref.abs().max())
+    assert scale > 0 and float((gw - gw_ref).abs().max()) <= 2e-6 * scale
+    # layouts the kernel does not read are refused by the helper (the caller then takes the matrix form)
+    assert ops.density_logit_gradient_parts(g_sigma, sigma, geo_a[:, 1:16], None, 15, (lo, hi)) is None      # rows not 16-byte aligned
+    assert ops.density_logit_gradient_parts(g_sigma, sigma, geo_a[:, :15].contiguous(), None, 15, (lo, hi)) is None  # 15-float rows

@@ -676,3 +676,37 @@ def test_overflowing_step_is_skipped_for_every_parameter_with_the_last_table_def
         d = (pa[n] - pb[n]).abs()
         if d.numel():
             assert float(d.mean()) <= 1e-6 and float((d <= 1e-4).float().mean()) >= 0.999, (n, float(d.mean()), float(d.max()))
+
+
+def test_density_gradient_composed_equals_the_matrix_form_in_the_step(dev, variants):
+    """RenderRaysFn.backward / _density_backward with the density network's logit gradient formed inside the MLP backward
+    (nvsf_mlp_bwd_density; the second LiDAR head writes geometry-gradient rows of its own) against the sigma_geo pass + accumulating
+    second head they replace: same gradients on every parameter (fp32 atomic order only)."""
+    from nvsf import synthetic as S
+    from nvsf.nerf.models.network_static import NeRFNetworkStatic
+    from nvsf.nerf.train_step import RenderTrainStep
+    kw = dict(bound=S.BOUND, min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH, log2_hashmap_size=14)
+    torch.manual_seed(2)
+    teacher = NeRFNetworkStatic(**kw)
+    with torch.no_grad():
+        for enc in (teacher.hash_encoder_lidar, teacher.hash_encoder_camera):
+            enc.params.normal_(0.0, 0.2)
+    teacher = teacher.to(dev).eval()
+    batch = _batch(S, teacher, dev, n=600, T=64)
+    grads = {}
+    for form in ("composed", "matrix"):
+        variants.set(density_grad=form)
+        torch.manual_seed(6)
+        m = NeRFNetworkStatic(**kw).to(dev)
+        step = RenderTrainStep(m, num_steps=64, scale=S.SCALE, ema_decay=None)
+        step.scaler = _LossScaler()(init_scale=64.0, growth_interval=10 ** 6)
+        torch.manual_seed(10)
+        step.forward_backward(batch)
+        torch.cuda.synchronize()
+        grads[form] = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+    variants.clear("density_grad")
+    assert set(grads["composed"]) == set(grads["matrix"]) and len(grads["matrix"]) == 6
+    for n, a in grads["matrix"].items():
+        b = grads["composed"][n]
+        scale = float(a.abs().max())
+        assert scale > 0 and float((a - b).abs().max()) <= 1e-5 * scale, n

@@ -35,6 +35,9 @@ if os.environ.get('MERGE') == '0':  # run sums off: atomics for every level belo
     _ops.merge_levels_from = lambda spec, fine, rows: fine
 if os.environ.get('BINS') == '0':   # no bins at all
     _ops._bin_from = lambda spec, M, rows: None
+if os.environ.get('DG'):  # composed / matrix: the density network's logit gradient inside the MLP backward or by nvsf_sigma_geo_bwd
+    from nvsf import testing as _testing
+    _cg = _testing.variant(density_grad=os.environ['DG']); _cg.__enter__()
 if os.environ.get('MLP_BWD'):  # staged / wave: force one kernel of nvsf_mlp_bwd
     from nvsf import testing as _testing
     _cm = _testing.variant(mlp_bwd=os.environ['MLP_BWD']); _cm.__enter__()
