@@ -1,12 +1,15 @@
 """End-to-end example of the multimodal training loop around the hot path (BASELINE config 4), one process per GPU:
 
-    python tools/train_example.py --root /path/to/kitti360_nvsf --sequence 1908 [--dynamic] [--steps 200]
+    python tools/train_example.py --root /path/to/kitti360_nvsf --sequence 1908 [--dynamic] [--epochs 6] [--plain]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 tools/train_example.py ...
 
 Data: the reference's on-disk formats (transforms_{seq}_{split}.json + range-image .npy + images; nvsf/nerf/dataset/formats.py).
 Without --root a small synthetic data set in those formats is written to a temporary directory first.
 Every step renders one frame per rank (frames are sharded over the ranks, nvsf/frame_shard.py), then ONE bucketed RCCL
-all-reduce of the gradients, then Adam under the loss scaler (nvsf/nerf/train_step.py).  Reports loss, PSNR and range RMSE.
+all-reduce of the gradients, then Adam under the loss scaler (nvsf/nerf/train_step.py).  The loop is the shipped configuration's
+(configs/kitti360_1908.txt: grad_loss, use_error_map; trainer.py:1035-1062): epochs over the frames, every second epoch samples 2 x 8 LiDAR
+patches from the error map and adds the structural regularisation, every step writes its per-ray losses back into the frame's error maps,
+one EMA update per epoch; --plain = random pixels and the default losses only.  Reports loss terms, PSNR, range RMSE, CD / F-score.
 """
 import argparse
 import os
@@ -20,7 +23,7 @@ import numpy as np
 import torch
 
 
-def synthetic_dataset(root, seq, n_frames=8, H=94, W=352, Hl=66, Wl=1030, seed=0):
+def synthetic_dataset(root, seq, n_frames=8, H=376, W=1408, Hl=66, Wl=1030, seed=0):  # KITTI-360's image / range-image sizes
     """A box-shaped toy scene in the reference's formats: constant-colour images, a range image of a sphere of radius 30 m."""
     from nvsf.nerf.dataset import formats as F
     rng = np.random.default_rng(seed)
@@ -39,7 +42,7 @@ def synthetic_dataset(root, seq, n_frames=8, H=94, W=352, Hl=66, Wl=1030, seed=0
         np.save(os.path.join(d, f"pano_{i:04d}.npy"), pc)
         frames.append({"frame_id": 1908 + i, "file_path": f"train/{seq}/img_{i:04d}.npy", "transform_matrix": pose,
                        "lidar_file_path": f"train/{seq}/pano_{i:04d}.npy", "lidar2world": pose})
-    K = np.array([[552.55 / 4, 0, W / 2], [0, 552.55 / 4, H / 2], [0, 0, 1]])
+    K = np.array([[552.55, 0, W / 2], [0, 552.55, H / 2], [0, 0, 1]])
     F.write_transforms(F.transforms_path(root, seq, "train"), w=W, h=H, w_lidar=Wl, h_lidar=Hl, K=K, frame_start=1908, frame_end=1908 + n_frames - 1,
                        num_frames=n_frames, frames=frames)
 
@@ -48,7 +51,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--root", default=None)
     ap.add_argument("--sequence", default="1908")
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--epochs", type=int, default=6)
+    ap.add_argument("--plain", action="store_true", help="no structural regularisation / error maps / patch epochs")
     ap.add_argument("--num-rays", type=int, default=4096)
     ap.add_argument("--num-steps", type=int, default=768)
     ap.add_argument("--dynamic", action="store_true", help="the reference's space-time model instead of the static hash field")
@@ -64,7 +68,7 @@ def main():
     from nvsf.nerf.train_step import RenderTrainStep
     root = args.root
     if root is None:
-        root = os.path.join(tempfile.gettempdir(), "nvsf_synthetic")
+        root = os.path.join(tempfile.gettempdir(), "nvsf_synthetic_376x1408")
         if rank == 0:
             synthetic_dataset(root, args.sequence)
         if world > 1:
@@ -80,16 +84,31 @@ def main():
         from nvsf.nerf.models.network_static import NeRFNetworkStatic
         model = NeRFNetworkStatic(bound=S.BOUND, min_near=S.MIN_NEAR, min_near_lidar=S.MIN_NEAR, lidar_max_depth=S.LIDAR_MAX_DEPTH,
                                   num_frames=data.meta["num_frames"]).to(dev)
-    trainer = RenderTrainStep(model, iters=args.steps, num_steps=args.num_steps)
     n = len(data)
-    for it in range(args.steps):
-        perm = np.random.default_rng(it // max(1, n // world)).permutation(n)  # the same permutation on every rank
-        frame = int(perm[(it * world + rank) % n])
-        batch = data.train_batch([frame])
-        loss, parts, n_coll = trainer.step(batch)
-        if rank == 0 and (it % 10 == 0 or it == args.steps - 1):
-            print(f"step {it:4d}  frame {frame:3d}  loss {float(loss):.4f}  " + "  ".join(f"{k} {float(v):.4f}" for k, v in parts.items())
-                  + f"  all-reduces/step {n_coll}", flush=True)
+    per_epoch = max(1, n // world)
+    trainer = RenderTrainStep(model, iters=args.epochs * per_epoch, num_steps=args.num_steps, scale=scale, grad_loss=not args.plain,
+                              use_error_map=not args.plain, change_patch_size_lidar=(1,) if args.plain else (2, 8))
+    if not args.plain:
+        trainer.attach_error_maps(data)
+    it = 0
+    for epoch in range(1, args.epochs + 1):
+        sampler = trainer.set_epoch(epoch, data)  # "random" / "patch" (trainer.py:1035-1062)
+        perm = np.random.default_rng(epoch).permutation(n)  # the same permutation on every rank
+        sums, count = {}, 0
+        for k in range(per_epoch):
+            frame = int(perm[(k * world + rank) % n])
+            loss, parts, n_coll = trainer.step(data.train_batch([frame]))
+            for name, v in dict(parts, total=loss).items():
+                sums[name] = sums.get(name, 0.0) + float(v)
+            count += 1
+            it += 1
+        trainer.end_epoch()  # one EMA update per epoch (trainer.py:1420-1421)
+        if rank == 0:
+            line = f"epoch {epoch:3d}  sampler {sampler:6s}  " + "  ".join(f"{k} {v / count:.4f}" for k, v in sums.items()) + f"  all-reduces/step {n_coll}"
+            if data.error_map is not None:
+                em = data.error_map
+                line += f"  error map: {int((em != 1).sum())} of {em.numel()} cells touched, max {float(em.max()):.1f}"
+            print(line, flush=True)
     # whole-frame evaluation (Trainer.eval_step / evaluate_one_epoch): every frame rendered with the staged loop, its rays split over the ranks
     from nvsf.nerf.train_step import evaluate_frames
     whole = FrameSet(root, args.sequence, "train", scale, device=dev, training=False)
