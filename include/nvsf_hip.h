@@ -346,7 +346,24 @@ int nvsf_planes_multi_fwd(const float* x, uint32_t x_stride, uint32_t M, const f
                           const uint32_t* h_offset_stride, const uint32_t* h_offset_col, const float* h_time,
                           float* const* h_out, int blend, nvsf_stream_t stream);
 
-/* autograd of the above: grad_planes_cl (same layout as planes_cl, fp32 atomics, caller zero-initialises; may be
+/* Backward of nvsf_planes_multi_fwd in one launch per gradient kind: evaluation e (group, offsets, time as above) has the
+ * gradient of its features in h_grad_out[e] (fp32 rows of n_scales*C floats, h_grad_stride[e] floats apart -- NULL array: dense rows --
+ * times h_grad_scale[e] -- NULL array: 1; NULL pointer: the evaluation contributes nothing).  A slice of a wider gradient matrix is read
+ * in place, and the evaluations of the blend 0.5 d + 0.25 (d1 + d2) (nvsf_planes_multi_fwd with blend != 0) share ONE gradient with the
+ * scales 0.5, 0.25, 0.25.  grad_planes_cl (may be
+ * NULL): the texel gradients of EVERY evaluation are ADDED into it, the evaluations of a group walked round by round with one set of
+ * texel-quad sums (addends of evaluations that fall into the same quad are merged before the atomic leaves).  h_grad_offsets[e] (the
+ * array or an entry may be NULL): receives d L / d (offset of evaluation e), 3 floats per row at column h_grad_offset_col[e] of rows
+ * of h_grad_offset_stride[e] floats -- the gradient the flow field is trained through (network_dynamic.py:250-271).
+ * Same addends as one nvsf_planes_bwd per evaluation; the order of the fp32 additions into a texel differs. */
+int nvsf_planes_multi_bwd(const float* x, uint32_t x_stride, uint32_t M, const float* planes_cl, uint32_t n_scales, uint32_t C,
+                          const uint32_t* h_res, uint32_t n_evals, const int* h_group, const float* const* h_offsets,
+                          const uint32_t* h_offset_stride, const uint32_t* h_offset_col, const float* h_time,
+                          const float* const* h_grad_out, const uint32_t* h_grad_stride, const float* h_grad_scale,
+                          float* grad_planes_cl, float* const* h_grad_offsets, const uint32_t* h_grad_offset_stride,
+                          const uint32_t* h_grad_offset_col, nvsf_stream_t stream);
+
+/* autograd of nvsf_planes_fwd: grad_planes_cl (same layout as planes_cl, fp32 atomics, caller zero-initialises; may be
  * NULL) and grad_xt [M,4] (may be NULL). */
 int nvsf_planes_bwd(const float* xt, uint32_t M, const float* planes_cl, uint32_t n_scales, uint32_t C,
                     const uint32_t* h_res, int want, const float* grad_static, const float* grad_dynamic,
@@ -446,10 +463,11 @@ int nvsf_density_dynamic_lm32_fwd(const float* plane_s, const float* plane_d, co
  * g_plane_quarter = 0.25 grad_x[:, 32:64], g_hash_s = grad_x[:, 64:96] (fp16 or fp32 rows of 32), g_hash_d_half = 0.5 grad_x[:, 96:120]
  * ([M,24], or [24][M] with hash_d_col_major != 0: the layout nvsf_hashgrid4d_dynamic_bwd_scalar_t reads), g_plane_s = grad_x[:, 0:32] as
  * rows of its own; hash_s_level_major != 0: g_hash_s as [8][M][4] (the layout of nvsf_hashgrid_fwd_level_major's output).  NULL outputs are
- * skipped.  The same values as the elementwise operations. */
+ * skipped.  The same values as the elementwise operations.  plane_half_scale: the factor of g_plane_half -- 0.5 for the blend of three
+ * separate tensors; 1 where the producer already blended them (plane_d = plane_1 = plane_2 one tensor, whose gradient is the whole slice). */
 int nvsf_density_tail_grad_split(const float* grad_x, uint32_t gx_stride, uint32_t M, float* g_plane_half, float* g_plane_quarter,
                                  void* g_hash_s, int hash_s_is_f16, int hash_s_level_major, float* g_hash_d_half, int hash_d_col_major,
-                                 float* g_plane_s, nvsf_stream_t stream);
+                                 float* g_plane_s, float plane_half_scale, nvsf_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Section 4: fused kernels of the uniform-sampling render (BASELINE config 2 hot path).

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(kBlock) void k_exp_col(const float* __restrict__ h,
 __global__ __launch_bounds__(kBlock) void k_density_tail_grad_split(const float* __restrict__ gx, uint32_t gx_stride, uint32_t M, float* __restrict__ g_half,
                                                                     float* __restrict__ g_quarter, void* __restrict__ g_hash_s, int hash_s_f16,
                                                                     float* __restrict__ g_hash_d, float* __restrict__ g_plane_s, int hash_d_col_major,
-                                                                    int hash_s_lm) {
+                                                                    int hash_s_lm, float half_scale) {
     // A workgroup stages 64 rows (columns 0 .. 119) in LDS with whole-line reads and writes every output from there in the order that
     // output wants: rows as 16-byte pieces, the column-major hash_d gradient ([24][M]: its consumer k_hash_dynamic_bwd_lds reads one
     // column per workgroup) as 64 consecutive floats per column.
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(kBlock) void k_density_tail_grad_split(const float*
                 *reinterpret_cast<float4*>(g_plane_s + at) = make_float4(a[0], a[1], a[2], a[3]);
             }
             const float* b = s_t + r * kPitch + 32 + 4u * q;
-            if (g_half) *reinterpret_cast<float4*>(g_half + at) = make_float4(0.5f * b[0], 0.5f * b[1], 0.5f * b[2], 0.5f * b[3]);
+            if (g_half) *reinterpret_cast<float4*>(g_half + at) = make_float4(half_scale * b[0], half_scale * b[1], half_scale * b[2], half_scale * b[3]);
             if (g_quarter) *reinterpret_cast<float4*>(g_quarter + at) = make_float4(0.25f * b[0], 0.25f * b[1], 0.25f * b[2], 0.25f * b[3]);
             if (g_hash_s) {
                 const float* c = s_t + r * kPitch + 64 + 4u * q;
@@ -360,7 +360,7 @@ NVSF_API int nvsf_exp_col(const float* h, uint32_t row_stride, uint32_t col, uin
 
 NVSF_API int nvsf_density_tail_grad_split(const float* grad_x, uint32_t gx_stride, uint32_t M, float* g_plane_half, float* g_plane_quarter,
                                           void* g_hash_s, int hash_s_is_f16, int hash_s_level_major, float* g_hash_d_half, int hash_d_col_major,
-                                          float* g_plane_s, hipStream_t stream) {
+                                          float* g_plane_s, float plane_half_scale, hipStream_t stream) {
     if (M == 0) return NVSF_OK;
     REQUIRE(grad_x && gx_stride >= 120 && gx_stride % 4 == 0 && (g_plane_half || g_plane_quarter || g_hash_s || g_hash_d_half || g_plane_s));
     const void* ptrs[] = {grad_x, g_plane_half, g_plane_quarter, g_hash_d_half, g_plane_s};
@@ -368,6 +368,7 @@ NVSF_API int nvsf_density_tail_grad_split(const float* grad_x, uint32_t gx_strid
     REQUIRE((reinterpret_cast<uintptr_t>(g_hash_s) & (hash_s_is_f16 ? 7u : 15u)) == 0);
     const uint32_t want = (M + 63u) / 64u;
     hipLaunchKernelGGL(k_density_tail_grad_split, dim3(want < 4096u ? want : 4096u), dim3(kBlock), 0, stream, grad_x, gx_stride, M,
-                       g_plane_half, g_plane_quarter, g_hash_s, hash_s_is_f16, g_hash_d_half, g_plane_s, hash_d_col_major, hash_s_level_major);
+                       g_plane_half, g_plane_quarter, g_hash_s, hash_s_is_f16, g_hash_d_half, g_plane_s, hash_d_col_major, hash_s_level_major,
+                       plane_half_scale);
     return nvsf_launch_status();
 }

@@ -436,6 +436,206 @@ __global__ __launch_bounds__(kBlock) void k_planes_bwd_runs(const float* __restr
         if (acc[j] != 0.0f) atomicAdd(g_planes + dst[j], acc[j]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward of SEVERAL evaluations of one position set in one launch (nvsf_planes_multi_bwd; the forward is k_planes_fwd_runs with the same
+// PlaneEvals): what a density query of the space-time field evaluates under autograd -- the static planes and the time planes at (x, t),
+// and the time planes at the flow-warped positions of the two neighbour frames (network_dynamic.py:220-271) -- used to be three
+// k_planes_bwd_runs launches (+ two coordinate-gradient launches) per ray batch.  Here the items of ALL evaluations are one launch:
+// item = (chunk of `run` rows, evaluation, scale), each walking its rows exactly as a k_planes_bwd_runs item does (same taps, same
+// products, same run sums: the same addends into the texels, in another order across items).  A first form that let one item walk
+// its group's evaluations in turn with ONE set of quad sums -- merging the neighbours' addends with the base evaluation's -- was
+// 25 % slower (5.4 against 3 x 1.44 ms per 3.1 M rows): three times longer items, a third of the parallelism.
+struct PlaneGradEvals {
+    const float* x;
+    uint32_t x_stride;
+    int n;
+    int grp[kMaxEval];
+    const float* off[kMaxEval];
+    uint32_t off_stride[kMaxEval], off_col[kMaxEval];
+    float t[kMaxEval];
+    const float* g[kMaxEval];      // gradient of the evaluation's features, rows of n_scales * 8 floats g_stride apart (nullptr: contributes nothing)
+    uint32_t g_stride[kMaxEval];   // ... a slice of a wider matrix is read in place (the density tail's input gradient)
+    float g_scale[kMaxEval];       // ... times this factor: the evaluations of a BLEND 0.5 d + 0.25 (d1 + d2) share one gradient (x 0.5, 0.25, 0.25)
+    float* g_off[kMaxEval];        // optional: receives d L / d offset (3 floats per row at column g_off_col, row stride g_off_stride)
+    uint32_t g_off_stride[kMaxEval], g_off_col[kMaxEval];
+};
+
+__device__ __forceinline__ float4 eval_position(const PlaneGradEvals& ev, int e, uint32_t m) {
+    const float* px = ev.x + (size_t)m * ev.x_stride;
+    float4 p = make_float4(px[0], px[1], px[2], ev.t[e]);
+    if (ev.off[e]) {
+        const float* po = ev.off[e] + (size_t)m * ev.off_stride[e] + ev.off_col[e];
+        p.x = p.x + po[0]; p.y = p.y + po[1]; p.z = p.z + po[2];  // fp32 adds, as torch.add forms x + flow
+    }
+    return p;
+}
+
+__global__ __launch_bounds__(kBlock) void k_planes_multi_bwd_runs(PlaneGradEvals ev, uint32_t M, const float* __restrict__ planes, PlaneMeta meta,
+                                                                  int live, float* __restrict__ g_planes, uint32_t run) {
+    __shared__ uint32_t s_taps[kBlock / 32][32][3][8];
+    const int lane = lane_id();
+    const int half = lane >> 5, k32 = lane & 31, tex = (lane >> 2) & 3, ch = (lane & 3) | ((lane >> 2) & 4);
+    // item = (chunk, live evaluation, scale), the scale fastest: the two halves of a wave (consecutive items, n_scales even) share the chunk
+    // AND the evaluation, whose constants are therefore wave-uniform (selected below by compares: a run-time index into the by-value
+    // struct would send it to scratch).  `live`: bit e set = evaluation e has a gradient.
+    const uint32_t n_live = (uint32_t)__builtin_popcount((unsigned)live);
+    const unsigned long long item = ((unsigned long long)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6)) * 2ull + (unsigned)half;
+    const uint32_t per_chunk = meta.n_scales * n_live;
+    const uint32_t chunk = (uint32_t)(item / per_chunk), rest = (uint32_t)(item - (unsigned long long)chunk * per_chunk);
+    const uint32_t slot = rest / meta.n_scales, s = rest - slot * meta.n_scales;
+    int grp = 0;
+    const float* gbase = nullptr;
+    const float* off = nullptr;
+    uint32_t off_stride = 0, off_col = 0, g_stride = 0;
+    float t_e = 0.0f, g_scale = 1.0f;
+    {
+        uint32_t seen = 0;
+#pragma unroll
+        for (int e = 0; e < kMaxEval; ++e) {
+            if (!((live >> e) & 1)) continue;
+            if (seen == slot) {
+                grp = ev.grp[e]; gbase = ev.g[e]; off = ev.off[e]; off_stride = ev.off_stride[e]; off_col = ev.off_col[e]; t_e = ev.t[e];
+                g_stride = ev.g_stride[e]; g_scale = ev.g_scale[e];
+            }
+            ++seen;
+        }
+    }
+    const unsigned long long first = (unsigned long long)chunk * run;
+    const bool active = first < M && gbase != nullptr;
+    const uint32_t m0 = active ? (uint32_t)first : 0u, m1 = active ? (uint32_t)(first + run < M ? first + run : M) : 0u;
+    const uint32_t ss = active ? s : 0u;
+    const uint32_t stride = g_stride;
+    const int pairs[3] = {grp == 0 ? 0 : 2, grp == 0 ? 1 : 4, grp == 0 ? 3 : 5};
+    uint32_t (*taps)[3][8] = s_taps[(threadIdx.x >> 5)];
+    float acc[3] = {0.0f, 0.0f, 0.0f};
+    uint32_t cur[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    uint32_t dst[3] = {0u, 0u, 0u};
+    const uint32_t n_rows = m1 - m0;
+    for (uint32_t r0 = 0; r0 < run; r0 += 32) {  // uniform trip count over the wave
+        {   // lane k32: taps of row r0 + k32 at the evaluation's own position (x + offset, t_e)
+            const uint32_t r = r0 + (uint32_t)k32;
+            const uint32_t m = r < n_rows ? m0 + r : (M - 1);
+            const float* px = ev.x + (size_t)m * ev.x_stride;
+            float p[4] = {px[0], px[1], px[2], t_e};
+            if (off) {
+                const float* po = off + (size_t)m * off_stride + off_col;
+                p[0] = p[0] + po[0]; p[1] = p[1] + po[1]; p[2] = p[2] + po[2];  // fp32 adds, as torch.add forms x + flow
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int a = kPa[pairs[j]], b = kPb[pairs[j]];
+                const Tap t = make_tap(p[a], p[b], meta.res[ss][a], meta.res[ss][b]);
+                uint32_t* o = taps[k32][j];
+                o[0] = __builtin_bit_cast(uint32_t, t.nw); o[1] = __builtin_bit_cast(uint32_t, t.ne);
+                o[2] = __builtin_bit_cast(uint32_t, t.sw); o[3] = __builtin_bit_cast(uint32_t, t.se);
+                o[4] = t.i00; o[5] = t.i01; o[6] = t.i10; o[7] = t.i11;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t k = 0; k < 32u; ++k) {
+            const uint32_t r = r0 + k;
+            const bool row_ok = r < n_rows;
+            const uint32_t m = row_ok ? m0 + r : (M - 1);
+            const float g = row_ok ? gbase[(size_t)m * stride + ss * kC + ch] * g_scale : 0.0f;  // (x 1 is exact: the unblended form is unchanged)
+            float v[3], w[3];
+            uint32_t idx[3], quad[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                w[j] = __builtin_bit_cast(float, taps[k][j][tex]);
+                idx[j] = taps[k][j][4 + tex];
+                quad[j] = taps[k][j][4];
+                float part = planes[meta.off[ss][pairs[j]] + (size_t)idx[j] * kC + ch] * w[j];
+                part += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part), 0x124 /* row_ror:4 */, 0xF, 0xF, false));
+                part += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part), 0x128 /* row_ror:8 */, 0xF, 0xF, false));
+                v[j] = part;
+            }
+            if (!row_ok) continue;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float gv = g * (v[(j + 1) % 3] * v[(j + 2) % 3]);
+                if (quad[j] != cur[j]) {
+                    if (acc[j] != 0.0f) atomicAdd(g_planes + dst[j], acc[j]);
+                    acc[j] = 0.0f;
+                    cur[j] = quad[j];
+                    dst[j] = meta.off[ss][pairs[j]] + idx[j] * kC + ch;
+                }
+                acc[j] += gv * w[j];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();  // the taps are overwritten by the next round
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        if (acc[j] != 0.0f) atomicAdd(g_planes + dst[j], acc[j]);
+}
+
+// d L / d (offset) of the evaluations that carry one (the flow towards the neighbour frames): thread = (row, evaluation); the arithmetic
+// of k_planes_bwd's coordinate half on the evaluation's own position (x + offset, t_e), time planes or static planes as the group says.
+__global__ __launch_bounds__(kBlock) void k_planes_multi_coord_bwd(PlaneGradEvals ev, uint32_t M, const float* __restrict__ planes, PlaneMeta meta) {
+    const uint32_t m = blockIdx.x * kBlock + threadIdx.x;
+    if (m >= M) return;
+    // the evaluation's constants selected by compares on blockIdx.y (no run-time index into the by-value struct)
+    int grp = 0;
+    const float* g_e = nullptr;
+    float* go_e = nullptr;
+    uint32_t go_stride = 0, go_col = 0, g_stride = 0;
+    float g_scale = 1.0f;
+    float4 p4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+    for (int e = 0; e < kMaxEval; ++e)
+        if ((int)blockIdx.y == e) {
+            grp = ev.grp[e]; g_e = ev.g[e]; go_e = ev.g_off[e]; go_stride = ev.g_off_stride[e]; go_col = ev.g_off_col[e];
+            g_stride = ev.g_stride[e]; g_scale = ev.g_scale[e];
+            if (g_e && go_e) p4 = eval_position(ev, e, m);
+        }
+    if (!g_e || !go_e) return;
+    const float p[4] = {p4.x, p4.y, p4.z, p4.w};
+    float gp[4] = {0, 0, 0, 0};
+    const uint32_t stride = g_stride;
+    const int pairs[3] = {grp == 0 ? 0 : 2, grp == 0 ? 1 : 4, grp == 0 ? 3 : 5};
+    for (uint32_t s = 0; s < meta.n_scales; ++s) {
+        const float* gout = g_e + (size_t)m * stride + s * kC;
+        Tap t[3];
+        float v[3][kC], dvx[3][kC], dvy[3][kC];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int a = kPa[pairs[j]], b = kPb[pairs[j]];
+            t[j] = make_tap(p[a], p[b], meta.res[s][a], meta.res[s][b]);
+            const float* plane = planes + meta.off[s][pairs[j]];
+            float tex00[kC], tex01[kC], tex10[kC], tex11[kC];
+            load_texel(plane, t[j].i00, tex00);
+            load_texel(plane, t[j].i01, tex01);
+            load_texel(plane, t[j].i10, tex10);
+            load_texel(plane, t[j].i11, tex11);
+            const float wx1 = t[j].ix_f - t[j].x0, wx0 = 1.0f - wx1, wy1 = t[j].iy_f - t[j].y0, wy0 = 1.0f - wy1;
+#pragma unroll
+            for (int k = 0; k < kC; ++k) {
+                v[j][k] = ((tex00[k] * t[j].nw + tex01[k] * t[j].ne) + tex10[k] * t[j].sw) + tex11[k] * t[j].se;
+                dvx[j][k] = (tex01[k] - tex00[k]) * wy0 + (tex11[k] - tex10[k]) * wy1;
+                dvy[j][k] = (tex10[k] - tex00[k]) * wx0 + (tex11[k] - tex01[k]) * wx1;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int q = pairs[j], a = kPa[q], b = kPb[q];
+            float dix = 0.0f, diy = 0.0f;
+#pragma unroll
+            for (int k = 0; k < kC; ++k) {
+                const float other = v[(j + 1) % 3][k] * v[(j + 2) % 3][k];
+                const float gv = (gout[k] * g_scale) * other;
+                dix += gv * dvx[j][k];
+                diy += gv * dvy[j][k];
+            }
+            gp[a] += dix * t[j].gx;
+            gp[b] += diy * t[j].gy;
+        }
+    }
+    float* o = go_e + (size_t)m * go_stride + go_col;
+    o[0] = gp[0]; o[1] = gp[1]; o[2] = gp[2];
+}
+
 int fill_plane_meta(PlaneMeta& meta, uint32_t n_scales, const uint32_t* h_res) {
     if (n_scales == 0 || n_scales > (uint32_t)kMaxScales || !h_res) return NVSF_ERR_INVALID_ARG;
     static const int pa[6] = {0, 0, 0, 1, 1, 2}, pb[6] = {1, 2, 3, 2, 3, 3};
@@ -536,6 +736,53 @@ NVSF_API int nvsf_planes_bwd(const float* xt, uint32_t M, const float* planes_cl
         const unsigned long long waves = (items + 1) / 2;
         hipLaunchKernelGGL(k_planes_bwd_runs, dim3((uint32_t)((waves + kBlock / kWave - 1) / (kBlock / kWave))), dim3(kBlock), 0, stream, xt, M,
                            planes_cl, meta, want, grad_static, grad_dynamic, grad_planes_cl, run);
+    }
+    return nvsf_launch_status();
+}
+
+NVSF_API int nvsf_planes_multi_bwd(const float* x, uint32_t x_stride, uint32_t M, const float* planes_cl, uint32_t n_scales, uint32_t C,
+                                   const uint32_t* h_res, uint32_t n_evals, const int* h_group, const float* const* h_offsets,
+                                   const uint32_t* h_offset_stride, const uint32_t* h_offset_col, const float* h_time,
+                                   const float* const* h_grad_out, const uint32_t* h_grad_stride, const float* h_grad_scale,
+                                   float* grad_planes_cl, float* const* h_grad_offsets, const uint32_t* h_grad_offset_stride,
+                                   const uint32_t* h_grad_offset_col, hipStream_t stream) {
+    if (M == 0 || n_evals == 0) return NVSF_OK;
+    REQUIRE(x && planes_cl && h_group && h_offsets && h_offset_stride && h_offset_col && h_time && h_grad_out && x_stride >= 3);
+    REQUIRE(n_evals <= (uint32_t)kMaxEval && (reinterpret_cast<uintptr_t>(planes_cl) & 15u) == 0);
+    if (C != (uint32_t)kC || n_scales != 4) return NVSF_ERR_UNSUPPORTED;
+    PlaneMeta meta;
+    const int st = fill_plane_meta(meta, n_scales, h_res);
+    if (st != NVSF_OK) return st;
+    PlaneGradEvals ev = {};
+    ev.x = x; ev.x_stride = x_stride; ev.n = (int)n_evals;
+    int groups = 0, any_coord = 0;
+    for (uint32_t e = 0; e < n_evals; ++e) {
+        REQUIRE(h_group[e] == 0 || h_group[e] == 1);
+        REQUIRE(!h_offsets[e] || h_offset_stride[e] >= h_offset_col[e] + 3);
+        ev.grp[e] = h_group[e]; ev.off[e] = h_offsets[e]; ev.off_stride[e] = h_offset_stride[e]; ev.off_col[e] = h_offset_col[e];
+        ev.t[e] = h_time[e]; ev.g[e] = h_grad_out[e];
+        ev.g_stride[e] = h_grad_stride ? h_grad_stride[e] : n_scales * (uint32_t)kC;
+        ev.g_scale[e] = h_grad_scale ? h_grad_scale[e] : 1.0f;
+        REQUIRE(!ev.g[e] || ev.g_stride[e] >= n_scales * (uint32_t)kC);
+        ev.g_off[e] = h_grad_offsets ? h_grad_offsets[e] : nullptr;
+        if (ev.g_off[e]) {
+            REQUIRE(h_grad_offset_stride && h_grad_offset_col && h_grad_offset_stride[e] >= h_grad_offset_col[e] + 3);
+            ev.g_off_stride[e] = h_grad_offset_stride[e]; ev.g_off_col[e] = h_grad_offset_col[e];
+            if (ev.g[e]) any_coord = 1;
+        }
+        if (ev.g[e]) groups |= 1 << h_group[e];
+    }
+    if (any_coord)
+        hipLaunchKernelGGL(k_planes_multi_coord_bwd, dim3(cdiv(M, kBlock), n_evals), dim3(kBlock), 0, stream, ev, M, planes_cl, meta);
+    if (grad_planes_cl && groups) {
+        const uint32_t run = 128u;
+        int live = 0;
+        for (uint32_t e = 0; e < n_evals; ++e)
+            if (ev.g[e]) live |= 1 << e;
+        const unsigned long long items = (unsigned long long)cdiv(M, run) * n_scales * (unsigned)__builtin_popcount((unsigned)live);
+        const unsigned long long waves = (items + 1) / 2;
+        hipLaunchKernelGGL(k_planes_multi_bwd_runs, dim3((uint32_t)((waves + kBlock / kWave - 1) / (kBlock / kWave))), dim3(kBlock), 0, stream, ev, M,
+                           planes_cl, meta, live, grad_planes_cl, run);
     }
     return nvsf_launch_status();
 }

@@ -46,7 +46,7 @@ SIGNATURES = {
     "nvsf_adam_update": [_P, _P, _P, _P, _U64, _F, _F, _F, _F, _P, _P, _P, _F, _P],
     "nvsf_ema_update": [_P, _P, _U64, _F],
     "nvsf_sigma_geo_bwd": [_P, _P, _P, _U, _U, _U, _P, _U, _F, _F],
-    "nvsf_density_tail_grad_split": [_P, _U, _U, _P, _P, _P, _I, _I, _P, _I, _P],
+    "nvsf_density_tail_grad_split": [_P, _U, _U, _P, _P, _P, _I, _I, _P, _I, _P, _F],
     "nvsf_cast_cols_f16": [_P, _I, _U, _U, _U, _P, _U],
     "nvsf_masked_sigmoid": [_P, _U, _U, _P, _U, _U, _P],
     "nvsf_sigmoid_bwd": [_P, _P, _U, _P],
@@ -61,6 +61,7 @@ SIGNATURES = {
     "nvsf_mlp_bwd_prefix": [_P, _U, _U, _U, _P, _U, _U, _U, _P, _U, _U, _U, _U, _P, _U, _U, _F, _P, _U, _P, _U, _I],
     "nvsf_planes_fwd": [_P, _U, _P, _U, _U, _P, _I, _P, _P],
     "nvsf_planes_multi_fwd": [_P, _U, _U, _P, _U, _U, _P, _U, _P, _P, _P, _P, _P, _P, _I],
+    "nvsf_planes_multi_bwd": [_P, _U, _U, _P, _U, _U, _P, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "nvsf_planes_bwd": [_P, _U, _P, _U, _U, _P, _I, _P, _P, _P, _P],
     "nvsf_hashgrid4d_dynamic_fwd": [_P, _U, _P, _U, _U, _U, _P, _P, _P, _P, _P, _I, _I, _P],
     "nvsf_hashgrid4d_dynamic3_fwd": [_P, _U, _P, _U, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P],

@@ -1055,6 +1055,156 @@ class PlanesFn(Function):
         return g_xt, g_planes, None, None, None
 
 
+def planes_multi_forward(x, evals, planes_cl, res_host, blend=False, out_f16=False):
+    """Several evaluations of ONE position set in one launch (nvsf_planes_multi_fwd): `evals` = [(group, offsets | None, offset_col, time)]
+    with group 0 = static / 1 = dynamic planes; returns the list of [M, n_scales * 8] feature matrices (fp32; blend: [static, blended
+    dynamic], fp16 rows with out_f16).  No autograd here: Planes4D.forward_multi (no-grad render) and PlanesMultiFn (training) call it."""
+    import ctypes
+    x = x.float()
+    if x.dim() != 2 or x.stride(1) != 1:
+        x = x.contiguous()
+    M, n = x.shape[0], len(evals)
+    S = len(res_host) // 4
+    width = S * 8
+    if out_f16 and not blend:
+        raise ValueError("planes_multi_forward: out_f16 needs blend=True")
+    outs = [torch.empty(M, width, dtype=torch.float16 if out_f16 else torch.float32, device=x.device) for _ in (evals[:2] if blend else evals)]
+    offs = []
+    for _, o, _, _ in evals:
+        if o is not None and (o.dtype != torch.float32 or o.dim() != 2 or o.stride(1) != 1):
+            o = o.float().contiguous()
+        offs.append(o)
+    _hip.call("nvsf_planes_multi_fwd", _hip.ptr_rows(x), x.stride(0), M, _hip.ptr(planes_cl), S, 8, _hip.host_u32(res_host), n,
+              _hip.host_i32([e[0] for e in evals]), (ctypes.c_void_p * n)(*[None if o is None else o.data_ptr() for o in offs]),
+              _hip.host_u32([0 if o is None else o.stride(0) for o in offs]), _hip.host_u32([e[2] for e in evals]),
+              _hip.host_f32([e[3] for e in evals]), (ctypes.c_void_p * n)(*([t.data_ptr() for t in outs] + [None] * (n - len(outs)))),
+              (2 if out_f16 else 1) if blend else 0)
+    return outs
+
+
+class PlanesMultiFn(Function):
+    """What one density query of the space-time field evaluates on its K-planes, as ONE autograd node (network_dynamic.py:220-271):
+    (x [M, 3], flow [M, 6] | None, planes_cl) -> (static at x, dynamic at (x, t), dynamic at (x + flow[:, :3], t1), dynamic at
+    (x + flow[:, 3:], t2)); a neighbour whose time is None is absent (its output is an empty tensor).
+    `blend`: the second output is the neighbour blend 0.5 d + 0.25 (d1 + d2) of network_dynamic.py:273 itself (formed inside the forward
+    kernel, an absent neighbour being the base evaluation as in the reference) and the other two outputs are empty: half the feature
+    matrices written, ONE gradient read by the three dynamic evaluations (x 0.5, 0.25, 0.25).
+    Forward = nvsf_planes_multi_fwd (one launch, bit-identical to one PlanesFn per evaluation); backward = nvsf_planes_multi_bwd: ONE
+    texel-scatter launch for all evaluations (on the training step's side stream, into its gradient sink, like PlanesFn's) and ONE
+    launch for the gradients of the two flow offsets; gradients that arrive as column slices of a wider matrix (the density tail's input
+    gradient) are read in place.  Replaces three PlanesFn nodes per ray batch: three forward, three scatter and two coordinate-gradient
+    launches, the [M, 4] position copies of the neighbours and their time columns."""
+
+    @staticmethod
+    def forward(ctx, x, flow, planes_cl, res_host, t0, t1, t2, train_ctx, blend=False):
+        x = x.float()
+        if x.dim() != 2 or x.stride(1) != 1:
+            x = x.contiguous()
+        cl = planes_cl.detach()
+        if cl.dtype != torch.float32 or not cl.is_contiguous():
+            cl = cl.float().contiguous()
+        fl = None
+        if flow is not None:
+            fl = flow.detach().float()
+            if fl.dim() != 2 or fl.stride(1) != 1:
+                fl = fl.contiguous()
+        base = (1, None, 0, float(t0))
+        evals = [(0, None, 0, float(t0)), base]
+        slots = [0, 1]
+        for slot, (tn, col) in enumerate(((t1, 0), (t2, 3)), start=2):
+            if tn is not None:
+                if fl is None:
+                    raise ValueError("PlanesMultiFn: a neighbour evaluation needs the flow offsets")
+                evals.append((1, fl, col, float(tn)))
+                slots.append(slot)
+            elif blend:  # the reference's plane_feat_1 = plane_feat_d for a frame without that neighbour
+                evals.append(base)
+                slots.append(slot)
+        outs = planes_multi_forward(x, evals, cl, res_host, blend=bool(blend))
+        ctx.save_for_backward(x, cl) if fl is None else ctx.save_for_backward(x, cl, fl)
+        ctx.evals_meta = [(e[0], e[2], e[3], e[1] is not None) for e in evals]
+        ctx.slots, ctx.res_host, ctx.blend = slots, res_host, bool(blend)
+        ctx.train_ctx, ctx.planes_param = train_ctx, planes_cl
+        if train_ctx is not None and isinstance(planes_cl, torch.nn.Parameter) and planes_cl.requires_grad and torch.is_grad_enabled():
+            train_ctx.expect(planes_cl)
+        full = [x.new_zeros(0)] * 4
+        for slot, o in zip(slots, outs):  # (blend: two outputs)
+            full[slot] = o
+        return tuple(full)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        import ctypes
+        saved = ctx.saved_tensors
+        x, cl = saved[0], saved[1]
+        fl = saved[2] if len(saved) > 2 else None
+        M, S = x.shape[0], len(ctx.res_host) // 4
+        need_flow, need_p = ctx.needs_input_grad[1] and fl is not None, ctx.needs_input_grad[2]
+        n = len(ctx.evals_meta)
+
+        def rows(t):  # fp32 rows with unit column stride are read where they are (a slice of the density tail's input gradient)
+            if t is None:
+                return None
+            if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 or t.stride(0) < t.shape[1]:
+                t = t.float().contiguous()
+            return t
+        if ctx.blend:
+            g_s, g_b = rows(grads[0]), rows(grads[1])
+            g = [g_s] + [g_b] * (n - 1)
+            scales = [1.0, 0.5] + [0.25] * (n - 2)
+        else:
+            g = [rows(grads[slot]) for slot in ctx.slots]
+            scales = [1.0] * n
+        res = _hip.host_u32(ctx.res_host)
+        groups = _hip.host_i32([m[0] for m in ctx.evals_meta])
+        has_off = [m[3] for m in ctx.evals_meta]
+        offs = (ctypes.c_void_p * n)(*[fl.data_ptr() if has_off[i] else None for i in range(n)])
+        off_stride = _hip.host_u32([fl.stride(0) if has_off[i] else 0 for i in range(n)])
+        off_col = _hip.host_u32([m[1] for m in ctx.evals_meta])
+        times = _hip.host_f32([m[2] for m in ctx.evals_meta])
+        g_ptrs = (ctypes.c_void_p * n)(*[None if t is None else t.data_ptr() for t in g])
+        g_strides = _hip.host_u32([S * 8 if t is None else t.stride(0) for t in g])
+        g_scales = _hip.host_f32(scales)
+
+        def launch(g_planes, g_flow):
+            if g_flow is not None:
+                go = (ctypes.c_void_p * n)(*[g_flow.data_ptr() if has_off[i] else None for i in range(n)])
+                gs = _hip.host_u32([g_flow.stride(0) if has_off[i] else 0 for i in range(n)])
+                gc = _hip.host_u32([ctx.evals_meta[i][1] if has_off[i] else 0 for i in range(n)])
+            else:
+                go = gs = gc = None
+            _hip.call("nvsf_planes_multi_bwd", _hip.ptr_rows(x), x.stride(0), M, _hip.ptr(cl), S, 8, res, n, groups, offs, off_stride, off_col, times,
+                      g_ptrs, g_strides, g_scales, _hip.ptr(g_planes), go, gs, gc)
+        g_flow = None
+        if need_flow:
+            # columns of an absent neighbour, or of one whose features received no gradient, stay zero
+            complete = sum(has_off) == 2 and all(g[i] is not None for i in range(n) if has_off[i])
+            g_flow = (torch.empty if complete else torch.zeros)(M, 6, dtype=torch.float32, device=x.device)
+        tctx, param = ctx.train_ctx, ctx.planes_param
+        sink_ok = (need_p and tctx is not None and tctx.sink is not None and isinstance(param, torch.nn.Parameter) and param.is_cuda
+                   and param.dtype == torch.float32)
+        none = (None,) * 6
+        if sink_ok and tctx.overlap:
+            if g_flow is not None:
+                launch(None, g_flow)  # what the flow field's backward waits for: on this stream
+            tensors = tuple(t for t in (x, cl, fl, *g) if t is not None)
+            if scatter_beside_backward(tctx, param, tensors, lambda view, pool: launch(view, None)):
+                return (None, g_flow, None) + none
+            raise _hip.NvsfHipError("PlanesMultiFn: the step's gradient sink refused the planes parameter")
+        if sink_ok:
+            last = tctx.done(param)
+            launch(tctx.sink.view_for(param), g_flow)
+            if last:
+                tctx.sink.mark_ready(param)
+            return (None, g_flow, None) + none
+        if tctx is not None and isinstance(param, torch.nn.Parameter):
+            tctx.done(param)
+        g_planes = torch.zeros_like(cl) if need_p else None
+        if g_planes is not None or g_flow is not None:
+            launch(g_planes, g_flow)
+        return (None, g_flow, g_planes) + none
+
+
 # ------------------------------------------------------------------------------------------------
 # uniform sampler / compositor (renderer_dynamic.py:155-237)
 # ------------------------------------------------------------------------------------------------

@@ -93,8 +93,23 @@ class NeRFNetwork(NeRFRenderer):
             return self._dynamic_features_fused(x, t, t_host, frame_idx, hash_enc, planes_enc, fp16)
         t_col = t.repeat(x.shape[0], 1) if t.shape[0] == 1 else t
         xt = torch.cat([x, t_col], dim=-1)
-        plane_s, plane_d = planes_enc(xt)
         flow = self.flow_net(xt, t_host, fp16=fp16)
+        # the K-planes of the query -- static + dynamic at (x, t), dynamic at the two flow-warped neighbour positions -- as ONE autograd node
+        # (ops.PlanesMultiFn: one forward launch, one texel-scatter launch, one launch for the flow gradients) where it is built
+        planes_node = (torch.is_grad_enabled() and testing.get("planes_train") == "fused" and x.is_cuda and t.shape[0] == 1
+                       and len(planes_enc.multiscale_res) == 4 and not x.requires_grad)
+        nb_time = [float(np.float32(f / self.num_frames)) if 0 <= f <= self.num_frames - 1 else None for f in (frame_idx + 1, frame_idx - 1)]
+        if planes_node:
+            planes_enc.wait_pending_update()
+            # where the fused density tail consumes them, the three dynamic evaluations leave the node already blended (0.5 d + 0.25 (d1 +
+            # d2), network_dynamic.py:273): the tail's own blend of (v, v, v) is v exactly, its gradient comes back as one slice
+            planes_blend = self._tail_fused_in_training()
+            plane_s, plane_d, pm_1, pm_2 = ops.PlanesMultiFn.apply(x, flow, planes_enc.planes_cl, planes_enc._res_host, float(np.float32(t_host)),
+                                                                   nb_time[0], nb_time[1], ops.train_context(planes_enc), planes_blend)
+            if planes_blend:
+                pm_1 = pm_2 = plane_d
+        else:
+            plane_s, plane_d = planes_enc(xt)
         fused3 = hash_enc.training_fused3(x, t, t_host, flow, frame_idx, self.num_frames)
         if fused3 is not None:
             # level-major [8, M, 4] where the fused density tail (DensityTailFn) will take it: `density` turns it back into rows otherwise
@@ -105,13 +120,15 @@ class NeRFNetwork(NeRFRenderer):
 
         def neighbour(offset, frame):
             """dynamic features at the flow-warped position in an adjacent frame (:242-271)"""
-            xn = x + offset
             tn = torch.tensor(frame / self.num_frames)
+            xn = None if (fused3 is not None and planes_node) else x + offset  # (both fused nodes read x + flow inside their kernels)
             if fused3 is not None:
                 hn = hash_1f if frame > frame_idx else hash_2f
             else:
                 with torch.no_grad():
                     hn = hash_enc.forward_dynamic(xn, tn, float(np.float32(frame / self.num_frames)))
+            if planes_node:
+                return hn, (pm_1 if frame > frame_idx else pm_2)
             # the reference builds this column on the host and copies it (t1.repeat(N, 1).to(device), :250): a pageable
             # multi-megabyte H2D copy that also drains the stream; the same fp32 value is written on the device instead
             t_coln = torch.full((xn.shape[0], 1), float(tn), dtype=torch.float32, device=xn.device)
@@ -288,6 +305,9 @@ class DensityTailFn(torch.autograd.Function):
         ctx.spec = net.sigma_net.spec
         ctx.hash_s_dtype = hash_s.dtype
         ctx.hash_s_lm = hash_s.dim() == 3
+        # (plane_d, plane_1, plane_2) one tensor = the blend formed by its producer (ops.PlanesMultiFn(blend=True)): 0.5 v + 0.25 (v + v) = v,
+        # and the gradient of that one tensor is the whole slice g[:, 32:64], unscaled (nvsf_density_tail_grad_split(plane_half_scale = 1))
+        ctx.planes_blended = plane_1 is plane_d and plane_2 is plane_d
         return sigma, h[:, 1:net.sigma_net.spec.n_out]
 
     @staticmethod
@@ -320,8 +340,9 @@ class DensityTailFn(torch.autograd.Function):
             # the blend factors and the dtype of hash_s applied in ONE pass over the rows (nvsf_density_tail_grad_split)
             dev = grad_x.device
             f32 = dict(dtype=torch.float32, device=dev)
+            blended = ctx.planes_blended and need[2]   # one tensor for (plane_d, plane_1, plane_2): its gradient is the whole slice, unscaled
             g_half = torch.empty(M, 32, **f32) if need[2] else None
-            g_quarter = torch.empty(M, 32, **f32) if (need[3] or need[4]) else None
+            g_quarter = torch.empty(M, 32, **f32) if ((need[3] or need[4]) and not blended) else None
             g_hs = None
             if need[5] and ctx.hash_s_dtype in (torch.float16, torch.float32):  # in hash_s's own layout: rows [M, 32] or level-major [8, M, 4]
                 g_hs = torch.empty((8, M, 4) if ctx.hash_s_lm else (M, 32), dtype=ctx.hash_s_dtype, device=dev)
@@ -332,11 +353,11 @@ class DensityTailFn(torch.autograd.Function):
             if g_half is not None or g_quarter is not None or g_hs is not None or g_hd is not None or g_ps is not None:
                 _hip.call("nvsf_density_tail_grad_split", _hip.ptr(grad_x), grad_x.stride(0), M, _hip.ptr(g_half), _hip.ptr(g_quarter), _hip.ptr(g_hs),
                           1 if ctx.hash_s_dtype == torch.float16 else 0, 1 if ctx.hash_s_lm else 0, None if g_hd is None else g_hd.data_ptr(), 1,
-                          _hip.ptr(g_ps))
+                          _hip.ptr(g_ps), 1.0 if blended else 0.5)
             out[1], out[2], out[6] = g_ps, g_half, g_hd
-            if need[3]:
+            if need[3] and not blended:
                 out[3] = g_quarter
-            if need[4]:
+            if need[4] and not blended:
                 out[4] = g_quarter
             if need[5]:
                 out[5] = g_hs if g_hs is not None else DensityTailFn._hash_s_grad(ctx, grad_x)

@@ -123,28 +123,7 @@ class Planes4D(nn.Module):
         neighbour 2) and the result is [static, 0.5 d + 0.25 (d1 + d2)] (the blend of network_dynamic.py:273, formed in the kernel:
         the neighbour features never reach memory).  out_f16 (with blend): the two results as fp16 rows, rounded as the density
         kernel rounds its inputs (nvsf_density_dynamic_f16planes_fwd reads them)."""
-        import ctypes
-        from nvsf import _hip
-        x = x.float()
-        if x.dim() != 2 or x.stride(1) != 1:
-            x = x.contiguous()
-        M, n = x.shape[0], len(evals)
-        width = self.n_output_dims // 2
-        if out_f16 and not blend:
-            raise ValueError("forward_multi: out_f16 needs blend=True")
-        outs = [torch.empty(M, width, dtype=torch.float16 if out_f16 else torch.float32, device=x.device) for _ in (evals[:2] if blend else evals)]
-        offs = []
-        for _, o, _, _ in evals:
-            if o is not None and (o.dtype != torch.float32 or o.dim() != 2 or o.stride(1) != 1):
-                o = o.float().contiguous()
-            offs.append(o)
-        _hip.call("nvsf_planes_multi_fwd", _hip.ptr_rows(x), x.stride(0), M, _hip.ptr(self._channel_last()), len(self.multiscale_res), 8,
-                  _hip.host_u32(self._res_host), n, _hip.host_i32([e[0] for e in evals]),
-                  (ctypes.c_void_p * n)(*[None if o is None else o.data_ptr() for o in offs]),
-                  _hip.host_u32([0 if o is None else o.stride(0) for o in offs]), _hip.host_u32([e[2] for e in evals]),
-                  _hip.host_f32([e[3] for e in evals]), (ctypes.c_void_p * n)(*([t.data_ptr() for t in outs] + [None] * (n - len(outs)))),
-                  (2 if out_f16 else 1) if blend else 0)
-        return outs
+        return ops.planes_multi_forward(x, evals, self._channel_last(), self._res_host, blend=blend, out_f16=out_f16)
 
     def forward_static(self, input):
         return self._encode(input, 1)

@@ -33,6 +33,7 @@ _PYTHON = {
     "dynamic_fused": (True, False),             # network_dynamic no-grad feature path: fused launches / operator calls
     "density_tail_train": ("fused", "chain"),   # network_dynamic.density with autograd: DensityTailFn / torch blend + cat + MLP
     "density_fn": ("fused", "chain"),           # network_static.density: DensityFn / encoder -> MLP -> trunc_exp modules
+    "planes_train": ("fused", "separate"),       # network_dynamic training features: ONE K-planes node for a density query / one PlanesFn per evaluation
     "density_grad": ("composed", "matrix"),      # field_ops._density_backward: logit gradient formed inside the MLP backward / nvsf_sigma_geo_bwd pass
     "table_scatter": ("binned", "atomic"),      # field_ops._bin_from: binned fine levels where they pay / every level through nvsf_hashgrid_bwd
 }

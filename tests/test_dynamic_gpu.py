@@ -774,3 +774,84 @@ def test_dynamic_hash_gradient_through_lds_keeps_non_finite_gradients(dev, poiso
     lvl = lambda p, l: sums[p][specs[p].offsets[l]:specs[p].offsets[l + 1]]
     assert not torch.isfinite(lvl(1, 3)).all() and not torch.isfinite(lvl(2, 5)).all()
     assert torch.isfinite(sums[0]).all() and torch.isfinite(lvl(1, 2)).all() and torch.isfinite(lvl(2, 4)).all()
+
+
+@pytest.mark.parametrize("M,neighbours", [(29 * 211, (True, True)), (5000, (True, False)), (300, (False, True)), (64 * 130 + 7, (False, False))])
+def test_planes_multi_node_equals_one_node_per_evaluation(dev, M, neighbours):
+    """ops.PlanesMultiFn (round 5: the K-planes of one density query as ONE autograd node -- nvsf_planes_multi_fwd / nvsf_planes_multi_bwd)
+    against one PlanesFn per evaluation, which is pinned by the reference's autograd (test_planes4d_forward_backward): features bit for
+    bit, the gradient of the flow offsets bit for bit (same arithmetic per row), texel gradients up to the order of the fp32 additions
+    (the fused scatter merges the evaluations' addends of one texel quad); first / last frame (a neighbour absent) and no neighbour at all."""
+    from nvsf import field_ops as ops
+    from nvsf.nerf.models.planes_field import Planes4D
+    rng = np.random.default_rng(M)
+    n_rays = max(1, M // 211)
+    o = rng.random((n_rays, 1, 3)) * 0.4 + 0.3
+    d = rng.standard_normal((n_rays, 1, 3))
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    x_np = np.clip(o + d * np.linspace(0, 0.3, 211).reshape(1, 211, 1), 0, 1).reshape(-1, 3)
+    x_np = np.concatenate([x_np, rng.random((M - x_np.shape[0], 3))])[:M].astype(np.float32)
+    t0, t1, t2 = 0.37, 0.37 + 1 / 64, 0.37 - 1 / 64
+    torch.manual_seed(0)
+    enc = Planes4D(resolution=[32, 32, 32, 8], multiscale_res=[1, 2, 4, 8]).to(dev)
+    with torch.no_grad():
+        enc.planes_cl.add_(torch.randn_like(enc.planes_cl) * 0.1)   # time planes away from their all-ones initialisation
+    x = _t(x_np, dev)
+    flow0 = _t((rng.standard_normal((M, 6)) * 3e-3).astype(np.float32), dev)
+    gen = torch.Generator().manual_seed(1)
+    w = [torch.randn(M, 32, generator=gen).to(dev) for _ in range(4)]
+    # ---- one PlanesFn per evaluation (the form of rounds 1-4)
+    flow_a = flow0.clone().requires_grad_()
+    enc.planes_cl.grad = None
+    col = lambda v: torch.full((M, 1), v, dtype=torch.float32, device=dev)
+    s_a, d_a = enc(torch.cat([x, col(t0)], -1))
+    outs_a = [s_a, d_a]
+    if neighbours[0]:
+        outs_a.append(enc.forward_dynamic(torch.cat([x + flow_a[:, :3], col(t1)], -1)))
+    if neighbours[1]:
+        outs_a.append(enc.forward_dynamic(torch.cat([x + flow_a[:, 3:], col(t2)], -1)))
+    sum((o_ * w_).sum() for o_, w_ in zip(outs_a, w)).backward()
+    gp_a = enc.planes_cl.grad.detach().clone()
+    gf_a = flow_a.grad.detach().clone() if flow_a.grad is not None else torch.zeros_like(flow0)
+    # ---- one node
+    flow_b = flow0.clone().requires_grad_()
+    enc.planes_cl.grad = None
+    full = ops.PlanesMultiFn.apply(x, flow_b, enc.planes_cl, enc._res_host, float(np.float32(t0)), float(np.float32(t1)) if neighbours[0] else None,
+                                   float(np.float32(t2)) if neighbours[1] else None, None)
+    outs_b = [full[0], full[1]] + ([full[2]] if neighbours[0] else []) + ([full[3]] if neighbours[1] else [])
+    assert (full[2].numel() > 0) == neighbours[0] and (full[3].numel() > 0) == neighbours[1]
+    for a, b in zip(outs_a, outs_b):
+        assert torch.equal(a.detach(), b.detach())
+    sum((o_ * w_).sum() for o_, w_ in zip(outs_b, w)).backward()
+    gp_b = enc.planes_cl.grad.detach().clone()
+    gf_b = flow_b.grad.detach().clone() if flow_b.grad is not None else torch.zeros_like(flow0)
+    assert torch.equal(gf_a, gf_b)
+    if any(neighbours):
+        assert float(gf_a.abs().max()) > 0
+    scale = float(gp_a.abs().max())
+    assert scale > 0 and float((gp_a - gp_b).abs().max()) <= 2e-5 * scale
+    # ---- the blended form (what the fused density tail consumes): second output = 0.5 d + 0.25 (d1 + d2), an absent neighbour = the base
+    # evaluation (network_dynamic.py:240-273); its gradient arrives as a column slice of a wider matrix and is read in place
+    flow_c = flow0.clone().requires_grad_()
+    enc.planes_cl.grad = None
+    d1 = outs_a[2] if neighbours[0] else d_a
+    d2 = outs_a[-1] if neighbours[1] else d_a
+    blend_ref = (0.5 * d_a + 0.25 * (d1 + d2)).detach()
+    wide = torch.randn(M, 120, generator=gen).to(dev)   # "the density tail's input gradient": plane_s | plane_d slices
+    full = ops.PlanesMultiFn.apply(x, flow_c, enc.planes_cl, enc._res_host, float(np.float32(t0)), float(np.float32(t1)) if neighbours[0] else None,
+                                   float(np.float32(t2)) if neighbours[1] else None, None, True)
+    assert full[2].numel() == 0 and full[3].numel() == 0
+    assert torch.equal(full[0].detach(), s_a.detach()) and torch.equal(full[1].detach(), blend_ref)
+    torch.autograd.backward([full[0], full[1]], [wide[:, 0:32], wide[:, 32:64]])
+    gp_c, gf_c = enc.planes_cl.grad.detach().clone(), (flow_c.grad.detach().clone() if flow_c.grad is not None else torch.zeros_like(flow0))
+    # reference: the same loss through one PlanesFn per evaluation and torch's blend
+    flow_d = flow0.clone().requires_grad_()
+    enc.planes_cl.grad = None
+    s_d, d_d = enc(torch.cat([x, col(t0)], -1))
+    e1 = enc.forward_dynamic(torch.cat([x + flow_d[:, :3], col(t1)], -1)) if neighbours[0] else d_d
+    e2 = enc.forward_dynamic(torch.cat([x + flow_d[:, 3:], col(t2)], -1)) if neighbours[1] else d_d
+    ((s_d * wide[:, 0:32]).sum() + ((0.5 * d_d + 0.25 * (e1 + e2)) * wide[:, 32:64]).sum()).backward()
+    gp_d, gf_d = enc.planes_cl.grad.detach().clone(), (flow_d.grad.detach().clone() if flow_d.grad is not None else torch.zeros_like(flow0))
+    assert torch.equal(gf_c, gf_d)   # (0.25 g) * ... in the kernel, 0.25 * g by autograd: the same fp32 products
+    scale = float(gp_d.abs().max())
+    assert scale > 0 and float((gp_c - gp_d).abs().max()) <= 2e-5 * scale

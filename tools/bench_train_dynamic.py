@@ -17,6 +17,9 @@ batch = {"rays_o_lidar": torch.from_numpy(lo).to(dev)[None], "rays_d_lidar": tor
          "rays_o": torch.from_numpy(co).to(dev)[None], "rays_d": torch.from_numpy(cd).to(dev)[None], "time": torch.tensor([[0.5]], device=dev),
          "gt_depth": torch.rand(1, N, generator=g).to(dev) * 0.5, "gt_raydrop": (torch.rand(1, N, generator=g) > 0.3).float().to(dev),
          "gt_intensity": torch.rand(1, N, generator=g).to(dev), "gt_rgb": torch.rand(1, N, 3, generator=g).to(dev)}
+if os.environ.get("PT"):  # fused / separate: the K-planes of a density query as one autograd node or one per evaluation
+    from nvsf import testing as _testing
+    _cp = _testing.variant(planes_train=os.environ["PT"]); _cp.__enter__()
 step = RenderTrainStep(m, num_steps=T, scale=S.SCALE)
 for _ in range(2): step.step(batch)
 torch.cuda.synchronize(); t0 = time.perf_counter()
