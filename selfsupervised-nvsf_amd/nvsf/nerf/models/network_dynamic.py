@@ -329,12 +329,20 @@ class DensityTailFn(torch.autograd.Function):
             g_sigma = g_sigma.float().contiguous()
         if g_geo is not None and (g_geo.dtype != torch.float32 or g_geo.stride(1) != 1):
             g_geo = g_geo.float().contiguous()
-        grad_h = torch.empty(M, 16, dtype=torch.float32, device=x16.device)
-        _hip.call("nvsf_sigma_geo_bwd", None if g_sigma is None else _hip.ptr(g_sigma), _hip.ptr(sigma),
-                  None if g_geo is None else _hip.ptr_rows(g_geo), 0 if g_geo is None else g_geo.stride(0), spec.n_out - 1, M,
-                  _hip.ptr(grad_h), 16, activation._LO, activation._HI)
-        grad_h = grad_h[:, :spec.n_out]
-        grad_x, gw = ops.mlp_backward(x16[:, :spec.n_in], w16, spec, grad_h, need_grad_x=need_x)
+        # the logit gradient formed inside the MLP backward where the pieces have the layout it reads (nvsf_mlp_bwd_density, as the static
+        # field's node does), else by a pass of its own
+        parts = None
+        if testing.get("density_grad") == "composed" and x16.is_cuda:
+            parts = ops.density_logit_gradient_parts(g_sigma, sigma, g_geo, None, spec.n_out - 1, (activation._LO, activation._HI))
+        if parts is not None:
+            grad_x, gw = ops.mlp_backward(x16[:, :spec.n_in], w16, spec, None, need_grad_x=need_x, density_grad=parts)
+        else:
+            grad_h = torch.empty(M, 16, dtype=torch.float32, device=x16.device)
+            _hip.call("nvsf_sigma_geo_bwd", None if g_sigma is None else _hip.ptr(g_sigma), _hip.ptr(sigma),
+                      None if g_geo is None else _hip.ptr_rows(g_geo), 0 if g_geo is None else g_geo.stride(0), spec.n_out - 1, M,
+                      _hip.ptr(grad_h), 16, activation._LO, activation._HI)
+            grad_h = grad_h[:, :spec.n_out]
+            grad_x, gw = ops.mlp_backward(x16[:, :spec.n_in], w16, spec, grad_h, need_grad_x=need_x)
         out = [None] * 10
         if need_x and grad_x.is_cuda and grad_x.stride(1) == 1 and grad_x.stride(0) % 4 == 0 and grad_x.shape[1] >= 120:
             # the blend factors and the dtype of hash_s applied in ONE pass over the rows (nvsf_density_tail_grad_split)

@@ -247,11 +247,13 @@ def test_fused_dynamic_features_equal_the_separate_launches(dev, flow_scale, t_v
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("logit_grad", ["composed", "matrix"])  # formed inside the MLP backward (production) / by nvsf_sigma_geo_bwd
 @pytest.mark.parametrize("t_val", [0.4, 0.0])  # interior frame (two neighbours) / first frame (one neighbour aliases the current frame)
-def test_density_tail_training_path_equals_the_operator_path(dev, t_val, variants):
+def test_density_tail_training_path_equals_the_operator_path(dev, t_val, logit_grad, variants):
     """DensityTailFn (blend + concatenation + density MLP in one forward launch, fused MLP backward, gradient handed back per
     input with the blend factors) against the operator path (torch blends, torch.cat, tcnn.Network autograd): density outputs
     and every parameter gradient of a density query."""
+    variants.set(density_grad=logit_grad)
     from nvsf.nerf.models.network_dynamic import NeRFNetwork
     x = (torch.rand(6000, 3, generator=torch.Generator().manual_seed(1)) * 2 - 1).to(dev) * 1.9
     t = torch.tensor([[t_val]], device=dev)

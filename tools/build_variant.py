@@ -1,0 +1,22 @@
+"""Experiment helper: a copy of the library with ONE translation unit compiled with extra -D flags.
+
+    python tools/build_variant.py fused_field.hip lib_exp/aux2.so -DNVSF_FINE_AUX=2
+
+The production library is built first (build.py); the variant re-uses its objects.  For tools/ab_run.sh / ab_headline.sh.
+"""
+import os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "selfsupervised-nvsf_amd"))
+import build as B
+
+unit, out, defines = sys.argv[1], os.path.join(ROOT, sys.argv[2]), sys.argv[3:]
+B.build()
+hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+srcs = B.sources()
+src = [s for s in srcs if os.path.basename(s) == unit][0]
+os.makedirs(os.path.dirname(out), exist_ok=True)
+obj = out + ".o"
+subprocess.run([hipcc] + [f for f in B.FLAGS if f != "-shared"] + defines + ["-c", src, "-o", obj], check=True)
+subprocess.run([hipcc, "-shared", "-fPIC", f"--offload-arch={B.ARCH}", "-fvisibility=hidden"] + [obj if s == src else B._obj(s) for s in srcs] + ["-o", out], check=True)
+os.remove(obj)
+print(out)
