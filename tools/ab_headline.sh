@@ -6,6 +6,6 @@ for i in $(seq 1 ${3:-3}); do
     cp $R/$v $L
     python $R/bench.py --no-extra-legs --train-steps 0 --cpu-rays 0 --steps 200 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', round(d['ms_per_step'],4), [round(r['ms'],4) for r in d['kernels'][:3]])"
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', round(d['ms_per_step'],4), [round(r[1],4) for r in d['kernels'][:3]])"
   done
 done

@@ -9,5 +9,5 @@ python - <<PY
 import json
 l=[x for x in open("gpurun_out/b1.log") if x.startswith("{")][-1]
 d=json.loads(l)
-print(d["value"], d["ms_per_step"], [(k["kernel"], round(k["ms"],4)) for k in d["kernels"]])
+print(d["value"], d["ms_per_step"], [(k[0], round(k[1],4)) for k in d["kernels"]])
 PY
