@@ -41,7 +41,8 @@ const char* nvsf_build_digest(int which);
 
 /* TEST-ONLY: selects a second formulation of an operator -- the one the tests pin the production form against -- for every later
  * call of this process: name in {"march", "planes_fwd", "planes_bwd", "hashgrid_fwd", "hashgrid_bwd", "hash4d_bwd", "slice_plan",
- * "render_tail"}, value 0 = the production form (the default), 1 (march: 1, 2) = the reference form.  Returns the previous value,
+ * "render_tail", "march_skew", "mlp_bwd", "level_kinds"}, value 0 = the production form (the default), 1 (march: 1, 2; march_skew:
+ * 1 .. 8; mlp_bwd: 1, 2) = the reference form.  Returns the previous value,
  * or NVSF_ERR_INVALID_ARG.  Not thread-safe; results of either form are the same operator's (bit-identical or within the
  * tolerances stated in tests/).  No stream argument: nothing is launched. */
 int nvsf_test_variant(const char* name, int value);

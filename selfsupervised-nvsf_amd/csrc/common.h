@@ -35,6 +35,7 @@ enum NvsfVariantKey : int {
     kVarRenderTail,     // 0 two tiles per iteration, 1 one tile
     kVarMarchSkew,      // one-launch marcher: 0 off, q + 1 = the workgroups of ticket queue q start late (the other queues steal from it)
     kVarMlpBwd,         // nvsf_mlp_bwd: 0 by shape (wave-independent kernel, transposes on the matrix core; LDS-staged kernel for 32-64-16), 1 staged, 2 wave
+    kVarLevelKinds,     // gathering render kernels on the config-2 grid: 0 the instance with the level kinds compiled in, 1 the general one
     kVarCount
 };
 int nvsf_variant(int key);

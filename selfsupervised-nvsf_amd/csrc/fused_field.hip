@@ -166,7 +166,11 @@ struct DensityCtx {
 
 // One 16-sample tile: hash-grid encode of x in [0,1]^3 (per lane) -> this lane's B fragment of the sigma MLP
 // (levels {g, g+4, g+8, g+12} of sample lane & 15).
-template <int F, int QG, bool LDS_LV = false>
+constexpr uint32_t kFirstHashedC2 = 5;  // L16 F2 T2^19 base 16 -> 2048: 81^3 > 2^19
+// FH >= 0: the first hashed level as a compile-time constant (the launcher picks the instance of the grid at hand): the kind of every
+// level group -- dense, hashed, mixed -- is then known per unrolled q, the other index form and its selects are not compiled in, and the
+// four groups form one basic block.  FH < 0: the run-time value (cx.first_hashed), any grid.
+template <int F, int QG, bool LDS_LV = false, int FH = -1>
 __device__ __forceinline__ half8_t density_encode(const DensityCtx<F>& cx, const float (&x)[3]) {
     constexpr int Q = 8 / F;
     LaneLevels<F> lv_local;
@@ -184,7 +188,7 @@ __device__ __forceinline__ half8_t density_encode(const DensityCtx<F>& cx, const
         }
     }
     const LaneLevels<F>& lv = LDS_LV ? lv_local : cx.lv;
-    const uint32_t first_hashed = cx.first_hashed;
+    const uint32_t first_hashed = FH >= 0 ? (uint32_t)FH : cx.first_hashed;
     const int g = cx.g;
     // phase 1: cell / fraction per level, issue all 8*Q gathers
     half8_t xf;
@@ -1241,7 +1245,7 @@ __device__ __forceinline__ void ray_head_constants(const half8_t* xf, const _Flo
     }
 }
 
-template <bool LIDAR, int F = 2>
+template <bool LIDAR, int F = 2, int FH = -1>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 4))) void k_render_occupancy_lds(OccRays rr, const _Float16* __restrict__ table, uint32_t table_bytes,
                                                                  GridMeta meta, uint32_t first_hashed, const _Float16* __restrict__ w_sigma,
                                                                  const _Float16* __restrict__ w_a, const _Float16* __restrict__ w_b,
@@ -1373,7 +1377,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 4))) 
         const uint32_t cnt = __builtin_amdgcn_readfirstlane(count);
         if (cnt == 0u) break;
         const float x01[3] = {(sx + rr.bound) / extent, (sy + rr.bound) / extent, (sz + rr.bound) / extent};
-        const half8_t feat = density_encode<F, 8 / F, true>(cx, x01);
+        const half8_t feat = density_encode<F, 8 / F, true, FH>(cx, x01);
         float4_t o;
         {
             float4_t acc1[kHidTiles];
@@ -1487,7 +1491,7 @@ struct RenderTrainOut {
     float* rgb;      // [M, C]
 };
 
-template <bool LIDAR, bool FROM_FEATURES, bool TRAIN = false>
+template <bool LIDAR, bool FROM_FEATURES, bool TRAIN = false, int FH = -1>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_render_uniform(
     RayBatch rb, const _Float16* __restrict__ table, uint32_t table_bytes, GridMeta meta, uint32_t first_hashed,
     const uint2* __restrict__ feat, const _Float16* __restrict__ w_sigma, const _Float16* __restrict__ w_a, const _Float16* __restrict__ w_b,
@@ -1606,7 +1610,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             x[0] = (fminf(fmaxf(ox + rd0 * z, rb.lo[0]), rb.hi[0]) + rb.bound) * rb.inv_extent;
             x[1] = (fminf(fmaxf(oy + rd1 * z, rb.lo[1]), rb.hi[1]) + rb.bound) * rb.inv_extent;
             x[2] = (fminf(fmaxf(oz + rd2 * z, rb.lo[2]), rb.hi[2]) + rb.bound) * rb.inv_extent;
-            feat8 = density_encode<F, 4, true>(cx, x);
+            feat8 = density_encode<F, 4, true, FH>(cx, x);
             if constexpr (TRAIN) {
                 if (g == 0 && valid) { rt.x01[3 * s] = x[0]; rt.x01[3 * s + 1] = x[1]; rt.x01[3 * s + 2] = x[2]; }
             }
@@ -2206,11 +2210,12 @@ NVSF_API int nvsf_render_occupancy_fwd(const float* rays_o, const float* rays_d,
     const _Float16* wb = reinterpret_cast<const _Float16*>(head_b_weights_f16);
     const float b0 = h_bg_color ? h_bg_color[0] : 0.0f, b1 = h_bg_color ? h_bg_color[1] : 0.0f, b2 = h_bg_color ? h_bg_color[2] : 0.0f;
     const dim3 grid_dim(cdiv(N, kWavesPerBlock)), block(kBlock);
-#define LAUNCH_OCC(LD, FF)                                                                                                                \
-    hipLaunchKernelGGL((k_render_occupancy_lds<LD, FF>), grid_dim, block, 0, stream, rr, tb, (uint32_t)table_bytes, meta, first_hashed, ws, \
+#define LAUNCH_OCC(LD, FF, FH)                                                                                                            \
+    hipLaunchKernelGGL((k_render_occupancy_lds<LD, FF, FH>), grid_dim, block, 0, stream, rr, tb, (uint32_t)table_bytes, meta, first_hashed, ws, \
                        wa, wb, density_scale, T_thresh, b0, b1, b2, weights_sum, depth, image)
-    if (lidar) { if (F == 2) LAUNCH_OCC(true, 2); else LAUNCH_OCC(true, 4); }
-    else { if (F == 2) LAUNCH_OCC(false, 2); else LAUNCH_OCC(false, 4); }
+    const bool c2_grid = F == 2 && first_hashed == kFirstHashedC2 && nvsf_variant(kVarLevelKinds) == 0;  // the instance with the level kinds compiled in (density_encode)
+    if (lidar) { if (c2_grid) LAUNCH_OCC(true, 2, (int)kFirstHashedC2); else if (F == 2) LAUNCH_OCC(true, 2, -1); else LAUNCH_OCC(true, 4, -1); }
+    else { if (c2_grid) LAUNCH_OCC(false, 2, (int)kFirstHashedC2); else if (F == 2) LAUNCH_OCC(false, 2, -1); else LAUNCH_OCC(false, 4, -1); }
 #undef LAUNCH_OCC
     return nvsf_launch_status();
 }
@@ -2261,16 +2266,22 @@ static int render_uniform_impl(const float* rays_o, const float* rays_d, const f
     const float b0 = h_bg_color ? h_bg_color[0] : 0.0f, b1 = h_bg_color ? h_bg_color[1] : 0.0f, b2 = h_bg_color ? h_bg_color[2] : 0.0f;
     const int use_bg = (h_bg_color && !lidar) ? 1 : 0;
     const dim3 grid_dim(cdiv(N, kWavesPerBlock)), block(kBlock);
-#define LAUNCH_RU(LD, FF)                                                                                                             \
+#define LAUNCH_RU_FH(LD, FF, FH)                                                                                                      \
     do {                                                                                                                              \
         if (train)                                                                                                                    \
-            hipLaunchKernelGGL((k_render_uniform<LD, FF, true>), grid_dim, block, 0, stream, rb, tb, (uint32_t)table_bytes, meta,     \
+            hipLaunchKernelGGL((k_render_uniform<LD, FF, true, FH>), grid_dim, block, 0, stream, rb, tb, (uint32_t)table_bytes, meta, \
                                first_hashed, fp, ws, wa, wb, k_scale, w_thresh, b0, b1, b2, use_bg, z_vals, weights, weights_sum,     \
                                depth, image, *train);                                                                                \
         else                                                                                                                          \
-            hipLaunchKernelGGL((k_render_uniform<LD, FF, false>), grid_dim, block, 0, stream, rb, tb, (uint32_t)table_bytes, meta,    \
-                               first_hashed, fp, ws, wa, wb, k_scale, w_thresh, b0, b1, b2, use_bg, z_vals, weights, weights_sum,     \
-                               depth, image, RenderTrainOut());                                                                      \
+            hipLaunchKernelGGL((k_render_uniform<LD, FF, false, FH>), grid_dim, block, 0, stream, rb, tb, (uint32_t)table_bytes,      \
+                               meta, first_hashed, fp, ws, wa, wb, k_scale, w_thresh, b0, b1, b2, use_bg, z_vals, weights,            \
+                               weights_sum, depth, image, RenderTrainOut());                                                         \
+    } while (0)
+    // the gathering form has an instance for the grid of BASELINE config 2 (levels 0-4 dense, 5-15 hashed) beside the general one
+#define LAUNCH_RU(LD, FF)                                                                                                             \
+    do {                                                                                                                              \
+        if (!FF && first_hashed == kFirstHashedC2 && nvsf_variant(kVarLevelKinds) == 0) LAUNCH_RU_FH(LD, FF, (FF ? -1 : (int)kFirstHashedC2)); \
+        else LAUNCH_RU_FH(LD, FF, -1);                                                                                                \
     } while (0)
 #define LAUNCH_TAIL(LD)                                                                                                               \
     do {                                                                                                                              \
@@ -2286,6 +2297,7 @@ static int render_uniform_impl(const float* rays_o, const float* rays_d, const f
     else { if (fp) { if (tail2) LAUNCH_TAIL(false); else LAUNCH_RU(false, true); } else LAUNCH_RU(false, false); }
 #undef LAUNCH_TAIL
 #undef LAUNCH_RU
+#undef LAUNCH_RU_FH
     return nvsf_launch_status();
 }
 

@@ -33,7 +33,7 @@ __attribute__((visibility("hidden"))) int nvsf_cu_count() {
 
 NVSF_API int nvsf_test_variant(const char* name, int value) {
     static const char* const names[kVarCount] = {"march", "planes_fwd", "planes_bwd", "hashgrid_fwd", "hashgrid_bwd", "hash4d_bwd", "slice_plan",
-                                                 "render_tail", "march_skew", "mlp_bwd"};
+                                                 "render_tail", "march_skew", "mlp_bwd", "level_kinds"};
     if (!name || value < 0) return NVSF_ERR_INVALID_ARG;
     for (int k = 0; k < kVarCount; ++k)
         if (strcmp(name, names[k]) == 0) {

@@ -329,8 +329,8 @@ class DensityTailFn(torch.autograd.Function):
             g_sigma = g_sigma.float().contiguous()
         if g_geo is not None and (g_geo.dtype != torch.float32 or g_geo.stride(1) != 1):
             g_geo = g_geo.float().contiguous()
-        # the logit gradient formed inside the MLP backward where the pieces have the layout it reads (nvsf_mlp_bwd_density, as the static
-        # field's node does), else by a pass of its own
+        # the logit gradient formed inside the MLP backward where the pieces have the layout it reads (ops.mlp_backward(density_grad=...),
+        # as the static field's node does), else by a pass of its own
         parts = None
         if testing.get("density_grad") == "composed" and x16.is_cuda:
             parts = ops.density_logit_gradient_parts(g_sigma, sigma, g_geo, None, spec.n_out - 1, (activation._LO, activation._HI))

@@ -23,6 +23,7 @@ _NATIVE = {
     "slice_plan": {"balanced": 0, "home": 1},
     "render_tail": {"two": 0, "one": 1},
     "mlp_bwd": {"auto": 0, "staged": 1, "wave": 2},
+    "level_kinds": {"compiled": 0, "runtime": 1},
     "march_skew": {"off": 0, **{f"queue{q}": q + 1 for q in range(8)}},
 }
 # operator-side choices (Python): name -> allowed values, the first one is the production form

@@ -147,3 +147,58 @@ def test_two_tile_tail_equals_one_tile_tail_and_gather_render(dev, lidar, N, T, 
     assert torch.equal(two[0], gather[0]) and torch.equal(two[1], gather[1])
     for x, y in zip(two[2:], gather[2:]):
         assert float((x - y).abs().max()) <= 2e-6
+
+
+@pytest.mark.parametrize("lidar", [True, False])
+@pytest.mark.parametrize("N,T,noise", [(64, 128, False), (37, 100, True), (200, 768, True)])
+def test_level_kinds_compiled_in_equal_the_run_time_form(dev, lidar, N, T, noise, variants):
+    """On the grid of BASELINE config 2 (levels 0-4 dense, 5-15 hashed) the gathering kernels run the instance of density_encode that
+    knows each level group's kind at compile time (only one index form per group, no selects; fused_field.hip kFirstHashedC2); on any
+    other grid the general instance reads first_hashed at run time.  Same arithmetic: the evaluation render, the training forward with
+    everything it keeps for the backward, and the occupancy render are bit-identical between the two instances."""
+    from nvsf import field_ops as ops
+    from nvsf import synthetic as S
+    m = _model(dev, 0.1)
+    enc = m.hash_encoder_lidar if lidar else m.hash_encoder_camera
+    spec = enc.spec
+    assert spec.L == 16 and spec.F == 2 and next(l for l in range(16) if spec.res[l] ** 3 > spec.offsets[l + 1] - spec.offsets[l]) == 5
+    rng = np.random.default_rng(29)
+    o, d, nears, fars = _batch(m, dev, lidar, N, rng)
+    nz = torch.rand(N, T, device=dev) if noise else None
+    heads = (m.raydrop_net.weights_f16(), m.intensity_net.weights_f16()) if lidar else (m.color_net.weights_f16(), None)
+    args = (o, d, nears, fars, T, m._aabb_host, float(m.bound), enc.table_f16(), spec, m.sigma_net.weights_f16(), lidar, heads[0], heads[1],
+            m._k_scale(), None if lidar else [1.0, 0.5, 0.25], nz)
+    targs = (o, d, nears, fars, T, m._aabb_host, float(m.bound), nz, enc.table_f16(), spec, m.sigma_net.weights_f16(), lidar, heads[0], heads[1],
+             m._k_scale(), None if lidar else [1.0, 0.5, 0.25], ops.W_THRESH, False)
+    res = {}
+    for form in ("compiled", "runtime"):
+        variants.set(level_kinds=form)
+        res[form] = tuple(ops.render_uniform(*args, sliced=False)) + tuple(ops.render_uniform_train_forward(*targs))
+    variants.clear("level_kinds")
+    assert len(res["compiled"]) == 15
+    for k, (a, b) in enumerate(zip(res["compiled"], res["runtime"])):
+        assert torch.equal(a, b), k
+    assert float(res["compiled"][2].max()) > 0.05
+
+
+@pytest.mark.parametrize("lidar", [True, False])
+def test_level_kinds_compiled_in_equal_the_run_time_form_in_the_occupancy_render(dev, lidar, variants):
+    from nvsf import synthetic as S
+    m = _model(dev, 0.1).enable_occupancy_grid().to(dev).eval()
+    rng = np.random.default_rng(31)
+    grid = S.boxes_density_grid(rng, cascades=m.cascade, H=m.grid_size, n_boxes=64)
+    m.set_density_grid(torch.from_numpy(grid).to(dev), thresh=0.5)
+    o, d = (S.lidar_rays if lidar else S.camera_rays)(300, rng)
+    o, d = torch.from_numpy(o).to(dev)[None], torch.from_numpy(d).to(dev)[None]
+    res = {}
+    for form in ("compiled", "runtime"):
+        variants.set(level_kinds=form)
+        with torch.no_grad():
+            out = m.render(o, d, torch.tensor([[0.5]], device=dev), cal_lidar_color=lidar, max_steps=512, T_thresh=1e-4, fused=True)
+        res[form] = {k: v.clone() for k, v in out.items() if torch.is_tensor(v)}
+    variants.clear("level_kinds")
+    assert set(res["compiled"]) == set(res["runtime"]) and len(res["compiled"]) >= 3
+    for k, a in res["compiled"].items():
+        assert torch.equal(a, res["runtime"][k]), k
+    sfx = "_lidar" if lidar else ""
+    assert float(res["compiled"]["weights_sum" + sfx].max()) > 0.05
