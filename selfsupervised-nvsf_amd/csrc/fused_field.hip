@@ -1584,6 +1584,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     float carry = 1.0f, ws = 0.0f, dp = 0.0f, img[C];
 #pragma unroll
     for (int k = 0; k < C; ++k) img[k] = 0.0f;
+    // the sample fractions (and jitter) of a tile are requested one tile ahead: two dependent L2 round trips at the head of every
+    // tile's chain otherwise
+    float lin_cur = 0.0f, lin_nxt = 0.0f, nz_cur = 0.5f, nz_nxt = 0.5f;
+    auto request = [&](uint32_t i0) {
+        const uint32_t i = i0 + (uint32_t)c;
+        const uint32_t ic = i < T ? i : T - 1u, in = ic + 1u < T ? ic + 1u : ic;
+        lin_cur = rb.lin[ic];
+        lin_nxt = rb.lin[in];
+        if (rb.noise) {
+            nz_cur = rb.noise[row0 + ic];
+            nz_nxt = rb.noise[row0 + in];
+        }
+    };
+    if constexpr (!FROM_FEATURES) request(0u);
     for (uint32_t i0 = 0; i0 < T; i0 += 16) {
         const uint32_t i = i0 + (uint32_t)c;
         const bool valid = i < T;
@@ -1600,12 +1614,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             const u4_t packed = {p0.x, p1.x, p1.y, p0.y};
             feat8 = __builtin_bit_cast(half8_t, packed);
         } else {
-            z = near + range * rb.lin[ic];
-            z_next = near + range * rb.lin[ic + 1u < T ? ic + 1u : ic];
+            z = near + range * lin_cur;
+            z_next = near + range * lin_nxt;
             if (rb.noise) {
-                z = z + (rb.noise[s] - 0.5f) * sample_dist;
-                z_next = z_next + (rb.noise[ic + 1u < T ? s + 1 : s] - 0.5f) * sample_dist;
+                z = z + (nz_cur - 0.5f) * sample_dist;
+                z_next = z_next + (nz_nxt - 0.5f) * sample_dist;
             }
+            if (i0 + 16u < T) request(i0 + 16u);
             float x[3];
             x[0] = (fminf(fmaxf(ox + rd0 * z, rb.lo[0]), rb.hi[0]) + rb.bound) * rb.inv_extent;
             x[1] = (fminf(fmaxf(oy + rd1 * z, rb.lo[1]), rb.hi[1]) + rb.bound) * rb.inv_extent;
