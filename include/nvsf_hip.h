@@ -652,16 +652,24 @@ int nvsf_lidar_losses_bwd(const float* image_lidar, const float* depth_lidar, co
  * image; pano_range: the range channel of that frame ([H, W], element stride pano_stride floats: 3 for the [H, W, 3] ground truth).
  * First differences with the last column / row repeated, in metres (/ scale); masks = gt_raydrop x (|second difference of the TRUE
  * frame at the pixel| < 0.05); loss = alpha sum crit(grad_x(pred) m_x, grad_x(gt) m_x) + the same in y; criterion 0 L1, 1 MSE,
- * 2 Huber(delta = criterion_param), 3 SmoothL1(beta = criterion_param) (main_nvsf.py:204-221, `--depth_grad_loss`; the cosine form and
- * the Sobel / smoothness / TV options of the same block are not built).  One launch, deterministic sum. */
+ * 2 Huber(delta = criterion_param), 3 SmoothL1(beta = criterion_param) (main_nvsf.py:204-221, `--depth_grad_loss`), 4 cosine
+ * (trainer.py:442-452: per patch and direction 1 - <u, v> / (max(|u|, 1e-8) max(|v|, 1e-8)) over the patch's masked gradients,
+ * expanded over the patch and summed; patch_stats float [N / (patch_h patch_w), 6] receives the three inner products per
+ * direction for the backward, may be NULL for criteria 0-3).  sobel != 0 (`--sobel_grad`, trainer.py:316-328, 367-380): the
+ * gradients of both range images are the 3 x 3 Sobel cross-correlations with zero padding at the patch border instead of first
+ * differences (the masks stay those of the true frame).  Not built: `--grad_norm_smooth`, `--spatial_smooth`, `--tv_loss`
+ * (trainer.py:337-350 add a [num_patch, 1, pH, pW] tensor to the loss, which Trainer.train_one_epoch cannot back-propagate: the
+ * options fail in the reference itself).  One launch, deterministic sum. */
 int nvsf_lidar_grad_loss_fwd(const float* pred_depth, const float* gt_depth, const float* gt_raydrop, const int64_t* pano_inds,
                              const float* pano_range, uint32_t pano_stride, uint32_t N, uint32_t patch_h, uint32_t patch_w, uint32_t H,
-                             uint32_t W, float scale, int criterion, float criterion_param, float alpha, float* loss, nvsf_stream_t stream);
-/* gradient of the above with respect to pred_depth [N], given the gradient of the loss (a device float) */
+                             uint32_t W, float scale, int criterion, float criterion_param, float alpha, int sobel, float* patch_stats,
+                             float* loss, nvsf_stream_t stream);
+/* gradient of the above with respect to pred_depth [N], given the gradient of the loss (a device float) and, for the cosine
+ * criterion, the patch_stats the forward wrote */
 int nvsf_lidar_grad_loss_bwd(const float* pred_depth, const float* gt_depth, const float* gt_raydrop, const int64_t* pano_inds,
                              const float* pano_range, uint32_t pano_stride, uint32_t N, uint32_t patch_h, uint32_t patch_w, uint32_t H,
-                             uint32_t W, float scale, int criterion, float criterion_param, float alpha, const float* grad_loss,
-                             float* grad_pred_depth, nvsf_stream_t stream);
+                             uint32_t W, float scale, int criterion, float criterion_param, float alpha, int sobel, const float* patch_stats,
+                             const float* grad_loss, float* grad_pred_depth, nvsf_stream_t stream);
 
 /* ref: the error map behind the pixel sampler, nvsf/nerf/trainer.py:552-630 (`--use_error_map`, configs/kitti360_1908.txt:14).
  * nvsf_lidar_ray_losses: the per-ray LiDAR loss `lidar_loss` of trainer.py:213-216 (the three terms of nvsf_lidar_losses_fwd, not

@@ -124,7 +124,8 @@ __global__ __launch_bounds__(256) void k_mse_sum_bwd(const float* __restrict__ a
 // for the rendered and the true range alike.  The terms are masked by the true ray-drop channel and by the flatness of the TRUE
 // range image around the pixel (trainer.py:386-431): first differences of the whole frame (same padding rule), their absolute second
 // differences, mask = |second difference at (h, w)| < 0.05.  loss = alpha sum_j crit(grad_x m_x, gt_grad_x m_x) + the same in y
-// (trainer.py:449-458: criterion with reduction "none", summed), crit in {L1, MSE, Huber(delta), SmoothL1(beta)} (main_nvsf.py:204-221).
+// (trainer.py:449-458: criterion with reduction "none", summed), crit in {L1, MSE, Huber(delta), SmoothL1(beta)} (main_nvsf.py:204-221);
+// the cosine criterion and the Sobel gradients of the same block: sr_cos / sr_tap below.
 struct PatchGeom {
     uint32_t pH, pW, H, W;
     float scale;
@@ -155,14 +156,47 @@ __device__ __forceinline__ float pano_dy(const float* __restrict__ pano, uint32_
     const uint32_t hh = h < g.H - 1 ? h : g.H - 2;
     return (pano[((size_t)hh * g.W + w) * stride] - pano[((size_t)(hh + 1) * g.W + w) * stride]) / g.scale;
 }
-// e = m (grad(pred) - grad(gt)) of pixel j in direction `dir` (0: x, 1: y); also the index pair (a, b) with grad = q(a) - q(b) and m
-__device__ __forceinline__ float sr_error(const float* __restrict__ pred, const float* __restrict__ gt, const float* __restrict__ gt_rd,
-                                          const long long* __restrict__ inds, const float* __restrict__ pano, uint32_t pano_stride, uint32_t j,
-                                          int dir, const PatchGeom& g, uint32_t& a, uint32_t& b, float& m) {
-    const uint32_t c = j % g.pW, r = (j / g.pW) % g.pH;
-    if (dir == 0) { a = c < g.pW - 1 ? j : j - 1; b = a + 1; }
-    else { a = r < g.pH - 1 ? j : j - g.pW; b = a + g.pW; }
-    const float gp = pred[a] / g.scale - pred[b] / g.scale, gg = gt[a] / g.scale - gt[b] / g.scale;
+// d grad_dir(j) / d q(k) for two pixels of ONE patch (0 where pixel k does not enter the gradient at pixel j):
+//   manual differences: grad(j) = q(a) - q(b) with (a, b) = (j, j + step), in the last column / row the pair of the one before;
+//   --sobel_grad: F.conv2d(patch, K, padding = 1) (trainer.py:316-328, 367-380): cross-correlation with
+//                 Kx = [[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]], Ky = Kx^T, zero padding at the PATCH border.
+__device__ __forceinline__ float sr_tap(uint32_t rj, uint32_t cj, uint32_t rk, uint32_t ck, int dir, const PatchGeom& g, bool sobel) {
+    const int dr = (int)rk - (int)rj, dc = (int)ck - (int)cj;
+    if (sobel) {
+        if (dr < -1 || dr > 1 || dc < -1 || dc > 1) return 0.0f;
+        const int along = dir == 0 ? dc : dr, across = dir == 0 ? dr : dc;
+        return (float)along * (across == 0 ? 2.0f : 1.0f);
+    }
+    if (dir == 0) {
+        if (dr != 0) return 0.0f;
+        const uint32_t a = cj < g.pW - 1 ? cj : cj - 1;
+        return ck == a ? 1.0f : (ck == a + 1 ? -1.0f : 0.0f);
+    }
+    if (dc != 0) return 0.0f;
+    const uint32_t a = rj < g.pH - 1 ? rj : rj - 1;
+    return rk == a ? 1.0f : (rk == a + 1 ? -1.0f : 0.0f);
+}
+// gradient of the patch image q = v / scale at pixel j = (patch base + rj pW + cj)
+__device__ __forceinline__ float sr_grad(const float* __restrict__ v, uint32_t base, uint32_t rj, uint32_t cj, int dir, const PatchGeom& g, bool sobel) {
+    if (!sobel) {
+        uint32_t a, b;
+        if (dir == 0) { a = base + rj * g.pW + (cj < g.pW - 1 ? cj : cj - 1); b = a + 1; }
+        else { a = base + (rj < g.pH - 1 ? rj : rj - 1) * g.pW + cj; b = a + g.pW; }
+        return v[a] / g.scale - v[b] / g.scale;
+    }
+    float acc = 0.0f;  // row-major over the 3 x 3 window, zero taps skipped
+    for (int dr = -1; dr <= 1; ++dr)
+        for (int dc = -1; dc <= 1; ++dc) {
+            const int r = (int)rj + dr, c = (int)cj + dc;
+            if (r < 0 || c < 0 || r >= (int)g.pH || c >= (int)g.pW) continue;
+            const float k = sr_tap(rj, cj, (uint32_t)r, (uint32_t)c, dir, g, true);
+            if (k != 0.0f) acc += k * (v[base + (uint32_t)r * g.pW + (uint32_t)c] / g.scale);
+        }
+    return acc;
+}
+// mask of pixel j in direction dir: true ray-drop channel x flatness of the TRUE frame at the pixel (trainer.py:388-439)
+__device__ __forceinline__ float sr_mask(const float* __restrict__ gt_rd, const long long* __restrict__ inds, const float* __restrict__ pano,
+                                         uint32_t pano_stride, uint32_t j, int dir, const PatchGeom& g) {
     const uint32_t h = (uint32_t)(inds[j] / (long long)g.W), w = (uint32_t)(inds[j] % (long long)g.W);
     float second;
     if (dir == 0) {
@@ -172,54 +206,93 @@ __device__ __forceinline__ float sr_error(const float* __restrict__ pred, const 
         const uint32_t hh = h < g.H - 1 ? h : g.H - 2;
         second = fabsf(pano_dy(pano, pano_stride, hh, w, g)) - fabsf(pano_dy(pano, pano_stride, hh + 1, w, g));
     }
-    m = gt_rd[j] * (fabsf(second) < 0.05f ? 1.0f : 0.0f);
-    return gp * m - gg * m;
+    return gt_rd[j] * (fabsf(second) < 0.05f ? 1.0f : 0.0f);
+}
+struct SrTerm { float u, v, m; };  // masked gradient of the rendered range, of the true range, the mask
+__device__ __forceinline__ SrTerm sr_term(const float* __restrict__ pred, const float* __restrict__ gt, const float* __restrict__ gt_rd,
+                                          const long long* __restrict__ inds, const float* __restrict__ pano, uint32_t pano_stride, uint32_t j,
+                                          int dir, const PatchGeom& g, bool sobel) {
+    const uint32_t area = g.pH * g.pW, base = j / area * area, rj = (j - base) / g.pW, cj = (j - base) % g.pW;
+    SrTerm t;
+    t.m = sr_mask(gt_rd, inds, pano, pano_stride, j, dir, g);
+    t.u = sr_grad(pred, base, rj, cj, dir, g, sobel) * t.m;
+    t.v = sr_grad(gt, base, rj, cj, dir, g, sobel) * t.m;
+    return t;
+}
+
+// criterion 4, `--depth_grad_loss cos` (main_nvsf.py:211, trainer.py:442-452): per patch and direction cos = <u, v> / (max(|u|, eps)
+// max(|v|, eps)) over the patch's pH pW masked gradients (torch.nn.CosineSimilarity(dim = 1, eps = 1e-8) on the flattened patch), and
+// (1 - cos) expanded over the patch and summed: loss = alpha pH pW sum_patches (1 - cos_x) + (1 - cos_y).
+// patch_stats [P, 6] = (<u,v>, <u,u>, <v,v>) for x, then for y -- written by the forward, read by the backward.
+constexpr float kCosEps = 1e-8f;
+__device__ __forceinline__ float sr_cos(const float* __restrict__ st) {
+    return st[0] / (fmaxf(sqrtf(st[1]), kCosEps) * fmaxf(sqrtf(st[2]), kCosEps));
 }
 
 __global__ __launch_bounds__(kBlock) void k_lidar_grad_loss_fwd(const float* __restrict__ pred, const float* __restrict__ gt,
                                                                 const float* __restrict__ gt_rd, const long long* __restrict__ inds,
                                                                 const float* __restrict__ pano, uint32_t pano_stride, uint32_t N, PatchGeom g,
-                                                                int kind, float param, float alpha, float* __restrict__ loss) {
+                                                                int kind, float param, float alpha, int sobel, float* __restrict__ patch_stats,
+                                                                float* __restrict__ loss) {
     float acc[1] = {0.0f};
-    for (uint32_t j = threadIdx.x; j < N; j += kBlock) {
-        uint32_t a, b;
-        float m;
-        const float ex = sr_error(pred, gt, gt_rd, inds, pano, pano_stride, j, 0, g, a, b, m);
-        const float ey = sr_error(pred, gt, gt_rd, inds, pano, pano_stride, j, 1, g, a, b, m);
-        acc[0] += alpha * (sr_crit(ex, kind, param) + sr_crit(ey, kind, param));
+    if (kind < 4) {
+        for (uint32_t j = threadIdx.x; j < N; j += kBlock) {
+            const SrTerm x = sr_term(pred, gt, gt_rd, inds, pano, pano_stride, j, 0, g, sobel != 0);
+            const SrTerm y = sr_term(pred, gt, gt_rd, inds, pano, pano_stride, j, 1, g, sobel != 0);
+            acc[0] += alpha * (sr_crit(x.u - x.v, kind, param) + sr_crit(y.u - y.v, kind, param));
+        }
+    } else {
+        const uint32_t area = g.pH * g.pW;
+        for (uint32_t p = threadIdx.x; p < N / area; p += kBlock) {
+            float st[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            for (uint32_t j = p * area; j < (p + 1) * area; ++j)
+                for (int dir = 0; dir < 2; ++dir) {
+                    const SrTerm t = sr_term(pred, gt, gt_rd, inds, pano, pano_stride, j, dir, g, sobel != 0);
+                    st[3 * dir] += t.u * t.v;
+                    st[3 * dir + 1] += t.u * t.u;
+                    st[3 * dir + 2] += t.v * t.v;
+                }
+            for (int k = 0; k < 6; ++k) patch_stats[6 * (size_t)p + k] = st[k];
+            acc[0] += alpha * (float)area * ((1.0f - sr_cos(st)) + (1.0f - sr_cos(st + 3)));
+        }
     }
     float* o[1] = {loss};
     block_sums<1>(acc, o);
 }
 
-// d loss / d pred(k): pixel k enters grad(j) = q(a_j) - q(b_j) of itself, of its left / upper neighbour (as b) and -- in the second-to-last
-// column / row -- of the padded last one (as a)
+// d loss / d pred(k): pixel k enters the gradients of the pixels of its 3 x 3 neighbourhood inside its patch (sr_tap)
 __global__ __launch_bounds__(256) void k_lidar_grad_loss_bwd(const float* __restrict__ pred, const float* __restrict__ gt,
                                                              const float* __restrict__ gt_rd, const long long* __restrict__ inds,
                                                              const float* __restrict__ pano, uint32_t pano_stride, uint32_t N, PatchGeom g,
-                                                             int kind, float param, float alpha, const float* __restrict__ g_loss,
-                                                             float* __restrict__ grad_pred) {
+                                                             int kind, float param, float alpha, int sobel, const float* __restrict__ patch_stats,
+                                                             const float* __restrict__ g_loss, float* __restrict__ grad_pred) {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     if (k >= N) return;
-    const uint32_t c = k % g.pW, r = (k / g.pW) % g.pH;
+    const uint32_t area = g.pH * g.pW, p = k / area, base = p * area, rk = (k - base) / g.pW, ck = (k - base) % g.pW;
     float sum = 0.0f;
-#pragma unroll
-    for (int dir = 0; dir < 2; ++dir) {
-        const uint32_t step = dir == 0 ? 1u : g.pW, pos = dir == 0 ? c : r, len = dir == 0 ? g.pW : g.pH;
-        const uint32_t cand[3] = {k, k - step, k + step};
-        const bool ok[3] = {true, pos >= 1, pos + 1 < len};
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            if (!ok[t]) continue;
-            uint32_t a, b;
-            float m;
-            const float e = sr_error(pred, gt, gt_rd, inds, pano, pano_stride, cand[t], dir, g, a, b, m);
-            const float d = sr_crit_grad(e, kind, param) * m;
-            if (a == k) sum += d;
-            if (b == k) sum -= d;
+    for (int dr = -1; dr <= 1; ++dr)
+        for (int dc = -1; dc <= 1; ++dc) {
+            const int r = (int)rk + dr, c = (int)ck + dc;
+            if (r < 0 || c < 0 || r >= (int)g.pH || c >= (int)g.pW) continue;
+            const uint32_t j = base + (uint32_t)r * g.pW + (uint32_t)c;
+            for (int dir = 0; dir < 2; ++dir) {
+                const float tap = sr_tap((uint32_t)r, (uint32_t)c, rk, ck, dir, g, sobel != 0);
+                if (tap == 0.0f) continue;
+                const SrTerm t = sr_term(pred, gt, gt_rd, inds, pano, pano_stride, j, dir, g, sobel != 0);
+                float d;  // d loss / d u(j)
+                if (kind < 4) {
+                    d = alpha * sr_crit_grad(t.u - t.v, kind, param);
+                } else {
+                    const float* st = patch_stats + 6 * (size_t)p + 3 * dir;
+                    const float nu_raw = sqrtf(st[1]), nu = fmaxf(nu_raw, kCosEps), nv = fmaxf(sqrtf(st[2]), kCosEps);
+                    float dcos = t.v / (nu * nv);
+                    if (nu_raw > kCosEps) dcos -= st[0] / (nu * nu * nv) * (t.u / nu_raw);
+                    d = -alpha * (float)area * dcos;
+                }
+                sum += tap * d * t.m;
+            }
         }
-    }
-    grad_pred[k] = *g_loss * alpha * sum / g.scale;
+    grad_pred[k] = *g_loss * sum / g.scale;
 }
 
 // ---- error map of the pixel sampler (trainer.py:552-630) -----------------------------------------------------------------------
@@ -336,30 +409,32 @@ NVSF_API int nvsf_mse_sum_bwd(const float* a, const float* b, uint32_t n, float 
 
 NVSF_API int nvsf_lidar_grad_loss_fwd(const float* pred_depth, const float* gt_depth, const float* gt_raydrop, const int64_t* pano_inds,
                                       const float* pano_range, uint32_t pano_stride, uint32_t N, uint32_t patch_h, uint32_t patch_w, uint32_t H,
-                                      uint32_t W, float scale, int criterion, float criterion_param, float alpha, float* loss, hipStream_t stream) {
+                                      uint32_t W, float scale, int criterion, float criterion_param, float alpha, int sobel, float* patch_stats,
+                                      float* loss, hipStream_t stream) {
     REQUIRE(loss);
     if (N == 0) return hipMemsetAsync(loss, 0, 4, stream) == hipSuccess ? NVSF_OK : (int)hipGetLastError();
     REQUIRE(pred_depth && gt_depth && gt_raydrop && pano_inds && pano_range && pano_stride >= 1);
     REQUIRE(patch_h >= 2 && patch_w >= 2 && N % (patch_h * patch_w) == 0 && H >= 2 && W >= 2 && scale != 0.0f);
-    REQUIRE(criterion >= 0 && criterion <= 3 && (criterion < 2 || criterion_param > 0.0f));
+    REQUIRE(criterion >= 0 && criterion <= 4 && (criterion < 2 || criterion == 4 || criterion_param > 0.0f) && (criterion != 4 || patch_stats));
     const PatchGeom g = {patch_h, patch_w, H, W, scale};
     hipLaunchKernelGGL(k_lidar_grad_loss_fwd, dim3(1), dim3(kBlock), 0, stream, pred_depth, gt_depth, gt_raydrop,
-                       reinterpret_cast<const long long*>(pano_inds), pano_range, pano_stride, N, g, criterion, criterion_param, alpha, loss);
+                       reinterpret_cast<const long long*>(pano_inds), pano_range, pano_stride, N, g, criterion, criterion_param, alpha, sobel,
+                       patch_stats, loss);
     return nvsf_launch_status();
 }
 
 NVSF_API int nvsf_lidar_grad_loss_bwd(const float* pred_depth, const float* gt_depth, const float* gt_raydrop, const int64_t* pano_inds,
                                       const float* pano_range, uint32_t pano_stride, uint32_t N, uint32_t patch_h, uint32_t patch_w, uint32_t H,
-                                      uint32_t W, float scale, int criterion, float criterion_param, float alpha, const float* grad_loss,
-                                      float* grad_pred_depth, hipStream_t stream) {
+                                      uint32_t W, float scale, int criterion, float criterion_param, float alpha, int sobel,
+                                      const float* patch_stats, const float* grad_loss, float* grad_pred_depth, hipStream_t stream) {
     if (N == 0) return NVSF_OK;
     REQUIRE(pred_depth && gt_depth && gt_raydrop && pano_inds && pano_range && pano_stride >= 1 && grad_loss && grad_pred_depth);
     REQUIRE(patch_h >= 2 && patch_w >= 2 && N % (patch_h * patch_w) == 0 && H >= 2 && W >= 2 && scale != 0.0f);
-    REQUIRE(criterion >= 0 && criterion <= 3 && (criterion < 2 || criterion_param > 0.0f));
+    REQUIRE(criterion >= 0 && criterion <= 4 && (criterion < 2 || criterion == 4 || criterion_param > 0.0f) && (criterion != 4 || patch_stats));
     const PatchGeom g = {patch_h, patch_w, H, W, scale};
     hipLaunchKernelGGL(k_lidar_grad_loss_bwd, dim3(cdiv(N, 256)), dim3(256), 0, stream, pred_depth, gt_depth, gt_raydrop,
-                       reinterpret_cast<const long long*>(pano_inds), pano_range, pano_stride, N, g, criterion, criterion_param, alpha, grad_loss,
-                       grad_pred_depth);
+                       reinterpret_cast<const long long*>(pano_inds), pano_range, pano_stride, N, g, criterion, criterion_param, alpha, sobel,
+                       patch_stats, grad_loss, grad_pred_depth);
     return nvsf_launch_status();
 }
 

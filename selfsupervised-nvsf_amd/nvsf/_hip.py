@@ -72,8 +72,8 @@ SIGNATURES = {
     "nvsf_density_dynamic_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _U, _P, _P, _P, _P, _P],
     "nvsf_lidar_losses_fwd": [_P, _P, _P, _P, _P, _P, _U, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P],
     "nvsf_lidar_losses_bwd": [_P, _P, _P, _P, _P, _P, _U, _F, _F, _F, _F, _F, _P, _P, _P, _P, _P, _P, _P],
-    "nvsf_lidar_grad_loss_fwd": [_P, _P, _P, _P, _P, _U, _U, _U, _U, _U, _U, _F, _I, _F, _F, _P],
-    "nvsf_lidar_grad_loss_bwd": [_P, _P, _P, _P, _P, _U, _U, _U, _U, _U, _U, _F, _I, _F, _F, _P, _P],
+    "nvsf_lidar_grad_loss_fwd": [_P, _P, _P, _P, _P, _U, _U, _U, _U, _U, _U, _F, _I, _F, _F, _I, _P, _P],
+    "nvsf_lidar_grad_loss_bwd": [_P, _P, _P, _P, _P, _U, _U, _U, _U, _U, _U, _F, _I, _F, _F, _I, _P, _P, _P],
     "nvsf_lidar_ray_losses": [_P, _P, _P, _P, _P, _U, _F, _F, _F, _F, _P, _P],
     "nvsf_mse_rows": [_P, _P, _U, _U, _F, _P, _P],
     "nvsf_error_map_update": [_P, _P, _U, _U, _P, _U, _U, _F, _F, _P, _P],

@@ -18,10 +18,11 @@ Only what sits directly around the hot path, restated from the reference's `Trai
 Across GPUs the step is frame-sharded: every rank renders its own frame, then ONE bucketed gradient all-reduce
 (nvsf/frame_shard.py).  Checkpoints use the reference's dict (utils.py:622-747).
 Shipped-config extras (configs/kitti360_1908.txt:13-15 `grad_loss`, `use_error_map`): the structural regularisation on LiDAR patches
-in its `grad_loss` form (trainer.py:296-470: first differences of the rendered / true range inside pH x pW patches, masked by the true
+in its `grad_loss` form (trainer.py:296-470: first differences (or Sobel gradients) of the rendered / true range inside pH x pW patches, masked by the true
 ray-drop channel and the flatness of the true frame; `LidarGradLossFn`, csrc/losses.hip), the alternation between random pixels and
 patches (trainer.py:1035-1062: `set_epoch`) and the error maps the patch sampler draws from (trainer.py:552-630: `update_error_maps`).
-Logging, UNet refinement and the Sobel / smoothness / TV / cosine options of the regulariser are out of scope.
+The regulariser's criteria (`--depth_grad_loss` l1 / mse / huber / smoothl1 / cos) and `--sobel_grad` are built; its three smoothness switches
+fail in the reference itself (see __init__).  Logging and UNet refinement are out of scope.
 """
 import math
 import warnings
@@ -114,14 +115,15 @@ class MseSumFn(torch.autograd.Function):
 class LidarGradLossFn(torch.autograd.Function):
     """Structural regularisation of trainer.py:296-470 in its `grad_loss` form as one launch each way (nvsf_lidar_grad_loss_fwd / _bwd):
     pred_depth, gt_depth [1, N] the masked ranges (scene units), gt_raydrop [1, N], pano_inds int64 [1, N] pixel indices of the batch
-    (N / (pH pW) patches in patch order), pano_frame [H, W, 3] (or [1, H, W, 3]) the frame's ground truth (channel 2 = range x scale)."""
-    CRITERIA = {"l1": 0, "mse": 1, "huber": 2, "smoothl1": 3}
+    (N / (pH pW) patches in patch order), pano_frame [H, W, 3] (or [1, H, W, 3]) the frame's ground truth (channel 2 = range x scale).
+    criterion: `--depth_grad_loss` (main_nvsf.py:86, 204-221); sobel: `--sobel_grad` (:107)."""
+    CRITERIA = {"l1": 0, "mse": 1, "huber": 2, "smoothl1": 3, "cos": 4}
 
     @staticmethod
-    def forward(ctx, pred_depth, gt_depth, gt_raydrop, pano_inds, pano_frame, patch, scale, criterion, alpha):
+    def forward(ctx, pred_depth, gt_depth, gt_raydrop, pano_inds, pano_frame, patch, scale, criterion, alpha, sobel=False):
         from nvsf import _hip
         if criterion not in LidarGradLossFn.CRITERIA:
-            raise NotImplementedError(f"depth_grad_loss={criterion!r}: l1 / mse / huber / smoothl1 are built (the cosine form is not)")
+            raise ValueError(f"depth_grad_loss={criterion!r}: one of {sorted(LidarGradLossFn.CRITERIA)} (main_nvsf.py:86)")
         c = lambda t: t.detach().float().contiguous()
         pd, gd, rd = c(pred_depth), c(gt_depth), c(gt_raydrop)
         inds = pano_inds.detach().long().contiguous()
@@ -134,10 +136,11 @@ class LidarGradLossFn(torch.autograd.Function):
         kind = LidarGradLossFn.CRITERIA[criterion]
         param = 0.2 * float(scale) if criterion == "huber" else (0.1 if criterion == "smoothl1" else 0.0)  # main_nvsf.py:207-208
         out = torch.empty((), dtype=torch.float32, device=pd.device)
+        stats = torch.empty(N // (pH * pW), 6, dtype=torch.float32, device=pd.device) if criterion == "cos" else None
         args = (_hip.ptr(pd), _hip.ptr(gd), _hip.ptr(rd), _hip.ptr(inds), frame.data_ptr() + 4 * (C - 1 if C >= 3 else 0), C, N, pH, pW, H, W,
-                float(scale), kind, float(param), float(alpha))
+                float(scale), kind, float(param), float(alpha), 1 if sobel else 0, _hip.ptr(stats))
         _hip.call("nvsf_lidar_grad_loss_fwd", *args, _hip.ptr(out))
-        ctx.save_for_backward(pd, gd, rd, inds, frame)
+        ctx.save_for_backward(pd, gd, rd, inds, frame, *(() if stats is None else (stats,)))
         ctx.args, ctx.shape = args, pred_depth.shape
         return out
 
@@ -147,14 +150,15 @@ class LidarGradLossFn(torch.autograd.Function):
         pd = ctx.saved_tensors[0]
         grad = torch.empty_like(pd)
         _hip.call("nvsf_lidar_grad_loss_bwd", *ctx.args, _hip.ptr(g.float().contiguous()), _hip.ptr(grad))
-        return (grad.view(ctx.shape),) + (None,) * 8
+        return (grad.view(ctx.shape),) + (None,) * 9
 
 
 class RenderTrainStep:
     def __init__(self, model, lr=1e-2, iters=30000, num_steps=768, alpha_d=1.0, alpha_r=0.01, alpha_i=0.1, alpha_rgb=1.0,
                  smooth_factor=0.0, use_urf_loss=False, bucket_bytes=64 << 20, fp16=True, scale=1.0, chamfer_loss=True,
                  flow_loss=False, pc_list=None, ema_decay=0.95, split_backward=True, ray_chunks=1, grad_loss=False, depth_grad_loss="l1",
-                 alpha_grad=0.1, patch_size_lidar=1, change_patch_size_lidar=(2, 8), change_patch_size_epoch=2, use_error_map=False):
+                 alpha_grad=0.1, patch_size_lidar=1, change_patch_size_lidar=(2, 8), change_patch_size_epoch=2, use_error_map=False,
+                 sobel_grad=False, grad_norm_smooth=False, spatial_smooth=False, tv_loss=False):
         """Defaults = the reference's CLI defaults (main_nvsf.py:60-97).  `scale`: the scene scale the chamfer loss divides by
         (opt.scale); `pc_list`: {frame index: [P, 3] tensor} world-frame point clouds for the scene-flow loss
         (Trainer.process_pointcloud, trainer.py:1848-1912, builds them from the range images); `ema_decay=None` disables EMA.
@@ -190,6 +194,12 @@ class RenderTrainStep:
         # structural regularisation on LiDAR patches + the error maps of the patch sampler (main_nvsf.py:79-111 defaults; the shipped
         # config switches grad_loss and use_error_map on, configs/kitti360_1908.txt:13-14)
         self.grad_loss, self.depth_grad_loss, self.alpha_grad = bool(grad_loss), str(depth_grad_loss), float(alpha_grad)
+        self.sobel_grad = bool(sobel_grad)
+        if grad_norm_smooth or spatial_smooth or tv_loss:
+            # trainer.py:337-350 add a [num_patch, 1, pH, pW] tensor to the loss, so that `loss` is no scalar any more and
+            # scaler.scale(loss).backward() (trainer.py:1332) raises: the three switches cannot be trained with in the reference
+            raise NotImplementedError("grad_norm_smooth / spatial_smooth / tv_loss make the reference's loss a non-scalar tensor "
+                                      "(trainer.py:337-350, 543-545) that its own backward call rejects; there is no behaviour to match")
         self.patch_size_lidar = patch_size_lidar
         self.change_patch_size_lidar, self.change_patch_size_epoch = tuple(change_patch_size_lidar), int(change_patch_size_epoch)
         self.use_error_map, self.pixel_sampler = bool(use_error_map), "random"
@@ -311,7 +321,7 @@ class RenderTrainStep:
                     if "rays_pano_inds" not in batch or "pano_frame" not in batch:
                         raise ValueError("grad_loss on LiDAR patches needs batch['rays_pano_inds'] and batch['pano_frame'] (FrameSet.train_batch)")
                     out["sr"] = LidarGradLossFn.apply(pred_depth, gt_d * gt_rd, gt_rd, batch["rays_pano_inds"], batch["pano_frame"], (pH, pW),
-                                                      self.scale, self.depth_grad_loss, self.alpha_grad)
+                                                      self.scale, self.depth_grad_loss, self.alpha_grad, self.sobel_grad)
                 if self.error_maps is not None:
                     self._for_error_map["lidar"] = (r["image_lidar"].detach(), r["depth_lidar"].detach(), gt_rd, gt_i, gt_d)
             else:  # host-side logic tests: the same terms as torch expressions
