@@ -37,6 +37,12 @@ def timed(kind, iters=60):
     return a.elapsed_time(b) / iters
 
 
+if "--forms" in sys.argv:  # each batch through both forms of the render: one-launch gather / level-sliced encode + streaming tail
+    from nvsf import testing
+    for form in (False, True):
+        with testing.variant(density_sliced=form):
+            print("sliced" if form else "gather", "lidar %.4f ms  camera %.4f ms" % (timed("lidar", 200), timed("camera", 200)))
+    sys.exit(0)
 if "--shipped-only" in sys.argv:  # A/B of two builds of the library (tools/ab_run.sh): the two renders as shipped, nothing else
     print("lidar %.4f ms  camera %.4f ms" % (timed("lidar", 300), timed("camera", 300)))
     sys.exit(0)
