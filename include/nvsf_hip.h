@@ -79,11 +79,22 @@ int nvsf_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* 
  * `rays` but write no samples (raymarching.cu:457).
  * Deviation (documented in DESIGN.md): sample ranges are assigned in ray-index order by a prefix
  * sum, not in atomicAdd arrival order, and ray n is recorded at rays[n] (the reference's slot is
- * atomicAdd(counter+1,1), which equals n only up to a permutation). */
+ * atomicAdd(counter+1,1), which equals n only up to a permutation).
+ * Runs the one-launch form below on a scratch block it takes from the device's stream-ordered memory pool for the duration of the
+ * launch (hipMallocAsync / hipFreeAsync on `stream`; no synchronisation), so that the reference's argument list gets the fast
+ * kernel; falls back to nvsf_march_rays_train_passes when the pool cannot serve the block.  As for the one-launch form,
+ * counter[1] < 0 after the call marks a launch whose bounded inter-workgroup wait expired (never seen outside the test that forces
+ * it): the outputs are invalid and the call is to be repeated through nvsf_march_rays_train_passes on the counter as it was. */
 int nvsf_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
                           float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                           const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
                           int32_t* rays, int32_t* counter, const float* noises, nvsf_stream_t stream);
+/* The same operator as count / scan / write launches: no wait between workgroups, no scratch, the same outputs bit for bit.  What
+ * the one-launch form is repeated through when its wait expired, and the form the tests pin it against. */
+int nvsf_march_rays_train_passes(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
+                                 float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
+                                 const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,
+                                 int32_t* rays, int32_t* counter, const float* noises, nvsf_stream_t stream);
 
 /* The same operator in ONE launch (no second classification of the chain, no scan launch): every wave counts its ray once and
  * keeps the sample masks of its batches on chip; worker workgroups publish the sum of each ticket of four rays, one scanner wave
@@ -91,7 +102,7 @@ int nvsf_march_rays_train(const float* rays_o, const float* rays_d, const uint8_
  * arguments, same outputs bit for bit (ray-index order), plus a caller-owned scratch `workspace` of at least
  * nvsf_march_rays_train_ws_bytes(N) bytes (1 KB + 16 bytes per four rays), 8-byte aligned, contents irrelevant on entry (it is cleared on
  * the stream first) and meaningless afterwards.  The reference's signature (raymarching.h:27-44) has no scratch argument, hence
- * the separate entry point; nvsf_march_rays_train stays the reference-shaped one.
+ * the separate entry point for callers that own a scratch block; nvsf_march_rays_train takes one from the stream-ordered pool.
  * counter[1] < 0 after the call (its sign bit set) marks a launch whose bounded inter-workgroup wait expired (outputs invalid; the
  * mark is sticky: later calls on the same counter leave it negative).  `spin_limit` = polls a waiting wave makes before it gives up,
  * 0 = the library's default (2^22); tests pass 1 to force the expiry path. */

@@ -1008,10 +1008,11 @@ NVSF_API int nvsf_packbits(const float* grid, uint32_t N, float density_thresh, 
     return nvsf_launch_status();
 }
 
-NVSF_API int nvsf_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
-                                   uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
-                                   const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays,
-                                   int32_t* counter, const float* noises, hipStream_t stream) {
+// count / scan / write as three launches: no inter-workgroup wait, no scratch (the form the one-launch kernel falls back to)
+NVSF_API int nvsf_march_rays_train_passes(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
+                                          uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
+                                          const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays,
+                                          int32_t* counter, const float* noises, hipStream_t stream) {
     if (N == 0) return NVSF_OK;
     REQUIRE(rays_o && rays_d && grid && nears && fars && xyzs && dirs && deltas && rays && counter && noises);
     REQUIRE(C >= 1 && C <= 8 && H >= 2 && H <= 1024 && max_steps >= 1);
@@ -1066,6 +1067,28 @@ NVSF_API int nvsf_march_rays_train_ws(const float* rays_o, const float* rays_d, 
                        max_steps, N, C, H, M, nears, fars, noises, rays, counter, reinterpret_cast<unsigned long long*>(workspace), xyzs, dirs,
                        deltas, serial, spin_limit ? spin_limit : kMarchSpinLimit, (uint32_t)nvsf_variant(kVarMarchSkew));
     return nvsf_launch_status();
+}
+
+// The reference-shaped entry (raymarching.h:27-44: no scratch argument): the one-launch form on a scratch block taken from and
+// returned to the device's stream-ordered pool around the launch (hipMallocAsync / hipFreeAsync on `stream`: after the first call
+// the pool hands the same block back, no device synchronisation); the three-launch form when the pool has nothing to give or a
+// test selected one of the first formulations.  Expiry of the bounded wait is reported as by nvsf_march_rays_train_ws.
+NVSF_API int nvsf_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
+                                   uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
+                                   const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays,
+                                   int32_t* counter, const float* noises, hipStream_t stream) {
+    if (N == 0) return NVSF_OK;
+    void* scratch = nullptr;
+    const size_t bytes = nvsf_march_rays_train_ws_bytes(N);
+    if (nvsf_variant(kVarMarch) != 0 || hipMallocAsync(&scratch, bytes, stream) != hipSuccess || !scratch) {
+        (void)hipGetLastError();
+        return nvsf_march_rays_train_passes(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays,
+                                            counter, noises, stream);
+    }
+    const int st = nvsf_march_rays_train_ws(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays,
+                                            counter, noises, scratch, bytes, 0u, stream);
+    const hipError_t fr = hipFreeAsync(scratch, stream);
+    return st != NVSF_OK ? st : (fr == hipSuccess ? NVSF_OK : (int)fr);
 }
 
 NVSF_API int nvsf_composite_rays_train_forward(const float* sigmas, const float* rgbs, const float* deltas, const int32_t* rays,

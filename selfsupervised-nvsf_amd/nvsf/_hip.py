@@ -24,6 +24,7 @@ SIGNATURES = {
     "nvsf_morton3D_invert": [_P, _U, _P],
     "nvsf_packbits": [_P, _U, _F, _P],
     "nvsf_march_rays_train": [_P, _P, _P, _F, _F, _U, _U, _U, _U, _U, _P, _P, _P, _P, _P, _P, _P, _P],
+    "nvsf_march_rays_train_passes": [_P, _P, _P, _F, _F, _U, _U, _U, _U, _U, _P, _P, _P, _P, _P, _P, _P, _P],
     "nvsf_march_rays_train_ws": [_P, _P, _P, _F, _F, _U, _U, _U, _U, _U, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_size_t, _U],
     "nvsf_composite_rays_train_forward": [_P, _P, _P, _P, _U, _U, _F, _P, _P, _P],
     "nvsf_composite_rays_train_backward": [_P, _P, _P, _P, _P, _P, _P, _P, _U, _U, _F, _P, _P],

@@ -191,8 +191,9 @@ class _march_rays_train(Function):
                 perturb=False, align=-1, force_all_rays=False, dt_gamma=0, max_steps=1024, _entry="ws", _spin_limit=0):
         """Occupancy-grid sample generation.  Returns xyzs [M,3], dirs [M,3], deltas [M,2], rays int32 [N,3]
         with rays[n] = (ray id, first sample, sample count).
-        `_entry`, `_spin_limit` (not in the reference's signature) are for tests: "ref" selects the reference-shaped
-        three-launch entry point; a spin limit of 1 forces the one-launch kernel's expiry path."""
+        `_entry`, `_spin_limit` (not in the reference's signature) are for tests: "ref" selects the three-launch entry point
+        (nvsf_march_rays_train_passes), "c" the reference-shaped C entry (nvsf_march_rays_train: the one-launch kernel on a scratch
+        block from the stream-ordered pool); a spin limit of 1 forces the one-launch kernel's expiry path."""
         rays_o, rays_d = _rays(rays_o), _rays(rays_d)
         density_bitfield = _dev(density_bitfield).contiguous()
         nears, fars = _dev(nears).contiguous(), _dev(fars).contiguous()
@@ -219,15 +220,16 @@ class _march_rays_train(Function):
             step_counter = torch.zeros(2, dtype=torch.int32, device=dev)
         noises = torch.rand(N, dtype=dt, device=dev) if perturb else torch.zeros(N, dtype=dt, device=dev)
 
-        # one-launch form (nvsf_march_rays_train_ws: counts once, ranges from a scanner wave inside the launch); the reference-shaped
-        # three-launch entry point nvsf_march_rays_train gives the same outputs bit for bit (_entry="ref" selects it)
-        use_ws = N > 0 and _entry != "ref"
+        # one-launch form (nvsf_march_rays_train_ws: counts once, ranges from a scanner wave inside the launch) on a scratch tensor of
+        # torch's allocator; the three-launch entry point nvsf_march_rays_train_passes gives the same outputs bit for bit
+        use_ws = N > 0 and _entry == "ws"
         check_march_status()
         ws_bytes = _hip.march_ws_bytes(N) if use_ws else 0
         workspace = torch.empty(ws_bytes // 8, dtype=torch.int64, device=dev) if use_ws else None
 
         # the read-back path can recover from an expired wait of the one-launch kernel (below): it needs the counter as it was
-        before = step_counter.clone() if (use_ws and sliced) else None
+        one_launch = use_ws or (N > 0 and _entry == "c")
+        before = step_counter.clone() if (one_launch and sliced) else None
 
         def launch(ws=use_ws):
             if ws:
@@ -236,7 +238,8 @@ class _march_rays_train(Function):
                           _hip.ptr(dirs), _hip.ptr(deltas), _hip.ptr(rays), _hip.ptr(step_counter), _hip.ptr(noises), _hip.ptr(workspace),
                           ws_bytes, int(_spin_limit))
                 return
-            _hip.call("nvsf_march_rays_train", _hip.ptr(rays_o), _hip.ptr(rays_d), _hip.ptr(density_bitfield), float(bound),
+            _hip.call("nvsf_march_rays_train" if (_entry == "c" and ws is not None) else "nvsf_march_rays_train_passes", _hip.ptr(rays_o),
+                      _hip.ptr(rays_d), _hip.ptr(density_bitfield), float(bound),
                       float(dt_gamma), int(max_steps), N, int(C), int(H), M, _hip.ptr(nears), _hip.ptr(fars), _hip.ptr(xyzs),
                       _hip.ptr(dirs), _hip.ptr(deltas), _hip.ptr(rays), _hip.ptr(step_counter), _hip.ptr(noises))
         launch()
@@ -245,14 +248,14 @@ class _march_rays_train(Function):
             m, status, first = torch.stack([step_counter[0], step_counter[1], rays[0, 1]]).tolist() if N > 0 else (int(step_counter[0].item()), 0, 0)
             if status < 0 and before is not None and int(before[1]) >= 0:
                 # the one-launch kernel gave up on an inter-workgroup wait (a bounded spin; never seen outside the test that forces
-                # it): nothing of this call is usable, but the reference-shaped three-launch entry point -- no waits between
+                # it): nothing of this call is usable, but the three-launch entry point -- no waits between
                 # workgroups, same outputs bit for bit -- can redo it instead of failing the training run here
                 warnings.warn("nvsf_march_rays_train_ws: a bounded inter-workgroup wait expired; the call is repeated through "
-                              "nvsf_march_rays_train (three launches)")
+                              "nvsf_march_rays_train_passes (three launches)")
                 step_counter.copy_(before)
                 if not sliced:
                     rays.zero_()
-                launch(ws=False)
+                launch(ws=None)
                 m, status, first = torch.stack([step_counter[0], step_counter[1], rays[0, 1]]).tolist()
             if status < 0:
                 raise _hip.NvsfHipError("nvsf_march_rays_train_ws: a bounded inter-workgroup wait expired (counter[1] < 0); "
@@ -275,7 +278,7 @@ class _march_rays_train(Function):
                 xyzs[written:].zero_()
                 dirs[written:].zero_()
                 deltas[written:].zero_()
-        elif use_ws:
+        elif one_launch:
             _note_status(step_counter)
         return xyzs, dirs, deltas, rays
 

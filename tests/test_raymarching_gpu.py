@@ -110,7 +110,7 @@ def test_march_rays_train(rm, dev, scene, n, max_steps, dt_gamma, perturb_seed, 
     to, td, tb, tn, tf, tz = T(o), T(d), T(scene["bits"]), T(nears), T(fars), T(noises)
     xyzs = torch.zeros(M, 3, device=dev); dirs = torch.zeros(M, 3, device=dev); deltas = torch.zeros(M, 2, device=dev)
     rays = torch.empty(n, 3, dtype=torch.int32, device=dev); counter = torch.zeros(2, dtype=torch.int32, device=dev)
-    _hip.call("nvsf_march_rays_train", _hip.ptr(to), _hip.ptr(td), _hip.ptr(tb), 2.0, float(dt_gamma), max_steps, n, 2, 128, M,
+    _hip.call("nvsf_march_rays_train_passes", _hip.ptr(to), _hip.ptr(td), _hip.ptr(tb), 2.0, float(dt_gamma), max_steps, n, 2, 128, M,
               _hip.ptr(tn), _hip.ptr(tf), _hip.ptr(xyzs), _hip.ptr(dirs), _hip.ptr(deltas), _hip.ptr(rays), _hip.ptr(counter), _hip.ptr(tz))
     assert np.array_equal(counter.cpu().numpy(), cr)
     assert np.array_equal(rays.cpu().numpy(), rr)
@@ -172,7 +172,7 @@ def test_march_rays_train_ws_with_skewed_ticket_queues(rm, dev, scene, variants,
     M = n * max_steps
     xyzs = torch.zeros(M, 3, device=dev); dirs = torch.zeros(M, 3, device=dev); deltas = torch.zeros(M, 2, device=dev)
     rays = torch.empty(n, 3, dtype=torch.int32, device=dev); counter = torch.zeros(2, dtype=torch.int32, device=dev)
-    _hip.call("nvsf_march_rays_train", _hip.ptr(to), _hip.ptr(td), _hip.ptr(tb), 2.0, 0.0, max_steps, n, 2, 128, M,
+    _hip.call("nvsf_march_rays_train_passes", _hip.ptr(to), _hip.ptr(td), _hip.ptr(tb), 2.0, 0.0, max_steps, n, 2, 128, M,
               _hip.ptr(tn), _hip.ptr(tf), _hip.ptr(xyzs), _hip.ptr(dirs), _hip.ptr(deltas), _hip.ptr(rays), _hip.ptr(counter), _hip.ptr(tz))
     variants.set(march_skew=queue)
     # a spin limit far below the default (2^22 polls = seconds): a stalled launch fails this test quickly instead of hanging it
@@ -212,7 +212,7 @@ def test_march_rays_train_ws_equals_three_launch_form(rm, dev, scene, kind, dt_g
     for M, c0 in ((n * max_steps, (0, 0)), (n * max_steps // 8, (40, 3))):
         xyzs = torch.zeros(M, 3, device=dev); dirs = torch.zeros(M, 3, device=dev); deltas = torch.zeros(M, 2, device=dev)
         rays = torch.empty(n, 3, dtype=torch.int32, device=dev); counter = torch.tensor(list(c0), dtype=torch.int32, device=dev)
-        _hip.call("nvsf_march_rays_train", _hip.ptr(to), _hip.ptr(td), _hip.ptr(tb), 2.0, float(dt_gamma), max_steps, n, 2, 128, M,
+        _hip.call("nvsf_march_rays_train_passes", _hip.ptr(to), _hip.ptr(td), _hip.ptr(tb), 2.0, float(dt_gamma), max_steps, n, 2, 128, M,
                   _hip.ptr(tn), _hip.ptr(tf), _hip.ptr(xyzs), _hip.ptr(dirs), _hip.ptr(deltas), _hip.ptr(rays), _hip.ptr(counter), _hip.ptr(tz))
         ref = (counter.cpu(), rays.cpu(), xyzs.cpu(), dirs.cpu(), deltas.cpu())
         got = _march_ws(dev, to, td, tb, tn, tf, tz, n, max_steps, dt_gamma, M, c0)
@@ -242,7 +242,9 @@ def test_march_rays_train_other_grid_shapes(rm, dev, C, H, bound, dt_gamma):
     assert m > 10000
     T = lambda a: _t(a, dev)
     to, td, tb, tn, tf, tz = T(o), T(d), T(bits), T(nears), T(fars), T(noises)
-    for entry in ("nvsf_march_rays_train", "nvsf_march_rays_train_ws"):
+    # the three-launch form, the reference-shaped entry (one launch on a scratch block of the stream-ordered pool) and the one-launch
+    # form on a caller-owned scratch block
+    for entry in ("nvsf_march_rays_train_passes", "nvsf_march_rays_train", "nvsf_march_rays_train_ws"):
         xyzs = torch.zeros(M, 3, device=dev); dirs = torch.zeros(M, 3, device=dev); deltas = torch.zeros(M, 2, device=dev)
         rays = torch.empty(n, 3, dtype=torch.int32, device=dev); counter = torch.zeros(2, dtype=torch.int32, device=dev)
         extra = ()
@@ -274,7 +276,7 @@ def test_march_rays_train_ws_more_tickets_than_workgroups(rm, dev, p, dt_gamma):
     M = n * max_steps
     xyzs = torch.zeros(M, 3, device=dev); dirs = torch.zeros(M, 3, device=dev); deltas = torch.zeros(M, 2, device=dev)
     rays = torch.empty(n, 3, dtype=torch.int32, device=dev); counter = torch.zeros(2, dtype=torch.int32, device=dev)
-    _hip.call("nvsf_march_rays_train", _hip.ptr(to), _hip.ptr(td), _hip.ptr(tb), 2.0, float(dt_gamma), max_steps, n, 2, 128, M,
+    _hip.call("nvsf_march_rays_train_passes", _hip.ptr(to), _hip.ptr(td), _hip.ptr(tb), 2.0, float(dt_gamma), max_steps, n, 2, 128, M,
               _hip.ptr(tn), _hip.ptr(tf), _hip.ptr(xyzs), _hip.ptr(dirs), _hip.ptr(deltas), _hip.ptr(rays), _hip.ptr(counter), _hip.ptr(tz))
     ref = (counter.cpu(), rays.cpu(), xyzs.cpu(), dirs.cpu(), deltas.cpu())
     assert int(ref[0][0]) > 100000 and int(ref[0][1]) == n
@@ -311,7 +313,7 @@ def test_march_rays_train_wave_forms_equal_the_thread_form(rm, dev, scene, kind,
         variants.set(march=march)
         xyzs = torch.zeros(M, 3, device=dev); dirs = torch.zeros(M, 3, device=dev); deltas = torch.zeros(M, 2, device=dev)
         rays = torch.empty(n, 3, dtype=torch.int32, device=dev); counter = torch.zeros(2, dtype=torch.int32, device=dev)
-        _hip.call("nvsf_march_rays_train", _hip.ptr(to), _hip.ptr(td), _hip.ptr(tb), 2.0, float(dt_gamma), max_steps, n, 2, 128, M,
+        _hip.call("nvsf_march_rays_train_passes", _hip.ptr(to), _hip.ptr(td), _hip.ptr(tb), 2.0, float(dt_gamma), max_steps, n, 2, 128, M,
                   _hip.ptr(tn), _hip.ptr(tf), _hip.ptr(xyzs), _hip.ptr(dirs), _hip.ptr(deltas), _hip.ptr(rays), _hip.ptr(counter), _hip.ptr(tz))
         out[march] = (counter.cpu(), rays.cpu(), xyzs.cpu(), dirs.cpu(), deltas.cpu())
     total = int(out["thread"][0][0])
@@ -467,3 +469,53 @@ def test_march_rays_train_expired_wait_is_reported(rm, dev, scene):
     out = rm.march_rays_train(to, td, 2.0, tb, 2, 128, tn, tf, None, -1, False, 128, True, 0, max_steps)
     assert out[0].shape[0] > 0
     rm.check_march_status(wait=True)
+
+
+def test_reference_shaped_entry_takes_its_scratch_from_the_stream_ordered_pool(rm, dev):
+    """nvsf_march_rays_train has the reference's argument list (raymarching.h:27-44: no scratch) and runs the one-launch kernel on a block
+    it takes from the device's stream-ordered pool around the launch: repeated calls, calls of different sizes back to back and calls on
+    two streams give what nvsf_march_rays_train_passes gives, bit for bit; the wrapper's `_entry="c"` goes through it."""
+    from nvsf import _hip
+    rng = np.random.default_rng(41)
+    C, H, bound, max_steps = 2, 128, 2.0, 256
+    grid = (rng.random((C, H ** 3)) < 0.3).astype(np.float32)
+    bits = O.packbits(grid, 0.5)
+    tb = _t(bits, dev)
+    side = torch.cuda.Stream(device=dev)
+
+    def run(entry, n, stream=None):
+        r = np.random.default_rng(n)
+        o = ((r.random((n, 3)) * 2 - 1) * 0.5).astype(np.float32)
+        d = r.normal(size=(n, 3)).astype(np.float32)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        nears, fars = O.near_far_from_aabb(o, d, np.array([-bound] * 3 + [bound] * 3, np.float32), 0.02)
+        M = n * max_steps
+        to, td, tn, tf = _t(o, dev), _t(d, dev), _t(nears, dev), _t(fars, dev)
+        tz = torch.zeros(n, device=dev)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream()):
+            xyzs = torch.zeros(M, 3, device=dev); dirs = torch.zeros(M, 3, device=dev); deltas = torch.zeros(M, 2, device=dev)
+            rays = torch.empty(n, 3, dtype=torch.int32, device=dev); counter = torch.zeros(2, dtype=torch.int32, device=dev)
+            _hip.call(entry, _hip.ptr(to), _hip.ptr(td), _hip.ptr(tb), bound, 0.0, max_steps, n, C, H, M, _hip.ptr(tn), _hip.ptr(tf),
+                      _hip.ptr(xyzs), _hip.ptr(dirs), _hip.ptr(deltas), _hip.ptr(rays), _hip.ptr(counter), _hip.ptr(tz))
+        torch.cuda.synchronize()
+        m = int(counter[0])
+        return counter.cpu(), rays.cpu(), xyzs[:m].cpu(), dirs[:m].cpu(), deltas[:m].cpu()
+
+    for n, stream in ((700, None), (4000, None), (700, None), (33, side), (4000, side), (1, None)):
+        ref = run("nvsf_march_rays_train_passes", n)
+        got = run("nvsf_march_rays_train", n, stream)
+        assert int(ref[0][0]) > 0 and int(got[0][1]) == n
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b), (n, stream is not None)
+    # through the drop-in wrapper
+    n = 500
+    r = np.random.default_rng(5)
+    o = _t(((r.random((n, 3)) * 2 - 1) * 0.5).astype(np.float32), dev)
+    d = torch.nn.functional.normalize(_t(r.normal(size=(n, 3)).astype(np.float32), dev), dim=-1)
+    nears, fars = rm.near_far_from_aabb(o, d, torch.tensor([-bound] * 3 + [bound] * 3, device=dev), 0.02)
+    outs = {e: rm.march_rays_train(o, d, bound, tb, C, H, nears, fars, None, -1, False, -1, True, 0, max_steps, e) for e in ("ws", "c", "ref")}
+    for e in ("c", "ref"):
+        for a, b in zip(outs["ws"], outs[e]):
+            assert torch.equal(a, b), e
+    assert outs["ws"][0].shape[0] > 1000

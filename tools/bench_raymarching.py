@@ -100,7 +100,16 @@ def raymarching_rooflines(dev, n_rays_march=32768, occupied=1.0, seed=0):
                   P(xyzs), P(dirs), P(deltas), P(rays), P(counter), P(noises))
     ms = _time_ms(march, 5)
     m = int(counter[0].item())
-    rows.append(_row(f"march_rays_train[{occupied:.0%} occupied, reference-shaped entry: count / scan / write launches]", ms, 48 * N + 32 * m,
+    rows.append(_row(f"march_rays_train[{occupied:.0%} occupied, reference-shaped entry: one launch, scratch from the stream-ordered pool]", ms,
+                     48 * N + 32 * m, "48 B/ray + 32 B/sample", m))
+
+    def march_passes():
+        counter.zero_()
+        _hip.call("nvsf_march_rays_train_passes", P(o), P(d), P(bitfield), bound, 0.0, max_steps, N, C, H, M, P(nears), P(fars),
+                  P(xyzs), P(dirs), P(deltas), P(rays), P(counter), P(noises))
+    ms = _time_ms(march_passes, 5)
+    assert int(counter[0].item()) == m
+    rows.append(_row(f"march_rays_train_passes[{occupied:.0%} occupied: count / scan / write launches]", ms, 48 * N + 32 * m,
                      "48 B/ray + 32 B/sample", m))
     ws_bytes = _hip.march_ws_bytes(N)
     workspace = torch.empty(ws_bytes // 8, dtype=torch.int64, device=dev)
