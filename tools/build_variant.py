@@ -1,6 +1,6 @@
 """Experiment helper: a copy of the library with ONE translation unit compiled with extra -D flags.
 
-    python tools/build_variant.py fused_field.hip lib_exp/aux2.so -DNVSF_FINE_AUX=2
+    python tools/build_variant.py fused_field.hip lib_exp/variant.so -DSOME_SWITCH=1   # a switch the translation unit reads under #ifdef for the experiment
 
 The production library is built first (build.py); the variant re-uses its objects.  For tools/ab_run.sh / ab_headline.sh.
 """
