@@ -27,7 +27,7 @@ static inline unsigned cdiv(unsigned long long a, unsigned b) { return (unsigned
 enum NvsfVariantKey : int {
     kVarMarch = 0,      // march_rays_train: 0 wave kernels / one launch, 1 one thread per ray, 2 wave kernels walking a batch member by member
     kVarPlanesFwd,      // 0 rows walked along the ray, 1 one thread per (sample, scale)
-    kVarPlanesBwd,      // 0 run-merging, 1 one atomic per (sample, texel, channel)
+    kVarPlanesBwd,      // 0 run-merging (multi entry: time planes through an LDS image), 1 one atomic per (sample, texel, channel), 2 as 0 with global atomics only
     kVarHashgridFwd,    // 0 level-per-XCD where eligible, 1 the generic row kernel
     kVarHashgridBwd,    // 0 corner-parallel run merging, 1 one thread per (row, level)
     kVarHash4dBwd,      // 0 LDS accumulation, 1 run-merging global atomics

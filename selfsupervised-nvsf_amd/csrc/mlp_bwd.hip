@@ -39,23 +39,46 @@ struct GoCompose {
     const float* geo_b;
     uint32_t stride;
     float lo, hi;
-    // the eight values of lane group g of sample row `row`: outputs 8 (g & 1) .. + 7
-    __device__ __forceinline__ void load(size_t row, int g, float (&go)[8]) const {
+    // The operands of lane group g of sample row `row` (outputs 8 (g & 1) .. + 7) in two steps.  issue(): LOADS ONLY -- the operands of
+    // iteration it + 1 are requested while iteration it computes, and anything here that consumed a returned value (the first form
+    // summed the two heads' rows and multiplied sigma inside the fetch) puts an s_waitcnt vmcnt(0) right behind the request: the
+    // whole memory latency exposed once per iteration, k_mlp_bwd<1,1> 173 -> 336 us in the config-4 step.
+    // compose(): the arithmetic, where the values are consumed one iteration later.  Every lane loads all four scalars (column 7 of
+    // both rows, grad_sigma, sigma -- lines its 16-byte loads touch anyway) so that no load sits behind a lane-dependent branch.
+    __device__ __forceinline__ void issue(size_t row, int g, float (&raw)[8], float (&ex)[12]) const {
         const uint32_t h = (uint32_t)g & 1u;
         const float* ra = geo_a + row * stride;
         const float4* pa = reinterpret_cast<const float4*>(ra) + 2 * h;
-        float4 a = pa[0], b = pa[1];
-        float prev = h ? ra[7] : 0.0f;
-        if (geo_b) {
+        const float4 a = pa[0], b = pa[1];
+        raw[0] = a.x; raw[1] = a.y; raw[2] = a.z; raw[3] = a.w; raw[4] = b.x; raw[5] = b.y; raw[6] = b.z; raw[7] = b.w;
+        ex[8] = ra[7];
+        ex[10] = (grad_sigma ? grad_sigma : sigma)[row];  // (a select of the POINTER: a select of load-or-constant makes the compiler park the constant in scratch)
+        ex[11] = sigma[row];
+        if (geo_b) {  // uniform
             const float* rb = geo_b + row * stride;
             const float4* pb = reinterpret_cast<const float4*>(rb) + 2 * h;
             const float4 a2 = pb[0], b2 = pb[1];
-            a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
-            b.x += b2.x; b.y += b2.y; b.z += b2.z;
-            if (h) prev += rb[7];
+            ex[0] = a2.x; ex[1] = a2.y; ex[2] = a2.z; ex[3] = a2.w; ex[4] = b2.x; ex[5] = b2.y; ex[6] = b2.z; ex[7] = b2.w;
+            ex[9] = rb[7];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ex[j] = 0.0f;
+            ex[9] = 0.0f;
         }
-        if (!h) prev = grad_sigma ? grad_sigma[row] * fminf(fmaxf(sigma[row], lo), hi) : 0.0f;
-        go[0] = prev; go[1] = a.x; go[2] = a.y; go[3] = a.z; go[4] = a.w; go[5] = b.x; go[6] = b.y; go[7] = b.z;
+    }
+    __device__ __forceinline__ void compose(int g, const float (&raw)[8], const float (&ex)[12], float (&go)[8]) const {
+        const bool h = (g & 1) != 0;
+        float v[7] = {raw[0], raw[1], raw[2], raw[3], raw[4], raw[5], raw[6]};
+        float prev = ex[8];
+        if (geo_b) {  // uniform
+#pragma unroll
+            for (int j = 0; j < 7; ++j) v[j] += ex[j];
+            prev += ex[9];
+        }
+        if (!h) prev = grad_sigma ? ex[10] * fminf(fmaxf(ex[11], lo), hi) : 0.0f;
+        go[0] = prev;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) go[1 + j] = v[j];
     }
 };
 
@@ -121,7 +144,7 @@ __device__ __forceinline__ void relu_mask(float4_t (&gacc)[kHidTiles], const hal
             if (!(h[t >> 1][(t & 1) * 4 + r] > (_Float16)0.0f)) gacc[t][r] = 0.0f;
 }
 
-template <int IN_STEPS, int N_HIDDEN, bool X_F16, bool FAST>
+template <int IN_STEPS, int N_HIDDEN, bool X_F16, bool FAST, bool COMPOSE>
 __global__ __launch_bounds__(kBlock) void k_mlp_bwd(const void* __restrict__ x, uint32_t M, uint32_t n_in, uint32_t x_stride,
                                                     const _Float16* __restrict__ weights, uint32_t in_cols,
                                                     const float* __restrict__ grad_out, uint32_t n_out, uint32_t go_stride, float grad_scale,
@@ -164,10 +187,11 @@ __global__ __launch_bounds__(kBlock) void k_mlp_bwd(const void* __restrict__ x, 
     struct Operands {
         half8_t xf[IN_STEPS];
         float go[8];
+        float ex[COMPOSE ? 12 : 1];  // COMPOSE: the second head's row and the four scalars, as loaded
         uint32_t m;
         bool valid;
     };
-    auto fetch = [&](uint32_t it, Operands& op) {
+    auto fetch = [&](uint32_t it, Operands& op) __attribute__((always_inline)) {
         const uint32_t tile = (it * gridDim.x + blockIdx.x) * kWavesPerBlock + (uint32_t)w;
         op.m = tile * 16 + (uint32_t)c;
         op.valid = tile < n_tiles && op.m < M;
@@ -176,8 +200,8 @@ __global__ __launch_bounds__(kBlock) void k_mlp_bwd(const void* __restrict__ x, 
         const _Float16* prow = pre.a ? pre.row_of((tile_u < n_tiles && tile_u * 16u < M) ? tile_u * 16u : M - 1u) : nullptr;
         issue_x_row<IN_STEPS, X_F16, FAST>(op.xf, x, row, x_stride, g, (int)n_in, (int)in_cols, vec_ok != 0, tail, prow, pre.split);
         const float* go_row = grad_out + row * go_stride;
-        if (gc.sigma) {  // density network: the logit gradient composed from (grad_sigma, sigma, geometry gradient rows)
-            gc.load(row, g, op.go);
+        if constexpr (COMPOSE) {  // density network: the logit gradient composed from (grad_sigma, sigma, geometry gradient rows)
+            gc.issue(row, g, op.go, op.ex);
         } else if (go_vec) {  // 16 outputs, 16-byte aligned rows: two 16-byte loads for the lanes that hold outputs (g < 2)
             const float4* p = reinterpret_cast<const float4*>(go_row) + 2 * (g & 1);
             const float4 a = p[0], b = p[1];
@@ -230,8 +254,15 @@ __global__ __launch_bounds__(kBlock) void k_mlp_bwd(const void* __restrict__ x, 
         const half8_t(&h_last)[kHidSteps] = N_HIDDEN == 2 ? h1 : h0;
         // ---- output gradient -> B fragment (natural order of the 16 outputs, zero beyond n_out, scaled)
         half8_t go;
+        float gov[8];
+        if constexpr (COMPOSE) {
+            gc.compose(g, cur.go, cur.ex, gov);
+        } else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) go[j] = (valid && g < 2 && 8u * g + j < n_out) ? (_Float16)(cur.go[j] * grad_scale) : (_Float16)0.0f;
+            for (int j = 0; j < 8; ++j) gov[j] = cur.go[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) go[j] = (valid && g < 2 && 8u * g + j < n_out) ? (_Float16)(gov[j] * grad_scale) : (_Float16)0.0f;
         // ---- data path backward
         float4_t gacc[kHidTiles];
 #pragma unroll
@@ -403,7 +434,7 @@ __device__ __forceinline__ void mfma16_agpr(float4_t& acc, half8_t a, half8_t b)
     asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
 }
 
-template <int IN_STEPS, int N_HIDDEN, bool X_F16, bool FAST>
+template <int IN_STEPS, int N_HIDDEN, bool X_F16, bool FAST, bool COMPOSE>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_mlp_bwd_wave(
     const void* __restrict__ x, uint32_t M, uint32_t n_in, uint32_t x_stride, const _Float16* __restrict__ weights, uint32_t in_cols,
     const float* __restrict__ grad_out, uint32_t n_out, uint32_t go_stride, float grad_scale, float* __restrict__ grad_x, uint32_t gx_stride,
@@ -452,10 +483,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) 
     struct Operands {
         half8_t xf[IN_STEPS];
         float go[8];
+        float ex[COMPOSE ? 12 : 1];  // COMPOSE: the second head's row and the four scalars, as loaded
         uint32_t m;
         bool valid;
     };
-    auto fetch = [&](uint32_t it, int u, Operands& op) {
+    auto fetch = [&](uint32_t it, int u, Operands& op) __attribute__((always_inline)) {
         const uint32_t tile = 2u * ((it * gridDim.x + blockIdx.x) * kWavesPerBlock + (uint32_t)w) + (uint32_t)u;
         op.m = tile * 16 + (uint32_t)c;
         op.valid = tile < n_tiles && op.m < M;
@@ -464,8 +496,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) 
         const _Float16* prow = pre.a ? pre.row_of((tile_u < n_tiles && tile_u * 16u < M) ? tile_u * 16u : M - 1u) : nullptr;
         issue_x_row<IN_STEPS, X_F16, FAST>(op.xf, x, row, x_stride, g, (int)n_in, (int)in_cols, vec_ok != 0, tail, prow, pre.split);
         const float* go_row = grad_out + row * go_stride;
-        if (gc.sigma) {
-            gc.load(row, g, op.go);
+        if constexpr (COMPOSE) {
+            gc.issue(row, g, op.go, op.ex);
         } else if (go_vec) {
             const float4* p = reinterpret_cast<const float4*>(go_row) + 2 * (g & 1);
             const float4 a = p[0], b = p[1];
@@ -495,6 +527,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) 
             for (int s = 0; s < IN_STEPS; ++s) xf[u][s] = next[u].xf[s];
 #pragma unroll
             for (int j = 0; j < 8; ++j) gor[u][j] = next[u].go[j];
+            if constexpr (COMPOSE) gc.compose(g, next[u].go, next[u].ex, gor[u]);
             m[u] = next[u].m;
             valid[u] = next[u].valid;
             if constexpr (FAST) xf[u][IN_STEPS - 1] = tail.apply(xf[u][IN_STEPS - 1]);
@@ -733,20 +766,27 @@ static int mlp_bwd_impl(const void* x, int x_is_f16, uint32_t M, uint32_t n_in, 
         blocks = (n_pairs + kWavesPerBlock - 1) / kWavesPerBlock;
         if (blocks > cus) blocks = cus;
     }
-#define LAUNCH(S, H, XF, FA)                                                                                                               \
+#define LAUNCH(S, H, XF, FA, CO)                                                                                                           \
     do {                                                                                                                                   \
         if (staged)                                                                                                                        \
-            hipLaunchKernelGGL((k_mlp_bwd<S, H, XF, FA>), dim3(blocks), dim3(kBlock), 0, stream, x, M, n_in, x_stride, w, in_cols,        \
+            hipLaunchKernelGGL((k_mlp_bwd<S, H, XF, FA, CO>), dim3(blocks), dim3(kBlock), 0, stream, x, M, n_in, x_stride, w, in_cols,    \
                                grad_out, n_out, go_stride, grad_scale, grad_x, gx_stride, grad_weights_f32, vec_ok, gx_col0,              \
-                               gx_accumulate, go_vec, pre, gc);                                                                                \
+                               gx_accumulate, go_vec, pre, gc);                                                                            \
         else                                                                                                                               \
-            hipLaunchKernelGGL((k_mlp_bwd_wave<S, H, XF, FA>), dim3(blocks), dim3(kBlock), 0, stream, x, M, n_in, x_stride, w, in_cols,   \
-                               grad_out, n_out, go_stride, grad_scale, grad_x, gx_stride, grad_weights_f32, vec_ok, gx_col0,              \
-                               gx_accumulate, go_vec, pre, gc);                                                                                \
+            hipLaunchKernelGGL((k_mlp_bwd_wave<S, H, XF, FA, CO>), dim3(blocks), dim3(kBlock), 0, stream, x, M, n_in, x_stride, w,        \
+                               in_cols, grad_out, n_out, go_stride, grad_scale, grad_x, gx_stride, grad_weights_f32, vec_ok, gx_col0,     \
+                               gx_accumulate, go_vec, pre, gc);                                                                            \
     } while (0)
-#define BY_F(S, H, XF) do { if (fast) LAUNCH(S, H, XF, true); else LAUNCH(S, H, XF, false); } while (0)
-#define BY_X(S, H) do { if (x_is_f16) BY_F(S, H, true); else BY_F(S, H, false); } while (0)
-#define BY_H(S) do { if (n_hidden == 1) BY_X(S, 1); else BY_X(S, 2); } while (0)
+// the composed operand fetch is built for the density networks' shape only: ONE hidden layer (sigma_net, network_dynamic.py:125-135)
+#define BY_C1(S, XF, FA) do { if (gc.sigma) LAUNCH(S, 1, XF, FA, true); else LAUNCH(S, 1, XF, FA, false); } while (0)
+#define BY_F1(S, XF) do { if (fast) BY_C1(S, XF, true); else BY_C1(S, XF, false); } while (0)
+#define BY_F2(S, XF) do { if (fast) LAUNCH(S, 2, XF, true, false); else LAUNCH(S, 2, XF, false, false); } while (0)
+#define BY_H(S)                                                                                                                            \
+    do {                                                                                                                                   \
+        if (n_hidden == 1) { if (x_is_f16) BY_F1(S, true); else BY_F1(S, false); }                                                         \
+        else { if (x_is_f16) BY_F2(S, true); else BY_F2(S, false); }                                                                       \
+    } while (0)
+    if (gc.sigma && n_hidden != 1) return NVSF_ERR_UNSUPPORTED;
     switch (in_steps) {
         case 1: BY_H(1); break;
         case 2: BY_H(2); break;

@@ -571,6 +571,230 @@ __global__ __launch_bounds__(kBlock) void k_planes_multi_bwd_runs(PlaneGradEvals
         if (acc[j] != 0.0f) atomicAdd(g_planes + dst[j], acc[j]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The TIME-plane evaluations of nvsf_planes_multi_bwd through an on-chip image (the production form; k_planes_multi_bwd_runs keeps the
+// spatial planes and is the test reference for these).
+//
+// Every evaluation of the multi entry has ONE time t_e for all its rows, so the three time planes (xt, yt, zt) of a scale are only ever
+// touched in the two rows Y0, Y1 around t_e: 2 x W texels per plane, W = 32 ... 256.  The run-merging kernel sends every run sum of
+// every item of every evaluation there as a memory-side fp32 atomic: at 4096 x 768 rows a texel of those rows receives 10^5 - 10^6
+// addends, (i) at the slowest atomic rate there is (many adders on a few lines), 2.6 ms per launch at 2048 + 2048 rays, 5.2 ms at
+// 4096 + 4096 -- the largest kernel of the config-5 training step -- and (ii) in an order that changes from run to run: 1e-4 of the
+// largest entry between two runs of the SAME step (GPUTEST_r05), 27 x the error of one evaluation against fp64.
+//
+// Here a workgroup owns (slice of the chunks, evaluation, scale): its items walk their rows exactly as the items of the run-merging
+// kernel do -- same taps (make_tap), same gathers, same products, same run sums in registers -- and a run sum goes into a 64-bit
+// FIXED-POINT image of the scale's three time planes in LDS (ds_add_u64; integer adds commute: the image does not depend on the order
+// in which the waves arrive).  The image is 1-D: the weights of the two time rows are the same for every row of the launch, so the
+// two time-row lanes of a texel column are added first (one DPP add) and the image holds G[plane][X][channel] = sum g v v wx (wy0 +
+// wy1); the final pass adds wy0 G and wy1 G to rows Y0, Y1 of the global gradient with contiguous fp32 atomics -- one addend per
+// (slice, evaluation) and texel: ~130 instead of 10^5 - 10^6.  Scale of the image: 2^(36 - e), e the exponent of a bound of the
+// workgroup's addends (largest |g| of its slice x g_scale x the product of the two largest |texel| of the planes' two rows; the
+// interpolated values are convex combinations): exact product, one truncation per run sum at 2^-36 of the bound; a run sum is at
+// most 2 x 128 addends (2^45), a slice at most 2^17 rows: no overflow.  Non-finite gradients or texels (GradScaler overflow steps)
+// are kept out of the image and reported as a NaN in the scale's first time texel, as k_hash_dynamic_bwd_lds does.
+constexpr int kTimeBlock = 512;             // 8 waves = 16 items of 32 lanes
+constexpr int kTimeItems = kTimeBlock / 32;
+
+struct TimeTap {
+    uint32_t Y0, Y1;
+    float wy0, wy1;   // (y1 - iy), (iy - y0) of make_tap
+};
+__device__ __forceinline__ TimeTap make_time_tap(float t, uint32_t H) {
+    float iy = ((t * 2.0f - 1.0f + 1.0f) / 2.0f) * (float)(H - 1);
+    iy = fminf((float)(H - 1), fmaxf(iy, 0.0f));
+    const float y0 = floorf(iy), y1 = y0 + 1.0f;
+    TimeTap r;
+    r.wy0 = y1 - iy; r.wy1 = iy - y0;
+    r.Y0 = (uint32_t)y0; r.Y1 = r.Y0 + 1 < H ? r.Y0 + 1 : H - 1;
+    return r;
+}
+
+__global__ __launch_bounds__(kTimeBlock) void k_planes_multi_bwd_time_lds(PlaneGradEvals ev, uint32_t M, const float* __restrict__ planes,
+                                                                          PlaneMeta meta, int live, float* __restrict__ g_planes, uint32_t run,
+                                                                          uint32_t chunks_per_slice) {
+    extern __shared__ unsigned long long s_img[];         // [W0 * 8 | W1 * 8 | W2 * 8]
+    __shared__ float s_tap_ix[kTimeItems][32][3];         // per item: the x half of the taps of a round of 32 rows (make_tap's ix, x0)
+    __shared__ uint32_t s_tap_x0[kTimeItems][32][3];
+    __shared__ float s_red[4][kTimeBlock / kWave];
+    __shared__ int s_bad;
+    const int lane = lane_id();
+    const int k32 = lane & 31, tex = (lane >> 2) & 3, ch = (lane & 3) | ((lane >> 2) & 4);
+    const uint32_t slot = blockIdx.y / meta.n_scales, s = blockIdx.y - slot * meta.n_scales;
+    const float* gbase = nullptr;
+    const float* off = nullptr;
+    uint32_t off_stride = 0, off_col = 0, stride = 0;
+    float t_e = 0.0f, g_scale = 1.0f;
+    {
+        uint32_t seen = 0;
+#pragma unroll
+        for (int e = 0; e < kMaxEval; ++e) {
+            if (!((live >> e) & 1)) continue;
+            if (seen == slot) {
+                gbase = ev.g[e]; off = ev.off[e]; off_stride = ev.off_stride[e]; off_col = ev.off_col[e]; t_e = ev.t[e];
+                stride = ev.g_stride[e]; g_scale = ev.g_scale[e];
+            }
+            ++seen;
+        }
+    }
+    const uint32_t n_chunks = (uint32_t)(((unsigned long long)M + run - 1) / run);
+    const uint32_t c_lo = blockIdx.x * chunks_per_slice, c_hi = c_lo + chunks_per_slice < n_chunks ? c_lo + chunks_per_slice : n_chunks;
+    if (gbase == nullptr || c_lo >= c_hi) return;  // uniform over the workgroup
+    const uint32_t W[3] = {meta.res[s][0], meta.res[s][1], meta.res[s][2]}, H = meta.res[s][3];
+    const uint32_t poff[3] = {meta.off[s][2], meta.off[s][4], meta.off[s][5]};  // pairs (0,3), (1,3), (2,3)
+    const uint32_t ioff[3] = {0u, W[0] * kC, (W[0] + W[1]) * kC};
+    const uint32_t n_img = (W[0] + W[1] + W[2]) * kC;
+    const TimeTap ty = make_time_tap(t_e, H);
+    const uint32_t m_lo = c_lo * run, m_hi = (unsigned long long)c_hi * run < M ? c_hi * run : M;
+
+    // ---- bound of the slice's addends --------------------------------------------------------------------------------------------
+    float mx[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // |g|, |texel| of the three planes' two rows
+    bool bad = false;
+    for (uint32_t i = threadIdx.x; i < (m_hi - m_lo) * kC; i += kTimeBlock) {
+        const float a = fabsf(gbase[(size_t)(m_lo + (i >> 3)) * stride + s * kC + (i & 7u)]);
+        if (a <= 3.402823466e38f) mx[0] = fmaxf(mx[0], a);
+        else bad = true;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const uint32_t row_len = W[j] * kC;
+        for (uint32_t i = threadIdx.x; i < 2u * row_len; i += kTimeBlock) {
+            const uint32_t Y = i < row_len ? ty.Y0 : ty.Y1, c = i < row_len ? i : i - row_len;
+            const float a = fabsf(planes[poff[j] + (size_t)Y * row_len + c]);
+            if (a <= 3.402823466e38f) mx[1 + j] = fmaxf(mx[1 + j], a);
+            else bad = true;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx[q] = fmaxf(mx[q], __shfl_xor(mx[q], o));
+        if (lane == 0) s_red[q][threadIdx.x >> 6] = mx[q];
+    }
+    if (threadIdx.x == 0) s_bad = 0;
+    for (uint32_t i = threadIdx.x; i < n_img; i += kTimeBlock) s_img[i] = 0ull;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        mx[q] = 0.0f;
+        for (int wv = 0; wv < kTimeBlock / kWave; ++wv) mx[q] = fmaxf(mx[q], s_red[q][wv]);
+    }
+    const float v_lo = fminf(mx[1], fminf(mx[2], mx[3]));
+    const float vv = v_lo == mx[1] ? mx[2] * mx[3] : (v_lo == mx[2] ? mx[1] * mx[3] : mx[1] * mx[2]);  // product of the two largest
+    const float bound = (mx[0] * fabsf(g_scale)) * vv;
+    float* const poison = g_planes + poff[0] + (size_t)ty.Y0 * W[0] * kC;
+    if (!(bound > 0.0f) || !(bound <= 3.402823466e38f)) {  // uniform: nothing to add, or nothing finite
+        if (bad || bound > 0.0f) s_bad = 1;
+        __syncthreads();
+        if (s_bad != 0 && threadIdx.x == 0) atomicAdd(poison, __builtin_nanf(""));
+        return;
+    }
+    int e = (int)((__float_as_uint(bound) >> 23) & 0xFFu) - 127;
+    e = e < -90 ? -90 : e;
+    const float to_fixed = __builtin_ldexpf(1.0f, 36 - e);
+
+    // ---- the walk: k_planes_multi_bwd_runs' item, its run sums into the image ----------------------------------------------------
+    const uint32_t it = threadIdx.x >> 5;
+    float acc[3] = {0.0f, 0.0f, 0.0f};
+    uint32_t cur[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, dst[3] = {0u, 0u, 0u};
+    const float wy = (tex & 2) ? ty.wy1 : ty.wy0;
+    const uint32_t Yl = (tex & 2) ? ty.Y1 : ty.Y0;
+#define NVSF_TIME_FLUSH(j)                                                                                                          \
+    {                                                                                                                               \
+        const float G = acc[j] + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc[j]), 0x128 /* row_ror:8 */, 0xF, 0xF, false)); \
+        if (!(tex & 2) && G != 0.0f) {                                                                                              \
+            if (fabsf(G) <= 3.402823466e38f) atomicAdd(&s_img[ioff[j] + dst[j]], (unsigned long long)(long long)(G * to_fixed));    \
+            else bad = true;                                                                                                        \
+        }                                                                                                                           \
+        acc[j] = 0.0f;                                                                                                              \
+    }
+    for (uint32_t c0 = c_lo; c0 < c_hi; c0 += kTimeItems) {  // uniform trip count over the workgroup
+        const uint32_t c = c0 + it;
+        const bool active = c < c_hi;
+        const uint32_t m0 = active ? c * run : 0u, m1 = active ? (m0 + run < M ? m0 + run : M) : 0u;
+        const uint32_t n_rows = m1 - m0;
+        for (uint32_t r0 = 0; r0 < run; r0 += 32) {
+            {   // lane k32: the x taps of row r0 + k32 at the evaluation's own position
+                const uint32_t r = r0 + (uint32_t)k32;
+                const uint32_t m = r < n_rows ? m0 + r : (M - 1);
+                const float* px = ev.x + (size_t)m * ev.x_stride;
+                float p[3] = {px[0], px[1], px[2]};
+                if (off) {
+                    const float* po = off + (size_t)m * off_stride + off_col;
+                    p[0] = p[0] + po[0]; p[1] = p[1] + po[1]; p[2] = p[2] + po[2];  // fp32 adds, as torch.add forms x + flow
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const Tap t = make_tap(p[j], t_e, W[j], H);
+                    s_tap_ix[it][k32][j] = t.ix_f;
+                    s_tap_x0[it][k32][j] = (uint32_t)t.x0;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (uint32_t k = 0; k < 32u; ++k) {
+                const uint32_t r = r0 + k;
+                const bool row_ok = r < n_rows;
+                const uint32_t m = row_ok ? m0 + r : (M - 1);
+                float g = row_ok ? gbase[(size_t)m * stride + s * kC + ch] * g_scale : 0.0f;
+                if (!(fabsf(g) <= 3.402823466e38f)) g = 0.0f;  // reported through the bound pass
+                float v[3], w[3];
+                uint32_t X0[3], Xl[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float ix = s_tap_ix[it][k][j];
+                    X0[j] = s_tap_x0[it][k][j];
+                    const float x0 = (float)X0[j], x1 = x0 + 1.0f;
+                    w[j] = ((tex & 1) ? (ix - x0) : (x1 - ix)) * wy;  // make_tap's nw / ne / sw / se
+                    Xl[j] = (tex & 1) ? (X0[j] + 1 < W[j] ? X0[j] + 1 : W[j] - 1) : X0[j];
+                    float part = planes[poff[j] + ((size_t)Yl * W[j] + Xl[j]) * kC + ch] * w[j];
+                    part += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part), 0x124 /* row_ror:4 */, 0xF, 0xF, false));
+                    part += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part), 0x128 /* row_ror:8 */, 0xF, 0xF, false));
+                    v[j] = part;
+                }
+                if (!row_ok) continue;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const float gv = g * (v[(j + 1) % 3] * v[(j + 2) % 3]);
+                    if (X0[j] != cur[j]) {  // uniform over the item's 32 lanes
+                        NVSF_TIME_FLUSH(j)
+                        cur[j] = X0[j];
+                        dst[j] = Xl[j] * kC + ch;
+                    }
+                    acc[j] += gv * w[j];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();  // the taps are overwritten by the next round
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            NVSF_TIME_FLUSH(j)
+            cur[j] = 0xFFFFFFFFu;
+        }
+    }
+#undef NVSF_TIME_FLUSH
+    if (bad) s_bad = 1;
+    __syncthreads();
+
+    // ---- the image into rows Y0, Y1 of the global gradient ----------------------------------------------------------------------
+    const double from_fixed = (double)__builtin_ldexpf(1.0f, e - 36);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const uint32_t row_len = W[j] * kC;
+        float* r0p = g_planes + poff[j] + (size_t)ty.Y0 * row_len;
+        float* r1p = g_planes + poff[j] + (size_t)ty.Y1 * row_len;
+        for (uint32_t i = threadIdx.x; i < row_len; i += kTimeBlock) {
+            const long long fx = (long long)s_img[ioff[j] + i];
+            if (fx == 0) continue;
+            const float G = (float)((double)fx * from_fixed);
+            atomicAdd(r0p + i, G * ty.wy0);
+            if (ty.wy1 != 0.0f) atomicAdd(r1p + i, G * ty.wy1);
+        }
+    }
+    if (s_bad != 0 && threadIdx.x == 0) atomicAdd(poison, __builtin_nanf(""));
+}
+
 // d L / d (offset) of the evaluations that carry one (the flow towards the neighbour frames): thread = (row, evaluation); the arithmetic
 // of k_planes_bwd's coordinate half on the evaluation's own position (x + offset, t_e), time planes or static planes as the group says.
 __global__ __launch_bounds__(kBlock) void k_planes_multi_coord_bwd(PlaneGradEvals ev, uint32_t M, const float* __restrict__ planes, PlaneMeta meta) {
@@ -721,7 +945,7 @@ NVSF_API int nvsf_planes_bwd(const float* xt, uint32_t M, const float* planes_cl
     PlaneMeta meta;
     const int st = fill_plane_meta(meta, n_scales, h_res);
     if (st != NVSF_OK) return st;
-    if (nvsf_variant(kVarPlanesBwd) != 0) {  // 1 (tests): one atomic per (sample, texel, channel), the first formulation
+    if (nvsf_variant(kVarPlanesBwd) == 1) {  // 1 (tests): one atomic per (sample, texel, channel), the first formulation
         hipLaunchKernelGGL(k_planes_bwd, dim3(cdiv(M, kBlock)), dim3(kBlock), 0, stream, xt, M, planes_cl, meta, want, grad_static,
                            grad_dynamic, grad_planes_cl, grad_xt);
         return nvsf_launch_status();
@@ -776,9 +1000,32 @@ NVSF_API int nvsf_planes_multi_bwd(const float* x, uint32_t x_stride, uint32_t M
         hipLaunchKernelGGL(k_planes_multi_coord_bwd, dim3(cdiv(M, kBlock), n_evals), dim3(kBlock), 0, stream, ev, M, planes_cl, meta);
     if (grad_planes_cl && groups) {
         const uint32_t run = 128u;
-        int live = 0;
+        int live = 0, live_time = 0;
         for (uint32_t e = 0; e < n_evals; ++e)
-            if (ev.g[e]) live |= 1 << e;
+            if (ev.g[e]) {
+                live |= 1 << e;
+                if (ev.grp[e] == 1) live_time |= 1 << e;
+            }
+        // production: the time-plane evaluations through the LDS image (k_planes_multi_bwd_time_lds), the spatial planes as run sums
+        // into global atomics.  Variant != 0 (tests), small batches (the slices would not fill the chip) or planes too wide for LDS:
+        // every evaluation through the run-merging kernel
+        uint32_t img_floats = 0;
+        for (uint32_t s = 0; s < n_scales; ++s) {
+            const uint32_t f = (meta.res[s][0] + meta.res[s][1] + meta.res[s][2]) * (uint32_t)kC;
+            img_floats = f > img_floats ? f : img_floats;
+        }
+        const size_t lds = (size_t)img_floats * sizeof(unsigned long long);
+        if (live_time && nvsf_variant(kVarPlanesBwd) == 0 && M >= (1u << 16) && lds <= 48u * 1024u) {  // + 12 KB of taps: inside the 64 KB a workgroup gets without an attribute
+            const uint32_t n_time = (uint32_t)__builtin_popcount((unsigned)live_time);
+            const uint32_t n_chunks = cdiv(M, run);
+            uint32_t n_slices = (2u * (uint32_t)nvsf_cu_count() + n_scales * n_time - 1) / (n_scales * n_time);  // two workgroups per CU
+            n_slices = n_slices > n_chunks ? n_chunks : n_slices;
+            const uint32_t chunks_per_slice = (n_chunks + n_slices - 1) / n_slices;
+            hipLaunchKernelGGL(k_planes_multi_bwd_time_lds, dim3(cdiv(n_chunks, chunks_per_slice), n_scales * n_time), dim3(kTimeBlock), lds, stream,
+                               ev, M, planes_cl, meta, live_time, grad_planes_cl, run, chunks_per_slice);
+            live &= ~live_time;
+        }
+        if (!live) return nvsf_launch_status();
         const unsigned long long items = (unsigned long long)cdiv(M, run) * n_scales * (unsigned)__builtin_popcount((unsigned)live);
         const unsigned long long waves = (items + 1) / 2;
         hipLaunchKernelGGL(k_planes_multi_bwd_runs, dim3((uint32_t)((waves + kBlock / kWave - 1) / (kBlock / kWave))), dim3(kBlock), 0, stream, ev, M,

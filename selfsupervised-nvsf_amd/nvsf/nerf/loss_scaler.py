@@ -99,6 +99,13 @@ class LossScaler:
                 optimizer.step()
         return found_inf
 
+    def hold_growth(self):
+        """The next `update` cannot complete a growth interval (device-side clamp of the tracker, no read-back): for a step whose
+        overflow decision is not final yet (RenderTrainStep's deferred table check)."""
+        if self._enabled and self._growth_interval >= 2:
+            self._lazy_init()
+            self._growth_tracker.clamp_(max=self._growth_interval - 2)
+
     def update(self, found_inf):
         if not self._enabled:
             return

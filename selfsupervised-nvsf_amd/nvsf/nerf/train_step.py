@@ -131,13 +131,15 @@ class LidarGradLossFn(torch.autograd.Function):
         frame = frame[0] if frame.dim() == 4 else frame
         frame = frame.contiguous()
         H, W, C = frame.shape
+        if C < 3:  # the reference reads data['pano_frame'][0, ..., 2] (trainer.py:296-470): the range channel is channel 2
+            raise ValueError(f"LidarGradLossFn: pano_frame needs >= 3 channels [raydrop, intensity, range], got {C}")
         pH, pW = int(patch[0]), int(patch[1])
         N = pd.numel()
         kind = LidarGradLossFn.CRITERIA[criterion]
         param = 0.2 * float(scale) if criterion == "huber" else (0.1 if criterion == "smoothl1" else 0.0)  # main_nvsf.py:207-208
         out = torch.empty((), dtype=torch.float32, device=pd.device)
         stats = torch.empty(N // (pH * pW), 6, dtype=torch.float32, device=pd.device) if criterion == "cos" else None
-        args = (_hip.ptr(pd), _hip.ptr(gd), _hip.ptr(rd), _hip.ptr(inds), frame.data_ptr() + 4 * (C - 1 if C >= 3 else 0), C, N, pH, pW, H, W,
+        args = (_hip.ptr(pd), _hip.ptr(gd), _hip.ptr(rd), _hip.ptr(inds), frame.data_ptr() + 4 * 2, C, N, pH, pW, H, W,
                 float(scale), kind, float(param), float(alpha), 1 if sobel else 0, _hip.ptr(stats))
         _hip.call("nvsf_lidar_grad_loss_fwd", *args, _hip.ptr(out))
         ctx.save_for_backward(pd, gd, rd, inds, frame, *(() if stats is None else (stats,)))
@@ -325,6 +327,8 @@ class RenderTrainStep:
                 if self.error_maps is not None:
                     self._for_error_map["lidar"] = (r["image_lidar"].detach(), r["depth_lidar"].detach(), gt_rd, gt_i, gt_d)
             else:  # host-side logic tests: the same terms as torch expressions
+                if self.grad_loss and self._patch_dims()[0] > 1:
+                    raise NotImplementedError("grad_loss (the structural regulariser on LiDAR patches) exists as HIP kernels only: the host branch would drop the 'sr' term silently")
                 gt_int, gt_depth = gt_i * gt_rd, gt_d * gt_rd  # trainer.py:187-189
                 pred_rd = r["image_lidar"][:, :, 0]
                 pred_int = r["image_lidar"][:, :, 1] * gt_rd
@@ -435,6 +439,14 @@ class RenderTrainStep:
         """The calling stream waits for the optimiser pass `step` left on the scatter stream (the last table's).  Readers inside this
         package that go through the encoders' fp16 copies wait by themselves (tinycudann._HalfCache.pending); call this before
         touching the fp32 parameters or the optimiser state directly (end_epoch / checkpoint_state / load_checkpoint do)."""
+        if self._late_carry is not None:
+            # a late-only overflow that has not reached the scaler yet is settled here (callers: end of epoch, checkpoint, load -- the
+            # host is waiting anyway), so that it is neither lost with a checkpoint nor applied to a freshly loaded scaler
+            ev_c, carry = self._late_carry
+            self._late_carry = None
+            ev_c.synchronize()
+            if float(carry) != 0.0:
+                self.scaler.update(carry)
         if self._pending is not None:
             ev, params = self._pending
             torch.cuda.current_stream().wait_event(ev)
@@ -506,8 +518,14 @@ class RenderTrainStep:
         if found is not None:
             prev, self._late_carry = self._late_carry, (None if not late or carry is None else (ev, carry))
             if prev is not None:  # a late-only overflow of the PREVIOUS step (its event is long past: this step's passes read that table)
-                torch.cuda.current_stream().wait_event(prev[0])
+                main = torch.cuda.current_stream()
+                main.wait_event(prev[0])
+                prev[1].record_stream(main)  # allocated on the side stream, consumed here
                 found = torch.maximum(found, prev[1])
+            if self._late_carry is not None:
+                # this step's late check is still pending: its `found` may yet turn out to have been an overflow, so the step must not be
+                # the one that completes a growth interval (the scale would double now and halve one step later)
+                self.scaler.hold_growth()
             self.scaler.update(found)
         if self.error_maps is not None:
             self.update_error_maps(batch)

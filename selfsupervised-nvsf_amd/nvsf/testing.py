@@ -16,7 +16,7 @@ import contextlib
 _NATIVE = {
     "march": {"wave": 0, "thread": 1, "serial": 2},
     "planes_fwd": {"runs": 0, "sample": 1},
-    "planes_bwd": {"runs": 0, "atomic": 1},
+    "planes_bwd": {"runs": 0, "atomic": 1, "global": 2},  # multi entry: 0 time planes through the LDS image, 1 / 2 every evaluation as run sums into global atomics
     "hashgrid_fwd": {"auto": 0, "generic": 1},
     "hashgrid_bwd": {"corners": 0, "atomic": 1},
     "hash4d_bwd": {"lds": 0, "runs": 1},

@@ -778,7 +778,8 @@ def test_dynamic_hash_gradient_through_lds_keeps_non_finite_gradients(dev, poiso
     assert torch.isfinite(sums[0]).all() and torch.isfinite(lvl(1, 2)).all() and torch.isfinite(lvl(2, 4)).all()
 
 
-@pytest.mark.parametrize("M,neighbours", [(29 * 211, (True, True)), (5000, (True, False)), (300, (False, True)), (64 * 130 + 7, (False, False))])
+@pytest.mark.parametrize("M,neighbours", [(29 * 211, (True, True)), (5000, (True, False)), (300, (False, True)), (64 * 130 + 7, (False, False)),
+                                          (331 * 211, (True, True)), (70001, (False, True))])  # >= 2^16 rows: time planes through the LDS image
 def test_planes_multi_node_equals_one_node_per_evaluation(dev, M, neighbours):
     """ops.PlanesMultiFn (round 5: the K-planes of one density query as ONE autograd node -- nvsf_planes_multi_fwd / nvsf_planes_multi_bwd)
     against one PlanesFn per evaluation, which is pinned by the reference's autograd (test_planes4d_forward_backward): features bit for
@@ -857,3 +858,72 @@ def test_planes_multi_node_equals_one_node_per_evaluation(dev, M, neighbours):
     assert torch.equal(gf_c, gf_d)   # (0.25 g) * ... in the kernel, 0.25 * g by autograd: the same fp32 products
     scale = float(gp_d.abs().max())
     assert scale > 0 and float((gp_c - gp_d).abs().max()) <= 2e-5 * scale
+
+
+def _ray_rows(n_rays, T, rng, dev):
+    o = rng.random((n_rays, 1, 3)) * 0.4 + 0.3
+    d = rng.standard_normal((n_rays, 1, 3))
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    return _t(np.clip(o + d * np.linspace(0, 0.35, T).reshape(1, T, 1), 0, 1).reshape(-1, 3).astype(np.float32), dev)
+
+
+@pytest.mark.parametrize("t0", [0.37, 0.0, 1.0])
+def test_time_plane_gradient_through_the_lds_image_equals_the_run_merging_kernel(dev, t0, variants):
+    """k_planes_multi_bwd_time_lds (production for >= 2^16 rows: the time-plane evaluations of nvsf_planes_multi_bwd accumulate in a 64-bit
+    fixed-point LDS image, planes.hip) against k_planes_multi_bwd_runs (testing.variant(planes_bwd="global"): every evaluation as run sums
+    into memory-side fp32 atomics, itself pinned against one PlanesFn per evaluation above and through that against the reference's
+    autograd): same sums up to fp32 addition order, accumulating into a non-zero buffer, the same texels touched; first / last frame
+    (t = 0, 1: the upper time row carries weight 0 / is the border row); and two runs of the production form agree to 2e-6 (the image is
+    order-independent, what is left is the order of ~130 slice sums per texel), where the run-merging form is only good for ~1e-5 here."""
+    from nvsf.nerf.models.planes_field import Planes4D
+    from planes_calls import multi_bwd_call as _multi_bwd_call
+    rng = np.random.default_rng(5)
+    torch.manual_seed(0)
+    enc = Planes4D(resolution=[32, 32, 32, 8], multiscale_res=[1, 2, 4, 8]).to(dev)
+    with torch.no_grad():
+        enc.planes_cl.add_(torch.randn_like(enc.planes_cl) * 0.1)
+    x = _ray_rows(400, 211, rng, dev)
+    M = x.shape[0]
+    assert M >= 1 << 16
+    flow = _t((rng.standard_normal((M, 8)) * 3e-3).astype(np.float32), dev)
+    gen = torch.Generator().manual_seed(2)
+    g = torch.randn(M, 120, generator=gen).to(dev)
+    g[torch.rand(M, generator=gen).to(dev) < 0.1] = 0.0
+    times = [t0, t0, min(t0 + 1 / 64, 1.0), max(t0 - 1 / 64, 0.0)]
+    base = torch.full_like(enc.planes_cl, 0.25)
+    lds = _multi_bwd_call(enc, x, flow, g, times, dev, grad=base.clone())
+    lds2 = _multi_bwd_call(enc, x, flow, g, times, dev, grad=base.clone())
+    variants.set(planes_bwd="global")
+    ref = _multi_bwd_call(enc, x, flow, g, times, dev, grad=base.clone())
+    variants.clear("planes_bwd")
+    assert torch.equal(lds == 0.25, ref == 0.25)  # the same texels are touched
+    for si in range(4):
+        for pi in range(6):
+            _, _, off, C, H, W = enc._layout[si * 6 + pi]
+            a, a2, b = (t[off:off + C * H * W] - 0.25 for t in (lds, lds2, ref))
+            scale = float(b.abs().max())
+            assert scale > 0
+            assert float((a - b).abs().max()) <= 2e-5 * scale, (si, pi)
+            if pi in (2, 4, 5):
+                assert float((a - a2).abs().max()) <= 2e-6 * scale, (si, pi)
+
+
+@pytest.mark.parametrize("poison", [float("inf"), float("nan")])
+def test_time_plane_gradient_through_the_lds_image_keeps_non_finite_gradients(dev, poison):
+    """A non-finite feature gradient (fp16 overflow under GradScaler) must leave the time planes of its scale non-finite, as the
+    memory-atomic kernels do, so that found_inf skips the step; the other scales' time planes stay finite."""
+    from nvsf.nerf.models.planes_field import Planes4D
+    from planes_calls import multi_bwd_call as _multi_bwd_call
+    rng = np.random.default_rng(6)
+    torch.manual_seed(0)
+    enc = Planes4D(resolution=[32, 32, 32, 8], multiscale_res=[1, 2, 4, 8]).to(dev)
+    x = _ray_rows(320, 211, rng, dev)
+    M = x.shape[0]
+    flow = torch.zeros(M, 6, device=dev)
+    g = torch.randn(M, 120, device=dev)
+    g[12345, 32 + 8 * 2 + 3] = poison   # dynamic slice, scale 2, channel 3
+    gp = _multi_bwd_call(enc, x, flow, g, [0.5, 0.5, 0.5 + 1 / 64, 0.5 - 1 / 64], dev)
+    for si in range(4):
+        for pi in (2, 4, 5):
+            _, _, off, C, H, W = enc._layout[si * 6 + pi]
+            assert bool(torch.isfinite(gp[off:off + C * H * W]).all()) == (si != 2 or pi != 2), (si, pi)

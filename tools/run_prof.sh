@@ -7,8 +7,9 @@ O=$R/gpurun_out/$T
 mkdir -p $O
 # 1. two-rank control-flow check on one device (numbers meaningless, tagged invalid)
 NVSF_BENCH_SAME_DEVICE=1 timeout 600 python bench.py --gpus 2 --steps 5 --warmup 2 --train-steps 2 --no-extra-legs --cpu-rays 0 > $O/bench2.log 2>&1
+rc2=$?   # of the bench run itself (captured before the copy below replaces $?)
 cp $R/gpurun_out/bench_detail.json $O/bench2_detail.json
-echo "rc2=$?" >> $O/bench2.log
+echo "rc2=$rc2" >> $O/bench2.log
 # 2. default bench line
 timeout 900 python bench.py > $O/bench1.log 2>&1
 cp $R/gpurun_out/bench_detail.json $O/bench1_detail.json   # (the profiled runs below overwrite gpurun_out/bench_detail.json)
