@@ -531,7 +531,50 @@ def eval_leg(model, dev, T, frames, dist):
             "ranks": world, "collective": "all_gather of depth / image chunks" if world > 1 else "none", "outputs_complete_and_finite": ok}
 
 
-def occupancy_leg(model_cls, dev, n_rays, steps):
+def occupancy_outputs_match_oracle(m, grid, lidar_rays, camera_rays, tensors, n_check, T_thresh=1e-4, max_steps=1024):
+    """Config 3's parity field: the one-launch occupancy render of the TIMED batches against the CPU oracle's
+    survivor loop (oracle/: march_rays -> field -> composite_rays, raymarching.cu:808-1053) on the first `n_check` rays of each
+    batch.  Rule of tests/test_occupancy_gpu.py: 1e-4 abs on every output, except that a ray whose transmittance lands within float
+    noise of T_thresh may take ONE more sample on one side -- bounded by that sample's weight (<= 1.05 T_thresh on weights_sum and
+    image, x t_max on depth); at least 97 % of the rays must meet the plain 1e-4."""
+    import oracle_lib as O
+    from nvsf import synthetic as S
+    tl, tc, tm = tensors
+    bits = O.packbits(grid, 0.5)
+    f16 = lambda net: net.params.detach().cpu().numpy().astype(np.float16)
+    res = {"tolerance": 1e-4, "terminal_sample_allowance": 1.05 * T_thresh, "ok": True}
+    with torch.no_grad():
+        outs = {True: m.render(tl[0], tl[1], tm, cal_lidar_color=True, max_steps=max_steps, T_thresh=T_thresh, fused=True),
+                False: m.render(tc[0], tc[1], tm, cal_lidar_color=False, max_steps=max_steps, T_thresh=T_thresh, fused=True)}
+    for lidar, (o, d) in ((True, lidar_rays), (False, camera_rays)):
+        o, d = o[:n_check], d[:n_check]
+        enc = m.hash_encoder_lidar if lidar else m.hash_encoder_camera
+        field = (enc.params.detach().cpu().numpy().astype(np.float16), enc.spec, f16(m.sigma_net),
+                 f16(m.raydrop_net) if lidar else f16(m.color_net), f16(m.intensity_net) if lidar else None)
+        if lidar:
+            nears, fars = np.full(len(o), m.min_near_lidar, np.float32), np.full(len(o), m.lidar_max_depth, np.float32)
+        else:
+            nears, fars = O.near_far_from_aabb(o, d, np.array([-S.BOUND] * 3 + [S.BOUND] * 3, np.float32), m.min_near)
+        ref = O.render_occupancy_infer(o, d, nears, fars, bits, float(S.BOUND), m.cascade, m.grid_size, max_steps, 0.0, field, lidar, T_thresh=T_thresh)
+        sfx = "_lidar" if lidar else ""
+        out = outs[lidar]
+        e_ws = np.abs(out["weights_sum" + sfx].cpu().numpy()[:n_check] - ref["weights_sum"])
+        e_dp = np.abs(out["depth" + sfx][0].cpu().numpy()[:n_check] - ref["depth"])
+        e_im = np.abs(out["image" + sfx][0].cpu().numpy()[:n_check] - ref["image"]).max(-1)
+        exact = (e_ws <= 1e-4) & (e_dp <= 1e-4) & (e_im <= 1e-4)
+        t_max = float(fars[fars < 1e30].max()) if (fars < 1e30).any() else 0.0
+        w1 = 1.05 * T_thresh
+        within = bool((e_ws <= 1e-4 + w1).all() and (e_im <= 1e-4 + w1).all() and (e_dp <= 1e-4 + w1 * max(t_max, 1.0)).all())
+        res["checked_rays" + sfx] = int(len(o))
+        res["exact_fraction" + sfx] = float(exact.mean())
+        res["max_abs_err" + sfx] = float(max(e_ws[exact].max(initial=0.0), e_dp[exact].max(initial=0.0), e_im[exact].max(initial=0.0)))
+        res["max_abs_err_terminal_rays" + sfx] = float(max(e_ws.max(initial=0.0), e_im.max(initial=0.0)))
+        res["largest_weights_sum" + sfx] = float(ref["weights_sum"].max())
+        res["ok"] = bool(res["ok"] and within and exact.mean() >= 0.97)
+    return res
+
+
+def occupancy_leg(model_cls, dev, n_rays, steps, n_check=128):
     """Secondary figure (BASELINE config 3): the config-2 field and ray batches through the occupancy-grid renderer,
     procedural occupancy grid (union of 64 random boxes, ~10 % occupied), max 1024 samples per ray.
     eval = the one-launch fused kernel; eval_host_loop = the reference's protocol (march_rays -> field -> composite_rays
@@ -568,6 +611,7 @@ def occupancy_leg(model_cls, dev, n_rays, steps):
     m.eval()
     dt = timed(True, steps)
     out["eval"] = {"value": 2 * n_rays / dt, "ms_per_step": dt * 1e3, "path": "nvsf_render_occupancy_fwd (one launch per batch)"}
+    out["outputs_match_oracle"] = occupancy_outputs_match_oracle(m, grid, (lo, ld), (co, cd), (tl, tc, tm), n_check)
     dt = timed(False, max(2, steps // 4))
     out["eval_host_loop"] = {"value": 2 * n_rays / dt, "ms_per_step": dt * 1e3, "path": "march_rays -> field -> composite_rays survivor loop"}
     m.train()
@@ -864,6 +908,12 @@ def compact_line(line, detail_path=None):
     if isinstance(o, dict):
         out["occupancy"] = {"value": _get(o, "eval", "value"), "ms_per_step": _get(o, "eval", "ms_per_step"),
                             "train_forward_ms": _get(o, "train_forward", "ms_per_step"), "occupied_fraction": o.get("occupied_fraction")}
+        om = o.get("outputs_match_oracle")
+        if isinstance(om, dict):
+            out["occupancy"]["outputs_match_oracle"] = {"ok": om.get("ok"), "tolerance": om.get("tolerance"),
+                                                         "max_abs_err": max(om.get("max_abs_err_lidar") or 0.0, om.get("max_abs_err") or 0.0),
+                                                         "exact_fraction": [om.get("exact_fraction_lidar"), om.get("exact_fraction")],
+                                                         "checked_rays": [om.get("checked_rays_lidar"), om.get("checked_rays")]}
 
     def grads(g):
         if not isinstance(g, dict):

@@ -80,9 +80,15 @@ int nvsf_packbits(const float* grid, uint32_t N, float density_thresh, uint8_t* 
  * Deviation (documented in DESIGN.md): sample ranges are assigned in ray-index order by a prefix
  * sum, not in atomicAdd arrival order, and ray n is recorded at rays[n] (the reference's slot is
  * atomicAdd(counter+1,1), which equals n only up to a permutation).
- * Runs the one-launch form below on a scratch block it takes from the device's stream-ordered memory pool for the duration of the
- * launch (hipMallocAsync / hipFreeAsync on `stream`; no synchronisation), so that the reference's argument list gets the fast
- * kernel; falls back to nvsf_march_rays_train_passes when the pool cannot serve the block.  As for the one-launch form,
+ * Runs the one-launch form below on a scratch block it takes from the device's DEFAULT stream-ordered memory pool for the duration
+ * of the launch (hipMallocAsync / hipFreeAsync on `stream`; no synchronisation), so that the reference's argument list gets the fast
+ * kernel; falls back to nvsf_march_rays_train_passes when the pool cannot serve the block.  Ownership: this is the ONE entry point of
+ * the library that does not work on caller-owned memory alone (the reference's signature has no scratch argument).  The first call
+ * on a device raises that pool's hipMemPoolAttrReleaseThreshold to 16 MiB (it is 0 by default: a freed block returns to the OS at the
+ * next synchronisation; a threshold the application has already raised is left alone), so the 1 KB + 16 B per four rays are served
+ * from the pool's reserve from the second call on: no allocation on the call path, at most 16 MiB held that the caller's own
+ * allocator does not see (nvsf_scratch_pool_stats).  Callers that want no library-side allocation at all use
+ * nvsf_march_rays_train_ws with their own scratch -- the Python wrapper does.  As for the one-launch form,
  * counter[1] < 0 after the call marks a launch whose bounded inter-workgroup wait expired (never seen outside the test that forces
  * it): the outputs are invalid and the call is to be repeated through nvsf_march_rays_train_passes on the counter as it was. */
 int nvsf_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
@@ -107,6 +113,10 @@ int nvsf_march_rays_train_passes(const float* rays_o, const float* rays_d, const
  * mark is sticky: later calls on the same counter leave it negative).  `spin_limit` = polls a waiting wave makes before it gives up,
  * 0 = the library's default (2^22); tests pass 1 to force the expiry path. */
 size_t nvsf_march_rays_train_ws_bytes(uint32_t N);
+
+/* Diagnostics of the pool nvsf_march_rays_train borrows from (the current device's default stream-ordered pool): bytes the pool
+ * holds reserved, bytes handed out, and its release threshold (any pointer may be NULL).  No stream argument: nothing is launched. */
+int nvsf_scratch_pool_stats(uint64_t* reserved_bytes, uint64_t* used_bytes, uint64_t* release_threshold);
 int nvsf_march_rays_train_ws(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound,
                              float dt_gamma, uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M,
                              const float* nears, const float* fars, float* xyzs, float* dirs, float* deltas,

@@ -1069,10 +1069,56 @@ NVSF_API int nvsf_march_rays_train_ws(const float* rays_o, const float* rays_d, 
     return nvsf_launch_status();
 }
 
+// Scratch of the reference-shaped entry below.  SURVEY 8b's ownership rule is "native code never allocates": the entry points that
+// take a caller-owned workspace (nvsf_march_rays_train_ws, what the Python wrapper calls) keep it.  The reference's own argument
+// list has no scratch, so ITS entry borrows the block (1 KB + 16 B per four rays) from the device's DEFAULT stream-ordered pool
+// (hipMallocAsync / hipFreeAsync on the caller's stream).  That pool's release threshold is 0 out of the box: every stream or device
+// synchronisation hands the freed block back to the OS and the next call is a real allocation again.  So the first call
+// on a device raises the threshold to kScratchPoolHold = 16 MiB (never lowers one the application has set): the pool then keeps up to that
+// many reserved bytes across synchronisations and serves the block from them -- no allocation on the call path after the first
+// call, nothing visible to (or taken from) PyTorch's caching allocator beyond those few KB.  nvsf_scratch_pool_stats reports the
+// pool's reserved / used bytes and threshold (tests/test_raymarching_gpu.py asserts no growth over 1000 calls).
+constexpr unsigned long long kScratchPoolHold = 16ull << 20;  // (the pool reserves in chunks of its own granularity, 2 MiB on this runtime: the hold must cover a chunk)
+static int scratch_pool_of_current_device(hipMemPool_t* pool) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetDefaultMemPool(pool, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    return dev;
+}
+static void scratch_pool_hold_once() {
+    static bool done[64] = {};
+    hipMemPool_t pool;
+    const int dev = scratch_pool_of_current_device(&pool);
+    if (dev < 0 || dev >= 64 || done[dev]) return;
+    done[dev] = true;
+    unsigned long long thr = 0;
+    if (hipMemPoolGetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr) == hipSuccess && thr < kScratchPoolHold) {
+        thr = kScratchPoolHold;
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &thr);
+    }
+    (void)hipGetLastError();
+}
+
+NVSF_API int nvsf_scratch_pool_stats(uint64_t* reserved_bytes, uint64_t* used_bytes, uint64_t* release_threshold) {
+    hipMemPool_t pool;
+    if (scratch_pool_of_current_device(&pool) < 0) return NVSF_ERR_UNSUPPORTED;
+    unsigned long long v[3] = {0, 0, 0};
+    if (hipMemPoolGetAttribute(pool, hipMemPoolAttrReservedMemCurrent, &v[0]) != hipSuccess ||
+        hipMemPoolGetAttribute(pool, hipMemPoolAttrUsedMemCurrent, &v[1]) != hipSuccess ||
+        hipMemPoolGetAttribute(pool, hipMemPoolAttrReleaseThreshold, &v[2]) != hipSuccess)
+        return (int)hipGetLastError();
+    if (reserved_bytes) *reserved_bytes = v[0];
+    if (used_bytes) *used_bytes = v[1];
+    if (release_threshold) *release_threshold = v[2];
+    return NVSF_OK;
+}
+
 // The reference-shaped entry (raymarching.h:27-44: no scratch argument): the one-launch form on a scratch block taken from and
-// returned to the device's stream-ordered pool around the launch (hipMallocAsync / hipFreeAsync on `stream`: after the first call
-// the pool hands the same block back, no device synchronisation); the three-launch form when the pool has nothing to give or a
-// test selected one of the first formulations.  Expiry of the bounded wait is reported as by nvsf_march_rays_train_ws.
+// returned to the device's stream-ordered pool around the launch (see above: no allocation and no synchronisation after the first
+// call); the three-launch form when the pool has nothing to give or a test selected one of the first formulations.  Expiry of the
+// bounded wait is reported as by nvsf_march_rays_train_ws.
 NVSF_API int nvsf_march_rays_train(const float* rays_o, const float* rays_d, const uint8_t* grid, float bound, float dt_gamma,
                                    uint32_t max_steps, uint32_t N, uint32_t C, uint32_t H, uint32_t M, const float* nears,
                                    const float* fars, float* xyzs, float* dirs, float* deltas, int32_t* rays,
@@ -1080,6 +1126,7 @@ NVSF_API int nvsf_march_rays_train(const float* rays_o, const float* rays_d, con
     if (N == 0) return NVSF_OK;
     void* scratch = nullptr;
     const size_t bytes = nvsf_march_rays_train_ws_bytes(N);
+    scratch_pool_hold_once();
     if (nvsf_variant(kVarMarch) != 0 || hipMallocAsync(&scratch, bytes, stream) != hipSuccess || !scratch) {
         (void)hipGetLastError();
         return nvsf_march_rays_train_passes(rays_o, rays_d, grid, bound, dt_gamma, max_steps, N, C, H, M, nears, fars, xyzs, dirs, deltas, rays,

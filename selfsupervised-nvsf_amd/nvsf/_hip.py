@@ -122,6 +122,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError here == header / library mismatch
         fn.argtypes = list(argtypes) + [_P]
         fn.restype = ctypes.c_int
+    lib.nvsf_scratch_pool_stats.restype = ctypes.c_int
+    lib.nvsf_scratch_pool_stats.argtypes = [ctypes.POINTER(ctypes.c_uint64)] * 3
     lib.nvsf_march_rays_train_ws_bytes.restype = ctypes.c_size_t
     lib.nvsf_march_rays_train_ws_bytes.argtypes = [_U]
     lib.nvsf_hashgrid_bwd_binned_ws_bytes.restype = ctypes.c_size_t

@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
 def test_python_binding_table_matches_header(hip_lib):
     from nvsf import _hip
     decls = _declared()
-    helpers = {"nvsf_version", "nvsf_build_digest", "nvsf_march_rays_train_ws_bytes", "nvsf_hashgrid_bwd_binned_ws_bytes", "nvsf_test_variant"}  # no stream argument: bound by hand in _hip.load()
+    helpers = {"nvsf_version", "nvsf_build_digest", "nvsf_march_rays_train_ws_bytes", "nvsf_hashgrid_bwd_binned_ws_bytes", "nvsf_test_variant", "nvsf_scratch_pool_stats"}  # no stream argument: bound by hand in _hip.load()
     assert set(_hip.SIGNATURES) == set(decls) - helpers
     assert _hip.march_ws_bytes(4096) == 8 * (16 * 8 + 2 * 1024)  # 8 ticket-queue heads, a 128-byte line each + {sum, prefix} per ticket of four rays
     for name, argtypes in _hip.SIGNATURES.items():

@@ -226,15 +226,15 @@ def _fp64_plane_grad(enc, xt, g_out, si, pi, pairs):
     wts = torch.cat([(1 - fu) * (1 - fv), fu * (1 - fv), (1 - fu) * fv, fu * fv])
     contrib = gval.repeat(4, 1) * wts[:, None]
     order = torch.argsort(keys)
-    keys, contrib = keys[order], contrib[order]
-    cs = torch.cumsum(contrib, 0)
+    keys = keys[order]
+    cs = torch.cumsum(contrib[order].t().contiguous(), 1)  # [C, 4 M], scanned along the contiguous axis (the strided scan takes 3 s per plane)
     last = torch.ones_like(keys, dtype=torch.bool)
     last[:-1] = keys[1:] != keys[:-1]
-    ends = cs[last]
+    ends = cs[:, last]
     seg = ends.clone()
-    seg[1:] -= ends[:-1]
+    seg[:, 1:] -= ends[:, :-1]
     out = torch.zeros(H * W, C, dtype=torch.float64, device=xt.device)
-    out[keys[last]] = seg
+    out[keys[last]] = seg.t()
     return out.view(-1)
 
 
@@ -354,30 +354,32 @@ def test_space_time_step_planes_gradient_against_fp64_of_its_own_addends(dev, dy
         variants.set(planes_bwd=variant)
         got[variant] = _grads(step, m, batch)[1]["planes_encoder_lidar.planes_cl"]
     variants.clear("planes_bwd")
-    assert len(seen) == 2 and seen[0]["blend"] and len(seen[0]["meta"]) == 4
-    rec = seen[0]
-    assert all(torch.equal(a, b) for a, b in zip(rec["g"], seen[1]["g"])) and torch.equal(rec["x"], seen[1]["x"])  # same operands both runs
+    assert len(seen) == 2 and all(r["blend"] and [mt[0] for mt in r["meta"]] == [0, 1, 1, 1] for r in seen)
+    # (the two runs' operands agree only up to an fp16 rounding step here and there: the chamfer term's backward adds its point gradients
+    # with atomics, as the reference's does (chamfer3D.cu:133-157), and a last-bit difference of dL/d(range) flips roundings of the fp16
+    # hand-overs on its way back through the MLPs -- measured 2.7e-4 of the largest entry -- so each run is held against the fp64 sum
+    # of the operands IT recorded)
+    assert torch.equal(seen[0]["x"], seen[1]["x"]) and float((seen[0]["g"][1] - seen[1]["g"][1]).abs().max()) <= 2e-3 * float(seen[0]["g"][1].abs().max())
     pairs = list(itertools.combinations(range(4), 2))
-    Mx = rec["x"].shape[0]
+    Mx = seen[0]["x"].shape[0]
     assert Mx == M
     col = lambda v: torch.full((Mx, 1), v, dtype=torch.float32, device=dev)
-    positions = []
-    for grp, off_col, t_e, has_off in rec["meta"]:
-        xe = rec["x"][:, :3] + rec["fl"][:, off_col:off_col + 3] if has_off else rec["x"][:, :3]  # fp32 add, as the kernels form x + flow
-        positions.append(torch.cat([xe, col(t_e)], -1))
-    assert [mt[0] for mt in rec["meta"]] == [0, 1, 1, 1]
-    g_s, g_d = rec["g"]
     worst = {"runs": [0.0, 0.0], "global": [0.0, 0.0]}
-    for si in range(len(enc.multiscale_res)):
-        for pi in range(6):
-            _, _, off, C, H, W = enc._layout[si * 6 + pi]
-            if 3 in pairs[pi]:
-                ref = sum(w * _fp64_plane_grad(enc, xt, g_d, si, pi, pairs) for w, xt in zip((0.5, 0.25, 0.25), positions[1:]))
-            else:
-                ref = _fp64_plane_grad(enc, positions[0], g_s, si, pi, pairs)
-            scale = float(ref.abs().max())
-            assert scale > 0
-            for variant in worst:
+    for variant, rec in zip(("runs", "global"), seen):
+        positions = []
+        for grp, off_col, t_e, has_off in rec["meta"]:
+            xe = rec["x"][:, :3] + rec["fl"][:, off_col:off_col + 3] if has_off else rec["x"][:, :3]  # fp32 add, as the kernels form x + flow
+            positions.append(torch.cat([xe, col(t_e)], -1))
+        g_s, g_d = rec["g"]
+        for si in range(len(enc.multiscale_res)):
+            for pi in range(6):
+                _, _, off, C, H, W = enc._layout[si * 6 + pi]
+                if 3 in pairs[pi]:
+                    ref = sum(w * _fp64_plane_grad(enc, xt, g_d, si, pi, pairs) for w, xt in zip((0.5, 0.25, 0.25), positions[1:]))
+                else:
+                    ref = _fp64_plane_grad(enc, positions[0], g_s, si, pi, pairs)
+                scale = float(ref.abs().max())
+                assert scale > 0
                 err = float((got[variant][off:off + C * H * W].double() - ref).abs().max()) / scale
                 worst[variant][int(3 in pairs[pi])] = max(worst[variant][int(3 in pairs[pi])], err)
     print(f"K-planes texel gradient of the STEP vs fp64 of its own addends (LiDAR pass, M = {Mx}): production spatial {worst['runs'][0]:.2e} / time "

@@ -465,7 +465,8 @@ def test_overflow_only_in_a_deferred_table_gradient_never_reaches_the_table(dev,
     hand-over (nvsf_density_tail_grad_split), where a finite fp32 value above 65504 becomes inf while the density MLP's own weight
     gradient stays finite.  Emulated here by writing an inf into the deferred table's gradient behind its scatter (on the scatter's
     stream, every early gradient clean): the deferred Adam pass must skip (table, fp16 copy and EMA shadow untouched, no nan
-    anywhere), everything early may move (its gradients were clean), and the scaler halves its scale one step later."""
+    anywhere), everything early may move (its gradients were clean), and the scaler halves its scale one step later -- or at the next
+    sync() (end of epoch / checkpoint), whichever comes first."""
     import copy
     from nvsf import field_ops
     from nvsf import synthetic as S
@@ -500,7 +501,9 @@ def test_overflow_only_in_a_deferred_table_gradient_never_reaches_the_table(dev,
     torch.manual_seed(1)
     step.ema.before_step()
     step.step(batch)  # the poison is in this first step
-    step.sync()
+    assert step.scaler.get_scale() == 1.0       # the early decision was "clean" ...
+    step.sync()                                  # ... and sync() settles a late-only overflow that has not reached the scaler yet
+    assert step.scaler.get_scale() == 0.5 and step._late_carry is None
     torch.cuda.synchronize()
     before = {n: p.detach().clone() for n, p in m.named_parameters()}
     names = dict(m.named_parameters())
@@ -514,22 +517,33 @@ def test_overflow_only_in_a_deferred_table_gradient_never_reaches_the_table(dev,
     assert not torch.equal(m.sigma_net.params.detach(), ref["sigma_net.params"])  # early parameters were clean and moved
     for n, p in names.items():
         assert bool(torch.isfinite(p).all()), n
-    assert step.scaler.get_scale() == 1.0       # the early decision was "clean" ...
     torch.manual_seed(2)
     step.ema.before_step()
     step.step(batch)
     step.sync()
     torch.cuda.synchronize()
     assert all(bool(torch.isfinite(p.grad).all()) for p in m.parameters() if p.grad is not None)  # this step itself was clean
-    assert step.scaler.get_scale() == 0.5        # ... and the late-only overflow reached the scaler one step later
+    assert step.scaler.get_scale() == 0.5        # settled once, not twice
     assert not torch.equal(table.detach(), before["hash_encoder_lidar.hash_static.params"])  # a clean step updates the table again
     for n, p in names.items():
         assert bool(torch.isfinite(p).all()), n
+    # the same without a sync() in between (the training loop's case): the late-only overflow reaches the scaler with the NEXT step's update
+    poisoned.clear()
     torch.manual_seed(3)
+    step.ema.before_step()
+    step.step(batch)                             # poisoned again
+    assert step.scaler.get_scale() == 0.5 and step._late_carry is not None
+    torch.manual_seed(4)
+    step.ema.before_step()
+    step.step(batch)
+    assert step.scaler.get_scale() == 0.25       # one step later
+    torch.manual_seed(5)
     step.ema.before_step()
     step.step(batch)
     step.sync()
-    assert step.scaler.get_scale() == 0.5        # carried once, not twice
+    assert step.scaler.get_scale() == 0.25       # carried once, not twice
+    for n, p in names.items():
+        assert bool(torch.isfinite(p).all()), n
 
 
 def test_fp32_readers_wait_for_the_deferred_update(dev, net):

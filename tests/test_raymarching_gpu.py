@@ -519,3 +519,53 @@ def test_reference_shaped_entry_takes_its_scratch_from_the_stream_ordered_pool(r
         for a, b in zip(outs["ws"], outs[e]):
             assert torch.equal(a, b), e
     assert outs["ws"][0].shape[0] > 1000
+
+
+def test_reference_shaped_entry_does_not_grow_the_pool_it_borrows_from(rm, dev):
+    """VERDICT r5 item 8 / SURVEY 8b "Ownership": nvsf_march_rays_train is the one entry point that borrows memory the caller did not
+    pass in (1 KB + 16 B per four rays from the device's default stream-ordered pool).  1000 calls interleaved with torch allocations,
+    frees, stream and device synchronisations (each of which returns a freed block to the OS under the pool's default threshold of
+    0): the pool's reserved bytes do not grow after the first call, nothing stays handed out, and the threshold the library set is
+    the documented 16 MiB (or whatever larger value the application had)."""
+    import ctypes
+    from nvsf import _hip
+    lib = _hip.load()
+
+    def stats():
+        v = [ctypes.c_uint64(0) for _ in range(3)]
+        assert lib.nvsf_scratch_pool_stats(*[ctypes.byref(x) for x in v]) == 0
+        return tuple(int(x.value) for x in v)
+    rng = np.random.default_rng(3)
+    C, H, bound, max_steps, n = 1, 64, 1.0, 64, 2048
+    tb = _t(O.packbits((rng.random((C, H ** 3)) < 0.2).astype(np.float32), 0.5), dev)
+    o = _t(((rng.random((n, 3)) * 2 - 1) * 0.5).astype(np.float32), dev)
+    d = torch.nn.functional.normalize(_t(rng.normal(size=(n, 3)).astype(np.float32), dev), dim=-1)
+    nears, fars = rm.near_far_from_aabb(o, d, torch.tensor([-bound] * 3 + [bound] * 3, device=dev), 0.02)
+    M = n * max_steps
+    xyzs = torch.zeros(M, 3, device=dev); dirs = torch.zeros(M, 3, device=dev); deltas = torch.zeros(M, 2, device=dev)
+    rays = torch.empty(n, 3, dtype=torch.int32, device=dev); counter = torch.zeros(2, dtype=torch.int32, device=dev)
+    tz = torch.zeros(n, device=dev)
+
+    def call():
+        counter.zero_()
+        _hip.call("nvsf_march_rays_train", _hip.ptr(o), _hip.ptr(d), _hip.ptr(tb), bound, 0.0, max_steps, n, C, H, M, _hip.ptr(nears), _hip.ptr(fars),
+                  _hip.ptr(xyzs), _hip.ptr(dirs), _hip.ptr(deltas), _hip.ptr(rays), _hip.ptr(counter), _hip.ptr(tz))
+    call()
+    torch.cuda.synchronize()
+    first = int(counter[0])
+    reserved0, used0, threshold = stats()
+    assert first > 0 and threshold >= 16 << 20 and used0 == 0 and 0 < reserved0 <= threshold
+    keep = []
+    for i in range(1000):
+        call()
+        if i % 7 == 0:
+            keep.append(torch.empty(int(rng.integers(1, 1 << 20)), device=dev))   # the caller's allocator at work in between
+        if i % 50 == 0:
+            keep.clear()
+            torch.cuda.synchronize()   # where a pool with threshold 0 gives its blocks back
+        elif i % 13 == 0:
+            torch.cuda.current_stream().synchronize()
+    torch.cuda.synchronize()
+    reserved1, used1, _ = stats()
+    assert int(counter[0]) == first
+    assert used1 == 0 and reserved1 <= reserved0, (reserved0, reserved1)

@@ -710,3 +710,24 @@ def test_density_gradient_composed_equals_the_matrix_form_in_the_step(dev, varia
         b = grads["composed"][n]
         scale = float(a.abs().max())
         assert scale > 0 and float((a - b).abs().max()) <= 1e-5 * scale, n
+
+
+def test_loss_scaler_hold_growth_delays_the_doubling_by_one_update(dev):
+    """a step whose deferred overflow check is still pending must not be the one that completes a growth interval
+    (LossScaler.hold_growth: a device-side clamp of GradScaler's growth tracker before `update`)."""
+    from nvsf.nerf.loss_scaler import LossScaler
+    clean = torch.zeros(1, device=dev)
+    plain, held = LossScaler(device=dev, init_scale=4.0, growth_interval=3), LossScaler(device=dev, init_scale=4.0, growth_interval=3)
+    for sc in (plain, held):
+        sc.update(clean)
+        sc.update(clean)
+    plain.update(clean)
+    assert plain.get_scale() == 8.0             # third clean update in a row: doubled
+    held.hold_growth()
+    held.update(clean)
+    assert held.get_scale() == 4.0              # held: this update cannot complete the interval ...
+    held.update(clean)
+    assert held.get_scale() == 8.0              # ... the next one does
+    held.hold_growth()
+    held.update(torch.ones(1, device=dev))
+    assert held.get_scale() == 4.0              # an overflow halves as always
