@@ -572,29 +572,35 @@ __global__ __launch_bounds__(kBlock) void k_planes_multi_bwd_runs(PlaneGradEvals
 }
 
 // ------------------------------------------------------------------------------------------------
-// The TIME-plane evaluations of nvsf_planes_multi_bwd through an on-chip image (the production form; k_planes_multi_bwd_runs keeps the
+// The TIME-plane evaluations of nvsf_planes_multi_bwd through on-chip images (the production form; k_planes_multi_bwd_runs keeps the
 // spatial planes and is the test reference for these).
 //
 // Every evaluation of the multi entry has ONE time t_e for all its rows, so the three time planes (xt, yt, zt) of a scale are only ever
-// touched in the two rows Y0, Y1 around t_e: 2 x W texels per plane, W = 32 ... 256.  The run-merging kernel sends every run sum of
-// every item of every evaluation there as a memory-side fp32 atomic: at 4096 x 768 rows a texel of those rows receives 10^5 - 10^6
-// addends, (i) at the slowest atomic rate there is (many adders on a few lines), 2.6 ms per launch at 2048 + 2048 rays, 5.2 ms at
-// 4096 + 4096 -- the largest kernel of the config-5 training step -- and (ii) in an order that changes from run to run: 1e-4 of the
-// largest entry between two runs of the SAME step (GPUTEST_r05), 27 x the error of one evaluation against fp64.
+// touched in the two rows Y0, Y1 around t_e, with the SAME two time weights wy0, wy1 for every row of the launch.  The run-merging
+// kernel nevertheless treats them as 2-D gathers and sends every run sum of every item of every evaluation to those 2 x W texels as
+// a memory-side fp32 atomic: at 4096 x 768 rows a texel receives 10^5 - 10^6 addends, (i) at the slowest atomic rate there is (many
+// adders on a few lines): 5.2 ms per launch, the largest kernel of the config-5 training step, and (ii) in an order that changes from
+// run to run: 1e-4 of the largest entry between two runs of the SAME step (GPUTEST_r05), 6e-4 against an fp64 sum of the step's own
+// addends (tests/test_config5_train_full_size_gpu.py).
 //
-// Here a workgroup owns (slice of the chunks, evaluation, scale): its items walk their rows exactly as the items of the run-merging
-// kernel do -- same taps (make_tap), same gathers, same products, same run sums in registers -- and a run sum goes into a 64-bit
-// FIXED-POINT image of the scale's three time planes in LDS (ds_add_u64; integer adds commute: the image does not depend on the order
-// in which the waves arrive).  The image is 1-D: the weights of the two time rows are the same for every row of the launch, so the
-// two time-row lanes of a texel column are added first (one DPP add) and the image holds G[plane][X][channel] = sum g v v wx (wy0 +
-// wy1); the final pass adds wy0 G and wy1 G to rows Y0, Y1 of the global gradient with contiguous fp32 atomics -- one addend per
-// (slice, evaluation) and texel: ~130 instead of 10^5 - 10^6.  Scale of the image: 2^(36 - e), e the exponent of a bound of the
-// workgroup's addends (largest |g| of its slice x g_scale x the product of the two largest |texel| of the planes' two rows; the
-// interpolated values are convex combinations): exact product, one truncation per run sum at 2^-36 of the bound; a run sum is at
-// most 2 x 128 addends (2^45), a slice at most 2^17 rows: no overflow.  Non-finite gradients or texels (GradScaler overflow steps)
-// are kept out of the image and reported as a NaN in the scale's first time texel, as k_hash_dynamic_bwd_lds does.
-constexpr int kTimeBlock = 512;             // 8 waves = 16 items of 32 lanes
-constexpr int kTimeItems = kTimeBlock / 32;
+// Here the problem is made 1-D.  A workgroup owns (slice of the chunks, evaluation, scale) and first folds the time axis away:
+//     A_j[X][c] = wy0 P_j[Y0][X][c] + wy1 P_j[Y1][X][c]        (LDS, fp32: the interpolated value is then  wx0 A[X0] + wx1 A[X1]),
+// walks its rows with 16 lanes per item (x side, channel): per row and plane one LDS read of A, one weight, one DPP add -- no global
+// gather, a quarter of the run-merging kernel's instructions per row -- forms g (v v) wx run sums in registers exactly as that
+// kernel does, and adds a run sum to a 64-bit FIXED-POINT image G_j[X][c] in LDS (ds_add_u64: integer adds commute, the image does
+// not depend on the order in which the waves arrive).  The final pass adds wy0 G and wy1 G to rows Y0, Y1 of the global gradient with
+// contiguous fp32 atomics: one addend per (slice, evaluation) and texel, ~500 instead of 10^5 - 10^6.
+// Arithmetic against the run-merging kernel: the value wx0 (wy0 P00 + wy1 P10) + wx1 (...) instead of the four-weight blend of
+// make_tap, the addend wy (sum g v v wx) instead of sum g v v (wx wy): the same real numbers, roundings at 1e-7 relative.
+// Scale of the image: 2^(36 - e), e the exponent of a bound of the workgroup's addends (largest |g| of its slice x g_scale x the
+// product of the two largest |A|; the interpolated values are convex combinations): exact product, one truncation per run sum at
+// 2^-36 of the bound; a run sum is at most 128 addends (2^44), a slice at most 2^17 rows: no overflow.  Non-finite gradients or
+// texels (GradScaler overflow steps) are kept out of the image and reported as a NaN in the scale's first time texel, as
+// k_hash_dynamic_bwd_lds does.
+constexpr int kTimeBlock = 1024;            // 16 waves = 64 items of 16 lanes sharing one image: the image (72 KB at the finest scale) allows one or two workgroups per CU whatever their size, and the walk needs the waves
+constexpr int kTimeItems = kTimeBlock / 16;
+constexpr int kTimeRows = 8;                // rows of an item per round (taps and gradient rows staged in LDS)
+constexpr int kTimeUnroll = 4;
 
 struct TimeTap {
     uint32_t Y0, Y1;
@@ -612,15 +618,16 @@ __device__ __forceinline__ TimeTap make_time_tap(float t, uint32_t H) {
 
 __global__ __launch_bounds__(kTimeBlock) void k_planes_multi_bwd_time_lds(PlaneGradEvals ev, uint32_t M, const float* __restrict__ planes,
                                                                           PlaneMeta meta, int live, float* __restrict__ g_planes, uint32_t run,
-                                                                          uint32_t chunks_per_slice) {
-    extern __shared__ unsigned long long s_img[];         // [W0 * 8 | W1 * 8 | W2 * 8]
-    __shared__ float s_tap_ix[kTimeItems][32][3];         // per item: the x half of the taps of a round of 32 rows (make_tap's ix, x0)
-    __shared__ uint32_t s_tap_x0[kTimeItems][32][3];
+                                                                          uint32_t chunks_per_slice, uint32_t s) {
+    extern __shared__ unsigned long long s_img[];         // [n_img] 64-bit sums, then [n_img] floats: the folded planes A
+    __shared__ float s_tap_ix[kTimeItems][kTimeRows][3];  // per item: make_tap's ix, x0 of a round of rows
+    __shared__ uint32_t s_tap_x0[kTimeItems][kTimeRows][3];
+    __shared__ float s_g[kTimeItems][kTimeRows][kC];      // ... and the rows' gradient values (scaled)
     __shared__ float s_red[4][kTimeBlock / kWave];
     __shared__ int s_bad;
     const int lane = lane_id();
-    const int k32 = lane & 31, tex = (lane >> 2) & 3, ch = (lane & 3) | ((lane >> 2) & 4);
-    const uint32_t slot = blockIdx.y / meta.n_scales, s = blockIdx.y - slot * meta.n_scales;
+    const int l16 = lane & 15, xs = (lane >> 3) & 1, ch = lane & 7;
+    const uint32_t slot = blockIdx.y;
     const float* gbase = nullptr;
     const float* off = nullptr;
     uint32_t off_stride = 0, off_col = 0, stride = 0;
@@ -644,25 +651,38 @@ __global__ __launch_bounds__(kTimeBlock) void k_planes_multi_bwd_time_lds(PlaneG
     const uint32_t poff[3] = {meta.off[s][2], meta.off[s][4], meta.off[s][5]};  // pairs (0,3), (1,3), (2,3)
     const uint32_t ioff[3] = {0u, W[0] * kC, (W[0] + W[1]) * kC};
     const uint32_t n_img = (W[0] + W[1] + W[2]) * kC;
+    float* const s_A = reinterpret_cast<float*>(s_img + n_img);
     const TimeTap ty = make_time_tap(t_e, H);
     const uint32_t m_lo = c_lo * run, m_hi = (unsigned long long)c_hi * run < M ? c_hi * run : M;
 
-    // ---- bound of the slice's addends --------------------------------------------------------------------------------------------
-    float mx[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // |g|, |texel| of the three planes' two rows
+    // ---- the folded planes, and a bound of the slice's addends ------------------------------------------------------------------
+    float mx[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // |g|, |A| of the three planes
     bool bad = false;
-    for (uint32_t i = threadIdx.x; i < (m_hi - m_lo) * kC; i += kTimeBlock) {
-        const float a = fabsf(gbase[(size_t)(m_lo + (i >> 3)) * stride + s * kC + (i & 7u)]);
-        if (a <= 3.402823466e38f) mx[0] = fmaxf(mx[0], a);
-        else bad = true;
+    {
+        const uint32_t n_g = (m_hi - m_lo) * kC;
+        for (uint32_t i0 = threadIdx.x; i0 < n_g; i0 += 4u * kTimeBlock) {  // four independent loads in flight per thread
+            float a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = i0 + (uint32_t)u * kTimeBlock, ii = i < n_g ? i : i0;
+                a[u] = fabsf(gbase[(size_t)(m_lo + (ii >> 3)) * stride + s * kC + (ii & 7u)]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (a[u] <= 3.402823466e38f) mx[0] = fmaxf(mx[0], a[u]);
+                else bad = true;
+            }
+        }
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const uint32_t row_len = W[j] * kC;
-        for (uint32_t i = threadIdx.x; i < 2u * row_len; i += kTimeBlock) {
-            const uint32_t Y = i < row_len ? ty.Y0 : ty.Y1, c = i < row_len ? i : i - row_len;
-            const float a = fabsf(planes[poff[j] + (size_t)Y * row_len + c]);
-            if (a <= 3.402823466e38f) mx[1 + j] = fmaxf(mx[1 + j], a);
-            else bad = true;
+        for (uint32_t i = threadIdx.x; i < row_len; i += kTimeBlock) {
+            const float p0 = planes[poff[j] + ty.Y0 * row_len + i], p1 = planes[poff[j] + ty.Y1 * row_len + i];
+            float a = p0 * ty.wy0 + p1 * ty.wy1;
+            if (fabsf(a) <= 3.402823466e38f) mx[1 + j] = fmaxf(mx[1 + j], fabsf(a));
+            else { bad = true; a = 0.0f; }
+            s_A[ioff[j] + i] = a;
         }
     }
 #pragma unroll
@@ -693,79 +713,120 @@ __global__ __launch_bounds__(kTimeBlock) void k_planes_multi_bwd_time_lds(PlaneG
     e = e < -90 ? -90 : e;
     const float to_fixed = __builtin_ldexpf(1.0f, 36 - e);
 
-    // ---- the walk: k_planes_multi_bwd_runs' item, its run sums into the image ----------------------------------------------------
-    const uint32_t it = threadIdx.x >> 5;
+    // ---- the walk ------------------------------------------------------------------------------------------------------------------
+    const uint32_t it = threadIdx.x >> 4;
     float acc[3] = {0.0f, 0.0f, 0.0f};
     uint32_t cur[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, dst[3] = {0u, 0u, 0u};
-    const float wy = (tex & 2) ? ty.wy1 : ty.wy0;
-    const uint32_t Yl = (tex & 2) ? ty.Y1 : ty.Y0;
 #define NVSF_TIME_FLUSH(j)                                                                                                          \
     {                                                                                                                               \
-        const float G = acc[j] + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc[j]), 0x128 /* row_ror:8 */, 0xF, 0xF, false)); \
-        if (!(tex & 2) && G != 0.0f) {                                                                                              \
-            if (fabsf(G) <= 3.402823466e38f) atomicAdd(&s_img[ioff[j] + dst[j]], (unsigned long long)(long long)(G * to_fixed));    \
+        if (acc[j] != 0.0f) {                                                                                                       \
+            if (fabsf(acc[j]) <= 3.402823466e38f) atomicAdd(&s_img[ioff[j] + dst[j]], (unsigned long long)(long long)(acc[j] * to_fixed)); \
             else bad = true;                                                                                                        \
         }                                                                                                                           \
         acc[j] = 0.0f;                                                                                                              \
     }
+    // The rows' operands come from global memory (positions, flow offsets, gradient rows): a round trip of several microseconds against
+    // ~1 us of work per round of kTimeRows rows, with two workgroups per CU at the finest scale to hide it.  So the loads of round
+    // q + 1 are ISSUED (into registers, nothing consumed) before round q is worked on, and staged into LDS when their turn comes.
+    struct RoundOperands {
+        float p[3], o[3], g[kTimeRows * kC / 16];
+    };
+    auto rows_of = [&](uint32_t c, uint32_t& m0, uint32_t& n_rows) {
+        const bool active = c < c_hi;
+        m0 = active ? c * run : 0u;
+        const uint32_t m1 = active ? (m0 + run < M ? m0 + run : M) : 0u;
+        n_rows = m1 - m0;
+    };
+    auto issue = [&](uint32_t c, uint32_t r0, RoundOperands& op) __attribute__((always_inline)) {
+        uint32_t m0, n_rows;
+        rows_of(c, m0, n_rows);
+        const uint32_t r = r0 + (uint32_t)(l16 & (kTimeRows - 1));
+        const uint32_t m = r < n_rows ? m0 + r : (M - 1);
+        const float* px = ev.x + (size_t)m * ev.x_stride;
+        op.p[0] = px[0]; op.p[1] = px[1]; op.p[2] = px[2];
+        if (off) {
+            const float* po = off + (size_t)m * off_stride + off_col;
+            op.o[0] = po[0]; op.o[1] = po[1]; op.o[2] = po[2];
+        }
+#pragma unroll
+        for (int i = 0; i < kTimeRows * kC / 16; ++i) {
+            const uint32_t idx = (uint32_t)i * 16u + (uint32_t)l16, rr = idx >> 3, cc = idx & 7u;
+            const uint32_t mr = r0 + rr < n_rows ? m0 + r0 + rr : (M - 1);
+            op.g[i] = gbase[(size_t)mr * stride + s * kC + cc];
+        }
+    };
+    RoundOperands nxt;
+    issue(c_lo + it, 0u, nxt);
     for (uint32_t c0 = c_lo; c0 < c_hi; c0 += kTimeItems) {  // uniform trip count over the workgroup
         const uint32_t c = c0 + it;
-        const bool active = c < c_hi;
-        const uint32_t m0 = active ? c * run : 0u, m1 = active ? (m0 + run < M ? m0 + run : M) : 0u;
-        const uint32_t n_rows = m1 - m0;
-        for (uint32_t r0 = 0; r0 < run; r0 += 32) {
-            {   // lane k32: the x taps of row r0 + k32 at the evaluation's own position
-                const uint32_t r = r0 + (uint32_t)k32;
-                const uint32_t m = r < n_rows ? m0 + r : (M - 1);
-                const float* px = ev.x + (size_t)m * ev.x_stride;
-                float p[3] = {px[0], px[1], px[2]};
-                if (off) {
-                    const float* po = off + (size_t)m * off_stride + off_col;
-                    p[0] = p[0] + po[0]; p[1] = p[1] + po[1]; p[2] = p[2] + po[2];  // fp32 adds, as torch.add forms x + flow
+        uint32_t m0, n_rows;
+        rows_of(c, m0, n_rows);
+        for (uint32_t r0 = 0; r0 < run; r0 += kTimeRows) {
+            {   // lanes 0..7 of the item: the x taps of row r0 + lane at the evaluation's own position; all 16: the rows' gradient values
+                float p[3] = {nxt.p[0], nxt.p[1], nxt.p[2]};
+                if (off) { p[0] = p[0] + nxt.o[0]; p[1] = p[1] + nxt.o[1]; p[2] = p[2] + nxt.o[2]; }  // fp32 adds, as torch.add forms x + flow
+                if (l16 < kTimeRows) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const Tap t = make_tap(p[j], t_e, W[j], H);
+                        s_tap_ix[it][l16][j] = t.ix_f;
+                        s_tap_x0[it][l16][j] = (uint32_t)t.x0;
+                    }
                 }
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const Tap t = make_tap(p[j], t_e, W[j], H);
-                    s_tap_ix[it][k32][j] = t.ix_f;
-                    s_tap_x0[it][k32][j] = (uint32_t)t.x0;
+                for (int i = 0; i < kTimeRows * kC / 16; ++i) {
+                    const uint32_t idx = (uint32_t)i * 16u + (uint32_t)l16, rr = idx >> 3, cc = idx & 7u;
+                    float g = nxt.g[i] * g_scale;
+                    if (!(r0 + rr < n_rows) || !(fabsf(g) <= 3.402823466e38f)) g = 0.0f;  // (non-finite: reported through the bound pass)
+                    s_g[it][rr][cc] = g;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            for (uint32_t k = 0; k < 32u; ++k) {
-                const uint32_t r = r0 + k;
-                const bool row_ok = r < n_rows;
-                const uint32_t m = row_ok ? m0 + r : (M - 1);
-                float g = row_ok ? gbase[(size_t)m * stride + s * kC + ch] * g_scale : 0.0f;
-                if (!(fabsf(g) <= 3.402823466e38f)) g = 0.0f;  // reported through the bound pass
-                float v[3], w[3];
-                uint32_t X0[3], Xl[3];
+            if (r0 + kTimeRows < run) issue(c, r0 + kTimeRows, nxt);       // the next round of this chunk ...
+            else if (c0 + kTimeItems < c_hi) issue(c + kTimeItems, 0u, nxt);  // ... or the first one of the item's next chunk (uniform)
+            // kTimeUnroll rows at a time: their LDS operands are all requested before the first of them is consumed
+            for (uint32_t k0 = 0; k0 < (uint32_t)kTimeRows; k0 += kTimeUnroll) {
+                float g_u[kTimeUnroll], val[kTimeUnroll][3], w_u[kTimeUnroll][3];
+                uint32_t X0[kTimeUnroll][3], Xl[kTimeUnroll][3];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const float ix = s_tap_ix[it][k][j];
-                    X0[j] = s_tap_x0[it][k][j];
-                    const float x0 = (float)X0[j], x1 = x0 + 1.0f;
-                    w[j] = ((tex & 1) ? (ix - x0) : (x1 - ix)) * wy;  // make_tap's nw / ne / sw / se
-                    Xl[j] = (tex & 1) ? (X0[j] + 1 < W[j] ? X0[j] + 1 : W[j] - 1) : X0[j];
-                    float part = planes[poff[j] + ((size_t)Yl * W[j] + Xl[j]) * kC + ch] * w[j];
-                    part += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part), 0x124 /* row_ror:4 */, 0xF, 0xF, false));
-                    part += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part), 0x128 /* row_ror:8 */, 0xF, 0xF, false));
-                    v[j] = part;
-                }
-                if (!row_ok) continue;
+                for (int u = 0; u < kTimeUnroll; ++u) {
+                    g_u[u] = s_g[it][k0 + u][ch];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const float gv = g * (v[(j + 1) % 3] * v[(j + 2) % 3]);
-                    if (X0[j] != cur[j]) {  // uniform over the item's 32 lanes
-                        NVSF_TIME_FLUSH(j)
-                        cur[j] = X0[j];
-                        dst[j] = Xl[j] * kC + ch;
+                    for (int j = 0; j < 3; ++j) {
+                        const float ix = s_tap_ix[it][k0 + u][j];
+                        X0[u][j] = s_tap_x0[it][k0 + u][j];
+                        const float x0 = (float)X0[u][j], x1 = x0 + 1.0f;
+                        w_u[u][j] = xs ? (ix - x0) : (x1 - ix);
+                        Xl[u][j] = xs ? (X0[u][j] + 1 < W[j] ? X0[u][j] + 1 : W[j] - 1) : X0[u][j];
+                        val[u][j] = s_A[ioff[j] + Xl[u][j] * kC + ch];
                     }
-                    acc[j] += gv * w[j];
+                }
+#pragma unroll
+                for (int u = 0; u < kTimeUnroll; ++u) {
+                    const bool row_ok = r0 + k0 + (uint32_t)u < n_rows;
+                    float v[3];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const float part = val[u][j] * w_u[u][j];
+                        v[j] = part + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, part), 0x128 /* row_ror:8 */, 0xF, 0xF, false));
+                    }
+                    if (row_ok) {  // uniform over the item's 16 lanes
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            const float gv = g_u[u] * (v[(j + 1) % 3] * v[(j + 2) % 3]);
+                            if (X0[u][j] != cur[j]) {
+                                NVSF_TIME_FLUSH(j)
+                                cur[j] = X0[u][j];
+                                dst[j] = Xl[u][j] * kC + ch;
+                            }
+                            acc[j] += gv * w_u[u][j];
+                        }
+                    }
                 }
             }
-            __builtin_amdgcn_wave_barrier();  // the taps are overwritten by the next round
+            __builtin_amdgcn_wave_barrier();  // the staged rows are overwritten by the next round
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -1014,15 +1075,22 @@ NVSF_API int nvsf_planes_multi_bwd(const float* x, uint32_t x_stride, uint32_t M
             const uint32_t f = (meta.res[s][0] + meta.res[s][1] + meta.res[s][2]) * (uint32_t)kC;
             img_floats = f > img_floats ? f : img_floats;
         }
-        const size_t lds = (size_t)img_floats * sizeof(unsigned long long);
-        if (live_time && nvsf_variant(kVarPlanesBwd) == 0 && M >= (1u << 16) && lds <= 48u * 1024u) {  // + 12 KB of taps: inside the 64 KB a workgroup gets without an attribute
+        if (live_time && nvsf_variant(kVarPlanesBwd) == 0 && M >= (1u << 16) && (size_t)img_floats * 12u <= 72u * 1024u) {
+            // One launch per scale, its images sized for that scale (9 ... 72 KB of 64-bit sums + folded planes, + 7 KB of staged rows:
+            // two workgroups per CU at the finest scale, more at the coarse ones), several times the resident capacity in workgroups
+            // so that the dispatcher evens out what the slices differ by (and what other streams' kernels take): a grid sized to the
+            // resident capacity that overshoots it by ONE workgroup runs twice as long (measured: 513 workgroups on 512 slots)
             const uint32_t n_time = (uint32_t)__builtin_popcount((unsigned)live_time);
             const uint32_t n_chunks = cdiv(M, run);
-            uint32_t n_slices = (2u * (uint32_t)nvsf_cu_count() + n_scales * n_time - 1) / (n_scales * n_time);  // two workgroups per CU
-            n_slices = n_slices > n_chunks ? n_chunks : n_slices;
-            const uint32_t chunks_per_slice = (n_chunks + n_slices - 1) / n_slices;
-            hipLaunchKernelGGL(k_planes_multi_bwd_time_lds, dim3(cdiv(n_chunks, chunks_per_slice), n_scales * n_time), dim3(kTimeBlock), lds, stream,
-                               ev, M, planes_cl, meta, live_time, grad_planes_cl, run, chunks_per_slice);
+            // a slice = a whole number of the workgroup's item rounds (kTimeItems chunks each), ~2 x CUs slices per evaluation
+            uint32_t iters = (n_chunks + (uint32_t)kTimeItems * 2u * (uint32_t)nvsf_cu_count() / 2u) / ((uint32_t)kTimeItems * 2u * (uint32_t)nvsf_cu_count());
+            iters = iters < 1u ? 1u : iters;
+            const uint32_t chunks_per_slice = iters * (uint32_t)kTimeItems;
+            for (uint32_t s = 0; s < n_scales; ++s) {
+                const size_t lds = (size_t)(meta.res[s][0] + meta.res[s][1] + meta.res[s][2]) * (size_t)kC * (sizeof(unsigned long long) + sizeof(float));
+                hipLaunchKernelGGL(k_planes_multi_bwd_time_lds, dim3(cdiv(n_chunks, chunks_per_slice), n_time), dim3(kTimeBlock), lds, stream, ev, M,
+                                   planes_cl, meta, live_time, grad_planes_cl, run, chunks_per_slice, s);
+            }
             live &= ~live_time;
         }
         if (!live) return nvsf_launch_status();

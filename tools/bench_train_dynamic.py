@@ -20,6 +20,9 @@ batch = {"rays_o_lidar": torch.from_numpy(lo).to(dev)[None], "rays_d_lidar": tor
 if os.environ.get("PT"):  # fused / separate: the K-planes of a density query as one autograd node or one per evaluation
     from nvsf import testing as _testing
     _cp = _testing.variant(planes_train=os.environ["PT"]); _cp.__enter__()
+if os.environ.get("PB"):  # lds / global: time planes of the K-planes node through the LDS image or as run sums into global atomics (round 5)
+    from nvsf import testing as _testing
+    _cb = _testing.variant(planes_bwd={"lds": "runs", "global": "global"}[os.environ["PB"]]); _cb.__enter__()
 step = RenderTrainStep(m, num_steps=T, scale=S.SCALE)
 for _ in range(2): step.step(batch)
 torch.cuda.synchronize(); t0 = time.perf_counter()
