@@ -706,6 +706,34 @@ def scatter_beside_backward(tctx, param, tensors, scatter):
     return True
 
 
+def scatter_beside_backward_multi(tctx, params, tensors, scatter):
+    """scatter_beside_backward for a node whose ONE scatter feeds several parameters (the time slices of the space-time grids: one
+    launch sums G[row] per coordinate pair, every slice's gradient is a multiple of it): `scatter(views, scratch pool)` adds into
+    `views[i]` = the sink's buffer of `params[i]` (distinct parameters), on the side stream.  False: nothing done (see above)."""
+    ok = (tctx is not None and tctx.overlap and tctx.sink is not None
+          and all(isinstance(p, torch.nn.Parameter) and p.is_cuda and p.dtype == torch.float32 for p in params))
+    if not ok:
+        if tctx is not None:
+            for p in params:
+                if isinstance(p, torch.nn.Parameter):
+                    tctx.done(p)
+        return False
+    last = [tctx.done(p) for p in params]
+    views = [tctx.sink.view_for(p) for p in params]  # obtained (and, the first time, zero-filled) on the main stream
+    if any(v is None for v in views):
+        raise _hip.NvsfHipError("the gradient sink has no buffer for one of these tables")
+    main, side = torch.cuda.current_stream(params[0].device), side_stream(params[0].device)
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        for t in tensors:
+            t.record_stream(side)
+        scatter(views, tctx.ws_pool)
+        for p, is_last in zip(params, last):
+            if is_last:
+                tctx.sink.mark_ready(p)
+    return True
+
+
 def side_stream(device):
     key = (device.type, device.index)
     if key not in _SIDE_STREAMS:

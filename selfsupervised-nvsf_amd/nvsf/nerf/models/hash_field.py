@@ -296,7 +296,21 @@ class HashDynFn(torch.autograd.Function):
         out = enc._forward_dynamic_fused(x, t, t_host, None, 0)
         ctx.save_for_backward(x)
         ctx.enc, ctx.t, ctx.t_host, ctx.k1, ctx.k2 = enc, t, t_host, k1, k2
+        HashDynFn._expect(ctx, enc, params)
         return out
+
+    @staticmethod
+    def _expect(ctx, enc, params):
+        """The slice parameters this node will scatter into, announced to the training step (ops.TrainContext.expect) so that the
+        step's gradient sink knows when each of them has received its last scatter."""
+        ctx.params = params
+        ctx.train_ctx = _ops.train_context(enc)
+        if ctx.train_ctx is not None and torch.is_grad_enabled():
+            seen = []
+            for p in params:
+                if isinstance(p, torch.nn.Parameter) and p.requires_grad and not any(p is q for q in seen):
+                    seen.append(p)
+                    ctx.train_ctx.expect(p)
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -326,22 +340,40 @@ class HashDynFn(torch.autograd.Function):
                      and M >= (1 << 16) and testing.get("hash4d_train") == "fused")
         g_out = grad_out if col_major else grad_out.float().contiguous()
         lag_t = _ops.device_constant(lag, x.device)
+        b_lo, b_hi = float(np.float32(k2) - idx), float(idx - np.float32(k1))
+
         # ... and the four features of an entry are the four Lagrange chunks: dL/dtable[row][i] = lag_i * blend * G[row] with ONE
-        # scalar sum per entry (nvsf_hashgrid4d_dynamic_bwd_scalar), expanded here
-        sums = [torch.zeros(s.n_rows, dtype=torch.float32, device=x.device) for s in specs]
-        sum_ptrs = (ctypes.c_void_p * 3)(*[g.data_ptr() for g in sums])
-        if col_major:
-            try:
-                _hip.call("nvsf_hashgrid4d_dynamic_bwd_scalar_t", _hip.ptr(x), x.shape[1], M, h_scales, h_res, h_off, g_out.data_ptr(), sum_ptrs)
-            except _hip.NvsfHipError:  # the launch would not take the LDS kernel: rows for the run-merging one
-                col_major, g_out = False, grad_out.contiguous()
-        if not col_major:
-            _hip.call("nvsf_hashgrid4d_dynamic_bwd_scalar", _hip.ptr(x), x.shape[1], M, h_scales, h_res, h_off, _hip.ptr(g_out), sum_ptrs)
+        # scalar sum per entry (nvsf_hashgrid4d_dynamic_bwd_scalar), expanded afterwards
+        def scatter_sums(g_rows_or_cols, is_col_major):
+            sums = [torch.zeros(s.n_rows, dtype=torch.float32, device=x.device) for s in specs]
+            sum_ptrs = (ctypes.c_void_p * 3)(*[g.data_ptr() for g in sums])
+            if is_col_major:
+                try:
+                    _hip.call("nvsf_hashgrid4d_dynamic_bwd_scalar_t", _hip.ptr(x), x.shape[1], M, h_scales, h_res, h_off, g_rows_or_cols.data_ptr(), sum_ptrs)
+                    return sums
+                except _hip.NvsfHipError:  # the launch would not take the LDS kernel: rows for the run-merging one
+                    g_rows_or_cols = g_rows_or_cols.contiguous()
+            _hip.call("nvsf_hashgrid4d_dynamic_bwd_scalar", _hip.ptr(x), x.shape[1], M, h_scales, h_res, h_off, _hip.ptr(g_rows_or_cols), sum_ptrs)
+            return sums
+
+        # Inside a training step the scatter and its expansion run on the step's side stream, straight into the gradient sink (round 6: the
+        # step's main stream is its critical path -- 30.4 ms busy without a gap at 4096 + 4096 rays -- and these 2.5 ms per pass were on
+        # it, while the side stream idled for 10 ms per step); nothing on the main stream reads these gradients before the optimiser.
+        params, tctx = getattr(ctx, "params", None), getattr(ctx, "train_ctx", None)
+        if params is not None and tctx is not None and len(params) == 6 and testing.get("hash4d_scatter") == "side":
+            plan = [(params[i], i, 1.0) for i in range(3)] if same else [(params[i], i % 3, b_lo if i < 3 else b_hi) for i in range(6)]
+            if len({id(p) for p, _, _ in plan}) == len(plan):
+                def scatter(views, pool):
+                    sums = scatter_sums(g_out, col_major)
+                    for view, (_, pair, factor) in zip(views, plan):
+                        view.view(-1, 4).addcmul_(sums[pair].view(-1, 1), lag_t.view(1, 4), value=factor)
+                if _ops.scatter_beside_backward_multi(tctx, [p for p, _, _ in plan], (x, g_out, lag_t), scatter):
+                    return (None,) * 6 + (None,) * len(params)
+        sums = scatter_sums(g_out, col_major)
         acc = [(g.view(-1, 1) * lag_t.view(1, 4)).reshape(-1) for g in sums]
         if same:  # the same parameter tensors were passed twice: the whole gradient goes to the first occurrence
             grads = acc + [None, None, None]
         else:
-            b_lo, b_hi = float(np.float32(k2) - idx), float(idx - np.float32(k1))
             grads = [g * b_lo for g in acc] + [g * b_hi for g in acc]
         return (None, None, None, None, None, None, *grads)
 
@@ -357,6 +389,7 @@ class HashDyn3Fn(torch.autograd.Function):
         out0, out1, out2 = enc.forward_dynamic3(x, t, t_host, offsets.detach(), [nb1, nb2])
         ctx.save_for_backward(x)
         ctx.enc, ctx.t, ctx.t_host, ctx.k1, ctx.k2 = enc, t, t_host, k1, k2
+        HashDynFn._expect(ctx, enc, params)
         outs = [out0, out1 if out1 is not None else out0.new_zeros(0), out2 if out2 is not None else out0.new_zeros(0)]
         ctx.mark_non_differentiable(outs[1], outs[2])
         return tuple(outs)

@@ -36,6 +36,7 @@ _PYTHON = {
     "density_fn": ("fused", "chain"),           # network_static.density: DensityFn / encoder -> MLP -> trunc_exp modules
     "planes_train": ("fused", "separate"),       # network_dynamic training features: ONE K-planes node for a density query / one PlanesFn per evaluation
     "density_grad": ("composed", "matrix"),      # field_ops._density_backward: logit gradient formed inside the MLP backward / nvsf_sigma_geo_bwd pass
+    "hash4d_scatter": ("side", "main"),          # hash_field.HashDynFn.backward inside a training step: on the step's side stream into the gradient sink / on the main stream through autograd
     "table_scatter": ("binned", "atomic"),      # field_ops._bin_from: binned fine levels where they pay / every level through nvsf_hashgrid_bwd
 }
 _state = {}

@@ -23,6 +23,9 @@ if os.environ.get("PT"):  # fused / separate: the K-planes of a density query as
 if os.environ.get("PB"):  # lds / global: time planes of the K-planes node through the LDS image or as run sums into global atomics (round 5)
     from nvsf import testing as _testing
     _cb = _testing.variant(planes_bwd={"lds": "runs", "global": "global"}[os.environ["PB"]]); _cb.__enter__()
+if os.environ.get("H4D"):  # side / main: the space-time grids' table scatter on the step's side stream or on the main stream
+    from nvsf import testing as _testing
+    _ch = _testing.variant(hash4d_scatter=os.environ["H4D"]); _ch.__enter__()
 step = RenderTrainStep(m, num_steps=T, scale=S.SCALE)
 for _ in range(2): step.step(batch)
 torch.cuda.synchronize(); t0 = time.perf_counter()
