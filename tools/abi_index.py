@@ -35,6 +35,7 @@ if __name__ == "__main__":
     print("| entry point | reference interface it stands for | called from |")
     print("|---|---|---|")
     for name, cites, who in rows():
-        special = {"nvsf_version": "library version string", "nvsf_build_digest": "none: digest of the sources the mapped library was built from (`build.py`, `bench.py`)", "nvsf_hashgrid_bwd_binned_ws_bytes": "workspace size of `nvsf_hashgrid_bwd_binned`", "nvsf_test_variant": "none: test-only choice of a reference formulation"}
+        special = {"nvsf_version": "library version string", "nvsf_build_digest": "none: digest of the sources the mapped library was built from (`build.py`, `bench.py`)", "nvsf_hashgrid_bwd_binned_ws_bytes": "workspace size of `nvsf_hashgrid_bwd_binned`", "nvsf_test_variant": "none: test-only choice of a reference formulation",
+                   "nvsf_scratch_pool_stats": "none: diagnostics of the stream-ordered pool `nvsf_march_rays_train` (`raymarching.h:27-44`: no scratch argument) borrows from"}
         ref = special.get(name) or ("; ".join(f"`{c}`" for c in cites[:3]) or "—")
         print(f"| `{name}` | {ref}{'' if cites or name in special else ' (derivative of the entry above)'} | {', '.join(f'`{w}`' for w in who) or 'C clients only'} |")
