@@ -17,6 +17,17 @@ src = [s for s in srcs if os.path.basename(s) == unit][0]
 os.makedirs(os.path.dirname(out), exist_ok=True)
 obj = out + ".o"
 subprocess.run([hipcc] + [f for f in B.FLAGS if f != "-shared"] + defines + ["-c", src, "-o", obj], check=True)
-subprocess.run([hipcc, "-shared", "-fPIC", f"--offload-arch={B.ARCH}", "-fvisibility=hidden"] + [obj if s == src else B._obj(s) for s in srcs] + ["-o", out], check=True)
+# The variant keeps the production digest of ALL sources (build.py / bench.py would otherwise rebuild it over the experiment) but
+# carries a RENDER digest of its own: bench.py's pmc_traffic then refuses the production build's counter profile for it
+# instead of passing it off as this library's.
+import hashlib
+ver_src = [s for s in srcs if os.path.basename(s) == "version.hip"][0]
+ver_obj = out + ".version.o"
+render = hashlib.sha1((B.csrc_digest() + unit + " ".join(defines)).encode()).hexdigest()[:16]
+subprocess.run([hipcc] + [f for f in B.FLAGS if f != "-shared"] + [f'-DNVSF_CSRC_DIGEST_ALL="{B.csrc_digest_all()}"', f'-DNVSF_CSRC_DIGEST_RENDER="{render}"',
+                                                                  "-c", ver_src, "-o", ver_obj], check=True)
+objs = [obj if s == src else (ver_obj if s == ver_src else B._obj(s)) for s in srcs]
+subprocess.run([hipcc, "-shared", "-fPIC", f"--offload-arch={B.ARCH}", "-fvisibility=hidden"] + objs + ["-o", out], check=True)
 os.remove(obj)
-print(out)
+os.remove(ver_obj)
+print(out, "render digest", render)
