@@ -403,7 +403,7 @@ def test_space_time_scatters_beside_backward_equal_one_stream(dev, dynamic):
     """Scatters on the side stream == everything on one stream, decided against the run-to-run spread of each configuration itself
     (ADVICE r5): the two forms launch the same kernels on the same operands, so they may differ only by what two runs
     of ONE form differ by -- the arrival order of fp32 atomics.  Each form runs twice; a parameter's cross-form gap must stay within
-    4 x the larger within-form gap (+ 2e-6 for parameters whose sums happen to repeat bit for bit), and every gap within an absolute
+    8 x the larger within-form gap (or a floor of 1e-5 / 2e-6 for parameters whose sums happen to repeat bit for bit), and every gap within an absolute
     bound derived from the addend counts: an entry is an fp32 sum of n addends in arrival order, each addition rounding the running sum
     by <= eps / 2 = 6e-8 of it -- n eps / 2 worst case, ~sqrt(n) eps typical, of the sum of magnitudes, which cancellation makes a
     multiple of the entry itself.  Tables and weights: n up to ~10^4 bin / workgroup sums => 1e-4 (measured: 1.5e-5 on the static
@@ -426,7 +426,9 @@ def test_space_time_scatters_beside_backward_equal_one_stream(dev, dynamic):
     for name in sorted(cross):
         bound = 2e-5 if name.endswith("planes_cl") else 1e-4
         assert within[name] <= bound, (name, within[name])
-        assert cross[name] <= max(4.0 * within[name], 2e-6), (name, cross[name], within[name])
+        # (a lost or doubled addend -- what a race produces -- is 1e-2 ... 1 of an entry; the factor only has to cover that a maximum over four
+        # cross pairs exceeds a maximum over two within pairs, the floor that a form may repeat itself bit for bit on a quiet parameter)
+        assert cross[name] <= max(8.0 * within[name], 2e-6 if name.endswith("planes_cl") else 1e-5), (name, cross[name], within[name])
         assert cross[name] <= bound, (name, cross[name])
     print("planes_cl gaps (cross / within):", ", ".join(f"{n} {cross[n]:.1e} / {within[n]:.1e}" for n in sorted(cross) if n.endswith("planes_cl")))
 
