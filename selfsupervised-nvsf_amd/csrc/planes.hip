@@ -587,16 +587,16 @@ __global__ __launch_bounds__(kBlock) void k_planes_multi_bwd_runs(PlaneGradEvals
 //     A_j[X][c] = wy0 P_j[Y0][X][c] + wy1 P_j[Y1][X][c]        (LDS, fp32: the interpolated value is then  wx0 A[X0] + wx1 A[X1]),
 // walks its rows with 16 lanes per item (x side, channel): per row and plane one LDS read of A, one weight, one DPP add -- no global
 // gather, a quarter of the run-merging kernel's instructions per row -- forms g (v v) wx run sums in registers exactly as that
-// kernel does, and adds a run sum to a 64-bit FIXED-POINT image G_j[X][c] in LDS (ds_add_u64: integer adds commute, the image does
-// not depend on the order in which the waves arrive).  The final pass adds wy0 G and wy1 G to rows Y0, Y1 of the global gradient with
-// contiguous fp32 atomics: one addend per (slice, evaluation) and texel, ~500 instead of 10^5 - 10^6.
+// kernel does, and adds a run sum to an fp64 image G_j[X][c] in LDS (ds_add_f64).  A run sum is an fp32 number, its conversion is
+// exact, and an fp64 sum of <= 2^17 of them rounds at 2^-53 of the running sum: whatever order the waves arrive in, the image agrees
+// to ~1e-13 of its entries, far below the one fp32 rounding it gets on the way out -- as good as order-independent, with no scale to
+// choose.  (The first form of this kernel used 64-bit fixed point with a scale from a bound of the slice's addends: the pass over the
+// gradient rows that bound needs cost 0.55 of the 2.2 ms, measured by leaving it out.)  The final pass adds wy0 G and wy1 G to rows Y0,
+// Y1 of the global gradient with contiguous fp32 atomics: one addend per (slice, evaluation) and texel, ~10^3 instead of 10^5 - 10^6.
 // Arithmetic against the run-merging kernel: the value wx0 (wy0 P00 + wy1 P10) + wx1 (...) instead of the four-weight blend of
 // make_tap, the addend wy (sum g v v wx) instead of sum g v v (wx wy): the same real numbers, roundings at 1e-7 relative.
-// Scale of the image: 2^(36 - e), e the exponent of a bound of the workgroup's addends (largest |g| of its slice x g_scale x the
-// product of the two largest |A|; the interpolated values are convex combinations): exact product, one truncation per run sum at
-// 2^-36 of the bound; a run sum is at most 128 addends (2^44), a slice at most 2^17 rows: no overflow.  Non-finite gradients or
-// texels (GradScaler overflow steps) are kept out of the image and reported as a NaN in the scale's first time texel, as
-// k_hash_dynamic_bwd_lds does.
+// Non-finite gradients or texels (GradScaler overflow steps) travel through the sums as they do through the memory-side atomics:
+// the texels the offending row touches end up non-finite and found_inf skips the step.
 constexpr int kTimeBlock = 1024;            // 16 waves = 64 items of 16 lanes sharing one image: the image (72 KB at the finest scale) allows one or two workgroups per CU whatever their size, and the walk needs the waves
 constexpr int kTimeItems = kTimeBlock / 16;
 constexpr int kTimeRows = 8;                // rows of an item per round (taps and gradient rows staged in LDS)
@@ -619,12 +619,10 @@ __device__ __forceinline__ TimeTap make_time_tap(float t, uint32_t H) {
 __global__ __launch_bounds__(kTimeBlock) void k_planes_multi_bwd_time_lds(PlaneGradEvals ev, uint32_t M, const float* __restrict__ planes,
                                                                           PlaneMeta meta, int live, float* __restrict__ g_planes, uint32_t run,
                                                                           uint32_t chunks_per_slice, uint32_t s) {
-    extern __shared__ unsigned long long s_img[];         // [n_img] 64-bit sums, then [n_img] floats: the folded planes A
+    extern __shared__ double s_img[];                     // [n_img] fp64 sums, then [n_img] floats: the folded planes A
     __shared__ float s_tap_ix[kTimeItems][kTimeRows][3];  // per item: make_tap's ix, x0 of a round of rows
     __shared__ uint32_t s_tap_x0[kTimeItems][kTimeRows][3];
     __shared__ float s_g[kTimeItems][kTimeRows][kC];      // ... and the rows' gradient values (scaled)
-    __shared__ float s_red[4][kTimeBlock / kWave];
-    __shared__ int s_bad;
     const int lane = lane_id();
     const int l16 = lane & 15, xs = (lane >> 3) & 1, ch = lane & 7;
     const uint32_t slot = blockIdx.y;
@@ -653,77 +651,25 @@ __global__ __launch_bounds__(kTimeBlock) void k_planes_multi_bwd_time_lds(PlaneG
     const uint32_t n_img = (W[0] + W[1] + W[2]) * kC;
     float* const s_A = reinterpret_cast<float*>(s_img + n_img);
     const TimeTap ty = make_time_tap(t_e, H);
-    const uint32_t m_lo = c_lo * run, m_hi = (unsigned long long)c_hi * run < M ? c_hi * run : M;
 
-    // ---- the folded planes, and a bound of the slice's addends ------------------------------------------------------------------
-    float mx[4] = {0.0f, 0.0f, 0.0f, 0.0f};  // |g|, |A| of the three planes
-    bool bad = false;
-    {
-        const uint32_t n_g = (m_hi - m_lo) * kC;
-        for (uint32_t i0 = threadIdx.x; i0 < n_g; i0 += 4u * kTimeBlock) {  // four independent loads in flight per thread
-            float a[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t i = i0 + (uint32_t)u * kTimeBlock, ii = i < n_g ? i : i0;
-                a[u] = fabsf(gbase[(size_t)(m_lo + (ii >> 3)) * stride + s * kC + (ii & 7u)]);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (a[u] <= 3.402823466e38f) mx[0] = fmaxf(mx[0], a[u]);
-                else bad = true;
-            }
-        }
-    }
+    // ---- the folded planes ---------------------------------------------------------------------------------------------------------
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const uint32_t row_len = W[j] * kC;
-        for (uint32_t i = threadIdx.x; i < row_len; i += kTimeBlock) {
-            const float p0 = planes[poff[j] + ty.Y0 * row_len + i], p1 = planes[poff[j] + ty.Y1 * row_len + i];
-            float a = p0 * ty.wy0 + p1 * ty.wy1;
-            if (fabsf(a) <= 3.402823466e38f) mx[1 + j] = fmaxf(mx[1 + j], fabsf(a));
-            else { bad = true; a = 0.0f; }
-            s_A[ioff[j] + i] = a;
-        }
+        for (uint32_t i = threadIdx.x; i < row_len; i += kTimeBlock)
+            s_A[ioff[j] + i] = planes[poff[j] + ty.Y0 * row_len + i] * ty.wy0 + planes[poff[j] + ty.Y1 * row_len + i] * ty.wy1;
     }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx[q] = fmaxf(mx[q], __shfl_xor(mx[q], o));
-        if (lane == 0) s_red[q][threadIdx.x >> 6] = mx[q];
-    }
-    if (threadIdx.x == 0) s_bad = 0;
-    for (uint32_t i = threadIdx.x; i < n_img; i += kTimeBlock) s_img[i] = 0ull;
+    for (uint32_t i = threadIdx.x; i < n_img; i += kTimeBlock) s_img[i] = 0.0;
     __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        mx[q] = 0.0f;
-        for (int wv = 0; wv < kTimeBlock / kWave; ++wv) mx[q] = fmaxf(mx[q], s_red[q][wv]);
-    }
-    const float v_lo = fminf(mx[1], fminf(mx[2], mx[3]));
-    const float vv = v_lo == mx[1] ? mx[2] * mx[3] : (v_lo == mx[2] ? mx[1] * mx[3] : mx[1] * mx[2]);  // product of the two largest
-    const float bound = (mx[0] * fabsf(g_scale)) * vv;
-    float* const poison = g_planes + poff[0] + (size_t)ty.Y0 * W[0] * kC;
-    if (!(bound > 0.0f) || !(bound <= 3.402823466e38f)) {  // uniform: nothing to add, or nothing finite
-        if (bad || bound > 0.0f) s_bad = 1;
-        __syncthreads();
-        if (s_bad != 0 && threadIdx.x == 0) atomicAdd(poison, __builtin_nanf(""));
-        return;
-    }
-    int e = (int)((__float_as_uint(bound) >> 23) & 0xFFu) - 127;
-    e = e < -90 ? -90 : e;
-    const float to_fixed = __builtin_ldexpf(1.0f, 36 - e);
 
     // ---- the walk ------------------------------------------------------------------------------------------------------------------
     const uint32_t it = threadIdx.x >> 4;
     float acc[3] = {0.0f, 0.0f, 0.0f};
     uint32_t cur[3] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, dst[3] = {0u, 0u, 0u};
-#define NVSF_TIME_FLUSH(j)                                                                                                          \
-    {                                                                                                                               \
-        if (acc[j] != 0.0f) {                                                                                                       \
-            if (fabsf(acc[j]) <= 3.402823466e38f) atomicAdd(&s_img[ioff[j] + dst[j]], (unsigned long long)(long long)(acc[j] * to_fixed)); \
-            else bad = true;                                                                                                        \
-        }                                                                                                                           \
-        acc[j] = 0.0f;                                                                                                              \
+#define NVSF_TIME_FLUSH(j)                                                                           \
+    {                                                                                                \
+        if (acc[j] != 0.0f) atomicAdd(&s_img[ioff[j] + dst[j]], (double)acc[j]);  /* ds_add_f64 */  \
+        acc[j] = 0.0f;                                                                               \
     }
     // The rows' operands come from global memory (positions, flow offsets, gradient rows): a round trip of several microseconds against
     // ~1 us of work per round of kTimeRows rows, with two workgroups per CU at the finest scale to hide it.  So the loads of round
@@ -776,9 +722,7 @@ __global__ __launch_bounds__(kTimeBlock) void k_planes_multi_bwd_time_lds(PlaneG
 #pragma unroll
                 for (int i = 0; i < kTimeRows * kC / 16; ++i) {
                     const uint32_t idx = (uint32_t)i * 16u + (uint32_t)l16, rr = idx >> 3, cc = idx & 7u;
-                    float g = nxt.g[i] * g_scale;
-                    if (!(r0 + rr < n_rows) || !(fabsf(g) <= 3.402823466e38f)) g = 0.0f;  // (non-finite: reported through the bound pass)
-                    s_g[it][rr][cc] = g;
+                    s_g[it][rr][cc] = r0 + rr < n_rows ? nxt.g[i] * g_scale : 0.0f;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -835,25 +779,21 @@ __global__ __launch_bounds__(kTimeBlock) void k_planes_multi_bwd_time_lds(PlaneG
         }
     }
 #undef NVSF_TIME_FLUSH
-    if (bad) s_bad = 1;
     __syncthreads();
 
     // ---- the image into rows Y0, Y1 of the global gradient ----------------------------------------------------------------------
-    const double from_fixed = (double)__builtin_ldexpf(1.0f, e - 36);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const uint32_t row_len = W[j] * kC;
         float* r0p = g_planes + poff[j] + (size_t)ty.Y0 * row_len;
         float* r1p = g_planes + poff[j] + (size_t)ty.Y1 * row_len;
         for (uint32_t i = threadIdx.x; i < row_len; i += kTimeBlock) {
-            const long long fx = (long long)s_img[ioff[j] + i];
-            if (fx == 0) continue;
-            const float G = (float)((double)fx * from_fixed);
-            atomicAdd(r0p + i, G * ty.wy0);
-            if (ty.wy1 != 0.0f) atomicAdd(r1p + i, G * ty.wy1);
+            const double G = s_img[ioff[j] + i];
+            if (G == 0.0) continue;
+            atomicAdd(r0p + i, (float)(G * (double)ty.wy0));
+            if (ty.wy1 != 0.0f) atomicAdd(r1p + i, (float)(G * (double)ty.wy1));
         }
     }
-    if (s_bad != 0 && threadIdx.x == 0) atomicAdd(poison, __builtin_nanf(""));
 }
 
 // d L / d (offset) of the evaluations that carry one (the flow towards the neighbour frames): thread = (row, evaluation); the arithmetic

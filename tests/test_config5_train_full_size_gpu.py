@@ -285,8 +285,8 @@ def test_planes_multi_texel_gradient_at_full_size_against_fp64(dev, dynamic, var
     """The texel scatter of the STEP's K-planes node at the timed size: nvsf_planes_multi_bwd with the static evaluation and the three
     time-plane evaluations of a density query (x, x + flow to the next frame, x + flow to the previous one) sharing one gradient slice
     x 0.5 / 0.25 / 0.25, on the LiDAR batch's sample positions and a smooth same-sign gradient, against the deterministic fp64 sum of the
-    same addends.  Production (time planes through the LDS fixed-point image) is held to 2e-5 of each plane's largest
-    entry on every plane and to 5e-6 on the time planes; the round-5 form (run sums into memory-side fp32 atomics, planes_bwd="global")
+    same addends.  Production (time planes through the fp64 LDS images) is held to 2e-5 of each plane's largest
+    entry on every plane and to 1e-5 on the time planes (measured 2e-6: ~10^3 slice sums per texel leave the images as fp32 atomics); the round-5 form (run sums into memory-side fp32 atomics, planes_bwd="global")
     is reported beside it: a time-plane texel receives 10^5 - 10^6 run sums there and loses them to fp32 rounding in arrival order."""
     import itertools
     from planes_calls import multi_bwd_call
@@ -323,7 +323,7 @@ def test_planes_multi_texel_gradient_at_full_size_against_fp64(dev, dynamic, var
                 worst[variant][int(3 in pairs[pi])] = max(worst[variant][int(3 in pairs[pi])], err)
     print(f"K-planes multi-evaluation texel gradient vs fp64 at M = {Mx}: production spatial {worst['runs'][0]:.2e} / time {worst['runs'][1]:.2e}; "
           f"global atomics only: spatial {worst['global'][0]:.2e} / time {worst['global'][1]:.2e} of a plane's largest entry")
-    assert worst["runs"][0] <= 2e-5 and worst["runs"][1] <= 5e-6
+    assert worst["runs"][0] <= 2e-5 and worst["runs"][1] <= 1e-5
     assert worst["global"][0] <= 2e-5 and worst["global"][1] <= 2e-3  # (informational: the form the LDS image replaced)
 
 
@@ -332,7 +332,7 @@ def test_space_time_step_planes_gradient_against_fp64_of_its_own_addends(dev, dy
     the step's own addends.  The operands of the LiDAR pass' PlanesMultiFn.backward -- positions, flow offsets, the two gradient
     slices of the density tail's input gradient, evaluation times -- are recorded as the step hands them over; the reference is
     _fp64_plane_grad over the static evaluation and the three time-plane evaluations x 0.5 / 0.25 / 0.25 (network_dynamic.py:273).
-    Production (time planes through the LDS fixed-point image) is held to 2e-5 of each plane's largest entry (5e-6 on the time
+    Production (time planes through the fp64 LDS images) is held to 2e-5 of each plane's largest entry (1e-5 on the time
     planes); the round-5 form (planes_bwd="global": run sums into memory-side fp32 atomics) is measured beside it -- it is the side
     whose time-plane texels lose 10^5 - 10^6 addends' low bits in arrival order (1e-4 between two runs of one step in GPUTEST_r05)."""
     import itertools
@@ -384,7 +384,7 @@ def test_space_time_step_planes_gradient_against_fp64_of_its_own_addends(dev, dy
                 worst[variant][int(3 in pairs[pi])] = max(worst[variant][int(3 in pairs[pi])], err)
     print(f"K-planes texel gradient of the STEP vs fp64 of its own addends (LiDAR pass, M = {Mx}): production spatial {worst['runs'][0]:.2e} / time "
           f"{worst['runs'][1]:.2e}; global atomics only: spatial {worst['global'][0]:.2e} / time {worst['global'][1]:.2e} of a plane's largest entry")
-    assert worst["runs"][0] <= 2e-5 and worst["runs"][1] <= 5e-6
+    assert worst["runs"][0] <= 2e-5 and worst["runs"][1] <= 1e-5
     assert worst["global"][0] <= 2e-5 and worst["global"][1] <= 1e-2  # (informational: the form the LDS image replaced)
 
 

@@ -883,12 +883,13 @@ def _ray_rows(n_rays, T, rng, dev):
 
 @pytest.mark.parametrize("t0", [0.37, 0.0, 1.0])
 def test_time_plane_gradient_through_the_lds_image_equals_the_run_merging_kernel(dev, t0, variants):
-    """k_planes_multi_bwd_time_lds (production for >= 2^16 rows: the time-plane evaluations of nvsf_planes_multi_bwd accumulate in a 64-bit
-    fixed-point LDS image, planes.hip) against k_planes_multi_bwd_runs (testing.variant(planes_bwd="global"): every evaluation as run sums
+    """k_planes_multi_bwd_time_lds (production for >= 2^16 rows: the time-plane evaluations of nvsf_planes_multi_bwd accumulate in 1-D fp64
+    images in LDS, planes.hip) against k_planes_multi_bwd_runs (testing.variant(planes_bwd="global"): every evaluation as run sums
     into memory-side fp32 atomics, itself pinned against one PlanesFn per evaluation above and through that against the reference's
     autograd): same sums up to fp32 addition order, accumulating into a non-zero buffer, the same texels touched; first / last frame
-    (t = 0, 1: the upper time row carries weight 0 / is the border row); and two runs of the production form agree to 2e-6 (the image is
-    order-independent, what is left is the order of ~130 slice sums per texel), where the run-merging form is only good for ~1e-5 here."""
+    (t = 0, 1: the upper time row carries weight 0 / is the border row); and two runs of the production form agree to 2e-6 (the fp64 image
+    does not care about arrival order at this precision, what is left is the order of the slice sums per texel), where the run-merging form is
+    only good for ~1e-5 here."""
     from nvsf.nerf.models.planes_field import Planes4D
     from planes_calls import multi_bwd_call as _multi_bwd_call
     rng = np.random.default_rng(5)
@@ -925,7 +926,8 @@ def test_time_plane_gradient_through_the_lds_image_equals_the_run_merging_kernel
 @pytest.mark.parametrize("poison", [float("inf"), float("nan")])
 def test_time_plane_gradient_through_the_lds_image_keeps_non_finite_gradients(dev, poison):
     """A non-finite feature gradient (fp16 overflow under GradScaler) must leave the time planes of its scale non-finite, as the
-    memory-atomic kernels do, so that found_inf skips the step; the other scales' time planes stay finite."""
+    memory-atomic kernels do (it travels through the run sums and the fp64 image like any addend), so that found_inf skips the step;
+    the other scales' time planes stay finite."""
     from nvsf.nerf.models.planes_field import Planes4D
     from planes_calls import multi_bwd_call as _multi_bwd_call
     rng = np.random.default_rng(6)
@@ -940,4 +942,4 @@ def test_time_plane_gradient_through_the_lds_image_keeps_non_finite_gradients(de
     for si in range(4):
         for pi in (2, 4, 5):
             _, _, off, C, H, W = enc._layout[si * 6 + pi]
-            assert bool(torch.isfinite(gp[off:off + C * H * W]).all()) == (si != 2 or pi != 2), (si, pi)
+            assert bool(torch.isfinite(gp[off:off + C * H * W]).all()) == (si != 2), (si, pi)
