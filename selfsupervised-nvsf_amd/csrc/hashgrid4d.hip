@@ -460,19 +460,22 @@ __global__ __launch_bounds__(kBlock) void k_hash_dynamic_bwd_scalar(const float*
 // fits the 160 KB of LDS of a CU.  So a workgroup owns (pair, level, row range, slice of the samples), accumulates its slice into an
 // LDS image of its rows (no memory-side atomic per sample and corner: those cost one 64-byte segment each, 2.96 ms per 1.6 M
 // samples in the run-merging kernel above) and adds the image to the global sums once, with contiguous atomics (the full-rate
-// shape).  The image is 64-bit FIXED POINT: LDS float atomics run at a quarter of the rate of the integer ones on gfx950
-// (hashgrid.hip, k_hashgrid_bwd_reduce).  Scale = 2^(36 - e), e the exponent of the largest |g| of the workgroup's own slice
-// and level (a first pass over the column; every workgroup converts back to fp32 before it adds to the global sums, so the scale
-// is private to it): the product is exact, one truncation per addend.  2^15-row levels take two workgroups per slice, one per
-// half of the rows (128 KB each); both walk the slice, each keeps the addends of its rows.
+// shape).  The image is fp64 (ds_add_f64): an addend w g is an fp32 number, its conversion is exact, and the fp64 sum of a slice's
+// addends rounds at 2^-53 of the running sum -- the arrival order of the waves changes the image by ~1e-13 of an entry, far below the
+// one fp32 rounding on the way out.  (Rounds 2-5 used 64-bit fixed point, scale 2^(36 - e) from the largest |g| of the slice and
+// level: that needs a pass over the gradient column before the walk.  Round 6 measured the fp64 form: config-5 step 28.9-29.2 against
+// 29.5-29.7 ms on the same box -- one read of the column instead of two, a one-instruction conversion instead of the float -> int64
+// sequence; the LDS fp64 adder is no slower here than the integer one was.)  A non-finite gradient (fp16 overflow under GradScaler)
+// travels through the sums as through the memory-side atomics: the rows it touches end up non-finite and found_inf skips the step
+// (ADVICE r3).  2^15-row levels take two workgroups per slice, one per half of the rows (128 KB each); both walk the slice, each
+// keeps the addends of its rows.
 template <int SPLIT>
 __global__ void k_hash_dynamic_bwd_lds(const float* __restrict__ x, uint32_t x_stride, uint32_t M, const float* __restrict__ grad_out,
                                        PlaneSums pg, uint32_t pl0, uint32_t chunk_len, uint32_t go_row, uint32_t go_col) {
     // grad_out[m * go_row + column * go_col]: rows [M, 24] (24, 1) or COLUMN-major (1, M) -- a workgroup reads ONE column of all its
     // samples: 4 bytes of every 96-byte row in the row form (every line of the matrix fetched by each of the 24 columns' workgroups:
     // 2.4 GB of line traffic per 1.57 M samples), contiguous in the column form
-    extern __shared__ unsigned long long s_fx[];
-    __shared__ float s_red[16];
+    extern __shared__ double s_sum[];
     const uint32_t part = blockIdx.y % SPLIT, yl = blockIdx.y / SPLIT;
     const uint32_t pl = pl0 + yl / kPlaneLevels, l = yl % kPlaneLevels;
     const GridMeta& g = pg.meta[pl];
@@ -484,29 +487,9 @@ __global__ void k_hash_dynamic_bwd_lds(const float* __restrict__ x, uint32_t x_s
     const unsigned long long first = (unsigned long long)blockIdx.x * chunk_len;
     const uint32_t m0 = (uint32_t)(first < M ? first : M), m1 = (uint32_t)(first + chunk_len < M ? first + chunk_len : M);
     const size_t gcol = ((size_t)pl * kPlaneLevels + l) * go_col;
-    // largest |g| of this slice and level
-    // A non-finite gradient (fp16 overflow under GradScaler) has to reach the table, as it does through the memory atomics, so that
-    // the scaler's found_inf check skips the step; it must not enter the fixed-point image (fmaxf drops a NaN, an inf would put the
-    // exponent at 128 and truncate every finite addend): such values are left out of the sums and the level's first entry of this
-    // workgroup's slice is made NaN.
-    float mx = 0.0f;
-    bool bad = false;
-    for (uint32_t m = m0 + threadIdx.x; m < m1; m += blockDim.x) {
-        const float a = fabsf(grad_out[(size_t)m * go_row + gcol]);
-        if (a <= 3.402823466e38f) mx = fmaxf(mx, a);
-        else bad = true;
-    }
-    if (__ballot(bad) != 0ull && (threadIdx.x & 63u) == 0u && n_rows != 0u) atomicAdd(pg.g[pl] + row0 + row_lo, __builtin_nanf(""));
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-    if ((threadIdx.x & 63u) == 0u) s_red[threadIdx.x >> 6] = mx;
-    for (uint32_t i = threadIdx.x; i < n_rows; i += blockDim.x) s_fx[i] = 0ull;
+    if (n_rows == 0u || m0 >= m1) return;  // uniform
+    for (uint32_t i = threadIdx.x; i < n_rows; i += blockDim.x) s_sum[i] = 0.0;
     __syncthreads();
-    mx = 0.0f;
-    for (uint32_t wv = 0; wv < (blockDim.x >> 6); ++wv) mx = fmaxf(mx, s_red[wv]);
-    if (!(mx > 0.0f) || n_rows == 0u) return;  // uniform
-    const int e = (int)((__float_as_uint(mx) >> 23) & 0xFFu) - 127;
-    const float to_fixed = __builtin_ldexpf(1.0f, 36 - e);
     // four samples per thread and round: their (strided, line-per-sample) loads are in flight together
     constexpr int U = 4;
     for (uint32_t mb = m0 + threadIdx.x; mb < m1; mb += U * blockDim.x) {
@@ -517,7 +500,6 @@ __global__ void k_hash_dynamic_bwd_lds(const float* __restrict__ x, uint32_t x_s
             const bool ok = m < m1;
             const size_t mm = ok ? m : m0;
             go[u] = ok ? grad_out[mm * go_row + gcol] : 0.0f;
-            if (!(fabsf(go[u]) <= 3.402823466e38f)) go[u] = 0.0f;  // reported above
             xa[u] = x[mm * x_stride + ca];
             xb[u] = x[mm * x_stride + cb];
         }
@@ -533,17 +515,16 @@ __global__ void k_hash_dynamic_bwd_lds(const float* __restrict__ x, uint32_t x_s
                 const float w = ((c & 1) ? ra : (1.0f - ra)) * ((c & 2) ? rb : (1.0f - rb));
                 const uint32_t cc[2] = {ia + (uint32_t)(c & 1), ib + (uint32_t)((c >> 1) & 1)};
                 const uint32_t row = grid_row<2>(cc, res, hsize) - row_lo;
-                const long long fx = (long long)((w * go[u]) * to_fixed);
-                if (row < n_rows && fx != 0) atomicAdd(&s_fx[row], (unsigned long long)fx);
+                const float v = w * go[u];
+                if (row < n_rows && v != 0.0f) atomicAdd(&s_sum[row], (double)v);
             }
         }
     }
     __syncthreads();
-    const double from_fixed = (double)__builtin_ldexpf(1.0f, e - 36);
     float* table = pg.g[pl] + row0 + row_lo;
     for (uint32_t i = threadIdx.x; i < n_rows; i += blockDim.x) {
-        const long long v = (long long)s_fx[i];
-        if (v != 0) atomicAdd(table + i, (float)((double)v * from_fixed));
+        const double v = s_sum[i];
+        if (v != 0.0) atomicAdd(table + i, (float)v);
     }
 }
 
@@ -694,7 +675,7 @@ static int hash4d_bwd_scalar_impl(const float* x, uint32_t x_stride, uint32_t M,
             const uint32_t rows = pg.meta[p].offset[l + 1] - pg.meta[p].offset[l];
             max_rows[p] = rows > max_rows[p] ? rows : max_rows[p];
         }
-        fits = fits && max_rows[p] * sizeof(unsigned long long) <= 2u * 128u * 1024u;
+        fits = fits && max_rows[p] * sizeof(double) <= 2u * 128u * 1024u;
     }
     const uint32_t go_row = grad_col_major ? 1u : (uint32_t)(3 * kPlaneLevels), go_col = grad_col_major ? M : 1u;
     if (!(fits && M >= (1u << 16) && nvsf_variant(kVarHash4dBwd) == 0) && grad_col_major) return NVSF_ERR_UNSUPPORTED;  // rows for the other kernel
@@ -703,8 +684,8 @@ static int hash4d_bwd_scalar_impl(const float* x, uint32_t x_stride, uint32_t M,
         while (p < 3) {
             int q = p + 1;
             while (q < 3 && max_rows[q] == max_rows[p]) ++q;  // consecutive pairs with equal level size share a launch
-            const uint32_t split = max_rows[p] * (uint32_t)sizeof(unsigned long long) > 128u * 1024u ? 2u : 1u;
-            const uint32_t lds = (max_rows[p] + split - 1) / split * (uint32_t)sizeof(unsigned long long);
+            const uint32_t split = max_rows[p] * (uint32_t)sizeof(double) > 128u * 1024u ? 2u : 1u;
+            const uint32_t lds = (max_rows[p] + split - 1) / split * (uint32_t)sizeof(double);
             const uint32_t threads = lds > 64u * 1024u ? 1024u : 512u;
             const uint32_t n_slices = lds > 64u * 1024u ? 32u : 64u;
             const uint32_t chunk_len = (M + n_slices - 1) / n_slices;
