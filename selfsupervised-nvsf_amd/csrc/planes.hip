@@ -798,6 +798,10 @@ __global__ __launch_bounds__(kTimeBlock) void k_planes_multi_bwd_time_lds(PlaneG
 
 // d L / d (offset) of the evaluations that carry one (the flow towards the neighbour frames): thread = (row, evaluation); the arithmetic
 // of k_planes_bwd's coordinate half on the evaluation's own position (x + offset, t_e), time planes or static planes as the group says.
+// TIME_ONLY: every evaluation of the launch is a time-plane group (what a training pass asks for: the offsets are the scene flow of the
+// neighbour frames, which warps the time planes only).  The second axis of those planes is t, whose gradient nobody receives: the derivative
+// along it and its sums are not formed (a third of the kernel's arithmetic; same values in the three spatial components).
+template <bool TIME_ONLY>
 __global__ __launch_bounds__(kBlock) void k_planes_multi_coord_bwd(PlaneGradEvals ev, uint32_t M, const float* __restrict__ planes, PlaneMeta meta) {
     const uint32_t m = blockIdx.x * kBlock + threadIdx.x;
     if (m >= M) return;
@@ -839,7 +843,7 @@ __global__ __launch_bounds__(kBlock) void k_planes_multi_coord_bwd(PlaneGradEval
             for (int k = 0; k < kC; ++k) {
                 v[j][k] = ((tex00[k] * t[j].nw + tex01[k] * t[j].ne) + tex10[k] * t[j].sw) + tex11[k] * t[j].se;
                 dvx[j][k] = (tex01[k] - tex00[k]) * wy0 + (tex11[k] - tex10[k]) * wy1;
-                dvy[j][k] = (tex10[k] - tex00[k]) * wx0 + (tex11[k] - tex01[k]) * wx1;
+                if constexpr (!TIME_ONLY) dvy[j][k] = (tex10[k] - tex00[k]) * wx0 + (tex11[k] - tex01[k]) * wx1;
             }
         }
 #pragma unroll
@@ -851,10 +855,10 @@ __global__ __launch_bounds__(kBlock) void k_planes_multi_coord_bwd(PlaneGradEval
                 const float other = v[(j + 1) % 3][k] * v[(j + 2) % 3][k];
                 const float gv = (gout[k] * g_scale) * other;
                 dix += gv * dvx[j][k];
-                diy += gv * dvy[j][k];
+                if constexpr (!TIME_ONLY) diy += gv * dvy[j][k];
             }
             gp[a] += dix * t[j].gx;
-            gp[b] += diy * t[j].gy;
+            if constexpr (!TIME_ONLY) gp[b] += diy * t[j].gy;
         }
     }
     float* o = go_e + (size_t)m * go_stride + go_col;
@@ -997,8 +1001,13 @@ NVSF_API int nvsf_planes_multi_bwd(const float* x, uint32_t x_stride, uint32_t M
         }
         if (ev.g[e]) groups |= 1 << h_group[e];
     }
-    if (any_coord)
-        hipLaunchKernelGGL(k_planes_multi_coord_bwd, dim3(cdiv(M, kBlock), n_evals), dim3(kBlock), 0, stream, ev, M, planes_cl, meta);
+    if (any_coord) {
+        bool time_only = true;
+        for (uint32_t e = 0; e < n_evals; ++e)
+            if (ev.g[e] && ev.g_off[e] && ev.grp[e] != 1) time_only = false;
+        if (time_only) hipLaunchKernelGGL(k_planes_multi_coord_bwd<true>, dim3(cdiv(M, kBlock), n_evals), dim3(kBlock), 0, stream, ev, M, planes_cl, meta);
+        else hipLaunchKernelGGL(k_planes_multi_coord_bwd<false>, dim3(cdiv(M, kBlock), n_evals), dim3(kBlock), 0, stream, ev, M, planes_cl, meta);
+    }
     if (grad_planes_cl && groups) {
         const uint32_t run = 128u;
         int live = 0, live_time = 0;
