@@ -672,7 +672,7 @@ __global__ __launch_bounds__(kTimeBlock) void k_planes_multi_bwd_time_lds(PlaneG
         acc[j] = 0.0f;                                                                               \
     }
     // The rows' operands come from global memory (positions, flow offsets, gradient rows): a round trip of several microseconds against
-    // ~1 us of work per round of kTimeRows rows, with two workgroups per CU at the finest scale to hide it.  So the loads of round
+    // ~1 us of work per round of kTimeRows rows, with one 1024-thread workgroup (4 waves per SIMD) per CU at the finest scale to hide it.  So the loads of round
     // q + 1 are ISSUED (into registers, nothing consumed) before round q is worked on, and staged into LDS when their turn comes.
     struct RoundOperands {
         float p[3], o[3], g[kTimeRows * kC / 16];
@@ -1025,8 +1025,8 @@ NVSF_API int nvsf_planes_multi_bwd(const float* x, uint32_t x_stride, uint32_t M
             img_floats = f > img_floats ? f : img_floats;
         }
         if (live_time && nvsf_variant(kVarPlanesBwd) == 0 && M >= (1u << 16) && (size_t)img_floats * 12u <= 72u * 1024u) {
-            // One launch per scale, its images sized for that scale (9 ... 72 KB of 64-bit sums + folded planes, + 7 KB of staged rows:
-            // two workgroups per CU at the finest scale, more at the coarse ones), several times the resident capacity in workgroups
+            // One launch per scale, its images sized for that scale (9 ... 72 KB of fp64 sums + folded planes, + 28 KB of staged rows:
+            // one 1024-thread workgroup per CU at the finest scale, two at the coarse ones), several times the resident capacity in workgroups
             // so that the dispatcher evens out what the slices differ by (and what other streams' kernels take): a grid sized to the
             // resident capacity that overshoots it by ONE workgroup runs twice as long (measured: 513 workgroups on 512 slots)
             const uint32_t n_time = (uint32_t)__builtin_popcount((unsigned)live_time);
