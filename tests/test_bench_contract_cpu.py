@@ -103,6 +103,8 @@ def test_committed_bench_line_follows_the_contract():
         assert leg in d, leg
     assert d["outputs_match_oracle"]["ok"] is True and d["train"]["grads_match"]["ok"] is True
     assert d["dynamic"]["outputs_match_fixture"]["ok"] is True
+    occ = d["occupancy"]["outputs_match_oracle"]  # config 3 carries a parity field of its own
+    assert occ["ok"] is True and occ["tolerance"] == 1e-4 and min(occ["checked_rays"]) >= 64 and min(occ["exact_fraction"]) >= 0.97
     det = json.load(open(files[-1].replace("_bench_line.json", "_bench_detail.json")))
     assert abs(det["value"] - d["value"]) / d["value"] < 1e-3
     for row in det["raymarching"]["kernels"] + det["field_ops"]["kernels"] + det["kernels"]:
