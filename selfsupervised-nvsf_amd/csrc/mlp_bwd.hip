@@ -742,7 +742,14 @@ static int mlp_bwd_impl(const void* x, int x_is_f16, uint32_t M, uint32_t n_in, 
     const int go_vec = n_out == 16 && go_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(grad_out) & 15u) == 0;
     const uint32_t n_tiles = (M + 15) / 16;
     uint32_t blocks = (n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
-    const uint32_t cap = 768u;  // 256 CUs x 3 resident workgroups of the narrow variants (2 of the wide ones: measured equal at 512 and 768); fewer workgroups = fewer flush atomics
+    // The staged kernel walks its tiles grid-stride.  A grid of exactly the resident capacity (256 CUs x 3 workgroups = 768, the figure of
+    // rounds 2-5: alone 0.180 ms, equal at 512 and 768) finishes together only when it has the device to itself; inside the training step
+    // the table scatter of the other stream holds slots, some workgroups start late and the launch lasts until the last of them is through
+    // its full share (0.46 ms in the step).  Four times the capacity leaves the balancing to the dispatcher: alone 0.186 ms (more weight
+    // staging and flush atomics), config-4 step 4.97-5.01 against 5.04-5.08 ms (same box, three alternating runs; 1536: 5.01-5.04,
+    // 6144: 5.08-5.12, 12288: 5.27-5.29).  The wave-independent kernel (one workgroup per CU, the whole register file) gains nothing
+    // from more workgroups: 5.32 / 5.50 ms at 2 x / 4 x.
+    const uint32_t cap = 3072u;
     if (blocks > cap) blocks = cap;
     const _Float16* w = reinterpret_cast<const _Float16*>(weights_f16);
     // FAST: 16-byte loads of x (mlp_device.h) and 16-byte stores of dX (window and rows aligned to four floats, rows wide
