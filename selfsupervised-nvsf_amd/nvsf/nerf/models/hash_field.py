@@ -360,6 +360,7 @@ class HashDynFn(torch.autograd.Function):
         # step's main stream is its critical path -- 30.4 ms busy without a gap at 4096 + 4096 rays -- and these 2.5 ms per pass were on
         # it, while the side stream idled for 10 ms per step); nothing on the main stream reads these gradients before the optimiser.
         params, tctx = getattr(ctx, "params", None), getattr(ctx, "train_ctx", None)
+        settled = False
         if params is not None and tctx is not None and len(params) == 6 and testing.get("hash4d_scatter") == "side":
             plan = [(params[i], i, 1.0) for i in range(3)] if same else [(params[i], i % 3, b_lo if i < 3 else b_hi) for i in range(6)]
             if len({id(p) for p, _, _ in plan}) == len(plan):
@@ -369,6 +370,13 @@ class HashDynFn(torch.autograd.Function):
                         view.view(-1, 4).addcmul_(sums[pair].view(-1, 1), lag_t.view(1, 4), value=factor)
                 if _ops.scatter_beside_backward_multi(tctx, [p for p, _, _ in plan], (x, g_out, lag_t), scatter):
                     return (None,) * 6 + (None,) * len(params)
+                settled = True  # (a refusal has settled them)
+        if params is not None and tctx is not None and not settled:  # the gradients go back through autograd: the announced scatters are settled here
+            seen = []
+            for p in params:
+                if isinstance(p, torch.nn.Parameter) and p.requires_grad and not any(p is q for q in seen):
+                    seen.append(p)
+                    tctx.done(p)
         sums = scatter_sums(g_out, col_major)
         acc = [(g.view(-1, 1) * lag_t.view(1, 4)).reshape(-1) for g in sums]
         if same:  # the same parameter tensors were passed twice: the whole gradient goes to the first occurrence
